@@ -1,0 +1,188 @@
+#!/usr/bin/env python
+"""bench.py — mel frames/sec of Sequential(*Melspectrogram(128 mel, 2048/512), AmplitudeToDb())
+on N MI355X (BASELINE.json metric; workload = configs[1]: 256 x 1ch x 16 kHz x 10 s per GPU).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the fused hot path over one device-resident synthetic batch per rank
+(weak scaling: per-GPU work fixed; ranks shard the batch axis, no data-path collective).  Rank 0
+prints ONE JSON line.  `roofline` is measured live with HIP events on the launch stream around the
+dominant (only) kernel; `cpu_baseline` times the CPU oracle (torch-CPU restatement of the reference's
+op sequence) on a bounded sample of the same workload on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SR, N_FFT, HOP, N_MELS = 16000, 2048, 512, 128
+BATCH, CHANNELS, SECONDS = 256, 1, 10
+LENGTH = SR * SECONDS
+FRAMES = 1 + LENGTH // HOP                         # 313
+HBM_PEAK_GBS = 8000.0                              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-stages', action='store_true')
+    return ap.parse_args()
+
+
+def event_ms(fn, iters):
+    """Average GPU duration of fn() (one kernel launch) from per-launch HIP event pairs recorded on the
+    stream the kernel is launched on (torch's current stream == the stream passed through the C ABI)."""
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
+    for i in range(iters):
+        starts[i].record()
+        fn()
+        ends[i].record()
+    torch.cuda.synchronize()
+    times = sorted(s.elapsed_time(e) for s, e in zip(starts, ends))
+    return sum(times) / len(times), times[len(times) // 2]
+
+
+def cpu_baseline():
+    from oracle import torch_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    rows = 64
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(rows, CHANNELS, LENGTH, generator=g) * 2 - 1
+
+    def run():
+        return torch_ref.melspectrogram_db(x, n_fft=N_FFT, hop=HOP, num_mels=N_MELS, sample_rate=SR)
+    run()
+    best = float('inf')
+    t_all = time.perf_counter()
+    reps = 0
+    while reps < 5 or (time.perf_counter() - t_all < 10.0 and reps < 40):
+        t0 = time.perf_counter()
+        run()
+        best = min(best, time.perf_counter() - t0)
+        reps += 1
+    return {'value': rows * CHANNELS * FRAMES / best, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d of the %d rows of the same workload (%dx%dx%d f32 uniform(-1,1), %d/%d/%d mel + dB), '
+                      'best of %d runs, torch %s CPU ops in the reference op order (oracle/torch_ref.py)'
+                      % (rows, BATCH, rows, CHANNELS, LENGTH, N_FFT, HOP, N_MELS, reps, torch.__version__)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    distributed = world > 1
+    import torch.distributed as dist
+    if distributed:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+
+    import torchaudio_contrib_amd as tac
+    tac._native.lib()                                   # fail loudly without the HIP library
+
+    gen = torch.Generator(device=dev).manual_seed(rank)
+    x = torch.rand(BATCH, CHANNELS, LENGTH, device=dev, generator=gen) * 2 - 1
+    model = torch.nn.Sequential(
+        *tac.Melspectrogram(num_mels=N_MELS, sample_rate=SR, fft_length=N_FFT, hop_length=HOP),
+        tac.AmplitudeToDb()).to(dev)
+
+    def step():
+        return tac.realize(model(x))
+
+    def sync():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        y = step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        y = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    assert tuple(y.shape) == (BATCH, CHANNELS, N_MELS, FRAMES)
+    if distributed:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    frames_per_step = world * BATCH * CHANNELS * FRAMES
+    value = frames_per_step * a.steps / elapsed
+
+    # ---- roofline of the dominant kernel (the fused melspec kernel is the only launch in a step)
+    mean_ms, med_ms = event_ms(step, min(a.steps, 50))
+    alg_bytes = BATCH * CHANNELS * FRAMES * (4 * HOP + 4 * N_MELS)      # 2560 B/frame
+    achieved = alg_bytes / (mean_ms * 1e-3) / 1e9
+    result = {
+        'metric': 'mel frames/sec', 'value': value, 'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps,
+        'warmup': a.warmup, 'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'Melspectrogram+AmplitudeToDb batch=%d/GPU x %dch x %dHz x %ds, fft_len=%d hop=%d '
+                               '%d mel (BASELINE configs[1])' % (BATCH, CHANNELS, SR, SECONDS, N_FFT, HOP, N_MELS),
+                   'global_batch': world * BATCH, 'frames_per_step': frames_per_step,
+                   'parallelism': 'batch-sharded x%d, no data-path collective' % world},
+        'roofline': {'kernel': 'melspec_kernel<1024,16> (fused STFT+power+mel MFMA+dB)', 'bound': 'hbm',
+                     'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                     'traffic': None, 'alg_bytes_per_launch': alg_bytes, 'kernel_ms_mean': mean_ms,
+                     'kernel_ms_median': med_ms},
+    }
+
+    if rank == 0 and not a.no_stages:
+        # secondary stages named by north_star, each one kernel: complex STFT and power spectrogram
+        stft_layer = tac.STFT(N_FFT, HOP).to(dev)
+        spec = tac.Spectrogram(N_FFT, HOP, power=2.).to(dev)
+        f_bins = N_FFT // 2 + 1
+        stages = {}
+        for name, fn, per_frame in (('stft_complex', lambda: tac.realize(stft_layer(x)), 4 * HOP + 8 * f_bins),
+                                    ('spectrogram_power', lambda: spec(x), 4 * HOP + 4 * f_bins)):
+            for _ in range(5):
+                fn()
+            ms, med = event_ms(fn, 30)
+            gbs = BATCH * CHANNELS * FRAMES * per_frame / (ms * 1e-3) / 1e9
+            stages[name] = {'kernel_ms_mean': ms, 'kernel_ms_median': med, 'alg_bytes_per_frame': per_frame,
+                            'achieved_GBs': gbs, 'frac_of_hbm_peak': gbs / HBM_PEAK_GBS}
+        result['stages'] = stages
+
+    if distributed:
+        # optional whole-batch output: one RCCL all-gather of the (B/N, C, M, T) shards
+        def step_gather():
+            return tac.distributed.all_gather_batch(model(x), total_rows=world * BATCH)
+        for _ in range(3):
+            step_gather()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step_gather()
+        sync()
+        tg = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        result['with_allgather'] = {'value': frames_per_step * a.steps / float(tg.item()), 'unit': 'frames/s',
+                                    'ms_per_step': float(tg.item()) / a.steps * 1e3}
+
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        result['cpu_baseline'] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(result))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,136 @@
+/* tac_amd.h — C ABI of libtac_amd.so: the MI355X (gfx950) engine behind the
+ * torchaudio-contrib Melspectrogram hot path.
+ *
+ * The reference (keunwoochoi/torchaudio-contrib) is pure Python over stock torch ops and has
+ * no FFI of its own; the boundary it exposes is its functional API
+ * (torchaudio_contrib/functional.py).  Each entry point below replaces the torch-op body of
+ * one (or a fused chain) of those functions; the citation names the reference lines.
+ *
+ * Conventions
+ *   - plain C types only: raw DEVICE pointers, sizes, scalars.  No torch types.
+ *   - every call is asynchronous on the caller-supplied HIP stream (`stream` is a
+ *     hipStream_t passed as void*; NULL = the default stream).
+ *   - outputs are caller-allocated; inputs are never written.
+ *   - return value: TAC_OK (0) or a negative TAC_E_* code; tac_strerror() gives text.
+ *     The only global state is an immutable, mutex-guarded twiddle-table cache keyed by
+ *     (n_fft, device); the first call for a new n_fft allocates + uploads it (do that
+ *     warm-up before capturing a hipGraph).
+ *   - "rows" = product of all leading dims (batch x channel), functional.py:89-91.
+ *   - frame-major physical layouts: complex STFT out[rows][T][F][2], spectrogram
+ *     out[rows][T][F], mel out[rows][T][M].  The Python layer returns them as the logical
+ *     (rows, F|M, T[,2]) strided views the reference itself produces (torch.stft /
+ *     transpose-matmul-transpose give exactly these strides).
+ */
+#ifndef TAC_AMD_H
+#define TAC_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TAC_OK 0
+#define TAC_E_INVALID (-1)      /* bad argument (null pointer, non-positive size, ...)        */
+#define TAC_E_UNSUPPORTED (-2)  /* n_fft not a power of two in [32, 4096], n_mels too large…  */
+#define TAC_E_SHORT_INPUT (-3)  /* signal too short for the requested padding / n_fft          */
+#define TAC_E_LAUNCH (-4)       /* HIP runtime error; see tac_last_hip_error()                 */
+
+/* pad_mode values (torch.nn.functional.pad modes accepted by torch.stft, functional.py:57-58) */
+#define TAC_PAD_CONSTANT 0
+#define TAC_PAD_REFLECT 1
+#define TAC_PAD_REPLICATE 2
+#define TAC_PAD_CIRCULAR 3
+
+const char* tac_strerror(int code);
+int tac_last_hip_error(void);
+int tac_abi_version(void);
+
+/* Number of STFT frames and bins for the given geometry (0 on invalid geometry).
+ * T = 1 + (L + 2*(center ? n_fft/2 : 0) - n_fft) / hop   (tests/test_functional.py:14-15). */
+int64_t tac_num_frames(int64_t L, int n_fft, int hop, int center);
+int tac_num_bins(int n_fft, int onesided);
+
+/* Geometry shared by the three STFT-family entry points. */
+typedef struct tac_stft_desc {
+    int64_t rows;        /* batch*channel                                              */
+    int64_t length;      /* samples per row (L)                                        */
+    int64_t row_stride;  /* elements between consecutive rows of `wave`                */
+    int32_t n_fft;       /* power of two, 32..4096                                     */
+    int32_t hop;         /* > 0                                                        */
+    int32_t win_length;  /* 1..n_fft; window is zero-padded centred to n_fft           */
+    int32_t center;      /* 1: pad n_fft/2 both sides with pad_mode                    */
+    int32_t pad_mode;    /* TAC_PAD_*                                                  */
+    int32_t normalized;  /* 1: multiply by n_fft^-0.5                                  */
+    int32_t onesided;    /* 1: F = n_fft/2+1, 0: F = n_fft                             */
+    int32_t reserved;
+} tac_stft_desc;
+
+/* (1) functional.stft, functional.py:48-113 (the torch.stft call at :99-107).
+ *     out: float[rows][T][F][2]. */
+int tac_stft_f32(const float* wave, const float* window, const tac_stft_desc* d,
+                 float* out, void* stream);
+
+/* (2) Spectrogram = stft + complex_norm(power) (functional.py:116-128, layers.py:267-304),
+ *     magnitude/power taken in the FFT epilogue; optionally followed by amplitude_to_db
+ *     (functional.py:277-296) when db != 0.   out: float[rows][T][F]. */
+int tac_spectrogram_f32(const float* wave, const float* window, const tac_stft_desc* d,
+                        float power, int db, float db_ref, float db_amin,
+                        float* out, void* stream);
+
+/* (3) Melspectrogram chain fused in one kernel: stft -> complex_norm(power) ->
+ *     apply_filterbank (functional.py:172-184) [-> amplitude_to_db], layers.py:307-381.
+ *     fb: float[F][n_mels] row-major dense filterbank exactly as create_mel_filter returns it
+ *     (functional.py:131-169); fb_plan: int32[2*ceil(n_mels/16)] from tac_filterbank_plan.
+ *     Requires onesided geometry with n_fft <= 2048; returns TAC_E_UNSUPPORTED otherwise
+ *     (callers then chain (2) and (4)).   out: float[rows][T][n_mels]. */
+int tac_melspec_f32(const float* wave, const float* window, const tac_stft_desc* d,
+                    float power, const float* fb, const int32_t* fb_plan, int32_t n_mels,
+                    int db, float db_ref, float db_amin, float* out, void* stream);
+
+/* Per 16-band tile [first, last+1) non-zero bin range of a dense filterbank
+ * (device kernel, no host sync).  plan: int32[2*ceil(n_mels/16)]. */
+int tac_filterbank_plan(const float* fb, int32_t n_freqs, int32_t n_mels, int32_t* plan,
+                        void* stream);
+
+/* (4) functional.apply_filterbank, functional.py:172-184: out[r][t][m] = sum_f spec[r][f][t]*fb[f][m]
+ *     as an fp32 MFMA (v_mfma_f32_16x16x4_f32) tile with zero-block skipping driven by fb_plan
+ *     (NULL = dense).  spec element (r, f, t) lives at spec[r*stride_r + f*stride_f + t*stride_t].
+ *     out: float[rows][T][n_mels]. */
+int tac_apply_filterbank_f32(const float* spec, int64_t rows, int32_t n_freqs, int64_t n_frames,
+                             int64_t stride_r, int64_t stride_f, int64_t stride_t,
+                             const float* fb, const int32_t* fb_plan, int32_t n_mels,
+                             float* out, void* stream);
+
+/* (5) functional.complex_norm, functional.py:116-128: out[i] = |(x[2i], x[2i+1])|^power. */
+int tac_complex_norm_f32(const float* x, int64_t n, float power, float* out, void* stream);
+
+/* (6) functional.amplitude_to_db, functional.py:277-296: 10*(log10(max(x^2, amin)) - log10(ref)). */
+int tac_amplitude_to_db_f32(const float* x, int64_t n, float ref, float amin, float* out,
+                            void* stream);
+
+/* (6b) functional.db_to_amplitude, functional.py:299-314: (10^(x/10 + log10 ref))^0.5. */
+int tac_db_to_amplitude_f32(const float* x, int64_t n, float ref, float* out, void* stream);
+
+/* (7) functional.mu_law_encoding, functional.py:317-335.  out: int64 codes.
+ *     thresholds (optional, device): int32[n_pos + n_neg] magnitude bit patterns at which the
+ *     reference's code changes for x >= 0 (ascending, first n_pos) and x <= 0 (next n_neg);
+ *     with them the result is bit-exact for |x| <= 1.  zero_code = code of x == 0. */
+int tac_mulaw_encode_f32_i64(const float* x, int64_t n, int32_t n_quantize,
+                             const int32_t* thresholds, int32_t n_pos, int32_t n_neg,
+                             int32_t zero_code, int64_t* out, void* stream);
+
+/* (8) functional.mu_law_decoding, functional.py:338-354, for int64 codes.  lut (optional,
+ *     device): float[n_quantize] table used for codes in [0, n_quantize); codes outside it
+ *     (or lut == NULL) go through the closed form. */
+int tac_mulaw_decode_i64_f32(const int64_t* codes, int64_t n, int32_t n_quantize,
+                             const float* lut, float* out, void* stream);
+
+/* (8b) same for float-valued codes (the reference accepts float input, functional.py:349). */
+int tac_mulaw_decode_f32_f32(const float* codes, int64_t n, int32_t n_quantize, float* out,
+                             void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAC_AMD_H */

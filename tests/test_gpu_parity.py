@@ -1,0 +1,316 @@
+"""-m gpu: HIP path (through the C ABI) vs the committed golden vectors captured from the reference
+and vs the live CPU oracle on the same seeded inputs.
+
+Tolerances (north_star): <= 1e-4 relative fp32 for floating outputs — measured as max|a-b|/max|b|
+per tensor for linear quantities and as absolute dB for dB quantities (the reference's own bar is
+1e-2 dB, tests/test_layers.py:83) — and bit-exact for mu-law integer codes.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import signals, torch_ref, numpy_ref
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-4        # north_star tolerance
+TIGHT = 2e-6      # what fp32 kernels should really achieve on linear outputs
+DB_ABS = 1e-3     # absolute dB
+
+
+@pytest.fixture(scope='module')
+def tac():
+    import torchaudio_contrib_amd as t
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    t._native.lib()                       # fail loudly if the HIP library is missing
+    return t
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t_):
+    return t_.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------ golden: cfg-1 (tests/test_layers.py path)
+def test_g1_stft_spectrogram_db(tac, golden):
+    g = golden('g1_cfg1')
+    x = dev(signals.audio_like((4, 1, 16000), seed=1))
+    win = torch.hann_window(512).cuda()
+    z = tac.stft(x, 512, hop_length=256, window=win)
+    assert tuple(z.shape) == (4, 1, 257, 63, 2)
+    assert rel_err(host(z), g['stft']) < TIGHT
+    mag = tac.complex_norm(z, 1.0)
+    assert rel_err(host(mag), g['mag']) < TIGHT
+    seq = torch.nn.Sequential(*tac.Spectrogram(512, hop_length=256, window=win),
+                              tac.AmplitudeToDb(ref=1.0, amin=1e-7)).cuda()
+    db = host(tac.realize(seq(x)))
+    assert np.abs(db - g['spec_db']).max() < DB_ABS
+
+
+# ------------------------------------------------------------------ golden: cfg-2 slice (the benchmarked chain)
+def test_g2_melspectrogram_db(tac, golden):
+    g = golden('g2_cfg2_slice')
+    x = dev(signals.audio_like((2, 1, 160000), seed=2))
+    mel = tac.Melspectrogram(num_mels=128, sample_rate=16000, fft_length=2048, hop_length=512).cuda()
+    out = mel(x)
+    assert tuple(out.shape) == (2, 1, 128, 313)
+    assert rel_err(host(out), g['mel']) < 1e-5
+    full = torch.nn.Sequential(*mel, tac.AmplitudeToDb()).cuda()
+    y = full(x)
+    assert isinstance(y, tac.DeferredSpectral)          # the unpacked chain is fused lazily
+    assert np.abs(host(y) - g['mel_db']).max() < DB_ABS
+    power = tac.Spectrogram(2048, hop_length=512, power=2.)(x)
+    assert rel_err(host(power[..., [int(i) for i in g['frame_index']]]), g['power_frames']) < 1e-5
+    # eager (unfused) evaluation must agree with the fused kernel
+    tac.set_lazy_fusion(False)
+    try:
+        y2 = full(x)
+        assert not isinstance(y2, tac.DeferredSpectral)
+        assert np.abs(host(y2) - g['mel_db']).max() < DB_ABS
+    finally:
+        tac.set_lazy_fusion(True)
+
+
+STFT_CASES = {
+    'n4096_h1024': dict(n=4096, kw=dict(hop_length=1024), full=True),
+    'n512_h128_win400': dict(n=512, kw=dict(hop_length=128, win_length=400)),
+    'n256_h64_normalized': dict(n=256, kw=dict(hop_length=64, normalized=True)),
+    'n256_h100_twosided': dict(n=256, kw=dict(hop_length=100, onesided=False)),
+    'n1024_h256_nocenter': dict(n=1024, kw=dict(hop_length=256, center=False)),
+    'n512_h256_constant': dict(n=512, kw=dict(hop_length=256, pad_mode='constant')),
+    'n512_h256_replicate': dict(n=512, kw=dict(hop_length=256, pad_mode='replicate')),
+    'n512_h256_circular': dict(n=512, kw=dict(hop_length=256, pad_mode='circular')),
+    'n1024_hdefault': dict(n=1024, kw=dict()),
+    'n2048_h512': dict(n=2048, kw=dict(hop_length=512)),
+    'n128_h32': dict(n=128, kw=dict(hop_length=32), length=2000),
+    'n64_h16': dict(n=64, kw=dict(hop_length=16), length=1000),
+}
+
+
+@pytest.mark.parametrize('name', sorted(STFT_CASES))
+def test_g4_stft_variants(tac, golden, name):
+    g = golden('g4_variants')
+    case = STFT_CASES[name]
+    base = signals.audio_like((1, 2, 20000), seed=4)
+    x = base if case.get('full') else base[..., :case.get('length', 6000)]
+    z = tac.stft(dev(x), case['n'], **case['kw'])
+    want = g[name]
+    assert tuple(z.shape) == want.shape
+    assert rel_err(host(z), want) < TIGHT
+
+
+def test_g4_custom_window_leading_dims_power(tac, golden):
+    g = golden('g4_variants')
+    base = signals.audio_like((1, 2, 20000), seed=4)
+    xs = dev(base[..., :6000])
+    win = dev(np.abs(signals.uniform((512,), seed=44)) + np.float32(0.25))
+    assert rel_err(host(tac.stft(xs, 512, hop_length=256, window=win)), g['n512_h256_customwin']) < TIGHT
+    x4 = dev(signals.audio_like((2, 2, 2, 3000), seed=5))
+    z = tac.stft(x4, 256, hop_length=64)
+    assert tuple(z.shape) == g['lead3_n256_h64'].shape
+    assert rel_err(host(z), g['lead3_n256_h64']) < TIGHT
+    assert rel_err(host(tac.Spectrogram(512, hop_length=256, power=0.7)(xs)), g['spec_p07_n512']) < 1e-5
+    assert rel_err(host(tac.Spectrogram(4096, hop_length=1024)(dev(base))), g['spec_p1_n4096']) < TIGHT
+
+
+def test_g4_mel_variants(tac, golden):
+    g = golden('g4_variants')
+    xm = dev(signals.audio_like((3, 1, 30000), seed=6))
+    mel = tac.Melspectrogram(num_mels=128, sample_rate=44100, fft_length=2048, hop_length=512).cuda()
+    assert rel_err(host(mel(xm)), g['mel_sr44100']) < 1e-5
+    melh = tac.Melspectrogram(num_mels=40, sample_rate=16000, min_freq=20.0, max_freq=7600.0, htk=True,
+                              fft_length=512, hop_length=160, win_length=400).cuda()
+    assert rel_err(host(melh(xm)), g['mel_htk40_n512']) < 1e-5
+    chain = torch.nn.Sequential(*melh, tac.AmplitudeToDb(ref=2.0, amin=1e-5))
+    assert np.abs(host(chain(xm)) - g['mel_htk40_n512_db']).max() < DB_ABS
+
+
+def test_unsupported_n_fft_is_loud(tac):
+    x = dev(signals.uniform((1, 1, 6000), seed=3))
+    with pytest.raises(NotImplementedError):
+        tac.stft(x, 400, hop_length=160)          # non power of two: no silent fallback
+
+
+def test_short_input_raises_runtime_error(tac):
+    # reference: strict-xfail RuntimeError for (1,100) with n_fft=512 reflect (tests/test_functional.py:31)
+    with pytest.raises(RuntimeError):
+        tac.stft(dev(signals.uniform((1, 100), seed=1)), 512, hop_length=256)
+    with pytest.raises(RuntimeError):
+        tac.STFT(512, hop_length=256).cuda()(dev(signals.uniform((1, 256), seed=1)))
+    z = tac.stft(dev(signals.uniform((1, 257), seed=1)), 512, hop_length=256)     # L=257 is legal
+    assert tuple(z.shape) == (1, 257, 2, 2)
+
+
+# ------------------------------------------------------------------ live oracle comparisons
+@pytest.mark.parametrize('shape,n,hop', [((1, 100000), 512, 256), ((1, 2, 100000), 512, 256),
+                                         ((3, 2, 33333), 1024, 200), ((5, 1, 9000), 2048, 512)])
+def test_stft_vs_oracles(tac, shape, n, hop):
+    x = signals.audio_like(shape, seed=11)
+    z = host(tac.stft(dev(x), n, hop_length=hop))
+    want_t = torch_ref.stft(torch.from_numpy(x), n, hop).numpy()
+    want_n = numpy_ref.stft(x, n, hop)
+    assert z.shape == want_t.shape
+    assert rel_err(z, want_t) < TIGHT
+    assert rel_err(z[..., 0] + 1j * z[..., 1], want_n) < TIGHT
+    mag, phase = tac.magphase(tac.stft(dev(x), n, hop_length=hop))
+    assert rel_err(host(mag), np.abs(want_n)) < TIGHT
+
+
+@pytest.mark.parametrize('power', [1, 2, 0.7])
+@pytest.mark.parametrize('shape', [(1, 2, 1025, 400, 2), (1025, 400, 2)])
+def test_complex_norm(tac, shape, power):
+    z = signals.uniform(shape, seed=12, scale=4.0)
+    got = host(tac.complex_norm(dev(z), power))
+    want = (z.astype(np.float64) ** 2).sum(-1) ** (power / 2)
+    assert np.abs(got - want).max() < 1e-5          # tests/test_functional.py:119-128 bar
+    zt = dev(z).transpose(0, 1)                      # dense but permuted input keeps its layout
+    got_t = tac.complex_norm(zt, power)
+    assert got_t.shape == zt.shape[:-1]
+    assert np.abs(host(got_t) - np.swapaxes(want, 0, 1)).max() < 1e-5
+
+
+@pytest.mark.parametrize('new_len', [120, 36])
+@pytest.mark.parametrize('shape', [(1, 257, 391), (1, 2, 257, 391), (257, 391), (3, 2, 2, 100, 70)])
+def test_apply_filterbank_dense_random(tac, shape, new_len):
+    spec = signals.uniform(shape, seed=13)
+    fb = signals.uniform((shape[-2], new_len), seed=14)
+    got = tac.apply_filterbank(dev(spec), dev(fb))
+    assert got.shape[-1] == shape[-1] and got.shape[-2] == new_len and got.dim() == len(shape)
+    want = np.einsum('...ft,fm->...mt', spec.astype(np.float64), fb.astype(np.float64))
+    assert rel_err(host(got), want) < 1e-5
+    want32 = torch_ref.apply_filterbank(torch.from_numpy(spec), torch.from_numpy(fb)).numpy()
+    assert rel_err(host(got), want32) < 1e-5
+    # frame-major strided view input (what Spectrogram hands over)
+    sv = dev(np.ascontiguousarray(np.swapaxes(spec, -1, -2))).transpose(-1, -2)
+    assert rel_err(host(tac.apply_filterbank(sv, dev(fb))), want) < 1e-5
+
+
+def test_apply_filterbank_mel_sparse_plan(tac):
+    fb = tac.create_mel_filter(1025, 128, 0.0, 8000, False)
+    spec = np.abs(signals.uniform((2, 1025, 300), seed=15))
+    got = host(tac.apply_filterbank(dev(spec), fb.cuda()))
+    want = np.einsum('rft,fm->rmt', spec.astype(np.float64), fb.numpy().astype(np.float64))
+    assert rel_err(got, want) < 1e-5
+
+
+def test_amplitude_db_known_answers(tac, golden):
+    amp = torch.tensor([0.000001, 0.0001, 0.1, 1.0, 10.0, 1000000.0]).sqrt().cuda()
+    db = torch.tensor([-60.0, -40.0, -10.0, 0.0, 10.0, 60.0])
+    got = tac.amplitude_to_db(amp, ref=1.0).cpu()
+    assert (got - db).abs().max() < 1e-5
+    assert (tac.db_to_amplitude(db.cuda(), ref=1.0).cpu() - amp.cpu()).abs().div(amp.cpu()).max() < 1e-6
+    back = tac.amplitude_to_db(tac.db_to_amplitude(db.cuda()))
+    assert (back.cpu() - db).abs().max() < 1e-5
+    g = golden('g5_mulaw')
+    xa = dev(signals.audio_like((4, 5000), seed=10))
+    assert np.abs(host(tac.amplitude_to_db(xa, ref=2.0, amin=1e-5)) - g['a2db_ref2']).max() < 1e-4
+    assert rel_err(host(tac.db_to_amplitude(xa * 40, ref=2.0)), g['db2a_ref2']) < 1e-5
+
+
+# ------------------------------------------------------------------ mu-law: bit-exact integers
+def test_mulaw_golden_bit_exact(tac, golden):
+    g = golden('g5_mulaw')
+    x2 = dev(signals.uniform((1000000,), seed=8, scale=1.0))
+    enc = tac.mu_law_encoding(x2, 256)
+    assert enc.dtype == torch.int64
+    assert np.array_equal(host(enc), g['enc256_unit'].astype(np.int64))
+    codes = dev((signals.uniform((4096,), seed=9) * 127.5 + 127.5).astype(np.int64).clip(0, 255))
+    dec = tac.mu_law_decoding(codes, 256)
+    assert np.array_equal(host(dec).view(np.uint32), g['dec256_codes'].view(np.uint32))
+    assert np.array_equal(host(tac.mu_law_decoding(torch.arange(256).cuda(), 256)).view(np.uint32),
+                          g['lut256'].view(np.uint32))
+    # round trip enc(dec(c)) == c for every code (tests/test_functional.py:195-199)
+    allc = torch.arange(256).cuda()
+    assert torch.equal(tac.mu_law_encoding(tac.mu_law_decoding(allc, 256), 256), allc)
+    layer_rt = tac.MuLawEncoding(256)(tac.MuLawDecoding(256)(allc))
+    assert torch.equal(layer_rt, allc)
+
+
+def test_mulaw_thresholds_edges(tac):
+    from torchaudio_contrib_amd import _mulaw_tables as tab
+    pos = np.array(tab.THR256_POS, dtype=np.uint32)
+    neg = np.array(tab.THR256_NEG, dtype=np.uint32)
+    # exactly at, and one ulp below, every threshold; plus +-0, +-1
+    mags = np.concatenate([pos, pos - 1, neg, neg - 1, [0, 0x3f800000]]).astype(np.uint32)
+    xs = np.concatenate([mags.view(np.float32), -(mags.view(np.float32))])
+    got = host(tac.mu_law_encoding(dev(xs), 256))
+    want = torch_ref.mu_law_encoding(torch.from_numpy(xs), 256).numpy()
+    assert np.array_equal(got, want)
+
+
+def test_mulaw_out_of_range_and_other_nq_best_effort(tac, golden):
+    g = golden('g5_mulaw')
+    x1 = signals.uniform((1000000,), seed=7, scale=4.0)
+    got = host(tac.mu_law_encoding(dev(x1), 256))
+    want = g['enc256_scale4'].astype(np.int64)
+    inside = np.abs(x1) <= 1.0
+    assert np.array_equal(got[inside], want[inside])                  # bit-exact on [-1, 1]
+    diff = np.abs(got - want)
+    assert diff.max() <= 1 and (diff != 0).mean() < 1e-4               # documented best effort outside
+    x2 = signals.uniform((200000,), seed=8, scale=1.0)[:200000]
+    for nq, key in ((65536, 'enc65536_unit'), (16, 'enc16_unit')):
+        got = host(tac.mu_law_encoding(dev(x2), nq))
+        diff = np.abs(got - g[key].astype(np.int64))
+        assert diff.max() <= 1 and (diff != 0).mean() < 1e-3
+
+
+# ------------------------------------------------------------------ size-independent properties at BASELINE sizes
+def test_cfg2_full_size_properties(tac):
+    """cfg-2 (256x1x160000, 2048/512/128): linearity of the power-mel map in amplitude², agreement of
+    fused vs unfused evaluation, frame-shift consistency, and a spot check of rows against the oracle."""
+    torch.manual_seed(0)
+    x = torch.rand(256, 1, 160000, device='cuda') * 2 - 1
+    mel = tac.Melspectrogram(num_mels=128, sample_rate=16000, fft_length=2048, hop_length=512).cuda()
+    y = mel(x)
+    assert tuple(y.shape) == (256, 1, 128, 313)
+    assert torch.isfinite(y).all()
+    y2 = mel(x * 0.5)
+    assert rel_err(host(y2), host(y) * 0.25) < 1e-5                  # power scales with gain²
+    tac.set_lazy_fusion(False)
+    try:
+        y3 = mel(x)
+    finally:
+        tac.set_lazy_fusion(True)
+    assert rel_err(host(y3), host(y)) < 1e-5                         # fused == op-by-op
+    # shifting the signal by one hop shifts interior frames by one
+    ys = mel(x[..., 512:])
+    assert rel_err(host(ys[..., 2:300]), host(y[..., 3:301])) < 1e-5
+    rows = [0, 77, 255]
+    want = torch_ref.melspectrogram_db(x[rows].cpu(), n_fft=2048, hop=512, num_mels=128, sample_rate=16000)
+    chain = torch.nn.Sequential(*mel, tac.AmplitudeToDb())
+    got = host(chain(x))[rows]
+    assert np.abs(got - want.numpy()).max() < DB_ABS
+
+
+def test_cfg4_multichannel_stress_slice(tac):
+    """cfg-4 shape family (8 channels, 4096/1024) at a length the oracle finishes in seconds."""
+    x = signals.audio_like((2, 8, 120000), seed=21)
+    got = tac.Spectrogram(4096, hop_length=1024)(dev(x))
+    want = torch_ref.spectrogram(torch.from_numpy(x), 4096, 1024).numpy()
+    assert got.shape == want.shape
+    assert rel_err(host(got), want) < TIGHT
+
+
+def test_cfg5_mulaw_roundtrip_full_size(tac):
+    """cfg-5: 1024x1x120000 @ n_quantize=256 — encode → decode → encode is idempotent and a checksum
+    of the codes matches the oracle's on a slice."""
+    torch.manual_seed(5)
+    x = torch.rand(1024, 1, 120000, device='cuda') * 2 - 1
+    c1 = tac.mu_law_encoding(x, 256)
+    c2 = tac.mu_law_encoding(tac.mu_law_decoding(c1, 256), 256)
+    assert torch.equal(c1, c2)
+    assert int(c1.min()) >= 0 and int(c1.max()) <= 255
+    sl = x[:8].cpu()
+    assert torch.equal(c1[:8].cpu(), torch_ref.mu_law_encoding(sl, 256))
+
+
+def test_state_dict_and_buffers_follow_device(tac):
+    m = torch.nn.Sequential(*tac.Melspectrogram(fft_length=1024, hop_length=256, sample_rate=16000),
+                            tac.AmplitudeToDb()).cuda()
+    assert list(m.state_dict().keys()) == []
+    assert m[0].window.is_cuda and m[2].filterbank.is_cuda
+    assert list(m.parameters()) == []

@@ -1,0 +1,25 @@
+"""torchaudio_contrib_amd — MI355X (gfx950) engine behind the torchaudio-contrib Melspectrogram path.
+
+Import surface mirrors ``torchaudio_contrib/__init__.py:1-2`` of the reference (everything from
+``functional`` and ``layers`` at top level).  The directory is named ``torchaudio-contrib_amd``;
+the importable name is ``torchaudio_contrib_amd`` (see the loader shim at the repo root).
+"""
+from . import _native
+from ._lazy import realize, set_lazy_fusion, lazy_fusion_enabled, DeferredSpectral
+from . import functional
+from . import layers
+from .functional import *      # noqa: F401,F403
+from .functional import (stft, complex_norm, create_mel_filter, apply_filterbank, angle, magphase,
+                         phase_vocoder, amplitude_to_db, db_to_amplitude, mu_law_encoding,
+                         mu_law_decoding)
+from .layers import (STFT, ComplexNorm, ApplyFilterbank, Filterbank, MelFilterbank, TimeStretch,
+                     Spectrogram, Melspectrogram, AmplitudeToDb, DbToAmplitude, MuLawEncoding,
+                     MuLawDecoding)
+from . import distributed
+
+__version__ = '0.1.0'
+
+
+def build_native(verbose=False):
+    """(Re)build libtac_amd.so for gfx950."""
+    return _native.build(verbose=verbose)

@@ -1,0 +1,129 @@
+"""ctypes binding of libtac_amd.so — the C ABI declared in include/tac_amd.h.
+
+PyTorch is plumbing here (device memory, the current HIP stream); every compute call goes to
+a hand-written gfx950 kernel through plain pointers.  There is deliberately NO fallback: if
+the library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libtac_amd.so')
+CSRC = os.path.join(_HERE, 'csrc')
+
+TAC_OK = 0
+TAC_E_INVALID = -1
+TAC_E_UNSUPPORTED = -2
+TAC_E_SHORT_INPUT = -3
+TAC_E_LAUNCH = -4
+
+PAD_MODES = {'constant': 0, 'reflect': 1, 'replicate': 2, 'circular': 3}
+
+EXPORTS = (
+    'tac_strerror', 'tac_last_hip_error', 'tac_abi_version', 'tac_num_frames', 'tac_num_bins',
+    'tac_stft_f32', 'tac_spectrogram_f32', 'tac_melspec_f32', 'tac_filterbank_plan',
+    'tac_apply_filterbank_f32', 'tac_complex_norm_f32', 'tac_amplitude_to_db_f32',
+    'tac_db_to_amplitude_f32', 'tac_mulaw_encode_f32_i64', 'tac_mulaw_decode_i64_f32',
+    'tac_mulaw_decode_f32_f32',
+)
+
+
+class StftDesc(ctypes.Structure):
+    """mirror of ``tac_stft_desc`` (include/tac_amd.h)."""
+    _fields_ = [('rows', ctypes.c_int64), ('length', ctypes.c_int64), ('row_stride', ctypes.c_int64),
+                ('n_fft', ctypes.c_int32), ('hop', ctypes.c_int32), ('win_length', ctypes.c_int32),
+                ('center', ctypes.c_int32), ('pad_mode', ctypes.c_int32), ('normalized', ctypes.c_int32),
+                ('onesided', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 into libtac_amd.so (hipcc cross-compiles without a GPU)."""
+    cmd = ['make', '-C', CSRC, '-j', str(min(8, os.cpu_count() or 1))]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or proc.returncode != 0:
+        print(proc.stdout)
+    if proc.returncode != 0:
+        raise NativeLibraryError('building libtac_amd.so failed:\n' + proc.stdout[-4000:])
+    global _lib
+    _lib = None
+    return LIB_PATH
+
+
+_lib = None
+_lock = threading.Lock()
+
+_P = ctypes.c_void_p
+_I32 = ctypes.c_int32
+_I64 = ctypes.c_int64
+_F = ctypes.c_float
+_DESC = ctypes.POINTER(StftDesc)
+
+
+def lib():
+    """Load (once) and return the ctypes handle; fail loudly when the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryError(
+                'libtac_amd.so not found at %s — build it with `make -C %s` (or '
+                '`python -c "import __graft_entry__ as g; g.build()"`).  There is no CPU fallback.'
+                % (LIB_PATH, CSRC))
+        h = ctypes.CDLL(LIB_PATH)
+        h.tac_strerror.restype = ctypes.c_char_p
+        h.tac_strerror.argtypes = [ctypes.c_int]
+        h.tac_last_hip_error.restype = ctypes.c_int
+        h.tac_abi_version.restype = ctypes.c_int
+        h.tac_num_frames.restype = _I64
+        h.tac_num_frames.argtypes = [_I64, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        h.tac_num_bins.restype = ctypes.c_int
+        h.tac_num_bins.argtypes = [ctypes.c_int, ctypes.c_int]
+        h.tac_stft_f32.argtypes = [_P, _P, _DESC, _P, _P]
+        h.tac_spectrogram_f32.argtypes = [_P, _P, _DESC, _F, ctypes.c_int, _F, _F, _P, _P]
+        h.tac_melspec_f32.argtypes = [_P, _P, _DESC, _F, _P, _P, _I32, ctypes.c_int, _F, _F, _P, _P]
+        h.tac_filterbank_plan.argtypes = [_P, _I32, _I32, _P, _P]
+        h.tac_apply_filterbank_f32.argtypes = [_P, _I64, _I32, _I64, _I64, _I64, _I64, _P, _P, _I32, _P, _P]
+        h.tac_complex_norm_f32.argtypes = [_P, _I64, _F, _P, _P]
+        h.tac_amplitude_to_db_f32.argtypes = [_P, _I64, _F, _F, _P, _P]
+        h.tac_db_to_amplitude_f32.argtypes = [_P, _I64, _F, _P, _P]
+        h.tac_mulaw_encode_f32_i64.argtypes = [_P, _I64, _I32, _P, _I32, _I32, _I32, _P, _P]
+        h.tac_mulaw_decode_i64_f32.argtypes = [_P, _I64, _I32, _P, _P, _P]
+        h.tac_mulaw_decode_f32_f32.argtypes = [_P, _I64, _I32, _P, _P]
+        for name in EXPORTS:
+            fn = getattr(h, name)
+            if name.endswith(('_f32', '_i64', '_plan')):
+                fn.restype = ctypes.c_int
+        _lib = h
+    return _lib
+
+
+def check(rc, what):
+    """Turn a TAC_E_* code into the Python exception the reference's torch ops would raise."""
+    if rc == TAC_OK:
+        return
+    h = lib()
+    msg = '%s: %s' % (what, h.tac_strerror(rc).decode())
+    if rc == TAC_E_LAUNCH:
+        msg += ' (hipError %d)' % h.tac_last_hip_error()
+    if rc == TAC_E_UNSUPPORTED:
+        raise NotImplementedError(msg)          # a RuntimeError subclass
+    raise RuntimeError(msg)
+
+
+def stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr())

@@ -1,0 +1,239 @@
+// elementwise.hip — HBM-bound streaming kernels of the path: complex_norm, amplitude_to_db,
+// db_to_amplitude, mu-law encode / decode (functional.py:116-128, 277-314, 317-354).
+// 16 B per lane per access where alignment allows, grid-stride over 256 CUs x 8 blocks.
+#include "host_common.hpp"
+
+namespace tac {
+
+constexpr int EW_THREADS = 256;
+
+static inline unsigned ew_blocks(long long work_items) {
+    long long cap = (long long)device_cu_count() * 8;
+    long long want = (work_items + EW_THREADS - 1) / EW_THREADS;
+    if (want < 1) want = 1;
+    return (unsigned)(want < cap ? want : cap);
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---------------------------------------------------------------- complex_norm
+__device__ __forceinline__ float norm_pow(float re, float im, float power) {
+    return cpow_mag(make_float2(re, im), power);
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(EW_THREADS) complex_norm_kernel(const float* __restrict__ x, long long n, float power,
+                                                                  float* __restrict__ out) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if constexpr (VEC) {
+        const long long n4 = n / 4;
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        float4* o4 = reinterpret_cast<float4*>(out);
+        for (long long j = i; j < n4; j += stride) {
+            float4 a = x4[2 * j], b = x4[2 * j + 1];
+            o4[j] = make_float4(norm_pow(a.x, a.y, power), norm_pow(a.z, a.w, power), norm_pow(b.x, b.y, power),
+                                norm_pow(b.z, b.w, power));
+        }
+        for (long long j = n4 * 4 + i; j < n; j += stride) out[j] = norm_pow(x[2 * j], x[2 * j + 1], power);
+    } else {
+        for (long long j = i; j < n; j += stride) out[j] = norm_pow(x[2 * j], x[2 * j + 1], power);
+    }
+}
+
+// ---------------------------------------------------------------- generic unary map
+struct AmpToDb {
+    float amin, log10_ref;
+    __device__ __forceinline__ float operator()(float v) const { return amp_to_db(v, amin, log10_ref); }
+};
+struct DbToAmp {
+    float log10_ref;
+    // (10^(x/10 + log10 ref))^0.5
+    __device__ __forceinline__ float operator()(float v) const { return sqrtf(powf(10.0f, v / 10.0f + log10_ref)); }
+};
+
+template <bool VEC, class Op>
+__global__ void __launch_bounds__(EW_THREADS) unary_kernel(const float* __restrict__ x, long long n, Op op,
+                                                           float* __restrict__ out) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if constexpr (VEC) {
+        const long long n4 = n / 4;
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        float4* o4 = reinterpret_cast<float4*>(out);
+        for (long long j = i; j < n4; j += stride) {
+            float4 a = x4[j];
+            o4[j] = make_float4(op(a.x), op(a.y), op(a.z), op(a.w));
+        }
+        for (long long j = n4 * 4 + i; j < n; j += stride) out[j] = op(x[j]);
+    } else {
+        for (long long j = i; j < n; j += stride) out[j] = op(x[j]);
+    }
+}
+
+// ---------------------------------------------------------------- mu-law
+// closed form in the reference's op order (functional.py:331-334), fp32
+__device__ __forceinline__ long long mulaw_formula(float x, float mu, float log1p_mu) {
+    float sgn = (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : x);     // torch.sign: 0 -> 0, NaN -> NaN
+    float comp = sgn * log1pf(mu * fabsf(x)) / log1p_mu;
+    float q = (comp + 1.0f) / 2.0f * mu + 0.5f;
+    if (!(fabsf(q) < 9.2233720e18f)) return (long long)0x8000000000000000ULL;   // x86 cvttss2si "indefinite"
+    return (long long)q;                                          // trunc toward zero == .long()
+}
+
+constexpr int MULAW_MAX_THR = 1024;
+
+template <bool VEC>
+__global__ void __launch_bounds__(EW_THREADS)
+mulaw_encode_kernel(const float* __restrict__ x, long long n, float mu, float log1p_mu, const int* __restrict__ thr,
+                    int n_pos, int n_neg, int zero_code, long long* __restrict__ out) {
+    __shared__ int s_thr[MULAW_MAX_THR];
+    const bool use_thr = thr != nullptr;
+    if (use_thr) {
+        for (int i = threadIdx.x; i < n_pos + n_neg; i += blockDim.x) s_thr[i] = thr[i];
+        __syncthreads();
+    }
+    auto encode = [&](float v) -> long long {
+        const long long est = mulaw_formula(v, mu, log1p_mu);
+        if (!use_thr) return est;
+        const unsigned raw = __float_as_uint(v);
+        const int bits = (int)(raw & 0x7fffffffu);
+        if (bits > 0x3f800000) return est;                        // |x| > 1 or NaN: closed form
+        const bool neg = (raw >> 31) != 0;
+        const int* tb = neg ? s_thr + n_pos : s_thr;
+        const int nt = neg ? n_neg : n_pos;
+        long long c = neg ? (long long)zero_code - est : est - (long long)zero_code;
+        int cnt = c < 0 ? 0 : (c > nt ? nt : (int)c);
+        while (cnt < nt && tb[cnt] <= bits) ++cnt;
+        while (cnt > 0 && tb[cnt - 1] > bits) --cnt;
+        return neg ? (long long)(zero_code - cnt) : (long long)(zero_code + cnt);
+    };
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if constexpr (VEC) {
+        const long long n4 = n / 4;
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        longlong2* o2 = reinterpret_cast<longlong2*>(out);
+        for (long long j = i; j < n4; j += stride) {
+            float4 a = x4[j];
+            o2[2 * j] = make_longlong2(encode(a.x), encode(a.y));
+            o2[2 * j + 1] = make_longlong2(encode(a.z), encode(a.w));
+        }
+        for (long long j = n4 * 4 + i; j < n; j += stride) out[j] = encode(x[j]);
+    } else {
+        for (long long j = i; j < n; j += stride) out[j] = encode(x[j]);
+    }
+}
+
+// closed form of functional.py:352-353
+__device__ __forceinline__ float mulaw_expand(float code, float mu, float log1p_mu) {
+    float y = (code / mu) * 2.0f - 1.0f;
+    float sgn = (y > 0.0f) ? 1.0f : ((y < 0.0f) ? -1.0f : y);
+    return sgn * (expf(fabsf(y) * log1p_mu) - 1.0f) / mu;
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(EW_THREADS)
+mulaw_decode_i64_kernel(const long long* __restrict__ codes, long long n, int nq, float mu, float log1p_mu,
+                        const float* __restrict__ lut, float* __restrict__ out) {
+    auto decode = [&](long long c) -> float {
+        if (lut != nullptr && c >= 0 && c < nq) return lut[c];
+        return mulaw_expand((float)c, mu, log1p_mu);
+    };
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if constexpr (VEC) {
+        const long long n4 = n / 4;
+        const longlong2* c2 = reinterpret_cast<const longlong2*>(codes);
+        float4* o4 = reinterpret_cast<float4*>(out);
+        for (long long j = i; j < n4; j += stride) {
+            longlong2 a = c2[2 * j], b = c2[2 * j + 1];
+            o4[j] = make_float4(decode(a.x), decode(a.y), decode(b.x), decode(b.y));
+        }
+        for (long long j = n4 * 4 + i; j < n; j += stride) out[j] = decode(codes[j]);
+    } else {
+        for (long long j = i; j < n; j += stride) out[j] = decode(codes[j]);
+    }
+}
+
+struct MulawExpandOp {
+    float mu, log1p_mu;
+    __device__ __forceinline__ float operator()(float c) const { return mulaw_expand(c, mu, log1p_mu); }
+};
+
+template <class Op>
+static int launch_unary(const float* x, int64_t n, Op op, float* out, void* stream) {
+    if (n == 0) return TAC_OK;
+    if (!x || !out || n < 0) return TAC_E_INVALID;
+    const bool vec = aligned16(x) && aligned16(out);
+    const unsigned blocks = ew_blocks(vec ? (n + 3) / 4 : n);
+    if (vec) hipLaunchKernelGGL((unary_kernel<true, Op>), dim3(blocks), dim3(EW_THREADS), 0, (hipStream_t)stream, x, (long long)n, op, out);
+    else hipLaunchKernelGGL((unary_kernel<false, Op>), dim3(blocks), dim3(EW_THREADS), 0, (hipStream_t)stream, x, (long long)n, op, out);
+    TAC_HIP(hipGetLastError());
+    return TAC_OK;
+}
+
+}  // namespace tac
+
+extern "C" {
+
+int tac_complex_norm_f32(const float* x, int64_t n, float power, float* out, void* stream) {
+    using namespace tac;
+    if (n == 0) return TAC_OK;
+    if (!x || !out || n < 0) return TAC_E_INVALID;
+    const bool vec = aligned16(x) && aligned16(out);
+    const unsigned blocks = ew_blocks(vec ? (n + 3) / 4 : n);
+    if (vec) hipLaunchKernelGGL(complex_norm_kernel<true>, dim3(blocks), dim3(EW_THREADS), 0, (hipStream_t)stream, x, (long long)n, power, out);
+    else hipLaunchKernelGGL(complex_norm_kernel<false>, dim3(blocks), dim3(EW_THREADS), 0, (hipStream_t)stream, x, (long long)n, power, out);
+    TAC_HIP(hipGetLastError());
+    return TAC_OK;
+}
+
+int tac_amplitude_to_db_f32(const float* x, int64_t n, float ref, float amin, float* out, void* stream) {
+    return tac::launch_unary(x, n, tac::AmpToDb{amin, log10f(ref)}, out, stream);
+}
+
+int tac_db_to_amplitude_f32(const float* x, int64_t n, float ref, float* out, void* stream) {
+    return tac::launch_unary(x, n, tac::DbToAmp{log10f(ref)}, out, stream);
+}
+
+int tac_mulaw_encode_f32_i64(const float* x, int64_t n, int32_t n_quantize, const int32_t* thresholds, int32_t n_pos,
+                             int32_t n_neg, int32_t zero_code, int64_t* out, void* stream) {
+    using namespace tac;
+    if (n == 0) return TAC_OK;
+    if (!x || !out || n < 0 || n_quantize < 2) return TAC_E_INVALID;
+    if (thresholds && (n_pos < 0 || n_neg < 0 || n_pos + n_neg > MULAW_MAX_THR)) return TAC_E_UNSUPPORTED;
+    const float mu = (float)(n_quantize - 1);
+    const float l1p = log1pf(mu);
+    const bool vec = aligned16(x) && aligned16(out);
+    const unsigned blocks = ew_blocks(vec ? (n + 3) / 4 : n);
+    long long* o = reinterpret_cast<long long*>(out);
+    if (vec) hipLaunchKernelGGL(mulaw_encode_kernel<true>, dim3(blocks), dim3(EW_THREADS), 0, (hipStream_t)stream, x, (long long)n, mu, l1p, thresholds, n_pos, n_neg, zero_code, o);
+    else hipLaunchKernelGGL(mulaw_encode_kernel<false>, dim3(blocks), dim3(EW_THREADS), 0, (hipStream_t)stream, x, (long long)n, mu, l1p, thresholds, n_pos, n_neg, zero_code, o);
+    TAC_HIP(hipGetLastError());
+    return TAC_OK;
+}
+
+int tac_mulaw_decode_i64_f32(const int64_t* codes, int64_t n, int32_t n_quantize, const float* lut, float* out,
+                             void* stream) {
+    using namespace tac;
+    if (n == 0) return TAC_OK;
+    if (!codes || !out || n < 0 || n_quantize < 2) return TAC_E_INVALID;
+    const float mu = (float)(n_quantize - 1);
+    const float l1p = log1pf(mu);
+    const bool vec = aligned16(codes) && aligned16(out);
+    const unsigned blocks = ew_blocks(vec ? (n + 3) / 4 : n);
+    const long long* c = reinterpret_cast<const long long*>(codes);
+    if (vec) hipLaunchKernelGGL(mulaw_decode_i64_kernel<true>, dim3(blocks), dim3(EW_THREADS), 0, (hipStream_t)stream, c, (long long)n, n_quantize, mu, l1p, lut, out);
+    else hipLaunchKernelGGL(mulaw_decode_i64_kernel<false>, dim3(blocks), dim3(EW_THREADS), 0, (hipStream_t)stream, c, (long long)n, n_quantize, mu, l1p, lut, out);
+    TAC_HIP(hipGetLastError());
+    return TAC_OK;
+}
+
+int tac_mulaw_decode_f32_f32(const float* codes, int64_t n, int32_t n_quantize, float* out, void* stream) {
+    if (n_quantize < 2) return TAC_E_INVALID;
+    const float mu = (float)(n_quantize - 1);
+    return tac::launch_unary(codes, n, tac::MulawExpandOp{mu, log1pf(mu)}, out, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,329 @@
+// fft_core.hpp — wave-level Stockham R2C FFT for gfx950 (wave64).
+//
+// One N-point real frame = one NC=N/2-point complex FFT of the packed (even, odd) samples plus
+// an R2C split.  A frame is owned by LPF = NC/E lanes of ONE wavefront, E complex elements per
+// lane (E=16 up to N=2048, 32 for N=4096); G = 64/LPF frames share a wave.  Because a frame never
+// leaves its wave, the inter-pass exchanges through LDS need no s_barrier: LDS executes one wave's
+// DS instructions in issue order, so a wave-level compiler fence is all the ordering required.
+//
+// Passes are radix-16 (in registers, 4x4) with a radix-{2,4,8,16} tail: N=2048 is 16·16·4, i.e.
+// two LDS exchanges + one for the R2C pairing.  LDS image of a frame is NC complex padded by one
+// element per 16 (index o -> o + o/16): that makes the stride-R writes of the first pass
+// bank-conflict free (checked lane-accurately in tools/emulate_wave_fft.py).
+//
+// Inter-pass twiddles, the window and the R2C twiddles depend only on the lane, not on the frame,
+// so persistent kernels load them ONCE into registers and reuse them for every frame.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace tac {
+
+typedef float2 cf;
+
+__device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cf cmul(cf a, cf b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+// a * (-i)
+__device__ __forceinline__ cf mul_neg_i(cf a) { return make_float2(a.y, -a.x); }
+
+// Compiler-only ordering point for same-wave LDS traffic (no instruction emitted).
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int lds_pad(int o) { return o + (o >> 4); }
+
+// ---------------------------------------------------------------- in-register DFTs (forward, natural order)
+__device__ __forceinline__ void dft2(cf& a, cf& b) {
+    cf t = csub(a, b);
+    a = cadd(a, b);
+    b = t;
+}
+
+__device__ __forceinline__ void dft4(cf& a0, cf& a1, cf& a2, cf& a3) {
+    cf s02 = cadd(a0, a2), d02 = csub(a0, a2);
+    cf s13 = cadd(a1, a3), d13 = mul_neg_i(csub(a1, a3));
+    a0 = cadd(s02, s13);
+    a1 = cadd(d02, d13);
+    a2 = csub(s02, s13);
+    a3 = csub(d02, d13);
+}
+
+#define TAC_SQRT_HALF 0.70710678118654752440f
+#define TAC_COS_PI_8 0.92387953251128675613f
+#define TAC_SIN_PI_8 0.38268343236508977173f
+
+// multiply by W16^M = exp(-2*pi*i*M/16), M compile-time
+template <int M>
+__device__ __forceinline__ cf mul_w16(cf v) {
+    if constexpr (M == 0) return v;
+    else if constexpr (M == 4) return mul_neg_i(v);
+    else if constexpr (M == 2) return make_float2((v.x + v.y) * TAC_SQRT_HALF, (v.y - v.x) * TAC_SQRT_HALF);
+    else if constexpr (M == 6) return make_float2((v.y - v.x) * TAC_SQRT_HALF, -(v.x + v.y) * TAC_SQRT_HALF);
+    else if constexpr (M == 1) return cmul(v, make_float2(TAC_COS_PI_8, -TAC_SIN_PI_8));
+    else if constexpr (M == 3) return cmul(v, make_float2(TAC_SIN_PI_8, -TAC_COS_PI_8));
+    else if constexpr (M == 9) return cmul(v, make_float2(-TAC_COS_PI_8, TAC_SIN_PI_8));
+    else return v;
+}
+
+template <int R>
+struct Dft;
+
+template <>
+struct Dft<2> {
+    __device__ static __forceinline__ void run(cf* v) { dft2(v[0], v[1]); }
+};
+template <>
+struct Dft<4> {
+    __device__ static __forceinline__ void run(cf* v) { dft4(v[0], v[1], v[2], v[3]); }
+};
+template <>
+struct Dft<8> {
+    __device__ static __forceinline__ void run(cf* v) {
+        cf e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+        cf o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+        dft4(e0, e1, e2, e3);
+        dft4(o0, o1, o2, o3);
+        o1 = mul_w16<2>(o1);   // W8^1
+        o2 = mul_w16<4>(o2);   // W8^2
+        o3 = mul_w16<6>(o3);   // W8^3
+        v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
+        v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
+        v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
+        v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
+    }
+};
+template <>
+struct Dft<16> {
+    // n = c + 4d, k = r + 4k':  X[r+4k'] = sum_c W4^{ck'} W16^{cr} (sum_d x[c+4d] W4^{dr})
+    __device__ static __forceinline__ void run(cf* v) {
+        cf a[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            a[c][0] = v[c]; a[c][1] = v[c + 4]; a[c][2] = v[c + 8]; a[c][3] = v[c + 12];
+            dft4(a[c][0], a[c][1], a[c][2], a[c][3]);
+        }
+        a[1][1] = mul_w16<1>(a[1][1]); a[1][2] = mul_w16<2>(a[1][2]); a[1][3] = mul_w16<3>(a[1][3]);
+        a[2][1] = mul_w16<2>(a[2][1]); a[2][2] = mul_w16<4>(a[2][2]); a[2][3] = mul_w16<6>(a[2][3]);
+        a[3][1] = mul_w16<3>(a[3][1]); a[3][2] = mul_w16<6>(a[3][2]); a[3][3] = mul_w16<9>(a[3][3]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            cf b0 = a[0][r], b1 = a[1][r], b2 = a[2][r], b3 = a[3][r];
+            dft4(b0, b1, b2, b3);
+            v[r] = b0; v[r + 4] = b1; v[r + 8] = b2; v[r + 12] = b3;
+        }
+    }
+};
+
+// ---------------------------------------------------------------- plan algebra (compile time)
+constexpr int radix_at(int nc, int pass) {
+    int rem = nc;
+    for (int p = 0; p < pass; ++p) rem /= (rem >= 16 ? 16 : rem);
+    return rem >= 16 ? 16 : rem;
+}
+constexpr int stride_at(int nc, int pass) {
+    int s = 1, rem = nc;
+    for (int p = 0; p < pass; ++p) { int r = rem >= 16 ? 16 : rem; s *= r; rem /= r; }
+    return s;
+}
+constexpr int num_passes(int nc) {
+    int n = 0, rem = nc;
+    while (rem > 1) { rem /= (rem >= 16 ? 16 : rem); ++n; }
+    return n;
+}
+constexpr int twiddles_before(int nc, int e, int pass) {   // hoisted-twiddle registers used by passes < pass
+    int n = 0;
+    for (int p = 1; p < pass; ++p) { int r = radix_at(nc, p); n += (e / r) * (r - 1); }
+    return n;
+}
+
+template <int NC_, int E_>
+struct WaveFft {
+    static constexpr int NC = NC_;
+    static constexpr int E = E_;
+    static constexpr int N = 2 * NC;
+    static constexpr int LPF = NC / E;            // lanes per frame
+    static constexpr int G = 64 / LPF;            // frames per wave
+    static constexpr int PADDED = NC + NC / 16 + 1;   // LDS complex slots per frame
+    static constexpr int NPASS = num_passes(NC);
+    static constexpr int NTW = twiddles_before(NC, E, NPASS) > 0 ? twiddles_before(NC, E, NPASS) : 1;
+    static constexpr int NPAIR = E / 2;           // R2C pairs per lane
+    static_assert(LPF >= 1 && LPF <= 64 && LPF * E == NC, "bad (NC, E)");
+
+    // W_NC table -> registers.  table[i] = exp(-2*pi*i*i/NC), i < NC.
+    __device__ static __forceinline__ void load_twiddles(cf* tw, const cf* __restrict__ table, int t) {
+        load_tw_pass<1>(tw, table, t);
+    }
+    template <int P>
+    __device__ static __forceinline__ void load_tw_pass(cf* tw, const cf* __restrict__ table, int t) {
+        if constexpr (P < NPASS) {
+            constexpr int R = radix_at(NC, P), S = stride_at(NC, P), OFF = twiddles_before(NC, E, P);
+            constexpr int NB = E / R;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                int j = t + b * LPF;
+                int js = j & (S - 1);
+#pragma unroll
+                for (int q = 1; q < R; ++q) tw[OFF + b * (R - 1) + q - 1] = table[js * q * (NC / (S * R))];
+            }
+            load_tw_pass<P + 1>(tw, table, t);
+        }
+    }
+
+    // v: E registers in first-pass order v[b*R0 + q] = z[(t + b*LPF) + q*NC/R0].
+    // On return the frame's spectrum Z[0..NC) sits in natural order at lds[lds_pad(i)].
+    __device__ static __forceinline__ void run(cf* v, cf* lds, const cf* tw, int t) {
+        pass<0>(v, lds, tw, t);
+        wave_lds_fence();
+    }
+
+    template <int P>
+    __device__ static __forceinline__ void pass(cf* v, cf* lds, const cf* tw, int t) {
+        constexpr int R = radix_at(NC, P), S = stride_at(NC, P), OFF = twiddles_before(NC, E, P);
+        constexpr int NB = E / R;
+        static_assert(NB >= 1, "radix larger than elements per lane");
+        if constexpr (P > 0) {
+            wave_lds_fence();
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                int j = t + b * LPF;
+#pragma unroll
+                for (int q = 0; q < R; ++q) v[b * R + q] = lds[lds_pad(j + q * (NC / R))];
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int q = 1; q < R; ++q) v[b * R + q] = cmul(v[b * R + q], tw[OFF + b * (R - 1) + q - 1]);
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) Dft<R>::run(v + b * R);
+        wave_lds_fence();   // every lane's reads of this pass precede any lane's writes (same wave, in order)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            int j = t + b * LPF;
+            int base = (j / S) * (S * R) + (j & (S - 1));
+#pragma unroll
+            for (int k = 0; k < R; ++k) lds[lds_pad(base + k * S)] = v[b * R + k];
+        }
+        if constexpr (P + 1 < NPASS) pass<P + 1>(v, lds, tw, t);
+    }
+
+    // R2C split of pair index k (0 <= k <= NC/2): returns X[k] in xa and X[NC-k] in xb.
+    // wk = exp(-2*pi*i*k/N).
+    __device__ static __forceinline__ void r2c_pair(const cf* lds, int k, cf wk, cf& xa, cf& xb) {
+        cf zk = lds[lds_pad(k)];
+        cf zm = lds[lds_pad((NC - k) & (NC - 1))];
+        cf ev = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+        cf od = make_float2(0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
+        cf tw = cmul(wk, od);
+        xa = cadd(ev, tw);
+        cf d = csub(ev, tw);
+        xb = make_float2(d.x, -d.y);
+    }
+};
+
+// ---------------------------------------------------------------- framing
+enum { PAD_CONSTANT = 0, PAD_REFLECT = 1, PAD_REPLICATE = 2, PAD_CIRCULAR = 3 };
+
+__device__ __forceinline__ float fetch_padded(const float* __restrict__ row, long long i, long long L, int mode) {
+    if (i >= 0 && i < L) return row[i];
+    if (mode == PAD_CONSTANT) return 0.0f;
+    if (mode == PAD_REFLECT) i = i < 0 ? -i : 2 * (L - 1) - i;
+    else if (mode == PAD_REPLICATE) i = i < 0 ? 0 : L - 1;
+    else i = i < 0 ? i + L : i - L;
+    return row[i];
+}
+
+struct FrameGeom {
+    const float* wave;      // device, rows x row_stride
+    long long row_stride;
+    long long length;       // L
+    const float* window;    // device, win_length
+    int win_length;
+    int win_offset;         // (N - win_length) / 2
+    int hop;
+    int center_pad;         // N/2 if center else 0
+    int pad_mode;
+    int vec2_ok;            // host-verified: float2 loads of interior frames are 8-byte aligned
+    long long n_frames;     // T
+    long long rows;
+    float scale;            // 1 or N^-0.5
+};
+
+// zero-padded, centred window value pair for complex element m (samples 2m, 2m+1)
+__device__ __forceinline__ float2 window_pair(const FrameGeom& g, int m) {
+    int n0 = 2 * m - g.win_offset, n1 = n0 + 1;
+    float w0 = (n0 >= 0 && n0 < g.win_length) ? g.window[n0] : 0.0f;
+    float w1 = (n1 >= 0 && n1 < g.win_length) ? g.window[n1] : 0.0f;
+    return make_float2(w0, w1);
+}
+
+// Load + window one frame into first-pass register order.  `frame` may be >= T (then zeros).
+template <class F, bool HOIST_WIN>
+__device__ __forceinline__ void load_frame(cf* v, const FrameGeom& g, const float2* win, long long row,
+                                           long long frame, int t) {
+    constexpr int R0 = radix_at(F::NC, 0);
+    constexpr int NB = F::E / R0;
+    const bool active = frame < g.n_frames;
+    const float* rp = g.wave + row * g.row_stride;
+    const long long start = frame * (long long)g.hop - g.center_pad;
+    const bool interior = active && start >= 0 && start + F::N <= g.length;
+    if (interior && g.vec2_ok) {
+        const float2* src = reinterpret_cast<const float2*>(rp + start);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int q = 0; q < R0; ++q) {
+                int m = t + b * F::LPF + q * (F::NC / R0);
+                float2 s = src[m];
+                float2 w = HOIST_WIN ? win[b * R0 + q] : window_pair(g, m);
+                v[b * R0 + q] = make_float2(s.x * w.x, s.y * w.y);
+            }
+    } else if (active) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int q = 0; q < R0; ++q) {
+                int m = t + b * F::LPF + q * (F::NC / R0);
+                float s0 = fetch_padded(rp, start + 2 * m, g.length, g.pad_mode);
+                float s1 = fetch_padded(rp, start + 2 * m + 1, g.length, g.pad_mode);
+                float2 w = HOIST_WIN ? win[b * R0 + q] : window_pair(g, m);
+                v[b * R0 + q] = make_float2(s0 * w.x, s1 * w.y);
+            }
+    } else {
+#pragma unroll
+        for (int e = 0; e < F::E; ++e) v[e] = make_float2(0.0f, 0.0f);
+    }
+}
+
+template <class F>
+__device__ __forceinline__ void load_window_regs(float2* win, const FrameGeom& g, int t) {
+    constexpr int R0 = radix_at(F::NC, 0);
+    constexpr int NB = F::E / R0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int q = 0; q < R0; ++q) win[b * R0 + q] = window_pair(g, t + b * F::LPF + q * (F::NC / R0));
+}
+
+// |X|^power of an (already scaled) spectrum value
+__device__ __forceinline__ float cpow_mag(cf x, float power) {
+    float s = x.x * x.x + x.y * x.y;
+    if (power == 2.0f) return s;
+    float m = sqrtf(s);
+    if (power == 1.0f) return m;
+    return powf(m, power);
+}
+
+// amplitude_to_db: 10*(log10(max(x*x, amin)) - log10(ref))   (reference squares its input)
+__device__ __forceinline__ float amp_to_db(float x, float amin, float log10_ref) {
+    float sq = fmaxf(x * x, amin);
+    if (!(sq == sq)) sq = x * x;   // keep NaN (torch.clamp propagates NaN, fmaxf would drop it)
+    return 10.0f * (log10f(sq) - log10_ref);
+}
+
+}  // namespace tac

@@ -1,0 +1,121 @@
+// host_common.hip — error strings, geometry validation, twiddle-table cache.
+#include "host_common.hpp"
+
+#include <cmath>
+#include <map>
+#include <mutex>
+#include <vector>
+
+namespace tac {
+
+thread_local int g_last_hip_error = 0;
+
+int device_cu_count() {
+    static thread_local int cached_dev = -1, cached_cus = 256;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev != cached_dev) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            cached_cus = cus;
+        cached_dev = dev;
+    }
+    return cached_cus;
+}
+
+int get_tables(int n_fft, Tables* out) {
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, Tables> cache;
+    int dev = 0;
+    TAC_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    auto key = std::make_pair(n_fft, dev);
+    auto it = cache.find(key);
+    if (it != cache.end()) {
+        *out = it->second;
+        return TAC_OK;
+    }
+    const int nc = n_fft / 2;
+    const int n_post = nc / 2 + 1;
+    std::vector<cf> host((size_t)nc + n_post);
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int k = 0; k < nc; ++k) {
+        double a = -two_pi * (double)k / (double)nc;
+        host[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    for (int k = 0; k < n_post; ++k) {
+        double a = -two_pi * (double)k / (double)n_fft;
+        host[nc + k] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    cf* dptr = nullptr;
+    TAC_HIP(hipMalloc((void**)&dptr, host.size() * sizeof(cf)));
+    TAC_HIP(hipMemcpy(dptr, host.data(), host.size() * sizeof(cf), hipMemcpyHostToDevice));
+    Tables t{dptr, dptr + nc};
+    cache[key] = t;
+    *out = t;
+    return TAC_OK;
+}
+
+int make_geometry(const float* wave, const float* window, const tac_stft_desc* d, FrameGeom* g,
+                  int64_t* n_frames) {
+    if (!wave || !window || !d || !g) return TAC_E_INVALID;
+    if (d->rows <= 0 || d->length <= 0 || d->hop <= 0 || d->n_fft <= 0) return TAC_E_INVALID;
+    if (d->win_length <= 0 || d->win_length > d->n_fft) return TAC_E_INVALID;
+    if (d->pad_mode < TAC_PAD_CONSTANT || d->pad_mode > TAC_PAD_CIRCULAR) return TAC_E_INVALID;
+    if (d->row_stride < d->length) return TAC_E_INVALID;
+    if (!is_pow2(d->n_fft) || d->n_fft < 32 || d->n_fft > 4096) return TAC_E_UNSUPPORTED;
+    const int pad = d->center ? d->n_fft / 2 : 0;
+    if (pad > 0) {
+        // torch's reflect pad needs pad < L, circular needs pad <= L (functional.py:99-107 -> F.pad)
+        if (d->pad_mode == TAC_PAD_REFLECT && pad >= d->length) return TAC_E_SHORT_INPUT;
+        if (d->pad_mode == TAC_PAD_CIRCULAR && pad > d->length) return TAC_E_SHORT_INPUT;
+    }
+    const int64_t T = tac_num_frames(d->length, d->n_fft, d->hop, d->center);
+    if (T <= 0) return TAC_E_SHORT_INPUT;
+    g->wave = wave;
+    g->row_stride = d->row_stride;
+    g->length = d->length;
+    g->window = window;
+    g->win_length = d->win_length;
+    g->win_offset = (d->n_fft - d->win_length) / 2;
+    g->hop = d->hop;
+    g->center_pad = pad;
+    g->pad_mode = d->pad_mode;
+    g->vec2_ok = ((d->hop & 1) == 0) && ((pad & 1) == 0) && ((d->row_stride & 1) == 0) &&
+                 ((reinterpret_cast<uintptr_t>(wave) & 7u) == 0);
+    g->n_frames = T;
+    g->rows = d->rows;
+    g->scale = d->normalized ? (float)(1.0 / std::sqrt((double)d->n_fft)) : 1.0f;
+    *n_frames = T;
+    return TAC_OK;
+}
+
+}  // namespace tac
+
+extern "C" {
+
+const char* tac_strerror(int code) {
+    switch (code) {
+        case TAC_OK: return "ok";
+        case TAC_E_INVALID: return "invalid argument";
+        case TAC_E_UNSUPPORTED: return "unsupported configuration for the HIP path";
+        case TAC_E_SHORT_INPUT: return "input too short for the requested n_fft / padding";
+        case TAC_E_LAUNCH: return "HIP runtime error";
+        default: return "unknown error";
+    }
+}
+
+int tac_last_hip_error(void) { return tac::g_last_hip_error; }
+
+int tac_abi_version(void) { return 1; }
+
+int64_t tac_num_frames(int64_t L, int n_fft, int hop, int center) {
+    if (L <= 0 || n_fft <= 0 || hop <= 0) return 0;
+    const int64_t padded = L + (center ? 2 * (int64_t)(n_fft / 2) : 0);
+    if (padded < n_fft) return 0;
+    return 1 + (padded - n_fft) / hop;
+}
+
+int tac_num_bins(int n_fft, int onesided) { return n_fft <= 0 ? 0 : (onesided ? n_fft / 2 + 1 : n_fft); }
+
+}  // extern "C"

@@ -1,0 +1,40 @@
+// host_common.hpp — host-side helpers shared by the C-ABI launchers of libtac_amd.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tac_amd.h"
+#include "fft_core.hpp"
+
+namespace tac {
+
+extern thread_local int g_last_hip_error;
+
+inline int hip_fail(hipError_t e) {
+    g_last_hip_error = (int)e;
+    return TAC_E_LAUNCH;
+}
+#define TAC_HIP(expr)                                   \
+    do {                                                \
+        hipError_t _e = (expr);                         \
+        if (_e != hipSuccess) return ::tac::hip_fail(_e); \
+    } while (0)
+
+struct Tables {
+    const cf* w_nc;   // exp(-2*pi*i*k/NC), k < NC          (NC = n_fft/2)
+    const cf* w_n;    // exp(-2*pi*i*k/N),  k <= NC/2
+};
+
+// immutable per-(n_fft, device) twiddle tables; first use allocates + uploads (synchronous)
+int get_tables(int n_fft, Tables* out);
+
+int device_cu_count();
+
+inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// Validates a descriptor the way torch.stft does and fills the device-side geometry.
+// Returns TAC_OK or an error code.  T is written to *n_frames.
+int make_geometry(const float* wave, const float* window, const tac_stft_desc* d, FrameGeom* g,
+                  int64_t* n_frames);
+
+}  // namespace tac

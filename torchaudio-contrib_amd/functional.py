@@ -1,0 +1,409 @@
+"""Functional API — same names, argument order, defaults and error behaviour as the reference's
+``torchaudio_contrib/functional.py``; every body launches hand-written gfx950 kernels through the
+C ABI in ``include/tac_amd.h`` (no torch compute ops on the hot path, no CPU fallback).
+
+Inputs must live on a HIP device (``tensor.is_cuda``) and be float32 (float16/bfloat16 are widened,
+as torch.stft does for half input in the reference).  Outputs are fresh tensors; the STFT-family
+results are returned as the same strided views the reference produces (physically frame-major,
+logically ``(*, channel, freq, time[, 2])``).
+"""
+import math
+import threading
+
+import torch
+
+from . import _native
+from ._lazy import realize as _realize
+
+__all__ = ['stft', 'complex_norm', 'create_mel_filter', 'apply_filterbank', 'angle', 'magphase',
+           'phase_vocoder', 'amplitude_to_db', 'db_to_amplitude', 'mu_law_encoding', 'mu_law_decoding']
+
+
+# ----------------------------------------------------------------------------- helpers
+def _device_f32(x, what):
+    """Validate + normalise an input tensor for the HIP path (never falls back to CPU)."""
+    if not torch.is_tensor(x):
+        raise TypeError('%s must be a torch.Tensor, got %s' % (what, type(x).__name__))
+    x = _realize(x)
+    if not x.is_cuda:
+        raise RuntimeError('%s is on %s: torchaudio_contrib_amd only runs on a HIP device (MI355X); '
+                           'move the tensor with .cuda() — there is no CPU path' % (what, x.device))
+    if x.requires_grad and torch.is_grad_enabled():
+        raise NotImplementedError('%s requires grad: the gfx950 kernels are forward-only' % what)
+    if x.dtype in (torch.float16, torch.bfloat16):
+        x = x.float()
+    if x.dtype != torch.float32:
+        raise NotImplementedError('%s has dtype %s: the gfx950 kernels compute in float32' % (what, x.dtype))
+    return x
+
+
+def _dense(x):
+    """Return x if it is non-overlapping & dense (any dim order), else a contiguous copy."""
+    if x.is_contiguous() or x.is_non_overlapping_and_dense():
+        return x
+    return x.contiguous()
+
+
+_window_cache = {}
+_cache_lock = threading.Lock()
+
+
+def _default_window(n, device):
+    key = (n, str(device))
+    w = _window_cache.get(key)
+    if w is None:
+        # periodic Hann, same constructor the reference calls (functional.py:93-97, layers.py:76-80)
+        w = torch.hann_window(n, device=device)
+        with _cache_lock:
+            _window_cache[key] = w
+    return w
+
+
+class _StftPlan(object):
+    """Validated geometry of one stft call (mirrors the checks torch.stft performs)."""
+    __slots__ = ('wave', 'window', 'desc', 'lead', 'n_frames', 'n_bins', 'n_fft', 'onesided')
+
+    def __init__(self, waveforms, fft_length, hop_length, win_length, window, center, pad_mode,
+                 normalized, onesided):
+        x = _device_f32(waveforms, 'waveforms')
+        if x.dim() < 1 or x.numel() == 0:
+            raise RuntimeError('stft: expected a non-empty tensor of shape (*, channel, time)')
+        n_fft = int(fft_length)
+        hop = n_fft // 4 if hop_length is None else int(hop_length)
+        win_length = n_fft if win_length is None else int(win_length)
+        length = x.shape[-1]
+        if n_fft <= 0 or hop <= 0:
+            raise RuntimeError('stft: expected 0 < n_fft and 0 < hop_length, got n_fft=%d hop_length=%d'
+                               % (n_fft, hop))
+        if not 0 < win_length <= n_fft:
+            raise RuntimeError('stft: expected 0 < win_length <= n_fft, got win_length=%d' % win_length)
+        if window is None:
+            window = _default_window(win_length, x.device)
+        else:
+            if not torch.is_tensor(window) or window.dim() != 1 or window.shape[0] != win_length:
+                raise RuntimeError('stft: expected a 1D window tensor of size equal to win_length=%d'
+                                   % win_length)
+            if window.device != x.device:
+                raise RuntimeError('stft: input and window must be on the same device, got %s and %s'
+                                   % (x.device, window.device))
+            window = _device_f32(window, 'window').contiguous()
+        if pad_mode not in _native.PAD_MODES:
+            raise NotImplementedError('stft: unsupported pad_mode %r' % (pad_mode,))
+        pad = n_fft // 2 if center else 0
+        if center and pad_mode == 'reflect' and pad >= length:
+            raise RuntimeError('stft: reflect padding (%d, %d) must be smaller than the signal length %d'
+                               % (pad, pad, length))
+        if center and pad_mode == 'circular' and pad > length:
+            raise RuntimeError('stft: circular padding (%d, %d) must not exceed the signal length %d'
+                               % (pad, pad, length))
+        if length + 2 * pad < n_fft:
+            raise RuntimeError('stft: expected n_fft <= padded signal length %d, got n_fft=%d'
+                               % (length + 2 * pad, n_fft))
+        if n_fft & (n_fft - 1) or not 32 <= n_fft <= 4096:
+            raise NotImplementedError('stft: the gfx950 FFT kernels cover power-of-two fft_length in '
+                                      '[32, 4096]; got %d' % n_fft)
+        self.lead = tuple(x.shape[:-1])
+        flat = x.reshape(-1, length)
+        if flat.stride(1) != 1 or (flat.shape[0] > 1 and flat.stride(0) < length):
+            flat = flat.contiguous()
+        self.wave = flat
+        self.window = window
+        self.n_fft = n_fft
+        self.onesided = bool(onesided)
+        self.n_frames = 1 + (length + 2 * pad - n_fft) // hop
+        self.n_bins = n_fft // 2 + 1 if onesided else n_fft
+        self.desc = _native.StftDesc(
+            rows=flat.shape[0], length=length, row_stride=flat.stride(0) if flat.shape[0] > 1 else length,
+            n_fft=n_fft, hop=hop, win_length=win_length, center=1 if center else 0,
+            pad_mode=_native.PAD_MODES[pad_mode], normalized=1 if normalized else 0,
+            onesided=1 if onesided else 0, reserved=0)
+
+    # launches ------------------------------------------------------------------
+    def run_stft(self):
+        out = torch.empty(self.lead + (self.n_frames, self.n_bins, 2), dtype=torch.float32,
+                          device=self.wave.device)
+        with torch.cuda.device(self.wave.device):
+            rc = _native.lib().tac_stft_f32(_native.ptr(self.wave), _native.ptr(self.window), self.desc,
+                                            _native.ptr(out), _native.stream_ptr(self.wave.device))
+        _native.check(rc, 'tac_stft_f32')
+        return out.transpose(-3, -2)
+
+    def run_spectrogram(self, power, db=None):
+        out = torch.empty(self.lead + (self.n_frames, self.n_bins), dtype=torch.float32,
+                          device=self.wave.device)
+        ref, amin = db if db is not None else (1.0, 1e-7)
+        with torch.cuda.device(self.wave.device):
+            rc = _native.lib().tac_spectrogram_f32(
+                _native.ptr(self.wave), _native.ptr(self.window), self.desc, float(power),
+                1 if db is not None else 0, float(ref), float(amin), _native.ptr(out),
+                _native.stream_ptr(self.wave.device))
+        _native.check(rc, 'tac_spectrogram_f32')
+        return out.transpose(-2, -1)
+
+    def can_fuse_mel(self, filterbank):
+        return (self.onesided and self.n_fft <= 2048 and filterbank.dim() == 2 and
+                filterbank.shape[0] == self.n_bins and 0 < filterbank.shape[1] <= 512 and
+                filterbank.is_cuda and filterbank.dtype == torch.float32 and
+                filterbank.device == self.wave.device)
+
+    def run_melspec(self, power, filterbank, db=None):
+        fb = filterbank if filterbank.is_contiguous() else filterbank.contiguous()
+        plan = _filterbank_plan(fb)
+        n_mels = fb.shape[1]
+        out = torch.empty(self.lead + (self.n_frames, n_mels), dtype=torch.float32, device=self.wave.device)
+        ref, amin = db if db is not None else (1.0, 1e-7)
+        with torch.cuda.device(self.wave.device):
+            rc = _native.lib().tac_melspec_f32(
+                _native.ptr(self.wave), _native.ptr(self.window), self.desc, float(power), _native.ptr(fb),
+                _native.ptr(plan), n_mels, 1 if db is not None else 0, float(ref), float(amin),
+                _native.ptr(out), _native.stream_ptr(self.wave.device))
+        _native.check(rc, 'tac_melspec_f32')
+        return out.transpose(-2, -1)
+
+
+_plan_cache = {}
+
+
+def _filterbank_plan(fb):
+    """int32[2*ceil(M/16)] non-zero bin range per 16-band tile, computed on device (no host sync),
+    cached per (storage address, version) so a module's constant filterbank is scanned once."""
+    key = (fb.data_ptr(), fb._version, tuple(fb.shape), str(fb.device))
+    hit = _plan_cache.get(key)
+    if hit is not None:
+        return hit
+    n_freqs, n_mels = fb.shape
+    plan = torch.empty(2 * ((n_mels + 15) // 16), dtype=torch.int32, device=fb.device)
+    with torch.cuda.device(fb.device):
+        rc = _native.lib().tac_filterbank_plan(_native.ptr(fb), n_freqs, n_mels, _native.ptr(plan),
+                                               _native.stream_ptr(fb.device))
+    _native.check(rc, 'tac_filterbank_plan')
+    with _cache_lock:
+        if len(_plan_cache) > 64:
+            _plan_cache.clear()
+        _plan_cache[key] = plan
+    return plan
+
+
+# ----------------------------------------------------------------------------- public API
+def stft(waveforms, fft_length, hop_length=None, win_length=None, window=None,
+         center=True, pad_mode='reflect', normalized=False, onesided=True):
+    """Short-time Fourier transform of ``(*, channel, time)`` waveforms →
+    ``(*, channel, num_freqs, time, complex=2)``  (reference: functional.py:48-113).
+
+    ``window=None`` means a periodic Hann window of ``win_length or fft_length`` (unlike torch.stft).
+    Framing, padding (``center``/``pad_mode``), windowing and the R2C FFT run in one gfx950 kernel.
+    """
+    return _StftPlan(waveforms, fft_length, hop_length, win_length, window, center, pad_mode,
+                     normalized, onesided).run_stft()
+
+
+def complex_norm(complex_tensor, power=1.0):
+    """``|z|**power`` over a trailing ``complex=2`` dim (reference: functional.py:116-128)."""
+    z = _device_f32(complex_tensor, 'complex_tensor')
+    if z.dim() < 1 or z.shape[-1] != 2:
+        raise RuntimeError('complex_norm: expected a trailing dimension of size 2, got shape %s'
+                           % (tuple(z.shape),))
+    if z.stride(-1) != 1 or not (z.is_contiguous() or z.is_non_overlapping_and_dense()) or \
+            any(s % 2 for s, n in zip(z.stride()[:-1], z.shape[:-1]) if n > 1):
+        z = z.contiguous()
+    out = torch.empty_strided(z.shape[:-1], tuple(s // 2 for s in z.stride()[:-1]),
+                              dtype=torch.float32, device=z.device)
+    n = out.numel()
+    if n:
+        with torch.cuda.device(z.device):
+            rc = _native.lib().tac_complex_norm_f32(_native.ptr(z), n, float(power), _native.ptr(out),
+                                                    _native.stream_ptr(z.device))
+        _native.check(rc, 'tac_complex_norm_f32')
+    return out
+
+
+def _hz_to_mel(hz, htk):
+    hz = torch.as_tensor(hz).to(torch.get_default_dtype())
+    if htk:
+        return 2595. * torch.log10(torch.tensor(1., dtype=torch.get_default_dtype()) + hz / 700.)
+    f_sp = 200.0 / 3
+    knee_hz = 1000.0
+    knee_mel = (knee_hz - 0.0) / f_sp
+    step = math.log(6.4) / 27.0
+    return torch.where(hz >= knee_hz, knee_mel + torch.log(hz / knee_hz) / step, (hz - 0.0) / f_sp)
+
+
+def _mel_to_hz(mel, htk):
+    mel = torch.as_tensor(mel).to(torch.get_default_dtype())
+    if htk:
+        return 700. * (10 ** (mel / 2595.) - 1.)
+    f_sp = 200.0 / 3
+    knee_hz = 1000.0
+    knee_mel = (knee_hz - 0.0) / f_sp
+    step = math.log(6.4) / 27.0
+    return torch.where(mel >= knee_mel, knee_hz * torch.exp(step * (mel - knee_mel)), 0.0 + f_sp * mel)
+
+
+def create_mel_filter(num_freqs, num_mels, min_freq, max_freq, htk):
+    """Dense ``(num_freqs, num_mels)`` triangular mel filterbank, Slaney (default) or HTK scale, no
+    area normalisation, bin grid ``linspace(min_freq, max_freq, num_freqs)`` (reference:
+    functional.py:131-169).  One-off init-time constant: evaluated with the same float32 host
+    arithmetic as the reference so the matrix is bit-identical; move it with ``.cuda()``."""
+    grid = torch.linspace(min_freq, max_freq, num_freqs)
+    knots = _mel_to_hz(torch.linspace(_hz_to_mel(min_freq, htk), _hz_to_mel(max_freq, htk), num_mels + 2), htk)
+    gap = knots[1:] - knots[:-1]
+    delta = knots.unsqueeze(0) - grid.unsqueeze(1)
+    lower = (-1. * delta[:, :-2]) / gap[:-1]
+    upper = delta[:, 2:] / gap[1:]
+    return torch.clamp(torch.min(lower, upper), min=0.)
+
+
+def apply_filterbank(mag_specgrams, filterbank):
+    """``(…, num_freqs, time) x (num_freqs, num_bands) → (…, num_bands, time)`` (reference:
+    functional.py:172-184) on the fp32 matrix cores, skipping the zero blocks of sparse banks."""
+    spec = _device_f32(mag_specgrams, 'mag_specgrams')
+    fb = _device_f32(filterbank, 'filterbank')
+    if fb.dim() != 2 or spec.dim() < 2 or spec.shape[-2] != fb.shape[0]:
+        raise RuntimeError('apply_filterbank: size mismatch, spectrogram %s vs filterbank %s'
+                           % (tuple(spec.shape), tuple(fb.shape)))
+    if fb.device != spec.device:
+        raise RuntimeError('apply_filterbank: spectrogram and filterbank must be on the same device')
+    fb = fb if fb.is_contiguous() else fb.contiguous()
+    n_freqs, n_frames = spec.shape[-2], spec.shape[-1]
+    lead = tuple(spec.shape[:-2])
+    n_mels = fb.shape[1]
+    out = torch.empty(lead + (n_frames, n_mels), dtype=torch.float32, device=spec.device)
+    if out.numel():
+        rows = spec.reshape(-1, n_freqs, n_frames)
+        plan = _filterbank_plan(fb)
+        with torch.cuda.device(spec.device):
+            rc = _native.lib().tac_apply_filterbank_f32(
+                _native.ptr(rows), rows.shape[0], n_freqs, n_frames, rows.stride(0), rows.stride(1),
+                rows.stride(2), _native.ptr(fb), _native.ptr(plan), n_mels, _native.ptr(out),
+                _native.stream_ptr(spec.device))
+        _native.check(rc, 'tac_apply_filterbank_f32')
+    return out.transpose(-2, -1)
+
+
+def angle(complex_tensor):
+    """Phase of a ``(*, 2)`` tensor (reference: functional.py:187-191).  Not on the Melspectrogram
+    path (SURVEY §8f "next"): composed from a device-side torch op."""
+    z = _realize(complex_tensor)
+    return torch.atan2(z[..., 1], z[..., 0])
+
+
+def magphase(complex_tensor, power=1.):
+    """(magnitude**power, phase) (reference: functional.py:194-201)."""
+    z = _realize(complex_tensor)
+    return complex_norm(z, power), angle(z)
+
+
+def phase_vocoder(complex_specgrams, rate, phase_advance):
+    """Time-stretch a complex spectrogram by ``rate`` without changing pitch (reference:
+    functional.py:204-274).  Outside the Melspectrogram hot path: kept for API
+    completeness as a composition of device-side torch ops; the magnitudes use the HIP complex_norm."""
+    spec = _realize(complex_specgrams)
+    lead = [slice(None)] * (spec.dim() - 2)
+    steps = torch.arange(0, spec.size(-2), rate, device=spec.device)
+    alphas = torch.remainder(steps, torch.tensor(1., device=spec.device))
+    phase_0 = angle(spec[tuple(lead + [slice(1)])])
+    spec = torch.nn.functional.pad(spec, [0, 0, 0, 2])
+    lo = spec[tuple(lead + [steps.long()])]
+    hi = spec[tuple(lead + [(steps + 1).long()])]
+    ang_lo, ang_hi = angle(lo), angle(hi)
+    mag_lo, mag_hi = torch.norm(lo, dim=-1), torch.norm(hi, dim=-1)
+    phase = ang_hi - ang_lo - phase_advance
+    phase = phase - 2 * math.pi * torch.round(phase / (2 * math.pi))
+    phase = phase + phase_advance
+    phase = torch.cat([phase_0, phase[tuple(lead + [slice(-1)])]], dim=-1)
+    phase_acc = torch.cumsum(phase, -1)
+    mag = alphas * mag_hi + (1 - alphas) * mag_lo
+    return torch.stack([mag * torch.cos(phase_acc), mag * torch.sin(phase_acc)], dim=-1)
+
+
+def _unary(x, what, launch):
+    x = _dense(_device_f32(x, what))
+    out = torch.empty_like(x)
+    if x.numel():
+        with torch.cuda.device(x.device):
+            rc = launch(_native.lib(), _native.ptr(x), x.numel(), _native.ptr(out), _native.stream_ptr(x.device))
+        _native.check(rc, what)
+    return out
+
+
+def amplitude_to_db(x, ref=1.0, amin=1e-7):
+    """``10·(log10(max(x², amin)) − log10(ref))`` — the reference squares its input
+    (functional.py:277-296)."""
+    return _unary(x, 'amplitude_to_db',
+                  lambda h, p, n, o, s: h.tac_amplitude_to_db_f32(p, n, float(ref), float(amin), o, s))
+
+
+def db_to_amplitude(x, ref=1.0):
+    """``(10^(x/10 + log10 ref))^0.5`` (reference: functional.py:299-314)."""
+    return _unary(x, 'db_to_amplitude',
+                  lambda h, p, n, o, s: h.tac_db_to_amplitude_f32(p, n, float(ref), o, s))
+
+
+_mulaw_consts = {}
+
+
+def _mulaw_tables(device):
+    key = str(device)
+    hit = _mulaw_consts.get(key)
+    if hit is None:
+        from . import _mulaw_tables as tab
+        thr = torch.tensor(list(tab.THR256_POS) + list(tab.THR256_NEG), dtype=torch.int32, device=device)
+        lut = torch.tensor(list(tab.LUT256_BITS), dtype=torch.int64).to(torch.int32).view(torch.float32)
+        hit = (thr, len(tab.THR256_POS), len(tab.THR256_NEG), tab.ZERO_CODE_256, lut.to(device))
+        with _cache_lock:
+            _mulaw_consts[key] = hit
+    return hit
+
+
+def mu_law_encoding(x, n_quantize=256):
+    """mu-law companding to int64 codes (reference: functional.py:317-335).
+
+    For ``n_quantize == 256`` and ``|x| <= 1`` the codes are bit-exact with the reference: the kernel
+    compares against the 255 float32 thresholds extracted from it (``_mulaw_tables.py``).  Other
+    ``n_quantize`` and out-of-range samples use the closed form in fp32 (can differ by one code on
+    ~1e-6 of samples, exactly where the reference's own vectorised log1p is not correctly rounded)."""
+    if torch.is_tensor(x) and not x.dtype.is_floating_point:
+        x = _realize(x).to(torch.float)
+    x = _device_f32(x, 'x')
+    x = x if x.is_contiguous() else x.contiguous()
+    out = torch.empty(x.shape, dtype=torch.int64, device=x.device)
+    if x.numel():
+        n_quantize = int(n_quantize)
+        if n_quantize == 256:
+            thr, n_pos, n_neg, zero, _ = _mulaw_tables(x.device)
+            thr_ptr = _native.ptr(thr)
+        else:
+            thr_ptr, n_pos, n_neg, zero = None, 0, 0, 0
+        with torch.cuda.device(x.device):
+            rc = _native.lib().tac_mulaw_encode_f32_i64(_native.ptr(x), x.numel(), n_quantize, thr_ptr,
+                                                        n_pos, n_neg, zero, _native.ptr(out),
+                                                        _native.stream_ptr(x.device))
+        _native.check(rc, 'tac_mulaw_encode_f32_i64')
+    return out
+
+
+def mu_law_decoding(x_mu, n_quantize=256, dtype=torch.get_default_dtype()):
+    """mu-law expansion (reference: functional.py:338-354).  Integer codes in ``[0, 256)`` with
+    ``n_quantize == 256`` are decoded through the reference's own 256-entry table (bit-exact);
+    everything else evaluates the closed form in fp32."""
+    codes = _realize(x_mu)
+    if not torch.is_tensor(codes):
+        raise TypeError('x_mu must be a torch.Tensor')
+    n_quantize = int(n_quantize)
+    if not codes.dtype.is_floating_point:
+        if dtype != torch.float32:
+            raise NotImplementedError('mu_law_decoding: the gfx950 kernel decodes to float32, got %s' % dtype)
+        if not codes.is_cuda:
+            raise RuntimeError('x_mu is on %s: torchaudio_contrib_amd only runs on a HIP device' % codes.device)
+        codes = codes.to(torch.int64).contiguous()
+        out = torch.empty(codes.shape, dtype=torch.float32, device=codes.device)
+        if codes.numel():
+            lut_ptr = _native.ptr(_mulaw_tables(codes.device)[4]) if n_quantize == 256 else None
+            with torch.cuda.device(codes.device):
+                rc = _native.lib().tac_mulaw_decode_i64_f32(_native.ptr(codes), codes.numel(), n_quantize,
+                                                            lut_ptr, _native.ptr(out),
+                                                            _native.stream_ptr(codes.device))
+            _native.check(rc, 'tac_mulaw_decode_i64_f32')
+        return out
+    return _unary(codes, 'mu_law_decoding',
+                  lambda h, p, n, o, s: h.tac_mulaw_decode_f32_f32(p, n, n_quantize, o, s))
