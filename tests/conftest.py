@@ -27,6 +27,7 @@ def golden():
 
 def rel_err(got, want):
     """max|got-want| / max|want| — the per-tensor relative error SURVEY §7 defines for linear outputs."""
-    got = np.asarray(got, dtype=np.float64)
-    want = np.asarray(want, dtype=np.float64)
+    got, want = np.asarray(got), np.asarray(want)
+    wide = np.complex128 if (np.iscomplexobj(got) or np.iscomplexobj(want)) else np.float64
+    got, want = got.astype(wide), want.astype(wide)
     return float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-300))

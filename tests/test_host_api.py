@@ -1,0 +1,189 @@
+"""not-gpu: host logic — C-ABI surface, geometry, module contracts, error behaviour, sharding."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def tac():
+    import torchaudio_contrib_amd as t
+    if not os.path.exists(t._native.LIB_PATH):
+        t.build_native()
+    return t
+
+
+def test_library_exports_every_declared_symbol(tac):
+    header = open(os.path.join(ROOT, 'include', 'tac_amd.h')).read()
+    declared = sorted(set(re.findall(r'\b(tac_[a-z0-9_]+)\s*\(', header)))
+    assert len(declared) >= 16
+    h = tac._native.lib()
+    for name in declared:
+        assert hasattr(h, name), name
+    assert sorted(tac._native.EXPORTS) == declared
+    assert h.tac_abi_version() == 1
+    assert h.tac_strerror(-3).decode().startswith('input too short')
+
+
+def test_geometry_helpers(tac):
+    h = tac._native.lib()
+    # T = (L + 2*pad - N + hop)//hop, tests/test_functional.py:14-15
+    for L, n, hop in [(100000, 512, 256), (160000, 2048, 512), (16000, 512, 256), (2880000, 4096, 1024)]:
+        assert h.tac_num_frames(L, n, hop, 1) == (L + 2 * (n // 2) - n + hop) // hop
+    assert h.tac_num_frames(160000, 2048, 512, 1) == 313
+    assert h.tac_num_frames(1000, 2048, 512, 0) == 0
+    assert h.tac_num_bins(2048, 1) == 1025 and h.tac_num_bins(2048, 0) == 2048
+    assert ctypes.sizeof(tac._native.StftDesc) == 56
+
+
+def test_no_cpu_fallback(tac):
+    x = torch.zeros(1, 1, 4096)
+    for fn in (lambda: tac.stft(x, 512), lambda: tac.complex_norm(torch.zeros(3, 2)),
+               lambda: tac.amplitude_to_db(x), lambda: tac.mu_law_encoding(x),
+               lambda: tac.mu_law_decoding(torch.zeros(4, dtype=torch.long)),
+               lambda: tac.apply_filterbank(torch.zeros(1, 5, 7), torch.zeros(5, 3)),
+               lambda: tac.Melspectrogram(fft_length=512)(x)):
+        with pytest.raises(RuntimeError, match='HIP device'):
+            fn()
+
+
+def test_layer_contracts(tac):
+    layer = tac.STFT(fft_length=512, hop_length=256)
+    assert torch.is_tensor(layer.window) and not layer.window.requires_grad
+    assert layer.window.size(0) <= layer.fft_length
+    assert torch.equal(layer.window, torch.hann_window(512))
+    assert tac.STFT(512, win_length=400).window.shape == (400,)
+    assert repr(layer) == ('STFT(fft_length=512, hop_length=256, win_length=None)'
+                           '(center=True, pad_mode=reflect, normalized=False, onesided=True)')
+    assert repr(tac.ComplexNorm(2.0)) == 'ComplexNorm(power=2.0)'
+    assert repr(tac.AmplitudeToDb()) == 'AmplitudeToDb(ref=1.0, amin=1e-07)'
+    assert repr(tac.DbToAmplitude(2.0)) == 'DbToAmplitude(ref=2.0)'
+    assert repr(tac.MuLawEncoding()) == 'MuLawEncoding(n_quantize=256)'
+    assert repr(tac.MuLawDecoding(16)) == 'MuLawDecoding(n_quantize=16)'
+    assert repr(tac.TimeStretch(256, 257, 0.7)) == 'TimeStretch(fixed_rate=0.7)'
+    assert repr(tac.MelFilterbank(sample_rate=16000)) == \
+        'MelFilterbank(num_freqs=1025, snum_mels=128, min_freq=0.0, max_freq=8000), htk=False'
+    ts = tac.TimeStretch(hop_length=256, num_freqs=1025)
+    assert torch.is_tensor(ts.phase_advance) and ts.phase_advance.shape == (1025, 1)
+    with pytest.raises(ValueError):
+        ts(torch.zeros(1, 1025, 4, 2))
+
+
+def test_factories_and_state_dict(tac):
+    mel = tac.Melspectrogram(num_mels=128, sample_rate=16000, fft_length=2048, hop_length=512)
+    assert isinstance(mel, torch.nn.Sequential)
+    assert [type(c).__name__ for c in mel] == ['STFT', 'ComplexNorm', 'ApplyFilterbank']
+    assert [n for n, _ in mel.named_buffers()] == ['0.window', '2.filterbank']
+    assert mel[1].power == 2.0 and mel[2].filterbank.shape == (1025, 128)
+    assert list(mel.parameters()) == [] and len(mel.state_dict()) == 0
+    full = torch.nn.Sequential(*mel, tac.AmplitudeToDb())
+    assert len(full) == 4 and len(full.state_dict()) == 0
+    full.load_state_dict({})
+    # num_freqs argument is ignored (layers.py:330-331 of the reference)
+    assert tac.Melspectrogram(num_freqs=7, fft_length=512)[2].filterbank.shape == (257, 128)
+    spec = tac.Spectrogram(512, hop_length=256)
+    assert [type(c).__name__ for c in spec] == ['STFT', 'ComplexNorm'] and spec[1].power == 1.0
+    with pytest.raises(TypeError):
+        tac.Melspectrogram(num_mels=64)                      # missing fft_length
+    with pytest.raises(ValueError):
+        tac.MelFilterbank()                                  # neither max_freq nor sample_rate
+    with pytest.raises(AssertionError):
+        tac.AmplitudeToDb(ref=1e-8, amin=1e-7)
+
+    class Flat(tac.Filterbank):                              # pluggable provider class
+        def __init__(self, num_freqs, num_mels, **kw):
+            self.shape = (num_freqs, num_mels)
+
+        def get_filterbank(self):
+            return torch.ones(self.shape)
+    assert tac.Melspectrogram(num_mels=5, mel_filterbank=Flat, fft_length=64)[2].filterbank.sum() == 33 * 5
+    with pytest.raises(NotImplementedError):
+        tac.Filterbank().get_filterbank()
+
+
+def test_import_surface(tac):
+    for name in ['stft', 'complex_norm', 'create_mel_filter', 'apply_filterbank', 'angle', 'magphase',
+                 'phase_vocoder', 'amplitude_to_db', 'db_to_amplitude', 'mu_law_encoding', 'mu_law_decoding',
+                 'STFT', 'ComplexNorm', 'ApplyFilterbank', 'Filterbank', 'MelFilterbank', 'TimeStretch',
+                 'Spectrogram', 'Melspectrogram', 'AmplitudeToDb', 'DbToAmplitude', 'MuLawEncoding',
+                 'MuLawDecoding']:
+        assert hasattr(tac, name), name
+    import inspect
+    sig = inspect.signature(tac.stft)
+    assert list(sig.parameters) == ['waveforms', 'fft_length', 'hop_length', 'win_length', 'window', 'center',
+                                    'pad_mode', 'normalized', 'onesided']
+    assert sig.parameters['pad_mode'].default == 'reflect' and sig.parameters['onesided'].default is True
+    assert list(inspect.signature(tac.Melspectrogram).parameters)[:7] == [
+        'num_mels', 'sample_rate', 'min_freq', 'max_freq', 'num_freqs', 'htk', 'mel_filterbank']
+    assert inspect.signature(tac.mu_law_decoding).parameters['dtype'].default == torch.get_default_dtype()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'torchaudio-contrib_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.hpp')):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'oracle' not in src.replace('the oracle', '').replace('CPU oracle', ''), f
+                assert '/root/reference' not in src, f
+
+
+def test_shard_bounds(tac):
+    from torchaudio_contrib_amd.distributed import shard_bounds
+    for n, w in [(2048, 8), (10, 3), (3, 8), (256, 1)]:
+        cuts = [shard_bounds(n, w, r) for r in range(w)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+        sizes = [e - b for b, e in cuts]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(4, 2, 2)
+
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import torchaudio_contrib_amd as tac
+from torchaudio_contrib_amd.distributed import shard_batch, all_gather_batch, ShardedPipeline
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=sys.argv[3], RANK=str(rank), WORLD_SIZE=str(world))
+dist.init_process_group('gloo', rank=rank, world_size=world)
+whole = torch.arange(5 * 2 * 3 * 4, dtype=torch.float32).reshape(5, 2, 3, 4)     # uneven: 3 + 2 rows
+local = shard_batch(whole)
+assert local.shape[0] == (3 if rank == 0 else 2)
+# strided (.., M, T) view like the layers return: physical (.., T, M)
+phys = local.transpose(-2, -1).contiguous()
+view = phys.transpose(-2, -1)
+out = all_gather_batch(view, total_rows=5)
+assert out.shape == whole.shape and torch.equal(out, whole), rank
+out2 = all_gather_batch(local.contiguous())                   # row count discovered by all_reduce
+assert torch.equal(out2, whole)
+even = torch.arange(4 * 6, dtype=torch.float32).reshape(4, 6)
+assert torch.equal(all_gather_batch(shard_batch(even).clone(), total_rows=4), even)   # all_gather_into_tensor path
+pipe = ShardedPipeline(torch.nn.Identity(), gather=True)
+assert torch.equal(pipe(whole), whole)
+assert torch.equal(ShardedPipeline(torch.nn.Identity(), gather=False)(whole), local)
+dist.barrier()
+dist.destroy_process_group()
+print('rank', rank, 'ok')
+'''
+
+
+def test_gloo_world2_shard_and_allgather(tmp_path):
+    """N>1 control flow (shard -> local pipeline -> single all-gather) on CPU with gloo, world_size 2."""
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER % ROOT)
+    port = str(29500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), '2', port], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert 'rank %d ok' % r in o

@@ -50,7 +50,7 @@ def main():
 
     def spec():
         x = signals.audio_like((2, 1, 30000), seed=2)
-        got = tac.Spectrogram(2048, 512, power=2.)(torch.from_numpy(x).cuda()).cpu().numpy()
+        got = tac.Spectrogram(2048, 512, power=2.).cuda()(torch.from_numpy(x).cuda()).cpu().numpy()
         want = torch_ref.spectrogram(torch.from_numpy(x), 2048, 512, power=2.0).numpy()
         return 'rel %.3e' % rel(got, want)
     section('spectrogram power=2', spec)

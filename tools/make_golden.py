@@ -188,6 +188,10 @@ def g5(skip_scan):
     x2 = T(signals.uniform((1000000,), seed=8, scale=1.0))
     out['enc256_unit'] = np32(ref.mu_law_encoding(x2, 256)).astype(np.int16)
     out['enc65536_unit'] = np32(ref.mu_law_encoding(x2[:200000], 65536)).astype(np.int32)
+    pos, neg = out['thr256_pos_bits'].astype(np.uint32), out['thr256_neg_bits'].astype(np.uint32)
+    mags = np.concatenate([pos, pos - 1, neg, neg - 1, [0, 0x3f800000]]).astype(np.uint32)
+    edges = np.concatenate([mags.view(np.float32), -(mags.view(np.float32))])
+    out['enc256_edges'] = np32(ref.mu_law_encoding(T(edges), 256)).astype(np.int16)
     out['enc16_unit'] = np32(ref.mu_law_encoding(x2[:200000], 16)).astype(np.int16)
     codes = T((signals.uniform((4096,), seed=9) * 127.5 + 127.5).astype(np.int64).clip(0, 255))
     out['dec256_codes'] = np32(ref.mu_law_decoding(codes, 256))

@@ -31,8 +31,8 @@ def all_gather_batch(local, total_rows=None, group=None):
     """Concatenate every rank's output shard along dim 0 with a single collective.
 
     ``local`` may be one of the strided (…, M, T) views the layers return: the gather is done on the
-    physical frame-major buffers (a dim-0 concat commutes with the trailing transpose), one
-    ``all_gather_into_tensor`` when shards are equal-sized, ``all_gather`` into a list otherwise.
+    physical frame-major buffers (a dim-0 concat commutes with the trailing transpose) with one
+    ``all_gather_into_tensor``; uneven shards are padded to the largest and trimmed afterwards.
     """
     from ._lazy import realize
     local = realize(local)
@@ -48,12 +48,17 @@ def all_gather_batch(local, total_rows=None, group=None):
         total_rows = int(cnt.item())
     sizes = [shard_bounds(total_rows, world, r) for r in range(world)]
     sizes = [e - b for b, e in sizes]
-    out = torch.empty((total_rows,) + tuple(phys.shape[1:]), dtype=phys.dtype, device=phys.device)
     if all(s == sizes[0] for s in sizes) and rows == sizes[0]:
+        out = torch.empty((total_rows,) + tuple(phys.shape[1:]), dtype=phys.dtype, device=phys.device)
         dist.all_gather_into_tensor(out, phys, group=group)
     else:
-        chunks = list(out.split(sizes, dim=0))
-        dist.all_gather(chunks, phys, group=group)
+        # uneven tail: still ONE collective — pad every shard to the largest, gather, drop the padding
+        biggest = max(sizes)
+        padded = phys.new_zeros((biggest,) + tuple(phys.shape[1:]))
+        padded[:rows] = phys
+        buf = torch.empty((world * biggest,) + tuple(phys.shape[1:]), dtype=phys.dtype, device=phys.device)
+        dist.all_gather_into_tensor(buf, padded, group=group)
+        out = torch.cat([buf[r * biggest:r * biggest + n] for r, n in enumerate(sizes)], dim=0)
     return out.transpose(-2, -1) if transposed else out
 
 
