@@ -1,0 +1,36 @@
+#!/usr/bin/env python
+"""Tiny driver for rocprofv3: launch one kernel family a few times at cfg-2 size.
+    python tools/prof_driver.py mel|stft|spec|mulaw [iters]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torchaudio_contrib_amd as tac  # noqa: E402
+
+what = sys.argv[1] if len(sys.argv) > 1 else 'mel'
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+x = torch.rand(256, 1, 160000, device='cuda') * 2 - 1
+if what == 'mel':
+    m = torch.nn.Sequential(*tac.Melspectrogram(num_mels=128, sample_rate=16000, fft_length=2048, hop_length=512),
+                            tac.AmplitudeToDb()).cuda()
+    fn = lambda: tac.realize(m(x))
+elif what == 'stft':
+    layer = tac.STFT(2048, 512).cuda()
+    fn = lambda: tac.realize(layer(x))
+elif what == 'spec':
+    s = tac.Spectrogram(2048, 512, power=2.).cuda()
+    fn = lambda: s(x)
+elif what == 'unfused':
+    tac.set_lazy_fusion(False)
+    m = torch.nn.Sequential(*tac.Melspectrogram(num_mels=128, sample_rate=16000, fft_length=2048, hop_length=512),
+                            tac.AmplitudeToDb()).cuda()
+    fn = lambda: m(x)
+elif what == 'mulaw':
+    xm = torch.rand(1024, 1, 120000, device='cuda') * 2 - 1
+    fn = lambda: tac.mu_law_decoding(tac.mu_law_encoding(xm, 256), 256)
+for _ in range(iters):
+    y = fn()
+torch.cuda.synchronize()
+print(what, tuple(y.shape))

@@ -12,7 +12,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libtac_amd.so')
+LIB_PATH = os.environ.get('TAC_AMD_LIB', os.path.join(_HERE, 'libtac_amd.so'))   # override: A/B builds
 CSRC = os.path.join(_HERE, 'csrc')
 
 TAC_OK = 0

@@ -37,11 +37,22 @@ def _device_f32(x, what):
     return x
 
 
+def _is_dense(x):
+    """True when x's elements tile one gap-free block of memory (in any dim order)."""
+    if x.is_contiguous():
+        return True
+    dims = sorted((st, n) for st, n in zip(x.stride(), x.shape) if n > 1)
+    expect = 1
+    for st, n in dims:
+        if st != expect:
+            return False
+        expect *= n
+    return True
+
+
 def _dense(x):
     """Return x if it is non-overlapping & dense (any dim order), else a contiguous copy."""
-    if x.is_contiguous() or x.is_non_overlapping_and_dense():
-        return x
-    return x.contiguous()
+    return x if _is_dense(x) else x.contiguous()
 
 
 _window_cache = {}
@@ -161,26 +172,24 @@ class _StftPlan(object):
         return out.transpose(-2, -1)
 
 
-_plan_cache = {}
-
-
 def _filterbank_plan(fb):
-    """int32[2*ceil(M/16)] non-zero bin range per 16-band tile, computed on device (no host sync),
-    cached per (storage address, version) so a module's constant filterbank is scanned once."""
-    key = (fb.data_ptr(), fb._version, tuple(fb.shape), str(fb.device))
-    hit = _plan_cache.get(key)
-    if hit is not None:
-        return hit
+    """int32[2*ceil(M/16)] non-zero bin range per 16-band tile, computed on device (no host sync).
+    The plan rides on the filterbank tensor object itself (a module's constant buffer is scanned once)
+    and is recomputed when the tensor is modified in place; keying a cache on ``data_ptr`` would go
+    stale when the allocator reuses an address."""
+    hit = getattr(fb, '_tac_plan', None)
+    if hit is not None and hit[0] == fb._version and hit[1].device == fb.device:
+        return hit[1]
     n_freqs, n_mels = fb.shape
     plan = torch.empty(2 * ((n_mels + 15) // 16), dtype=torch.int32, device=fb.device)
     with torch.cuda.device(fb.device):
         rc = _native.lib().tac_filterbank_plan(_native.ptr(fb), n_freqs, n_mels, _native.ptr(plan),
                                                _native.stream_ptr(fb.device))
     _native.check(rc, 'tac_filterbank_plan')
-    with _cache_lock:
-        if len(_plan_cache) > 64:
-            _plan_cache.clear()
-        _plan_cache[key] = plan
+    try:
+        fb._tac_plan = (fb._version, plan)
+    except Exception:       # exotic tensor subclasses without attribute storage: just recompute next time
+        pass
     return plan
 
 
@@ -203,7 +212,7 @@ def complex_norm(complex_tensor, power=1.0):
     if z.dim() < 1 or z.shape[-1] != 2:
         raise RuntimeError('complex_norm: expected a trailing dimension of size 2, got shape %s'
                            % (tuple(z.shape),))
-    if z.stride(-1) != 1 or not (z.is_contiguous() or z.is_non_overlapping_and_dense()) or \
+    if z.stride(-1) != 1 or not _is_dense(z) or \
             any(s % 2 for s, n in zip(z.stride()[:-1], z.shape[:-1]) if n > 1):
         z = z.contiguous()
     out = torch.empty_strided(z.shape[:-1], tuple(s // 2 for s in z.stride()[:-1]),
