@@ -80,18 +80,26 @@ int tac_spectrogram_f32(const float* wave, const float* window, const tac_stft_d
 
 /* (3) Melspectrogram chain fused in one kernel: stft -> complex_norm(power) ->
  *     apply_filterbank (functional.py:172-184) [-> amplitude_to_db], layers.py:307-381.
- *     fb: float[F][n_mels] row-major dense filterbank exactly as create_mel_filter returns it
- *     (functional.py:131-169); fb_plan: int32[2*ceil(n_mels/16)] from tac_filterbank_plan.
- *     Requires onesided geometry with n_fft <= 2048; returns TAC_E_UNSUPPORTED otherwise
- *     (callers then chain (2) and (4)).   out: float[rows][T][n_mels]. */
-int tac_melspec_f32(const float* wave, const float* window, const tac_stft_desc* d,
-                    float power, const float* fb, const int32_t* fb_plan, int32_t n_mels,
+ *     fb: DEVICE float[F][n_mels] row-major dense filterbank exactly as create_mel_filter returns it
+ *     (functional.py:131-169); fb_plan_host: HOST int32[2*ceil(n_mels/16)] from tac_filterbank_plan
+ *     (passed to the kernel by value).  Requires onesided geometry with n_fft <= 2048 and a filterbank
+ *     sparse enough for the register-resident weights (sum over 16-band tiles of ceil(range/4) <= 384
+ *     at n_fft = 2048) and power in {1, 2}; returns TAC_E_UNSUPPORTED otherwise — callers then chain (2) and (4).
+ *     out: float[rows][T][n_mels]. */
+int tac_melspec_f32(const float* wave, const float* window, const tac_stft_desc* d, float power,
+                    const float* fb, const int32_t* fb_plan_host, int32_t n_mels,
                     int db, float db_ref, float db_amin, float* out, void* stream);
 
-/* Per 16-band tile [first, last+1) non-zero bin range of a dense filterbank
- * (device kernel, no host sync).  plan: int32[2*ceil(n_mels/16)]. */
+/* TAC_OK when (3) can run this geometry + filterbank plan, TAC_E_UNSUPPORTED when it cannot
+ * (no launch, no device access). */
+int tac_melspec_supported(const tac_stft_desc* d, float power, const int32_t* fb_plan_host,
+                          int32_t n_mels);
+
+/* Per 16-band tile [first, last+1) non-zero bin range of a dense filterbank, computed by a device
+ * kernel into plan (DEVICE int32[2*ceil(n_mels/16)]).  When plan_host is non-NULL the stream is
+ * synchronised and the plan is also copied there (one-off per filterbank). */
 int tac_filterbank_plan(const float* fb, int32_t n_freqs, int32_t n_mels, int32_t* plan,
-                        void* stream);
+                        int32_t* plan_host, void* stream);
 
 /* (4) functional.apply_filterbank, functional.py:172-184: out[r][t][m] = sum_f spec[r][f][t]*fb[f][m]
  *     as an fp32 MFMA (v_mfma_f32_16x16x4_f32) tile with zero-block skipping driven by fb_plan

@@ -120,24 +120,36 @@ struct Dft<16> {
 };
 
 // ---------------------------------------------------------------- plan algebra (compile time)
-constexpr int radix_at(int nc, int pass) {
-    int rem = nc;
-    for (int p = 0; p < pass; ++p) rem /= (rem >= 16 ? 16 : rem);
-    return rem >= 16 ? 16 : rem;
-}
-constexpr int stride_at(int nc, int pass) {
-    int s = 1, rem = nc;
-    for (int p = 0; p < pass; ++p) { int r = rem >= 16 ? 16 : rem; s *= r; rem /= r; }
-    return s;
-}
 constexpr int num_passes(int nc) {
     int n = 0, rem = nc;
     while (rem > 1) { rem /= (rem >= 16 ? 16 : rem); ++n; }
     return n;
 }
+// Radix order: 16 first, 16 last, the small leftover radix in the MIDDLE (N=2048: 16·4·16).  All
+// butterflies of the middle pass then share j mod 16, so it needs r-1 twiddle registers per lane instead
+// of (E/r)(r-1); 2048 goes from 54 to 36 hoisted twiddles.
+constexpr int radix_at(int nc, int pass) {
+    int r[4] = {1, 1, 1, 1};
+    int n = 0, rem = nc;
+    while (rem > 1) { int x = rem >= 16 ? 16 : rem; r[n++] = x; rem /= x; }
+    if (n == 3) { int t = r[1]; r[1] = r[2]; r[2] = t; }
+    return r[pass];
+}
+constexpr int stride_at(int nc, int pass) {
+    int s = 1;
+    for (int p = 0; p < pass; ++p) s *= radix_at(nc, p);
+    return s;
+}
+// A pass's butterflies b = 0..E/R-1 use j = t + b*LPF; when LPF is a multiple of the stride S they all see
+// the same j mod S and share one set of R-1 twiddles.
+constexpr bool pass_shares_twiddles(int nc, int e, int pass) { return ((nc / e) % stride_at(nc, pass)) == 0; }
+constexpr int pass_twiddles(int nc, int e, int pass) {
+    int r = radix_at(nc, pass);
+    return (pass_shares_twiddles(nc, e, pass) ? 1 : e / r) * (r - 1);
+}
 constexpr int twiddles_before(int nc, int e, int pass) {   // hoisted-twiddle registers used by passes < pass
     int n = 0;
-    for (int p = 1; p < pass; ++p) { int r = radix_at(nc, p); n += (e / r) * (r - 1); }
+    for (int p = 1; p < pass; ++p) n += pass_twiddles(nc, e, p);
     return n;
 }
 
@@ -162,7 +174,7 @@ struct WaveFft {
     __device__ static __forceinline__ void load_tw_pass(cf* tw, const cf* __restrict__ table, int t) {
         if constexpr (P < NPASS) {
             constexpr int R = radix_at(NC, P), S = stride_at(NC, P), OFF = twiddles_before(NC, E, P);
-            constexpr int NB = E / R;
+            constexpr int NB = pass_shares_twiddles(NC, E, P) ? 1 : E / R;
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 int j = t + b * LPF;
@@ -174,49 +186,63 @@ struct WaveFft {
         }
     }
 
-    // v: E registers in first-pass order v[b*R0 + q] = z[(t + b*LPF) + q*NC/R0].
-    // On return the frame's spectrum Z[0..NC) sits in natural order at lds[lds_pad(i)].
-    __device__ static __forceinline__ void run(cf* v, cf* lds, const cf* tw, int t) {
-        pass<0>(v, lds, tw, t);
+    // v[f]: E registers per frame in first-pass order v[f][b*R0 + q] = z_f[(t + b*LPF) + q*NC/R0].
+    // NF independent frames are advanced pass by pass together so that one frame's LDS round trip
+    // hides behind the other's butterflies (ILP instead of occupancy: the kernels run 2 waves/SIMD).
+    // On return frame f's spectrum Z[0..NC) sits in natural order at lds[f][lds_pad(i)].
+    template <int NF>
+    __device__ static __forceinline__ void run(cf (&v)[NF][E_], cf* const (&lds)[NF], const cf* tw, int t) {
+        pass<0, NF>(v, lds, tw, t);
         wave_lds_fence();
     }
 
-    template <int P>
-    __device__ static __forceinline__ void pass(cf* v, cf* lds, const cf* tw, int t) {
+    template <int P, int NF>
+    __device__ static __forceinline__ void pass(cf (&v)[NF][E_], cf* const (&lds)[NF], const cf* tw, int t) {
         constexpr int R = radix_at(NC, P), S = stride_at(NC, P), OFF = twiddles_before(NC, E, P);
         constexpr int NB = E / R;
         static_assert(NB >= 1, "radix larger than elements per lane");
         if constexpr (P > 0) {
             wave_lds_fence();
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                int j = t + b * LPF;
+            for (int f = 0; f < NF; ++f)
 #pragma unroll
-                for (int q = 0; q < R; ++q) v[b * R + q] = lds[lds_pad(j + q * (NC / R))];
-            }
+                for (int b = 0; b < NB; ++b) {
+                    const int j = t + b * LPF;
 #pragma unroll
-            for (int b = 0; b < NB; ++b)
+                    for (int q = 0; q < R; ++q) v[f][b * R + q] = lds[f][lds_pad(j + q * (NC / R))];
+                }
 #pragma unroll
-                for (int q = 1; q < R; ++q) v[b * R + q] = cmul(v[b * R + q], tw[OFF + b * (R - 1) + q - 1]);
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int q = 1; q < R; ++q)
+                        v[f][b * R + q] = cmul(v[f][b * R + q],
+                                               tw[OFF + (pass_shares_twiddles(NC, E, P) ? 0 : b) * (R - 1) + q - 1]);
         }
 #pragma unroll
-        for (int b = 0; b < NB; ++b) Dft<R>::run(v + b * R);
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) Dft<R>::run(&v[f][b * R]);
         wave_lds_fence();   // every lane's reads of this pass precede any lane's writes (same wave, in order)
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            int j = t + b * LPF;
-            int base = (j / S) * (S * R) + (j & (S - 1));
+        for (int f = 0; f < NF; ++f)
 #pragma unroll
-            for (int k = 0; k < R; ++k) lds[lds_pad(base + k * S)] = v[b * R + k];
-        }
-        if constexpr (P + 1 < NPASS) pass<P + 1>(v, lds, tw, t);
+            for (int b = 0; b < NB; ++b) {
+                const int j = t + b * LPF;
+                const int base = (j / S) * (S * R) + (j & (S - 1));
+#pragma unroll
+                for (int k = 0; k < R; ++k) lds[f][lds_pad(base + k * S)] = v[f][b * R + k];
+            }
+        if constexpr (P + 1 < NPASS) pass<P + 1, NF>(v, lds, tw, t);
     }
 
     // R2C split of pair index k (0 <= k <= NC/2): returns X[k] in xa and X[NC-k] in xb.
     // wk = exp(-2*pi*i*k/N).
     __device__ static __forceinline__ void r2c_pair(const cf* lds, int k, cf wk, cf& xa, cf& xb) {
-        cf zk = lds[lds_pad(k)];
-        cf zm = lds[lds_pad((NC - k) & (NC - 1))];
+        r2c_split(lds[lds_pad(k)], lds[lds_pad((NC - k) & (NC - 1))], wk, xa, xb);
+    }
+    __device__ static __forceinline__ void r2c_split(cf zk, cf zm, cf wk, cf& xa, cf& xb) {
         cf ev = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
         cf od = make_float2(0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
         cf tw = cmul(wk, od);
@@ -228,15 +254,6 @@ struct WaveFft {
 
 // ---------------------------------------------------------------- framing
 enum { PAD_CONSTANT = 0, PAD_REFLECT = 1, PAD_REPLICATE = 2, PAD_CIRCULAR = 3 };
-
-__device__ __forceinline__ float fetch_padded(const float* __restrict__ row, long long i, long long L, int mode) {
-    if (i >= 0 && i < L) return row[i];
-    if (mode == PAD_CONSTANT) return 0.0f;
-    if (mode == PAD_REFLECT) i = i < 0 ? -i : 2 * (L - 1) - i;
-    else if (mode == PAD_REPLICATE) i = i < 0 ? 0 : L - 1;
-    else i = i < 0 ? i + L : i - L;
-    return row[i];
-}
 
 struct FrameGeom {
     const float* wave;      // device, rows x row_stride
@@ -254,49 +271,88 @@ struct FrameGeom {
     float scale;            // 1 or N^-0.5
 };
 
-// zero-padded, centred window value pair for complex element m (samples 2m, 2m+1)
+// zero-padded, centred window value pair for complex element m (samples 2m, 2m+1).  Branch-free:
+// clamped unconditional loads + selects, so the 2E loads of a lane issue back to back.
 __device__ __forceinline__ float2 window_pair(const FrameGeom& g, int m) {
-    int n0 = 2 * m - g.win_offset, n1 = n0 + 1;
-    float w0 = (n0 >= 0 && n0 < g.win_length) ? g.window[n0] : 0.0f;
-    float w1 = (n1 >= 0 && n1 < g.win_length) ? g.window[n1] : 0.0f;
-    return make_float2(w0, w1);
+    const int n0 = 2 * m - g.win_offset, n1 = n0 + 1;
+    const int last = g.win_length - 1;
+    const int c0 = n0 < 0 ? 0 : (n0 > last ? last : n0);
+    const int c1 = n1 < 0 ? 0 : (n1 > last ? last : n1);
+    const float w0 = g.window[c0], w1 = g.window[c1];
+    return make_float2(c0 == n0 ? w0 : 0.0f, c1 == n1 ? w1 : 0.0f);
+}
+
+// Source index of padded position i (torch.nn.functional.pad semantics), branch-free; *zero is set when
+// the sample is a constant-pad zero.  L < 2^31 (host-checked).
+__device__ __forceinline__ int padded_index(int i, int L, int mode, bool* zero) {
+    const int refl = i < 0 ? -i : (i >= L ? 2 * (L - 1) - i : i);
+    const int clmp = i < 0 ? 0 : (i >= L ? L - 1 : i);
+    const int circ = i < 0 ? i + L : (i >= L ? i - L : i);
+    int j = mode == PAD_REFLECT ? refl : (mode == PAD_CIRCULAR ? circ : clmp);
+    j = j < 0 ? 0 : (j >= L ? L - 1 : j);                 // never read out of bounds, whatever the geometry
+    *zero = (mode == PAD_CONSTANT) && (i != clmp);
+    return j;
 }
 
 // Load + window one frame into first-pass register order.  `frame` may be >= T (then zeros).
+// Control flow is kept at WHOLE-FRAME granularity on purpose (three straight-line bodies): per-element
+// conditions make hipcc split the unrolled loads into one basic block each, which serialises their
+// latencies.  Interior frames: 16 float2 loads from a wave-uniform base.  Frames touching the padding:
+// gathered through padded_index() four elements at a time in a rolled loop via the frame's LDS buffer.
 template <class F, bool HOIST_WIN>
-__device__ __forceinline__ void load_frame(cf* v, const FrameGeom& g, const float2* win, long long row,
+__device__ __forceinline__ void load_frame(cf* v, const FrameGeom& g, const float2* win, cf* lds, long long row,
                                            long long frame, int t) {
     constexpr int R0 = radix_at(F::NC, 0);
     constexpr int NB = F::E / R0;
-    const bool active = frame < g.n_frames;
     const float* rp = g.wave + row * g.row_stride;
     const long long start = frame * (long long)g.hop - g.center_pad;
-    const bool interior = active && start >= 0 && start + F::N <= g.length;
-    if (interior && g.vec2_ok) {
-        const float2* src = reinterpret_cast<const float2*>(rp + start);
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-            for (int q = 0; q < R0; ++q) {
-                int m = t + b * F::LPF + q * (F::NC / R0);
-                float2 s = src[m];
-                float2 w = HOIST_WIN ? win[b * R0 + q] : window_pair(g, m);
-                v[b * R0 + q] = make_float2(s.x * w.x, s.y * w.y);
-            }
-    } else if (active) {
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-            for (int q = 0; q < R0; ++q) {
-                int m = t + b * F::LPF + q * (F::NC / R0);
-                float s0 = fetch_padded(rp, start + 2 * m, g.length, g.pad_mode);
-                float s1 = fetch_padded(rp, start + 2 * m + 1, g.length, g.pad_mode);
-                float2 w = HOIST_WIN ? win[b * R0 + q] : window_pair(g, m);
-                v[b * R0 + q] = make_float2(s0 * w.x, s1 * w.y);
-            }
-    } else {
+    if (frame >= g.n_frames) {
 #pragma unroll
         for (int e = 0; e < F::E; ++e) v[e] = make_float2(0.0f, 0.0f);
+    } else if (g.vec2_ok && start >= 0 && start + F::N <= g.length) {
+        const float2* src = reinterpret_cast<const float2*>(rp + start);
+        float2 s[F::E];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int q = 0; q < R0; ++q) s[b * R0 + q] = src[t + b * F::LPF + q * (F::NC / R0)];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int q = 0; q < R0; ++q) {
+                const float2 w = HOIST_WIN ? win[b * R0 + q] : window_pair(g, t + b * F::LPF + q * (F::NC / R0));
+                v[b * R0 + q] = make_float2(s[b * R0 + q].x * w.x, s[b * R0 + q].y * w.y);
+            }
+    } else {
+        const int L = (int)g.length;
+        const int s0 = (int)start;
+#pragma unroll 1
+        for (int e0 = 0; e0 < F::E; e0 += 4) {
+            int j[8];
+            bool z[8];
+            int mm[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u;
+                mm[u] = t + (e / R0) * F::LPF + (e % R0) * (F::NC / R0);
+                j[2 * u] = padded_index(s0 + 2 * mm[u], L, g.pad_mode, &z[2 * u]);
+                j[2 * u + 1] = padded_index(s0 + 2 * mm[u] + 1, L, g.pad_mode, &z[2 * u + 1]);
+            }
+            float a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = rp[j[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float2 w = window_pair(g, mm[u]);
+                lds[lds_pad(mm[u])] = make_float2(z[2 * u] ? 0.0f : a[2 * u] * w.x, z[2 * u + 1] ? 0.0f : a[2 * u + 1] * w.y);
+            }
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int q = 0; q < R0; ++q) v[b * R0 + q] = lds[lds_pad(t + b * F::LPF + q * (F::NC / R0))];
+        wave_lds_fence();
     }
 }
 

@@ -8,6 +8,10 @@
 // waveform — no padded copy, no framed copy, no separate window multiply.
 #include "host_common.hpp"
 
+#ifndef TAC_ABL
+#define TAC_ABL 0      // ablation builds only (tools): 1 = no global loads, 2 = no stores, 3 = no FFT passes
+#endif
+
 namespace tac {
 
 constexpr int STFT_WAVES = 4;
@@ -22,99 +26,183 @@ struct StftEpilogue {
     float log10_ref;
 };
 
-template <int NC, int MODE>
-__device__ __forceinline__ void emit_bin(const StftEpilogue& ep, float* obase, int bin, cf x, float scale) {
-    constexpr int N = 2 * NC;
-    x.x *= scale;
-    x.y *= scale;
-    if constexpr (MODE == 0) {
-        reinterpret_cast<float2*>(obase)[bin] = x;
-        if (!ep.onesided && bin > 0 && bin < NC) reinterpret_cast<float2*>(obase)[N - bin] = make_float2(x.x, -x.y);
-    } else {
-        float v = cpow_mag(x, ep.power);
-        if (ep.db) v = amp_to_db(v, ep.amin, ep.log10_ref);
+// |X|^p (+ dB) for the general case, kept out of the unrolled per-bin code: the squared magnitudes are
+// parked in the frame's own LDS buffer and transformed by this ROLLED loop (one copy of powf/log10f in
+// the kernel instead of 34 per frame), which also turns the stores into full coalesced rows.
+template <int NC, int LPF>
+__device__ __noinline__ void finish_power_row(const float* prow, float* obase, int t, int nbins, float power,
+                                              int db, float amin, float log10_ref) {
+#pragma unroll 1
+    for (int bin = t; bin < nbins; bin += LPF) {
+        float s = prow[bin <= NC ? bin : 2 * NC - bin];
+        float v = (power == 2.0f) ? s : ((power == 1.0f) ? sqrtf(s) : powf(sqrtf(s), power));
+        if (db) v = amp_to_db(v, amin, log10_ref);
         obase[bin] = v;
-        if (!ep.onesided && bin > 0 && bin < NC) obase[N - bin] = v;
     }
 }
 
-// Loop-invariant per-lane constants: HOIST_* keeps them in registers for the whole kernel;
-// otherwise the lane index is laundered through an empty asm each frame so the compiler cannot
-// hoist the (L1-resident) table loads out of the frame loop and blow the register budget.
-template <int NC, int E, int MODE, bool HOIST_TW, bool HOIST_WIN, bool HOIST_PTW>
-__global__ void __launch_bounds__(STFT_WAVES * 64)
+// NF frames per wave are advanced together (see WaveFft::run): with everything loop-invariant —
+// inter-pass twiddles, window, R2C twiddles — held in registers the kernel sits at 2 waves/SIMD and gets
+// its latency hiding from the second in-flight frame instead of from occupancy.
+template <int NC, int E, int MODE, int NF, bool HOIST>
+__global__ void __launch_bounds__(STFT_WAVES * 64, 2)
 stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
     using F = WaveFft<NC, E>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf* smem = reinterpret_cast<cf*>(smem_raw);
 
     const int lane = threadIdx.x & 63;
-    const int w = threadIdx.x >> 6;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sub = lane / F::LPF;
     const int t = lane % F::LPF;
-    cf* lds = smem + (w * F::G + sub) * F::PADDED;
+    cf* lds[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) lds[f] = smem + ((w * NF + f) * F::G + sub) * F::PADDED;
 
     cf tw[F::NTW];
-    float2 win[HOIST_WIN ? F::E : 1];
-    cf ptw[HOIST_PTW ? F::NPAIR : 1];
-    if constexpr (HOIST_TW) F::load_twiddles(tw, tb.w_nc, t);
-    if constexpr (HOIST_WIN) load_window_regs<F>(win, g, t);
-    if constexpr (HOIST_PTW) {
+    cf ptw[HOIST ? F::NPAIR : 1];
+    if constexpr (HOIST) {
+        F::load_twiddles(tw, tb.w_nc, t);
 #pragma unroll
         for (int i = 0; i < F::NPAIR; ++i) ptw[i] = tb.w_n[t + i * F::LPF];
     }
 
-    const long long groups_per_row = (g.n_frames + F::G - 1) / F::G;
-    const long long total = g.rows * groups_per_row;
-    const long long chunk = (total + gridDim.x - 1) / gridDim.x;
-    const long long begin = (long long)blockIdx.x * chunk;
-    const long long end = begin + chunk < total ? begin + chunk : total;
+    const int groups_per_row = (int)((g.n_frames + F::G - 1) / F::G);
+    const int total = (int)g.rows * groups_per_row;
+    const int chunk = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int begin = (int)blockIdx.x * chunk;
+    const int end = begin + chunk < total ? begin + chunk : total;
     const int nbins = ep.onesided ? NC + 1 : 2 * NC;
     const long long per_frame = (long long)nbins * (MODE == 0 ? 2 : 1);
 
-    for (long long grp = begin + w; grp < end; grp += STFT_WAVES) {
-        const long long row = grp / groups_per_row;
-        const long long frame = (grp - row * groups_per_row) * F::G + sub;
-        cf v[F::E];
+    for (int base = begin + w * NF; base < end; base += STFT_WAVES * NF) {
+        cf v[NF][E];
+        long long row[NF], frame[NF];
         int tl = t;
-        if constexpr (!(HOIST_TW && HOIST_WIN && HOIST_PTW)) asm volatile("" : "+v"(tl));
-        if constexpr (!HOIST_TW) F::load_twiddles(tw, tb.w_nc, tl);
-        load_frame<F, HOIST_WIN>(v, g, win, row, frame, HOIST_WIN ? t : tl);
-        F::run(v, lds, tw, t);
-        if (frame < g.n_frames) {
-            float* obase = ep.out + (row * g.n_frames + frame) * per_frame;
+        asm volatile("" : "+v"(tl));          // launder: keeps the per-iteration table loads inside the loop
+        if constexpr (!HOIST) F::load_twiddles(tw, tb.w_nc, tl);
+        float2 win[F::E];                     // window: L1-resident, shared by the NF frames of this iteration
+        load_window_regs<F>(win, g, tl);
 #pragma unroll
-            for (int i = 0; i < F::NPAIR; ++i) {
-                const int k = t + i * F::LPF;
-                cf xa, xb;
-                F::r2c_pair(lds, k, HOIST_PTW ? ptw[i] : tb.w_n[tl + i * F::LPF], xa, xb);
-                emit_bin<NC, MODE>(ep, obase, k, xa, g.scale);
-                emit_bin<NC, MODE>(ep, obase, NC - k, xb, g.scale);
-            }
-            if (t == 0) {
-                cf xa, xb;
-                F::r2c_pair(lds, NC / 2, make_float2(0.0f, -1.0f), xa, xb);
-                emit_bin<NC, MODE>(ep, obase, NC / 2, xa, g.scale);
+        for (int f = 0; f < NF; ++f) {
+            const int grp = base + f;
+            const int r = grp / groups_per_row;
+            row[f] = r;
+            frame[f] = (grp < end) ? (long long)(grp - r * groups_per_row) * F::G + sub : g.n_frames;
+#if TAC_ABL == 1
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[f][e] = make_float2((float)(t + e) * win[e].x, (float)(base + e) * win[e].y);
+#else
+            load_frame<F, true>(v[f], g, win, lds[f], row[f], frame[f], t);
+#endif
+        }
+#if TAC_ABL == 3
+        wave_lds_fence();
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int e = 0; e < E; ++e) lds[f][lds_pad(t + e * F::LPF)] = v[f][e];
+        wave_lds_fence();
+#else
+        F::template run<NF>(v, lds, tw, t);
+#endif
+        const bool simple = (MODE == 0) ? (ep.onesided != 0) : (ep.onesided && ep.power == 2.0f && !ep.db);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+#if TAC_ABL == 2
+            const bool live = frame[f] < g.n_frames && g.scale == 12345.0f;   // never true: stores skipped, math kept
+#else
+            const bool live = frame[f] < g.n_frames;
+#endif
+            float* obase = ep.out + (row[f] * g.n_frames + (live ? frame[f] : 0)) * per_frame;
+            float2* o2 = reinterpret_cast<float2*>(obase);
+            float* prow = reinterpret_cast<float*>(lds[f]);
+            if (simple) {
+                // common case: X (complex) or |X|^2 goes straight from registers to coalesced stores
+                if (live) {
+#pragma unroll
+                    for (int i = 0; i < F::NPAIR; ++i) {
+                        const int k = t + i * F::LPF;
+                        cf xa, xb;
+                        F::r2c_pair(lds[f], k, HOIST ? ptw[i] : tb.w_n[tl + i * F::LPF], xa, xb);
+                        xa.x *= g.scale; xa.y *= g.scale; xb.x *= g.scale; xb.y *= g.scale;
+                        if constexpr (MODE == 0) {
+                            o2[k] = xa;
+                            o2[NC - k] = xb;
+                        } else {
+                            obase[k] = xa.x * xa.x + xa.y * xa.y;
+                            obase[NC - k] = xb.x * xb.x + xb.y * xb.y;
+                        }
+                    }
+                    if (t == 0) {
+                        cf xm, unused;
+                        F::r2c_pair(lds[f], NC / 2, make_float2(0.0f, -1.0f), xm, unused);
+                        xm.x *= g.scale; xm.y *= g.scale;
+                        if constexpr (MODE == 0) o2[NC / 2] = xm;
+                        else obase[NC / 2] = xm.x * xm.x + xm.y * xm.y;
+                    }
+                }
+            } else {
+                // two-sided output, |X|^p with p != 2, or a dB epilogue: gather first, then finish in rolled loops
+                cf xa[F::NPAIR], xb[F::NPAIR], xm, unused;
+#pragma unroll
+                for (int i = 0; i < F::NPAIR; ++i) {
+                    F::r2c_pair(lds[f], t + i * F::LPF, HOIST ? ptw[i] : tb.w_n[tl + i * F::LPF], xa[i], xb[i]);
+                    xa[i].x *= g.scale; xa[i].y *= g.scale; xb[i].x *= g.scale; xb[i].y *= g.scale;
+                }
+                F::r2c_pair(lds[f], NC / 2, make_float2(0.0f, -1.0f), xm, unused);
+                xm.x *= g.scale; xm.y *= g.scale;
+                if constexpr (MODE == 0) {
+                    if (live) {
+#pragma unroll
+                        for (int i = 0; i < F::NPAIR; ++i) {
+                            const int k = t + i * F::LPF;
+                            o2[k] = xa[i];
+                            o2[NC - k] = xb[i];
+                            if (k > 0) {            // mirror bins N-k = conj(X[k]), 0 < k < NC
+                                o2[2 * NC - k] = make_float2(xa[i].x, -xa[i].y);
+                                o2[NC + k] = make_float2(xb[i].x, -xb[i].y);
+                            }
+                        }
+                        if (t == 0) {
+                            o2[NC / 2] = xm;
+                            o2[NC + NC / 2] = make_float2(xm.x, -xm.y);
+                        }
+                    }
+                } else {
+                    wave_lds_fence();       // all Z reads of this frame are done: reuse its buffer as the |X|^2 row
+#pragma unroll
+                    for (int i = 0; i < F::NPAIR; ++i) {
+                        const int k = t + i * F::LPF;
+                        prow[k] = xa[i].x * xa[i].x + xa[i].y * xa[i].y;
+                        prow[NC - k] = xb[i].x * xb[i].x + xb[i].y * xb[i].y;
+                    }
+                    if (t == 0) prow[NC / 2] = xm.x * xm.x + xm.y * xm.y;
+                    wave_lds_fence();
+                    if (live) finish_power_row<NC, F::LPF>(prow, obase, t, nbins, ep.power, ep.db, ep.amin, ep.log10_ref);
+                }
             }
         }
-        wave_lds_fence();   // next frame's first-pass writes must follow these reads
+        wave_lds_fence();   // next iteration's first-pass writes must follow these reads
     }
 }
 
 template <int NC, int E, int MODE>
 static int launch_stft(const FrameGeom& g, const Tables& tb, const StftEpilogue& ep, hipStream_t stream) {
     using F = WaveFft<NC, E>;
+    constexpr int NF = (E <= 16) ? 2 : 1;
+    constexpr bool HOIST = (E <= 16);
     const long long groups = g.rows * ((g.n_frames + F::G - 1) / F::G);
-    const size_t lds_bytes = (size_t)STFT_WAVES * F::G * F::PADDED * sizeof(cf);
+    if (groups >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
+    const size_t lds_bytes = (size_t)STFT_WAVES * NF * F::G * F::PADDED * sizeof(cf);
     int per_cu = (int)(160 * 1024 / lds_bytes);
-    if (per_cu > 8) per_cu = 8;
+    if (per_cu > 2) per_cu = 2;        // 256-register waves: two 4-wave workgroups fill a CU
     if (per_cu < 1) per_cu = 1;
     long long max_blocks = (long long)device_cu_count() * per_cu;
-    long long want = (groups + STFT_WAVES - 1) / STFT_WAVES;
+    long long want = (groups + STFT_WAVES * NF - 1) / (STFT_WAVES * NF);
     long long blocks = want < max_blocks ? want : max_blocks;
     if (blocks < 1) blocks = 1;
-    constexpr bool H = (E <= 16);
-    auto kern = stft_kernel<NC, E, MODE, H, false, false>;
+    auto kern = stft_kernel<NC, E, MODE, NF, HOIST>;
     static bool attr_set = false;
     if (!attr_set && lds_bytes > 64 * 1024) {
         TAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

@@ -7,6 +7,7 @@ as torch.stft does for half input in the reference).  Outputs are fresh tensors;
 results are returned as the same strided views the reference produces (physically frame-major,
 logically ``(*, channel, freq, time[, 2])``).
 """
+import ctypes
 import math
 import threading
 
@@ -151,46 +152,56 @@ class _StftPlan(object):
         _native.check(rc, 'tac_spectrogram_f32')
         return out.transpose(-2, -1)
 
-    def can_fuse_mel(self, filterbank):
-        return (self.onesided and self.n_fft <= 2048 and filterbank.dim() == 2 and
+    def can_fuse_mel(self, filterbank, power=2.0):
+        """True when the single fused kernel covers this geometry and filterbank (sparse enough for the
+        register-resident weights); otherwise the caller chains spectrogram + apply_filterbank kernels."""
+        if not (self.onesided and self.n_fft <= 2048 and filterbank.dim() == 2 and
                 filterbank.shape[0] == self.n_bins and 0 < filterbank.shape[1] <= 512 and
                 filterbank.is_cuda and filterbank.dtype == torch.float32 and
-                filterbank.device == self.wave.device)
+                filterbank.device == self.wave.device and filterbank.is_contiguous()):
+            return False
+        _, host = _filterbank_plan(filterbank)
+        rc = _native.lib().tac_melspec_supported(self.desc, float(power), ctypes.cast(host, ctypes.c_void_p),
+                                                 filterbank.shape[1])
+        return rc == _native.TAC_OK
 
     def run_melspec(self, power, filterbank, db=None):
-        fb = filterbank if filterbank.is_contiguous() else filterbank.contiguous()
-        plan = _filterbank_plan(fb)
+        fb = filterbank
+        _, plan_host = _filterbank_plan(fb)
         n_mels = fb.shape[1]
         out = torch.empty(self.lead + (self.n_frames, n_mels), dtype=torch.float32, device=self.wave.device)
         ref, amin = db if db is not None else (1.0, 1e-7)
         with torch.cuda.device(self.wave.device):
             rc = _native.lib().tac_melspec_f32(
                 _native.ptr(self.wave), _native.ptr(self.window), self.desc, float(power), _native.ptr(fb),
-                _native.ptr(plan), n_mels, 1 if db is not None else 0, float(ref), float(amin),
+                ctypes.cast(plan_host, ctypes.c_void_p), n_mels, 1 if db is not None else 0, float(ref), float(amin),
                 _native.ptr(out), _native.stream_ptr(self.wave.device))
         _native.check(rc, 'tac_melspec_f32')
         return out.transpose(-2, -1)
 
 
 def _filterbank_plan(fb):
-    """int32[2*ceil(M/16)] non-zero bin range per 16-band tile, computed on device (no host sync).
-    The plan rides on the filterbank tensor object itself (a module's constant buffer is scanned once)
-    and is recomputed when the tensor is modified in place; keying a cache on ``data_ptr`` would go
-    stale when the allocator reuses an address."""
+    """(device int32 plan, host ctypes copy): non-zero bin range per 16-band tile, computed by a device
+    kernel.  The plan rides on the filterbank tensor object itself (a module's constant buffer is scanned
+    once — the only host sync on the path — and rescanned when modified in place); keying a cache on
+    ``data_ptr`` would go stale when the allocator reuses an address."""
     hit = getattr(fb, '_tac_plan', None)
     if hit is not None and hit[0] == fb._version and hit[1].device == fb.device:
-        return hit[1]
+        return hit[1], hit[2]
     n_freqs, n_mels = fb.shape
-    plan = torch.empty(2 * ((n_mels + 15) // 16), dtype=torch.int32, device=fb.device)
+    n_ints = 2 * ((n_mels + 15) // 16)
+    plan = torch.empty(n_ints, dtype=torch.int32, device=fb.device)
+    host = (ctypes.c_int32 * n_ints)()
     with torch.cuda.device(fb.device):
         rc = _native.lib().tac_filterbank_plan(_native.ptr(fb), n_freqs, n_mels, _native.ptr(plan),
+                                               ctypes.cast(host, ctypes.c_void_p),
                                                _native.stream_ptr(fb.device))
     _native.check(rc, 'tac_filterbank_plan')
     try:
-        fb._tac_plan = (fb._version, plan)
+        fb._tac_plan = (fb._version, plan, host)
     except Exception:       # exotic tensor subclasses without attribute storage: just recompute next time
         pass
-    return plan
+    return plan, host
 
 
 # ----------------------------------------------------------------------------- public API
@@ -279,7 +290,7 @@ def apply_filterbank(mag_specgrams, filterbank):
     out = torch.empty(lead + (n_frames, n_mels), dtype=torch.float32, device=spec.device)
     if out.numel():
         rows = spec.reshape(-1, n_freqs, n_frames)
-        plan = _filterbank_plan(fb)
+        plan, _ = _filterbank_plan(fb)
         with torch.cuda.device(spec.device):
             rc = _native.lib().tac_apply_filterbank_f32(
                 _native.ptr(rows), rows.shape[0], n_freqs, n_frames, rows.stride(0), rows.stride(1),

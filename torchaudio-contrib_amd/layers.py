@@ -105,7 +105,7 @@ class ApplyFilterbank(_ModuleNoStateBuffers):
     def forward(self, mag_specgrams):
         x = mag_specgrams
         if isinstance(x, DeferredSpectral) and x.pending() and x._stage == 'spec' and x._db is None \
-                and x._plan.can_fuse_mel(self.filterbank):
+                and x._plan.can_fuse_mel(self.filterbank, x._power):
             return x.with_filterbank(self.filterbank)
         return F.apply_filterbank(x, self.filterbank)
 
