@@ -36,6 +36,8 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 __device__ __forceinline__ int lds_pad(int o) { return o + (o >> 4); }
+// padded offset of a compile-time multiple of 16: pad(a + c) == pad(a) + lds_pad_c(c)
+__device__ __forceinline__ constexpr int lds_pad_c(int c) { return c + c / 16; }
 
 // ---------------------------------------------------------------- in-register DFTs (forward, natural order)
 __device__ __forceinline__ void dft2(cf& a, cf& b) {
@@ -207,9 +209,12 @@ struct WaveFft {
             for (int f = 0; f < NF; ++f)
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
-                    const int j = t + b * LPF;
+                    // NC/R is a multiple of 16 for every pass after the first, so pad(j + c) = pad(j) + pad(c):
+                    // one address register per butterfly, the rest are DS immediate offsets.
+                    static_assert((NC / R) % 16 == 0, "read stride must keep the padding affine");
+                    const cf* src = lds[f] + lds_pad(t + b * LPF);
 #pragma unroll
-                    for (int q = 0; q < R; ++q) v[f][b * R + q] = lds[f][lds_pad(j + q * (NC / R))];
+                    for (int q = 0; q < R; ++q) v[f][b * R + q] = src[lds_pad_c(q * (NC / R))];
                 }
 #pragma unroll
             for (int f = 0; f < NF; ++f)
@@ -230,9 +235,17 @@ struct WaveFft {
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const int j = t + b * LPF;
-                const int base = (j / S) * (S * R) + (j & (S - 1));
+                if constexpr (S == 1) {
+                    static_assert(R == 16, "first pass is radix 16");
+                    cf* dst = lds[f] + 17 * j;                          // pad(16 j + k) = 17 j + k, k < 16
 #pragma unroll
-                for (int k = 0; k < R; ++k) lds[f][lds_pad(base + k * S)] = v[f][b * R + k];
+                    for (int k = 0; k < R; ++k) dst[k] = v[f][b * R + k];
+                } else {
+                    static_assert(S % 16 == 0, "write stride must keep the padding affine");
+                    cf* dst = lds[f] + lds_pad((j / S) * (S * R) + (j & (S - 1)));
+#pragma unroll
+                    for (int k = 0; k < R; ++k) dst[lds_pad_c(k * S)] = v[f][b * R + k];
+                }
             }
         if constexpr (P + 1 < NPASS) pass<P + 1, NF>(v, lds, tw, t);
     }
@@ -360,10 +373,18 @@ template <class F>
 __device__ __forceinline__ void load_window_regs(float2* win, const FrameGeom& g, int t) {
     constexpr int R0 = radix_at(F::NC, 0);
     constexpr int NB = F::E / R0;
+    if (g.win_length == F::N) {          // full-length window (the default): plain float2 loads, no index math
+        const float2* w2 = reinterpret_cast<const float2*>(g.window);
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int q = 0; q < R0; ++q) win[b * R0 + q] = window_pair(g, t + b * F::LPF + q * (F::NC / R0));
+            for (int q = 0; q < R0; ++q) win[b * R0 + q] = w2[t + b * F::LPF + q * (F::NC / R0)];
+    } else {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int q = 0; q < R0; ++q) win[b * R0 + q] = window_pair(g, t + b * F::LPF + q * (F::NC / R0));
+    }
 }
 
 // |X|^power of an (already scaled) spectrum value

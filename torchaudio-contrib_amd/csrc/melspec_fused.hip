@@ -15,8 +15,8 @@
 //            tile's K loop covers just that range.  All K-steps of all tiles are cut into equal
 //            contiguous shares, one per wave, so the wide high-frequency tiles do not serialise on one
 //            SIMD.  A wave's share never changes, so its B fragments (the filter weights) are loaded
-//            ONCE into registers at kernel start: steady-state phase B is one ds_read + one MFMA per
-//            step, no global traffic.  Shares write partial 16x16 tiles to LDS slots in a fixed order
+//            per tile in one burst issued before the phase-A barrier (L2-resident, latency hidden behind
+//            the barrier wait); all P-row LDS reads of the share are issued together, then the MFMA chain runs.  Shares write partial 16x16 tiles to LDS slots in a fixed order
 //   phase C  fixed-order sum of a tile's partials (deterministic), optional dB epilogue, coalesced
 //            512-byte row stores of out[row][frame][0..M)
 #include "host_common.hpp"
@@ -50,23 +50,43 @@ struct MelArgs {
     float* out;            // [rows][T][M]
 };
 
-enum { STEP_VALID = 1 << 21, STEP_FLUSH = 1 << 20 };
-
 struct MelTables {
-    int meta[MEL_MAX_WAVES][MEL_MAXS];       // k | tile << 12 | flush | valid, per wave per step
+    int koff[MEL_MAX_WAVES][MEL_MAXS];       // first bin k of each K-step of a wave's share (0 when unused)
+    int uoff[MEL_MAX_WAVES][MEL_MAXS];       // k * M + tile * 16: fb offset of the step's (kq = 0, band 0) weight
+    int edge[MEL_MAX_WAVES][MEL_MAXS];       // step touches bins >= F or bands >= M: lanes must be masked
+    int nsteps[MEL_MAX_WAVES];
+    unsigned flush_lo[MEL_MAX_WAVES];        // bit i: step i closes a partial tile (store + reset accumulator)
+    unsigned flush_hi[MEL_MAX_WAVES];
     int wave_slot0[MEL_MAX_WAVES];
     int tile_first[MEL_MAX_BAND_TILES];
     int tile_count[MEL_MAX_BAND_TILES];
 };
 
+#ifndef TAC_MEL_TIMING
+#define TAC_MEL_TIMING 0   // 1: overwrite out[block*8 + i] with per-phase cycle sums (s_memtime), debug only
+#endif
+#if TAC_MEL_TIMING
+#define TAC_STAMP(i) do { long long _n = clock64(); tacc[i] += (float)(_n - tlast); tlast = _n; } while (0)
+#else
+#define TAC_STAMP(i) do {} while (0)
+#endif
+#ifndef TAC_MEL_TWHOIST
+#define TAC_MEL_TWHOIST 1
+#endif
+#ifndef TAC_MEL_NF
+#define TAC_MEL_NF 1        // frames in flight per wave at N >= 2048 (A/B knob; 2 spills at 256 VGPRs and measures slower)
+#endif
+
 template <int NC, int E>
 struct MelCfg {
     using F = WaveFft<NC, E>;
-    static constexpr int NF = (F::G == 1) ? 2 : 1;                     // frames in flight per wave
-    static constexpr int FPW = NF * F::G;                              // frames per wave per tile
-    static constexpr int WAVES = (MEL_TILE / FPW) >= 4 ? ((MEL_TILE / FPW) > 8 ? 8 : (MEL_TILE / FPW)) : 4;
-    static constexpr int NBUF = (WAVES * FPW) > MEL_TILE ? (WAVES * FPW) : MEL_TILE;
-    static constexpr int PROW = 2 * F::PADDED;                         // floats between consecutive P rows
+    static constexpr int GT = (MEL_TILE / F::G) >= 1 ? (MEL_TILE / F::G) : 1;   // lane-groups (waves' worth) per tile
+    static constexpr int WAVES = GT >= 8 ? 8 : 4;
+    static constexpr int GPW = (GT / WAVES) >= 1 ? (GT / WAVES) : 1;            // groups per wave per tile
+    static constexpr int NF = (GPW >= 2 && TAC_MEL_NF >= 2) ? 2 : 1;            // groups in flight per wave
+    static constexpr int REPS = GPW / NF;
+    static constexpr int NBUF = (WAVES * GPW * F::G) > MEL_TILE ? (WAVES * GPW * F::G) : MEL_TILE;
+    static constexpr int PROW = 2 * F::PADDED;                                  // floats between consecutive P rows
     static_assert(PROW >= NC + 1 + 3, "P row must hold F bins + K-step overrun");
 };
 
@@ -95,8 +115,17 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
     const int fr = lane & 15, kq = lane >> 4;
 
     // ---- one-off setup: cut the K-steps into per-wave shares
-    for (int i = tid; i < MEL_MAX_WAVES * MEL_MAXS; i += WAVES * 64) (&tab->meta[0][0])[i] = 0;
-    if (tid < MEL_MAX_WAVES) tab->wave_slot0[tid] = 0;
+    for (int i = tid; i < MEL_MAX_WAVES * MEL_MAXS; i += WAVES * 64) {
+        (&tab->koff[0][0])[i] = 0;
+        (&tab->uoff[0][0])[i] = 0;
+        (&tab->edge[0][0])[i] = 0;
+    }
+    if (tid < MEL_MAX_WAVES) {
+        tab->wave_slot0[tid] = 0;
+        tab->nsteps[tid] = 0;
+        tab->flush_lo[tid] = 0;
+        tab->flush_hi[tid] = 0;
+    }
     __syncthreads();
     if (tid == 0) {
         const int total = mel_total_steps(plan, m.n_band_tiles);
@@ -114,9 +143,16 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
                 const int room = share - li;
                 const int take = rem < room ? rem : room;
                 if (li == 0) tab->wave_slot0[owner] = slot;
-                for (int s2 = 0; s2 < take; ++s2)
-                    tab->meta[owner][li + s2] = (lo + 4 * (done + s2)) | (bt << 12) | STEP_VALID |
-                                                (s2 == take - 1 ? STEP_FLUSH : 0);
+                for (int s2 = 0; s2 < take; ++s2) {
+                    tab->koff[owner][li + s2] = lo + 4 * (done + s2);
+                    const int k = lo + 4 * (done + s2);
+                    tab->uoff[owner][li + s2] = k * m.n_mels + bt * 16;
+                    tab->edge[owner][li + s2] = (k + 3 >= NC + 1) || (bt * 16 + 15 >= m.n_mels);
+                }
+                const int last = li + take - 1;
+                if (last < 32) tab->flush_lo[owner] |= 1u << last;
+                else tab->flush_hi[owner] |= 1u << (last - 32);
+                tab->nsteps[owner] = li + take;
                 ++slot;
                 pos += take;
                 done += take;
@@ -127,21 +163,23 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
     }
     __syncthreads();
 
-    // ---- this wave's filter weights -> registers, once
-    float breg[MEL_MAXS];
-#pragma unroll
-    for (int i = 0; i < MEL_MAXS; ++i) {
-        const int mt = tab->meta[w][i];
-        const int k = (mt & 0xfff) + kq;
-        const int band = ((mt >> 12) & 0xff) * 16 + fr;
-        breg[i] = ((mt & STEP_VALID) && band < m.n_mels && k < NBINS) ? m.fb[(long long)k * m.n_mels + band] : 0.0f;
-    }
+    // the second-dispatched half of the workgroup loses VALU arbitration to the older half on every SIMD
+    // (MI355X_MICROARCH.md "Two waves per SIMD"); one static priority bump evens out phase A
+    if (w >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
+
+    // ---- per-wave constants of phase B (wave-uniform -> SGPRs)
+    const int nsteps = __builtin_amdgcn_readfirstlane(tab->nsteps[w]);
+    const unsigned flush_lo = __builtin_amdgcn_readfirstlane(tab->flush_lo[w]);
+    const unsigned flush_hi = __builtin_amdgcn_readfirstlane(tab->flush_hi[w]);
+    const int slot0 = __builtin_amdgcn_readfirstlane(tab->wave_slot0[w]);
 
     cf tw[F::NTW];
     cf ptw[F::NPAIR];
+#if TAC_MEL_TWHOIST
     F::load_twiddles(tw, tb.w_nc, t);
 #pragma unroll
     for (int i = 0; i < F::NPAIR; ++i) ptw[i] = tb.w_n[t + i * F::LPF];
+#endif
 
     const int tiles_per_row = (int)((g.n_frames + MEL_TILE - 1) / MEL_TILE);
     const int total_tiles = (int)g.rows * tiles_per_row;
@@ -149,79 +187,119 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
     const int begin = (int)blockIdx.x * chunk;
     const int end = begin + chunk < total_tiles ? begin + chunk : total_tiles;
 
-    cf* lds[NF];
-    int fi[NF];
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-        fi[f] = (w * NF + f) * F::G + sub;                  // frame index within the tile owned by this lane group
-        lds[f] = bufs + fi[f] * F::PADDED;
-    }
-    const bool wave_has_frames = (w * C::FPW) < MEL_TILE;
+    const bool wave_has_frames = (w * C::GPW * F::G) < MEL_TILE;
+    // phase C walks idx = tid, tid + T, ... over (frame, band) = (idx / M, idx % M) without dividing per element
+    const int c_fg0 = tid / m.n_mels, c_band0 = tid % m.n_mels;
+    const int c_dfg = (WAVES * 64) / m.n_mels, c_dband = (WAVES * 64) % m.n_mels;
 
+#if TAC_MEL_TIMING
+    float tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = clock64();
+#endif
     for (int tile = begin; tile < end; ++tile) {
         const int row = tile / tiles_per_row;
         const long long f0 = (long long)(tile - row * tiles_per_row) * MEL_TILE;
+        TAC_STAMP(0);
 
         // ---------------- phase A: FFT, then overwrite each frame buffer with its |X|^p row
         if (wave_has_frames) {
-            cf v[NF][E];
-            int tl = t;
-            asm volatile("" : "+v"(tl));          // launder: window loads stay inside the loop (register budget)
-            float2 win[F::E];
-            load_window_regs<F>(win, g, tl);
+#pragma unroll 1
+            for (int rep = 0; rep < C::REPS; ++rep) {
+                cf* lds[NF];
+                int fi[NF];
 #pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                const long long frame = (fi[f] < MEL_TILE) ? f0 + fi[f] : g.n_frames;
-                load_frame<F, true>(v[f], g, win, lds[f], row, frame, t);
-            }
-#if TAC_MEL_ABL != 1
-            F::template run<NF>(v, lds, tw, t);
+                for (int f = 0; f < NF; ++f) {
+                    fi[f] = ((w * C::GPW + rep * NF + f) * F::G) + sub;     // frame index within the tile
+                    lds[f] = bufs + fi[f] * F::PADDED;
+                }
+                cf v[NF][E];
+                int tl = t;
+                asm volatile("" : "+v"(tl));      // launder: window loads stay inside the loop (register budget)
+                float2 win[F::E];
+                load_window_regs<F>(win, g, tl);
+#if !TAC_MEL_TWHOIST
+                F::load_twiddles(tw, tb.w_nc, tl);
+#pragma unroll
+                for (int i = 0; i < F::NPAIR; ++i) ptw[i] = tb.w_n[tl + i * F::LPF];
 #endif
 #pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                // gather every Z this lane needs BEFORE anything is overwritten (in-place row)
+                for (int f = 0; f < NF; ++f) {
+                    const long long frame = (fi[f] < MEL_TILE) ? f0 + fi[f] : g.n_frames;
+                    load_frame<F, true>(v[f], g, win, lds[f], row, frame, t);
+                }
+#if TAC_MEL_ABL != 1
+                F::template run<NF>(v, lds, tw, t);
+#endif
 #pragma unroll
-                for (int i = 0; i < F::NPAIR; ++i) {
-                    const int k = t + i * F::LPF;
-                    v[f][2 * i] = lds[f][lds_pad(k)];
-                    v[f][2 * i + 1] = lds[f][lds_pad((NC - k) & (NC - 1))];
-                }
-                const cf zmid = lds[f][lds_pad(NC / 2)];
-                wave_lds_fence();
-                float* prow = reinterpret_cast<float*>(lds[f]);
+                for (int f = 0; f < NF; ++f) {
+                    // gather every Z this lane needs BEFORE anything is overwritten (in-place row)
 #pragma unroll
-                for (int i = 0; i < F::NPAIR; ++i) {
-                    const int k = t + i * F::LPF;
-                    cf xa, xb;
-                    F::r2c_split(v[f][2 * i], v[f][2 * i + 1], ptw[i], xa, xb);
-                    xa.x *= g.scale; xa.y *= g.scale; xb.x *= g.scale; xb.y *= g.scale;
-                    const float pa = xa.x * xa.x + xa.y * xa.y, pb = xb.x * xb.x + xb.y * xb.y;
-                    prow[k] = POW2 ? pa : sqrtf(pa);
-                    prow[NC - k] = POW2 ? pb : sqrtf(pb);
+                    for (int i = 0; i < F::NPAIR; ++i) {
+                        const int k = t + i * F::LPF;
+                        v[f][2 * i] = lds[f][lds_pad(k)];
+                        v[f][2 * i + 1] = lds[f][lds_pad((NC - k) & (NC - 1))];
+                    }
+                    const cf zmid = lds[f][lds_pad(NC / 2)];
+                    wave_lds_fence();
+                    float* prow = reinterpret_cast<float*>(lds[f]);
+#pragma unroll
+                    for (int i = 0; i < F::NPAIR; ++i) {
+                        const int k = t + i * F::LPF;
+                        cf xa, xb;
+                        F::r2c_split(v[f][2 * i], v[f][2 * i + 1], ptw[i], xa, xb);
+                        xa.x *= g.scale; xa.y *= g.scale; xb.x *= g.scale; xb.y *= g.scale;
+                        const float pa = xa.x * xa.x + xa.y * xa.y, pb = xb.x * xb.x + xb.y * xb.y;
+                        prow[k] = POW2 ? pa : sqrtf(pa);
+                        prow[NC - k] = POW2 ? pb : sqrtf(pb);
+                    }
+                    if (t == 0) {
+                        const cf xm = make_float2(zmid.x * g.scale, -zmid.y * g.scale);    // X[NC/2] = conj(Z[NC/2])
+                        const float pm = xm.x * xm.x + xm.y * xm.y;
+                        prow[NC / 2] = POW2 ? pm : sqrtf(pm);
+                    }
+                    for (int c = t; c < 3; c += F::LPF) prow[NBINS + c] = 0.0f;           // K-step overrun columns
                 }
-                if (t == 0) {
-                    const cf xm = make_float2(zmid.x * g.scale, -zmid.y * g.scale);    // X[NC/2] = conj(Z[NC/2])
-                    const float pm = xm.x * xm.x + xm.y * xm.y;
-                    prow[NC / 2] = POW2 ? pm : sqrtf(pm);
-                }
-                for (int c = t; c < 3; c += F::LPF) prow[NBINS + c] = 0.0f;           // K-step overrun columns
             }
         }
+        // this wave's filter weights for phase B: loads issued BEFORE the barrier so the L2 round trip
+        // overlaps the wait for the slower waves; the registers they land in were phase A's (now dead)
+        float breg[MEL_MAXS];
+        int koff[MEL_MAXS];
+#if TAC_MEL_ABL != 2
+        {
+            // fb offset of step i for this lane = uoff[i] (wave-uniform) + (kq * M + fr) (lane constant)
+            const float* fbl = m.fb + (kq * m.n_mels + fr);
+#pragma unroll
+            for (int i = 0; i < MEL_MAXS; ++i) {
+                koff[i] = tab->koff[w][i];
+                const int u = tab->uoff[w][i];
+                breg[i] = fbl[u];
+                if (__builtin_amdgcn_readfirstlane(tab->edge[w][i])) {       // rare: tile/bin edge, mask the overrun
+                    const bool ok = (koff[i] + kq < NBINS) && (u % m.n_mels + fr < m.n_mels);
+                    breg[i] = ok ? fbl[ok ? u : 0] : 0.0f;
+                }
+            }
+        }
+#endif
+        TAC_STAMP(1);
         __syncthreads();
+        TAC_STAMP(2);
 
-        // ---------------- phase B: block-sparse P·fb on the matrix cores, weights from registers
+        // ---------------- phase B: block-sparse P·fb on the matrix cores
 #if TAC_MEL_ABL != 2
         {
             const float* abase = reinterpret_cast<const float*>(bufs) + fr * PROW + kq;
+            float a[MEL_MAXS];
+#pragma unroll
+            for (int i = 0; i < MEL_MAXS; ++i) a[i] = abase[koff[i]];      // all LDS reads in flight together
             f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-            int slot = tab->wave_slot0[w];
+            int slot = slot0;
 #pragma unroll
             for (int i = 0; i < MEL_MAXS; ++i) {
-                const int mt = __builtin_amdgcn_readfirstlane(tab->meta[w][i]);
-                if (mt & STEP_VALID) {
-                    const float a = abase[mt & 0xfff];
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, breg[i], acc, 0, 0, 0);
-                    if (mt & STEP_FLUSH) {
+                if (i < nsteps) {                                            // wave-uniform
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], breg[i], acc, 0, 0, 0);
+                    const bool fl = i < 32 ? ((flush_lo >> (i & 31)) & 1u) : ((flush_hi >> (i & 31)) & 1u);
+                    if (fl) {
                         float* pp = partial + slot * 256 + (kq * 4) * 16 + fr;   // D[frame = kq*4+r][band = fr]
                         pp[0] = acc[0]; pp[16] = acc[1]; pp[32] = acc[2]; pp[48] = acc[3];
                         ++slot;
@@ -231,31 +309,49 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
             }
         }
 #endif
+        TAC_STAMP(3);
         __syncthreads();
+        TAC_STAMP(4);
 
-        // ---------------- phase C: reduce partials, dB, store
+        // ---------------- phase C: reduce partials, dB, store.  One (band, 4-frame group) per thread so the
+        // four partial sums are independent chains and every store instruction writes whole 64-band runs.
         {
-            const int per_tile = MEL_TILE * m.n_mels;
-            for (int idx = tid; idx < per_tile; idx += WAVES * 64) {
-                const int fo = idx / m.n_mels;
-                const int band = idx - fo * m.n_mels;
+            int fg = c_fg0, band = c_band0;
+            for (int idx = tid; idx < 4 * m.n_mels; idx += WAVES * 64) {
                 const int bt = band >> 4;
                 const int first = tab->tile_first[bt], cnt = tab->tile_count[bt];
-                float sum = 0.0f;
-                for (int s2 = 0; s2 < cnt; ++s2) sum += partial[(first + s2) * 256 + fo * 16 + (band & 15)];
-                if (m.db) sum = amp_to_db(sum, m.amin, m.log10_ref);
-                const long long frame = f0 + fo;
+                float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                for (int s2 = 0; s2 < cnt; ++s2) {
+                    const float* pp = partial + (first + s2) * 256 + (fg * 4) * 16 + (band & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sum[r] += pp[r * 16];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = sum[r];
+                    if (m.db) v = amp_to_db(v, m.amin, m.log10_ref);
+                    const long long frame = f0 + fg * 4 + r;
 #if TAC_MEL_ABL == 3
-                if (frame < g.n_frames && sum == 12345.678f) m.out[(row * g.n_frames + frame) * m.n_mels + band] = sum;
+                    if (frame < g.n_frames && v == 12345.678f) m.out[(row * g.n_frames + frame) * m.n_mels + band] = v;
 #else
-                if (frame < g.n_frames) m.out[(row * g.n_frames + frame) * m.n_mels + band] = sum;
+                    if (frame < g.n_frames) m.out[(row * g.n_frames + frame) * m.n_mels + band] = v;
 #endif
+                }
+                band += c_dband;
+                fg += c_dfg;
+                if (band >= m.n_mels) { band -= m.n_mels; ++fg; }
             }
         }
+        TAC_STAMP(5);
         // no barrier needed here: the next tile's phase A touches the frame buffers only (all phase-B reads
         // of them are behind the barrier above), and the barrier after phase A orders these partial reads
         // before the next phase-B writes.
     }
+#if TAC_MEL_TIMING
+    __syncthreads();
+    if (lane == 0)
+        for (int i = 0; i < 6; ++i) m.out[((long long)blockIdx.x * WAVES + w) * 8 + i] = tacc[i];
+#endif
 }
 
 template <int NC, int E>
