@@ -54,28 +54,38 @@ def event_ms(fn, iters):
 
 
 def cpu_baseline():
+    """Time the CPU oracle (torch-CPU restatement of the reference op sequence) on a bounded sample.
+    The host may expose far more hardware threads than torch's CPU kernels scale to, so a few thread
+    counts are tried briefly and the best one is reported (cores = threads actually used)."""
     from oracle import torch_ref
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    avail = os.cpu_count() or 1
     rows = 64
     g = torch.Generator().manual_seed(0)
     x = torch.rand(rows, CHANNELS, LENGTH, generator=g) * 2 - 1
 
     def run():
         return torch_ref.melspectrogram_db(x, n_fft=N_FFT, hop=HOP, num_mels=N_MELS, sample_rate=SR)
-    run()
-    best = float('inf')
+
+    best, best_threads, reps_total = float('inf'), 1, 0
     t_all = time.perf_counter()
-    reps = 0
-    while reps < 5 or (time.perf_counter() - t_all < 10.0 and reps < 40):
-        t0 = time.perf_counter()
+    for threads in sorted({1, 8, 16, 32, 64, avail}):
+        if threads > avail or time.perf_counter() - t_all > 20.0:
+            continue
+        torch.set_num_threads(threads)
         run()
-        best = min(best, time.perf_counter() - t0)
-        reps += 1
-    return {'value': rows * CHANNELS * FRAMES / best, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d of the %d rows of the same workload (%dx%dx%d f32 uniform(-1,1), %d/%d/%d mel + dB), '
-                      'best of %d runs, torch %s CPU ops in the reference op order (oracle/torch_ref.py)'
-                      % (rows, BATCH, rows, CHANNELS, LENGTH, N_FFT, HOP, N_MELS, reps, torch.__version__)}
+        for _ in range(3):
+            t0 = time.perf_counter()
+            run()
+            dt = time.perf_counter() - t0
+            reps_total += 1
+            if dt < best:
+                best, best_threads = dt, threads
+    return {'value': rows * CHANNELS * FRAMES / best, 'unit': 'frames/s', 'cores': best_threads, 'kind': 'port',
+            'sample': '%d of the %d rows of the same workload (%dx%dx%d f32 uniform(-1,1), %d/%d/%d mel + dB), best of '
+                      '%d runs over thread counts up to %d (best at %d threads), torch %s CPU ops in the reference op '
+                      'order (oracle/torch_ref.py)'
+                      % (rows, BATCH, rows, CHANNELS, LENGTH, N_FFT, HOP, N_MELS, reps_total, avail, best_threads,
+                         torch.__version__)}
 
 
 def main():
@@ -138,7 +148,7 @@ def main():
                                '%d mel (BASELINE configs[1])' % (BATCH, CHANNELS, SR, SECONDS, N_FFT, HOP, N_MELS),
                    'global_batch': world * BATCH, 'frames_per_step': frames_per_step,
                    'parallelism': 'batch-sharded x%d, no data-path collective' % world},
-        'roofline': {'kernel': 'melspec_kernel<1024,16> (fused STFT+power+mel MFMA+dB)', 'bound': 'hbm',
+        'roofline': {'kernel': 'melspec_kernel<1024,16,16,true> (fused STFT+power+mel MFMA+dB)', 'bound': 'hbm',
                      'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                      'traffic': None, 'alg_bytes_per_launch': alg_bytes, 'kernel_ms_mean': mean_ms,
                      'kernel_ms_median': med_ms},

@@ -5,32 +5,39 @@
 // STFT (657 MB at cfg-2), the power spectrogram (328 MB) nor the linear mel tensor ever touch HBM:
 // algorithmic traffic is 4*hop bytes in + 4*M bytes out per frame.
 //
-// Per workgroup (one CU): loop over tiles of 16 consecutive frames of one row.  LDS holds 16 frame
-// buffers; a buffer is first the FFT exchange area of its frame and then, IN PLACE, the frame's
-// |X|^p row — there is no separate power tile, which is what lets 16 frames fit in 160 KB.
-//   phase A  every wave FFTs its frames (two in flight per wave at N=2048, fft_core.hpp) and overwrites
-//            each buffer with the power row
-//   phase B  P[16 x F] · fb[F x M] on v_mfma_f32_16x16x4_f32.  The triangular filters make fb
+// A workgroup loops over tiles of TILE consecutive frames of one row.  LDS holds TILE frame buffers; a
+// buffer is first the FFT exchange area of its frame and then, IN PLACE, the frame's |X|^p row — there
+// is no separate power tile.
+//   phase A  every wave FFTs its frames (fft_core.hpp) and overwrites each buffer with the power row
+//   phase B  P[TILE x F] · fb[F x M] on v_mfma_f32_16x16x4_f32.  The triangular filters make fb
 //            block-sparse: for every 16-band tile only bins [klo, khi) carry weight (the plan), so a
 //            tile's K loop covers just that range.  All K-steps of all tiles are cut into equal
 //            contiguous shares, one per wave, so the wide high-frequency tiles do not serialise on one
-//            SIMD.  A wave's share never changes, so its B fragments (the filter weights) are loaded
-//            per tile in one burst issued before the phase-A barrier (L2-resident, latency hidden behind
-//            the barrier wait); all P-row LDS reads of the share are issued together, then the MFMA chain runs.  Shares write partial 16x16 tiles to LDS slots in a fixed order
+//            SIMD.  A wave's share never changes; its B fragments (the filter weights) are fetched per
+//            tile in one burst issued BEFORE the phase-A barrier (L2-resident, latency hidden behind the
+//            barrier wait); the P-row LDS reads of a 48-step chunk are issued together, then the MFMA
+//            chain runs.  Shares write partial tiles to LDS slots in a fixed order
 //   phase C  fixed-order sum of a tile's partials (deterministic), optional dB epilogue, coalesced
-//            512-byte row stores of out[row][frame][0..M)
+//            row stores of out[row][frame][0..M)
+// Two geometries are compiled: TILE = 16 with one 8-wave workgroup per CU (155 KB LDS, the default), and an
+// experimental TILE = 8 with 4-wave workgroups at 78 KB so that TWO workgroups share a CU and one group's
+// MFMA / reduction / store phases could run under the other's FFT VALU work.  Measured at cfg-2 the second
+// form is slower (0.52 ms vs 0.37 ms: per-tile costs — weight burst, barriers, reduction — double while half
+// of every MFMA's 16 rows is wasted), so it is kept only as the TAC_MEL_TILE2048 A/B knob.
 #include "host_common.hpp"
 
 #ifndef TAC_MEL_ABL
 #define TAC_MEL_ABL 0    // ablation builds only: 1 = skip phase A math, 2 = skip phase B, 3 = skip phase C stores
 #endif
+#ifndef TAC_MEL_TILE2048
+#define TAC_MEL_TILE2048 16  // frames per tile at N = 2048 (A/B knob: 8 or 16; measured 0.52 ms vs 0.37 ms at cfg-2)
+#endif
 
 namespace tac {
 
-constexpr int MEL_TILE = 16;                 // frames per tile = MFMA M dimension
 constexpr int MEL_MAX_BAND_TILES = 32;       // n_mels <= 512
-constexpr int MEL_MAX_WAVES = 8;
-constexpr int MEL_MAXS = 48;                 // K-steps per wave held in registers
+constexpr int MEL_STEP_BUDGET = 384;         // K-steps per workgroup held in registers during phase B
+constexpr int MEL_CHUNK = 48;                // K-steps per register chunk
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -50,44 +57,40 @@ struct MelArgs {
     float* out;            // [rows][T][M]
 };
 
-struct MelTables {
-    int koff[MEL_MAX_WAVES][MEL_MAXS];       // first bin k of each K-step of a wave's share (0 when unused)
-    int uoff[MEL_MAX_WAVES][MEL_MAXS];       // k * M + tile * 16: fb offset of the step's (kq = 0, band 0) weight
-    int edge[MEL_MAX_WAVES][MEL_MAXS];       // step touches bins >= F or bands >= M: lanes must be masked
-    int nsteps[MEL_MAX_WAVES];
-    unsigned flush_lo[MEL_MAX_WAVES];        // bit i: step i closes a partial tile (store + reset accumulator)
-    unsigned flush_hi[MEL_MAX_WAVES];
-    int wave_slot0[MEL_MAX_WAVES];
-    int tile_first[MEL_MAX_BAND_TILES];
-    int tile_count[MEL_MAX_BAND_TILES];
-};
+enum { STEP_EDGE = 1 << 20 };                // step: k | tile << 12 | edge
 
 #ifndef TAC_MEL_TIMING
-#define TAC_MEL_TIMING 0   // 1: overwrite out[block*8 + i] with per-phase cycle sums (s_memtime), debug only
+#define TAC_MEL_TIMING 0   // 1: overwrite out[...] with per-phase cycle sums (s_memtime), debug only
 #endif
 #if TAC_MEL_TIMING
 #define TAC_STAMP(i) do { long long _n = clock64(); tacc[i] += (float)(_n - tlast); tlast = _n; } while (0)
 #else
 #define TAC_STAMP(i) do {} while (0)
 #endif
-#ifndef TAC_MEL_TWHOIST
-#define TAC_MEL_TWHOIST 1
-#endif
-#ifndef TAC_MEL_NF
-#define TAC_MEL_NF 1        // frames in flight per wave at N >= 2048 (A/B knob; 2 spills at 256 VGPRs and measures slower)
-#endif
 
-template <int NC, int E>
+template <int NC, int E, int TILE>
 struct MelCfg {
     using F = WaveFft<NC, E>;
-    static constexpr int GT = (MEL_TILE / F::G) >= 1 ? (MEL_TILE / F::G) : 1;   // lane-groups (waves' worth) per tile
-    static constexpr int WAVES = GT >= 8 ? 8 : 4;
-    static constexpr int GPW = (GT / WAVES) >= 1 ? (GT / WAVES) : 1;            // groups per wave per tile
-    static constexpr int NF = (GPW >= 2 && TAC_MEL_NF >= 2) ? 2 : 1;            // groups in flight per wave
-    static constexpr int REPS = GPW / NF;
-    static constexpr int NBUF = (WAVES * GPW * F::G) > MEL_TILE ? (WAVES * GPW * F::G) : MEL_TILE;
-    static constexpr int PROW = 2 * F::PADDED;                                  // floats between consecutive P rows
+    static constexpr int GT = (TILE / F::G) >= 1 ? (TILE / F::G) : 1;      // lane-groups (waves' worth) per tile
+    static constexpr int WAVES = (TILE == 8) ? 4 : (GT >= 8 ? 8 : 4);
+    static constexpr int GPW = (GT / WAVES) >= 1 ? (GT / WAVES) : 1;       // groups (sequential FFT rounds) per wave
+    static constexpr int NBUF = (WAVES * GPW * F::G) > TILE ? (WAVES * GPW * F::G) : TILE;
+    static constexpr int PROW = 2 * F::PADDED;                             // floats between consecutive P rows
+    static constexpr int CAP = MEL_STEP_BUDGET / WAVES;                    // K-steps per wave
+    static constexpr int NCHUNK = CAP / MEL_CHUNK;
+    static constexpr int SLOT = TILE * 16;                                 // floats per partial slot
     static_assert(PROW >= NC + 1 + 3, "P row must hold F bins + K-step overrun");
+    static_assert(CAP % MEL_CHUNK == 0 && NCHUNK <= 3, "step capacity must be whole chunks");
+};
+
+template <int WAVES, int CAP>
+struct MelTables {
+    int step[WAVES][CAP];                    // k | tile << 12 | edge  (0 when unused)
+    int nsteps[WAVES];
+    unsigned flush[WAVES][3];                // bit i: step i closes a partial tile (store + reset accumulator)
+    int wave_slot0[WAVES];
+    int tile_first[MEL_MAX_BAND_TILES];
+    int tile_count[MEL_MAX_BAND_TILES];
 };
 
 __host__ __device__ inline int mel_total_steps(const MelPlan& p, int n_band_tiles) {
@@ -96,16 +99,17 @@ __host__ __device__ inline int mel_total_steps(const MelPlan& p, int n_band_tile
     return total;
 }
 
-template <int NC, int E, bool POW2>
-__global__ void __launch_bounds__((MelCfg<NC, E>::WAVES * 64))
+template <int NC, int E, int TILE, bool POW2>
+__global__ void __launch_bounds__((MelCfg<NC, E, TILE>::WAVES * 64), 2)
 melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
-    using C = MelCfg<NC, E>;
+    using C = MelCfg<NC, E, TILE>;
     using F = typename C::F;
-    constexpr int NF = C::NF, WAVES = C::WAVES, NBINS = NC + 1, PROW = C::PROW;
+    using Tab = MelTables<C::WAVES, C::CAP>;
+    constexpr int WAVES = C::WAVES, NBINS = NC + 1, PROW = C::PROW, CAP = C::CAP, SLOT = C::SLOT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf* bufs = reinterpret_cast<cf*>(smem_raw);                                   // NBUF frame buffers
-    float* partial = reinterpret_cast<float*>(bufs + C::NBUF * F::PADDED);        // (ntiles + WAVES) x 256
-    MelTables* tab = reinterpret_cast<MelTables*>(partial + (m.n_band_tiles + WAVES) * 256);
+    float* partial = reinterpret_cast<float*>(bufs + C::NBUF * F::PADDED);        // (ntiles + WAVES) slots
+    Tab* tab = reinterpret_cast<Tab*>(partial + (m.n_band_tiles + WAVES) * SLOT);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -115,16 +119,11 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
     const int fr = lane & 15, kq = lane >> 4;
 
     // ---- one-off setup: cut the K-steps into per-wave shares
-    for (int i = tid; i < MEL_MAX_WAVES * MEL_MAXS; i += WAVES * 64) {
-        (&tab->koff[0][0])[i] = 0;
-        (&tab->uoff[0][0])[i] = 0;
-        (&tab->edge[0][0])[i] = 0;
-    }
-    if (tid < MEL_MAX_WAVES) {
+    for (int i = tid; i < WAVES * CAP; i += WAVES * 64) (&tab->step[0][0])[i] = 0;
+    if (tid < WAVES) {
         tab->wave_slot0[tid] = 0;
         tab->nsteps[tid] = 0;
-        tab->flush_lo[tid] = 0;
-        tab->flush_hi[tid] = 0;
+        tab->flush[tid][0] = tab->flush[tid][1] = tab->flush[tid][2] = 0;
     }
     __syncthreads();
     if (tid == 0) {
@@ -144,14 +143,12 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
                 const int take = rem < room ? rem : room;
                 if (li == 0) tab->wave_slot0[owner] = slot;
                 for (int s2 = 0; s2 < take; ++s2) {
-                    tab->koff[owner][li + s2] = lo + 4 * (done + s2);
                     const int k = lo + 4 * (done + s2);
-                    tab->uoff[owner][li + s2] = k * m.n_mels + bt * 16;
-                    tab->edge[owner][li + s2] = (k + 3 >= NC + 1) || (bt * 16 + 15 >= m.n_mels);
+                    const bool edge = (k + 3 >= NBINS) || (bt * 16 + 15 >= m.n_mels);
+                    tab->step[owner][li + s2] = k | (bt << 12) | (edge ? STEP_EDGE : 0);
                 }
                 const int last = li + take - 1;
-                if (last < 32) tab->flush_lo[owner] |= 1u << last;
-                else tab->flush_hi[owner] |= 1u << (last - 32);
+                tab->flush[owner][last >> 5] |= 1u << (last & 31);
                 tab->nsteps[owner] = li + take;
                 ++slot;
                 pos += take;
@@ -164,33 +161,36 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
     __syncthreads();
 
     // the second-dispatched half of the workgroup loses VALU arbitration to the older half on every SIMD
-    // (MI355X_MICROARCH.md "Two waves per SIMD"); one static priority bump evens out phase A
-    if (w >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
+    // (MI355X_MICROARCH.md "Two waves per SIMD"); with one workgroup per CU a static priority bump for it
+    // evens out phase A.  With two workgroups per CU the co-resident wave belongs to the OTHER group.
+    if (TILE == 16 && w >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
 
     // ---- per-wave constants of phase B (wave-uniform -> SGPRs)
     const int nsteps = __builtin_amdgcn_readfirstlane(tab->nsteps[w]);
-    const unsigned flush_lo = __builtin_amdgcn_readfirstlane(tab->flush_lo[w]);
-    const unsigned flush_hi = __builtin_amdgcn_readfirstlane(tab->flush_hi[w]);
+    const unsigned flush0 = __builtin_amdgcn_readfirstlane(tab->flush[w][0]);
+    const unsigned flush1 = __builtin_amdgcn_readfirstlane(tab->flush[w][1]);
+    const unsigned flush2 = __builtin_amdgcn_readfirstlane(tab->flush[w][2]);
     const int slot0 = __builtin_amdgcn_readfirstlane(tab->wave_slot0[w]);
 
     cf tw[F::NTW];
     cf ptw[F::NPAIR];
-#if TAC_MEL_TWHOIST
     F::load_twiddles(tw, tb.w_nc, t);
 #pragma unroll
     for (int i = 0; i < F::NPAIR; ++i) ptw[i] = tb.w_n[t + i * F::LPF];
-#endif
 
-    const int tiles_per_row = (int)((g.n_frames + MEL_TILE - 1) / MEL_TILE);
+    const int tiles_per_row = (int)((g.n_frames + TILE - 1) / TILE);
     const int total_tiles = (int)g.rows * tiles_per_row;
     const int chunk = (total_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
     const int begin = (int)blockIdx.x * chunk;
     const int end = begin + chunk < total_tiles ? begin + chunk : total_tiles;
 
-    const bool wave_has_frames = (w * C::GPW * F::G) < MEL_TILE;
-    // phase C walks idx = tid, tid + T, ... over (frame, band) = (idx / M, idx % M) without dividing per element
+    const bool wave_has_frames = (w * C::GPW * F::G) < TILE;
+    // phase C walks idx = tid, tid + T, ... over (band, 4-frame group) = (idx % M, idx / M) without dividing per element
     const int c_fg0 = tid / m.n_mels, c_band0 = tid % m.n_mels;
     const int c_dfg = (WAVES * 64) / m.n_mels, c_dband = (WAVES * 64) % m.n_mels;
+    // fb offset of a step for this lane = (k * M + tile * 16) (wave-uniform) + (kq * M + fr) (lane constant)
+    const float* fbl = m.fb + (kq * m.n_mels + fr);
+    const float* abase = reinterpret_cast<const float*>(bufs) + (fr & (TILE - 1)) * PROW + kq;
 
 #if TAC_MEL_TIMING
     float tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -198,86 +198,65 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
 #endif
     for (int tile = begin; tile < end; ++tile) {
         const int row = tile / tiles_per_row;
-        const long long f0 = (long long)(tile - row * tiles_per_row) * MEL_TILE;
+        const long long f0 = (long long)(tile - row * tiles_per_row) * TILE;
         TAC_STAMP(0);
 
         // ---------------- phase A: FFT, then overwrite each frame buffer with its |X|^p row
         if (wave_has_frames) {
 #pragma unroll 1
-            for (int rep = 0; rep < C::REPS; ++rep) {
-                cf* lds[NF];
-                int fi[NF];
-#pragma unroll
-                for (int f = 0; f < NF; ++f) {
-                    fi[f] = ((w * C::GPW + rep * NF + f) * F::G) + sub;     // frame index within the tile
-                    lds[f] = bufs + fi[f] * F::PADDED;
-                }
-                cf v[NF][E];
+            for (int rep = 0; rep < C::GPW; ++rep) {
+                const int fi = ((w * C::GPW + rep) * F::G) + sub;           // frame index within the tile
+                cf* lds[1] = {bufs + fi * F::PADDED};
+                cf v[1][E];
                 int tl = t;
                 asm volatile("" : "+v"(tl));      // launder: window loads stay inside the loop (register budget)
                 float2 win[F::E];
                 load_window_regs<F>(win, g, tl);
-#if !TAC_MEL_TWHOIST
-                F::load_twiddles(tw, tb.w_nc, tl);
-#pragma unroll
-                for (int i = 0; i < F::NPAIR; ++i) ptw[i] = tb.w_n[tl + i * F::LPF];
-#endif
-#pragma unroll
-                for (int f = 0; f < NF; ++f) {
-                    const long long frame = (fi[f] < MEL_TILE) ? f0 + fi[f] : g.n_frames;
-                    load_frame<F, true>(v[f], g, win, lds[f], row, frame, t);
-                }
+                load_frame<F, true>(v[0], g, win, lds[0], row, (fi < TILE) ? f0 + fi : g.n_frames, t);
 #if TAC_MEL_ABL != 1
-                F::template run<NF>(v, lds, tw, t);
+                F::template run<1>(v, lds, tw, t);
 #endif
+                // gather every Z this lane needs BEFORE anything is overwritten (in-place row)
 #pragma unroll
-                for (int f = 0; f < NF; ++f) {
-                    // gather every Z this lane needs BEFORE anything is overwritten (in-place row)
-#pragma unroll
-                    for (int i = 0; i < F::NPAIR; ++i) {
-                        const int k = t + i * F::LPF;
-                        v[f][2 * i] = lds[f][lds_pad(k)];
-                        v[f][2 * i + 1] = lds[f][lds_pad((NC - k) & (NC - 1))];
-                    }
-                    const cf zmid = lds[f][lds_pad(NC / 2)];
-                    wave_lds_fence();
-                    float* prow = reinterpret_cast<float*>(lds[f]);
-#pragma unroll
-                    for (int i = 0; i < F::NPAIR; ++i) {
-                        const int k = t + i * F::LPF;
-                        cf xa, xb;
-                        F::r2c_split(v[f][2 * i], v[f][2 * i + 1], ptw[i], xa, xb);
-                        xa.x *= g.scale; xa.y *= g.scale; xb.x *= g.scale; xb.y *= g.scale;
-                        const float pa = xa.x * xa.x + xa.y * xa.y, pb = xb.x * xb.x + xb.y * xb.y;
-                        prow[k] = POW2 ? pa : sqrtf(pa);
-                        prow[NC - k] = POW2 ? pb : sqrtf(pb);
-                    }
-                    if (t == 0) {
-                        const cf xm = make_float2(zmid.x * g.scale, -zmid.y * g.scale);    // X[NC/2] = conj(Z[NC/2])
-                        const float pm = xm.x * xm.x + xm.y * xm.y;
-                        prow[NC / 2] = POW2 ? pm : sqrtf(pm);
-                    }
-                    for (int c = t; c < 3; c += F::LPF) prow[NBINS + c] = 0.0f;           // K-step overrun columns
+                for (int i = 0; i < F::NPAIR; ++i) {
+                    const int k = t + i * F::LPF;
+                    v[0][2 * i] = lds[0][lds_pad(k)];
+                    v[0][2 * i + 1] = lds[0][lds_pad((NC - k) & (NC - 1))];
                 }
+                const cf zmid = lds[0][lds_pad(NC / 2)];
+                wave_lds_fence();
+                float* prow = reinterpret_cast<float*>(lds[0]);
+#pragma unroll
+                for (int i = 0; i < F::NPAIR; ++i) {
+                    const int k = t + i * F::LPF;
+                    cf xa, xb;
+                    F::r2c_split(v[0][2 * i], v[0][2 * i + 1], ptw[i], xa, xb);
+                    xa.x *= g.scale; xa.y *= g.scale; xb.x *= g.scale; xb.y *= g.scale;
+                    const float pa = xa.x * xa.x + xa.y * xa.y, pb = xb.x * xb.x + xb.y * xb.y;
+                    prow[k] = POW2 ? pa : sqrtf(pa);
+                    prow[NC - k] = POW2 ? pb : sqrtf(pb);
+                }
+                if (t == 0) {
+                    const cf xm = make_float2(zmid.x * g.scale, -zmid.y * g.scale);    // X[NC/2] = conj(Z[NC/2])
+                    const float pm = xm.x * xm.x + xm.y * xm.y;
+                    prow[NC / 2] = POW2 ? pm : sqrtf(pm);
+                }
+                for (int c = t; c < 3; c += F::LPF) prow[NBINS + c] = 0.0f;           // K-step overrun columns
             }
         }
+
         // this wave's filter weights for phase B: loads issued BEFORE the barrier so the L2 round trip
         // overlaps the wait for the slower waves; the registers they land in were phase A's (now dead)
-        float breg[MEL_MAXS];
-        int koff[MEL_MAXS];
+        float breg[CAP];
 #if TAC_MEL_ABL != 2
-        {
-            // fb offset of step i for this lane = uoff[i] (wave-uniform) + (kq * M + fr) (lane constant)
-            const float* fbl = m.fb + (kq * m.n_mels + fr);
 #pragma unroll
-            for (int i = 0; i < MEL_MAXS; ++i) {
-                koff[i] = tab->koff[w][i];
-                const int u = tab->uoff[w][i];
-                breg[i] = fbl[u];
-                if (__builtin_amdgcn_readfirstlane(tab->edge[w][i])) {       // rare: tile/bin edge, mask the overrun
-                    const bool ok = (koff[i] + kq < NBINS) && (u % m.n_mels + fr < m.n_mels);
-                    breg[i] = ok ? fbl[ok ? u : 0] : 0.0f;
-                }
+        for (int i = 0; i < CAP; ++i) {
+            const int st = tab->step[w][i];
+            const int u = (st & 0xfff) * m.n_mels + ((st >> 12) & 0xff) * 16;
+            breg[i] = fbl[u];
+            if (__builtin_amdgcn_readfirstlane(st) & STEP_EDGE) {                    // rare: tile/bin edge
+                const bool ok = ((st & 0xfff) + kq < NBINS) && (((st >> 12) & 0xff) * 16 + fr < m.n_mels);
+                breg[i] = ok ? fbl[ok ? u : 0] : 0.0f;
             }
         }
 #endif
@@ -288,22 +267,33 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
         // ---------------- phase B: block-sparse P·fb on the matrix cores
 #if TAC_MEL_ABL != 2
         {
-            const float* abase = reinterpret_cast<const float*>(bufs) + fr * PROW + kq;
-            float a[MEL_MAXS];
-#pragma unroll
-            for (int i = 0; i < MEL_MAXS; ++i) a[i] = abase[koff[i]];      // all LDS reads in flight together
             f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
             int slot = slot0;
 #pragma unroll
-            for (int i = 0; i < MEL_MAXS; ++i) {
-                if (i < nsteps) {                                            // wave-uniform
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], breg[i], acc, 0, 0, 0);
-                    const bool fl = i < 32 ? ((flush_lo >> (i & 31)) & 1u) : ((flush_hi >> (i & 31)) & 1u);
-                    if (fl) {
-                        float* pp = partial + slot * 256 + (kq * 4) * 16 + fr;   // D[frame = kq*4+r][band = fr]
-                        pp[0] = acc[0]; pp[16] = acc[1]; pp[32] = acc[2]; pp[48] = acc[3];
-                        ++slot;
-                        acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            for (int c = 0; c < C::NCHUNK; ++c) {
+                if (c * MEL_CHUNK < nsteps) {                                        // wave-uniform
+                    float a[MEL_CHUNK];
+#pragma unroll
+                    for (int i = 0; i < MEL_CHUNK; ++i) a[i] = abase[tab->step[w][c * MEL_CHUNK + i] & 0xfff];
+                    const unsigned fl = c == 0 ? flush0 : (c == 1 ? flush1 : flush2);
+                    const unsigned fh = c == 0 ? flush1 : (c == 1 ? flush2 : 0u);
+#pragma unroll
+                    for (int i = 0; i < MEL_CHUNK; ++i) {
+                        const int gi = c * MEL_CHUNK + i;
+                        if (gi < nsteps) {                                           // wave-uniform
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], breg[gi], acc, 0, 0, 0);
+                            const int bit = (c * MEL_CHUNK) % 32 + i;                // position relative to word `fl`
+                            const bool flush_now = bit < 32 ? ((fl >> (bit & 31)) & 1u) : ((fh >> (bit & 31)) & 1u);
+                            if (flush_now) {
+                                // D[frame = kq*4 + r][band = fr]; only rows < TILE are real frames
+                                if (TILE == 16 || kq < 2) {
+                                    float* pp = partial + slot * SLOT + (kq * 4) * 16 + fr;
+                                    pp[0] = acc[0]; pp[16] = acc[1]; pp[32] = acc[2]; pp[48] = acc[3];
+                                }
+                                ++slot;
+                                acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                            }
+                        }
                     }
                 }
             }
@@ -314,15 +304,15 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
         TAC_STAMP(4);
 
         // ---------------- phase C: reduce partials, dB, store.  One (band, 4-frame group) per thread so the
-        // four partial sums are independent chains and every store instruction writes whole 64-band runs.
+        // four partial sums are independent chains and every store instruction writes whole band runs.
         {
             int fg = c_fg0, band = c_band0;
-            for (int idx = tid; idx < 4 * m.n_mels; idx += WAVES * 64) {
+            for (int idx = tid; idx < (TILE / 4) * m.n_mels; idx += WAVES * 64) {
                 const int bt = band >> 4;
                 const int first = tab->tile_first[bt], cnt = tab->tile_count[bt];
                 float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
                 for (int s2 = 0; s2 < cnt; ++s2) {
-                    const float* pp = partial + (first + s2) * 256 + (fg * 4) * 16 + (band & 15);
+                    const float* pp = partial + (first + s2) * SLOT + (fg * 4) * 16 + (band & 15);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) sum[r] += pp[r * 16];
                 }
@@ -354,25 +344,25 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
 #endif
 }
 
-template <int NC, int E>
+template <int NC, int E, int TILE>
 static size_t mel_lds_bytes(int n_band_tiles) {
-    using C = MelCfg<NC, E>;
-    return (size_t)C::NBUF * C::F::PADDED * sizeof(cf) + (size_t)(n_band_tiles + C::WAVES) * 256 * sizeof(float) +
-           sizeof(MelTables);
+    using C = MelCfg<NC, E, TILE>;
+    return (size_t)C::NBUF * C::F::PADDED * sizeof(cf) + (size_t)(n_band_tiles + C::WAVES) * C::SLOT * sizeof(float) +
+           sizeof(MelTables<C::WAVES, C::CAP>);
 }
 
-template <int NC, int E>
+template <int NC, int E, int TILE>
 static int launch_mel(const FrameGeom& g, const Tables& tb, MelArgs m, const MelPlan& plan, hipStream_t stream,
                       bool query_only) {
-    using C = MelCfg<NC, E>;
-    const size_t lds_bytes = mel_lds_bytes<NC, E>(m.n_band_tiles);
+    using C = MelCfg<NC, E, TILE>;
+    const size_t lds_bytes = mel_lds_bytes<NC, E, TILE>(m.n_band_tiles);
     if (lds_bytes > 160 * 1024) return TAC_E_UNSUPPORTED;
     if (m.power != 2.0f && m.power != 1.0f) return TAC_E_UNSUPPORTED;      // |X|^p, p not in {1, 2}: chain (2)+(4)
-    if (mel_total_steps(plan, m.n_band_tiles) > C::WAVES * MEL_MAXS) return TAC_E_UNSUPPORTED;   // dense bank: chain (2)+(4)
+    if (mel_total_steps(plan, m.n_band_tiles) > MEL_STEP_BUDGET) return TAC_E_UNSUPPORTED;   // dense bank: chain (2)+(4)
     for (int bt = 0; bt < m.n_band_tiles; ++bt)
         if (plan.hi[bt] > 4000 || plan.lo[bt] < 0) return TAC_E_INVALID;
     if (query_only) return TAC_OK;
-    const long long tiles = g.rows * ((g.n_frames + MEL_TILE - 1) / MEL_TILE);
+    const long long tiles = g.rows * ((g.n_frames + TILE - 1) / TILE);
     if (tiles >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
     int per_cu = (int)(160 * 1024 / lds_bytes);
     if (per_cu > 2) per_cu = 2;
@@ -381,7 +371,7 @@ static int launch_mel(const FrameGeom& g, const Tables& tb, MelArgs m, const Mel
     long long blocks = tiles < max_blocks ? tiles : max_blocks;
     if (blocks < 1) blocks = 1;
     const bool pow2 = (m.power == 2.0f);
-    auto kern = pow2 ? melspec_kernel<NC, E, true> : melspec_kernel<NC, E, false>;
+    auto kern = pow2 ? melspec_kernel<NC, E, TILE, true> : melspec_kernel<NC, E, TILE, false>;
     static bool attr_set[2] = {false, false};
     if (!attr_set[pow2]) {
         TAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -396,13 +386,13 @@ static int launch_mel(const FrameGeom& g, const Tables& tb, MelArgs m, const Mel
 static int dispatch_mel(int n_fft, const FrameGeom& g, const Tables& tb, const MelArgs& m, const MelPlan& plan,
                         hipStream_t s, bool query_only) {
     switch (n_fft) {
-        case 32: return launch_mel<16, 16>(g, tb, m, plan, s, query_only);
-        case 64: return launch_mel<32, 16>(g, tb, m, plan, s, query_only);
-        case 128: return launch_mel<64, 16>(g, tb, m, plan, s, query_only);
-        case 256: return launch_mel<128, 16>(g, tb, m, plan, s, query_only);
-        case 512: return launch_mel<256, 16>(g, tb, m, plan, s, query_only);
-        case 1024: return launch_mel<512, 16>(g, tb, m, plan, s, query_only);
-        case 2048: return launch_mel<1024, 16>(g, tb, m, plan, s, query_only);
+        case 32: return launch_mel<16, 16, 16>(g, tb, m, plan, s, query_only);
+        case 64: return launch_mel<32, 16, 16>(g, tb, m, plan, s, query_only);
+        case 128: return launch_mel<64, 16, 16>(g, tb, m, plan, s, query_only);
+        case 256: return launch_mel<128, 16, 16>(g, tb, m, plan, s, query_only);
+        case 512: return launch_mel<256, 16, 16>(g, tb, m, plan, s, query_only);
+        case 1024: return launch_mel<512, 16, 16>(g, tb, m, plan, s, query_only);
+        case 2048: return launch_mel<1024, 16, TAC_MEL_TILE2048>(g, tb, m, plan, s, query_only);
         default: return TAC_E_UNSUPPORTED;
     }
 }
