@@ -55,9 +55,10 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sub = lane / F::LPF;
     const int t = lane % F::LPF;
+    constexpr int WAVE_SLOTS = ((NF * F::G * F::PADDED + 1) / 2) * 2;     // complex slots per wave, 16-byte multiple
     cf* lds[NF];
 #pragma unroll
-    for (int f = 0; f < NF; ++f) lds[f] = smem + ((w * NF + f) * F::G + sub) * F::PADDED;
+    for (int f = 0; f < NF; ++f) lds[f] = smem + w * WAVE_SLOTS + (f * F::G + sub) * F::PADDED;
 
     cf tw[F::NTW];
     cf ptw[HOIST ? F::NPAIR : 1];
@@ -67,15 +68,19 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
         for (int i = 0; i < F::NPAIR; ++i) ptw[i] = tb.w_n[t + i * F::LPF];
     }
 
-    const int groups_per_row = (int)((g.n_frames + F::G - 1) / F::G);
-    const int total = (int)g.rows * groups_per_row;
+    // work unit of one wave-iteration: NF*G consecutive frames of ONE row (so their output rows are adjacent)
+    constexpr int FPU = NF * F::G;
+    const int units_per_row = (int)((g.n_frames + FPU - 1) / FPU);
+    const int total = (int)g.rows * units_per_row;
     const int chunk = (total + (int)gridDim.x - 1) / (int)gridDim.x;
     const int begin = (int)blockIdx.x * chunk;
     const int end = begin + chunk < total ? begin + chunk : total;
     const int nbins = ep.onesided ? NC + 1 : 2 * NC;
     const long long per_frame = (long long)nbins * (MODE == 0 ? 2 : 1);
 
-    for (int base = begin + w * NF; base < end; base += STFT_WAVES * NF) {
+    for (int unit = begin + w; unit < end; unit += STFT_WAVES) {
+        const int urow = unit / units_per_row;
+        const long long uframe0 = (long long)(unit - urow * units_per_row) * FPU;
         cf v[NF][E];
         long long row[NF], frame[NF];
         int tl = t;
@@ -85,13 +90,11 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
         load_window_regs<F>(win, g, tl);
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-            const int grp = base + f;
-            const int r = grp / groups_per_row;
-            row[f] = r;
-            frame[f] = (grp < end) ? (long long)(grp - r * groups_per_row) * F::G + sub : g.n_frames;
+            row[f] = urow;
+            frame[f] = uframe0 + f * F::G + sub;            // may be >= T: load_frame() then yields zeros
 #if TAC_ABL == 1
 #pragma unroll
-            for (int e = 0; e < E; ++e) v[f][e] = make_float2((float)(t + e) * win[e].x, (float)(base + e) * win[e].y);
+            for (int e = 0; e < E; ++e) v[f][e] = make_float2((float)(t + e) * win[e].x, (float)(unit + e) * win[e].y);
 #else
             load_frame<F, true>(v[f], g, win, lds[f], row[f], frame[f], t);
 #endif
@@ -107,8 +110,68 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
         F::template run<NF>(v, lds, tw, t);
 #endif
         const bool simple = (MODE == 0) ? (ep.onesided != 0) : (ep.onesided && ep.power == 2.0f && !ep.db);
+        bool done = false;
+        if constexpr (F::G == 1 && TAC_ABL != 2) {
+            if (simple) {
+                // Wide-store epilogue: the unit's NF output rows are adjacent in memory, so they are staged in
+                // output order in LDS (in place over the consumed spectra) and streamed out with 16-byte
+                // ds_read_b128 -> global_store_dwordx4, ~8 store instructions per frame instead of 34 narrow ones
+                // (the narrow stores were issue-bound: 0.22 of 0.44 ms at cfg-2).  The staging origin is shifted
+                // by the rows' misalignment so LDS and global addresses share their 16-byte phase.
+                constexpr int LENF = (MODE == 0 ? 2 : 1) * (NC + 1);
+                const long long g0 = ((long long)urow * g.n_frames + uframe0) * LENF;
+                const int a = (int)(g0 & 3);
+                float* stage = reinterpret_cast<float*>(lds[0]) + a;
+                int nlive = 0;
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    if (frame[f] < g.n_frames) {                                  // wave-uniform
+                        cf xa[F::NPAIR], xb[F::NPAIR], xm, unused;
+#pragma unroll
+                        for (int i = 0; i < F::NPAIR; ++i) {
+                            F::r2c_pair(lds[f], t + i * F::LPF, HOIST ? ptw[i] : tb.w_n[tl + i * F::LPF], xa[i], xb[i]);
+                            xa[i].x *= g.scale; xa[i].y *= g.scale; xb[i].x *= g.scale; xb[i].y *= g.scale;
+                        }
+                        F::r2c_pair(lds[f], NC / 2, make_float2(0.0f, -1.0f), xm, unused);
+                        xm.x *= g.scale; xm.y *= g.scale;
+                        wave_lds_fence();                                         // every Z of this frame is in registers
+                        float* srow = stage + f * LENF;
+#pragma unroll
+                        for (int i = 0; i < F::NPAIR; ++i) {
+                            const int k = t + i * F::LPF;
+                            if constexpr (MODE == 0) {
+                                reinterpret_cast<float2*>(srow)[k] = xa[i];
+                                reinterpret_cast<float2*>(srow)[NC - k] = xb[i];
+                            } else {
+                                srow[k] = xa[i].x * xa[i].x + xa[i].y * xa[i].y;
+                                srow[NC - k] = xb[i].x * xb[i].x + xb[i].y * xb[i].y;
+                            }
+                        }
+                        if (t == 0) {
+                            if constexpr (MODE == 0) reinterpret_cast<float2*>(srow)[NC / 2] = xm;
+                            else srow[NC / 2] = xm.x * xm.x + xm.y * xm.y;
+                        }
+                        wave_lds_fence();
+                        ++nlive;
+                    }
+                }
+                const int len = nlive * LENF;
+                float* gdst = ep.out + g0;
+                const int npre = (4 - a) & 3;
+                if (lane < npre && lane < len) gdst[lane] = stage[lane];
+                const int nchunks = len > npre ? (len - npre) >> 2 : 0;
+                const float4* s4 = reinterpret_cast<const float4*>(stage + npre);
+                float4* g4 = reinterpret_cast<float4*>(gdst + npre);
+#pragma unroll 4
+                for (int c = lane; c < nchunks; c += 64) g4[c] = s4[c];
+                const int tail0 = npre + 4 * nchunks;
+                if (lane < len - tail0) gdst[tail0 + lane] = stage[tail0 + lane];
+                done = true;
+            }
+        }
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
+            if (done) break;
 #if TAC_ABL == 2
             const bool live = frame[f] < g.n_frames && g.scale == 12345.0f;   // never true: stores skipped, math kept
 #else
@@ -192,14 +255,14 @@ static int launch_stft(const FrameGeom& g, const Tables& tb, const StftEpilogue&
     using F = WaveFft<NC, E>;
     constexpr int NF = (E <= 16) ? 2 : 1;
     constexpr bool HOIST = (E <= 16);
-    const long long groups = g.rows * ((g.n_frames + F::G - 1) / F::G);
+    const long long groups = g.rows * ((g.n_frames + NF * F::G - 1) / (NF * F::G));     // wave-iterations
     if (groups >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
-    const size_t lds_bytes = (size_t)STFT_WAVES * NF * F::G * F::PADDED * sizeof(cf);
+    const size_t lds_bytes = (size_t)STFT_WAVES * (((NF * F::G * F::PADDED + 1) / 2) * 2) * sizeof(cf);
     int per_cu = (int)(160 * 1024 / lds_bytes);
     if (per_cu > 2) per_cu = 2;        // 256-register waves: two 4-wave workgroups fill a CU
     if (per_cu < 1) per_cu = 1;
     long long max_blocks = (long long)device_cu_count() * per_cu;
-    long long want = (groups + STFT_WAVES * NF - 1) / (STFT_WAVES * NF);
+    long long want = (groups + STFT_WAVES - 1) / STFT_WAVES;
     long long blocks = want < max_blocks ? want : max_blocks;
     if (blocks < 1) blocks = 1;
     auto kern = stft_kernel<NC, E, MODE, NF, HOIST>;
