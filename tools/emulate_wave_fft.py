@@ -9,16 +9,13 @@ import numpy as np
 
 
 def radix_plan(nc):
-    """16 first, 16 last, the small leftover radix in the middle: the middle pass then needs only
-    (r-1) twiddle registers per lane (all its butterflies share j % 16) — see fft_core.hpp."""
+    """greedy 16, 16, ..., r — see fft_core.hpp for how the later passes share twiddle registers."""
     plan = []
     rem = nc
     while rem > 1:
         r = min(16, rem)
         plan.append(r)
         rem //= r
-    if len(plan) == 3:
-        plan = [plan[0], plan[2], plan[1]]
     return plan
 
 

@@ -72,6 +72,22 @@ __device__ __forceinline__ cf mul_w16(cf v) {
     else return v;
 }
 
+// multiply by W32^m = exp(-2*pi*i*m/32).  `m` is a loop index of fully unrolled loops, so after unrolling
+// every call sees a constant: the table lookups fold to literals and the quarter/eighth-turn cases to
+// add/sub/swap forms.
+__device__ __forceinline__ cf mul_w32(cf v, int m) {
+    constexpr float C[32] = {1.0000000000e+00f, 9.8078528040e-01f, 9.2387953251e-01f, 8.3146961230e-01f, 7.0710678119e-01f, 5.5557023302e-01f, 3.8268343237e-01f, 1.9509032202e-01f, 6.1232339957e-17f, -1.9509032202e-01f, -3.8268343237e-01f, -5.5557023302e-01f, -7.0710678119e-01f, -8.3146961230e-01f, -9.2387953251e-01f, -9.8078528040e-01f, -1.0000000000e+00f, -9.8078528040e-01f, -9.2387953251e-01f, -8.3146961230e-01f, -7.0710678119e-01f, -5.5557023302e-01f, -3.8268343237e-01f, -1.9509032202e-01f, -1.8369701987e-16f, 1.9509032202e-01f, 3.8268343237e-01f, 5.5557023302e-01f, 7.0710678119e-01f, 8.3146961230e-01f, 9.2387953251e-01f, 9.8078528040e-01f};
+    constexpr float S[32] = {0.0000000000e+00f, -1.9509032202e-01f, -3.8268343237e-01f, -5.5557023302e-01f, -7.0710678119e-01f, -8.3146961230e-01f, -9.2387953251e-01f, -9.8078528040e-01f, -1.0000000000e+00f, -9.8078528040e-01f, -9.2387953251e-01f, -8.3146961230e-01f, -7.0710678119e-01f, -5.5557023302e-01f, -3.8268343237e-01f, -1.9509032202e-01f, -1.2246467991e-16f, 1.9509032202e-01f, 3.8268343237e-01f, 5.5557023302e-01f, 7.0710678119e-01f, 8.3146961230e-01f, 9.2387953251e-01f, 9.8078528040e-01f, 1.0000000000e+00f, 9.8078528040e-01f, 9.2387953251e-01f, 8.3146961230e-01f, 7.0710678119e-01f, 5.5557023302e-01f, 3.8268343237e-01f, 1.9509032202e-01f};
+    m &= 31;
+    if (m == 0) return v;
+    if (m == 8) return mul_neg_i(v);
+    if (m == 16) return make_float2(-v.x, -v.y);
+    if (m == 24) return make_float2(-v.y, v.x);
+    if (m == 4) return make_float2((v.x + v.y) * TAC_SQRT_HALF, (v.y - v.x) * TAC_SQRT_HALF);
+    if (m == 12) return make_float2((v.y - v.x) * TAC_SQRT_HALF, -(v.x + v.y) * TAC_SQRT_HALF);
+    return cmul(v, make_float2(C[m], S[m]));
+}
+
 template <int R>
 struct Dft;
 
@@ -127,24 +143,29 @@ constexpr int num_passes(int nc) {
     while (rem > 1) { rem /= (rem >= 16 ? 16 : rem); ++n; }
     return n;
 }
-// Radix order: 16 first, 16 last, the small leftover radix in the MIDDLE (N=2048: 16·4·16).  All
-// butterflies of the middle pass then share j mod 16, so it needs r-1 twiddle registers per lane instead
-// of (E/r)(r-1); 2048 goes from 54 to 36 hoisted twiddles.
+// Radix order: greedy 16, 16, ..., r (N=2048: 16·16·4).  Twiddle registers are what this design is short of
+// (everything lane-dependent is hoisted for the kernel's lifetime), so both later passes are arranged to
+// need only R-1 lane-dependent factors each:
+//  * a middle pass whose butterflies b = 0..E/R-1 use j = t + b*LPF with LPF a multiple of the stride S:
+//    they all see the same j mod S and share one set;
+//  * the LAST pass, where j mod S = j = t + b*LPF: W_NC^{(t + b*LPF) q} = W_NC^{t q} · W_E^{b q}, i.e. one
+//    lane-dependent set W_NC^{t q} times COMPILE-TIME constants W_E^{b q}.
+// N=2048 needs 15 + 3 = 18 complex twiddle registers instead of 54 (plain) — at the price of 9 constant
+// multiplies per frame.
 constexpr int radix_at(int nc, int pass) {
-    int r[4] = {1, 1, 1, 1};
-    int n = 0, rem = nc;
-    while (rem > 1) { int x = rem >= 16 ? 16 : rem; r[n++] = x; rem /= x; }
-    if (n == 3) { int t = r[1]; r[1] = r[2]; r[2] = t; }
-    return r[pass];
+    int rem = nc;
+    for (int p = 0; p < pass; ++p) rem /= (rem >= 16 ? 16 : rem);
+    return rem >= 16 ? 16 : rem;
 }
 constexpr int stride_at(int nc, int pass) {
     int s = 1;
     for (int p = 0; p < pass; ++p) s *= radix_at(nc, p);
     return s;
 }
-// A pass's butterflies b = 0..E/R-1 use j = t + b*LPF; when LPF is a multiple of the stride S they all see
-// the same j mod S and share one set of R-1 twiddles.
-constexpr bool pass_shares_twiddles(int nc, int e, int pass) { return ((nc / e) % stride_at(nc, pass)) == 0; }
+constexpr bool pass_is_last(int nc, int pass) { return pass + 1 == num_passes(nc); }
+constexpr bool pass_shares_twiddles(int nc, int e, int pass) {
+    return pass_is_last(nc, pass) || ((nc / e) % stride_at(nc, pass)) == 0;
+}
 constexpr int pass_twiddles(int nc, int e, int pass) {
     int r = radix_at(nc, pass);
     return (pass_shares_twiddles(nc, e, pass) ? 1 : e / r) * (r - 1);
@@ -188,6 +209,13 @@ struct WaveFft {
         }
     }
 
+    // W_E^{b q} factor of the last pass (identity elsewhere); M32 = b*q*32/E
+    template <int P>
+    __device__ static __forceinline__ cf last_pass_const(cf x, int m32) {
+        if constexpr (pass_is_last(NC, P) && P > 0) return mul_w32(x, m32);
+        else return x;
+    }
+
     // v[f]: E registers per frame in first-pass order v[f][b*R0 + q] = z_f[(t + b*LPF) + q*NC/R0].
     // NF independent frames are advanced pass by pass together so that one frame's LDS round trip
     // hides behind the other's butterflies (ILP instead of occupancy: the kernels run 2 waves/SIMD).
@@ -222,7 +250,7 @@ struct WaveFft {
                 for (int b = 0; b < NB; ++b)
 #pragma unroll
                     for (int q = 1; q < R; ++q)
-                        v[f][b * R + q] = cmul(v[f][b * R + q],
+                        v[f][b * R + q] = cmul(last_pass_const<P>(v[f][b * R + q], b * q * (32 / E)),
                                                tw[OFF + (pass_shares_twiddles(NC, E, P) ? 0 : b) * (R - 1) + q - 1]);
         }
 #pragma unroll
