@@ -41,9 +41,8 @@ __device__ __noinline__ void finish_power_row(const float* prow, float* obase, i
     }
 }
 
-// NF frames per wave are advanced together (see WaveFft::run): with everything loop-invariant —
-// inter-pass twiddles, window, R2C twiddles — held in registers the kernel sits at 2 waves/SIMD and gets
-// its latency hiding from the second in-flight frame instead of from occupancy.
+// NF frames per wave can be advanced together (see WaveFft::run); with the inter-pass and R2C twiddles held
+// in registers the kernel sits at 2 waves/SIMD.  NF = 1 is what ships (see launch_stft).
 template <int NC, int E, int MODE, int NF, bool HOIST>
 __global__ void __launch_bounds__(STFT_WAVES * 64, 2)
 stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
@@ -253,7 +252,9 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 template <int NC, int E, int MODE>
 static int launch_stft(const FrameGeom& g, const Tables& tb, const StftEpilogue& ep, hipStream_t stream) {
     using F = WaveFft<NC, E>;
-    constexpr int NF = (E <= 16) ? 2 : 1;
+    // frames in flight per wave: measured at cfg-2 (complex STFT) NF=1 0.28 ms vs NF=2 0.33 ms — two frames need
+    // ~64 more live registers than the 256 available at 2 waves/SIMD and the spills cost more than the ILP buys
+    constexpr int NF = 1;
     constexpr bool HOIST = (E <= 16);
     const long long groups = g.rows * ((g.n_frames + NF * F::G - 1) / (NF * F::G));     // wave-iterations
     if (groups >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
