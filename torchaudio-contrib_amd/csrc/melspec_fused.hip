@@ -13,10 +13,9 @@
 //            block-sparse: for every 16-band tile only bins [klo, khi) carry weight (the plan), so a
 //            tile's K loop covers just that range.  All K-steps of all tiles are cut into equal
 //            contiguous shares, one per wave, so the wide high-frequency tiles do not serialise on one
-//            SIMD.  A wave's share never changes; its B fragments (the filter weights) are fetched per
-//            tile in one burst issued BEFORE the phase-A barrier (L2-resident, latency hidden behind the
-//            barrier wait); the P-row LDS reads of a 48-step chunk are issued together, then the MFMA
-//            chain runs.  Shares write partial tiles to LDS slots in a fixed order
+//            SIMD.  A wave's share never changes, so its B fragments (the filter weights) are loaded ONCE
+//            into registers at kernel start; the P-row LDS reads of a 48-step chunk are issued together,
+//            then the MFMA chain runs.  Shares write partial tiles to LDS slots in a fixed order
 //   phase C  fixed-order sum of a tile's partials (deterministic), optional dB epilogue, coalesced
 //            row stores of out[row][frame][0..M)
 // Two geometries are compiled: TILE = 16 with one 8-wave workgroup per CU (155 KB LDS, the default), and an
@@ -192,6 +191,21 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
     const float* fbl = m.fb + (kq * m.n_mels + fr);
     const float* abase = reinterpret_cast<const float*>(bufs) + (fr & (TILE - 1)) * PROW + kq;
 
+    // this wave's filter weights for phase B (its share never changes): loaded ONCE, register-resident for the
+    // kernel's lifetime — steady-state phase B touches no global memory (measured 0.38 -> 0.32 ms at cfg-2)
+    float breg[CAP];
+#if TAC_MEL_ABL != 2
+#pragma unroll
+    for (int i = 0; i < CAP; ++i) {
+        const int st = tab->step[w][i];
+        const int u = (st & 0xfff) * m.n_mels + ((st >> 12) & 0xff) * 16;
+        breg[i] = fbl[u];
+        if (__builtin_amdgcn_readfirstlane(st) & STEP_EDGE) {                    // rare: tile/bin edge
+            const bool ok = ((st & 0xfff) + kq < NBINS) && (((st >> 12) & 0xff) * 16 + fr < m.n_mels);
+            breg[i] = ok ? fbl[ok ? u : 0] : 0.0f;
+        }
+    }
+#endif
 #if TAC_MEL_TIMING
     float tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = clock64();
@@ -245,21 +259,6 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
             }
         }
 
-        // this wave's filter weights for phase B: loads issued BEFORE the barrier so the L2 round trip
-        // overlaps the wait for the slower waves; the registers they land in were phase A's (now dead)
-        float breg[CAP];
-#if TAC_MEL_ABL != 2
-#pragma unroll
-        for (int i = 0; i < CAP; ++i) {
-            const int st = tab->step[w][i];
-            const int u = (st & 0xfff) * m.n_mels + ((st >> 12) & 0xff) * 16;
-            breg[i] = fbl[u];
-            if (__builtin_amdgcn_readfirstlane(st) & STEP_EDGE) {                    // rare: tile/bin edge
-                const bool ok = ((st & 0xfff) + kq < NBINS) && (((st >> 12) & 0xff) * 16 + fr < m.n_mels);
-                breg[i] = ok ? fbl[ok ? u : 0] : 0.0f;
-            }
-        }
-#endif
         TAC_STAMP(1);
         __syncthreads();
         TAC_STAMP(2);
