@@ -154,6 +154,18 @@ def main():
                      'kernel_ms_median': med_ms},
     }
 
+    # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in
+    # separate passes, gfx950 x2 FETCH correction applied — tools/summarize_profiles.py); bench.py cannot run the
+    # profiler on itself, so the field is filled from that artefact when it is present.
+    try:
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01', 'pmc_mel.json')))
+        for kname, d in pmc.items():
+            if 'melspec_kernel<1024' in kname and 'hbm_traffic_bytes_per_launch' in d:
+                result['roofline']['traffic'] = d['hbm_traffic_bytes_per_launch']
+                result['roofline']['traffic_source'] = 'profiles/r01/pmc_mel.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)'
+    except Exception:
+        pass
+
     if rank == 0 and not a.no_stages:
         # secondary stages named by north_star, each one kernel: complex STFT and power spectrogram
         stft_layer = tac.STFT(N_FFT, HOP).to(dev)

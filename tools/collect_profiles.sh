@@ -1,0 +1,18 @@
+#!/bin/bash
+# Run ON THE GPU BOX (via gpurun): rocprofv3 kernel trace of the bench command + separate PMC passes for the
+# dominant kernels.  Writes under gpurun_out/$1/; tools/summarize_profiles.py turns it into profiles/$1/.
+set -u
+tag=${1:-r01}
+out=gpurun_out/$tag
+export TMPDIR=/tmp
+mkdir -p $out
+cd ${GRAFT_REPO_ROOT:-.}
+python bench.py > $out/bench_N1.json 2> $out/bench_N1.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o bench -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline > $out/kt_bench.log 2>&1
+for k in mel stft spec; do
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_${k}_fetch -o p -- python tools/prof_driver.py $k 3 > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_${k}_write -o p -- python tools/prof_driver.py $k 3 > /dev/null 2>&1
+  rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $out/pmc_${k}_sq -o p -- python tools/prof_driver.py $k 3 > /dev/null 2>&1
+  rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_${k}_mfma -o p -- python tools/prof_driver.py $k 3 > /dev/null 2>&1
+done
+ls $out
