@@ -142,10 +142,29 @@ def test_g4_mel_variants(tac, golden):
     assert np.abs(host(chain(xm)) - g['mel_htk40_n512_db']).max() < DB_ABS
 
 
-def test_unsupported_n_fft_is_loud(tac):
-    x = dev(signals.uniform((1, 1, 6000), seed=3))
+def test_non_power_of_two_and_large_n_fft(tac, golden):
+    """fft_length outside the FFT kernels' power-of-two range runs as a windowed-DFT matrix product on the fp32
+    MFMA (reference: torch.stft accepts any n_fft, SURVEY §8 a-1 [probed] N=400)."""
+    base = signals.audio_like((1, 2, 20000), seed=4)
+    z = tac.stft(dev(base[..., :6000]), 400, hop_length=160)
+    want = golden('g4_variants')['n400_h160']
+    assert tuple(z.shape) == want.shape
+    assert rel_err(host(z), want) < 5e-6
+    x = signals.audio_like((2, 1, 30000), seed=31)
+    for n, hop, kw in ((8192, 2048, {}), (6000, 1500, dict(win_length=4800)), (100, 30, dict(onesided=False)),
+                       (1000, 250, dict(center=False, normalized=True))):
+        got = host(tac.stft(dev(x), n, hop_length=hop, **kw))
+        ref = numpy_ref.stft(x, n, hop, **kw)
+        assert got.shape[:-1] == ref.shape
+        assert rel_err(got[..., 0] + 1j * got[..., 1], ref) < 5e-6
+    spec = torch.nn.Sequential(*tac.Spectrogram(400, hop_length=160, power=2.), tac.AmplitudeToDb()).cuda()
+    want_db = torch_ref.amplitude_to_db(torch_ref.spectrogram(torch.from_numpy(x), 400, 160, power=2.0)).numpy()
+    assert np.abs(host(spec(dev(x))) - want_db).max() < DB_ABS
+    mel = tac.Melspectrogram(num_mels=40, sample_rate=16000, fft_length=400, hop_length=160).cuda()
+    want_mel = torch_ref.melspectrogram(torch.from_numpy(x), num_mels=40, sample_rate=16000, n_fft=400, hop=160).numpy()
+    assert rel_err(host(mel(dev(x))), want_mel) < 1e-5
     with pytest.raises(NotImplementedError):
-        tac.stft(x, 400, hop_length=160)          # non power of two: no silent fallback
+        tac.stft(dev(x), 10000, hop_length=2500)          # beyond every HIP path: loud, no silent fallback
 
 
 def test_short_input_raises_runtime_error(tac):

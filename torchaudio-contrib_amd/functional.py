@@ -73,7 +73,8 @@ def _default_window(n, device):
 
 class _StftPlan(object):
     """Validated geometry of one stft call (mirrors the checks torch.stft performs)."""
-    __slots__ = ('wave', 'window', 'desc', 'lead', 'n_frames', 'n_bins', 'n_fft', 'onesided')
+    __slots__ = ('wave', 'window', 'desc', 'lead', 'n_frames', 'n_bins', 'n_fft', 'onesided', 'fft_kernel',
+                 'hop', 'center', 'pad_mode', 'normalized', 'win_length')
 
     def __init__(self, waveforms, fft_length, hop_length, win_length, window, center, pad_mode,
                  normalized, onesided):
@@ -111,9 +112,12 @@ class _StftPlan(object):
         if length + 2 * pad < n_fft:
             raise RuntimeError('stft: expected n_fft <= padded signal length %d, got n_fft=%d'
                                % (length + 2 * pad, n_fft))
-        if n_fft & (n_fft - 1) or not 32 <= n_fft <= 4096:
-            raise NotImplementedError('stft: the gfx950 FFT kernels cover power-of-two fft_length in '
-                                      '[32, 4096]; got %d' % n_fft)
+        # power-of-two sizes in [32, 4096] take the wave-level FFT kernels; every other size up to 8192 is
+        # evaluated as a windowed-DFT matrix product on the fp32 matrix cores (see _run_stft_dft)
+        self.fft_kernel = (n_fft & (n_fft - 1)) == 0 and 32 <= n_fft <= 4096
+        if not self.fft_kernel and n_fft > 8192:
+            raise NotImplementedError('stft: fft_length %d is outside the HIP path (power of two in [32, 4096], '
+                                      'or any length <= 8192 through the DFT-matrix kernel)' % n_fft)
         self.lead = tuple(x.shape[:-1])
         flat = x.reshape(-1, length)
         if flat.stride(1) != 1 or (flat.shape[0] > 1 and flat.stride(0) < length):
@@ -122,16 +126,39 @@ class _StftPlan(object):
         self.window = window
         self.n_fft = n_fft
         self.onesided = bool(onesided)
+        self.hop, self.center, self.pad_mode = hop, bool(center), pad_mode
+        self.normalized, self.win_length = bool(normalized), win_length
         self.n_frames = 1 + (length + 2 * pad - n_fft) // hop
         self.n_bins = n_fft // 2 + 1 if onesided else n_fft
-        self.desc = _native.StftDesc(
+        self.desc = None if not self.fft_kernel else _native.StftDesc(
             rows=flat.shape[0], length=length, row_stride=flat.stride(0) if flat.shape[0] > 1 else length,
             n_fft=n_fft, hop=hop, win_length=win_length, center=1 if center else 0,
             pad_mode=_native.PAD_MODES[pad_mode], normalized=1 if normalized else 0,
             onesided=1 if onesided else 0, reserved=0)
 
     # launches ------------------------------------------------------------------
+    def _run_stft_dft(self):
+        """Any fft_length (non power of two, or 4096 < N <= 8192): the framed signal is never materialised — the
+        filterbank GEMM kernel reads frame t, sample n at ``padded[row, t*hop + n]`` (stride_f = 1, stride_t = hop)
+        and multiplies by the (N, 2F) matrix w[n]·(cos, -sin)(2*pi*k*n/N) on v_mfma_f32_16x16x4_f32.  The padded
+        copy is plain data movement done by torch; everything arithmetic is the HIP kernel."""
+        x = self.wave
+        if self.center:
+            pad = self.n_fft // 2
+            x = torch.nn.functional.pad(x.unsqueeze(1), (pad, pad), mode=self.pad_mode).squeeze(1)
+        x = x.contiguous()
+        mat = _dft_matrix(self.window, self.n_fft, self.win_length, self.onesided, self.normalized)
+        out = torch.empty(self.lead + (self.n_frames, self.n_bins, 2), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = _native.lib().tac_apply_filterbank_f32(
+                _native.ptr(x), x.shape[0], self.n_fft, self.n_frames, x.stride(0), 1, self.hop,
+                _native.ptr(mat), None, 2 * self.n_bins, _native.ptr(out), _native.stream_ptr(x.device))
+        _native.check(rc, 'tac_apply_filterbank_f32 (DFT matrix)')
+        return out.transpose(-3, -2)
+
     def run_stft(self):
+        if not self.fft_kernel:
+            return self._run_stft_dft()
         out = torch.empty(self.lead + (self.n_frames, self.n_bins, 2), dtype=torch.float32,
                           device=self.wave.device)
         with torch.cuda.device(self.wave.device):
@@ -141,6 +168,9 @@ class _StftPlan(object):
         return out.transpose(-3, -2)
 
     def run_spectrogram(self, power, db=None):
+        if not self.fft_kernel:
+            mag = complex_norm(self._run_stft_dft(), power)
+            return mag if db is None else amplitude_to_db(mag, ref=db[0], amin=db[1])
         out = torch.empty(self.lead + (self.n_frames, self.n_bins), dtype=torch.float32,
                           device=self.wave.device)
         ref, amin = db if db is not None else (1.0, 1e-7)
@@ -155,7 +185,7 @@ class _StftPlan(object):
     def can_fuse_mel(self, filterbank, power=2.0):
         """True when the single fused kernel covers this geometry and filterbank (sparse enough for the
         register-resident weights); otherwise the caller chains spectrogram + apply_filterbank kernels."""
-        if not (self.onesided and self.n_fft <= 2048 and filterbank.dim() == 2 and
+        if not (self.fft_kernel and self.onesided and self.n_fft <= 2048 and filterbank.dim() == 2 and
                 filterbank.shape[0] == self.n_bins and 0 < filterbank.shape[1] <= 512 and
                 filterbank.is_cuda and filterbank.dtype == torch.float32 and
                 filterbank.device == self.wave.device and filterbank.is_contiguous()):
@@ -178,6 +208,35 @@ class _StftPlan(object):
                 _native.ptr(out), _native.stream_ptr(self.wave.device))
         _native.check(rc, 'tac_melspec_f32')
         return out.transpose(-2, -1)
+
+
+def _dft_matrix(window, n_fft, win_length, onesided, normalized):
+    """(N, 2F) float32 device matrix [w[n] cos(2 pi k n / N), -w[n] sin(2 pi k n / N)] for the DFT-matrix path;
+    evaluated once per (window tensor version, geometry) in float64 on the host — a constant table like the FFT
+    twiddles — and cached on the window tensor."""
+    import numpy as np
+    cache = getattr(window, '_tac_dft', None)
+    key = (window._version, n_fft, win_length, bool(onesided), bool(normalized))
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    w = np.zeros(n_fft, dtype=np.float64)
+    off = (n_fft - win_length) // 2
+    w[off:off + win_length] = window.detach().double().cpu().numpy()
+    if normalized:
+        w = w / math.sqrt(n_fft)
+    n_bins = n_fft // 2 + 1 if onesided else n_fft
+    n = np.arange(n_fft, dtype=np.int64)[:, None]
+    k = np.arange(n_bins, dtype=np.int64)[None, :]
+    ang = (2.0 * math.pi / n_fft) * ((n * k) % n_fft).astype(np.float64)
+    mat = np.empty((n_fft, n_bins, 2), dtype=np.float32)
+    mat[..., 0] = np.cos(ang) * w[:, None]
+    mat[..., 1] = -np.sin(ang) * w[:, None]
+    dev = torch.from_numpy(mat.reshape(n_fft, 2 * n_bins)).to(window.device)
+    try:
+        window._tac_dft = (key, dev)
+    except Exception:
+        pass
+    return dev
 
 
 def _filterbank_plan(fb):
