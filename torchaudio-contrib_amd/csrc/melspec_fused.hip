@@ -36,7 +36,7 @@ namespace tac {
 
 constexpr int MEL_MAX_BAND_TILES = 32;       // n_mels <= 512
 constexpr int MEL_STEP_BUDGET = 384;         // K-steps per workgroup held in registers during phase B
-constexpr int MEL_CHUNK = 48;                // K-steps per register chunk
+constexpr int MEL_CHUNK = 8;                 // K-step granularity of the per-wave capacity
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -67,7 +67,7 @@ enum { STEP_EDGE = 1 << 20 };                // step: k | tile << 12 | edge
 #define TAC_STAMP(i) do {} while (0)
 #endif
 
-template <int NC, int E, int TILE>
+template <int NC, int E, int TILE, int BUDGET = MEL_STEP_BUDGET>
 struct MelCfg {
     using F = WaveFft<NC, E>;
     static constexpr int GT = (TILE / F::G) >= 1 ? (TILE / F::G) : 1;      // lane-groups (waves' worth) per tile
@@ -75,11 +75,11 @@ struct MelCfg {
     static constexpr int GPW = (GT / WAVES) >= 1 ? (GT / WAVES) : 1;       // groups (sequential FFT rounds) per wave
     static constexpr int NBUF = (WAVES * GPW * F::G) > TILE ? (WAVES * GPW * F::G) : TILE;
     static constexpr int PROW = 2 * F::PADDED;                             // floats between consecutive P rows
-    static constexpr int CAP = MEL_STEP_BUDGET / WAVES;                    // K-steps per wave
+    static constexpr int CAP = BUDGET / WAVES;                             // K-steps per wave (register-resident)
     static constexpr int NCHUNK = CAP / MEL_CHUNK;
     static constexpr int SLOT = TILE * 16;                                 // floats per partial slot
     static_assert(PROW >= NC + 1 + 3, "P row must hold F bins + K-step overrun");
-    static_assert(CAP % MEL_CHUNK == 0 && NCHUNK <= 3, "step capacity must be whole chunks");
+    static_assert(CAP % MEL_CHUNK == 0, "step capacity must be whole chunks");
 };
 
 template <int WAVES, int CAP>
@@ -98,10 +98,10 @@ __host__ __device__ inline int mel_total_steps(const MelPlan& p, int n_band_tile
     return total;
 }
 
-template <int NC, int E, int TILE, bool POW2>
-__global__ void __launch_bounds__((MelCfg<NC, E, TILE>::WAVES * 64), 2)
+template <int NC, int E, int TILE, int BUDGET, bool POW2>
+__global__ void __launch_bounds__((MelCfg<NC, E, TILE, BUDGET>::WAVES * 64), 2)
 melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
-    using C = MelCfg<NC, E, TILE>;
+    using C = MelCfg<NC, E, TILE, BUDGET>;
     using F = typename C::F;
     using Tab = MelTables<C::WAVES, C::CAP>;
     constexpr int WAVES = C::WAVES, NBINS = NC + 1, PROW = C::PROW, CAP = C::CAP, SLOT = C::SLOT;
@@ -191,6 +191,13 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
     const float* fbl = m.fb + (kq * m.n_mels + fr);
     const float* abase = reinterpret_cast<const float*>(bufs) + (fr & (TILE - 1)) * PROW + kq;
 
+    // lane i of `step_lane[c]` keeps the (wave-uniform) word of step c*64 + i: phase B pulls each step's bin
+    // offset out with v_readlane instead of a dependent LDS table read, so the P-row reads issue back to back
+    constexpr int NSL = (CAP + 63) / 64;
+    int step_lane[NSL];
+#pragma unroll
+    for (int c = 0; c < NSL; ++c) step_lane[c] = (c * 64 + lane < CAP) ? tab->step[w][c * 64 + lane] : 0;
+
     // this wave's filter weights for phase B (its share never changes): loaded ONCE, register-resident for the
     // kernel's lifetime — steady-state phase B touches no global memory (measured 0.38 -> 0.32 ms at cfg-2)
     float breg[CAP];
@@ -199,7 +206,7 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
     for (int i = 0; i < CAP; ++i) {
         const int st = tab->step[w][i];
         const int u = (st & 0xfff) * m.n_mels + ((st >> 12) & 0xff) * 16;
-        breg[i] = fbl[u];
+        breg[i] = (i < nsteps) ? fbl[u] : 0.0f;
         if (__builtin_amdgcn_readfirstlane(st) & STEP_EDGE) {                    // rare: tile/bin edge
             const bool ok = ((st & 0xfff) + kq < NBINS) && (((st >> 12) & 0xff) * 16 + fr < m.n_mels);
             breg[i] = ok ? fbl[ok ? u : 0] : 0.0f;
@@ -263,37 +270,30 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
         __syncthreads();
         TAC_STAMP(2);
 
-        // ---------------- phase B: block-sparse P·fb on the matrix cores
+        // ---------------- phase B: block-sparse P·fb on the matrix cores.  Steps past the share's end carry
+        // zero weights (and read P[.][0]), so the chain needs no validity branch — only the flush points branch.
 #if TAC_MEL_ABL != 2
         {
             f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
             int slot = slot0;
+            float a[CAP];
 #pragma unroll
-            for (int c = 0; c < C::NCHUNK; ++c) {
-                if (c * MEL_CHUNK < nsteps) {                                        // wave-uniform
-                    float a[MEL_CHUNK];
+            for (int i = 0; i < CAP; ++i) {
+                const int st = __builtin_amdgcn_readlane(step_lane[i / 64], i % 64);   // SGPR, no memory
+                a[i] = abase[st & 0xfff];
+            }
 #pragma unroll
-                    for (int i = 0; i < MEL_CHUNK; ++i) a[i] = abase[tab->step[w][c * MEL_CHUNK + i] & 0xfff];
-                    const unsigned fl = c == 0 ? flush0 : (c == 1 ? flush1 : flush2);
-                    const unsigned fh = c == 0 ? flush1 : (c == 1 ? flush2 : 0u);
-#pragma unroll
-                    for (int i = 0; i < MEL_CHUNK; ++i) {
-                        const int gi = c * MEL_CHUNK + i;
-                        if (gi < nsteps) {                                           // wave-uniform
-                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], breg[gi], acc, 0, 0, 0);
-                            const int bit = (c * MEL_CHUNK) % 32 + i;                // position relative to word `fl`
-                            const bool flush_now = bit < 32 ? ((fl >> (bit & 31)) & 1u) : ((fh >> (bit & 31)) & 1u);
-                            if (flush_now) {
-                                // D[frame = kq*4 + r][band = fr]; only rows < TILE are real frames
-                                if (TILE == 16 || kq < 2) {
-                                    float* pp = partial + slot * SLOT + (kq * 4) * 16 + fr;
-                                    pp[0] = acc[0]; pp[16] = acc[1]; pp[32] = acc[2]; pp[48] = acc[3];
-                                }
-                                ++slot;
-                                acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                            }
-                        }
+            for (int i = 0; i < CAP; ++i) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], breg[i], acc, 0, 0, 0);
+                const unsigned word = i < 32 ? flush0 : (i < 64 ? flush1 : flush2);
+                if ((word >> (i & 31)) & 1u) {                                      // wave-uniform
+                    // D[frame = kq*4 + r][band = fr]; only rows < TILE are real frames
+                    if (TILE == 16 || kq < 2) {
+                        float* pp = partial + slot * SLOT + (kq * 4) * 16 + fr;
+                        pp[0] = acc[0]; pp[16] = acc[1]; pp[32] = acc[2]; pp[48] = acc[3];
                     }
+                    ++slot;
+                    acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                 }
             }
         }
@@ -343,21 +343,24 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
 #endif
 }
 
-template <int NC, int E, int TILE>
+template <int NC, int E, int TILE, int BUDGET>
 static size_t mel_lds_bytes(int n_band_tiles) {
-    using C = MelCfg<NC, E, TILE>;
+    using C = MelCfg<NC, E, TILE, BUDGET>;
     return (size_t)C::NBUF * C::F::PADDED * sizeof(cf) + (size_t)(n_band_tiles + C::WAVES) * C::SLOT * sizeof(float) +
            sizeof(MelTables<C::WAVES, C::CAP>);
 }
 
-template <int NC, int E, int TILE>
-static int launch_mel(const FrameGeom& g, const Tables& tb, MelArgs m, const MelPlan& plan, hipStream_t stream,
-                      bool query_only) {
-    using C = MelCfg<NC, E, TILE>;
-    const size_t lds_bytes = mel_lds_bytes<NC, E, TILE>(m.n_band_tiles);
+template <int NC, int E, int TILE, int BUDGET>
+static int launch_mel_budget(const FrameGeom& g, const Tables& tb, MelArgs m, const MelPlan& plan, hipStream_t stream,
+                             bool query_only) {
+    using C = MelCfg<NC, E, TILE, BUDGET>;
+    const size_t lds_bytes = mel_lds_bytes<NC, E, TILE, BUDGET>(m.n_band_tiles);
     if (lds_bytes > 160 * 1024) return TAC_E_UNSUPPORTED;
     if (m.power != 2.0f && m.power != 1.0f) return TAC_E_UNSUPPORTED;      // |X|^p, p not in {1, 2}: chain (2)+(4)
-    if (mel_total_steps(plan, m.n_band_tiles) > MEL_STEP_BUDGET) return TAC_E_UNSUPPORTED;   // dense bank: chain (2)+(4)
+    {   // every wave's share (ceil(total / WAVES) steps) must fit its register-resident capacity
+        const int total = mel_total_steps(plan, m.n_band_tiles);
+        if ((total + C::WAVES - 1) / C::WAVES > C::CAP) return TAC_E_UNSUPPORTED;   // dense bank: chain (2)+(4)
+    }
     for (int bt = 0; bt < m.n_band_tiles; ++bt)
         if (plan.hi[bt] > 4000 || plan.lo[bt] < 0) return TAC_E_INVALID;
     if (query_only) return TAC_OK;
@@ -370,7 +373,7 @@ static int launch_mel(const FrameGeom& g, const Tables& tb, MelArgs m, const Mel
     long long blocks = tiles < max_blocks ? tiles : max_blocks;
     if (blocks < 1) blocks = 1;
     const bool pow2 = (m.power == 2.0f);
-    auto kern = pow2 ? melspec_kernel<NC, E, TILE, true> : melspec_kernel<NC, E, TILE, false>;
+    auto kern = pow2 ? melspec_kernel<NC, E, TILE, BUDGET, true> : melspec_kernel<NC, E, TILE, BUDGET, false>;
     static bool attr_set[2] = {false, false};
     if (!attr_set[pow2]) {
         TAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -380,6 +383,17 @@ static int launch_mel(const FrameGeom& g, const Tables& tb, MelArgs m, const Mel
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::WAVES * 64), lds_bytes, stream, g, tb, m, plan);
     TAC_HIP(hipGetLastError());
     return TAC_OK;
+}
+
+// Register budget: the weights of a wave's share stay in VGPRs for the whole kernel, so the capacity is compiled
+// in.  Typical 128-band mel banks need ~300 steps per workgroup (38 per wave): the 320-step build leaves the FFT
+// phase 8 more registers than the 384-step one and is tried first.
+template <int NC, int E, int TILE>
+static int launch_mel(const FrameGeom& g, const Tables& tb, MelArgs m, const MelPlan& plan, hipStream_t stream,
+                      bool query_only) {
+    int rc = launch_mel_budget<NC, E, TILE, 320>(g, tb, m, plan, stream, query_only);
+    if (rc == TAC_E_UNSUPPORTED) rc = launch_mel_budget<NC, E, TILE, MEL_STEP_BUDGET>(g, tb, m, plan, stream, query_only);
+    return rc;
 }
 
 static int dispatch_mel(int n_fft, const FrameGeom& g, const Tables& tb, const MelArgs& m, const MelPlan& plan,
