@@ -172,10 +172,15 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
     const int slot0 = __builtin_amdgcn_readfirstlane(tab->wave_slot0[w]);
 
     cf tw[F::NTW];
-    cf ptw[F::NPAIR];
+    constexpr bool FACT = (E == 16) && (F::LPF * 32 == 2 * NC);      // W_N^{i*LPF} == W_32^i
+    cf ptw[FACT ? 1 : F::NPAIR];
     F::load_twiddles(tw, tb.w_nc, t);
+    if constexpr (FACT) {
+        ptw[0] = tb.w_n[t];
+    } else {
 #pragma unroll
-    for (int i = 0; i < F::NPAIR; ++i) ptw[i] = tb.w_n[t + i * F::LPF];
+        for (int i = 0; i < F::NPAIR; ++i) ptw[i] = tb.w_n[t + i * F::LPF];
+    }
 
     const int tiles_per_row = (int)((g.n_frames + TILE - 1) / TILE);
     const int total_tiles = (int)g.rows * tiles_per_row;
@@ -251,7 +256,8 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
                 for (int i = 0; i < F::NPAIR; ++i) {
                     const int k = t + i * F::LPF;
                     cf xa, xb;
-                    F::r2c_split(v[0][2 * i], v[0][2 * i + 1], ptw[i], xa, xb);
+                    if constexpr (FACT) F::r2c_split_factored(v[0][2 * i], v[0][2 * i + 1], ptw[0], i, xa, xb);
+                    else F::r2c_split(v[0][2 * i], v[0][2 * i + 1], ptw[FACT ? 0 : i], xa, xb);
                     xa.x *= g.scale; xa.y *= g.scale; xb.x *= g.scale; xb.y *= g.scale;
                     const float pa = xa.x * xa.x + xa.y * xa.y, pb = xb.x * xb.x + xb.y * xb.y;
                     prow[k] = POW2 ? pa : sqrtf(pa);
