@@ -90,6 +90,20 @@ int tac_melspec_f32(const float* wave, const float* window, const tac_stft_desc*
                     const float* fb, const int32_t* fb_plan_host, int32_t n_mels,
                     int db, float db_ref, float db_amin, float* out, void* stream);
 
+/* (3b) The same fused chain with a band-sparse VALU contraction instead of the MFMA tile: every (frame, band)
+ *      output is one thread's dot product over the band's contiguous bin run, weights packed in LDS.  For
+ *      triangular mel banks (1.5 % non-zero) this is the faster form; tac_melbank_pack returns
+ *      TAC_E_UNSUPPORTED for banks that are not band-sparse enough (sum over bands of the padded support
+ *      lengths > 3072), in which case callers use (3).
+ *      tac_melbank_pack: one-off per (filterbank, n_fft); copies fb to the host (synchronises `stream`), deals the
+ *      bands to lane groups longest-first and uploads wpack (DEVICE float[wpack_cap >= 3072]) and desc (DEVICE
+ *      int32[desc_cap >= 4096]); info_host: HOST int32[4] = {weight floats, desc stride, lane groups, max group load}. */
+int tac_melbank_pack(const float* fb, int32_t n_freqs, int32_t n_mels, int32_t n_fft, float* wpack,
+                     int32_t wpack_cap, int32_t* desc, int32_t desc_cap, int32_t* info_host, void* stream);
+int tac_melspec_sparse_f32(const float* wave, const float* window, const tac_stft_desc* d, float power,
+                           const float* wpack, const int32_t* desc, const int32_t* info_host, int32_t n_mels,
+                           int db, float db_ref, float db_amin, float* out, void* stream);
+
 /* TAC_OK when (3) can run this geometry + filterbank plan, TAC_E_UNSUPPORTED when it cannot
  * (no launch, no device access). */
 int tac_melspec_supported(const tac_stft_desc* d, float power, const int32_t* fb_plan_host,

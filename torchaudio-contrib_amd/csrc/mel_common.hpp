@@ -1,0 +1,106 @@
+// mel_common.hpp — pieces shared by the two fused Melspectrogram kernels (MFMA and band-sparse VALU
+// contraction): the frame-buffer geometry and phase A (FFT of a tile's frames, in-place power rows).
+#pragma once
+#include "host_common.hpp"
+
+#ifndef TAC_MEL_ABL
+#define TAC_MEL_ABL 0    // ablation builds only: 1 = skip phase A math, 2 = skip phase B, 3 = skip phase C stores
+#endif
+
+namespace tac {
+
+constexpr int MEL_STEP_BUDGET = 384;         // K-steps per workgroup held in registers during MFMA phase B
+constexpr int MEL_CHUNK = 8;                 // K-step granularity of the per-wave capacity
+
+// A workgroup owns tiles of TILE consecutive frames of one row; LDS holds one buffer per frame which is first the
+// FFT exchange area and then, in place, the frame's |X|^p row (row stride PROW floats == 2 mod 32).
+template <int NC, int E, int TILE, int BUDGET = MEL_STEP_BUDGET>
+struct MelCfg {
+    using F = WaveFft<NC, E>;
+    static constexpr int TILE_FRAMES = TILE;
+    static constexpr int GT = (TILE / F::G) >= 1 ? (TILE / F::G) : 1;      // lane-groups (waves' worth) per tile
+    static constexpr int WAVES = (TILE == 8) ? 4 : (GT >= 8 ? 8 : 4);
+    static constexpr int GPW = (GT / WAVES) >= 1 ? (GT / WAVES) : 1;       // groups (sequential FFT rounds) per wave
+    static constexpr int NBUF = (WAVES * GPW * F::G) > TILE ? (WAVES * GPW * F::G) : TILE;
+    static constexpr int PROW = 2 * F::PADDED;                             // floats between consecutive P rows
+    static constexpr int CAP = BUDGET / WAVES;                             // K-steps per wave (register-resident)
+    static constexpr int NCHUNK = CAP / MEL_CHUNK;
+    static constexpr int SLOT = TILE * 16;                                 // floats per partial slot
+    static_assert(PROW >= NC + 1 + 3, "P row must hold F bins + K-step overrun");
+    static_assert(CAP % MEL_CHUNK == 0, "step capacity must be whole chunks");
+};
+
+// Lane-invariant FFT constants of a fused kernel (registers for the kernel's lifetime).
+template <class F>
+struct MelFftConsts {
+    static constexpr bool FACT = (F::E == 16) && (F::LPF * 32 == 2 * F::NC);      // W_N^{i*LPF} == W_32^i
+    cf tw[F::NTW];
+    cf ptw[FACT ? 1 : F::NPAIR];
+    __device__ __forceinline__ void load(const Tables& tb, int t) {
+        F::load_twiddles(tw, tb.w_nc, t);
+        if constexpr (FACT) {
+            ptw[0] = tb.w_n[t];
+        } else {
+#pragma unroll
+            for (int i = 0; i < F::NPAIR; ++i) ptw[i] = tb.w_n[t + i * F::LPF];
+        }
+    }
+};
+
+// Phase A of one tile: every wave FFTs its frames and overwrites each frame buffer with the power row.
+template <class C, bool POW2>
+__device__ __forceinline__ void mel_phase_a(const FrameGeom& g, cf* bufs, const MelFftConsts<typename C::F>& k,
+                                            int w, int sub, int t, int row, long long f0) {
+    using F = typename C::F;
+    constexpr int NC = F::NC, E = F::E, NBINS = NC + 1, TILE = C::TILE_FRAMES;
+    constexpr bool FACT = MelFftConsts<F>::FACT;
+    const cf* tw = k.tw;
+    const cf* ptw = k.ptw;
+    const bool wave_has_frames = (w * C::GPW * F::G) < TILE;
+    if (wave_has_frames) {
+#pragma unroll 1
+        for (int rep = 0; rep < C::GPW; ++rep) {
+            const int fi = ((w * C::GPW + rep) * F::G) + sub;           // frame index within the tile
+            cf* lds[1] = {bufs + fi * F::PADDED};
+            cf v[1][E];
+            int tl = t;
+            asm volatile("" : "+v"(tl));      // launder: window loads stay inside the loop (register budget)
+            float2 win[F::E];
+            load_window_regs<F>(win, g, tl);
+            load_frame<F, true>(v[0], g, win, lds[0], row, (fi < TILE) ? f0 + fi : g.n_frames, t);
+#if TAC_MEL_ABL != 1
+            F::template run<1>(v, lds, tw, t);
+#endif
+            // gather every Z this lane needs BEFORE anything is overwritten (in-place row)
+#pragma unroll
+            for (int i = 0; i < F::NPAIR; ++i) {
+                const int k = t + i * F::LPF;
+                v[0][2 * i] = lds[0][lds_pad(k)];
+                v[0][2 * i + 1] = lds[0][lds_pad((NC - k) & (NC - 1))];
+            }
+            const cf zmid = lds[0][lds_pad(NC / 2)];
+            wave_lds_fence();
+            float* prow = reinterpret_cast<float*>(lds[0]);
+#pragma unroll
+            for (int i = 0; i < F::NPAIR; ++i) {
+                const int k = t + i * F::LPF;
+                cf xa, xb;
+                if constexpr (FACT) F::r2c_split_factored(v[0][2 * i], v[0][2 * i + 1], ptw[0], i, xa, xb);
+                else F::r2c_split(v[0][2 * i], v[0][2 * i + 1], ptw[FACT ? 0 : i], xa, xb);
+                xa.x *= g.scale; xa.y *= g.scale; xb.x *= g.scale; xb.y *= g.scale;
+                const float pa = xa.x * xa.x + xa.y * xa.y, pb = xb.x * xb.x + xb.y * xb.y;
+                prow[k] = POW2 ? pa : sqrtf(pa);
+                prow[NC - k] = POW2 ? pb : sqrtf(pb);
+            }
+            if (t == 0) {
+                const cf xm = make_float2(zmid.x * g.scale, -zmid.y * g.scale);    // X[NC/2] = conj(Z[NC/2])
+                const float pm = xm.x * xm.x + xm.y * xm.y;
+                prow[NC / 2] = POW2 ? pm : sqrtf(pm);
+            }
+            for (int c = t; c < 3; c += F::LPF) prow[NBINS + c] = 0.0f;           // K-step overrun columns
+        }
+    }
+
+}
+
+}  // namespace tac

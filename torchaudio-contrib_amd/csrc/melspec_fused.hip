@@ -23,11 +23,7 @@
 // MFMA / reduction / store phases could run under the other's FFT VALU work.  Measured at cfg-2 the second
 // form is slower (0.52 ms vs 0.37 ms: per-tile costs — weight burst, barriers, reduction — double while half
 // of every MFMA's 16 rows is wasted), so it is kept only as the TAC_MEL_TILE2048 A/B knob.
-#include "host_common.hpp"
-
-#ifndef TAC_MEL_ABL
-#define TAC_MEL_ABL 0    // ablation builds only: 1 = skip phase A math, 2 = skip phase B, 3 = skip phase C stores
-#endif
+#include "mel_common.hpp"
 #ifndef TAC_MEL_TILE2048
 #define TAC_MEL_TILE2048 16  // frames per tile at N = 2048 (A/B knob: 8 or 16; measured 0.52 ms vs 0.37 ms at cfg-2)
 #endif
@@ -35,8 +31,6 @@
 namespace tac {
 
 constexpr int MEL_MAX_BAND_TILES = 32;       // n_mels <= 512
-constexpr int MEL_STEP_BUDGET = 384;         // K-steps per workgroup held in registers during phase B
-constexpr int MEL_CHUNK = 8;                 // K-step granularity of the per-wave capacity
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -66,21 +60,6 @@ enum { STEP_EDGE = 1 << 20 };                // step: k | tile << 12 | edge
 #else
 #define TAC_STAMP(i) do {} while (0)
 #endif
-
-template <int NC, int E, int TILE, int BUDGET = MEL_STEP_BUDGET>
-struct MelCfg {
-    using F = WaveFft<NC, E>;
-    static constexpr int GT = (TILE / F::G) >= 1 ? (TILE / F::G) : 1;      // lane-groups (waves' worth) per tile
-    static constexpr int WAVES = (TILE == 8) ? 4 : (GT >= 8 ? 8 : 4);
-    static constexpr int GPW = (GT / WAVES) >= 1 ? (GT / WAVES) : 1;       // groups (sequential FFT rounds) per wave
-    static constexpr int NBUF = (WAVES * GPW * F::G) > TILE ? (WAVES * GPW * F::G) : TILE;
-    static constexpr int PROW = 2 * F::PADDED;                             // floats between consecutive P rows
-    static constexpr int CAP = BUDGET / WAVES;                             // K-steps per wave (register-resident)
-    static constexpr int NCHUNK = CAP / MEL_CHUNK;
-    static constexpr int SLOT = TILE * 16;                                 // floats per partial slot
-    static_assert(PROW >= NC + 1 + 3, "P row must hold F bins + K-step overrun");
-    static_assert(CAP % MEL_CHUNK == 0, "step capacity must be whole chunks");
-};
 
 template <int WAVES, int CAP>
 struct MelTables {
@@ -171,16 +150,8 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
     const unsigned flush2 = __builtin_amdgcn_readfirstlane(tab->flush[w][2]);
     const int slot0 = __builtin_amdgcn_readfirstlane(tab->wave_slot0[w]);
 
-    cf tw[F::NTW];
-    constexpr bool FACT = (E == 16) && (F::LPF * 32 == 2 * NC);      // W_N^{i*LPF} == W_32^i
-    cf ptw[FACT ? 1 : F::NPAIR];
-    F::load_twiddles(tw, tb.w_nc, t);
-    if constexpr (FACT) {
-        ptw[0] = tb.w_n[t];
-    } else {
-#pragma unroll
-        for (int i = 0; i < F::NPAIR; ++i) ptw[i] = tb.w_n[t + i * F::LPF];
-    }
+    MelFftConsts<F> fftk;
+    fftk.load(tb, t);
 
     const int tiles_per_row = (int)((g.n_frames + TILE - 1) / TILE);
     const int total_tiles = (int)g.rows * tiles_per_row;
@@ -188,7 +159,6 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
     const int begin = (int)blockIdx.x * chunk;
     const int end = begin + chunk < total_tiles ? begin + chunk : total_tiles;
 
-    const bool wave_has_frames = (w * C::GPW * F::G) < TILE;
     // phase C walks idx = tid, tid + T, ... over (band, 4-frame group) = (idx % M, idx / M) without dividing per element
     const int c_fg0 = tid / m.n_mels, c_band0 = tid % m.n_mels;
     const int c_dfg = (WAVES * 64) / m.n_mels, c_dband = (WAVES * 64) % m.n_mels;
@@ -227,51 +197,8 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
         const long long f0 = (long long)(tile - row * tiles_per_row) * TILE;
         TAC_STAMP(0);
 
-        // ---------------- phase A: FFT, then overwrite each frame buffer with its |X|^p row
-        if (wave_has_frames) {
-#pragma unroll 1
-            for (int rep = 0; rep < C::GPW; ++rep) {
-                const int fi = ((w * C::GPW + rep) * F::G) + sub;           // frame index within the tile
-                cf* lds[1] = {bufs + fi * F::PADDED};
-                cf v[1][E];
-                int tl = t;
-                asm volatile("" : "+v"(tl));      // launder: window loads stay inside the loop (register budget)
-                float2 win[F::E];
-                load_window_regs<F>(win, g, tl);
-                load_frame<F, true>(v[0], g, win, lds[0], row, (fi < TILE) ? f0 + fi : g.n_frames, t);
-#if TAC_MEL_ABL != 1
-                F::template run<1>(v, lds, tw, t);
-#endif
-                // gather every Z this lane needs BEFORE anything is overwritten (in-place row)
-#pragma unroll
-                for (int i = 0; i < F::NPAIR; ++i) {
-                    const int k = t + i * F::LPF;
-                    v[0][2 * i] = lds[0][lds_pad(k)];
-                    v[0][2 * i + 1] = lds[0][lds_pad((NC - k) & (NC - 1))];
-                }
-                const cf zmid = lds[0][lds_pad(NC / 2)];
-                wave_lds_fence();
-                float* prow = reinterpret_cast<float*>(lds[0]);
-#pragma unroll
-                for (int i = 0; i < F::NPAIR; ++i) {
-                    const int k = t + i * F::LPF;
-                    cf xa, xb;
-                    if constexpr (FACT) F::r2c_split_factored(v[0][2 * i], v[0][2 * i + 1], ptw[0], i, xa, xb);
-                    else F::r2c_split(v[0][2 * i], v[0][2 * i + 1], ptw[FACT ? 0 : i], xa, xb);
-                    xa.x *= g.scale; xa.y *= g.scale; xb.x *= g.scale; xb.y *= g.scale;
-                    const float pa = xa.x * xa.x + xa.y * xa.y, pb = xb.x * xb.x + xb.y * xb.y;
-                    prow[k] = POW2 ? pa : sqrtf(pa);
-                    prow[NC - k] = POW2 ? pb : sqrtf(pb);
-                }
-                if (t == 0) {
-                    const cf xm = make_float2(zmid.x * g.scale, -zmid.y * g.scale);    // X[NC/2] = conj(Z[NC/2])
-                    const float pm = xm.x * xm.x + xm.y * xm.y;
-                    prow[NC / 2] = POW2 ? pm : sqrtf(pm);
-                }
-                for (int c = t; c < 3; c += F::LPF) prow[NBINS + c] = 0.0f;           // K-step overrun columns
-            }
-        }
-
+        // ---------------- phase A: FFT, then overwrite each frame buffer with its |X|^p row (mel_common.hpp)
+        mel_phase_a<C, POW2>(g, bufs, fftk, w, sub, t, row, f0);
         TAC_STAMP(1);
         __syncthreads();
         TAC_STAMP(2);

@@ -1,0 +1,269 @@
+// melspec_sparse.hip — the fused Melspectrogram chain with a BAND-SPARSE VALU filterbank contraction.
+//
+// Same reference chain and phase A as melspec_fused.hip (layers.py:307-381), different phase B.  A triangular
+// mel bank has ~16 non-zero weights per band out of 1025 (1.5 %); the MFMA formulation executes 16x16x4 tiles
+// over each 16-band tile's bin range — 38 400 flop per frame for 4 042 useful ones, ~6 000 cycles per 16-frame
+// tile — and needs partial tiles + a reduction pass because the K ranges are split over waves.  Here every
+// (frame, band) output is one thread's private dot product over the band's CONTIGUOUS bin run:
+//   * 16 lanes = the 16 frames of the tile share one band at a time (weight reads are LDS broadcasts, the
+//     power-row reads hit 16 distinct banks because the row stride is 2 mod 32);
+//   * bands are dealt to the lane groups longest-first (LPT) by tac_melbank_pack, so all groups of a wave
+//     run inner loops of similar length at the same time and finish together;
+//   * weights live in LDS as 16-byte aligned, zero-padded runs: one ds_read_b128 feeds four FMAs.
+// No MFMA, no partial tiles, no weight registers: the 16 KB of partial slots become the weight + output tile
+// storage and the FFT phase gets 40 more registers.  Banks that are not band-sparse enough for the LDS budget
+// return TAC_E_UNSUPPORTED and take the MFMA kernels instead.
+#include "mel_common.hpp"
+
+#include <algorithm>
+#include <vector>
+
+namespace tac {
+
+constexpr int SP_TILE = 16;
+constexpr int SP_MAX_W = 3072;               // floats of packed weights that may live in LDS (12 KB)
+
+struct SparseArgs {
+    const float* wpack;    // device, wtot floats
+    const int* desc;       // device, groups x dstride ints: {nb,0,0,0} then nb x {band, first bin, n4, weight offset}
+    int wtot;              // multiple of 4
+    int dstride;           // multiple of 4
+    int n_mels;
+    int db;
+    float amin;
+    float log10_ref;
+    float* out;            // [rows][T][M]
+};
+
+template <int NC, int E, bool POW2>
+__global__ void __launch_bounds__((MelCfg<NC, E, SP_TILE>::WAVES * 64), 2)
+melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
+    using C = MelCfg<NC, E, SP_TILE>;
+    using F = typename C::F;
+    constexpr int WAVES = C::WAVES, PROW = C::PROW, TILE = SP_TILE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf* bufs = reinterpret_cast<cf*>(smem_raw);                                   // NBUF frame buffers
+    float* wlds = reinterpret_cast<float*>(bufs + C::NBUF * F::PADDED);           // packed weights (16-byte aligned)
+    const int ostr = m.n_mels | 1;                                                // odd row stride: conflict-free columns
+    float* otile = wlds + m.wtot;                                                 // [TILE][ostr]
+    int* dlds = reinterpret_cast<int*>(otile + ((TILE * ostr + 3) & ~3));         // [groups][dstride]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sub = lane / F::LPF;
+    const int t = lane % F::LPF;
+
+    for (int i = tid; i < m.wtot; i += WAVES * 64) wlds[i] = m.wpack[i];
+    for (int i = tid; i < WAVES * 4 * m.dstride; i += WAVES * 64) dlds[i] = m.desc[i];
+
+    MelFftConsts<F> fftk;
+    fftk.load(tb, t);
+    __syncthreads();
+
+    const int tiles_per_row = (int)((g.n_frames + TILE - 1) / TILE);
+    const int total_tiles = (int)g.rows * tiles_per_row;
+    const int chunk = (total_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int begin = (int)blockIdx.x * chunk;
+    const int end = begin + chunk < total_tiles ? begin + chunk : total_tiles;
+
+    // phase B identity of this thread: lane group (16 lanes) = one band at a time, lane in group = frame
+    const int fr = tid & 15;
+    const int* dg = dlds + (tid >> 4) * m.dstride;
+    const float* prow = reinterpret_cast<const float*>(bufs) + fr * PROW;
+    // phase C walks idx = tid, tid + T, ... over (frame, band) = (idx / M, idx % M) without dividing per element
+    const int c_f0 = tid / m.n_mels, c_band0 = tid % m.n_mels;
+    const int c_df = (WAVES * 64) / m.n_mels, c_dband = (WAVES * 64) % m.n_mels;
+
+    for (int tile = begin; tile < end; ++tile) {
+        const int row = tile / tiles_per_row;
+        const long long f0 = (long long)(tile - row * tiles_per_row) * TILE;
+
+        // ---------------- phase A: FFT, then overwrite each frame buffer with its |X|^p row (mel_common.hpp)
+        mel_phase_a<C, POW2>(g, bufs, fftk, w, sub, t, row, f0);
+        __syncthreads();
+
+        // ---------------- phase B: one private dot product per (frame, band)
+#if TAC_MEL_ABL != 2
+        {
+            const int nb = dg[0];
+            for (int b = 0; b < nb; ++b) {
+                const int4 d = *reinterpret_cast<const int4*>(dg + 4 + 4 * b);       // band, first bin, n4, weight offset
+                const float* p = prow + d.y;
+                const float4* w4 = reinterpret_cast<const float4*>(wlds + d.w);
+                float acc0 = 0.0f, acc1 = 0.0f;
+#pragma unroll 2
+                for (int j = 0; j < d.z; ++j) {
+                    const float4 wv = w4[j];
+                    acc0 = fmaf(wv.x, p[4 * j], acc0);
+                    acc1 = fmaf(wv.y, p[4 * j + 1], acc1);
+                    acc0 = fmaf(wv.z, p[4 * j + 2], acc0);
+                    acc1 = fmaf(wv.w, p[4 * j + 3], acc1);
+                }
+                otile[fr * ostr + d.x] = acc0 + acc1;
+            }
+        }
+#endif
+        __syncthreads();
+
+        // ---------------- phase C: dB epilogue + coalesced row stores of out[row][frame][0..M)
+        {
+            int fo = c_f0, band = c_band0;
+            for (int idx = tid; idx < TILE * m.n_mels; idx += WAVES * 64) {
+                float v = otile[fo * ostr + band];
+                if (m.db) v = amp_to_db(v, m.amin, m.log10_ref);
+                const long long frame = f0 + fo;
+#if TAC_MEL_ABL == 3
+                if (frame < g.n_frames && v == 12345.678f) m.out[(row * g.n_frames + frame) * m.n_mels + band] = v;
+#else
+                if (frame < g.n_frames) m.out[(row * g.n_frames + frame) * m.n_mels + band] = v;
+#endif
+                band += c_dband;
+                fo += c_df;
+                if (band >= m.n_mels) { band -= m.n_mels; ++fo; }
+            }
+        }
+        // the barrier after the next phase A orders these otile reads before the next phase-B writes
+    }
+}
+
+template <int NC, int E>
+static int sparse_groups() { return MelCfg<NC, E, SP_TILE>::WAVES * 4; }
+
+static int sparse_groups_for(int n_fft) {
+    switch (n_fft) {
+        case 32: return sparse_groups<16, 16>();
+        case 64: return sparse_groups<32, 16>();
+        case 128: return sparse_groups<64, 16>();
+        case 256: return sparse_groups<128, 16>();
+        case 512: return sparse_groups<256, 16>();
+        case 1024: return sparse_groups<512, 16>();
+        case 2048: return sparse_groups<1024, 16>();
+        default: return 0;
+    }
+}
+
+template <int NC, int E>
+static int launch_sparse(const FrameGeom& g, const Tables& tb, const SparseArgs& m, float power, hipStream_t stream) {
+    using C = MelCfg<NC, E, SP_TILE>;
+    const int ostr = m.n_mels | 1;
+    const size_t lds_bytes = (size_t)C::NBUF * C::F::PADDED * sizeof(cf) + (size_t)m.wtot * 4 +
+                             (size_t)((SP_TILE * ostr + 3) & ~3) * 4 + (size_t)C::WAVES * 4 * m.dstride * 4;
+    if (lds_bytes > 160 * 1024) return TAC_E_UNSUPPORTED;
+    const long long tiles = g.rows * ((g.n_frames + SP_TILE - 1) / SP_TILE);
+    if (tiles >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
+    int per_cu = (int)(160 * 1024 / lds_bytes);
+    if (per_cu > 2) per_cu = 2;
+    if (per_cu < 1) per_cu = 1;
+    long long max_blocks = (long long)device_cu_count() * per_cu;
+    long long blocks = tiles < max_blocks ? tiles : max_blocks;
+    if (blocks < 1) blocks = 1;
+    const bool pow2 = (power == 2.0f);
+    auto kern = pow2 ? melspec_sparse_kernel<NC, E, true> : melspec_sparse_kernel<NC, E, false>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[pow2]) {
+        TAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[pow2] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::WAVES * 64), lds_bytes, stream, g, tb, m);
+    TAC_HIP(hipGetLastError());
+    return TAC_OK;
+}
+
+}  // namespace tac
+
+extern "C" {
+
+int tac_melbank_pack(const float* fb, int32_t n_freqs, int32_t n_mels, int32_t n_fft, float* wpack,
+                     int32_t wpack_cap, int32_t* desc, int32_t desc_cap, int32_t* info_host, void* stream) {
+    using namespace tac;
+    if (!fb || !wpack || !desc || !info_host || n_freqs <= 0 || n_mels <= 0) return TAC_E_INVALID;
+    const int groups = sparse_groups_for(n_fft);
+    if (groups == 0 || n_freqs != n_fft / 2 + 1) return TAC_E_UNSUPPORTED;
+    std::vector<float> h((size_t)n_freqs * n_mels);
+    TAC_HIP(hipMemcpyAsync(h.data(), fb, h.size() * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    TAC_HIP(hipStreamSynchronize((hipStream_t)stream));
+    struct Band { int m, lo, len; };
+    std::vector<Band> bands(n_mels);
+    long long total = 0;
+    for (int m = 0; m < n_mels; ++m) {
+        int lo = n_freqs, hi = 0;
+        for (int f = 0; f < n_freqs; ++f)
+            if (h[(size_t)f * n_mels + m] != 0.0f) { lo = f < lo ? f : lo; hi = f + 1; }
+        bands[m] = {m, hi > lo ? lo : 0, hi > lo ? hi - lo : 0};
+        total += (bands[m].len + 3) & ~3;
+    }
+    if (total > SP_MAX_W || total > wpack_cap) return TAC_E_UNSUPPORTED;      // not band-sparse enough for LDS
+    // longest-processing-time dealing: sorted descending, each band to the currently lightest group
+    std::stable_sort(bands.begin(), bands.end(), [](const Band& a, const Band& b) { return a.len > b.len; });
+    std::vector<std::vector<Band>> per(groups);
+    std::vector<int> load(groups, 0);
+    for (const Band& b : bands) {
+        int best = 0;
+        for (int gI = 1; gI < groups; ++gI)
+            if (load[gI] < load[best] || (load[gI] == load[best] && per[gI].size() < per[best].size())) best = gI;
+        per[best].push_back(b);
+        load[best] += ((b.len + 3) & ~3) + 2;      // +2: per-band loop overhead in "element" units
+    }
+    size_t maxnb = 0;
+    for (auto& v : per) maxnb = std::max(maxnb, v.size());
+    const int dstride = 4 + 4 * (int)maxnb;
+    if ((long long)groups * dstride > desc_cap) return TAC_E_UNSUPPORTED;
+    std::vector<float> wp((size_t)total, 0.0f);
+    std::vector<int32_t> dd((size_t)groups * dstride, 0);
+    int woff = 0, maxload = 0;
+    for (int gI = 0; gI < groups; ++gI) {
+        dd[(size_t)gI * dstride] = (int)per[gI].size();
+        int gl = 0;
+        for (size_t bI = 0; bI < per[gI].size(); ++bI) {
+            const Band& b = per[gI][bI];
+            const int n4 = (b.len + 3) / 4;
+            int32_t* e = &dd[(size_t)gI * dstride + 4 + 4 * bI];
+            e[0] = b.m; e[1] = b.lo; e[2] = n4; e[3] = woff;
+            for (int j = 0; j < b.len; ++j) wp[woff + j] = h[(size_t)(b.lo + j) * n_mels + b.m];
+            woff += 4 * n4;
+            gl += 4 * n4;
+        }
+        maxload = std::max(maxload, gl);
+    }
+    TAC_HIP(hipMemcpyAsync(wpack, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
+    TAC_HIP(hipMemcpyAsync(desc, dd.data(), dd.size() * sizeof(int32_t), hipMemcpyHostToDevice, (hipStream_t)stream));
+    TAC_HIP(hipStreamSynchronize((hipStream_t)stream));
+    info_host[0] = (int32_t)total;
+    info_host[1] = dstride;
+    info_host[2] = groups;
+    info_host[3] = maxload;
+    return TAC_OK;
+}
+
+int tac_melspec_sparse_f32(const float* wave, const float* window, const tac_stft_desc* d, float power,
+                           const float* wpack, const int32_t* desc, const int32_t* info_host, int32_t n_mels,
+                           int db, float db_ref, float db_amin, float* out, void* stream) {
+    using namespace tac;
+    if (!wpack || !desc || !info_host || !out || !d || n_mels <= 0) return TAC_E_INVALID;
+    if (!d->onesided || d->n_fft > 2048) return TAC_E_UNSUPPORTED;
+    if (power != 2.0f && power != 1.0f) return TAC_E_UNSUPPORTED;
+    if (info_host[2] != sparse_groups_for(d->n_fft)) return TAC_E_INVALID;         // pack built for another geometry
+    FrameGeom g;
+    int64_t T = 0;
+    int rc = make_geometry(wave, window, d, &g, &T);
+    if (rc != TAC_OK) return rc;
+    Tables tb;
+    rc = get_tables(d->n_fft, &tb);
+    if (rc != TAC_OK) return rc;
+    SparseArgs m{wpack, desc, info_host[0], info_host[1], n_mels, db ? 1 : 0, db_amin, db ? log10f(db_ref) : 0.0f, out};
+    hipStream_t s = (hipStream_t)stream;
+    switch (d->n_fft) {
+        case 32: return launch_sparse<16, 16>(g, tb, m, power, s);
+        case 64: return launch_sparse<32, 16>(g, tb, m, power, s);
+        case 128: return launch_sparse<64, 16>(g, tb, m, power, s);
+        case 256: return launch_sparse<128, 16>(g, tb, m, power, s);
+        case 512: return launch_sparse<256, 16>(g, tb, m, power, s);
+        case 1024: return launch_sparse<512, 16>(g, tb, m, power, s);
+        case 2048: return launch_sparse<1024, 16>(g, tb, m, power, s);
+        default: return TAC_E_UNSUPPORTED;
+    }
+}
+
+}  // extern "C"

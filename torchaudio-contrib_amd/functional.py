@@ -9,6 +9,7 @@ logically ``(*, channel, freq, time[, 2])``).
 """
 import ctypes
 import math
+import os
 import threading
 
 import torch
@@ -190,6 +191,10 @@ class _StftPlan(object):
                 filterbank.is_cuda and filterbank.dtype == torch.float32 and
                 filterbank.device == self.wave.device and filterbank.is_contiguous()):
             return False
+        if power in (1.0, 2.0) and _MEL_PATH != 'mfma' and _melbank_pack(filterbank, self.n_fft) is not None:
+            return True
+        if _MEL_PATH == 'sparse':
+            return False
         _, host = _filterbank_plan(filterbank)
         rc = _native.lib().tac_melspec_supported(self.desc, float(power), ctypes.cast(host, ctypes.c_void_p),
                                                  filterbank.shape[1])
@@ -197,10 +202,20 @@ class _StftPlan(object):
 
     def run_melspec(self, power, filterbank, db=None):
         fb = filterbank
-        _, plan_host = _filterbank_plan(fb)
         n_mels = fb.shape[1]
         out = torch.empty(self.lead + (self.n_frames, n_mels), dtype=torch.float32, device=self.wave.device)
         ref, amin = db if db is not None else (1.0, 1e-7)
+        pack = _melbank_pack(fb, self.n_fft) if (_MEL_PATH != 'mfma' and power in (1.0, 2.0)) else None
+        if pack is not None:          # band-sparse contraction (the faster form for triangular banks)
+            wpack, desc, info = pack
+            with torch.cuda.device(self.wave.device):
+                rc = _native.lib().tac_melspec_sparse_f32(
+                    _native.ptr(self.wave), _native.ptr(self.window), self.desc, float(power), _native.ptr(wpack),
+                    _native.ptr(desc), ctypes.cast(info, ctypes.c_void_p), n_mels, 1 if db is not None else 0,
+                    float(ref), float(amin), _native.ptr(out), _native.stream_ptr(self.wave.device))
+            _native.check(rc, 'tac_melspec_sparse_f32')
+            return out.transpose(-2, -1)
+        _, plan_host = _filterbank_plan(fb)
         with torch.cuda.device(self.wave.device):
             rc = _native.lib().tac_melspec_f32(
                 _native.ptr(self.wave), _native.ptr(self.window), self.desc, float(power), _native.ptr(fb),
@@ -237,6 +252,41 @@ def _dft_matrix(window, n_fft, win_length, onesided, normalized):
     except Exception:
         pass
     return dev
+
+
+# A/B knob for the two fused Melspectrogram kernels: 'auto' (band-sparse when the bank allows it, else MFMA),
+# 'sparse', 'mfma'
+_MEL_PATH = os.environ.get('TAC_MEL_PATH', 'auto')
+
+
+def _melbank_pack(fb, n_fft):
+    """(wpack, desc, info) device/host buffers of the band-sparse contraction for this filterbank and fft size, or
+    None when the bank is not band-sparse enough (then the MFMA kernels are used).  Built once per filterbank
+    version (one host sync) and cached on the tensor object."""
+    cache = getattr(fb, '_tac_pack', None)
+    if cache is None or cache[0] != fb._version:
+        cache = (fb._version, {})
+        try:
+            fb._tac_pack = cache
+        except Exception:
+            pass
+    if n_fft in cache[1]:
+        return cache[1][n_fft]
+    n_freqs, n_mels = fb.shape
+    wpack = torch.empty(3072, dtype=torch.float32, device=fb.device)
+    desc = torch.empty(4096, dtype=torch.int32, device=fb.device)
+    info = (ctypes.c_int32 * 4)()
+    with torch.cuda.device(fb.device):
+        rc = _native.lib().tac_melbank_pack(_native.ptr(fb), n_freqs, n_mels, n_fft, _native.ptr(wpack), 3072,
+                                            _native.ptr(desc), 4096, ctypes.cast(info, ctypes.c_void_p),
+                                            _native.stream_ptr(fb.device))
+    if rc == _native.TAC_E_UNSUPPORTED:
+        result = None
+    else:
+        _native.check(rc, 'tac_melbank_pack')
+        result = (wpack, desc, info)
+    cache[1][n_fft] = result
+    return result
 
 
 def _filterbank_plan(fb):
