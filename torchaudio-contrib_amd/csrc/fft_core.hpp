@@ -408,6 +408,32 @@ __device__ __forceinline__ void load_frame(cf* v, const FrameGeom& g, const floa
     }
 }
 
+// ---- split-phase variant for software prefetch: issue the raw (unwindowed) loads of an interior frame
+// early, apply the window when the frame is consumed.  Returns false (nothing loaded) for frames that
+// touch the padding or lie past the end — those go through load_frame() at consumption time.
+template <class F>
+__device__ __forceinline__ bool prefetch_frame_raw(float2* raw, const FrameGeom& g, long long row, long long frame,
+                                                   int t) {
+    constexpr int R0 = radix_at(F::NC, 0);
+    constexpr int NB = F::E / R0;
+    const long long start = frame * (long long)g.hop - g.center_pad;
+    const bool ok = g.vec2_ok && frame < g.n_frames && start >= 0 && start + F::N <= g.length;
+    if (ok) {
+        const float2* src = reinterpret_cast<const float2*>(g.wave + row * g.row_stride + start);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int q = 0; q < R0; ++q) raw[b * R0 + q] = src[t + b * F::LPF + q * (F::NC / R0)];
+    }
+    return ok;
+}
+
+template <class F>
+__device__ __forceinline__ void apply_window(cf* v, const float2* raw, const float2* win) {
+#pragma unroll
+    for (int e = 0; e < F::E; ++e) v[e] = make_float2(raw[e].x * win[e].x, raw[e].y * win[e].y);
+}
+
 template <class F>
 __device__ __forceinline__ void load_window_regs(float2* win, const FrameGeom& g, int t) {
     constexpr int R0 = radix_at(F::NC, 0);

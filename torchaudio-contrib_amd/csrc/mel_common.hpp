@@ -31,12 +31,15 @@ struct MelCfg {
 };
 
 // Lane-invariant FFT constants of a fused kernel (registers for the kernel's lifetime).
-template <class F>
+template <class F, bool HOISTW = false>
 struct MelFftConsts {
     static constexpr bool FACT = (F::E == 16) && (F::LPF * 32 == 2 * F::NC);      // W_N^{i*LPF} == W_32^i
+    static constexpr bool HOIST_WINDOW = HOISTW;
     cf tw[F::NTW];
     cf ptw[FACT ? 1 : F::NPAIR];
-    __device__ __forceinline__ void load(const Tables& tb, int t) {
+    float2 win[HOISTW ? F::E : 1];            // window pairs of this lane's elements (kernels with spare registers)
+    __device__ __forceinline__ void load(const Tables& tb, const FrameGeom& g, int t) {
+        if constexpr (HOISTW) load_window_regs<F>(win, g, t);
         F::load_twiddles(tw, tb.w_nc, t);
         if constexpr (FACT) {
             ptw[0] = tb.w_n[t];
@@ -48,59 +51,74 @@ struct MelFftConsts {
 };
 
 // Phase A of one tile: every wave FFTs its frames and overwrites each frame buffer with the power row.
-template <class C, bool POW2>
-__device__ __forceinline__ void mel_phase_a(const FrameGeom& g, cf* bufs, const MelFftConsts<typename C::F>& k,
-                                            int w, int sub, int t, int row, long long f0) {
+// NFA = frames advanced together per wave (1, or 2 when the wave owns two frames of the tile and the kernel has
+// the registers for it: the second in-flight frame hides the LDS round trips of the first).
+// pre_raw / pre_ok: optional software prefetch of the wave's FIRST frame of this tile (raw samples requested
+// during the previous tile's contraction / store phases; G == 1 geometries only).
+template <class C, bool POW2, int NFA = 1, bool HOISTW = false>
+__device__ __forceinline__ void mel_phase_a(const FrameGeom& g, cf* bufs, const MelFftConsts<typename C::F, HOISTW>& k,
+                                            int w, int sub, int t, int row, long long f0,
+                                            const float2* pre_raw = nullptr, bool pre_ok = false) {
     using F = typename C::F;
     constexpr int NC = F::NC, E = F::E, NBINS = NC + 1, TILE = C::TILE_FRAMES;
-    constexpr bool FACT = MelFftConsts<F>::FACT;
+    constexpr bool FACT = MelFftConsts<F, HOISTW>::FACT;
+    constexpr int NF = (C::GPW % NFA == 0) ? NFA : 1;
     const cf* tw = k.tw;
     const cf* ptw = k.ptw;
     const bool wave_has_frames = (w * C::GPW * F::G) < TILE;
     if (wave_has_frames) {
 #pragma unroll 1
-        for (int rep = 0; rep < C::GPW; ++rep) {
-            const int fi = ((w * C::GPW + rep) * F::G) + sub;           // frame index within the tile
-            cf* lds[1] = {bufs + fi * F::PADDED};
-            cf v[1][E];
+        for (int rep = 0; rep < C::GPW; rep += NF) {
+            cf* lds[NF];
+            int fi[NF];
+            cf v[NF][E];
             int tl = t;
             asm volatile("" : "+v"(tl));      // launder: window loads stay inside the loop (register budget)
-            float2 win[F::E];
-            load_window_regs<F>(win, g, tl);
-            load_frame<F, true>(v[0], g, win, lds[0], row, (fi < TILE) ? f0 + fi : g.n_frames, t);
+            float2 winl[HOISTW ? 1 : F::E];
+            if constexpr (!HOISTW) load_window_regs<F>(winl, g, tl);
+            const float2* win = HOISTW ? k.win : winl;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                fi[f] = ((w * C::GPW + rep + f) * F::G) + sub;              // frame index within the tile
+                lds[f] = bufs + fi[f] * F::PADDED;
+                if (f == 0 && rep == 0 && pre_ok) apply_window<F>(v[f], pre_raw, win);
+                else load_frame<F, true>(v[f], g, win, lds[f], row, (fi[f] < TILE) ? f0 + fi[f] : g.n_frames, t);
+            }
 #if TAC_MEL_ABL != 1
-            F::template run<1>(v, lds, tw, t);
+            F::template run<NF>(v, lds, tw, t);
 #endif
-            // gather every Z this lane needs BEFORE anything is overwritten (in-place row)
 #pragma unroll
-            for (int i = 0; i < F::NPAIR; ++i) {
-                const int k = t + i * F::LPF;
-                v[0][2 * i] = lds[0][lds_pad(k)];
-                v[0][2 * i + 1] = lds[0][lds_pad((NC - k) & (NC - 1))];
-            }
-            const cf zmid = lds[0][lds_pad(NC / 2)];
-            wave_lds_fence();
-            float* prow = reinterpret_cast<float*>(lds[0]);
+            for (int f = 0; f < NF; ++f) {
+                // gather every Z this lane needs BEFORE anything is overwritten (in-place row)
 #pragma unroll
-            for (int i = 0; i < F::NPAIR; ++i) {
-                const int k = t + i * F::LPF;
-                cf xa, xb;
-                if constexpr (FACT) F::r2c_split_factored(v[0][2 * i], v[0][2 * i + 1], ptw[0], i, xa, xb);
-                else F::r2c_split(v[0][2 * i], v[0][2 * i + 1], ptw[FACT ? 0 : i], xa, xb);
-                xa.x *= g.scale; xa.y *= g.scale; xb.x *= g.scale; xb.y *= g.scale;
-                const float pa = xa.x * xa.x + xa.y * xa.y, pb = xb.x * xb.x + xb.y * xb.y;
-                prow[k] = POW2 ? pa : sqrtf(pa);
-                prow[NC - k] = POW2 ? pb : sqrtf(pb);
+                for (int i = 0; i < F::NPAIR; ++i) {
+                    const int kk = t + i * F::LPF;
+                    v[f][2 * i] = lds[f][lds_pad(kk)];
+                    v[f][2 * i + 1] = lds[f][lds_pad((NC - kk) & (NC - 1))];
+                }
+                const cf zmid = lds[f][lds_pad(NC / 2)];
+                wave_lds_fence();
+                float* prow = reinterpret_cast<float*>(lds[f]);
+#pragma unroll
+                for (int i = 0; i < F::NPAIR; ++i) {
+                    const int kk = t + i * F::LPF;
+                    cf xa, xb;
+                    if constexpr (FACT) F::r2c_split_factored(v[f][2 * i], v[f][2 * i + 1], ptw[0], i, xa, xb);
+                    else F::r2c_split(v[f][2 * i], v[f][2 * i + 1], ptw[FACT ? 0 : i], xa, xb);
+                    xa.x *= g.scale; xa.y *= g.scale; xb.x *= g.scale; xb.y *= g.scale;
+                    const float pa = xa.x * xa.x + xa.y * xa.y, pb = xb.x * xb.x + xb.y * xb.y;
+                    prow[kk] = POW2 ? pa : sqrtf(pa);
+                    prow[NC - kk] = POW2 ? pb : sqrtf(pb);
+                }
+                if (t == 0) {
+                    const cf xm = make_float2(zmid.x * g.scale, -zmid.y * g.scale);    // X[NC/2] = conj(Z[NC/2])
+                    const float pm = xm.x * xm.x + xm.y * xm.y;
+                    prow[NC / 2] = POW2 ? pm : sqrtf(pm);
+                }
+                for (int c = t; c < 3; c += F::LPF) prow[NBINS + c] = 0.0f;           // K-step overrun columns
             }
-            if (t == 0) {
-                const cf xm = make_float2(zmid.x * g.scale, -zmid.y * g.scale);    // X[NC/2] = conj(Z[NC/2])
-                const float pm = xm.x * xm.x + xm.y * xm.y;
-                prow[NC / 2] = POW2 ? pm : sqrtf(pm);
-            }
-            for (int c = t; c < 3; c += F::LPF) prow[NBINS + c] = 0.0f;           // K-step overrun columns
         }
     }
-
 }
 
 }  // namespace tac

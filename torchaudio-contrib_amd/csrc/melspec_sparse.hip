@@ -18,6 +18,16 @@
 #include <algorithm>
 #include <vector>
 
+#ifndef TAC_SP_PREFETCH
+#define TAC_SP_PREFETCH 0   // prefetch the next tile's first frame per wave during phases B/C (A/B knob; measured neutral)
+#endif
+#ifndef TAC_SP_HOISTW
+#define TAC_SP_HOISTW 1    // keep the window in registers for the kernel's lifetime (A/B knob)
+#endif
+#ifndef TAC_SP_NF
+#define TAC_SP_NF 1      // frames advanced together per wave in phase A (A/B knob; 2 spills 128 B and measures 10 % slower)
+#endif
+
 namespace tac {
 
 constexpr int SP_TILE = 16;
@@ -57,8 +67,8 @@ melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
     for (int i = tid; i < m.wtot; i += WAVES * 64) wlds[i] = m.wpack[i];
     for (int i = tid; i < WAVES * 4 * m.dstride; i += WAVES * 64) dlds[i] = m.desc[i];
 
-    MelFftConsts<F> fftk;
-    fftk.load(tb, t);
+    MelFftConsts<F, TAC_SP_HOISTW != 0> fftk;
+    fftk.load(tb, g, t);
     __syncthreads();
 
     const int tiles_per_row = (int)((g.n_frames + TILE - 1) / TILE);
@@ -75,12 +85,30 @@ melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
     const int c_f0 = tid / m.n_mels, c_band0 = tid % m.n_mels;
     const int c_df = (WAVES * 64) / m.n_mels, c_dband = (WAVES * 64) % m.n_mels;
 
+    // software prefetch of this wave's first frame of the NEXT tile (raw samples, 32 registers that are idle during
+    // the contraction and store phases): its HBM/L2 round trip is hidden instead of opening every phase A
+    constexpr bool PREFETCH = (F::G == 1) && (TAC_SP_PREFETCH != 0);
+    float2 raw[PREFETCH ? F::E : 1];
+    bool pre_ok = false;
+    if constexpr (PREFETCH) {
+        if (begin < end) {
+            const int r0 = begin / tiles_per_row;
+            pre_ok = prefetch_frame_raw<F>(raw, g, r0, (long long)(begin - r0 * tiles_per_row) * TILE + w * C::GPW, t);
+        }
+    }
+
     for (int tile = begin; tile < end; ++tile) {
         const int row = tile / tiles_per_row;
         const long long f0 = (long long)(tile - row * tiles_per_row) * TILE;
 
         // ---------------- phase A: FFT, then overwrite each frame buffer with its |X|^p row (mel_common.hpp)
-        mel_phase_a<C, POW2>(g, bufs, fftk, w, sub, t, row, f0);
+        mel_phase_a<C, POW2, TAC_SP_NF, TAC_SP_HOISTW != 0>(g, bufs, fftk, w, sub, t, row, f0, raw, pre_ok);
+        if constexpr (PREFETCH) {
+            const int nt = tile + 1;
+            const int nr = nt / tiles_per_row;
+            pre_ok = (nt < end) &&
+                     prefetch_frame_raw<F>(raw, g, nr, (long long)(nt - nr * tiles_per_row) * TILE + w * C::GPW, t);
+        }
         __syncthreads();
 
         // ---------------- phase B: one private dot product per (frame, band)
