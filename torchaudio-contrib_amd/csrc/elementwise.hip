@@ -93,19 +93,24 @@ mulaw_encode_kernel(const float* __restrict__ x, long long n, float mu, float lo
         for (int i = threadIdx.x; i < n_pos + n_neg; i += blockDim.x) s_thr[i] = thr[i];
         __syncthreads();
     }
+    // |x| <= 1 with a threshold table: the code is the number of thresholds <= |x|'s bit pattern.  A cheap
+    // estimate (hardware log2, within +-1 code) picks the starting index and two branch-free compare steps in
+    // each direction make it exact; the precise closed form is only evaluated for out-of-range inputs.
+    const float est_scale = 0.5f * mu / (log1p_mu * 1.4426950408889634f);         // codes per log2 unit
     auto encode = [&](float v) -> long long {
-        const long long est = mulaw_formula(v, mu, log1p_mu);
-        if (!use_thr) return est;
         const unsigned raw = __float_as_uint(v);
         const int bits = (int)(raw & 0x7fffffffu);
-        if (bits > 0x3f800000) return est;                        // |x| > 1 or NaN: closed form
+        if (!use_thr || bits > 0x3f800000) return mulaw_formula(v, mu, log1p_mu);   // no table, |x| > 1 or NaN
         const bool neg = (raw >> 31) != 0;
         const int* tb = neg ? s_thr + n_pos : s_thr;
         const int nt = neg ? n_neg : n_pos;
-        long long c = neg ? (long long)zero_code - est : est - (long long)zero_code;
-        int cnt = c < 0 ? 0 : (c > nt ? nt : (int)c);
-        while (cnt < nt && tb[cnt] <= bits) ++cnt;
-        while (cnt > 0 && tb[cnt - 1] > bits) --cnt;
+        int cnt = (int)(__log2f(1.0f + mu * __uint_as_float((unsigned)bits)) * est_scale + 0.5f);
+        cnt = cnt < 0 ? 0 : (cnt > nt ? nt : cnt);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            cnt += (cnt < nt && tb[cnt < nt ? cnt : nt - 1] <= bits) ? 1 : 0;
+            cnt -= (cnt > 0 && tb[cnt > 0 ? cnt - 1 : 0] > bits) ? 1 : 0;
+        }
         return neg ? (long long)(zero_code - cnt) : (long long)(zero_code + cnt);
     };
     const long long stride = (long long)gridDim.x * blockDim.x;
