@@ -82,6 +82,7 @@ def test_g2_melspectrogram_db(tac, golden):
     tac.set_lazy_fusion(False)
     try:
         y2 = full(x)
+        if path == 'sparse':                             # (a small dense bank still fits the MFMA form's step budget)
         assert not isinstance(y2, tac.DeferredSpectral)
         assert np.abs(host(y2) - g['mel_db']).max() < DB_ABS
     finally:
@@ -227,6 +228,60 @@ def test_apply_filterbank_mel_sparse_plan(tac):
     got = host(tac.apply_filterbank(dev(spec), fb.cuda()))
     want = np.einsum('rft,fm->rmt', spec.astype(np.float64), fb.numpy().astype(np.float64))
     assert rel_err(got, want) < 1e-5
+
+
+@pytest.mark.parametrize('path', ['sparse', 'mfma'])
+def test_fused_kernels_on_custom_filterbanks(tac, path, monkeypatch):
+    """Both fused contraction forms against float64 on banks that stress the packing: a band with no support, a band
+    with interior zeros, n_mels not a multiple of 16, weights reaching the last bin; plus a dense random bank, which
+    the band-sparse form rejects (falls back to the MFMA form or to spectrogram + MFMA GEMM kernels) — all through the layer chain."""
+    import torchaudio_contrib_amd.functional as Fn
+    monkeypatch.setattr(Fn, '_MEL_PATH', path)
+    x = signals.audio_like((3, 2, 20000), seed=41)
+    n_fft, hop, f_bins = 1024, 256, 513
+    rng = np.random.default_rng(7)
+    fb = np.zeros((f_bins, 50), dtype=np.float32)
+    for m in range(50):
+        lo = int(rng.integers(0, f_bins - 40))
+        ln = int(rng.integers(1, 40))
+        fb[lo:lo + ln, m] = rng.random(ln).astype(np.float32) + 0.1
+    fb[:, 7] = 0.0                                   # empty band
+    fb[100:140, 9] = 1.0
+    fb[110:130, 9] = 0.0                             # interior zeros inside the support
+    fb[f_bins - 5:, 49] = 2.0                        # support touching the Nyquist bin
+    chain = torch.nn.Sequential(tac.STFT(n_fft, hop), tac.ComplexNorm(2.0), tac.ApplyFilterbank(torch.from_numpy(fb)),
+                                tac.AmplitudeToDb()).cuda()
+    y = chain(dev(x))
+    assert isinstance(y, tac.DeferredSpectral) and y._stage == 'mel'          # really fused
+    p = np.abs(numpy_ref.stft(x, n_fft, hop)) ** 2
+    mel = np.einsum('...ft,fm->...mt', p, fb.astype(np.float64))
+    want = 10.0 * np.log10(np.maximum(mel ** 2, 1e-7))
+    assert np.abs(host(y) - want).max() < DB_ABS
+    lin = torch.nn.Sequential(*list(chain)[:3])(dev(x))
+    assert rel_err(host(lin), mel) < 1e-5
+    # magnitude (power = 1) chain takes the same kernels
+    chain1 = torch.nn.Sequential(tac.STFT(n_fft, hop), tac.ComplexNorm(1.0), tac.ApplyFilterbank(torch.from_numpy(fb))).cuda()
+    assert rel_err(host(chain1(dev(x))), np.einsum('...ft,fm->...mt', np.sqrt(p), fb.astype(np.float64))) < 1e-5
+    # dense random bank: not fusable, still exact
+    dense = signals.uniform((f_bins, 24), seed=42)
+    chain2 = torch.nn.Sequential(tac.STFT(n_fft, hop), tac.ComplexNorm(2.0), tac.ApplyFilterbank(torch.from_numpy(dense))).cuda()
+    y2 = chain2(dev(x))
+    if path == 'sparse':                             # (a small dense bank still fits the MFMA form's step budget)
+        assert not isinstance(y2, tac.DeferredSpectral)
+    assert rel_err(host(y2), np.einsum('...ft,fm->...mt', p, dense.astype(np.float64))) < 1e-5
+
+
+def test_filterbank_buffer_replaced_in_place_is_repacked(tac):
+    """The pack / plan ride on the filterbank tensor and follow in-place edits (no stale cache)."""
+    x = dev(signals.audio_like((2, 1, 9000), seed=43))
+    mel = tac.Melspectrogram(num_mels=32, sample_rate=16000, fft_length=512, hop_length=128).cuda()
+    y1 = host(mel(x))
+    mel[2].filterbank.mul_(2.0)
+    y2 = host(mel(x))
+    assert rel_err(y2, 2.0 * y1) < 1e-6
+    mel[2].filterbank[:, :16] = 0.0
+    y3 = host(mel(x))
+    assert np.abs(y3[:, :, :16]).max() == 0.0 and rel_err(y3[:, :, 16:], y2[:, :, 16:]) < 1e-6
 
 
 def test_amplitude_db_known_answers(tac, golden):
