@@ -82,7 +82,6 @@ def test_g2_melspectrogram_db(tac, golden):
     tac.set_lazy_fusion(False)
     try:
         y2 = full(x)
-        if path == 'sparse':                             # (a small dense bank still fits the MFMA form's step budget)
         assert not isinstance(y2, tac.DeferredSpectral)
         assert np.abs(host(y2) - g['mel_db']).max() < DB_ABS
     finally:
