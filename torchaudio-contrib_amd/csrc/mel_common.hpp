@@ -26,7 +26,7 @@ struct MelCfg {
     static constexpr int CAP = BUDGET / WAVES;                             // K-steps per wave (register-resident)
     static constexpr int NCHUNK = CAP / MEL_CHUNK;
     static constexpr int SLOT = TILE * 16;                                 // floats per partial slot
-    static_assert(PROW >= NC + 1 + 3, "P row must hold F bins + K-step overrun");
+    static_assert(PROW >= NC + 1 + 7, "P row must hold F bins + contraction overrun");
     static_assert(CAP % MEL_CHUNK == 0, "step capacity must be whole chunks");
 };
 
@@ -115,7 +115,7 @@ __device__ __forceinline__ void mel_phase_a(const FrameGeom& g, cf* bufs, const 
                     const float pm = xm.x * xm.x + xm.y * xm.y;
                     prow[NC / 2] = POW2 ? pm : sqrtf(pm);
                 }
-                for (int c = t; c < 3; c += F::LPF) prow[NBINS + c] = 0.0f;           // K-step overrun columns
+                for (int c = t; c < 7; c += F::LPF) prow[NBINS + c] = 0.0f;           // contraction overrun columns
             }
         }
     }

@@ -35,7 +35,7 @@ constexpr int SP_MAX_W = 3072;               // floats of packed weights that ma
 
 struct SparseArgs {
     const float* wpack;    // device, wtot floats
-    const int* desc;       // device, groups x dstride ints: {nb,0,0,0} then nb x {band, first bin, n4, weight offset}
+    const int* desc;       // device, groups x dstride ints: {nb,0,0,0} then nb x {band, first bin, n8, weight offset}
     int wtot;              // multiple of 4
     int dstride;           // multiple of 4
     int n_mels;
@@ -116,19 +116,26 @@ melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
         {
             const int nb = dg[0];
             for (int b = 0; b < nb; ++b) {
-                const int4 d = *reinterpret_cast<const int4*>(dg + 4 + 4 * b);       // band, first bin, n4, weight offset
+                const int4 d = *reinterpret_cast<const int4*>(dg + 4 + 4 * b);       // band, first bin, n8, weight offset
                 const float* p = prow + d.y;
                 const float4* w4 = reinterpret_cast<const float4*>(wlds + d.w);
-                float acc0 = 0.0f, acc1 = 0.0f;
-#pragma unroll 2
+                float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
+                // 8 taps per trip: 2 weight vectors (LDS broadcast) + 8 row reads in flight before the FMAs — the
+                // loop is LDS-latency-bound, so fewer, fatter trips is what shortens it
                 for (int j = 0; j < d.z; ++j) {
-                    const float4 wv = w4[j];
-                    acc0 = fmaf(wv.x, p[4 * j], acc0);
-                    acc1 = fmaf(wv.y, p[4 * j + 1], acc1);
-                    acc0 = fmaf(wv.z, p[4 * j + 2], acc0);
-                    acc1 = fmaf(wv.w, p[4 * j + 3], acc1);
+                    const float4 wa = w4[2 * j], wb = w4[2 * j + 1];
+                    const float* q = p + 8 * j;
+                    const float p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3], p4 = q[4], p5 = q[5], p6 = q[6], p7 = q[7];
+                    acc0 = fmaf(wa.x, p0, acc0);
+                    acc1 = fmaf(wa.y, p1, acc1);
+                    acc2 = fmaf(wa.z, p2, acc2);
+                    acc3 = fmaf(wa.w, p3, acc3);
+                    acc0 = fmaf(wb.x, p4, acc0);
+                    acc1 = fmaf(wb.y, p5, acc1);
+                    acc2 = fmaf(wb.z, p6, acc2);
+                    acc3 = fmaf(wb.w, p7, acc3);
                 }
-                otile[fr * ostr + d.x] = acc0 + acc1;
+                otile[fr * ostr + d.x] = (acc0 + acc1) + (acc2 + acc3);
             }
         }
 #endif
@@ -220,7 +227,7 @@ int tac_melbank_pack(const float* fb, int32_t n_freqs, int32_t n_mels, int32_t n
         for (int f = 0; f < n_freqs; ++f)
             if (h[(size_t)f * n_mels + m] != 0.0f) { lo = f < lo ? f : lo; hi = f + 1; }
         bands[m] = {m, hi > lo ? lo : 0, hi > lo ? hi - lo : 0};
-        total += (bands[m].len + 3) & ~3;
+        total += (bands[m].len + 7) & ~7;
     }
     if (total > SP_MAX_W || total > wpack_cap) return TAC_E_UNSUPPORTED;      // not band-sparse enough for LDS
     // longest-processing-time dealing: sorted descending, each band to the currently lightest group
@@ -232,7 +239,7 @@ int tac_melbank_pack(const float* fb, int32_t n_freqs, int32_t n_mels, int32_t n
         for (int gI = 1; gI < groups; ++gI)
             if (load[gI] < load[best] || (load[gI] == load[best] && per[gI].size() < per[best].size())) best = gI;
         per[best].push_back(b);
-        load[best] += ((b.len + 3) & ~3) + 2;      // +2: per-band loop overhead in "element" units
+        load[best] += ((b.len + 7) & ~7) + 4;      // +4: per-band loop overhead in "element" units
     }
     size_t maxnb = 0;
     for (auto& v : per) maxnb = std::max(maxnb, v.size());
@@ -246,12 +253,12 @@ int tac_melbank_pack(const float* fb, int32_t n_freqs, int32_t n_mels, int32_t n
         int gl = 0;
         for (size_t bI = 0; bI < per[gI].size(); ++bI) {
             const Band& b = per[gI][bI];
-            const int n4 = (b.len + 3) / 4;
+            const int n8 = (b.len + 7) / 8;
             int32_t* e = &dd[(size_t)gI * dstride + 4 + 4 * bI];
-            e[0] = b.m; e[1] = b.lo; e[2] = n4; e[3] = woff;
+            e[0] = b.m; e[1] = b.lo; e[2] = n8; e[3] = woff;
             for (int j = 0; j < b.len; ++j) wp[woff + j] = h[(size_t)(b.lo + j) * n_mels + b.m];
-            woff += 4 * n4;
-            gl += 4 * n4;
+            woff += 8 * n8;
+            gl += 8 * n8;
         }
         maxload = std::max(maxload, gl);
     }
