@@ -283,6 +283,24 @@ struct WaveFft {
     __device__ static __forceinline__ void r2c_pair(const cf* lds, int k, cf wk, cf& xa, cf& xb) {
         r2c_split(lds[lds_pad(k)], lds[lds_pad((NC - k) & (NC - 1))], wk, xa, xb);
     }
+    // 2·X[k] and 2·X[NC-k]: the halvings of the even/odd split are left to the caller's epilogue factor
+    __device__ static __forceinline__ void r2c_split_x2(cf zk, cf zm, cf wk, cf& xa, cf& xb) {
+        cf ev = make_float2(zk.x + zm.x, zk.y - zm.y);
+        cf od = make_float2(zk.y + zm.y, zm.x - zk.x);
+        cf tw = cmul(wk, od);
+        xa = cadd(ev, tw);
+        cf d = csub(ev, tw);
+        xb = make_float2(d.x, -d.y);
+    }
+    __device__ static __forceinline__ void r2c_split_factored_x2(cf zk, cf zm, cf w0, int i, cf& xa, cf& xb) {
+        static_assert(E == 16, "factored R2C twiddles are wired for 2E = 32");
+        cf ev = make_float2(zk.x + zm.x, zk.y - zm.y);
+        cf od = make_float2(zk.y + zm.y, zm.x - zk.x);
+        cf tw = cmul(w0, mul_w32(od, i));
+        xa = cadd(ev, tw);
+        cf d = csub(ev, tw);
+        xb = make_float2(d.x, -d.y);
+    }
     // Pair index i uses W_N^{t + i*LPF} = W_N^t · W_{2E}^i: one lane-dependent register (w0 = W_N^t) and a
     // COMPILE-TIME constant per pair instead of E/2 hoisted twiddles (E == 16 only: W_32^i).
     __device__ static __forceinline__ void r2c_split_factored(cf zk, cf zm, cf w0, int i, cf& xa, cf& xb) {

@@ -31,9 +31,11 @@ struct MelCfg {
 };
 
 // Lane-invariant FFT constants of a fused kernel (registers for the kernel's lifetime).
+// HOISTW: window register-resident too.  Kernels with spare registers (HOISTW) also keep all E/2 R2C twiddles
+// instead of the factored form (one register x compile-time constants), saving its extra complex multiplies.
 template <class F, bool HOISTW = false>
 struct MelFftConsts {
-    static constexpr bool FACT = (F::E == 16) && (F::LPF * 32 == 2 * F::NC);      // W_N^{i*LPF} == W_32^i
+    static constexpr bool FACT = !HOISTW && (F::E == 16) && (F::LPF * 32 == 2 * F::NC);      // W_N^{i*LPF} == W_32^i
     static constexpr bool HOIST_WINDOW = HOISTW;
     cf tw[F::NTW];
     cf ptw[FACT ? 1 : F::NPAIR];
@@ -97,16 +99,17 @@ __device__ __forceinline__ void mel_phase_a(const FrameGeom& g, cf* bufs, const 
                     v[f][2 * i + 1] = lds[f][lds_pad((NC - kk) & (NC - 1))];
                 }
                 const cf zmid = lds[f][lds_pad(NC / 2)];
+                const float pfac = 0.25f * g.scale * g.scale;              // |2X|^2 -> |scale·X|^2
                 wave_lds_fence();
                 float* prow = reinterpret_cast<float*>(lds[f]);
 #pragma unroll
                 for (int i = 0; i < F::NPAIR; ++i) {
                     const int kk = t + i * F::LPF;
                     cf xa, xb;
-                    if constexpr (FACT) F::r2c_split_factored(v[f][2 * i], v[f][2 * i + 1], ptw[0], i, xa, xb);
-                    else F::r2c_split(v[f][2 * i], v[f][2 * i + 1], ptw[FACT ? 0 : i], xa, xb);
-                    xa.x *= g.scale; xa.y *= g.scale; xb.x *= g.scale; xb.y *= g.scale;
-                    const float pa = xa.x * xa.x + xa.y * xa.y, pb = xb.x * xb.x + xb.y * xb.y;
+                    // xa, xb = 2·X: the halving and the `normalized` scale are one factor applied to the power
+                    if constexpr (FACT) F::r2c_split_factored_x2(v[f][2 * i], v[f][2 * i + 1], ptw[0], i, xa, xb);
+                    else F::r2c_split_x2(v[f][2 * i], v[f][2 * i + 1], ptw[FACT ? 0 : i], xa, xb);
+                    const float pa = (xa.x * xa.x + xa.y * xa.y) * pfac, pb = (xb.x * xb.x + xb.y * xb.y) * pfac;
                     prow[kk] = POW2 ? pa : sqrtf(pa);
                     prow[NC - kk] = POW2 ? pb : sqrtf(pb);
                 }

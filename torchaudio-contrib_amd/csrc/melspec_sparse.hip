@@ -21,6 +21,9 @@
 #ifndef TAC_SP_PREFETCH
 #define TAC_SP_PREFETCH 0   // prefetch the next tile's first frame per wave during phases B/C (A/B knob; measured neutral)
 #endif
+#ifndef TAC_SP_SPLIT
+#define TAC_SP_SPLIT 0     // N = 2048: two independent 4-wave halves per workgroup (A/B knob; measured 0.226 vs 0.220 ms)
+#endif
 #ifndef TAC_SP_HOISTW
 #define TAC_SP_HOISTW 1    // keep the window in registers for the kernel's lifetime (A/B knob)
 #endif
@@ -162,6 +165,120 @@ melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
     }
 }
 
+// ---------------------------------------------------------------- split variant (G == 1, i.e. N = 2048)
+// The 8 waves of the workgroup form two independent 4-wave HALVES, each a complete pipeline over its own
+// 8-frame tiles (own 8 frame buffers, own output tile, shared weights).  A half synchronises with an LDS
+// arrival counter instead of s_barrier, so while one half waits for HBM, sits at its barrier or runs the
+// contraction / store phases, the other half's FFT owns the SIMDs: the two waves on every SIMD are never in the
+// same phase by construction.  (Two 4-wave workgroups per CU would need 2 x 88 KB of LDS; one workgroup with
+// two halves shares the weights and fits.)
+__device__ __forceinline__ void half_barrier(int* counter, int& expected, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    expected += 4;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < expected)
+        __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <int NC, int E, bool POW2>
+__global__ void __launch_bounds__(512, 2)
+melspec_sparse_split_kernel(FrameGeom g, Tables tb, SparseArgs m) {
+    using C = MelCfg<NC, E, 8>;              // per half: 4 waves x 2 frames
+    using F = typename C::F;
+    static_assert(F::G == 1 && C::WAVES == 4 && C::GPW == 2, "split variant is wired for one frame per wave-round");
+    constexpr int PROW = C::PROW, HT = 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf* bufs = reinterpret_cast<cf*>(smem_raw);                                   // 16 frame buffers (8 per half)
+    float* wlds = reinterpret_cast<float*>(bufs + 16 * F::PADDED);
+    const int ostr = m.n_mels | 1;
+    float* otile = wlds + m.wtot;                                                 // [2][HT][ostr]
+    int* dlds = reinterpret_cast<int*>(otile + ((2 * HT * ostr + 3) & ~3));       // [32][dstride]
+    int* counters = dlds + 32 * m.dstride;                                        // [2]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = w >> 2, wl = w & 3;
+    const int t = lane;                       // G == 1: the whole wave is one frame
+    const int th = tid & 255;                 // thread index within the half
+
+    for (int i = tid; i < m.wtot; i += 512) wlds[i] = m.wpack[i];
+    for (int i = tid; i < 32 * m.dstride; i += 512) dlds[i] = m.desc[i];
+    if (tid < 2) counters[tid] = 0;
+
+    MelFftConsts<F, TAC_SP_HOISTW != 0> fftk;
+    fftk.load(tb, g, t);
+    __syncthreads();
+
+    const int tiles_per_row = (int)((g.n_frames + HT - 1) / HT);
+    const int total_tiles = (int)g.rows * tiles_per_row;
+    const int chunk = (total_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int wg_begin = (int)blockIdx.x * chunk;
+    const int wg_end = wg_begin + chunk < total_tiles ? wg_begin + chunk : total_tiles;
+    const int mid = wg_begin + (wg_end - wg_begin + 1) / 2;
+    const int begin = half == 0 ? wg_begin : mid;
+    const int end = half == 0 ? mid : wg_end;
+
+    cf* hbufs = bufs + half * HT * F::PADDED;
+    float* hot = otile + half * HT * ostr;
+    int* hcnt = counters + half;
+    int expected = 0;
+
+    const int fr = th & 7;                                                        // 8 lanes = the 8 frames share a band
+    const int* dg = dlds + (th >> 3) * m.dstride;
+    const float* prow = reinterpret_cast<const float*>(hbufs) + fr * PROW;
+    const int c_f0 = th / m.n_mels, c_band0 = th % m.n_mels;
+    const int c_df = 256 / m.n_mels, c_dband = 256 % m.n_mels;
+
+    for (int tile = begin; tile < end; ++tile) {
+        const int row = tile / tiles_per_row;
+        const long long f0 = (long long)(tile - row * tiles_per_row) * HT;
+
+        mel_phase_a<C, POW2, 1, TAC_SP_HOISTW != 0>(g, hbufs, fftk, wl, 0, t, row, f0);
+        half_barrier(hcnt, expected, lane);
+
+        {
+            const int nb = dg[0];
+            for (int b = 0; b < nb; ++b) {
+                const int4 d = *reinterpret_cast<const int4*>(dg + 4 + 4 * b);       // band, first bin, n8, weight offset
+                const float* p = prow + d.y;
+                const float4* w4 = reinterpret_cast<const float4*>(wlds + d.w);
+                float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
+                for (int j = 0; j < d.z; ++j) {
+                    const float4 wa = w4[2 * j], wb = w4[2 * j + 1];
+                    const float* q = p + 8 * j;
+                    const float p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3], p4 = q[4], p5 = q[5], p6 = q[6], p7 = q[7];
+                    acc0 = fmaf(wa.x, p0, acc0);
+                    acc1 = fmaf(wa.y, p1, acc1);
+                    acc2 = fmaf(wa.z, p2, acc2);
+                    acc3 = fmaf(wa.w, p3, acc3);
+                    acc0 = fmaf(wb.x, p4, acc0);
+                    acc1 = fmaf(wb.y, p5, acc1);
+                    acc2 = fmaf(wb.z, p6, acc2);
+                    acc3 = fmaf(wb.w, p7, acc3);
+                }
+                hot[fr * ostr + d.x] = (acc0 + acc1) + (acc2 + acc3);
+            }
+        }
+        half_barrier(hcnt, expected, lane);
+
+        {
+            int fo = c_f0, band = c_band0;
+            for (int idx = th; idx < HT * m.n_mels; idx += 256) {
+                float v = hot[fo * ostr + band];
+                if (m.db) v = amp_to_db(v, m.amin, m.log10_ref);
+                const long long frame = f0 + fo;
+                if (frame < g.n_frames) m.out[(row * g.n_frames + frame) * m.n_mels + band] = v;
+                band += c_dband;
+                fo += c_df;
+                if (band >= m.n_mels) { band -= m.n_mels; ++fo; }
+            }
+        }
+        // the half-barrier after the next phase A orders these output-tile reads before the next contraction's writes
+    }
+}
+
 template <int NC, int E>
 static int sparse_groups() { return MelCfg<NC, E, SP_TILE>::WAVES * 4; }
 
@@ -194,6 +311,26 @@ static int launch_sparse(const FrameGeom& g, const Tables& tb, const SparseArgs&
     long long blocks = tiles < max_blocks ? tiles : max_blocks;
     if (blocks < 1) blocks = 1;
     const bool pow2 = (power == 2.0f);
+    if constexpr (C::F::G == 1 && C::WAVES == 8 && TAC_SP_SPLIT != 0) {
+        const size_t lds2 = (size_t)16 * C::F::PADDED * sizeof(cf) + (size_t)m.wtot * 4 +
+                            (size_t)((2 * 8 * ostr + 3) & ~3) * 4 + (size_t)32 * m.dstride * 4 + 16;
+        if (lds2 <= 160 * 1024) {
+            const long long tiles8 = g.rows * ((g.n_frames + 7) / 8);
+            if (tiles8 >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
+            long long nb = (tiles8 + 1) / 2 < (long long)device_cu_count() ? (tiles8 + 1) / 2 : (long long)device_cu_count();
+            if (nb < 1) nb = 1;
+            auto k2 = pow2 ? melspec_sparse_split_kernel<NC, E, true> : melspec_sparse_split_kernel<NC, E, false>;
+            static bool attr2[2] = {false, false};
+            if (!attr2[pow2]) {
+                TAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k2),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr2[pow2] = true;
+            }
+            hipLaunchKernelGGL(k2, dim3((unsigned)nb), dim3(512), lds2, stream, g, tb, m);
+            TAC_HIP(hipGetLastError());
+            return TAC_OK;
+        }
+    }
     auto kern = pow2 ? melspec_sparse_kernel<NC, E, true> : melspec_sparse_kernel<NC, E, false>;
     static bool attr_set[2] = {false, false};
     if (!attr_set[pow2]) {
