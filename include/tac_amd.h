@@ -137,7 +137,10 @@ int tac_db_to_amplitude_f32(const float* x, int64_t n, float ref, float* out, vo
 /* (7) functional.mu_law_encoding, functional.py:317-335.  out: int64 codes.
  *     thresholds (optional, device): int32[n_pos + n_neg] magnitude bit patterns at which the
  *     reference's code changes for x >= 0 (ascending, first n_pos) and x <= 0 (next n_neg);
- *     with them the result is bit-exact for |x| <= 1.  zero_code = code of x == 0. */
+ *     they are a fast path for |x| <= 1 (a table search instead of the logarithm).  Without them,
+ *     and for |x| > 1 / NaN, the closed form is evaluated with the reference CPU path's exact
+ *     float32 roundings; either way the codes are bit-identical to the reference's.
+ *     zero_code = code of x == 0. */
 int tac_mulaw_encode_f32_i64(const float* x, int64_t n, int32_t n_quantize,
                              const int32_t* thresholds, int32_t n_pos, int32_t n_neg,
                              int32_t zero_code, int64_t* out, void* stream);

@@ -327,20 +327,24 @@ def test_mulaw_thresholds_edges(tac, golden):
     assert np.array_equal(got, g['enc256_edges'].astype(np.int64))
 
 
-def test_mulaw_out_of_range_and_other_nq_best_effort(tac, golden):
+def test_mulaw_out_of_range_and_other_nq_bit_exact(tac, golden):
+    """Outside [-1, 1] and for n_quantize != 256 the encoder evaluates the closed form with the reference CPU
+    path's exact float32 roundings (csrc/exact_math.hpp), so those codes are bit-exact too."""
     g = golden('g5_mulaw')
     x1 = signals.uniform((1000000,), seed=7, scale=4.0)
-    got = host(tac.mu_law_encoding(dev(x1), 256))
-    want = g['enc256_scale4'].astype(np.int64)
-    inside = np.abs(x1) <= 1.0
-    assert np.array_equal(got[inside], want[inside])                  # bit-exact on [-1, 1]
-    diff = np.abs(got - want)
-    assert diff.max() <= 1 and (diff != 0).mean() < 1e-4               # documented best effort outside
+    assert np.array_equal(host(tac.mu_law_encoding(dev(x1), 256)), g['enc256_scale4'].astype(np.int64))
     x2 = signals.uniform((200000,), seed=8, scale=1.0)[:200000]
     for nq, key in ((65536, 'enc65536_unit'), (16, 'enc16_unit')):
-        got = host(tac.mu_law_encoding(dev(x2), nq))
-        diff = np.abs(got - g[key].astype(np.int64))
-        assert diff.max() <= 1 and (diff != 0).mean() < 1e-3
+        assert np.array_equal(host(tac.mu_law_encoding(dev(x2), nq)), g[key].astype(np.int64)), key
+    x3 = signals.uniform((200000,), seed=11, scale=1000.0)
+    for nq, key in ((1024, 'enc1024_scale1000'), (7, 'enc7_scale1000')):
+        assert np.array_equal(host(tac.mu_law_encoding(dev(x3), nq)), g[key].astype(np.int64)), key
+    # +-0, +-1, denormals, just outside the unit interval, huge, inf and NaN (x86 float->int64 "indefinite")
+    sp = dev(g['special_inputs'])
+    assert np.array_equal(host(tac.mu_law_encoding(sp, 256)), g['enc256_special'])
+    assert np.array_equal(host(tac.mu_law_encoding(sp, 65536)), g['enc65536_special'])
+    # unaligned / odd-length views take the scalar path of the same kernel
+    assert np.array_equal(host(tac.mu_law_encoding(dev(x3)[1:99998], 1024)), g['enc1024_scale1000'][1:99998].astype(np.int64))
 
 
 # ------------------------------------------------------------------ size-independent properties at BASELINE sizes

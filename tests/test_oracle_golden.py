@@ -143,3 +143,35 @@ def test_threshold_tables_match_golden(golden):
     cnt_neg = np.searchsorted(np.array(tab.THR256_NEG, dtype=np.uint32), bits, side='right')
     codes = np.where(neg, tab.ZERO_CODE_256 - cnt_neg, tab.ZERO_CODE_256 + cnt_pos)
     assert np.array_equal(codes, g['enc256_unit'].astype(np.int64))
+
+
+def test_exact_log1p_closed_form_reproduces_golden_codes(golden):
+    """csrc/exact_math.hpp (the closed-form encoder's log1p, compiled here for the host with g++) reproduces the
+    reference codes stored in g5 for every n_quantize / range combination, independent of this host's torch."""
+    import ctypes
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        'check_log1p_replica', os.path.join(os.path.dirname(__file__), '..', 'tools', 'check_log1p_replica.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lib = mod.build()
+    g = golden('g5_mulaw')
+
+    def enc(x, nq):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.empty(x.size, np.int64)
+        lib.run_enc(mod.ptr(x), mod.ptr(y), ctypes.c_long(x.size), ctypes.c_int(nq))
+        return y
+
+    x1 = signals.uniform((1000000,), seed=7, scale=4.0)
+    x2 = signals.uniform((1000000,), seed=8, scale=1.0)
+    x3 = signals.uniform((200000,), seed=11, scale=1000.0)
+    assert np.array_equal(enc(x1, 256), g['enc256_scale4'].astype(np.int64))
+    assert np.array_equal(enc(x2, 256), g['enc256_unit'].astype(np.int64))
+    assert np.array_equal(enc(x2[:200000], 65536), g['enc65536_unit'].astype(np.int64))
+    assert np.array_equal(enc(x2[:200000], 16), g['enc16_unit'].astype(np.int64))
+    assert np.array_equal(enc(x3, 1024), g['enc1024_scale1000'].astype(np.int64))
+    assert np.array_equal(enc(x3, 7), g['enc7_scale1000'].astype(np.int64))
+    assert np.array_equal(enc(g['special_inputs'], 256), g['enc256_special'])
+    assert np.array_equal(enc(g['special_inputs'], 65536), g['enc65536_special'])

@@ -193,6 +193,13 @@ def g5(skip_scan):
     edges = np.concatenate([mags.view(np.float32), -(mags.view(np.float32))])
     out['enc256_edges'] = np32(ref.mu_law_encoding(T(edges), 256)).astype(np.int16)
     out['enc16_unit'] = np32(ref.mu_law_encoding(x2[:200000], 16)).astype(np.int16)
+    x3 = T(signals.uniform((200000,), seed=11, scale=1000.0))     # far outside [-1, 1]: closed-form path
+    out['enc1024_scale1000'] = np32(ref.mu_law_encoding(x3, 1024)).astype(np.int32)
+    out['enc7_scale1000'] = np32(ref.mu_law_encoding(x3, 7)).astype(np.int16)
+    out['special_inputs'] = np.array([0.0, -0.0, 1.0, -1.0, 1e-45, -1e-45, 1e-39, -1e-39, 1.0000001, -1.0000001,
+                                      1e10, -1e10, 1e30, -1e30, np.inf, -np.inf, np.nan], np.float32)
+    out['enc256_special'] = np32(ref.mu_law_encoding(T(out['special_inputs']), 256)).astype(np.int64)
+    out['enc65536_special'] = np32(ref.mu_law_encoding(T(out['special_inputs']), 65536)).astype(np.int64)
     codes = T((signals.uniform((4096,), seed=9) * 127.5 + 127.5).astype(np.int64).clip(0, 255))
     out['dec256_codes'] = np32(ref.mu_law_decoding(codes, 256))
     out['db_known_amp'] = np32(ref.amplitude_to_db(torch.tensor([1e-6, 1e-4, 0.1, 1.0, 10.0, 1e6]).sqrt()))

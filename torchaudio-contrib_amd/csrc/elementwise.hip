@@ -2,6 +2,7 @@
 // db_to_amplitude, mu-law encode / decode (functional.py:116-128, 277-314, 317-354).
 // 16 B per lane per access where alignment allows, grid-stride over 256 CUs x 8 blocks.
 #include "host_common.hpp"
+#include "exact_math.hpp"
 
 namespace tac {
 
@@ -72,10 +73,11 @@ __global__ void __launch_bounds__(EW_THREADS) unary_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------- mu-law
-// closed form in the reference's op order (functional.py:331-334), fp32
+// closed form in the reference's op order (functional.py:331-334), fp32, every operation individually rounded
 __device__ __forceinline__ long long mulaw_formula(float x, float mu, float log1p_mu) {
+#pragma clang fp contract(off)
     float sgn = (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : x);     // torch.sign: 0 -> 0, NaN -> NaN
-    float comp = sgn * log1pf(mu * fabsf(x)) / log1p_mu;
+    float comp = sgn * exact_log1pf(mu * fabsf(x)) / log1p_mu;
     float q = (comp + 1.0f) / 2.0f * mu + 0.5f;
     if (!(fabsf(q) < 9.2233720e18f)) return (long long)0x8000000000000000ULL;   // x86 cvttss2si "indefinite"
     return (long long)q;                                          // trunc toward zero == .long()
@@ -209,7 +211,7 @@ int tac_mulaw_encode_f32_i64(const float* x, int64_t n, int32_t n_quantize, cons
     if (!x || !out || n < 0 || n_quantize < 2) return TAC_E_INVALID;
     if (thresholds && (n_pos < 0 || n_neg < 0 || n_pos + n_neg > MULAW_MAX_THR)) return TAC_E_UNSUPPORTED;
     const float mu = (float)(n_quantize - 1);
-    const float l1p = log1pf(mu);
+    const float l1p = exact_log1pf(mu);
     const bool vec = aligned16(x) && aligned16(out);
     const unsigned blocks = ew_blocks(vec ? (n + 3) / 4 : n);
     long long* o = reinterpret_cast<long long*>(out);
@@ -225,7 +227,7 @@ int tac_mulaw_decode_i64_f32(const int64_t* codes, int64_t n, int32_t n_quantize
     if (n == 0) return TAC_OK;
     if (!codes || !out || n < 0 || n_quantize < 2) return TAC_E_INVALID;
     const float mu = (float)(n_quantize - 1);
-    const float l1p = log1pf(mu);
+    const float l1p = exact_log1pf(mu);
     const bool vec = aligned16(codes) && aligned16(out);
     const unsigned blocks = ew_blocks(vec ? (n + 3) / 4 : n);
     const long long* c = reinterpret_cast<const long long*>(codes);
@@ -238,7 +240,7 @@ int tac_mulaw_decode_i64_f32(const int64_t* codes, int64_t n, int32_t n_quantize
 int tac_mulaw_decode_f32_f32(const float* codes, int64_t n, int32_t n_quantize, float* out, void* stream) {
     if (n_quantize < 2) return TAC_E_INVALID;
     const float mu = (float)(n_quantize - 1);
-    return tac::launch_unary(codes, n, tac::MulawExpandOp{mu, log1pf(mu)}, out, stream);
+    return tac::launch_unary(codes, n, tac::MulawExpandOp{mu, tac::exact_log1pf(mu)}, out, stream);
 }
 
 }  // extern "C"

@@ -489,8 +489,8 @@ def mu_law_encoding(x, n_quantize=256):
 
     For ``n_quantize == 256`` and ``|x| <= 1`` the codes are bit-exact with the reference: the kernel
     compares against the 255 float32 thresholds extracted from it (``_mulaw_tables.py``).  Other
-    ``n_quantize`` and out-of-range samples use the closed form in fp32 (can differ by one code on
-    ~1e-6 of samples, exactly where the reference's own vectorised log1p is not correctly rounded)."""
+    ``n_quantize`` and out-of-range samples evaluate the closed form with the exact float32 roundings
+    of the reference's CPU path (``csrc/exact_math.hpp``) and are bit-exact as well."""
     if torch.is_tensor(x) and not x.dtype.is_floating_point:
         x = _realize(x).to(torch.float)
     x = _device_f32(x, 'x')
