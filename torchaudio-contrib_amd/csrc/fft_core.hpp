@@ -35,6 +35,27 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Phase stamps for the timing builds of the tools (TAC_STFT_TIMING): NoStamp compiles to nothing.
+struct NoStamp {
+    __device__ __forceinline__ void mark(int) {}
+};
+struct CycleStamp {
+    long long last;
+    float acc[12];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) acc[i] = 0.0f;
+        last = clock64();
+    }
+    __device__ __forceinline__ void mark(int i) {
+        __builtin_amdgcn_sched_barrier(0);
+        const long long now = clock64();
+        acc[i] += (float)(now - last);
+        last = now;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+
 __device__ __forceinline__ int lds_pad(int o) { return o + (o >> 4); }
 // padded offset of a compile-time multiple of 16: pad(a + c) == pad(a) + lds_pad_c(c)
 __device__ __forceinline__ constexpr int lds_pad_c(int c) { return c + c / 16; }
@@ -222,12 +243,18 @@ struct WaveFft {
     // On return frame f's spectrum Z[0..NC) sits in natural order at lds[f][lds_pad(i)].
     template <int NF>
     __device__ static __forceinline__ void run(cf (&v)[NF][E_], cf* const (&lds)[NF], const cf* tw, int t) {
-        pass<0, NF>(v, lds, tw, t);
+        NoStamp st;
+        run<NF>(v, lds, tw, t, st);
+    }
+    // stamps (timing builds): 2P+1 = pass P's operands read back and twiddled, 2P+2 = its butterflies done
+    template <int NF, class ST>
+    __device__ static __forceinline__ void run(cf (&v)[NF][E_], cf* const (&lds)[NF], const cf* tw, int t, ST& st) {
+        pass<0, NF>(v, lds, tw, t, st);
         wave_lds_fence();
     }
 
-    template <int P, int NF>
-    __device__ static __forceinline__ void pass(cf (&v)[NF][E_], cf* const (&lds)[NF], const cf* tw, int t) {
+    template <int P, int NF, class ST>
+    __device__ static __forceinline__ void pass(cf (&v)[NF][E_], cf* const (&lds)[NF], const cf* tw, int t, ST& st) {
         constexpr int R = radix_at(NC, P), S = stride_at(NC, P), OFF = twiddles_before(NC, E, P);
         constexpr int NB = E / R;
         static_assert(NB >= 1, "radix larger than elements per lane");
@@ -252,11 +279,13 @@ struct WaveFft {
                     for (int q = 1; q < R; ++q)
                         v[f][b * R + q] = cmul(last_pass_const<P>(v[f][b * R + q], b * q * (32 / E)),
                                                tw[OFF + (pass_shares_twiddles(NC, E, P) ? 0 : b) * (R - 1) + q - 1]);
+            st.mark(2 * P + 1);
         }
 #pragma unroll
         for (int f = 0; f < NF; ++f)
 #pragma unroll
             for (int b = 0; b < NB; ++b) Dft<R>::run(&v[f][b * R]);
+        st.mark(2 * P + 2);
         wave_lds_fence();   // every lane's reads of this pass precede any lane's writes (same wave, in order)
 #pragma unroll
         for (int f = 0; f < NF; ++f)
@@ -275,7 +304,7 @@ struct WaveFft {
                     for (int k = 0; k < R; ++k) dst[lds_pad_c(k * S)] = v[f][b * R + k];
                 }
             }
-        if constexpr (P + 1 < NPASS) pass<P + 1, NF>(v, lds, tw, t);
+        if constexpr (P + 1 < NPASS) pass<P + 1, NF>(v, lds, tw, t, st);
     }
 
     // R2C split of pair index k (0 <= k <= NC/2): returns X[k] in xa and X[NC-k] in xb.

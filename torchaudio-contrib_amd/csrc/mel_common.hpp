@@ -33,9 +33,9 @@ struct MelCfg {
 // Lane-invariant FFT constants of a fused kernel (registers for the kernel's lifetime).
 // HOISTW: window register-resident too.  Kernels with spare registers (HOISTW) also keep all E/2 R2C twiddles
 // instead of the factored form (one register x compile-time constants), saving its extra complex multiplies.
-template <class F, bool HOISTW = false>
+template <class F, bool HOISTW = false, bool FORCE_FACT = false>
 struct MelFftConsts {
-    static constexpr bool FACT = !HOISTW && (F::E == 16) && (F::LPF * 32 == 2 * F::NC);      // W_N^{i*LPF} == W_32^i
+    static constexpr bool FACT = (!HOISTW || FORCE_FACT) && (F::E == 16) && (F::LPF * 32 == 2 * F::NC);   // W_N^{i*LPF} == W_32^i
     static constexpr bool HOIST_WINDOW = HOISTW;
     cf tw[F::NTW];
     cf ptw[FACT ? 1 : F::NPAIR];
@@ -57,19 +57,29 @@ struct MelFftConsts {
 // the registers for it: the second in-flight frame hides the LDS round trips of the first).
 // pre_raw / pre_ok: optional software prefetch of the wave's FIRST frame of this tile (raw samples requested
 // during the previous tile's contraction / store phases; G == 1 geometries only).
-template <class C, bool POW2, int NFA = 1, bool HOISTW = false>
-__device__ __forceinline__ void mel_phase_a(const FrameGeom& g, cf* bufs, const MelFftConsts<typename C::F, HOISTW>& k,
+// PIPE (G == 1 kernels): every frame's raw samples are requested one frame ahead — right after the previous frame's
+// butterflies, before its R2C/power epilogue — so the HBM/L2 round trip never opens a frame.  raw/pre_ok carry the
+// request across calls; (next_row, next_f0) name the tile whose first frame of this wave follows this tile's last
+// (next_f0 < 0: none).  The frame loop is fully unrolled so the compiler can count the stores between a request
+// and its use (gfx950's single in-order vmcnt: an uncounted wait would also wait for those stores' acknowledgements).
+template <class C, bool POW2, int NFA = 1, bool HOISTW = false, class ST = NoStamp, bool PIPE = false, class K = void>
+__device__ __forceinline__ void mel_phase_a(const FrameGeom& g, cf* bufs, const K& k,
                                             int w, int sub, int t, int row, long long f0,
-                                            const float2* pre_raw = nullptr, bool pre_ok = false) {
+                                            float2* pre_raw = nullptr, bool* pre_ok_p = nullptr, ST* stp = nullptr,
+                                            int next_row = 0, long long next_f0 = -1) {
+    ST st_local;
+    ST& st = stp ? *stp : st_local;
+    bool pre_ok = pre_ok_p ? *pre_ok_p : false;
     using F = typename C::F;
     constexpr int NC = F::NC, E = F::E, NBINS = NC + 1, TILE = C::TILE_FRAMES;
-    constexpr bool FACT = MelFftConsts<F, HOISTW>::FACT;
+    constexpr bool FACT = K::FACT;
+    static_assert(K::HOIST_WINDOW == HOISTW, "window hoisting of the constants and the caller disagree");
     constexpr int NF = (C::GPW % NFA == 0) ? NFA : 1;
     const cf* tw = k.tw;
     const cf* ptw = k.ptw;
     const bool wave_has_frames = (w * C::GPW * F::G) < TILE;
     if (wave_has_frames) {
-#pragma unroll 1
+#pragma unroll PIPE ? C::GPW : 1
         for (int rep = 0; rep < C::GPW; rep += NF) {
             cf* lds[NF];
             int fi[NF];
@@ -83,12 +93,25 @@ __device__ __forceinline__ void mel_phase_a(const FrameGeom& g, cf* bufs, const 
             for (int f = 0; f < NF; ++f) {
                 fi[f] = ((w * C::GPW + rep + f) * F::G) + sub;              // frame index within the tile
                 lds[f] = bufs + fi[f] * F::PADDED;
-                if (f == 0 && rep == 0 && pre_ok) apply_window<F>(v[f], pre_raw, win);
+                if (f == 0 && (PIPE || rep == 0) && pre_ok) apply_window<F>(v[f], pre_raw, win);
                 else load_frame<F, true>(v[f], g, win, lds[f], row, (fi[f] < TILE) ? f0 + fi[f] : g.n_frames, t);
             }
+            st.mark(8);
 #if TAC_MEL_ABL != 1
-            F::template run<NF>(v, lds, tw, t);
+            F::template run<NF>(v, lds, tw, t, st);
 #endif
+            st.mark(9);
+            if constexpr (PIPE) {
+                static_assert(F::G == 1 && NF == 1, "pipelined phase A is wired for one frame per wave-round");
+                __builtin_amdgcn_sched_barrier(0);
+                const bool same_tile = rep + 1 < C::GPW;
+                const int nrow = same_tile ? row : next_row;
+                const long long nfi = w * C::GPW + (same_tile ? rep + 1 : 0);
+                const long long nframe = (same_tile ? f0 : next_f0) + nfi;
+                pre_ok = false;
+                if ((same_tile || next_f0 >= 0) && nfi < TILE) pre_ok = prefetch_frame_raw<F>(pre_raw, g, nrow, nframe, t);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
                 // gather every Z this lane needs BEFORE anything is overwritten (in-place row)
@@ -120,8 +143,10 @@ __device__ __forceinline__ void mel_phase_a(const FrameGeom& g, cf* bufs, const 
                 }
                 for (int c = t; c < 7; c += F::LPF) prow[NBINS + c] = 0.0f;           // contraction overrun columns
             }
+            st.mark(10);
         }
     }
+    if (pre_ok_p) *pre_ok_p = pre_ok;
 }
 
 }  // namespace tac

@@ -21,6 +21,15 @@
 #ifndef TAC_SP_PREFETCH
 #define TAC_SP_PREFETCH 0   // prefetch the next tile's first frame per wave during phases B/C (A/B knob; measured neutral)
 #endif
+#ifndef TAC_SP_PIPE
+#define TAC_SP_PIPE 1       // one-frame-per-wave geometries: request every frame's samples one frame ahead (mel_common.hpp)
+#endif
+#ifndef TAC_SP_FACT
+#define TAC_SP_FACT 1       // R2C twiddles as one lane register x compile-time W_32^i (frees 14 registers for the prefetch)
+#endif
+#ifndef TAC_SP_TIMING
+#define TAC_SP_TIMING 0   // 1: debug builds of tools/mel_phase_timing.py — phase cycle sums overwrite the head of out[]
+#endif
 #ifndef TAC_SP_SPLIT
 #define TAC_SP_SPLIT 0     // N = 2048: two independent 4-wave halves per workgroup (A/B knob; measured 0.226 vs 0.220 ms)
 #endif
@@ -70,7 +79,7 @@ melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
     for (int i = tid; i < m.wtot; i += WAVES * 64) wlds[i] = m.wpack[i];
     for (int i = tid; i < WAVES * 4 * m.dstride; i += WAVES * 64) dlds[i] = m.desc[i];
 
-    MelFftConsts<F, TAC_SP_HOISTW != 0> fftk;
+    MelFftConsts<F, TAC_SP_HOISTW != 0, (TAC_SP_FACT != 0) && (TAC_SP_PIPE != 0)> fftk;
     fftk.load(tb, g, t);
     __syncthreads();
 
@@ -90,22 +99,39 @@ melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
 
     // software prefetch of this wave's first frame of the NEXT tile (raw samples, 32 registers that are idle during
     // the contraction and store phases): its HBM/L2 round trip is hidden instead of opening every phase A
-    constexpr bool PREFETCH = (F::G == 1) && (TAC_SP_PREFETCH != 0);
-    float2 raw[PREFETCH ? F::E : 1];
+    constexpr bool PIPE = (F::G == 1) && (TAC_SP_PIPE != 0);
+    constexpr bool PREFETCH = !PIPE && (F::G == 1) && (TAC_SP_PREFETCH != 0);
+    float2 raw[(PREFETCH || PIPE) ? F::E : 1];
     bool pre_ok = false;
-    if constexpr (PREFETCH) {
+    if constexpr (PREFETCH || PIPE) {
         if (begin < end) {
             const int r0 = begin / tiles_per_row;
             pre_ok = prefetch_frame_raw<F>(raw, g, r0, (long long)(begin - r0 * tiles_per_row) * TILE + w * C::GPW, t);
         }
+        __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the tile loop is entered with nothing in flight
     }
 
+#if TAC_SP_TIMING
+    CycleStamp st;
+    st.init();
+#else
+    NoStamp st;
+#endif
     for (int tile = begin; tile < end; ++tile) {
         const int row = tile / tiles_per_row;
         const long long f0 = (long long)(tile - row * tiles_per_row) * TILE;
+        st.mark(0);
 
         // ---------------- phase A: FFT, then overwrite each frame buffer with its |X|^p row (mel_common.hpp)
-        mel_phase_a<C, POW2, TAC_SP_NF, TAC_SP_HOISTW != 0>(g, bufs, fftk, w, sub, t, row, f0, raw, pre_ok);
+        if constexpr (PIPE) {
+            const int nt = tile + 1;
+            const int nr = nt / tiles_per_row;
+            const long long nf0 = nt < end ? (long long)(nt - nr * tiles_per_row) * TILE : -1;
+            mel_phase_a<C, POW2, 1, TAC_SP_HOISTW != 0, decltype(st), true>(g, bufs, fftk, w, sub, t, row, f0, raw, &pre_ok,
+                                                                             &st, nr, nf0);
+        } else {
+            mel_phase_a<C, POW2, TAC_SP_NF, TAC_SP_HOISTW != 0>(g, bufs, fftk, w, sub, t, row, f0, raw, &pre_ok, &st);
+        }
         if constexpr (PREFETCH) {
             const int nt = tile + 1;
             const int nr = nt / tiles_per_row;
@@ -113,6 +139,7 @@ melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
                      prefetch_frame_raw<F>(raw, g, nr, (long long)(nt - nr * tiles_per_row) * TILE + w * C::GPW, t);
         }
         __syncthreads();
+        st.mark(1);                                        // barrier A (waiting for the slowest wave's FFTs)
 
         // ---------------- phase B: one private dot product per (frame, band)
 #if TAC_MEL_ABL != 2
@@ -142,7 +169,9 @@ melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
             }
         }
 #endif
+        st.mark(7);                                        // phase B
         __syncthreads();
+        st.mark(11);                                       // barrier B
 
         // ---------------- phase C: dB epilogue + coalesced row stores of out[row][frame][0..M)
         {
@@ -163,6 +192,12 @@ melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
         }
         // the barrier after the next phase A orders these otile reads before the next phase-B writes
     }
+#if TAC_SP_TIMING
+    st.mark(0);
+    __syncthreads();
+    if (lane == 0)
+        for (int i = 0; i < 12; ++i) m.out[((long long)blockIdx.x * WAVES + w) * 16 + i] = st.acc[i];
+#endif
 }
 
 // ---------------------------------------------------------------- split variant (G == 1, i.e. N = 2048)

@@ -12,7 +12,17 @@
 #define TAC_ABL 0      // ablation builds only (tools): 1 = no global loads, 2 = no stores, 3 = no FFT passes
 #endif
 
+#ifndef TAC_STFT_TIMING
+#define TAC_STFT_TIMING 0   // 1: debug builds of tools/stft_phase_timing.py — per-phase cycle sums overwrite the head of out[]
+#endif
+
 namespace tac {
+
+#if TAC_STFT_TIMING
+using StftStamp = CycleStamp;
+#else
+using StftStamp = NoStamp;
+#endif
 
 constexpr int STFT_WAVES = 4;
 
@@ -77,7 +87,12 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
     const int nbins = ep.onesided ? NC + 1 : 2 * NC;
     const long long per_frame = (long long)nbins * (MODE == 0 ? 2 : 1);
 
+    StftStamp st;
+#if TAC_STFT_TIMING
+    st.init();
+#endif
     for (int unit = begin + w; unit < end; unit += STFT_WAVES) {
+        st.mark(0);                                         // loop overhead + previous iteration's store issue
         const int urow = unit / units_per_row;
         const long long uframe0 = (long long)(unit - urow * units_per_row) * FPU;
         cf v[NF][E];
@@ -106,8 +121,10 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
             for (int e = 0; e < E; ++e) lds[f][lds_pad(t + e * F::LPF)] = v[f][e];
         wave_lds_fence();
 #else
-        F::template run<NF>(v, lds, tw, t);
+        st.mark(8);                                         // frame loaded (global latency) and windowed
+        F::template run<NF>(v, lds, tw, t, st);
 #endif
+        st.mark(9);                                         // last pass's spectrum written to LDS
         const bool simple = (MODE == 0) ? (ep.onesided != 0) : (ep.onesided && ep.power == 2.0f && !ep.db);
         bool done = false;
         if constexpr (F::G == 1 && TAC_ABL != 2) {
@@ -154,6 +171,7 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
                         ++nlive;
                     }
                 }
+                st.mark(10);                                // R2C split + staging of the output row
                 const int len = nlive * LENF;
                 float* gdst = ep.out + g0;
                 const int npre = (4 - a) & 3;
@@ -246,8 +264,171 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
             }
         }
         wave_lds_fence();   // next iteration's first-pass writes must follow these reads
+        st.mark(11);                                        // output row streamed out (store issue)
     }
+#if TAC_STFT_TIMING
+    __syncthreads();
+    if (lane == 0)
+        for (int i = 0; i < 12; ++i) ep.out[((long long)blockIdx.x * STFT_WAVES + w) * 16 + i] = st.acc[i];
+#endif
 }
+
+// ---------------------------------------------------------------- software-pipelined variant
+// One frame per wave (n_fft = 2048) with the plain epilogue (one-sided complex, or |X|^2).  The phase stamps of
+// the kernel above (tools/stft_phase_timing.py) showed where a frame's ~13k cycles went: 40 % waiting for its
+// own samples — the loads were issued right behind the previous frame's stores, and gfx950's single in-order
+// vmcnt makes "my loads have landed" imply "all older stores are acknowledged" — and 22 % issuing those stores.
+// Here the NEXT frame's samples are requested before the current frame's stores, every store is unconditional
+// (clamped duplicate lanes instead of predication) so the compiler can wait with an exact vmcnt(#stores) while
+// the stores drain behind the next frame's butterflies, and the window comes from LDS (lgkmcnt, not vmcnt).
+template <int NC, int E, int MODE>
+__global__ void __launch_bounds__(STFT_WAVES * 64, 2)
+stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
+    using F = WaveFft<NC, E>;
+    static_assert(F::G == 1 && radix_at(NC, 0) == E, "one frame per wave, single first-pass butterfly per lane");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf* smem = reinterpret_cast<cf*>(smem_raw);
+    const int t = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int WAVE_SLOTS = ((F::PADDED + 1) / 2) * 2;
+    cf* const lds = smem + w * WAVE_SLOTS;
+    float2* const wlds = reinterpret_cast<float2*>(smem + STFT_WAVES * WAVE_SLOTS);    // NC window pairs
+    for (int m = threadIdx.x; m < NC; m += STFT_WAVES * 64) wlds[m] = window_pair(g, m);
+
+    cf tw[F::NTW];
+    cf ptw[F::NPAIR];
+    F::load_twiddles(tw, tb.w_nc, t);
+#pragma unroll
+    for (int i = 0; i < F::NPAIR; ++i) ptw[i] = tb.w_n[t + i * F::LPF];
+
+    const int T = (int)g.n_frames;
+    const int total = (int)g.rows * T;
+    const int chunk = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int begin = (int)blockIdx.x * chunk;
+    const int end = begin + chunk < total ? begin + chunk : total;
+    constexpr int LENF = (MODE == 0 ? 2 : 1) * (NC + 1);
+    constexpr int NST = ((LENF >> 2) + 63) / 64;          // 16-byte wave-stores per output row
+
+    float2 raw[E];
+    bool pre = false;
+    int unit = begin + w;
+    if (unit < end) pre = prefetch_frame_raw<F>(raw, g, unit / T, unit % T, t);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): the loop is entered with nothing in flight
+    __syncthreads();
+
+    StftStamp st;
+#if TAC_STFT_TIMING
+    st.init();
+#endif
+    for (; unit < end; unit += STFT_WAVES) {
+        st.mark(0);
+        const int urow = unit / T;
+        const int uframe = unit - urow * T;
+        cf v[1][E];
+        cf* const ldsv[1] = {lds};
+        if (pre) {
+#pragma unroll
+            for (int q = 0; q < E; ++q) {
+                const float2 wv = wlds[t + q * F::LPF];
+                v[0][q] = make_float2(raw[q].x * wv.x, raw[q].y * wv.y);
+            }
+        } else {
+            load_frame<F, false>(v[0], g, nullptr, lds, urow, uframe, t);     // frames touching the padding
+        }
+        st.mark(8);
+        F::template run<1>(v, ldsv, tw, t, st);
+        st.mark(9);
+
+        // request the next frame now: it lands while this frame is split, staged and stored
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const int nxt = unit + STFT_WAVES;
+            pre = false;
+            if (nxt < end) pre = prefetch_frame_raw<F>(raw, g, nxt / T, nxt % T, t);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        const long long g0 = ((long long)urow * T + uframe) * LENF;
+        const int a = (int)(g0 & 3);
+        float* const stage = reinterpret_cast<float*>(lds) + a;      // LDS and global share their 16-byte phase
+        {
+            cf xa[F::NPAIR], xb[F::NPAIR], xm, unused;
+#pragma unroll
+            for (int i = 0; i < F::NPAIR; ++i) {
+                F::r2c_pair(lds, t + i * F::LPF, ptw[i], xa[i], xb[i]);
+                xa[i].x *= g.scale; xa[i].y *= g.scale; xb[i].x *= g.scale; xb[i].y *= g.scale;
+            }
+            F::r2c_pair(lds, NC / 2, make_float2(0.0f, -1.0f), xm, unused);
+            xm.x *= g.scale; xm.y *= g.scale;
+            wave_lds_fence();                                         // every Z of this frame is in registers
+#pragma unroll
+            for (int i = 0; i < F::NPAIR; ++i) {
+                const int k = t + i * F::LPF;
+                if constexpr (MODE == 0) {
+                    reinterpret_cast<float2*>(stage)[k] = xa[i];
+                    reinterpret_cast<float2*>(stage)[NC - k] = xb[i];
+                } else {
+                    stage[k] = xa[i].x * xa[i].x + xa[i].y * xa[i].y;
+                    stage[NC - k] = xb[i].x * xb[i].x + xb[i].y * xb[i].y;
+                }
+            }
+            if (t == 0) {
+                if constexpr (MODE == 0) reinterpret_cast<float2*>(stage)[NC / 2] = xm;
+                else stage[NC / 2] = xm.x * xm.x + xm.y * xm.y;
+            }
+            wave_lds_fence();
+        }
+        st.mark(10);
+        // the row leaves as 1 + NST + 1 unconditional stores: out-of-range lanes repeat a neighbour's element
+        float* const gdst = ep.out + g0;
+        const int npre = (4 - a) & 3;
+        const int nchunks = (LENF - npre) >> 2;
+        {
+            const int hmax = (npre > 1 ? npre : 1) - 1;
+            const int hi = t < hmax ? t : hmax;
+            gdst[hi] = stage[hi];
+        }
+        const float4* const s4 = reinterpret_cast<const float4*>(stage + npre);
+        float4* const g4 = reinterpret_cast<float4*>(gdst + npre);
+        static_assert(NST == 4 || NST == 8, "row store is written out for 4 or 8 wave-stores");
+        const int last = nchunks - 1;
+#define TAC_ROW_IDX(i) const int c##i = (t + 64 * i) < last ? (t + 64 * i) : last;
+#define TAC_ROW_RD(i) const float4 b##i = s4[c##i];
+#define TAC_ROW_WR(i) g4[c##i] = b##i;
+        TAC_ROW_IDX(0) TAC_ROW_IDX(1) TAC_ROW_IDX(2) TAC_ROW_IDX(3)
+        TAC_ROW_RD(0) TAC_ROW_RD(1) TAC_ROW_RD(2) TAC_ROW_RD(3)
+        if constexpr (NST == 8) {
+            TAC_ROW_IDX(4) TAC_ROW_IDX(5) TAC_ROW_IDX(6) TAC_ROW_IDX(7)
+            TAC_ROW_RD(4) TAC_ROW_RD(5) TAC_ROW_RD(6) TAC_ROW_RD(7)
+            __builtin_amdgcn_sched_barrier(0);            // all LDS reads in flight before the first store issues
+            TAC_ROW_WR(0) TAC_ROW_WR(1) TAC_ROW_WR(2) TAC_ROW_WR(3)
+            TAC_ROW_WR(4) TAC_ROW_WR(5) TAC_ROW_WR(6) TAC_ROW_WR(7)
+        } else {
+            __builtin_amdgcn_sched_barrier(0);
+            TAC_ROW_WR(0) TAC_ROW_WR(1) TAC_ROW_WR(2) TAC_ROW_WR(3)
+        }
+#undef TAC_ROW_IDX
+#undef TAC_ROW_RD
+#undef TAC_ROW_WR
+        {
+            const int r = LENF - npre - 4 * nchunks;
+            const int rmax = (r > 1 ? r : 1) - 1;
+            const int ti = LENF - 1 - (t < rmax ? t : rmax);
+            gdst[ti] = stage[ti];
+        }
+        wave_lds_fence();   // next iteration's first-pass writes must follow these reads
+        st.mark(11);
+    }
+#if TAC_STFT_TIMING
+    __syncthreads();
+    if (t == 0)
+        for (int i = 0; i < 12; ++i) ep.out[((long long)blockIdx.x * STFT_WAVES + w) * 16 + i] = st.acc[i];
+#endif
+}
+
+#ifndef TAC_STFT_PIPE
+#define TAC_STFT_PIPE 1     // 0: A/B knob, n_fft = 2048 plain epilogues go through the generic kernel
+#endif
 
 template <int NC, int E, int MODE>
 static int launch_stft(const FrameGeom& g, const Tables& tb, const StftEpilogue& ep, hipStream_t stream) {
@@ -258,6 +439,19 @@ static int launch_stft(const FrameGeom& g, const Tables& tb, const StftEpilogue&
     constexpr bool HOIST = (E <= 16);
     const long long groups = g.rows * ((g.n_frames + NF * F::G - 1) / (NF * F::G));     // wave-iterations
     if (groups >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
+    if constexpr (TAC_STFT_PIPE && F::G == 1 && E == 16) {
+        const bool simple = (MODE == 0) ? (ep.onesided != 0) : (ep.onesided && ep.power == 2.0f && !ep.db);
+        if (simple) {
+            const size_t bytes = (size_t)STFT_WAVES * (((F::PADDED + 1) / 2) * 2) * sizeof(cf) + (size_t)NC * sizeof(float2);
+            long long blocks = (groups + STFT_WAVES - 1) / STFT_WAVES;
+            const long long cap = (long long)device_cu_count() * 2;
+            if (blocks > cap) blocks = cap;
+            hipLaunchKernelGGL((stft_pipe_kernel<NC, E, MODE>), dim3((unsigned)blocks), dim3(STFT_WAVES * 64), bytes,
+                               stream, g, tb, ep);
+            TAC_HIP(hipGetLastError());
+            return TAC_OK;
+        }
+    }
     const size_t lds_bytes = (size_t)STFT_WAVES * (((NF * F::G * F::PADDED + 1) / 2) * 2) * sizeof(cf);
     int per_cu = (int)(160 * 1024 / lds_bytes);
     if (per_cu > 2) per_cu = 2;        // 256-register waves: two 4-wave workgroups fill a CU
