@@ -17,11 +17,11 @@ phys = (y.transpose(2, 3) if what == 'stft' else y.transpose(-2, -1)).contiguous
 t = phys[:nblk * 4 * 16].view(nblk, 4, 16).cpu()[..., :12]
 names = {0: 'loop top / store drain', 8: 'load + window', 2: 'pass0 butterflies', 3: 'pass1 readback+twiddle',
          4: 'pass1 butterflies', 5: 'pass2 readback+twiddle', 6: 'pass2 butterflies', 9: 'last-pass LDS write',
-         10: 'r2c + stage', 11: 'row store issue'}
+         1: 'next-frame load issue', 7: 'r2c split', 10: 'row staging (LDS)', 11: 'row store issue'}
 tot = t.sum(-1)
 frames_per_wave = 256 * 313 / (nblk * 4)
 print('%s: per-wave total cycles: mean %.0f min %.0f max %.0f  (%.1f frames per wave -> %.0f cycles per frame)'
       % (what, tot.mean(), tot.min(), tot.max(), frames_per_wave, tot.mean() / frames_per_wave))
-for i in (0, 8, 2, 3, 4, 5, 6, 9, 10, 11):
+for i in (0, 8, 2, 3, 4, 5, 6, 9, 1, 7, 10, 11):
     col = t[..., i]
     print('%-26s %9.0f cycles/frame  (%.1f%%)' % (names[i], col.mean() / frames_per_wave, 100 * col.mean() / tot.mean()))

@@ -19,7 +19,7 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 
 // ---------------------------------------------------------------- complex_norm
 __device__ __forceinline__ float norm_pow(float re, float im, float power) {
-    return cpow_mag(make_float2(re, im), power);
+    return cpow_mag(mkc(re, im), power);
 }
 
 template <bool VEC>

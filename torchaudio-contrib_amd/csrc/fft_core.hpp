@@ -18,15 +18,92 @@
 
 namespace tac {
 
-typedef float2 cf;
-
-__device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ cf cmul(cf a, cf b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+// Complex value = one 64-bit register pair.  The arithmetic below is written for gfx950's PACKED f32 VALU ops
+// (v_pk_add/mul/fma_f32: two lanes of a register pair per instruction, with per-operand half selection and sign
+// modifiers): a complex add is one instruction, a complex multiply two, a radix-4 butterfly eight.  A packed op
+// occupies the SIMD as long as two scalar ones, but it takes ONE issue slot of the wave — and these kernels run
+// two 256-register waves per SIMD, each limited to about one VALU issue per four cycles (measured,
+// tools/ubench/valu_rate.hip), so per-wave issue slots, not SIMD cycles, are what the FFT is short of.
+// The rotations / conjugations are folded into the consuming add via op_sel / neg modifiers, which hipcc does not
+// derive from shuffles by itself (it emits v_mov + v_xor), hence the one-line asm helpers.
+typedef float cf __attribute__((ext_vector_type(2)));
+__host__ __device__ __forceinline__ cf mkc(float x, float y) {
+    cf r;
+    r.x = x;
+    r.y = y;
+    return r;
 }
+
+#ifndef TAC_PACKED
+#define TAC_PACKED 1        // 0: A/B knob, the same algebra on scalar f32 ops
+#endif
+
+#if TAC_PACKED
+__device__ __forceinline__ cf cadd(cf a, cf b) { return a + b; }
+__device__ __forceinline__ cf csub(cf a, cf b) { return a - b; }
+// a + (-i)·b and a - (-i)·b
+__device__ __forceinline__ cf cadd_rot(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ cf csub_rot(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a + conj(b) and a - conj(b)
+__device__ __forceinline__ cf cadd_conj(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ cf csub_conj(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// conj(a - b)
+__device__ __forceinline__ cf csub_then_conj(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a · w (w a register twiddle): (a.x·w) + a.y·(-w.y, w.x)
+__device__ __forceinline__ cf cmul(cf a, cf w) {
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+// w · (-i·d): the R2C split's twiddled odd part, d = zk - conj(zm)
+__device__ __forceinline__ cf cmul_rot(cf w, cf d) {
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(t) : "v"(d), "v"(w));                    // d.y·w
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(d), "v"(w), "v"(t));   // + d.x·(w.y, -w.x)
+    return r;
+}
+// a · (C + iS) with compile-time C, S: the constant pairs live in SGPRs
+__device__ __forceinline__ cf cmulc(cf a, float C, float S) { return mkc(a.x, a.x) * mkc(C, S) + mkc(a.y, a.y) * mkc(-S, C); }
+__device__ __forceinline__ cf cscale(cf a, float s) { return a * mkc(s, s); }
+__device__ __forceinline__ cf cmul_elem(cf a, cf b) { return a * b; }        // lane-wise product (window)
+#else
+__device__ __forceinline__ cf cadd(cf a, cf b) { return mkc(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cf csub(cf a, cf b) { return mkc(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cf cadd_rot(cf a, cf b) { return mkc(a.x + b.y, a.y - b.x); }
+__device__ __forceinline__ cf csub_rot(cf a, cf b) { return mkc(a.x - b.y, a.y + b.x); }
+__device__ __forceinline__ cf cadd_conj(cf a, cf b) { return mkc(a.x + b.x, a.y - b.y); }
+__device__ __forceinline__ cf csub_conj(cf a, cf b) { return mkc(a.x - b.x, a.y + b.y); }
+__device__ __forceinline__ cf csub_then_conj(cf a, cf b) { return mkc(a.x - b.x, b.y - a.y); }
+__device__ __forceinline__ cf cmul(cf a, cf b) { return mkc(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ cf cmul_rot(cf w, cf d) { return cmul(w, mkc(d.y, -d.x)); }
+__device__ __forceinline__ cf cmulc(cf a, float C, float S) { return cmul(a, mkc(C, S)); }
+__device__ __forceinline__ cf cscale(cf a, float s) { return mkc(a.x * s, a.y * s); }
+__device__ __forceinline__ cf cmul_elem(cf a, cf b) { return mkc(a.x * b.x, a.y * b.y); }
+#endif
 // a * (-i)
-__device__ __forceinline__ cf mul_neg_i(cf a) { return make_float2(a.y, -a.x); }
+__device__ __forceinline__ cf mul_neg_i(cf a) { return mkc(a.y, -a.x); }
+__device__ __forceinline__ float cnorm2(cf a) { return a.x * a.x + a.y * a.y; }
 
 // Compiler-only ordering point for same-wave LDS traffic (no instruction emitted).
 __device__ __forceinline__ void wave_lds_fence() {
@@ -69,11 +146,20 @@ __device__ __forceinline__ void dft2(cf& a, cf& b) {
 
 __device__ __forceinline__ void dft4(cf& a0, cf& a1, cf& a2, cf& a3) {
     cf s02 = cadd(a0, a2), d02 = csub(a0, a2);
-    cf s13 = cadd(a1, a3), d13 = mul_neg_i(csub(a1, a3));
+    cf s13 = cadd(a1, a3), d13 = csub(a1, a3);
     a0 = cadd(s02, s13);
-    a1 = cadd(d02, d13);
+    a1 = cadd_rot(d02, d13);
     a2 = csub(s02, s13);
-    a3 = csub(d02, d13);
+    a3 = csub_rot(d02, d13);
+}
+// the same butterfly when input a2 still carries a pending factor (-i): a2 <- (-i)·a2 folded into the first stage
+__device__ __forceinline__ void dft4_rot2(cf& a0, cf& a1, cf& a2, cf& a3) {
+    cf s02 = cadd_rot(a0, a2), d02 = csub_rot(a0, a2);
+    cf s13 = cadd(a1, a3), d13 = csub(a1, a3);
+    a0 = cadd(s02, s13);
+    a1 = cadd_rot(d02, d13);
+    a2 = csub(s02, s13);
+    a3 = csub_rot(d02, d13);
 }
 
 #define TAC_SQRT_HALF 0.70710678118654752440f
@@ -85,11 +171,11 @@ template <int M>
 __device__ __forceinline__ cf mul_w16(cf v) {
     if constexpr (M == 0) return v;
     else if constexpr (M == 4) return mul_neg_i(v);
-    else if constexpr (M == 2) return make_float2((v.x + v.y) * TAC_SQRT_HALF, (v.y - v.x) * TAC_SQRT_HALF);
-    else if constexpr (M == 6) return make_float2((v.y - v.x) * TAC_SQRT_HALF, -(v.x + v.y) * TAC_SQRT_HALF);
-    else if constexpr (M == 1) return cmul(v, make_float2(TAC_COS_PI_8, -TAC_SIN_PI_8));
-    else if constexpr (M == 3) return cmul(v, make_float2(TAC_SIN_PI_8, -TAC_COS_PI_8));
-    else if constexpr (M == 9) return cmul(v, make_float2(-TAC_COS_PI_8, TAC_SIN_PI_8));
+    else if constexpr (M == 2) return cscale(cadd_rot(v, v), TAC_SQRT_HALF);        // (x+y, y-x)/sqrt2
+    else if constexpr (M == 6) return cscale(csub_rot(v, v), -TAC_SQRT_HALF);       // (y-x, -(x+y))/sqrt2
+    else if constexpr (M == 1) return cmulc(v, TAC_COS_PI_8, -TAC_SIN_PI_8);
+    else if constexpr (M == 3) return cmulc(v, TAC_SIN_PI_8, -TAC_COS_PI_8);
+    else if constexpr (M == 9) return cmulc(v, -TAC_COS_PI_8, TAC_SIN_PI_8);
     else return v;
 }
 
@@ -102,11 +188,11 @@ __device__ __forceinline__ cf mul_w32(cf v, int m) {
     m &= 31;
     if (m == 0) return v;
     if (m == 8) return mul_neg_i(v);
-    if (m == 16) return make_float2(-v.x, -v.y);
-    if (m == 24) return make_float2(-v.y, v.x);
-    if (m == 4) return make_float2((v.x + v.y) * TAC_SQRT_HALF, (v.y - v.x) * TAC_SQRT_HALF);
-    if (m == 12) return make_float2((v.y - v.x) * TAC_SQRT_HALF, -(v.x + v.y) * TAC_SQRT_HALF);
-    return cmul(v, make_float2(C[m], S[m]));
+    if (m == 16) return mkc(-v.x, -v.y);
+    if (m == 24) return mkc(-v.y, v.x);
+    if (m == 4) return cscale(cadd_rot(v, v), TAC_SQRT_HALF);
+    if (m == 12) return cscale(csub_rot(v, v), -TAC_SQRT_HALF);
+    return cmulc(v, C[m], S[m]);
 }
 
 template <int R>
@@ -147,12 +233,13 @@ struct Dft<16> {
             dft4(a[c][0], a[c][1], a[c][2], a[c][3]);
         }
         a[1][1] = mul_w16<1>(a[1][1]); a[1][2] = mul_w16<2>(a[1][2]); a[1][3] = mul_w16<3>(a[1][3]);
-        a[2][1] = mul_w16<2>(a[2][1]); a[2][2] = mul_w16<4>(a[2][2]); a[2][3] = mul_w16<6>(a[2][3]);
+        a[2][1] = mul_w16<2>(a[2][1]); /* a[2][2]·W16^4 = -i: folded into column 2's butterfly */ a[2][3] = mul_w16<6>(a[2][3]);
         a[3][1] = mul_w16<3>(a[3][1]); a[3][2] = mul_w16<6>(a[3][2]); a[3][3] = mul_w16<9>(a[3][3]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             cf b0 = a[0][r], b1 = a[1][r], b2 = a[2][r], b3 = a[3][r];
-            dft4(b0, b1, b2, b3);
+            if (r == 2) dft4_rot2(b0, b1, b2, b3);
+            else dft4(b0, b1, b2, b3);
             v[r] = b0; v[r + 4] = b1; v[r + 8] = b2; v[r + 12] = b3;
         }
     }
@@ -307,47 +394,26 @@ struct WaveFft {
         if constexpr (P + 1 < NPASS) pass<P + 1, NF>(v, lds, tw, t, st);
     }
 
-    // R2C split of pair index k (0 <= k <= NC/2): returns X[k] in xa and X[NC-k] in xb.
-    // wk = exp(-2*pi*i*k/N).
+    // R2C split of pair index k (0 <= k <= NC/2): returns 2·X[k] in xa and 2·X[NC-k] in xb (the halving of the
+    // even/odd split is left to the caller's epilogue factor).  wk = exp(-2*pi*i*k/N).
+    //   ev = zk + conj(zm), d = zk - conj(zm), tw = wk·(-i·d);  2X[k] = ev + tw, 2X[NC-k] = conj(ev - tw)
     __device__ static __forceinline__ void r2c_pair(const cf* lds, int k, cf wk, cf& xa, cf& xb) {
-        r2c_split(lds[lds_pad(k)], lds[lds_pad((NC - k) & (NC - 1))], wk, xa, xb);
+        r2c_split_x2(lds[lds_pad(k)], lds[lds_pad((NC - k) & (NC - 1))], wk, xa, xb);
     }
-    // 2·X[k] and 2·X[NC-k]: the halvings of the even/odd split are left to the caller's epilogue factor
     __device__ static __forceinline__ void r2c_split_x2(cf zk, cf zm, cf wk, cf& xa, cf& xb) {
-        cf ev = make_float2(zk.x + zm.x, zk.y - zm.y);
-        cf od = make_float2(zk.y + zm.y, zm.x - zk.x);
-        cf tw = cmul(wk, od);
+        const cf ev = cadd_conj(zk, zm), d = csub_conj(zk, zm);
+        const cf tw = cmul_rot(wk, d);
         xa = cadd(ev, tw);
-        cf d = csub(ev, tw);
-        xb = make_float2(d.x, -d.y);
-    }
-    __device__ static __forceinline__ void r2c_split_factored_x2(cf zk, cf zm, cf w0, int i, cf& xa, cf& xb) {
-        static_assert(E == 16, "factored R2C twiddles are wired for 2E = 32");
-        cf ev = make_float2(zk.x + zm.x, zk.y - zm.y);
-        cf od = make_float2(zk.y + zm.y, zm.x - zk.x);
-        cf tw = cmul(w0, mul_w32(od, i));
-        xa = cadd(ev, tw);
-        cf d = csub(ev, tw);
-        xb = make_float2(d.x, -d.y);
+        xb = csub_then_conj(ev, tw);
     }
     // Pair index i uses W_N^{t + i*LPF} = W_N^t · W_{2E}^i: one lane-dependent register (w0 = W_N^t) and a
-    // COMPILE-TIME constant per pair instead of E/2 hoisted twiddles (E == 16 only: W_32^i).
-    __device__ static __forceinline__ void r2c_split_factored(cf zk, cf zm, cf w0, int i, cf& xa, cf& xb) {
+    // COMPILE-TIME constant per pair instead of E/2 hoisted twiddles (E == 16 only: W_32^i; -i = W_32^8).
+    __device__ static __forceinline__ void r2c_split_factored_x2(cf zk, cf zm, cf w0, int i, cf& xa, cf& xb) {
         static_assert(E == 16, "factored R2C twiddles are wired for 2E = 32");
-        cf ev = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
-        cf od = make_float2(0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
-        cf tw = cmul(w0, mul_w32(od, i));
+        const cf ev = cadd_conj(zk, zm), d = csub_conj(zk, zm);
+        const cf tw = (i == 0) ? cmul_rot(w0, d) : cmul(mul_w32(d, i + 8), w0);
         xa = cadd(ev, tw);
-        cf d = csub(ev, tw);
-        xb = make_float2(d.x, -d.y);
-    }
-    __device__ static __forceinline__ void r2c_split(cf zk, cf zm, cf wk, cf& xa, cf& xb) {
-        cf ev = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
-        cf od = make_float2(0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
-        cf tw = cmul(wk, od);
-        xa = cadd(ev, tw);
-        cf d = csub(ev, tw);
-        xb = make_float2(d.x, -d.y);
+        xb = csub_then_conj(ev, tw);
     }
 };
 
@@ -364,7 +430,7 @@ struct FrameGeom {
     int hop;
     int center_pad;         // N/2 if center else 0
     int pad_mode;
-    int vec2_ok;            // host-verified: float2 loads of interior frames are 8-byte aligned
+    int vec2_ok;            // host-verified: cf loads of interior frames are 8-byte aligned
     long long n_frames;     // T
     long long rows;
     float scale;            // 1 or N^-0.5
@@ -372,13 +438,13 @@ struct FrameGeom {
 
 // zero-padded, centred window value pair for complex element m (samples 2m, 2m+1).  Branch-free:
 // clamped unconditional loads + selects, so the 2E loads of a lane issue back to back.
-__device__ __forceinline__ float2 window_pair(const FrameGeom& g, int m) {
+__device__ __forceinline__ cf window_pair(const FrameGeom& g, int m) {
     const int n0 = 2 * m - g.win_offset, n1 = n0 + 1;
     const int last = g.win_length - 1;
     const int c0 = n0 < 0 ? 0 : (n0 > last ? last : n0);
     const int c1 = n1 < 0 ? 0 : (n1 > last ? last : n1);
     const float w0 = g.window[c0], w1 = g.window[c1];
-    return make_float2(c0 == n0 ? w0 : 0.0f, c1 == n1 ? w1 : 0.0f);
+    return mkc(c0 == n0 ? w0 : 0.0f, c1 == n1 ? w1 : 0.0f);
 }
 
 // Source index of padded position i (torch.nn.functional.pad semantics), branch-free; *zero is set when
@@ -396,10 +462,10 @@ __device__ __forceinline__ int padded_index(int i, int L, int mode, bool* zero) 
 // Load + window one frame into first-pass register order.  `frame` may be >= T (then zeros).
 // Control flow is kept at WHOLE-FRAME granularity on purpose (three straight-line bodies): per-element
 // conditions make hipcc split the unrolled loads into one basic block each, which serialises their
-// latencies.  Interior frames: 16 float2 loads from a wave-uniform base.  Frames touching the padding:
+// latencies.  Interior frames: 16 cf loads from a wave-uniform base.  Frames touching the padding:
 // gathered through padded_index() four elements at a time in a rolled loop via the frame's LDS buffer.
 template <class F, bool HOIST_WIN>
-__device__ __forceinline__ void load_frame(cf* v, const FrameGeom& g, const float2* win, cf* lds, long long row,
+__device__ __forceinline__ void load_frame(cf* v, const FrameGeom& g, const cf* win, cf* lds, long long row,
                                            long long frame, int t) {
     constexpr int R0 = radix_at(F::NC, 0);
     constexpr int NB = F::E / R0;
@@ -407,10 +473,10 @@ __device__ __forceinline__ void load_frame(cf* v, const FrameGeom& g, const floa
     const long long start = frame * (long long)g.hop - g.center_pad;
     if (frame >= g.n_frames) {
 #pragma unroll
-        for (int e = 0; e < F::E; ++e) v[e] = make_float2(0.0f, 0.0f);
+        for (int e = 0; e < F::E; ++e) v[e] = mkc(0.0f, 0.0f);
     } else if (g.vec2_ok && start >= 0 && start + F::N <= g.length) {
-        const float2* src = reinterpret_cast<const float2*>(rp + start);
-        float2 s[F::E];
+        const cf* src = reinterpret_cast<const cf*>(rp + start);
+        cf s[F::E];
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -419,8 +485,8 @@ __device__ __forceinline__ void load_frame(cf* v, const FrameGeom& g, const floa
         for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int q = 0; q < R0; ++q) {
-                const float2 w = HOIST_WIN ? win[b * R0 + q] : window_pair(g, t + b * F::LPF + q * (F::NC / R0));
-                v[b * R0 + q] = make_float2(s[b * R0 + q].x * w.x, s[b * R0 + q].y * w.y);
+                const cf w = HOIST_WIN ? win[b * R0 + q] : window_pair(g, t + b * F::LPF + q * (F::NC / R0));
+                v[b * R0 + q] = cmul_elem(s[b * R0 + q], w);
             }
     } else {
         const int L = (int)g.length;
@@ -442,8 +508,8 @@ __device__ __forceinline__ void load_frame(cf* v, const FrameGeom& g, const floa
             for (int u = 0; u < 8; ++u) a[u] = rp[j[u]];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float2 w = window_pair(g, mm[u]);
-                lds[lds_pad(mm[u])] = make_float2(z[2 * u] ? 0.0f : a[2 * u] * w.x, z[2 * u + 1] ? 0.0f : a[2 * u + 1] * w.y);
+                const cf w = window_pair(g, mm[u]);
+                lds[lds_pad(mm[u])] = mkc(z[2 * u] ? 0.0f : a[2 * u] * w.x, z[2 * u + 1] ? 0.0f : a[2 * u + 1] * w.y);
             }
         }
         wave_lds_fence();
@@ -459,14 +525,14 @@ __device__ __forceinline__ void load_frame(cf* v, const FrameGeom& g, const floa
 // early, apply the window when the frame is consumed.  Returns false (nothing loaded) for frames that
 // touch the padding or lie past the end — those go through load_frame() at consumption time.
 template <class F>
-__device__ __forceinline__ bool prefetch_frame_raw(float2* raw, const FrameGeom& g, long long row, long long frame,
+__device__ __forceinline__ bool prefetch_frame_raw(cf* raw, const FrameGeom& g, long long row, long long frame,
                                                    int t) {
     constexpr int R0 = radix_at(F::NC, 0);
     constexpr int NB = F::E / R0;
     const long long start = frame * (long long)g.hop - g.center_pad;
     const bool ok = g.vec2_ok && frame < g.n_frames && start >= 0 && start + F::N <= g.length;
     if (ok) {
-        const float2* src = reinterpret_cast<const float2*>(g.wave + row * g.row_stride + start);
+        const cf* src = reinterpret_cast<const cf*>(g.wave + row * g.row_stride + start);
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -476,17 +542,17 @@ __device__ __forceinline__ bool prefetch_frame_raw(float2* raw, const FrameGeom&
 }
 
 template <class F>
-__device__ __forceinline__ void apply_window(cf* v, const float2* raw, const float2* win) {
+__device__ __forceinline__ void apply_window(cf* v, const cf* raw, const cf* win) {
 #pragma unroll
-    for (int e = 0; e < F::E; ++e) v[e] = make_float2(raw[e].x * win[e].x, raw[e].y * win[e].y);
+    for (int e = 0; e < F::E; ++e) v[e] = cmul_elem(raw[e], win[e]);
 }
 
 template <class F>
-__device__ __forceinline__ void load_window_regs(float2* win, const FrameGeom& g, int t) {
+__device__ __forceinline__ void load_window_regs(cf* win, const FrameGeom& g, int t) {
     constexpr int R0 = radix_at(F::NC, 0);
     constexpr int NB = F::E / R0;
-    if (g.win_length == F::N) {          // full-length window (the default): plain float2 loads, no index math
-        const float2* w2 = reinterpret_cast<const float2*>(g.window);
+    if (g.win_length == F::N) {          // full-length window (the default): plain cf loads, no index math
+        const cf* w2 = reinterpret_cast<const cf*>(g.window);
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -501,7 +567,7 @@ __device__ __forceinline__ void load_window_regs(float2* win, const FrameGeom& g
 
 // |X|^power of an (already scaled) spectrum value
 __device__ __forceinline__ float cpow_mag(cf x, float power) {
-    float s = x.x * x.x + x.y * x.y;
+    float s = cnorm2(x);
     if (power == 2.0f) return s;
     float m = sqrtf(s);
     if (power == 1.0f) return m;

@@ -41,11 +41,11 @@ int get_tables(int n_fft, Tables* out) {
     const double two_pi = 6.283185307179586476925286766559;
     for (int k = 0; k < nc; ++k) {
         double a = -two_pi * (double)k / (double)nc;
-        host[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+        host[k] = mkc((float)std::cos(a), (float)std::sin(a));
     }
     for (int k = 0; k < n_post; ++k) {
         double a = -two_pi * (double)k / (double)n_fft;
-        host[nc + k] = make_float2((float)std::cos(a), (float)std::sin(a));
+        host[nc + k] = mkc((float)std::cos(a), (float)std::sin(a));
     }
     cf* dptr = nullptr;
     TAC_HIP(hipMalloc((void**)&dptr, host.size() * sizeof(cf)));

@@ -39,7 +39,7 @@ struct MelFftConsts {
     static constexpr bool HOIST_WINDOW = HOISTW;
     cf tw[F::NTW];
     cf ptw[FACT ? 1 : F::NPAIR];
-    float2 win[HOISTW ? F::E : 1];            // window pairs of this lane's elements (kernels with spare registers)
+    cf win[HOISTW ? F::E : 1];            // window pairs of this lane's elements (kernels with spare registers)
     __device__ __forceinline__ void load(const Tables& tb, const FrameGeom& g, int t) {
         if constexpr (HOISTW) load_window_regs<F>(win, g, t);
         F::load_twiddles(tw, tb.w_nc, t);
@@ -65,7 +65,7 @@ struct MelFftConsts {
 template <class C, bool POW2, int NFA = 1, bool HOISTW = false, class ST = NoStamp, bool PIPE = false, class K = void>
 __device__ __forceinline__ void mel_phase_a(const FrameGeom& g, cf* bufs, const K& k,
                                             int w, int sub, int t, int row, long long f0,
-                                            float2* pre_raw = nullptr, bool* pre_ok_p = nullptr, ST* stp = nullptr,
+                                            cf* pre_raw = nullptr, bool* pre_ok_p = nullptr, ST* stp = nullptr,
                                             int next_row = 0, long long next_f0 = -1) {
     ST st_local;
     ST& st = stp ? *stp : st_local;
@@ -86,9 +86,9 @@ __device__ __forceinline__ void mel_phase_a(const FrameGeom& g, cf* bufs, const 
             cf v[NF][E];
             int tl = t;
             asm volatile("" : "+v"(tl));      // launder: window loads stay inside the loop (register budget)
-            float2 winl[HOISTW ? 1 : F::E];
+            cf winl[HOISTW ? 1 : F::E];
             if constexpr (!HOISTW) load_window_regs<F>(winl, g, tl);
-            const float2* win = HOISTW ? k.win : winl;
+            const cf* win = HOISTW ? k.win : winl;
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
                 fi[f] = ((w * C::GPW + rep + f) * F::G) + sub;              // frame index within the tile
@@ -132,12 +132,12 @@ __device__ __forceinline__ void mel_phase_a(const FrameGeom& g, cf* bufs, const 
                     // xa, xb = 2·X: the halving and the `normalized` scale are one factor applied to the power
                     if constexpr (FACT) F::r2c_split_factored_x2(v[f][2 * i], v[f][2 * i + 1], ptw[0], i, xa, xb);
                     else F::r2c_split_x2(v[f][2 * i], v[f][2 * i + 1], ptw[FACT ? 0 : i], xa, xb);
-                    const float pa = (xa.x * xa.x + xa.y * xa.y) * pfac, pb = (xb.x * xb.x + xb.y * xb.y) * pfac;
+                    const float pa = cnorm2(xa) * pfac, pb = cnorm2(xb) * pfac;
                     prow[kk] = POW2 ? pa : sqrtf(pa);
                     prow[NC - kk] = POW2 ? pb : sqrtf(pb);
                 }
                 if (t == 0) {
-                    const cf xm = make_float2(zmid.x * g.scale, -zmid.y * g.scale);    // X[NC/2] = conj(Z[NC/2])
+                    const cf xm = mkc(zmid.x * g.scale, -zmid.y * g.scale);    // X[NC/2] = conj(Z[NC/2])
                     const float pm = xm.x * xm.x + xm.y * xm.y;
                     prow[NC / 2] = POW2 ? pm : sqrtf(pm);
                 }

@@ -101,7 +101,7 @@ melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
     // the contraction and store phases): its HBM/L2 round trip is hidden instead of opening every phase A
     constexpr bool PIPE = (F::G == 1) && (TAC_SP_PIPE != 0);
     constexpr bool PREFETCH = !PIPE && (F::G == 1) && (TAC_SP_PREFETCH != 0);
-    float2 raw[(PREFETCH || PIPE) ? F::E : 1];
+    cf raw[(PREFETCH || PIPE) ? F::E : 1];
     bool pre_ok = false;
     if constexpr (PREFETCH || PIPE) {
         if (begin < end) {

@@ -86,6 +86,7 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
     const int end = begin + chunk < total ? begin + chunk : total;
     const int nbins = ep.onesided ? NC + 1 : 2 * NC;
     const long long per_frame = (long long)nbins * (MODE == 0 ? 2 : 1);
+    const float hscale = 0.5f * g.scale;                  // the R2C split returns 2·X
 
     StftStamp st;
 #if TAC_STFT_TIMING
@@ -100,7 +101,7 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
         int tl = t;
         asm volatile("" : "+v"(tl));          // launder: keeps the per-iteration table loads inside the loop
         if constexpr (!HOIST) F::load_twiddles(tw, tb.w_nc, tl);
-        float2 win[F::E];                     // window: L1-resident, shared by the NF frames of this iteration
+        cf win[F::E];                     // window: L1-resident, shared by the NF frames of this iteration
         load_window_regs<F>(win, g, tl);
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
@@ -108,7 +109,7 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
             frame[f] = uframe0 + f * F::G + sub;            // may be >= T: load_frame() then yields zeros
 #if TAC_ABL == 1
 #pragma unroll
-            for (int e = 0; e < E; ++e) v[f][e] = make_float2((float)(t + e) * win[e].x, (float)(unit + e) * win[e].y);
+            for (int e = 0; e < E; ++e) v[f][e] = mkc((float)(t + e) * win[e].x, (float)(unit + e) * win[e].y);
 #else
             load_frame<F, true>(v[f], g, win, lds[f], row[f], frame[f], t);
 #endif
@@ -146,26 +147,26 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 #pragma unroll
                         for (int i = 0; i < F::NPAIR; ++i) {
                             F::r2c_pair(lds[f], t + i * F::LPF, HOIST ? ptw[i] : tb.w_n[tl + i * F::LPF], xa[i], xb[i]);
-                            xa[i].x *= g.scale; xa[i].y *= g.scale; xb[i].x *= g.scale; xb[i].y *= g.scale;
+                            xa[i] = cscale(xa[i], hscale); xb[i] = cscale(xb[i], hscale);
                         }
-                        F::r2c_pair(lds[f], NC / 2, make_float2(0.0f, -1.0f), xm, unused);
-                        xm.x *= g.scale; xm.y *= g.scale;
+                        F::r2c_pair(lds[f], NC / 2, mkc(0.0f, -1.0f), xm, unused);
+                        xm = cscale(xm, hscale);
                         wave_lds_fence();                                         // every Z of this frame is in registers
                         float* srow = stage + f * LENF;
 #pragma unroll
                         for (int i = 0; i < F::NPAIR; ++i) {
                             const int k = t + i * F::LPF;
                             if constexpr (MODE == 0) {
-                                reinterpret_cast<float2*>(srow)[k] = xa[i];
-                                reinterpret_cast<float2*>(srow)[NC - k] = xb[i];
+                                reinterpret_cast<cf*>(srow)[k] = xa[i];
+                                reinterpret_cast<cf*>(srow)[NC - k] = xb[i];
                             } else {
-                                srow[k] = xa[i].x * xa[i].x + xa[i].y * xa[i].y;
-                                srow[NC - k] = xb[i].x * xb[i].x + xb[i].y * xb[i].y;
+                                srow[k] = cnorm2(xa[i]);
+                                srow[NC - k] = cnorm2(xb[i]);
                             }
                         }
                         if (t == 0) {
-                            if constexpr (MODE == 0) reinterpret_cast<float2*>(srow)[NC / 2] = xm;
-                            else srow[NC / 2] = xm.x * xm.x + xm.y * xm.y;
+                            if constexpr (MODE == 0) reinterpret_cast<cf*>(srow)[NC / 2] = xm;
+                            else srow[NC / 2] = cnorm2(xm);
                         }
                         wave_lds_fence();
                         ++nlive;
@@ -195,7 +196,7 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
             const bool live = frame[f] < g.n_frames;
 #endif
             float* obase = ep.out + (row[f] * g.n_frames + (live ? frame[f] : 0)) * per_frame;
-            float2* o2 = reinterpret_cast<float2*>(obase);
+            cf* o2 = reinterpret_cast<cf*>(obase);
             float* prow = reinterpret_cast<float*>(lds[f]);
             if (simple) {
                 // common case: X (complex) or |X|^2 goes straight from registers to coalesced stores
@@ -205,21 +206,21 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
                         const int k = t + i * F::LPF;
                         cf xa, xb;
                         F::r2c_pair(lds[f], k, HOIST ? ptw[i] : tb.w_n[tl + i * F::LPF], xa, xb);
-                        xa.x *= g.scale; xa.y *= g.scale; xb.x *= g.scale; xb.y *= g.scale;
+                        xa = cscale(xa, hscale); xb = cscale(xb, hscale);
                         if constexpr (MODE == 0) {
                             o2[k] = xa;
                             o2[NC - k] = xb;
                         } else {
-                            obase[k] = xa.x * xa.x + xa.y * xa.y;
-                            obase[NC - k] = xb.x * xb.x + xb.y * xb.y;
+                            obase[k] = cnorm2(xa);
+                            obase[NC - k] = cnorm2(xb);
                         }
                     }
                     if (t == 0) {
                         cf xm, unused;
-                        F::r2c_pair(lds[f], NC / 2, make_float2(0.0f, -1.0f), xm, unused);
-                        xm.x *= g.scale; xm.y *= g.scale;
+                        F::r2c_pair(lds[f], NC / 2, mkc(0.0f, -1.0f), xm, unused);
+                        xm = cscale(xm, hscale);
                         if constexpr (MODE == 0) o2[NC / 2] = xm;
-                        else obase[NC / 2] = xm.x * xm.x + xm.y * xm.y;
+                        else obase[NC / 2] = cnorm2(xm);
                     }
                 }
             } else {
@@ -228,10 +229,10 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 #pragma unroll
                 for (int i = 0; i < F::NPAIR; ++i) {
                     F::r2c_pair(lds[f], t + i * F::LPF, HOIST ? ptw[i] : tb.w_n[tl + i * F::LPF], xa[i], xb[i]);
-                    xa[i].x *= g.scale; xa[i].y *= g.scale; xb[i].x *= g.scale; xb[i].y *= g.scale;
+                    xa[i] = cscale(xa[i], hscale); xb[i] = cscale(xb[i], hscale);
                 }
-                F::r2c_pair(lds[f], NC / 2, make_float2(0.0f, -1.0f), xm, unused);
-                xm.x *= g.scale; xm.y *= g.scale;
+                F::r2c_pair(lds[f], NC / 2, mkc(0.0f, -1.0f), xm, unused);
+                xm = cscale(xm, hscale);
                 if constexpr (MODE == 0) {
                     if (live) {
 #pragma unroll
@@ -240,13 +241,13 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
                             o2[k] = xa[i];
                             o2[NC - k] = xb[i];
                             if (k > 0) {            // mirror bins N-k = conj(X[k]), 0 < k < NC
-                                o2[2 * NC - k] = make_float2(xa[i].x, -xa[i].y);
-                                o2[NC + k] = make_float2(xb[i].x, -xb[i].y);
+                                o2[2 * NC - k] = mkc(xa[i].x, -xa[i].y);
+                                o2[NC + k] = mkc(xb[i].x, -xb[i].y);
                             }
                         }
                         if (t == 0) {
                             o2[NC / 2] = xm;
-                            o2[NC + NC / 2] = make_float2(xm.x, -xm.y);
+                            o2[NC + NC / 2] = mkc(xm.x, -xm.y);
                         }
                     }
                 } else {
@@ -254,10 +255,10 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 #pragma unroll
                     for (int i = 0; i < F::NPAIR; ++i) {
                         const int k = t + i * F::LPF;
-                        prow[k] = xa[i].x * xa[i].x + xa[i].y * xa[i].y;
-                        prow[NC - k] = xb[i].x * xb[i].x + xb[i].y * xb[i].y;
+                        prow[k] = cnorm2(xa[i]);
+                        prow[NC - k] = cnorm2(xb[i]);
                     }
-                    if (t == 0) prow[NC / 2] = xm.x * xm.x + xm.y * xm.y;
+                    if (t == 0) prow[NC / 2] = cnorm2(xm);
                     wave_lds_fence();
                     if (live) finish_power_row<NC, F::LPF>(prow, obase, t, nbins, ep.power, ep.db, ep.amin, ep.log10_ref);
                 }
@@ -292,7 +293,7 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int WAVE_SLOTS = ((F::PADDED + 1) / 2) * 2;
     cf* const lds = smem + w * WAVE_SLOTS;
-    float2* const wlds = reinterpret_cast<float2*>(smem + STFT_WAVES * WAVE_SLOTS);    // NC window pairs
+    cf* const wlds = reinterpret_cast<cf*>(smem + STFT_WAVES * WAVE_SLOTS);    // NC window pairs
     for (int m = threadIdx.x; m < NC; m += STFT_WAVES * 64) wlds[m] = window_pair(g, m);
 
     cf tw[F::NTW];
@@ -308,8 +309,9 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
     const int end = begin + chunk < total ? begin + chunk : total;
     constexpr int LENF = (MODE == 0 ? 2 : 1) * (NC + 1);
     constexpr int NST = ((LENF >> 2) + 63) / 64;          // 16-byte wave-stores per output row
+    const float hscale = 0.5f * g.scale;                  // the R2C split returns 2·X
 
-    float2 raw[E];
+    cf raw[E];
     bool pre = false;
     int unit = begin + w;
     if (unit < end) pre = prefetch_frame_raw<F>(raw, g, unit / T, unit % T, t);
@@ -329,8 +331,8 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
         if (pre) {
 #pragma unroll
             for (int q = 0; q < E; ++q) {
-                const float2 wv = wlds[t + q * F::LPF];
-                v[0][q] = make_float2(raw[q].x * wv.x, raw[q].y * wv.y);
+                const cf wv = wlds[t + q * F::LPF];
+                v[0][q] = cmul_elem(raw[q], wv);
             }
         } else {
             load_frame<F, false>(v[0], g, nullptr, lds, urow, uframe, t);     // frames touching the padding
@@ -347,6 +349,7 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
             if (nxt < end) pre = prefetch_frame_raw<F>(raw, g, nxt / T, nxt % T, t);
         }
         __builtin_amdgcn_sched_barrier(0);
+        st.mark(1);                                         // next frame's loads issued
 
         const long long g0 = ((long long)urow * T + uframe) * LENF;
         const int a = (int)(g0 & 3);
@@ -356,25 +359,26 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 #pragma unroll
             for (int i = 0; i < F::NPAIR; ++i) {
                 F::r2c_pair(lds, t + i * F::LPF, ptw[i], xa[i], xb[i]);
-                xa[i].x *= g.scale; xa[i].y *= g.scale; xb[i].x *= g.scale; xb[i].y *= g.scale;
+                xa[i] = cscale(xa[i], hscale); xb[i] = cscale(xb[i], hscale);
             }
-            F::r2c_pair(lds, NC / 2, make_float2(0.0f, -1.0f), xm, unused);
-            xm.x *= g.scale; xm.y *= g.scale;
+            F::r2c_pair(lds, NC / 2, mkc(0.0f, -1.0f), xm, unused);
+            xm = cscale(xm, hscale);
             wave_lds_fence();                                         // every Z of this frame is in registers
+            st.mark(7);                                               // R2C split done
 #pragma unroll
             for (int i = 0; i < F::NPAIR; ++i) {
                 const int k = t + i * F::LPF;
                 if constexpr (MODE == 0) {
-                    reinterpret_cast<float2*>(stage)[k] = xa[i];
-                    reinterpret_cast<float2*>(stage)[NC - k] = xb[i];
+                    reinterpret_cast<cf*>(stage)[k] = xa[i];
+                    reinterpret_cast<cf*>(stage)[NC - k] = xb[i];
                 } else {
-                    stage[k] = xa[i].x * xa[i].x + xa[i].y * xa[i].y;
-                    stage[NC - k] = xb[i].x * xb[i].x + xb[i].y * xb[i].y;
+                    stage[k] = cnorm2(xa[i]);
+                    stage[NC - k] = cnorm2(xb[i]);
                 }
             }
             if (t == 0) {
-                if constexpr (MODE == 0) reinterpret_cast<float2*>(stage)[NC / 2] = xm;
-                else stage[NC / 2] = xm.x * xm.x + xm.y * xm.y;
+                if constexpr (MODE == 0) reinterpret_cast<cf*>(stage)[NC / 2] = xm;
+                else stage[NC / 2] = cnorm2(xm);
             }
             wave_lds_fence();
         }
@@ -442,7 +446,7 @@ static int launch_stft(const FrameGeom& g, const Tables& tb, const StftEpilogue&
     if constexpr (TAC_STFT_PIPE && F::G == 1 && E == 16) {
         const bool simple = (MODE == 0) ? (ep.onesided != 0) : (ep.onesided && ep.power == 2.0f && !ep.db);
         if (simple) {
-            const size_t bytes = (size_t)STFT_WAVES * (((F::PADDED + 1) / 2) * 2) * sizeof(cf) + (size_t)NC * sizeof(float2);
+            const size_t bytes = (size_t)STFT_WAVES * (((F::PADDED + 1) / 2) * 2) * sizeof(cf) + (size_t)NC * sizeof(cf);
             long long blocks = (groups + STFT_WAVES - 1) / STFT_WAVES;
             const long long cap = (long long)device_cu_count() * 2;
             if (blocks > cap) blocks = cap;
