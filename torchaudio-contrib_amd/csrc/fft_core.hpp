@@ -331,17 +331,25 @@ struct WaveFft {
     template <int NF>
     __device__ static __forceinline__ void run(cf (&v)[NF][E_], cf* const (&lds)[NF], const cf* tw, int t) {
         NoStamp st;
-        run<NF>(v, lds, tw, t, st);
+        run<NF>(v, lds, tw, t, st, t);
     }
-    // stamps (timing builds): 2P+1 = pass P's operands read back and twiddled, 2P+2 = its butterflies done
+    // stamps (timing builds): 2P+1 = pass P's operands read back and twiddled, 2P+2 = its butterflies done.
+    // t0: the lane's first-pass column (v[f][b*R0 + q] = z_f[(t0 + b*LPF) + q*NC/R0]); any permutation of the
+    // lanes works there (frame_col_of_lane) because pass 0 only uses it to place its outputs.
+    template <int NF, class ST>
+    __device__ static __forceinline__ void run(cf (&v)[NF][E_], cf* const (&lds)[NF], const cf* tw, int t, ST& st,
+                                               int t0) {
+        pass<0, NF>(v, lds, tw, t, st, t0);
+        wave_lds_fence();
+    }
     template <int NF, class ST>
     __device__ static __forceinline__ void run(cf (&v)[NF][E_], cf* const (&lds)[NF], const cf* tw, int t, ST& st) {
-        pass<0, NF>(v, lds, tw, t, st);
-        wave_lds_fence();
+        run<NF>(v, lds, tw, t, st, t);
     }
 
     template <int P, int NF, class ST>
-    __device__ static __forceinline__ void pass(cf (&v)[NF][E_], cf* const (&lds)[NF], const cf* tw, int t, ST& st) {
+    __device__ static __forceinline__ void pass(cf (&v)[NF][E_], cf* const (&lds)[NF], const cf* tw, int t, ST& st,
+                                                int t0) {
         constexpr int R = radix_at(NC, P), S = stride_at(NC, P), OFF = twiddles_before(NC, E, P);
         constexpr int NB = E / R;
         static_assert(NB >= 1, "radix larger than elements per lane");
@@ -378,7 +386,7 @@ struct WaveFft {
         for (int f = 0; f < NF; ++f)
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                const int j = t + b * LPF;
+                const int j = (P == 0 ? t0 : t) + b * LPF;
                 if constexpr (S == 1) {
                     static_assert(R == 16, "first pass is radix 16");
                     cf* dst = lds[f] + 17 * j;                          // pad(16 j + k) = 17 j + k, k < 16
@@ -391,7 +399,7 @@ struct WaveFft {
                     for (int k = 0; k < R; ++k) dst[lds_pad_c(k * S)] = v[f][b * R + k];
                 }
             }
-        if constexpr (P + 1 < NPASS) pass<P + 1, NF>(v, lds, tw, t, st);
+        if constexpr (P + 1 < NPASS) pass<P + 1, NF>(v, lds, tw, t, st, t0);
     }
 
     // R2C split of pair index k (0 <= k <= NC/2): returns 2·X[k] in xa and 2·X[NC-k] in xb (the halving of the
@@ -431,6 +439,7 @@ struct FrameGeom {
     int center_pad;         // N/2 if center else 0
     int pad_mode;
     int vec2_ok;            // host-verified: cf loads of interior frames are 8-byte aligned
+    int vec4_ok;            // ... and 16-byte aligned (hop, pad, row stride multiples of 4 samples)
     long long n_frames;     // T
     long long rows;
     float scale;            // 1 or N^-0.5
@@ -539,6 +548,53 @@ __device__ __forceinline__ bool prefetch_frame_raw(cf* raw, const FrameGeom& g, 
             for (int q = 0; q < R0; ++q) raw[b * R0 + q] = src[t + b * F::LPF + q * (F::NC / R0)];
     }
     return ok;
+}
+
+// ---- 16-byte variant for one-frame-per-wave geometries (LPF == 64): 8 dwordx4 requests per frame instead of 16
+// dwordx2 (the address path, not bandwidth, is what a frame's loads queue on).  Lane t's request i covers complex
+// elements 2t + 128i and 2t + 128i + 1, i.e. columns (2t mod 64, +1) at q = 2i + (t >= 32): one v_permlane32_swap per
+// register (frame_raw_unswizzle, at consumption time) leaves lane t < 32 with column 2t and lane t >= 32 with column
+// 2(t-32)+1, each for all q — the lane -> column map frame_col_of_lane(), which callers use for the window, the
+// edge-frame path and pass 0's output placement.
+__device__ __forceinline__ int frame_col_of_lane(int t, bool vec4) { return vec4 ? (((t & 31) << 1) | (t >> 5)) : t; }
+
+template <class F>
+__device__ __forceinline__ bool prefetch_frame_raw_x(cf* raw, const FrameGeom& g, long long row, long long frame,
+                                                     int t, int col, bool vec4) {
+    static_assert(F::LPF == 64 && radix_at(F::NC, 0) == F::E, "wired for one frame per wave");
+    const long long start = frame * (long long)g.hop - g.center_pad;
+    const bool ok = g.vec2_ok && frame < g.n_frames && start >= 0 && start + F::N <= g.length;
+    if (ok) {
+        const float* base = g.wave + row * g.row_stride + start;
+        if (vec4) {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            const f4* src = reinterpret_cast<const f4*>(base);
+#pragma unroll
+            for (int i = 0; i < F::E / 2; ++i) {
+                const f4 x = src[t + i * 64];
+                raw[2 * i] = mkc(x.x, x.y);
+                raw[2 * i + 1] = mkc(x.z, x.w);
+            }
+        } else {
+            const cf* src = reinterpret_cast<const cf*>(base);
+#pragma unroll
+            for (int q = 0; q < F::E; ++q) raw[q] = src[col + q * (F::NC / F::E)];
+        }
+    }
+    return ok;
+}
+
+template <class F>
+__device__ __forceinline__ void frame_raw_unswizzle(cf* raw, bool vec4) {
+    if (vec4) {
+#pragma unroll
+        for (int i = 0; i < F::E / 2; ++i) {
+            const auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(raw[2 * i].x), __float_as_uint(raw[2 * i + 1].x), false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(raw[2 * i].y), __float_as_uint(raw[2 * i + 1].y), false, false);
+            raw[2 * i] = mkc(__uint_as_float(sx[0]), __uint_as_float(sy[0]));
+            raw[2 * i + 1] = mkc(__uint_as_float(sx[1]), __uint_as_float(sy[1]));
+        }
+    }
 }
 
 template <class F>

@@ -84,6 +84,8 @@ int make_geometry(const float* wave, const float* window, const tac_stft_desc* d
     g->pad_mode = d->pad_mode;
     g->vec2_ok = ((d->hop & 1) == 0) && ((pad & 1) == 0) && ((d->row_stride & 1) == 0) &&
                  ((reinterpret_cast<uintptr_t>(wave) & 7u) == 0);
+    g->vec4_ok = g->vec2_ok && ((d->hop & 3) == 0) && ((pad & 3) == 0) && ((d->row_stride & 3) == 0) &&
+                 ((reinterpret_cast<uintptr_t>(wave) & 15u) == 0);
     g->n_frames = T;
     g->rows = d->rows;
     g->scale = d->normalized ? (float)(1.0 / std::sqrt((double)d->n_fft)) : 1.0f;

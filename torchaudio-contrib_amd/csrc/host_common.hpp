@@ -6,6 +6,11 @@
 #include "../../include/tac_amd.h"
 #include "fft_core.hpp"
 
+#ifndef TAC_V4_LOADS
+#define TAC_V4_LOADS 0      // 1: fetch frames with 16-byte requests + v_permlane32_swap (A/B knob: measured neutral for the
+                            // STFT kernels and slower for the fused mel kernel, whose register budget it breaks)
+#endif
+
 namespace tac {
 
 extern thread_local int g_last_hip_error;

@@ -40,8 +40,9 @@ struct MelFftConsts {
     cf tw[F::NTW];
     cf ptw[FACT ? 1 : F::NPAIR];
     cf win[HOISTW ? F::E : 1];            // window pairs of this lane's elements (kernels with spare registers)
-    __device__ __forceinline__ void load(const Tables& tb, const FrameGeom& g, int t) {
-        if constexpr (HOISTW) load_window_regs<F>(win, g, t);
+    // tcol: the lane's first-pass column (== t unless frames are fetched with 16-byte requests, fft_core.hpp)
+    __device__ __forceinline__ void load(const Tables& tb, const FrameGeom& g, int t, int tcol) {
+        if constexpr (HOISTW) load_window_regs<F>(win, g, tcol);
         F::load_twiddles(tw, tb.w_nc, t);
         if constexpr (FACT) {
             ptw[0] = tb.w_n[t];
@@ -66,7 +67,8 @@ template <class C, bool POW2, int NFA = 1, bool HOISTW = false, class ST = NoSta
 __device__ __forceinline__ void mel_phase_a(const FrameGeom& g, cf* bufs, const K& k,
                                             int w, int sub, int t, int row, long long f0,
                                             cf* pre_raw = nullptr, bool* pre_ok_p = nullptr, ST* stp = nullptr,
-                                            int next_row = 0, long long next_f0 = -1) {
+                                            int next_row = 0, long long next_f0 = -1, int tcol = -1, bool vec4 = false) {
+    if (tcol < 0) tcol = t;
     ST st_local;
     ST& st = stp ? *stp : st_local;
     bool pre_ok = pre_ok_p ? *pre_ok_p : false;
@@ -87,18 +89,22 @@ __device__ __forceinline__ void mel_phase_a(const FrameGeom& g, cf* bufs, const 
             int tl = t;
             asm volatile("" : "+v"(tl));      // launder: window loads stay inside the loop (register budget)
             cf winl[HOISTW ? 1 : F::E];
-            if constexpr (!HOISTW) load_window_regs<F>(winl, g, tl);
+            if constexpr (!HOISTW) load_window_regs<F>(winl, g, PIPE ? tcol : tl);
             const cf* win = HOISTW ? k.win : winl;
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
                 fi[f] = ((w * C::GPW + rep + f) * F::G) + sub;              // frame index within the tile
                 lds[f] = bufs + fi[f] * F::PADDED;
-                if (f == 0 && (PIPE || rep == 0) && pre_ok) apply_window<F>(v[f], pre_raw, win);
-                else load_frame<F, true>(v[f], g, win, lds[f], row, (fi[f] < TILE) ? f0 + fi[f] : g.n_frames, t);
+                if (f == 0 && (PIPE || rep == 0) && pre_ok) {
+                    if constexpr (PIPE) frame_raw_unswizzle<F>(pre_raw, vec4);
+                    apply_window<F>(v[f], pre_raw, win);
+                } else {
+                    load_frame<F, true>(v[f], g, win, lds[f], row, (fi[f] < TILE) ? f0 + fi[f] : g.n_frames, PIPE ? tcol : t);
+                }
             }
             st.mark(8);
 #if TAC_MEL_ABL != 1
-            F::template run<NF>(v, lds, tw, t, st);
+            F::template run<NF>(v, lds, tw, t, st, PIPE ? tcol : t);
 #endif
             st.mark(9);
             if constexpr (PIPE) {
@@ -109,7 +115,8 @@ __device__ __forceinline__ void mel_phase_a(const FrameGeom& g, cf* bufs, const 
                 const long long nfi = w * C::GPW + (same_tile ? rep + 1 : 0);
                 const long long nframe = (same_tile ? f0 : next_f0) + nfi;
                 pre_ok = false;
-                if ((same_tile || next_f0 >= 0) && nfi < TILE) pre_ok = prefetch_frame_raw<F>(pre_raw, g, nrow, nframe, t);
+                if ((same_tile || next_f0 >= 0) && nfi < TILE)
+                    pre_ok = prefetch_frame_raw_x<F>(pre_raw, g, nrow, nframe, t, tcol, vec4);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll

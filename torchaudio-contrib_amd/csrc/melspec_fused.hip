@@ -151,7 +151,7 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
     const int slot0 = __builtin_amdgcn_readfirstlane(tab->wave_slot0[w]);
 
     MelFftConsts<F> fftk;
-    fftk.load(tb, g, t);
+    fftk.load(tb, g, t, t);
 
     const int tiles_per_row = (int)((g.n_frames + TILE - 1) / TILE);
     const int total_tiles = (int)g.rows * tiles_per_row;

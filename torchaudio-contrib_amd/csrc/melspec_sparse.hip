@@ -57,7 +57,7 @@ struct SparseArgs {
     float* out;            // [rows][T][M]
 };
 
-template <int NC, int E, bool POW2>
+template <int NC, int E, bool POW2, bool V4>
 __global__ void __launch_bounds__((MelCfg<NC, E, SP_TILE>::WAVES * 64), 2)
 melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
     using C = MelCfg<NC, E, SP_TILE>;
@@ -79,8 +79,11 @@ melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
     for (int i = tid; i < m.wtot; i += WAVES * 64) wlds[i] = m.wpack[i];
     for (int i = tid; i < WAVES * 4 * m.dstride; i += WAVES * 64) dlds[i] = m.desc[i];
 
+    constexpr bool PIPE = (F::G == 1) && (TAC_SP_PIPE != 0);
+    constexpr bool v4 = PIPE && V4;                       // frames fetched with 16-byte requests (fft_core.hpp)
+    const int tcol = frame_col_of_lane(t, v4);
     MelFftConsts<F, TAC_SP_HOISTW != 0, (TAC_SP_FACT != 0) && (TAC_SP_PIPE != 0)> fftk;
-    fftk.load(tb, g, t);
+    fftk.load(tb, g, t, tcol);
     __syncthreads();
 
     const int tiles_per_row = (int)((g.n_frames + TILE - 1) / TILE);
@@ -99,14 +102,15 @@ melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
 
     // software prefetch of this wave's first frame of the NEXT tile (raw samples, 32 registers that are idle during
     // the contraction and store phases): its HBM/L2 round trip is hidden instead of opening every phase A
-    constexpr bool PIPE = (F::G == 1) && (TAC_SP_PIPE != 0);
     constexpr bool PREFETCH = !PIPE && (F::G == 1) && (TAC_SP_PREFETCH != 0);
     cf raw[(PREFETCH || PIPE) ? F::E : 1];
     bool pre_ok = false;
     if constexpr (PREFETCH || PIPE) {
         if (begin < end) {
             const int r0 = begin / tiles_per_row;
-            pre_ok = prefetch_frame_raw<F>(raw, g, r0, (long long)(begin - r0 * tiles_per_row) * TILE + w * C::GPW, t);
+            const long long fr0 = (long long)(begin - r0 * tiles_per_row) * TILE + w * C::GPW;
+            if constexpr (PIPE) pre_ok = prefetch_frame_raw_x<F>(raw, g, r0, fr0, t, tcol, v4);
+            else pre_ok = prefetch_frame_raw<F>(raw, g, r0, fr0, t);
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the tile loop is entered with nothing in flight
     }
@@ -128,7 +132,7 @@ melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
             const int nr = nt / tiles_per_row;
             const long long nf0 = nt < end ? (long long)(nt - nr * tiles_per_row) * TILE : -1;
             mel_phase_a<C, POW2, 1, TAC_SP_HOISTW != 0, decltype(st), true>(g, bufs, fftk, w, sub, t, row, f0, raw, &pre_ok,
-                                                                             &st, nr, nf0);
+                                                                             &st, nr, nf0, tcol, v4);
         } else {
             mel_phase_a<C, POW2, TAC_SP_NF, TAC_SP_HOISTW != 0>(g, bufs, fftk, w, sub, t, row, f0, raw, &pre_ok, &st);
         }
@@ -243,7 +247,7 @@ melspec_sparse_split_kernel(FrameGeom g, Tables tb, SparseArgs m) {
     if (tid < 2) counters[tid] = 0;
 
     MelFftConsts<F, TAC_SP_HOISTW != 0> fftk;
-    fftk.load(tb, g, t);
+    fftk.load(tb, g, t, t);
     __syncthreads();
 
     const int tiles_per_row = (int)((g.n_frames + HT - 1) / HT);
@@ -366,12 +370,15 @@ static int launch_sparse(const FrameGeom& g, const Tables& tb, const SparseArgs&
             return TAC_OK;
         }
     }
-    auto kern = pow2 ? melspec_sparse_kernel<NC, E, true> : melspec_sparse_kernel<NC, E, false>;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[pow2]) {
+    constexpr bool CAN_V4 = (C::F::G == 1) && (TAC_SP_PIPE != 0) && (TAC_V4_LOADS != 0);
+    const bool v4 = CAN_V4 && g.vec4_ok;
+    auto kern = v4 ? (pow2 ? melspec_sparse_kernel<NC, E, true, CAN_V4> : melspec_sparse_kernel<NC, E, false, CAN_V4>)
+                   : (pow2 ? melspec_sparse_kernel<NC, E, true, false> : melspec_sparse_kernel<NC, E, false, false>);
+    static bool attr_set[4] = {false, false, false, false};
+    if (!attr_set[pow2 + 2 * v4]) {
         TAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set[pow2] = true;
+        attr_set[pow2 + 2 * v4] = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::WAVES * 64), lds_bytes, stream, g, tb, m);
     TAC_HIP(hipGetLastError());

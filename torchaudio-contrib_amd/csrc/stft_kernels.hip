@@ -12,6 +12,9 @@
 #define TAC_ABL 0      // ablation builds only (tools): 1 = no global loads, 2 = no stores, 3 = no FFT passes
 #endif
 
+#ifndef TAC_STFT_OCC
+#define TAC_STFT_OCC 2      // waves per SIMD the generic kernel is compiled for (A/B knob; 3 drops the hoisted twiddles)
+#endif
 #ifndef TAC_STFT_TIMING
 #define TAC_STFT_TIMING 0   // 1: debug builds of tools/stft_phase_timing.py — per-phase cycle sums overwrite the head of out[]
 #endif
@@ -54,7 +57,7 @@ __device__ __noinline__ void finish_power_row(const float* prow, float* obase, i
 // NF frames per wave can be advanced together (see WaveFft::run); with the inter-pass and R2C twiddles held
 // in registers the kernel sits at 2 waves/SIMD.  NF = 1 is what ships (see launch_stft).
 template <int NC, int E, int MODE, int NF, bool HOIST>
-__global__ void __launch_bounds__(STFT_WAVES * 64, 2)
+__global__ void __launch_bounds__(STFT_WAVES * 64, TAC_STFT_OCC)
 stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
     using F = WaveFft<NC, E>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -282,7 +285,7 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 // Here the NEXT frame's samples are requested before the current frame's stores, every store is unconditional
 // (clamped duplicate lanes instead of predication) so the compiler can wait with an exact vmcnt(#stores) while
 // the stores drain behind the next frame's butterflies, and the window comes from LDS (lgkmcnt, not vmcnt).
-template <int NC, int E, int MODE>
+template <int NC, int E, int MODE, bool V4>
 __global__ void __launch_bounds__(STFT_WAVES * 64, 2)
 stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
     using F = WaveFft<NC, E>;
@@ -293,8 +296,12 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int WAVE_SLOTS = ((F::PADDED + 1) / 2) * 2;
     cf* const lds = smem + w * WAVE_SLOTS;
-    cf* const wlds = reinterpret_cast<cf*>(smem + STFT_WAVES * WAVE_SLOTS);    // NC window pairs
-    for (int m = threadIdx.x; m < NC; m += STFT_WAVES * 64) wlds[m] = window_pair(g, m);
+    // window pairs, one 144-byte row per first-pass column: a lane's 16 values are 8 conflict-free ds_read_b128
+    cf* const wlds = reinterpret_cast<cf*>(smem + STFT_WAVES * WAVE_SLOTS);
+    constexpr int WROW = E + 2;
+    for (int m = threadIdx.x; m < NC; m += STFT_WAVES * 64) wlds[(m & 63) * WROW + (m >> 6)] = window_pair(g, m);
+    constexpr bool v4 = V4;                               // frames fetched with 16-byte requests (fft_core.hpp)
+    const int col = frame_col_of_lane(t, v4);
 
     cf tw[F::NTW];
     cf ptw[F::NPAIR];
@@ -314,7 +321,7 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
     cf raw[E];
     bool pre = false;
     int unit = begin + w;
-    if (unit < end) pre = prefetch_frame_raw<F>(raw, g, unit / T, unit % T, t);
+    if (unit < end) pre = prefetch_frame_raw_x<F>(raw, g, unit / T, unit % T, t, col, v4);
     __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): the loop is entered with nothing in flight
     __syncthreads();
 
@@ -329,16 +336,22 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
         cf v[1][E];
         cf* const ldsv[1] = {lds};
         if (pre) {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            const f4* wp = reinterpret_cast<const f4*>(wlds + col * WROW);
+            f4 wv[E / 2];
 #pragma unroll
-            for (int q = 0; q < E; ++q) {
-                const cf wv = wlds[t + q * F::LPF];
-                v[0][q] = cmul_elem(raw[q], wv);
+            for (int i = 0; i < E / 2; ++i) wv[i] = wp[i];
+            frame_raw_unswizzle<F>(raw, v4);
+#pragma unroll
+            for (int i = 0; i < E / 2; ++i) {
+                v[0][2 * i] = cmul_elem(raw[2 * i], mkc(wv[i].x, wv[i].y));
+                v[0][2 * i + 1] = cmul_elem(raw[2 * i + 1], mkc(wv[i].z, wv[i].w));
             }
         } else {
-            load_frame<F, false>(v[0], g, nullptr, lds, urow, uframe, t);     // frames touching the padding
+            load_frame<F, false>(v[0], g, nullptr, lds, urow, uframe, col);   // frames touching the padding
         }
         st.mark(8);
-        F::template run<1>(v, ldsv, tw, t, st);
+        F::template run<1>(v, ldsv, tw, t, st, col);
         st.mark(9);
 
         // request the next frame now: it lands while this frame is split, staged and stored
@@ -346,7 +359,7 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
         {
             const int nxt = unit + STFT_WAVES;
             pre = false;
-            if (nxt < end) pre = prefetch_frame_raw<F>(raw, g, nxt / T, nxt % T, t);
+            if (nxt < end) pre = prefetch_frame_raw_x<F>(raw, g, nxt / T, nxt % T, t, col, v4);
         }
         __builtin_amdgcn_sched_barrier(0);
         st.mark(1);                                         // next frame's loads issued
@@ -440,25 +453,29 @@ static int launch_stft(const FrameGeom& g, const Tables& tb, const StftEpilogue&
     // frames in flight per wave: measured at cfg-2 (complex STFT) NF=1 0.28 ms vs NF=2 0.33 ms — two frames need
     // ~64 more live registers than the 256 available at 2 waves/SIMD and the spills cost more than the ILP buys
     constexpr int NF = 1;
-    constexpr bool HOIST = (E <= 16);
+    constexpr bool HOIST = (E <= 16) && (TAC_STFT_OCC <= 2);
     const long long groups = g.rows * ((g.n_frames + NF * F::G - 1) / (NF * F::G));     // wave-iterations
     if (groups >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
     if constexpr (TAC_STFT_PIPE && F::G == 1 && E == 16) {
         const bool simple = (MODE == 0) ? (ep.onesided != 0) : (ep.onesided && ep.power == 2.0f && !ep.db);
         if (simple) {
-            const size_t bytes = (size_t)STFT_WAVES * (((F::PADDED + 1) / 2) * 2) * sizeof(cf) + (size_t)NC * sizeof(cf);
+            const size_t bytes = (size_t)STFT_WAVES * (((F::PADDED + 1) / 2) * 2) * sizeof(cf) + (size_t)64 * (E + 2) * sizeof(cf);
             long long blocks = (groups + STFT_WAVES - 1) / STFT_WAVES;
             const long long cap = (long long)device_cu_count() * 2;
             if (blocks > cap) blocks = cap;
-            hipLaunchKernelGGL((stft_pipe_kernel<NC, E, MODE>), dim3((unsigned)blocks), dim3(STFT_WAVES * 64), bytes,
-                               stream, g, tb, ep);
+            if (TAC_V4_LOADS && g.vec4_ok)
+                hipLaunchKernelGGL((stft_pipe_kernel<NC, E, MODE, (TAC_V4_LOADS != 0)>), dim3((unsigned)blocks), dim3(STFT_WAVES * 64),
+                                   bytes, stream, g, tb, ep);
+            else
+                hipLaunchKernelGGL((stft_pipe_kernel<NC, E, MODE, false>), dim3((unsigned)blocks), dim3(STFT_WAVES * 64),
+                                   bytes, stream, g, tb, ep);
             TAC_HIP(hipGetLastError());
             return TAC_OK;
         }
     }
     const size_t lds_bytes = (size_t)STFT_WAVES * (((NF * F::G * F::PADDED + 1) / 2) * 2) * sizeof(cf);
     int per_cu = (int)(160 * 1024 / lds_bytes);
-    if (per_cu > 2) per_cu = 2;        // 256-register waves: two 4-wave workgroups fill a CU
+    if (per_cu > TAC_STFT_OCC) per_cu = TAC_STFT_OCC;        // 256-register waves: two 4-wave workgroups fill a CU
     if (per_cu < 1) per_cu = 1;
     long long max_blocks = (long long)device_cu_count() * per_cu;
     long long want = (groups + STFT_WAVES - 1) / STFT_WAVES;
