@@ -55,7 +55,10 @@ struct SparseArgs {
     float amin;
     float log10_ref;
     float* out;            // [rows][T][M]
+    int out_vec4;          // n_mels % 4 == 0 and out 16-byte aligned: phase C moves four bands per lane
 };
+
+__host__ __device__ inline int sparse_ostr(int n_mels, int out_vec4) { return out_vec4 ? n_mels + 4 : (n_mels | 1); }
 
 template <int NC, int E, bool POW2, bool V4>
 __global__ void __launch_bounds__((MelCfg<NC, E, SP_TILE>::WAVES * 64), 2)
@@ -66,7 +69,9 @@ melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf* bufs = reinterpret_cast<cf*>(smem_raw);                                   // NBUF frame buffers
     float* wlds = reinterpret_cast<float*>(bufs + C::NBUF * F::PADDED);           // packed weights (16-byte aligned)
-    const int ostr = m.n_mels | 1;                                                // odd row stride: conflict-free columns
+    // output-tile row stride: n_mels + 4 keeps rows 16-byte aligned for phase C's float4 reads (the 16 frames of a band
+    // then write 2-way bank-conflicted, which ds_write_b32 absorbs); otherwise an odd stride, conflict-free columns
+    const int ostr = sparse_ostr(m.n_mels, m.out_vec4);
     float* otile = wlds + m.wtot;                                                 // [TILE][ostr]
     int* dlds = reinterpret_cast<int*>(otile + ((TILE * ostr + 3) & ~3));         // [groups][dstride]
 
@@ -99,6 +104,9 @@ melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
     // phase C walks idx = tid, tid + T, ... over (frame, band) = (idx / M, idx % M) without dividing per element
     const int c_f0 = tid / m.n_mels, c_band0 = tid % m.n_mels;
     const int c_df = (WAVES * 64) / m.n_mels, c_dband = (WAVES * 64) % m.n_mels;
+    const int q4 = m.n_mels >> 2;                        // float4 groups per output row (out_vec4 path)
+    const int c4_f0 = q4 ? tid / q4 : 0, c4_b0 = q4 ? tid % q4 : 0;
+    const int c4_df = q4 ? (WAVES * 64) / q4 : 0, c4_db = q4 ? (WAVES * 64) % q4 : 0;
 
     // software prefetch of this wave's first frame of the NEXT tile (raw samples, 32 registers that are idle during
     // the contraction and store phases): its HBM/L2 round trip is hidden instead of opening every phase A
@@ -178,7 +186,29 @@ melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
         st.mark(11);                                       // barrier B
 
         // ---------------- phase C: dB epilogue + coalesced row stores of out[row][frame][0..M)
-        {
+        if (m.out_vec4) {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            int fo = c4_f0, b4 = c4_b0;
+            for (int idx = tid; idx < TILE * q4; idx += WAVES * 64) {
+                f4 v = *reinterpret_cast<const f4*>(otile + fo * ostr + 4 * b4);
+                if (m.db) {
+                    v.x = amp_to_db(v.x, m.amin, m.log10_ref);
+                    v.y = amp_to_db(v.y, m.amin, m.log10_ref);
+                    v.z = amp_to_db(v.z, m.amin, m.log10_ref);
+                    v.w = amp_to_db(v.w, m.amin, m.log10_ref);
+                }
+                const long long frame = f0 + fo;
+#if TAC_MEL_ABL == 3
+                if (frame < g.n_frames && v.x == 12345.678f)
+#else
+                if (frame < g.n_frames)
+#endif
+                    *reinterpret_cast<f4*>(m.out + (row * g.n_frames + frame) * m.n_mels + 4 * b4) = v;
+                b4 += c4_db;
+                fo += c4_df;
+                if (b4 >= q4) { b4 -= q4; ++fo; }
+            }
+        } else {
             int fo = c_f0, band = c_band0;
             for (int idx = tid; idx < TILE * m.n_mels; idx += WAVES * 64) {
                 float v = otile[fo * ostr + band];
@@ -337,7 +367,7 @@ static int sparse_groups_for(int n_fft) {
 template <int NC, int E>
 static int launch_sparse(const FrameGeom& g, const Tables& tb, const SparseArgs& m, float power, hipStream_t stream) {
     using C = MelCfg<NC, E, SP_TILE>;
-    const int ostr = m.n_mels | 1;
+    const int ostr = sparse_ostr(m.n_mels, m.out_vec4);
     const size_t lds_bytes = (size_t)C::NBUF * C::F::PADDED * sizeof(cf) + (size_t)m.wtot * 4 +
                              (size_t)((SP_TILE * ostr + 3) & ~3) * 4 + (size_t)C::WAVES * 4 * m.dstride * 4;
     if (lds_bytes > 160 * 1024) return TAC_E_UNSUPPORTED;
@@ -466,7 +496,8 @@ int tac_melspec_sparse_f32(const float* wave, const float* window, const tac_stf
     Tables tb;
     rc = get_tables(d->n_fft, &tb);
     if (rc != TAC_OK) return rc;
-    SparseArgs m{wpack, desc, info_host[0], info_host[1], n_mels, db ? 1 : 0, db_amin, db ? log10f(db_ref) : 0.0f, out};
+    const int out_vec4 = ((n_mels & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0);
+    SparseArgs m{wpack, desc, info_host[0], info_host[1], n_mels, db ? 1 : 0, db_amin, db ? log10f(db_ref) : 0.0f, out, out_vec4};
     hipStream_t s = (hipStream_t)stream;
     switch (d->n_fft) {
         case 32: return launch_sparse<16, 16>(g, tb, m, power, s);
