@@ -161,23 +161,20 @@ melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
                 const int4 d = *reinterpret_cast<const int4*>(dg + 4 + 4 * b);       // band, first bin, n8, weight offset
                 const float* p = prow + d.y;
                 const float4* w4 = reinterpret_cast<const float4*>(wlds + d.w);
-                float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
-                // 8 taps per trip: 2 weight vectors (LDS broadcast) + 8 row reads in flight before the FMAs — the
-                // loop is LDS-latency-bound, so fewer, fatter trips is what shortens it
+                cf acc0 = mkc(0.0f, 0.0f), acc1 = mkc(0.0f, 0.0f);
+                // 8 taps per trip: 2 weight vectors (LDS broadcast) + 4 eight-byte row reads (bands start on even bins,
+                // tac_melbank_pack) in flight before 4 packed FMAs — the loop is LDS-bound, so fewer, fatter accesses
+                // are what shortens it (ds_read_b64 moves twice the bytes per LDS cycle of ds_read_b32)
                 for (int j = 0; j < d.z; ++j) {
                     const float4 wa = w4[2 * j], wb = w4[2 * j + 1];
-                    const float* q = p + 8 * j;
-                    const float p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3], p4 = q[4], p5 = q[5], p6 = q[6], p7 = q[7];
-                    acc0 = fmaf(wa.x, p0, acc0);
-                    acc1 = fmaf(wa.y, p1, acc1);
-                    acc2 = fmaf(wa.z, p2, acc2);
-                    acc3 = fmaf(wa.w, p3, acc3);
-                    acc0 = fmaf(wb.x, p4, acc0);
-                    acc1 = fmaf(wb.y, p5, acc1);
-                    acc2 = fmaf(wb.z, p6, acc2);
-                    acc3 = fmaf(wb.w, p7, acc3);
+                    const cf* q = reinterpret_cast<const cf*>(p + 8 * j);
+                    const cf p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3];
+                    acc0 = __builtin_elementwise_fma(mkc(wa.x, wa.y), p0, acc0);
+                    acc1 = __builtin_elementwise_fma(mkc(wa.z, wa.w), p1, acc1);
+                    acc0 = __builtin_elementwise_fma(mkc(wb.x, wb.y), p2, acc0);
+                    acc1 = __builtin_elementwise_fma(mkc(wb.z, wb.w), p3, acc1);
                 }
-                otile[fr * ostr + d.x] = (acc0 + acc1) + (acc2 + acc3);
+                otile[fr * ostr + d.x] = (acc0.x + acc0.y) + (acc1.x + acc1.y);
             }
         }
 #endif
@@ -435,6 +432,7 @@ int tac_melbank_pack(const float* fb, int32_t n_freqs, int32_t n_mels, int32_t n
         int lo = n_freqs, hi = 0;
         for (int f = 0; f < n_freqs; ++f)
             if (h[(size_t)f * n_mels + m] != 0.0f) { lo = f < lo ? f : lo; hi = f + 1; }
+        lo &= ~1;                                            // even first bin: the kernel reads the power row 8 bytes at a time
         bands[m] = {m, hi > lo ? lo : 0, hi > lo ? hi - lo : 0};
         total += (bands[m].len + 7) & ~7;
     }
