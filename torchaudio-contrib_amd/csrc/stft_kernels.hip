@@ -285,8 +285,11 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 // Here the NEXT frame's samples are requested before the current frame's stores, every store is unconditional
 // (clamped duplicate lanes instead of predication) so the compiler can wait with an exact vmcnt(#stores) while
 // the stores drain behind the next frame's butterflies, and the window comes from LDS (lgkmcnt, not vmcnt).
-template <int NC, int E, int MODE, bool V4>
-__global__ void __launch_bounds__(STFT_WAVES * 64, 2)
+// LEAN: the lane-dependent twiddles live in LDS (one conflict-free 144-byte row per lane, read where they are used)
+// and the R2C twiddles are one register x compile-time constants, which fits the kernel into 168 registers = three
+// waves per SIMD (three 4-wave workgroups per CU) instead of two.
+template <int NC, int E, int MODE, bool V4, bool LEAN>
+__global__ void __launch_bounds__(STFT_WAVES * 64, LEAN ? 3 : 2)
 stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
     using F = WaveFft<NC, E>;
     static_assert(F::G == 1 && radix_at(NC, 0) == E, "one frame per wave, single first-pass butterfly per lane");
@@ -303,11 +306,24 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
     constexpr bool v4 = V4;                               // frames fetched with 16-byte requests (fft_core.hpp)
     const int col = frame_col_of_lane(t, v4);
 
-    cf tw[F::NTW];
-    cf ptw[F::NPAIR];
-    F::load_twiddles(tw, tb.w_nc, t);
+    static_assert(!LEAN || F::NTW == E + 2, "lean twiddle rows share the window rows' conflict-free 144-byte pitch");
+    cf twr[LEAN ? 1 : F::NTW];
+    cf ptw[LEAN ? 1 : F::NPAIR];
+    cf* const twl = wlds + 64 * WROW + t * WROW;          // LEAN: this lane's twiddle row
+    if constexpr (LEAN) {
+        if (threadIdx.x < 64) {
+            cf tmp[F::NTW];
+            F::load_twiddles(tmp, tb.w_nc, t);
 #pragma unroll
-    for (int i = 0; i < F::NPAIR; ++i) ptw[i] = tb.w_n[t + i * F::LPF];
+            for (int i = 0; i < F::NTW; ++i) twl[i] = tmp[i];
+        }
+        ptw[0] = tb.w_n[t];
+    } else {
+        F::load_twiddles(twr, tb.w_nc, t);
+#pragma unroll
+        for (int i = 0; i < F::NPAIR; ++i) ptw[i] = tb.w_n[t + i * F::LPF];
+    }
+    const cf* const tw = LEAN ? twl : twr;
 
     const int T = (int)g.n_frames;
     const int total = (int)g.rows * T;
@@ -371,7 +387,9 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
             cf xa[F::NPAIR], xb[F::NPAIR], xm, unused;
 #pragma unroll
             for (int i = 0; i < F::NPAIR; ++i) {
-                F::r2c_pair(lds, t + i * F::LPF, ptw[i], xa[i], xb[i]);
+                const int k = t + i * F::LPF;
+                if constexpr (LEAN) F::r2c_split_factored_x2(lds[lds_pad(k)], lds[lds_pad((NC - k) & (NC - 1))], ptw[0], i, xa[i], xb[i]);
+                else F::r2c_pair(lds, k, ptw[i], xa[i], xb[i]);
                 xa[i] = cscale(xa[i], hscale); xb[i] = cscale(xb[i], hscale);
             }
             F::r2c_pair(lds, NC / 2, mkc(0.0f, -1.0f), xm, unused);
@@ -446,29 +464,37 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 #ifndef TAC_STFT_PIPE
 #define TAC_STFT_PIPE 1     // 0: A/B knob, n_fft = 2048 plain epilogues go through the generic kernel
 #endif
+#ifndef TAC_STFT_LEAN
+#define TAC_STFT_LEAN 0     // 1: three waves per SIMD with LDS-resident twiddles (A/B knob: measured equal to two, 0.240 vs 0.238 ms)
+#endif
 
 template <int NC, int E, int MODE>
 static int launch_stft(const FrameGeom& g, const Tables& tb, const StftEpilogue& ep, hipStream_t stream) {
     using F = WaveFft<NC, E>;
     // frames in flight per wave: measured at cfg-2 (complex STFT) NF=1 0.28 ms vs NF=2 0.33 ms — two frames need
     // ~64 more live registers than the 256 available at 2 waves/SIMD and the spills cost more than the ILP buys
-    constexpr int NF = 1;
+#ifndef TAC_STFT_NF
+#define TAC_STFT_NF 1
+#endif
+    constexpr int NF = (E <= 16) ? TAC_STFT_NF : 1;
     constexpr bool HOIST = (E <= 16) && (TAC_STFT_OCC <= 2);
     const long long groups = g.rows * ((g.n_frames + NF * F::G - 1) / (NF * F::G));     // wave-iterations
     if (groups >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
     if constexpr (TAC_STFT_PIPE && F::G == 1 && E == 16) {
         const bool simple = (MODE == 0) ? (ep.onesided != 0) : (ep.onesided && ep.power == 2.0f && !ep.db);
         if (simple) {
-            const size_t bytes = (size_t)STFT_WAVES * (((F::PADDED + 1) / 2) * 2) * sizeof(cf) + (size_t)64 * (E + 2) * sizeof(cf);
+            constexpr bool LEAN = TAC_STFT_LEAN != 0;
+            const size_t bytes = (size_t)STFT_WAVES * (((F::PADDED + 1) / 2) * 2) * sizeof(cf) +
+                                 (size_t)(LEAN ? 128 : 64) * (E + 2) * sizeof(cf);
             long long blocks = (groups + STFT_WAVES - 1) / STFT_WAVES;
-            const long long cap = (long long)device_cu_count() * 2;
+            const long long cap = (long long)device_cu_count() * (LEAN ? 3 : 2);
             if (blocks > cap) blocks = cap;
             if (TAC_V4_LOADS && g.vec4_ok)
-                hipLaunchKernelGGL((stft_pipe_kernel<NC, E, MODE, (TAC_V4_LOADS != 0)>), dim3((unsigned)blocks), dim3(STFT_WAVES * 64),
-                                   bytes, stream, g, tb, ep);
+                hipLaunchKernelGGL((stft_pipe_kernel<NC, E, MODE, (TAC_V4_LOADS != 0), LEAN>), dim3((unsigned)blocks),
+                                   dim3(STFT_WAVES * 64), bytes, stream, g, tb, ep);
             else
-                hipLaunchKernelGGL((stft_pipe_kernel<NC, E, MODE, false>), dim3((unsigned)blocks), dim3(STFT_WAVES * 64),
-                                   bytes, stream, g, tb, ep);
+                hipLaunchKernelGGL((stft_pipe_kernel<NC, E, MODE, false, LEAN>), dim3((unsigned)blocks),
+                                   dim3(STFT_WAVES * 64), bytes, stream, g, tb, ep);
             TAC_HIP(hipGetLastError());
             return TAC_OK;
         }
