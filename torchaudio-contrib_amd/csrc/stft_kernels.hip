@@ -277,6 +277,9 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 #endif
 }
 
+#ifndef TAC_PIPE_ABL
+#define TAC_PIPE_ABL 0      // ablation builds only: 1 = no row stores, 2 = no FFT passes, 3 = no frame loads
+#endif
 // ---------------------------------------------------------------- software-pipelined variant
 // One frame per wave (n_fft = 2048) with the plain epilogue (one-sided complex, or |X|^2).  The phase stamps of
 // the kernel above (tools/stft_phase_timing.py) showed where a frame's ~13k cycles went: 40 % waiting for its
@@ -341,6 +344,15 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
     __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): the loop is entered with nothing in flight
     __syncthreads();
 
+#ifndef TAC_PIPE_LATE_STORES
+#define TAC_PIPE_LATE_STORES 0   // complex rows: hold back the second half of a row's stores until the next frame is windowed (A/B knob)
+#endif
+    constexpr bool LATE = (TAC_PIPE_LATE_STORES != 0) && (NST == 8);
+    float4 lb4 = {0, 0, 0, 0}, lb5 = lb4, lb6 = lb4, lb7 = lb4;
+    float4* lg4 = nullptr;
+    int lc4 = 0, lc5 = 0, lc6 = 0, lc7 = 0;
+    bool have_late = false;
+
     StftStamp st;
 #if TAC_STFT_TIMING
     st.init();
@@ -366,8 +378,20 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
         } else {
             load_frame<F, false>(v[0], g, nullptr, lds, urow, uframe, col);   // frames touching the padding
         }
+        if constexpr (LATE) {
+            if (have_late) {
+                lg4[lc4] = lb4; lg4[lc5] = lb5; lg4[lc6] = lb6; lg4[lc7] = lb7;
+            }
+        }
         st.mark(8);
+#if TAC_PIPE_ABL == 2
+        wave_lds_fence();
+#pragma unroll
+        for (int e = 0; e < E; ++e) lds[lds_pad(t + e * F::LPF)] = v[0][e];
+        wave_lds_fence();
+#else
         F::template run<1>(v, ldsv, tw, t, st, col);
+#endif
         st.mark(9);
 
         // request the next frame now: it lands while this frame is split, staged and stored
@@ -375,7 +399,13 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
         {
             const int nxt = unit + STFT_WAVES;
             pre = false;
+#if TAC_PIPE_ABL == 3
+            pre = nxt < end;
+#pragma unroll
+            for (int q = 0; q < E; ++q) raw[q] = mkc((float)(t + q), (float)(unit - q));
+#else
             if (nxt < end) pre = prefetch_frame_raw_x<F>(raw, g, nxt / T, nxt % T, t, col, v4);
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
         st.mark(1);                                         // next frame's loads issued
@@ -418,6 +448,10 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
         float* const gdst = ep.out + g0;
         const int npre = (4 - a) & 3;
         const int nchunks = (LENF - npre) >> 2;
+#if TAC_PIPE_ABL == 1
+        if (hscale == 12345.0f)                           // never true: the row stores are skipped, everything else kept
+#endif
+        {
         {
             const int hmax = (npre > 1 ? npre : 1) - 1;
             const int hi = t < hmax ? t : hmax;
@@ -437,7 +471,14 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
             TAC_ROW_RD(4) TAC_ROW_RD(5) TAC_ROW_RD(6) TAC_ROW_RD(7)
             __builtin_amdgcn_sched_barrier(0);            // all LDS reads in flight before the first store issues
             TAC_ROW_WR(0) TAC_ROW_WR(1) TAC_ROW_WR(2) TAC_ROW_WR(3)
-            TAC_ROW_WR(4) TAC_ROW_WR(5) TAC_ROW_WR(6) TAC_ROW_WR(7)
+            if constexpr (LATE) {
+                lb4 = b4; lb5 = b5; lb6 = b6; lb7 = b7;
+                lc4 = c4; lc5 = c5; lc6 = c6; lc7 = c7;
+                lg4 = g4;
+                have_late = true;
+            } else {
+                TAC_ROW_WR(4) TAC_ROW_WR(5) TAC_ROW_WR(6) TAC_ROW_WR(7)
+            }
         } else {
             __builtin_amdgcn_sched_barrier(0);
             TAC_ROW_WR(0) TAC_ROW_WR(1) TAC_ROW_WR(2) TAC_ROW_WR(3)
@@ -451,8 +492,14 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
             const int ti = LENF - 1 - (t < rmax ? t : rmax);
             gdst[ti] = stage[ti];
         }
+        }
         wave_lds_fence();   // next iteration's first-pass writes must follow these reads
         st.mark(11);
+    }
+    if constexpr (LATE) {
+        if (have_late) {
+            lg4[lc4] = lb4; lg4[lc5] = lb5; lg4[lc6] = lb6; lg4[lc7] = lb7;
+        }
     }
 #if TAC_STFT_TIMING
     __syncthreads();
