@@ -426,6 +426,22 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
             xm = cscale(xm, hscale);
             wave_lds_fence();                                         // every Z of this frame is in registers
             st.mark(7);                                               // R2C split done
+#ifndef TAC_PIPE_DIRECT_POWER
+#define TAC_PIPE_DIRECT_POWER 0   // |X|^2 rows straight from registers (17 dword wave-stores) instead of LDS staging (A/B knob)
+#endif
+            if constexpr (MODE == 1 && TAC_PIPE_DIRECT_POWER != 0) {
+                float* const orow = ep.out + g0;
+#pragma unroll
+                for (int i = 0; i < F::NPAIR; ++i) {
+                    const int k = t + i * F::LPF;
+                    orow[k] = cnorm2(xa[i]);
+                    orow[NC - k] = cnorm2(xb[i]);
+                }
+                orow[NC / 2] = cnorm2(xm);                            // every lane holds the same value
+                st.mark(10);
+                st.mark(11);
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < F::NPAIR; ++i) {
                 const int k = t + i * F::LPF;
