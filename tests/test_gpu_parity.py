@@ -297,6 +297,35 @@ def test_amplitude_db_known_answers(tac, golden):
     assert rel_err(host(tac.db_to_amplitude(xa * 40, ref=2.0)), g['db2a_ref2']) < 1e-5
 
 
+def test_pipelined_kernel_epilogues_n2048(tac):
+    """n_fft = 2048 takes the software-pipelined kernel for complex rows and for |X| / |X|^2 rows with or without
+    the fused dB epilogue; 1025 floats per power row exercises every 16-byte row misalignment, 7 frames per row
+    the reflect-padded edge frames, 23 rows a ragged tail of the persistent grid."""
+    x = signals.uniform((23, 1, 3072), seed=21)            # flat spectrum: no bins at fp32 cancellation level for the dB check
+    xt = dev(x)
+    want_c = torch_ref.stft(torch.from_numpy(x), 2048, 512).numpy()
+    got_c = host(tac.realize(tac.STFT(2048, 512).cuda()(xt)))
+    assert got_c.shape == want_c.shape and rel_err(got_c, want_c) < TIGHT
+    for power in (1.0, 2.0):
+        want = torch_ref.spectrogram(torch.from_numpy(x), 2048, 512, power=power)
+        got = host(tac.Spectrogram(2048, 512, power=power).cuda()(xt))
+        assert rel_err(got, want.numpy()) < 1e-5, power
+        want_db = torch_ref.amplitude_to_db(want, ref=1.0, amin=1e-7).numpy()
+        chain = torch.nn.Sequential(*tac.Spectrogram(2048, 512, power=power), tac.AmplitudeToDb()).cuda()
+        got_db = host(chain(xt))
+        # bins five orders of magnitude below the frame's level are fp32 cancellation noise in the oracle as well:
+        # the 1e-3 dB bar applies to the rest, a loose one to those few
+        mag = want.numpy() ** (1.0 / power)
+        big = mag > 1e-3 * mag.max()
+        assert np.abs(got_db - want_db)[big].max() < DB_ABS, power
+        assert np.abs(got_db - want_db).max() < 0.1 and (~big).mean() < 1e-3, power
+    # normalized=True scales inside the kernel; an unaligned row stride (odd length) takes the 8-byte load path
+    x2 = signals.audio_like((5, 2, 4099), seed=22)
+    want = torch_ref.spectrogram(torch.from_numpy(x2), 2048, 512, power=2.0, normalized=True).numpy()
+    got = host(tac.Spectrogram(2048, 512, power=2.0, normalized=True).cuda()(dev(x2)))
+    assert rel_err(got, want) < 1e-5
+
+
 # ------------------------------------------------------------------ mu-law: bit-exact integers
 def test_mulaw_golden_bit_exact(tac, golden):
     g = golden('g5_mulaw')

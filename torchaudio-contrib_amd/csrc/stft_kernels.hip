@@ -288,6 +288,15 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 // Here the NEXT frame's samples are requested before the current frame's stores, every store is unconditional
 // (clamped duplicate lanes instead of predication) so the compiler can wait with an exact vmcnt(#stores) while
 // the stores drain behind the next frame's butterflies, and the window comes from LDS (lgkmcnt, not vmcnt).
+// Real-valued row epilogues of the pipelined kernel: MODE 1 = |X|^2, 2 = |X|, 3 = |X|^2 in dB, 4 = |X| in dB
+// (amplitude_to_db squares its input, functional.py:291-296).  0 = complex rows.
+template <int MODE>
+__device__ __forceinline__ float pipe_row_value(float norm2, const StftEpilogue& ep) {
+    float v = (MODE == 2 || MODE == 4) ? sqrtf(norm2) : norm2;
+    if constexpr (MODE >= 3) v = amp_to_db(v, ep.amin, ep.log10_ref);
+    return v;
+}
+
 // LEAN: the lane-dependent twiddles live in LDS (one conflict-free 144-byte row per lane, read where they are used)
 // and the R2C twiddles are one register x compile-time constants, which fits the kernel into 168 registers = three
 // waves per SIMD (three 4-wave workgroups per CU) instead of two.
@@ -429,7 +438,7 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 #ifndef TAC_PIPE_DIRECT_POWER
 #define TAC_PIPE_DIRECT_POWER 0   // |X|^2 rows straight from registers (17 dword wave-stores) instead of LDS staging (A/B knob)
 #endif
-            if constexpr (MODE == 1 && TAC_PIPE_DIRECT_POWER != 0) {
+            if constexpr (MODE == 1 && TAC_PIPE_DIRECT_POWER != 0) {   // (|X|^2 rows only)
                 float* const orow = ep.out + g0;
 #pragma unroll
                 for (int i = 0; i < F::NPAIR; ++i) {
@@ -449,13 +458,13 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
                     reinterpret_cast<cf*>(stage)[k] = xa[i];
                     reinterpret_cast<cf*>(stage)[NC - k] = xb[i];
                 } else {
-                    stage[k] = cnorm2(xa[i]);
-                    stage[NC - k] = cnorm2(xb[i]);
+                    stage[k] = pipe_row_value<MODE>(cnorm2(xa[i]), ep);
+                    stage[NC - k] = pipe_row_value<MODE>(cnorm2(xb[i]), ep);
                 }
             }
             if (t == 0) {
                 if constexpr (MODE == 0) reinterpret_cast<cf*>(stage)[NC / 2] = xm;
-                else stage[NC / 2] = cnorm2(xm);
+                else stage[NC / 2] = pipe_row_value<MODE>(cnorm2(xm), ep);
             }
             wave_lds_fence();
         }
@@ -531,6 +540,25 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 #define TAC_STFT_LEAN 0     // 1: three waves per SIMD with LDS-resident twiddles (A/B knob: measured equal to two, 0.240 vs 0.238 ms)
 #endif
 
+template <int NC, int E, int PMODE>
+static int launch_pipe(const FrameGeom& g, const Tables& tb, const StftEpilogue& ep, long long groups, hipStream_t stream) {
+    using F = WaveFft<NC, E>;
+    constexpr bool LEAN = TAC_STFT_LEAN != 0;
+    const size_t bytes = (size_t)STFT_WAVES * (((F::PADDED + 1) / 2) * 2) * sizeof(cf) +
+                         (size_t)(LEAN ? 128 : 64) * (E + 2) * sizeof(cf);
+    long long blocks = (groups + STFT_WAVES - 1) / STFT_WAVES;
+    const long long cap = (long long)device_cu_count() * (LEAN ? 3 : 2);
+    if (blocks > cap) blocks = cap;
+    if (TAC_V4_LOADS && g.vec4_ok)
+        hipLaunchKernelGGL((stft_pipe_kernel<NC, E, PMODE, (TAC_V4_LOADS != 0), LEAN>), dim3((unsigned)blocks),
+                           dim3(STFT_WAVES * 64), bytes, stream, g, tb, ep);
+    else
+        hipLaunchKernelGGL((stft_pipe_kernel<NC, E, PMODE, false, LEAN>), dim3((unsigned)blocks), dim3(STFT_WAVES * 64),
+                           bytes, stream, g, tb, ep);
+    TAC_HIP(hipGetLastError());
+    return TAC_OK;
+}
+
 template <int NC, int E, int MODE>
 static int launch_stft(const FrameGeom& g, const Tables& tb, const StftEpilogue& ep, hipStream_t stream) {
     using F = WaveFft<NC, E>;
@@ -544,22 +572,20 @@ static int launch_stft(const FrameGeom& g, const Tables& tb, const StftEpilogue&
     const long long groups = g.rows * ((g.n_frames + NF * F::G - 1) / (NF * F::G));     // wave-iterations
     if (groups >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
     if constexpr (TAC_STFT_PIPE && F::G == 1 && E == 16) {
-        const bool simple = (MODE == 0) ? (ep.onesided != 0) : (ep.onesided && ep.power == 2.0f && !ep.db);
-        if (simple) {
-            constexpr bool LEAN = TAC_STFT_LEAN != 0;
-            const size_t bytes = (size_t)STFT_WAVES * (((F::PADDED + 1) / 2) * 2) * sizeof(cf) +
-                                 (size_t)(LEAN ? 128 : 64) * (E + 2) * sizeof(cf);
-            long long blocks = (groups + STFT_WAVES - 1) / STFT_WAVES;
-            const long long cap = (long long)device_cu_count() * (LEAN ? 3 : 2);
-            if (blocks > cap) blocks = cap;
-            if (TAC_V4_LOADS && g.vec4_ok)
-                hipLaunchKernelGGL((stft_pipe_kernel<NC, E, MODE, (TAC_V4_LOADS != 0), LEAN>), dim3((unsigned)blocks),
-                                   dim3(STFT_WAVES * 64), bytes, stream, g, tb, ep);
-            else
-                hipLaunchKernelGGL((stft_pipe_kernel<NC, E, MODE, false, LEAN>), dim3((unsigned)blocks),
-                                   dim3(STFT_WAVES * 64), bytes, stream, g, tb, ep);
-            TAC_HIP(hipGetLastError());
-            return TAC_OK;
+        // pipelined kernel: one-sided complex rows, or |X| / |X|^2 rows with or without the dB epilogue
+        int pmode = -1;
+        if (ep.onesided) {
+            if (MODE == 0) pmode = 0;
+            else if (ep.power == 2.0f) pmode = ep.db ? 3 : 1;
+            else if (ep.power == 1.0f) pmode = ep.db ? 4 : 2;
+        }
+        switch (pmode) {
+            case 0: return launch_pipe<NC, E, 0>(g, tb, ep, groups, stream);
+            case 1: return launch_pipe<NC, E, 1>(g, tb, ep, groups, stream);
+            case 2: return launch_pipe<NC, E, 2>(g, tb, ep, groups, stream);
+            case 3: return launch_pipe<NC, E, 3>(g, tb, ep, groups, stream);
+            case 4: return launch_pipe<NC, E, 4>(g, tb, ep, groups, stream);
+            default: break;
         }
     }
     const size_t lds_bytes = (size_t)STFT_WAVES * (((NF * F::G * F::PADDED + 1) / 2) * 2) * sizeof(cf);
