@@ -103,7 +103,6 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
         long long row[NF], frame[NF];
         int tl = t;
         asm volatile("" : "+v"(tl));          // launder: keeps the per-iteration table loads inside the loop
-        if constexpr (!HOIST) F::load_twiddles(tw, tb.w_nc, tl);
         cf win[F::E];                     // window: L1-resident, shared by the NF frames of this iteration
         load_window_regs<F>(win, g, tl);
 #pragma unroll
@@ -116,6 +115,12 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 #else
             load_frame<F, true>(v[f], g, win, lds[f], row[f], frame[f], t);
 #endif
+        }
+        if constexpr (!HOIST) {
+            // twiddles only once the frame is windowed (the window's registers are free by then): N = 4096 keeps
+            // 64 data registers per lane and spilled 260 B with the tables requested up front
+            __builtin_amdgcn_sched_barrier(0);
+            F::load_twiddles(tw, tb.w_nc, tl);
         }
 #if TAC_ABL == 3
         wave_lds_fence();
