@@ -34,6 +34,9 @@ __host__ __device__ __forceinline__ cf mkc(float x, float y) {
     return r;
 }
 
+#ifndef TAC_EXP_NOCONF
+#define TAC_EXP_NOCONF 0   // timing experiment only (wrong results): pass read-backs and R2C reads without padding = conflict-free
+#endif
 #ifndef TAC_PACKED
 #define TAC_PACKED 1        // 0: A/B knob, the same algebra on scalar f32 ops
 #endif
@@ -362,9 +365,15 @@ struct WaveFft {
                     // NC/R is a multiple of 16 for every pass after the first, so pad(j + c) = pad(j) + pad(c):
                     // one address register per butterfly, the rest are DS immediate offsets.
                     static_assert((NC / R) % 16 == 0, "read stride must keep the padding affine");
+#if TAC_EXP_NOCONF
+                    const cf* src = lds[f] + (t + b * LPF);
+#pragma unroll
+                    for (int q = 0; q < R; ++q) v[f][b * R + q] = src[q * (NC / R)];
+#else
                     const cf* src = lds[f] + lds_pad(t + b * LPF);
 #pragma unroll
                     for (int q = 0; q < R; ++q) v[f][b * R + q] = src[lds_pad_c(q * (NC / R))];
+#endif
                 }
 #pragma unroll
             for (int f = 0; f < NF; ++f)
@@ -406,7 +415,11 @@ struct WaveFft {
     // even/odd split is left to the caller's epilogue factor).  wk = exp(-2*pi*i*k/N).
     //   ev = zk + conj(zm), d = zk - conj(zm), tw = wk·(-i·d);  2X[k] = ev + tw, 2X[NC-k] = conj(ev - tw)
     __device__ static __forceinline__ void r2c_pair(const cf* lds, int k, cf wk, cf& xa, cf& xb) {
+#if TAC_EXP_NOCONF
+        r2c_split_x2(lds[k], lds[(NC - k) & (NC - 1)], wk, xa, xb);
+#else
         r2c_split_x2(lds[lds_pad(k)], lds[lds_pad((NC - k) & (NC - 1))], wk, xa, xb);
+#endif
     }
     __device__ static __forceinline__ void r2c_split_x2(cf zk, cf zm, cf wk, cf& xa, cf& xb) {
         const cf ev = cadd_conj(zk, zm), d = csub_conj(zk, zm);

@@ -3,6 +3,9 @@
 #pragma once
 #include "host_common.hpp"
 
+#ifndef TAC_MEL_PRIO
+#define TAC_MEL_PRIO 0     // 1: hand the SIMD priority to the younger wave for a tile's second frame (A/B knob)
+#endif
 #ifndef TAC_MEL_ABL
 #define TAC_MEL_ABL 0    // ablation builds only: 1 = skip phase A math, 2 = skip phase B, 3 = skip phase C stores
 #endif
@@ -83,6 +86,11 @@ __device__ __forceinline__ void mel_phase_a(const FrameGeom& g, cf* bufs, const 
     if (wave_has_frames) {
 #pragma unroll PIPE ? C::GPW : 1
         for (int rep = 0; rep < C::GPW; rep += NF) {
+#if TAC_MEL_PRIO
+            // the older wave of a SIMD wins VALU arbitration, so after the first frame the younger one is behind:
+            // it gets the priority for the tile's second frame and both reach the barrier together
+            if (PIPE && C::WAVES == 8 && rep + NF >= C::GPW) { if (w >= 4) __builtin_amdgcn_s_setprio(2); }
+#endif
             cf* lds[NF];
             int fi[NF];
             cf v[NF][E];
@@ -153,6 +161,9 @@ __device__ __forceinline__ void mel_phase_a(const FrameGeom& g, cf* bufs, const 
             st.mark(10);
         }
     }
+#if TAC_MEL_PRIO
+    if (PIPE && C::WAVES == 8) __builtin_amdgcn_s_setprio(0);
+#endif
     if (pre_ok_p) *pre_ok_p = pre_ok;
 }
 
