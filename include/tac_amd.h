@@ -127,6 +127,10 @@ int tac_apply_filterbank_f32(const float* spec, int64_t rows, int32_t n_freqs, i
 /* (5) functional.complex_norm, functional.py:116-128: out[i] = |(x[2i], x[2i+1])|^power. */
 int tac_complex_norm_f32(const float* x, int64_t n, float power, float* out, void* stream);
 
+/* (5b) functional.angle / functional.magphase, functional.py:187-201: phase[i] =
+ *      atan2(x[2i+1], x[2i]); when mag != NULL also mag[i] = |(x[2i], x[2i+1])|^power, in the same pass. */
+int tac_magphase_f32(const float* x, int64_t n, float power, float* mag, float* phase, void* stream);
+
 /* (6) functional.amplitude_to_db, functional.py:277-296: 10*(log10(max(x^2, amin)) - log10(ref)). */
 int tac_amplitude_to_db_f32(const float* x, int64_t n, float ref, float amin, float* out,
                             void* stream);

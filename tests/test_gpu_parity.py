@@ -326,6 +326,28 @@ def test_pipelined_kernel_epilogues_n2048(tac):
     assert rel_err(got, want) < 1e-5
 
 
+def test_g6_angle_magphase(tac, golden):
+    """angle / magphase: one streaming kernel, golden values from the reference."""
+    g = golden('g6_magphase')
+    z = signals.audio_like((3, 65, 11, 2), seed=31)
+    z[0, 0, :4] = np.array([[0.0, 0.0], [1.0, 0.0], [-1.0, 0.0], [0.0, -2.0]], np.float32)
+    zt = dev(z)
+    assert np.abs(host(tac.angle(zt)) - g['angle']).max() < 2e-6
+    for p in (1.0, 2.0, 0.5):
+        m, ph = tac.magphase(zt, power=p)
+        assert rel_err(host(m), g['mag_p%g' % p]) < 1e-6
+        assert np.abs(host(ph) - g['phase_p%g' % p]).max() < 2e-6
+    # strided input (the STFT's (…, F, T, 2) view) and an odd element count (scalar tail of the vector kernel)
+    spec = tac.realize(tac.STFT(512, 128).cuda()(dev(signals.audio_like((2, 1, 4000), seed=32))))
+    m, ph = tac.magphase(spec, power=1.0)
+    want = torch_ref.magphase(spec.cpu(), 1.0)
+    assert m.shape == spec.shape[:-1] and rel_err(host(m), want[0].numpy()) < 1e-6
+    big = want[0].numpy() > 1e-3 * want[0].numpy().max()          # phase of a cancelling bin is noise in both
+    assert np.abs(host(ph) - want[1].numpy())[big].max() < 1e-5
+    odd = dev(signals.audio_like((7, 2), seed=33))
+    assert np.abs(host(tac.angle(odd)) - torch_ref.angle(odd.cpu()).numpy()).max() < 2e-6
+
+
 # ------------------------------------------------------------------ mu-law: bit-exact integers
 def test_mulaw_golden_bit_exact(tac, golden):
     g = golden('g5_mulaw')

@@ -175,3 +175,16 @@ def test_exact_log1p_closed_form_reproduces_golden_codes(golden):
     assert np.array_equal(enc(x3, 7), g['enc7_scale1000'].astype(np.int64))
     assert np.array_equal(enc(g['special_inputs'], 256), g['enc256_special'])
     assert np.array_equal(enc(g['special_inputs'], 65536), g['enc65536_special'])
+
+
+def test_g6_angle_magphase(golden):
+    """The oracle's angle / magphase restatement reproduces the reference's outputs (functional.py:187-201)."""
+    g = golden('g6_magphase')
+    z = signals.audio_like((3, 65, 11, 2), seed=31)
+    z[0, 0, :4] = np.array([[0.0, 0.0], [1.0, 0.0], [-1.0, 0.0], [0.0, -2.0]], np.float32)
+    zt = T(z)
+    assert np.abs(torch_ref.angle(zt).numpy() - g['angle']).max() < 1e-6
+    for p in (1.0, 2.0, 0.5):
+        m, ph = torch_ref.magphase(zt, p)
+        assert rel_err(m.numpy(), g['mag_p%g' % p]) < 1e-6
+        assert np.abs(ph.numpy() - g['phase_p%g' % p]).max() < 1e-6

@@ -209,13 +209,26 @@ def g5(skip_scan):
     np.savez_compressed(os.path.join(GOLD, 'g5_mulaw.npz'), **out)
 
 
+def g6():
+    """angle / magphase (functional.py:187-201) on a small complex tensor incl. the axes and the origin."""
+    z = signals.audio_like((3, 65, 11, 2), seed=31)
+    z[0, 0, :4] = np.array([[0.0, 0.0], [1.0, 0.0], [-1.0, 0.0], [0.0, -2.0]], np.float32)
+    zt = T(z)
+    out = {'angle': np32(ref.angle(zt))}
+    for p in (1.0, 2.0, 0.5):
+        m, ph = ref.magphase(zt, power=p)
+        out['mag_p%g' % p] = np32(m)
+        out['phase_p%g' % p] = np32(ph)
+    np.savez_compressed(os.path.join(GOLD, 'g6_magphase.npz'), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--skip-scan', action='store_true', help='reuse thresholds from the existing g5 file')
     ap.add_argument('--only', default='')
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
-    jobs = {'g1': g1, 'g2': g2, 'g3': g3, 'g4': g4, 'g5': lambda: g5(a.skip_scan)}
+    jobs = {'g1': g1, 'g2': g2, 'g3': g3, 'g4': g4, 'g5': lambda: g5(a.skip_scan), 'g6': g6}
     for name, fn in jobs.items():
         if a.only and name not in a.only.split(','):
             continue

@@ -42,6 +42,37 @@ __global__ void __launch_bounds__(EW_THREADS) complex_norm_kernel(const float* _
     }
 }
 
+// ---------------------------------------------------------------- angle / magphase (functional.py:187-201)
+// one pass over the complex pairs: phase = atan2(im, re), optionally also |z|^power (dual output)
+template <bool VEC, bool WITH_MAG>
+__global__ void __launch_bounds__(EW_THREADS) magphase_kernel(const float* __restrict__ x, long long n, float power,
+                                                              float* __restrict__ mag, float* __restrict__ phase) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if constexpr (VEC) {
+        const long long n4 = n / 4;
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        float4* p4 = reinterpret_cast<float4*>(phase);
+        float4* m4 = reinterpret_cast<float4*>(mag);
+        for (long long j = i; j < n4; j += stride) {
+            const float4 a = x4[2 * j], b = x4[2 * j + 1];
+            p4[j] = make_float4(atan2f(a.y, a.x), atan2f(a.w, a.z), atan2f(b.y, b.x), atan2f(b.w, b.z));
+            if constexpr (WITH_MAG)
+                m4[j] = make_float4(norm_pow(a.x, a.y, power), norm_pow(a.z, a.w, power), norm_pow(b.x, b.y, power),
+                                    norm_pow(b.z, b.w, power));
+        }
+        for (long long j = n4 * 4 + i; j < n; j += stride) {
+            phase[j] = atan2f(x[2 * j + 1], x[2 * j]);
+            if constexpr (WITH_MAG) mag[j] = norm_pow(x[2 * j], x[2 * j + 1], power);
+        }
+    } else {
+        for (long long j = i; j < n; j += stride) {
+            phase[j] = atan2f(x[2 * j + 1], x[2 * j]);
+            if constexpr (WITH_MAG) mag[j] = norm_pow(x[2 * j], x[2 * j + 1], power);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- generic unary map
 struct AmpToDb {
     float amin, log10_ref;
@@ -192,6 +223,24 @@ int tac_complex_norm_f32(const float* x, int64_t n, float power, float* out, voi
     const unsigned blocks = ew_blocks(vec ? (n + 3) / 4 : n);
     if (vec) hipLaunchKernelGGL(complex_norm_kernel<true>, dim3(blocks), dim3(EW_THREADS), 0, (hipStream_t)stream, x, (long long)n, power, out);
     else hipLaunchKernelGGL(complex_norm_kernel<false>, dim3(blocks), dim3(EW_THREADS), 0, (hipStream_t)stream, x, (long long)n, power, out);
+    TAC_HIP(hipGetLastError());
+    return TAC_OK;
+}
+
+int tac_magphase_f32(const float* x, int64_t n, float power, float* mag, float* phase, void* stream) {
+    using namespace tac;
+    if (n == 0) return TAC_OK;
+    if (!x || !phase || n < 0) return TAC_E_INVALID;
+    const bool vec = aligned16(x) && aligned16(phase) && (!mag || aligned16(mag));
+    const unsigned blocks = ew_blocks(vec ? (n + 3) / 4 : n);
+    const hipStream_t s = (hipStream_t)stream;
+    if (mag) {
+        if (vec) hipLaunchKernelGGL((magphase_kernel<true, true>), dim3(blocks), dim3(EW_THREADS), 0, s, x, (long long)n, power, mag, phase);
+        else hipLaunchKernelGGL((magphase_kernel<false, true>), dim3(blocks), dim3(EW_THREADS), 0, s, x, (long long)n, power, mag, phase);
+    } else {
+        if (vec) hipLaunchKernelGGL((magphase_kernel<true, false>), dim3(blocks), dim3(EW_THREADS), 0, s, x, (long long)n, power, mag, phase);
+        else hipLaunchKernelGGL((magphase_kernel<false, false>), dim3(blocks), dim3(EW_THREADS), 0, s, x, (long long)n, power, mag, phase);
+    }
     TAC_HIP(hipGetLastError());
     return TAC_OK;
 }

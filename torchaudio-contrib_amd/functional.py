@@ -328,15 +328,8 @@ def stft(waveforms, fft_length, hop_length=None, win_length=None, window=None,
 
 def complex_norm(complex_tensor, power=1.0):
     """``|z|**power`` over a trailing ``complex=2`` dim (reference: functional.py:116-128)."""
-    z = _device_f32(complex_tensor, 'complex_tensor')
-    if z.dim() < 1 or z.shape[-1] != 2:
-        raise RuntimeError('complex_norm: expected a trailing dimension of size 2, got shape %s'
-                           % (tuple(z.shape),))
-    if z.stride(-1) != 1 or not _is_dense(z) or \
-            any(s % 2 for s, n in zip(z.stride()[:-1], z.shape[:-1]) if n > 1):
-        z = z.contiguous()
-    out = torch.empty_strided(z.shape[:-1], tuple(s // 2 for s in z.stride()[:-1]),
-                              dtype=torch.float32, device=z.device)
+    z = _complex_pairs(complex_tensor, 'complex_norm')
+    out = _pair_output(z)
     n = out.numel()
     if n:
         with torch.cuda.device(z.device):
@@ -409,17 +402,45 @@ def apply_filterbank(mag_specgrams, filterbank):
     return out.transpose(-2, -1)
 
 
+def _complex_pairs(complex_tensor, what):
+    """Dense view of a ``(*, 2)`` tensor whose storage order the elementwise kernels can walk pair by pair."""
+    z = _device_f32(complex_tensor, what)
+    if z.dim() < 1 or z.shape[-1] != 2:
+        raise RuntimeError('%s: expected a trailing dimension of size 2, got shape %s' % (what, tuple(z.shape)))
+    if z.stride(-1) != 1 or not _is_dense(z) or \
+            any(s % 2 for s, n in zip(z.stride()[:-1], z.shape[:-1]) if n > 1):
+        z = z.contiguous()
+    return z
+
+
+def _pair_output(z):
+    return torch.empty_strided(z.shape[:-1], tuple(s // 2 for s in z.stride()[:-1]), dtype=torch.float32,
+                               device=z.device)
+
+
 def angle(complex_tensor):
-    """Phase of a ``(*, 2)`` tensor (reference: functional.py:187-191).  Not on the Melspectrogram
-    path (SURVEY §8f "next"): composed from a device-side torch op."""
-    z = _realize(complex_tensor)
-    return torch.atan2(z[..., 1], z[..., 0])
+    """Phase ``atan2(im, re)`` of a ``(*, 2)`` tensor (reference: functional.py:187-191); one streaming kernel
+    (SURVEY §8f rank 1)."""
+    z = _complex_pairs(complex_tensor, 'complex_tensor')
+    phase = _pair_output(z)
+    if phase.numel():
+        with torch.cuda.device(z.device):
+            rc = _native.lib().tac_magphase_f32(_native.ptr(z), phase.numel(), 1.0, None, _native.ptr(phase),
+                                                _native.stream_ptr(z.device))
+        _native.check(rc, 'tac_magphase_f32')
+    return phase
 
 
 def magphase(complex_tensor, power=1.):
-    """(magnitude**power, phase) (reference: functional.py:194-201)."""
-    z = _realize(complex_tensor)
-    return complex_norm(z, power), angle(z)
+    """``(|z|**power, atan2(im, re))`` (reference: functional.py:194-201), both outputs from one pass over z."""
+    z = _complex_pairs(complex_tensor, 'complex_tensor')
+    mag, phase = _pair_output(z), _pair_output(z)
+    if phase.numel():
+        with torch.cuda.device(z.device):
+            rc = _native.lib().tac_magphase_f32(_native.ptr(z), phase.numel(), float(power), _native.ptr(mag),
+                                                _native.ptr(phase), _native.stream_ptr(z.device))
+        _native.check(rc, 'tac_magphase_f32')
+    return mag, phase
 
 
 def phase_vocoder(complex_specgrams, rate, phase_advance):
