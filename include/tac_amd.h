@@ -131,6 +131,17 @@ int tac_complex_norm_f32(const float* x, int64_t n, float power, float* out, voi
  *      atan2(x[2i+1], x[2i]); when mag != NULL also mag[i] = |(x[2i], x[2i+1])|^power, in the same pass. */
 int tac_magphase_f32(const float* x, int64_t n, float power, float* mag, float* phase, void* stream);
 
+/* (5c) functional.phase_vocoder, functional.py:204-274.  spec: rows x n_freqs x n_frames complex
+ *      pairs with arbitrary element strides (in floats; the pair itself contiguous); phase_advance: n_freqs floats;
+ *      idx0/idx1/alpha (device, n_out each): for output frame i the two source frames floor(t_i), floor(t_i + 1)
+ *      (indices >= n_frames are the reference's zero padding) and the weight t_i mod 1, with t = arange(0, n_frames,
+ *      rate) evaluated the way the reference evaluates it (functional.py:233-237).  out: frame-major
+ *      [rows][n_out][n_freqs][2]. */
+int tac_phase_vocoder_f32(const float* spec, int64_t rows, int32_t n_freqs, int64_t n_frames,
+                          int64_t stride_r, int64_t stride_f, int64_t stride_t,
+                          const float* phase_advance, const int32_t* idx0, const int32_t* idx1,
+                          const float* alpha, int64_t n_out, float* out, void* stream);
+
 /* (6) functional.amplitude_to_db, functional.py:277-296: 10*(log10(max(x^2, amin)) - log10(ref)). */
 int tac_amplitude_to_db_f32(const float* x, int64_t n, float ref, float amin, float* out,
                             void* stream);

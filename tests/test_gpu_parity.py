@@ -348,6 +348,44 @@ def test_g6_angle_magphase(tac, golden):
     assert np.abs(host(tac.angle(odd)) - torch_ref.angle(odd.cpu()).numpy()).max() < 2e-6
 
 
+def test_g7_phase_vocoder_and_time_stretch(tac, golden):
+    """phase_vocoder against the reference's golden outputs, then the reference's own layer
+    chain STFT -> TimeStretch -> ComplexNorm (tests/test_layers.py:98-101) against the oracle."""
+    import math
+    g = golden('g7_phase_vocoder')
+    z = signals.audio_like((2, 1, 65, 40, 2), seed=41)
+    adv = torch.linspace(0, math.pi * 32, 65)[..., None]
+    for rate in (1.3, 0.7, 2.0):
+        got = tac.phase_vocoder(dev(z), rate, adv.cuda())
+        want = g['pv_rate%g' % rate]
+        assert tuple(got.shape) == want.shape
+        got = host(got)
+        # magnitudes are plain interpolation: tight.  The phase is a float32 running sum of terms as large as the
+        # bin's phase advance (pi*hop*f/F, ~100 rad here), so by the last frame it is ~5 000 rad with a float32
+        # spacing of 5e-4 rad: one-ulp differences between the device's and the host's atan2f decide roundings of
+        # that sum (the reference notes the same sensitivity, tests/test_functional.py:85-88).  Bound: a few
+        # spacings of the largest accumulated phase; low bins, whose sums stay small, must agree closely.
+        assert np.abs(np.hypot(got[..., 0], got[..., 1]) - np.hypot(want[..., 0], want[..., 1])).max() < 2e-6, rate
+        acc_max = want.shape[-2] * math.pi * 32
+        assert np.abs(got - want).max() < 8 * np.spacing(np.float32(acc_max)) * np.abs(want).max(), rate
+        assert np.abs(got - want)[:, :, :4].max() < 1e-4, rate
+    x = signals.audio_like((3, 2, 6000), seed=42)
+    hop, n_fft = 128, 512
+    chain = torch.nn.Sequential(tac.STFT(n_fft, hop), tac.TimeStretch(hop, n_fft // 2 + 1, fixed_rate=1.3),
+                                tac.ComplexNorm(power=2.)).cuda()
+    got = host(chain(dev(x)))
+    spec = torch_ref.stft(torch.from_numpy(x), n_fft, hop)
+    want = torch_ref.complex_norm(torch_ref.phase_vocoder(spec, 1.3, torch.linspace(0, math.pi * hop, n_fft // 2 + 1)[..., None]), 2.0)
+    assert got.shape == tuple(want.shape) and got.shape[-1] == math.ceil(spec.shape[-2] / 1.3)
+    assert rel_err(got, want.numpy()) < 1e-5
+    # rate 1 is the identity in the layer (layers.py:254-255); a missing rate raises like the reference
+    stft = tac.realize(tac.STFT(n_fft, hop).cuda()(dev(x)))
+    ts = tac.TimeStretch(hop, n_fft // 2 + 1).cuda()
+    assert torch.equal(ts(stft, 1.0), stft)
+    with pytest.raises(ValueError):
+        ts(stft)
+
+
 # ------------------------------------------------------------------ mu-law: bit-exact integers
 def test_mulaw_golden_bit_exact(tac, golden):
     g = golden('g5_mulaw')

@@ -188,3 +188,15 @@ def test_g6_angle_magphase(golden):
         m, ph = torch_ref.magphase(zt, p)
         assert rel_err(m.numpy(), g['mag_p%g' % p]) < 1e-6
         assert np.abs(ph.numpy() - g['phase_p%g' % p]).max() < 1e-6
+
+
+def test_g7_phase_vocoder(golden):
+    """The oracle's phase_vocoder restatement reproduces the reference (functional.py:204-274)."""
+    import math
+    g = golden('g7_phase_vocoder')
+    z = T(signals.audio_like((2, 1, 65, 40, 2), seed=41))
+    adv = torch.linspace(0, math.pi * 32, 65)[..., None]
+    for rate in (1.3, 0.7, 2.0):
+        got = torch_ref.phase_vocoder(z, rate, adv).numpy()
+        want = g['pv_rate%g' % rate]
+        assert got.shape == want.shape and rel_err(got, want) < 1e-6, rate

@@ -10,6 +10,7 @@ reference expects.  Inputs come from ``oracle.signals`` (pure function of index+
 only outputs are stored.  The reference's files never enter the repo or the GPU box.
 """
 import argparse
+import math
 import os
 import sys
 import time
@@ -222,13 +223,24 @@ def g6():
     np.savez_compressed(os.path.join(GOLD, 'g6_magphase.npz'), **out)
 
 
+def g7():
+    """phase_vocoder (functional.py:204-274) on a small complex spectrogram, three rates."""
+    num_freqs, hop = 65, 32
+    z = signals.audio_like((2, 1, num_freqs, 40, 2), seed=41)
+    adv = torch.linspace(0, math.pi * hop, num_freqs)[..., None]
+    out = {}
+    for rate in (1.3, 0.7, 2.0):
+        out['pv_rate%g' % rate] = np32(ref.phase_vocoder(T(z), rate, adv))
+    np.savez_compressed(os.path.join(GOLD, 'g7_phase_vocoder.npz'), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--skip-scan', action='store_true', help='reuse thresholds from the existing g5 file')
     ap.add_argument('--only', default='')
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
-    jobs = {'g1': g1, 'g2': g2, 'g3': g3, 'g4': g4, 'g5': lambda: g5(a.skip_scan), 'g6': g6}
+    jobs = {'g1': g1, 'g2': g2, 'g3': g3, 'g4': g4, 'g5': lambda: g5(a.skip_scan), 'g6': g6, 'g7': g7}
     for name, fn in jobs.items():
         if a.only and name not in a.only.split(','):
             continue

@@ -443,27 +443,55 @@ def magphase(complex_tensor, power=1.):
     return mag, phase
 
 
+_PV_GRID_CACHE = {}
+
+
+def _phase_vocoder_grid(n_frames, rate, device):
+    """Source-frame indices and interpolation weights of every output frame, evaluated exactly as the reference's CPU
+    path does (functional.py:233-247: float32 ``torch.arange(0, T, rate)``, ``% 1``, ``.long()``); which frames get
+    paired depends on that rounding, so it is computed with the same host ops and cached per (T, rate, device)."""
+    key = (int(n_frames), float(rate), str(device))
+    hit = _PV_GRID_CACHE.get(key)
+    if hit is None:
+        steps = torch.arange(0, n_frames, rate)
+        if len(_PV_GRID_CACHE) > 64:
+            _PV_GRID_CACHE.clear()
+        hit = (steps.long().to(torch.int32).to(device), (steps + 1).long().to(torch.int32).to(device),
+               torch.remainder(steps, torch.tensor(1.)).to(device))
+        _PV_GRID_CACHE[key] = hit
+    return hit
+
+
 def phase_vocoder(complex_specgrams, rate, phase_advance):
     """Time-stretch a complex spectrogram by ``rate`` without changing pitch (reference:
-    functional.py:204-274).  Outside the Melspectrogram hot path: kept for API
-    completeness as a composition of device-side torch ops; the magnitudes use the HIP complex_norm."""
-    spec = _realize(complex_specgrams)
-    lead = [slice(None)] * (spec.dim() - 2)
-    steps = torch.arange(0, spec.size(-2), rate, device=spec.device)
-    alphas = torch.remainder(steps, torch.tensor(1., device=spec.device))
-    phase_0 = angle(spec[tuple(lead + [slice(1)])])
-    spec = torch.nn.functional.pad(spec, [0, 0, 0, 2])
-    lo = spec[tuple(lead + [steps.long()])]
-    hi = spec[tuple(lead + [(steps + 1).long()])]
-    ang_lo, ang_hi = angle(lo), angle(hi)
-    mag_lo, mag_hi = torch.norm(lo, dim=-1), torch.norm(hi, dim=-1)
-    phase = ang_hi - ang_lo - phase_advance
-    phase = phase - 2 * math.pi * torch.round(phase / (2 * math.pi))
-    phase = phase + phase_advance
-    phase = torch.cat([phase_0, phase[tuple(lead + [slice(-1)])]], dim=-1)
-    phase_acc = torch.cumsum(phase, -1)
-    mag = alphas * mag_hi + (1 - alphas) * mag_lo
-    return torch.stack([mag * torch.cos(phase_acc), mag * torch.sin(phase_acc)], dim=-1)
+    functional.py:204-274): ``(*, F, T, 2) → (*, F, ceil(T / rate), 2)``.  One kernel; each lane
+    owns one (row, frequency) series and walks the output frames (csrc/phase_vocoder.hip)."""
+    spec = _device_f32(complex_specgrams, 'complex_specgrams')
+    if spec.dim() < 3 or spec.shape[-1] != 2:
+        raise RuntimeError('phase_vocoder: expected (*, num_freqs, time, 2), got shape %s' % (tuple(spec.shape),))
+    n_freqs, n_frames = spec.shape[-3], spec.shape[-2]
+    pa = _device_f32(phase_advance, 'phase_advance').reshape(-1).contiguous()
+    if pa.numel() != n_freqs:
+        raise RuntimeError('phase_vocoder: phase_advance has %d entries for %d frequency bins' % (pa.numel(), n_freqs))
+    if pa.device != spec.device:
+        raise RuntimeError('phase_vocoder: spectrogram and phase_advance must be on the same device')
+    if not rate > 0:
+        raise ValueError('phase_vocoder: rate must be positive, got %r' % (rate,))
+    lead = tuple(spec.shape[:-3])
+    idx0, idx1, alpha = _phase_vocoder_grid(n_frames, rate, spec.device)
+    n_out = idx0.numel()
+    if spec.stride(-1) != 1:
+        spec = spec.contiguous()
+    rows = spec.reshape((-1,) + tuple(spec.shape[-3:]))          # a view whenever the leading dims collapse
+    out = torch.empty(lead + (n_out, n_freqs, 2), dtype=torch.float32, device=spec.device)
+    if out.numel() and n_frames:
+        with torch.cuda.device(spec.device):
+            rc = _native.lib().tac_phase_vocoder_f32(
+                _native.ptr(rows), rows.shape[0], n_freqs, n_frames, rows.stride(0) if rows.shape[0] > 1 else 0,
+                rows.stride(1), rows.stride(2), _native.ptr(pa), _native.ptr(idx0), _native.ptr(idx1),
+                _native.ptr(alpha), n_out, _native.ptr(out), _native.stream_ptr(spec.device))
+        _native.check(rc, 'tac_phase_vocoder_f32')
+    return out.transpose(-3, -2)
 
 
 def _unary(x, what, launch):
