@@ -142,6 +142,38 @@ def test_g4_mel_variants(tac, golden):
     assert np.abs(host(chain(xm)) - g['mel_htk40_n512_db']).max() < DB_ABS
 
 
+def test_fused_mel_parameter_sweep_vs_oracle(tac):
+    """Seeded sweep over the fused Melspectrogram(+dB) chain — FFT size, hop, window length, band count, sample
+    rate, HTK / Slaney scale, frequency range, batch shapes with ragged last tiles — against the oracle chain
+    (layers.py:307-381).  Mel power within 2e-5 of the tensor maximum, dB within 1e-3 where the band is not at
+    cancellation level."""
+    rng = np.random.default_rng(7)
+    for case in range(24):
+        n = int(rng.choice([256, 512, 1024, 2048]))
+        hop = int(rng.choice([n // 4, n // 2, n // 8, int(rng.integers(1, n))]))
+        win_length = n if case % 3 else int(rng.integers(n // 2, n + 1))
+        num_mels = int(rng.choice([13, 40, 64, 80, 128]))
+        sr = int(rng.choice([8000, 16000, 22050, 44100]))
+        htk = bool(case % 2)
+        min_freq = float(rng.choice([0.0, 20.0, 125.0]))
+        max_freq = None if case % 4 else float(sr // 2 - int(rng.integers(0, sr // 8)))
+        shape = (int(rng.integers(1, 4)), int(rng.integers(1, 3)), int(rng.integers(2 * n, 6 * n)) + case % 2)
+        x = signals.uniform(shape, seed=300 + case)
+        mel = tac.Melspectrogram(num_mels=num_mels, sample_rate=sr, min_freq=min_freq, max_freq=max_freq, htk=htk,
+                                 fft_length=n, hop_length=hop, win_length=win_length).cuda()
+        want = torch_ref.melspectrogram(torch.from_numpy(x), num_mels=num_mels, sample_rate=sr, min_freq=min_freq,
+                                        max_freq=max_freq, htk=htk, n_fft=n, hop=hop, win_length=win_length)
+        got = host(mel(dev(x)))
+        tag = (case, n, hop, win_length, num_mels, sr, htk, min_freq, max_freq, shape)
+        assert got.shape == tuple(want.shape), tag
+        assert rel_err(got, want.numpy()) < 2e-5, tag
+        chain = torch.nn.Sequential(*mel, tac.AmplitudeToDb(ref=1.0, amin=1e-7)).cuda()
+        want_db = torch_ref.amplitude_to_db(want, ref=1.0, amin=1e-7).numpy()
+        got_db = host(chain(dev(x)))
+        big = want.numpy() > 1e-6 * want.numpy().max()
+        assert np.abs(got_db - want_db)[big].max() < DB_ABS, tag
+
+
 def test_non_power_of_two_and_large_n_fft(tac, golden):
     """fft_length outside the FFT kernels' power-of-two range runs as a windowed-DFT matrix product on the fp32
     MFMA (reference: torch.stft accepts any n_fft, SURVEY §8 a-1 [probed] N=400)."""
@@ -190,6 +222,36 @@ def test_stft_vs_oracles(tac, shape, n, hop):
     assert rel_err(z[..., 0] + 1j * z[..., 1], want_n) < TIGHT
     mag, phase = tac.magphase(tac.stft(dev(x), n, hop_length=hop))
     assert rel_err(host(mag), np.abs(want_n)) < TIGHT
+
+
+def test_stft_parameter_sweep_vs_oracle(tac):
+    """Seeded sweep over the STFT argument space (size, hop parity, short windows, centring, every pad mode,
+    normalisation, one/two-sided, odd lengths and row counts) — every kernel family and both load paths — against
+    the torch-CPU restatement of functional.py:48-113."""
+    rng = np.random.default_rng(2026)
+    checked = 0
+    for case in range(48):
+        n = int(rng.choice([32, 64, 128, 256, 512, 1024, 2048, 4096]))
+        hop = int(rng.integers(1, n + 1)) if case % 3 else int(rng.choice([n // 4, n // 2, n // 8 or 1]))
+        win_length = n if case % 4 else int(rng.integers(max(2, n // 4), n + 1))
+        center = bool(case % 5)
+        pad_mode = ['reflect', 'constant', 'replicate', 'circular'][case % 4]
+        normalized = bool(case % 7 == 0)
+        onesided = bool(case % 6)
+        rows = (int(rng.integers(1, 4)), int(rng.integers(1, 3)))
+        length = int(rng.integers(n + 1, 3 * n + 40)) + (case % 2)
+        x = signals.audio_like(rows + (length,), seed=100 + case)
+        window = None if case % 3 else torch.from_numpy(signals.uniform((win_length,), seed=200 + case) * 0.5 + 0.75)
+        kw = dict(win_length=win_length, window=window, center=center, pad_mode=pad_mode, normalized=normalized,
+                  onesided=onesided)
+        want = torch_ref.stft(torch.from_numpy(x), n, hop, **kw).numpy()
+        got = host(tac.stft(dev(x), n, hop_length=hop, win_length=win_length,
+                            window=None if window is None else window.cuda(), center=center, pad_mode=pad_mode,
+                            normalized=normalized, onesided=onesided))
+        assert got.shape == want.shape, (case, n, hop, kw)
+        assert rel_err(got, want) < 5e-6, (case, n, hop, win_length, center, pad_mode, normalized, onesided, length)
+        checked += 1
+    assert checked == 48
 
 
 @pytest.mark.parametrize('power', [1, 2, 0.7])
