@@ -34,6 +34,9 @@ __host__ __device__ __forceinline__ cf mkc(float x, float y) {
     return r;
 }
 
+#ifndef TAC_FFT_HALF
+#define TAC_FFT_HALF 1      // 0: A/B knob, the last pass stores every output and the R2C split reads both halves back
+#endif
 #ifndef TAC_EXP_NOCONF
 #define TAC_EXP_NOCONF 0   // timing experiment only (wrong results): pass read-backs and R2C reads without padding = conflict-free
 #endif
@@ -339,20 +342,29 @@ struct WaveFft {
     // stamps (timing builds): 2P+1 = pass P's operands read back and twiddled, 2P+2 = its butterflies done.
     // t0: the lane's first-pass column (v[f][b*R0 + q] = z_f[(t0 + b*LPF) + q*NC/R0]); any permutation of the
     // lanes works there (frame_col_of_lane) because pass 0 only uses it to place its outputs.
-    template <int NF, class ST>
+    // HALF: the last pass stores only the upper half of each lane's outputs (m >= E/2).  The R2C split pairs
+    // Z[k], k = t + i*LPF (i < E/2) — which the lane still holds in registers, reg_of_spectrum(i) — with Z[NC-k],
+    // which is always one of the upper-half outputs of lane (LPF - t) mod LPF: the lower half never needs to travel.
+    template <int NF, class ST, bool HALF = false>
     __device__ static __forceinline__ void run(cf (&v)[NF][E_], cf* const (&lds)[NF], const cf* tw, int t, ST& st,
                                                int t0) {
-        pass<0, NF>(v, lds, tw, t, st, t0);
+        pass<0, NF, ST, HALF>(v, lds, tw, t, st, t0);
         wave_lds_fence();
+    }
+    // register index (within v[f]) of Z[t + i*LPF] after the last pass: output m = b + NB*k sits in v[b*R + k]
+    __device__ static constexpr int reg_of_spectrum(int i) {
+        constexpr int R = radix_at(NC_, num_passes(NC_) - 1), NB = E_ / R;
+        return (i % NB) * R + (i / NB);
     }
     template <int NF, class ST>
     __device__ static __forceinline__ void run(cf (&v)[NF][E_], cf* const (&lds)[NF], const cf* tw, int t, ST& st) {
         run<NF>(v, lds, tw, t, st, t);
     }
 
-    template <int P, int NF, class ST>
+    template <int P, int NF, class ST, bool HALF = false>
     __device__ static __forceinline__ void pass(cf (&v)[NF][E_], cf* const (&lds)[NF], const cf* tw, int t, ST& st,
                                                 int t0) {
+        constexpr int KLO = (HALF && TAC_FFT_HALF && pass_is_last(NC_, P)) ? radix_at(NC_, P) / 2 : 0;     // first output stored
         constexpr int R = radix_at(NC, P), S = stride_at(NC, P), OFF = twiddles_before(NC, E, P);
         constexpr int NB = E / R;
         static_assert(NB >= 1, "radix larger than elements per lane");
@@ -400,15 +412,15 @@ struct WaveFft {
                     static_assert(R == 16, "first pass is radix 16");
                     cf* dst = lds[f] + 17 * j;                          // pad(16 j + k) = 17 j + k, k < 16
 #pragma unroll
-                    for (int k = 0; k < R; ++k) dst[k] = v[f][b * R + k];
+                    for (int k = KLO; k < R; ++k) dst[k] = v[f][b * R + k];
                 } else {
                     static_assert(S % 16 == 0, "write stride must keep the padding affine");
                     cf* dst = lds[f] + lds_pad((j / S) * (S * R) + (j & (S - 1)));
 #pragma unroll
-                    for (int k = 0; k < R; ++k) dst[lds_pad_c(k * S)] = v[f][b * R + k];
+                    for (int k = KLO; k < R; ++k) dst[lds_pad_c(k * S)] = v[f][b * R + k];
                 }
             }
-        if constexpr (P + 1 < NPASS) pass<P + 1, NF>(v, lds, tw, t, st, t0);
+        if constexpr (P + 1 < NPASS) pass<P + 1, NF, ST, HALF>(v, lds, tw, t, st, t0);
     }
 
     // R2C split of pair index k (0 <= k <= NC/2): returns 2·X[k] in xa and 2·X[NC-k] in xb (the halving of the
@@ -420,6 +432,11 @@ struct WaveFft {
 #else
         r2c_split_x2(lds[lds_pad(k)], lds[lds_pad((NC - k) & (NC - 1))], wk, xa, xb);
 #endif
+    }
+    // partner Z[NC-k] of pair index k = t + i*LPF from LDS; k == 0 pairs with itself (its slot is not stored under HALF)
+    __device__ static __forceinline__ cf r2c_partner(const cf* lds, int k, cf zk) {
+        const cf zm = lds[lds_pad((NC - k) & (NC - 1))];
+        return k == 0 ? zk : zm;
     }
     __device__ static __forceinline__ void r2c_split_x2(cf zk, cf zm, cf wk, cf& xa, cf& xb) {
         const cf ev = cadd_conj(zk, zm), d = csub_conj(zk, zm);

@@ -112,7 +112,7 @@ __device__ __forceinline__ void mel_phase_a(const FrameGeom& g, cf* bufs, const 
             }
             st.mark(8);
 #if TAC_MEL_ABL != 1
-            F::template run<NF>(v, lds, tw, t, st, PIPE ? tcol : t);
+            F::template run<NF, ST, true>(v, lds, tw, t, st, PIPE ? tcol : t);   // lower-half spectrum stays in registers
 #endif
             st.mark(9);
             if constexpr (PIPE) {
@@ -129,12 +129,14 @@ __device__ __forceinline__ void mel_phase_a(const FrameGeom& g, cf* bufs, const 
             }
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
-                // gather every Z this lane needs BEFORE anything is overwritten (in-place row)
+                // gather every partner Z[NC-k] this lane needs BEFORE anything is overwritten (in-place row); the
+                // Z[k] themselves never left the lane (WaveFft::run<..., HALF>)
+                cf zk[F::NPAIR], zm[F::NPAIR];
 #pragma unroll
                 for (int i = 0; i < F::NPAIR; ++i) {
                     const int kk = t + i * F::LPF;
-                    v[f][2 * i] = lds[f][lds_pad(kk)];
-                    v[f][2 * i + 1] = lds[f][lds_pad((NC - kk) & (NC - 1))];
+                    zk[i] = v[f][F::reg_of_spectrum(i)];
+                    zm[i] = (i == 0) ? F::r2c_partner(lds[f], kk, zk[i]) : lds[f][lds_pad(NC - kk)];
                 }
                 const cf zmid = lds[f][lds_pad(NC / 2)];
                 const float pfac = 0.25f * g.scale * g.scale;              // |2X|^2 -> |scale·X|^2
@@ -145,8 +147,8 @@ __device__ __forceinline__ void mel_phase_a(const FrameGeom& g, cf* bufs, const 
                     const int kk = t + i * F::LPF;
                     cf xa, xb;
                     // xa, xb = 2·X: the halving and the `normalized` scale are one factor applied to the power
-                    if constexpr (FACT) F::r2c_split_factored_x2(v[f][2 * i], v[f][2 * i + 1], ptw[0], i, xa, xb);
-                    else F::r2c_split_x2(v[f][2 * i], v[f][2 * i + 1], ptw[FACT ? 0 : i], xa, xb);
+                    if constexpr (FACT) F::r2c_split_factored_x2(zk[i], zm[i], ptw[0], i, xa, xb);
+                    else F::r2c_split_x2(zk[i], zm[i], ptw[FACT ? 0 : i], xa, xb);
                     const float pa = cnorm2(xa) * pfac, pb = cnorm2(xb) * pfac;
                     prow[kk] = POW2 ? pa : sqrtf(pa);
                     prow[NC - kk] = POW2 ? pb : sqrtf(pb);

@@ -404,7 +404,7 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
         for (int e = 0; e < E; ++e) lds[lds_pad(t + e * F::LPF)] = v[0][e];
         wave_lds_fence();
 #else
-        F::template run<1>(v, ldsv, tw, t, st, col);
+        F::template run<1, StftStamp, true>(v, ldsv, tw, t, st, col);       // lower-half spectrum stays in registers
 #endif
         st.mark(9);
 
@@ -432,8 +432,14 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 #pragma unroll
             for (int i = 0; i < F::NPAIR; ++i) {
                 const int k = t + i * F::LPF;
-                if constexpr (LEAN) F::r2c_split_factored_x2(lds[lds_pad(k)], lds[lds_pad((NC - k) & (NC - 1))], ptw[0], i, xa[i], xb[i]);
-                else F::r2c_pair(lds, k, ptw[i], xa[i], xb[i]);
+#if TAC_PIPE_ABL == 2
+                const cf zk = lds[lds_pad(k)], zm = lds[lds_pad((NC - k) & (NC - 1))];
+#else
+                const cf zk = v[0][F::reg_of_spectrum(i)];            // Z[k] never left this lane
+                const cf zm = (i == 0) ? F::r2c_partner(lds, k, zk) : lds[lds_pad(NC - k)];
+#endif
+                if constexpr (LEAN) F::r2c_split_factored_x2(zk, zm, ptw[0], i, xa[i], xb[i]);
+                else F::r2c_split_x2(zk, zm, ptw[i], xa[i], xb[i]);
                 xa[i] = cscale(xa[i], hscale); xb[i] = cscale(xb[i], hscale);
             }
             F::r2c_pair(lds, NC / 2, mkc(0.0f, -1.0f), xm, unused);
