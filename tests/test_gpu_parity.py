@@ -448,6 +448,34 @@ def test_g7_phase_vocoder_and_time_stretch(tac, golden):
         ts(stft)
 
 
+def test_non_finite_samples_poison_the_same_frames(tac):
+    """A NaN / Inf sample makes every bin of the frames that contain it NaN in the reference (the FFT mixes it
+    into all of them); the kernels must poison exactly those frames — across the window, the reflect padding and
+    the fused chain — and leave the others bit-for-bit unaffected."""
+    x = signals.uniform((2, 1, 9000), seed=51)
+    clean = x.copy()
+    x[0, 0, 4000] = np.nan
+    x[1, 0, 10] = np.inf                                    # inside the reflected prefix of the first frames
+    mel = tac.Melspectrogram(num_mels=64, sample_rate=16000, fft_length=1024, hop_length=256).cuda()
+    chain = torch.nn.Sequential(*mel, tac.AmplitudeToDb()).cuda()
+    want = torch_ref.melspectrogram_db(torch.from_numpy(x), n_fft=1024, hop=256, num_mels=64, sample_rate=16000).numpy()
+    got = host(chain(dev(x)))
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.isnan(got).any() and not np.isnan(got).all()
+    ok = ~np.isnan(want)
+    assert np.abs(got[ok] - want[ok]).max() < DB_ABS
+    ref_clean = host(chain(dev(clean)))
+    assert np.array_equal(got[ok], ref_clean[ok])            # untouched frames do not depend on the poisoned ones
+    # complex STFT: which bins of a poisoned frame come out NaN and which +-Inf (and whether the exactly-zero
+    # imaginary parts of DC / Nyquist stay zero) depends on the summation order, so compare per frame
+    z = host(tac.stft(dev(x), 1024, hop_length=256))
+    zw = torch_ref.stft(torch.from_numpy(x), 1024, 256).numpy()
+    bad, bad_w = ~np.isfinite(z).all(axis=(2, 4)), ~np.isfinite(zw).all(axis=(2, 4))
+    assert np.array_equal(bad, bad_w) and bad.any()
+    keep = np.broadcast_to(~bad[:, :, None, :, None], z.shape)
+    assert rel_err(z[keep], zw[keep]) < TIGHT
+
+
 # ------------------------------------------------------------------ mu-law: bit-exact integers
 def test_mulaw_golden_bit_exact(tac, golden):
     g = golden('g5_mulaw')

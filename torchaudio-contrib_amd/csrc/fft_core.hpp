@@ -662,8 +662,8 @@ __device__ __forceinline__ float cpow_mag(cf x, float power) {
 
 // amplitude_to_db: 10*(log10(max(x*x, amin)) - log10(ref))   (reference squares its input)
 __device__ __forceinline__ float amp_to_db(float x, float amin, float log10_ref) {
-    float sq = fmaxf(x * x, amin);
-    if (!(sq == sq)) sq = x * x;   // keep NaN (torch.clamp propagates NaN, fmaxf would drop it)
+    const float p = x * x;
+    const float sq = (p == p) ? fmaxf(p, amin) : p;   // keep NaN: torch.clamp propagates it, fmaxf alone would return amin
     return 10.0f * (log10f(sq) - log10_ref);
 }
 
