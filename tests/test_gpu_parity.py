@@ -476,6 +476,32 @@ def test_non_finite_samples_poison_the_same_frames(tac):
     assert rel_err(z[keep], zw[keep]) < TIGHT
 
 
+def test_non_contiguous_and_odd_layout_inputs(tac):
+    """Strided time axes, transposed leading dims, row strides that break 8-/16-byte alignment and storage offsets
+    must give exactly what the dense copy gives (the kernels take a row stride; everything else is normalised on
+    the host without touching the values)."""
+    base = dev(signals.uniform((3, 4, 8192), seed=61))
+    mel = torch.nn.Sequential(*tac.Melspectrogram(num_mels=40, sample_rate=16000, fft_length=512, hop_length=128),
+                              tac.AmplitudeToDb()).cuda()
+    views = {
+        'time-strided': base[..., ::2],
+        'leading-transposed': base.transpose(0, 1),
+        'row-stride-odd': base[..., :4097],               # rows start at odd sample offsets: scalar load path
+        'offset-storage': base[1:, 1:, 3:],
+        'expanded-channel': base[:, :1].expand(3, 4, 8192),
+    }
+    for name, v in views.items():
+        dense = v.contiguous()
+        assert torch.equal(tac.stft(v, 512, hop_length=128), tac.stft(dense, 512, hop_length=128)), name
+        assert torch.equal(mel(v), mel(dense)), name
+        want = torch_ref.stft(dense.cpu(), 512, 128).numpy()
+        assert rel_err(host(tac.stft(v, 512, hop_length=128)), want) < TIGHT, name
+    # elementwise ops on non-dense inputs
+    spec = tac.Spectrogram(512, 128, power=2.).cuda()(base)           # strided (…, F, T) view of a frame-major buffer
+    assert torch.equal(tac.amplitude_to_db(spec), tac.amplitude_to_db(spec.contiguous()))
+    assert torch.equal(tac.mu_law_encoding(base[..., ::3], 256), tac.mu_law_encoding(base[..., ::3].contiguous(), 256))
+
+
 # ------------------------------------------------------------------ mu-law: bit-exact integers
 def test_mulaw_golden_bit_exact(tac, golden):
     g = golden('g5_mulaw')
