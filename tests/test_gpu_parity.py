@@ -502,6 +502,27 @@ def test_non_contiguous_and_odd_layout_inputs(tac):
     assert torch.equal(tac.mu_law_encoding(base[..., ::3], 256), tac.mu_law_encoding(base[..., ::3].contiguous(), 256))
 
 
+def test_kernels_run_on_the_callers_stream(tac):
+    """Every entry point launches on torch's current stream (the C ABI takes the stream as an argument): work queued
+    on a side stream behind a long-running producer must see the producer's data, without a device-wide sync."""
+    side = torch.cuda.Stream()
+    x = dev(signals.uniform((8, 1, 40000), seed=71))
+    mel = torch.nn.Sequential(*tac.Melspectrogram(num_mels=64, sample_rate=16000, fft_length=1024, hop_length=256),
+                              tac.AmplitudeToDb()).cuda()
+    want = mel(x).clone()
+    want_codes = tac.mu_law_encoding(x, 256).clone()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        buf = torch.zeros_like(x)
+        for _ in range(20):                                  # keep the side stream busy ahead of the copy
+            buf = buf + 0.0
+        buf.copy_(x, non_blocking=True)
+        got = tac.realize(mel(buf))
+        codes = tac.mu_law_encoding(buf, 256)
+    side.synchronize()
+    assert torch.equal(got, want) and torch.equal(codes, want_codes)
+
+
 # ------------------------------------------------------------------ mu-law: bit-exact integers
 def test_mulaw_golden_bit_exact(tac, golden):
     g = golden('g5_mulaw')
