@@ -523,6 +523,24 @@ def test_kernels_run_on_the_callers_stream(tac):
     assert torch.equal(got, want) and torch.equal(codes, want_codes)
 
 
+def test_fused_call_is_hip_graph_capturable(tac):
+    """After a warm-up call the fused pipeline is one kernel launch on the current stream plus an allocator hit, so
+    it can be captured in a HIP graph and replayed on new data in the captured buffer."""
+    model = torch.nn.Sequential(*tac.Melspectrogram(num_mels=128, sample_rate=16000, fft_length=2048, hop_length=512),
+                                tac.AmplitudeToDb()).cuda()
+    x = dev(signals.uniform((4, 1, 16000), seed=81))
+    for _ in range(3):
+        tac.realize(model(x))
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        y = tac.realize(model(x))
+    x.copy_(dev(signals.uniform((4, 1, 16000), seed=82)))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, tac.realize(model(x)))
+
+
 # ------------------------------------------------------------------ mu-law: bit-exact integers
 def test_mulaw_golden_bit_exact(tac, golden):
     g = golden('g5_mulaw')
