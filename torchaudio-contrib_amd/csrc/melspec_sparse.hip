@@ -27,6 +27,9 @@
 #ifndef TAC_SP_FACT
 #define TAC_SP_FACT 1       // R2C twiddles as one lane register x compile-time W_32^i (frees 14 registers for the prefetch)
 #endif
+#ifndef TAC_SP_PB_PIPE
+#define TAC_SP_PB_PIPE 1    // software-pipelined contraction loop (0: A/B knob)
+#endif
 #ifndef TAC_SP_TIMING
 #define TAC_SP_TIMING 0   // 1: debug builds of tools/mel_phase_timing.py — phase cycle sums overwrite the head of out[]
 #endif
@@ -157,22 +160,38 @@ melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
 #if TAC_MEL_ABL != 2
         {
             const int nb = dg[0];
+            int4 dnext = *reinterpret_cast<const int4*>(dg + 4);                      // band, first bin, n8, weight offset
             for (int b = 0; b < nb; ++b) {
-                const int4 d = *reinterpret_cast<const int4*>(dg + 4 + 4 * b);       // band, first bin, n8, weight offset
+                const int4 d = dnext;
+                dnext = *reinterpret_cast<const int4*>(dg + 4 + 4 * (b + 1 < nb ? b + 1 : b));   // next band's descriptor in flight
                 const float* p = prow + d.y;
                 const float4* w4 = reinterpret_cast<const float4*>(wlds + d.w);
                 cf acc0 = mkc(0.0f, 0.0f), acc1 = mkc(0.0f, 0.0f);
                 // 8 taps per trip: 2 weight vectors (LDS broadcast) + 4 eight-byte row reads (bands start on even bins,
-                // tac_melbank_pack) in flight before 4 packed FMAs — the loop is LDS-bound, so fewer, fatter accesses
-                // are what shortens it (ds_read_b64 moves twice the bytes per LDS cycle of ds_read_b32)
+                // tac_melbank_pack) feed 4 packed FMAs.  The loop is LDS-latency-bound at 2 waves/SIMD, so it is software
+                // pipelined: trip j+1's six reads are issued before trip j's FMAs (the last trip re-reads itself).
+                float4 wa = w4[0], wb = w4[1];
+                const cf* q = reinterpret_cast<const cf*>(p);
+                cf p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3];
                 for (int j = 0; j < d.z; ++j) {
-                    const float4 wa = w4[2 * j], wb = w4[2 * j + 1];
-                    const cf* q = reinterpret_cast<const cf*>(p + 8 * j);
-                    const cf p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3];
+#if TAC_SP_PB_PIPE
+                    const int jn = j + 1 < d.z ? j + 1 : j;
+#else
+                    const int jn = j;                      // A/B knob: no look-ahead (the reads land right before their use)
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+                    const float4 nwa = w4[2 * jn], nwb = w4[2 * jn + 1];
+                    const cf* qn = reinterpret_cast<const cf*>(p + 8 * jn);
+                    const cf n0 = qn[0], n1 = qn[1], n2 = qn[2], n3 = qn[3];
                     acc0 = __builtin_elementwise_fma(mkc(wa.x, wa.y), p0, acc0);
                     acc1 = __builtin_elementwise_fma(mkc(wa.z, wa.w), p1, acc1);
                     acc0 = __builtin_elementwise_fma(mkc(wb.x, wb.y), p2, acc0);
                     acc1 = __builtin_elementwise_fma(mkc(wb.z, wb.w), p3, acc1);
+#if TAC_SP_PB_PIPE
+                    wa = nwa; wb = nwb; p0 = n0; p1 = n1; p2 = n2; p3 = n3;
+#else
+                    (void)nwa; (void)nwb; (void)n0; (void)n1; (void)n2; (void)n3;
+#endif
                 }
                 otile[fr * ostr + d.x] = (acc0.x + acc0.y) + (acc1.x + acc1.y);
             }
