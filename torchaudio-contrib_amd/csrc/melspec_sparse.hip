@@ -40,7 +40,7 @@
 #define TAC_SP_HOISTW 1    // keep the window in registers for the kernel's lifetime (A/B knob)
 #endif
 #ifndef TAC_SP_NF
-#define TAC_SP_NF 1      // frames advanced together per wave in phase A (A/B knob; 2 spills 128 B and measures 10 % slower)
+#define TAC_SP_NF 1      // frames advanced together per wave in phase A (A/B knob; 2 fits since the packed-math core but measures 3-6 % slower)
 #endif
 
 namespace tac {
