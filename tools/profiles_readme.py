@@ -78,6 +78,22 @@ for label, name, calls, ms, alg, traffic, c in rows:
                   c['SQ_INSTS_VMEM_WR'] / FRAMES, 100 * c['SQ_LDS_IDX_ACTIVE'] / 256 / cyc,
                   100 * c['SQ_LDS_BANK_CONFLICT'] / c['SQ_LDS_IDX_ACTIVE'], 100 * c['SQ_WAIT_ANY'] / c['SQ_WAVE_CYCLES']))
 out.append('')
+if all('SQ_WAIT_INST_ANY' in c for _, _, _, _, _, _, c in rows if c):
+    out.append('Where a wave\'s cycles go (disjoint SQ buckets, fractions of SQ_WAVE_CYCLES): parked at s_waitcnt / s_barrier '
+               '(SQ_WAIT_ANY), ready but not issued (SQ_WAIT_INST_ANY; of which waiting for the LDS queue SQ_WAIT_INST_LDS), '
+               'issuing (SQ_ACTIVE_INST_ANY; VALU / LDS / scalar shares):')
+    out.append('')
+    out.append('| kernel | parked | issue-stalled (LDS queue) | issuing (VALU / LDS / scalar) |')
+    out.append('|---|---|---|---|')
+    for label, name, calls, ms, alg, traffic, c in rows:
+        if not c:
+            continue
+        wc = c['SQ_WAVE_CYCLES']
+        out.append('| %s | %.0f %% | %.0f %% (%.0f %%) | %.0f %% (%.0f / %.0f / %.0f %%) |'
+                   % (label, 100 * c['SQ_WAIT_ANY'] / wc, 100 * c['SQ_WAIT_INST_ANY'] / wc, 100 * c['SQ_WAIT_INST_LDS'] / wc,
+                      100 * c['SQ_ACTIVE_INST_ANY'] / wc, 100 * c['SQ_ACTIVE_INST_VALU'] / wc,
+                      100 * c['SQ_ACTIVE_INST_LDS'] / wc, 100 * c['SQ_ACTIVE_INST_SCA'] / wc))
+    out.append('')
 out.append('All three kernels run 2 waves/SIMD (8 waves per CU), no scratch.  The fused kernel\'s HBM traffic equals its '
            'algorithmic bytes: every input sample leaves HBM exactly once and nothing but the mel-dB tensor is written.  '
            'DESIGN.md §3.2/§3.3 hold the phase-stamp breakdowns, the ablations and the list of variants measured not to help.')
