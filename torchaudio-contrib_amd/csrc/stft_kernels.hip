@@ -367,6 +367,15 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
     int lc4 = 0, lc5 = 0, lc6 = 0, lc7 = 0;
     bool have_late = false;
 
+#ifndef TAC_PIPE_STAGGER
+#define TAC_PIPE_STAGGER 0   // N > 0: waves start N*64*k cycles apart (k = (block + wave) mod 4) so their store phases interleave
+#endif
+#if TAC_PIPE_STAGGER
+    {
+        const int k = ((int)blockIdx.x + w) & 3;
+        for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(TAC_PIPE_STAGGER);
+    }
+#endif
     StftStamp st;
 #if TAC_STFT_TIMING
     st.init();
