@@ -508,7 +508,21 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
         const int last = nchunks - 1;
 #define TAC_ROW_IDX(i) const int c##i = (t + 64 * i) < last ? (t + 64 * i) : last;
 #define TAC_ROW_RD(i) const float4 b##i = s4[c##i];
+#ifndef TAC_PIPE_STORE_POLICY
+#define TAC_PIPE_STORE_POLICY 1   // cache policy of the row stores: 0 plain, 1 nt (default: the rows are written once and never re-read;
+                                  // measured 0.234 -> 0.19 ms on the complex STFT), 2 sc1 / 3 sc0 sc1 (write-through: 0.38 ms)
+#endif
+#if TAC_PIPE_STORE_POLICY == 0
 #define TAC_ROW_WR(i) g4[c##i] = b##i;
+#elif TAC_PIPE_STORE_POLICY == 1
+#define TAC_ROW_WR(i) __builtin_nontemporal_store(__builtin_bit_cast(__attribute__((ext_vector_type(4))) float, b##i), \
+            reinterpret_cast<__attribute__((ext_vector_type(4))) float*>(&g4[c##i]));
+#else
+        const __amdgpu_buffer_rsrc_t rowrs = __builtin_amdgcn_make_buffer_rsrc(g4, 0, 0x7fffffff, 0x00020000);
+#define TAC_ROW_WR(i) __builtin_amdgcn_raw_buffer_store_b128(                                              \
+            __builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, b##i), rowrs, c##i * 16, 0, \
+            TAC_PIPE_STORE_POLICY == 2 ? 16 : 17);
+#endif
         TAC_ROW_IDX(0) TAC_ROW_IDX(1) TAC_ROW_IDX(2) TAC_ROW_IDX(3)
         TAC_ROW_RD(0) TAC_ROW_RD(1) TAC_ROW_RD(2) TAC_ROW_RD(3)
         if constexpr (NST == 8) {
