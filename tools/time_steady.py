@@ -1,0 +1,27 @@
+#!/usr/bin/env python
+"""Steady-state kernel times (0.5 s spin-up per kernel, then 100 back-to-back launches with per-launch HIP events).
+    python tools/time_steady.py [stft spec mel]"""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torchaudio_contrib_amd as tac
+x = torch.rand(256, 1, 160000, device='cuda') * 2 - 1
+stft = tac.STFT(2048, 512).cuda()
+spec = tac.Spectrogram(2048, 512, power=2.).cuda()
+mel = torch.nn.Sequential(*tac.Melspectrogram(num_mels=128, sample_rate=16000, fft_length=2048, hop_length=512),
+                          tac.AmplitudeToDb()).cuda()
+fns = {'stft': lambda: tac.realize(stft(x)), 'spec': lambda: spec(x), 'mel': lambda: tac.realize(mel(x))}
+for name in (sys.argv[1:] or ['stft', 'spec', 'mel']):
+    fn = fns[name]
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.5:
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+    n = 100
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in ev)
+    print('%-10s %-5s median %.4f ms  p10 %.4f  p90 %.4f' % (os.environ.get('TAC_AMD_LIB', 'default')[-14:], name, ts[n // 2], ts[n // 10], ts[9 * n // 10]))
