@@ -510,7 +510,7 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 #define TAC_ROW_RD(i) const float4 b##i = s4[c##i];
 #ifndef TAC_PIPE_STORE_POLICY
 #define TAC_PIPE_STORE_POLICY 1   // cache policy of the row stores: 0 plain, 1 nt (default: the rows are written once and never re-read;
-                                  // measured 0.234 -> 0.19 ms on the complex STFT), 2 sc1 / 3 sc0 sc1 (write-through: 0.38 ms)
+                                  // measured 0.224 -> 0.158 ms on the complex STFT), 2 sc1 / 3 sc0 sc1 (write-through: 0.38 ms)
 #endif
 #if TAC_PIPE_STORE_POLICY == 0
 #define TAC_ROW_WR(i) g4[c##i] = b##i;
@@ -571,7 +571,7 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 #define TAC_STFT_PIPE 1     // 0: A/B knob, n_fft = 2048 plain epilogues go through the generic kernel
 #endif
 #ifndef TAC_STFT_LEAN
-#define TAC_STFT_LEAN 0     // 1: three waves per SIMD with LDS-resident twiddles (A/B knob: measured equal to two, 0.240 vs 0.238 ms)
+#define TAC_STFT_LEAN 0     // 1: three waves per SIMD with LDS-resident twiddles (A/B knob: measured equal to two, 0.163 vs 0.158 ms)
 #endif
 
 template <int NC, int E, int PMODE>
@@ -596,8 +596,8 @@ static int launch_pipe(const FrameGeom& g, const Tables& tb, const StftEpilogue&
 template <int NC, int E, int MODE>
 static int launch_stft(const FrameGeom& g, const Tables& tb, const StftEpilogue& ep, hipStream_t stream) {
     using F = WaveFft<NC, E>;
-    // frames in flight per wave: measured at cfg-2 (complex STFT) NF=1 0.28 ms vs NF=2 0.33 ms — two frames need
-    // ~64 more live registers than the 256 available at 2 waves/SIMD and the spills cost more than the ILP buys
+    // frames in flight per wave (generic kernel): two fit since the packed-math core (223 registers, no scratch) and
+    // measure 3 % faster without the pipelining; one is what ships
 #ifndef TAC_STFT_NF
 #define TAC_STFT_NF 1
 #endif
