@@ -25,10 +25,11 @@
 #define TAC_SP_PIPE 1       // one-frame-per-wave geometries: request every frame's samples one frame ahead (mel_common.hpp)
 #endif
 #ifndef TAC_SP_FACT
-#define TAC_SP_FACT 1       // R2C twiddles as one lane register x compile-time W_32^i (frees 14 registers for the prefetch)
+#define TAC_SP_FACT 0       // 1: R2C twiddles as one lane register x compile-time W_32^i (A/B knob: frees 14 registers, costs 7
+                            // constant multiplies per frame; steady-state timing: hoisting all eight is 2 % faster)
 #endif
 #ifndef TAC_SP_PB_PIPE
-#define TAC_SP_PB_PIPE 1    // software-pipelined contraction loop (0: A/B knob)
+#define TAC_SP_PB_PIPE 1    // software-pipelined contraction loop (0: A/B knob, plain loop)
 #endif
 #ifndef TAC_SP_TIMING
 #define TAC_SP_TIMING 0   // 1: debug builds of tools/mel_phase_timing.py — phase cycle sums overwrite the head of out[]
@@ -170,16 +171,12 @@ melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
                 // 8 taps per trip: 2 weight vectors (LDS broadcast) + 4 eight-byte row reads (bands start on even bins,
                 // tac_melbank_pack) feed 4 packed FMAs.  The loop is LDS-latency-bound at 2 waves/SIMD, so it is software
                 // pipelined: trip j+1's six reads are issued before trip j's FMAs (the last trip re-reads itself).
+#if TAC_SP_PB_PIPE
                 float4 wa = w4[0], wb = w4[1];
                 const cf* q = reinterpret_cast<const cf*>(p);
                 cf p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3];
                 for (int j = 0; j < d.z; ++j) {
-#if TAC_SP_PB_PIPE
                     const int jn = j + 1 < d.z ? j + 1 : j;
-#else
-                    const int jn = j;                      // A/B knob: no look-ahead (the reads land right before their use)
-                    __builtin_amdgcn_sched_barrier(0);
-#endif
                     const float4 nwa = w4[2 * jn], nwb = w4[2 * jn + 1];
                     const cf* qn = reinterpret_cast<const cf*>(p + 8 * jn);
                     const cf n0 = qn[0], n1 = qn[1], n2 = qn[2], n3 = qn[3];
@@ -187,12 +184,19 @@ melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
                     acc1 = __builtin_elementwise_fma(mkc(wa.z, wa.w), p1, acc1);
                     acc0 = __builtin_elementwise_fma(mkc(wb.x, wb.y), p2, acc0);
                     acc1 = __builtin_elementwise_fma(mkc(wb.z, wb.w), p3, acc1);
-#if TAC_SP_PB_PIPE
                     wa = nwa; wb = nwb; p0 = n0; p1 = n1; p2 = n2; p3 = n3;
-#else
-                    (void)nwa; (void)nwb; (void)n0; (void)n1; (void)n2; (void)n3;
-#endif
                 }
+#else
+                for (int j = 0; j < d.z; ++j) {               // A/B knob: no look-ahead
+                    const float4 wa = w4[2 * j], wb = w4[2 * j + 1];
+                    const cf* q = reinterpret_cast<const cf*>(p + 8 * j);
+                    const cf p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3];
+                    acc0 = __builtin_elementwise_fma(mkc(wa.x, wa.y), p0, acc0);
+                    acc1 = __builtin_elementwise_fma(mkc(wa.z, wa.w), p1, acc1);
+                    acc0 = __builtin_elementwise_fma(mkc(wb.x, wb.y), p2, acc0);
+                    acc1 = __builtin_elementwise_fma(mkc(wb.z, wb.w), p3, acc1);
+                }
+#endif
                 otile[fr * ostr + d.x] = (acc0.x + acc0.y) + (acc1.x + acc1.y);
             }
         }
