@@ -35,7 +35,7 @@
 #define TAC_SP_TIMING 0   // 1: debug builds of tools/mel_phase_timing.py — phase cycle sums overwrite the head of out[]
 #endif
 #ifndef TAC_SP_SPLIT
-#define TAC_SP_SPLIT 0     // N = 2048: two independent 4-wave halves per workgroup (A/B knob; measured 0.226 vs 0.220 ms)
+#define TAC_SP_SPLIT 0     // N = 2048: two independent 4-wave halves per workgroup (A/B knob; steady state 0.188 vs 0.175 ms)
 #endif
 #ifndef TAC_SP_HOISTW
 #define TAC_SP_HOISTW 1    // keep the window in registers for the kernel's lifetime (A/B knob)
@@ -63,6 +63,98 @@ struct SparseArgs {
 };
 
 __host__ __device__ inline int sparse_ostr(int n_mels, int out_vec4) { return out_vec4 ? n_mels + 4 : (n_mels | 1); }
+
+// ---------------------------------------------------------------- phases B and C (shared by both kernel forms)
+// phase B: one private dot product per (frame, band) — this thread's lane group owns the band list at dg, its lane
+// within the group owns the frame whose power row starts at prow; results go to the frame's row of the output tile.
+__device__ __forceinline__ void sparse_phase_b(const int* dg, const float* prow, const float* wlds, float* orow) {
+    const int nb = dg[0];
+    int4 dnext = *reinterpret_cast<const int4*>(dg + 4);                      // band, first bin, n8, weight offset
+    for (int b = 0; b < nb; ++b) {
+        const int4 d = dnext;
+        dnext = *reinterpret_cast<const int4*>(dg + 4 + 4 * (b + 1 < nb ? b + 1 : b));   // next band's descriptor in flight
+        const float* p = prow + d.y;
+        const float4* w4 = reinterpret_cast<const float4*>(wlds + d.w);
+        cf acc0 = mkc(0.0f, 0.0f), acc1 = mkc(0.0f, 0.0f);
+        // 8 taps per trip: 2 weight vectors (LDS broadcast) + 4 eight-byte row reads (bands start on even bins,
+        // tac_melbank_pack) feed 4 packed FMAs.  The loop is LDS-latency-bound at 2 waves/SIMD, so it is software
+        // pipelined: trip j+1's six reads are issued before trip j's FMAs (the last trip re-reads itself).
+#if TAC_SP_PB_PIPE
+        float4 wa = w4[0], wb = w4[1];
+        const cf* q = reinterpret_cast<const cf*>(p);
+        cf p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3];
+        for (int j = 0; j < d.z; ++j) {
+            const int jn = j + 1 < d.z ? j + 1 : j;
+            const float4 nwa = w4[2 * jn], nwb = w4[2 * jn + 1];
+            const cf* qn = reinterpret_cast<const cf*>(p + 8 * jn);
+            const cf n0 = qn[0], n1 = qn[1], n2 = qn[2], n3 = qn[3];
+            acc0 = __builtin_elementwise_fma(mkc(wa.x, wa.y), p0, acc0);
+            acc1 = __builtin_elementwise_fma(mkc(wa.z, wa.w), p1, acc1);
+            acc0 = __builtin_elementwise_fma(mkc(wb.x, wb.y), p2, acc0);
+            acc1 = __builtin_elementwise_fma(mkc(wb.z, wb.w), p3, acc1);
+            wa = nwa; wb = nwb; p0 = n0; p1 = n1; p2 = n2; p3 = n3;
+        }
+#else
+        for (int j = 0; j < d.z; ++j) {               // A/B knob: no look-ahead
+            const float4 wa = w4[2 * j], wb = w4[2 * j + 1];
+            const cf* q = reinterpret_cast<const cf*>(p + 8 * j);
+            const cf p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3];
+            acc0 = __builtin_elementwise_fma(mkc(wa.x, wa.y), p0, acc0);
+            acc1 = __builtin_elementwise_fma(mkc(wa.z, wa.w), p1, acc1);
+            acc0 = __builtin_elementwise_fma(mkc(wb.x, wb.y), p2, acc0);
+            acc1 = __builtin_elementwise_fma(mkc(wb.z, wb.w), p3, acc1);
+        }
+#endif
+        orow[d.x] = (acc0.x + acc0.y) + (acc1.x + acc1.y);
+    }
+}
+
+// phase C: dB epilogue + coalesced row stores of out[row][frame][0..M) by the NT threads that share the tile
+template <int NT>
+__device__ __forceinline__ void sparse_phase_c(const float* otile, int ostr, int th, int tile_frames, const SparseArgs& m,
+                                               const FrameGeom& g, int row, long long f0) {
+    if (m.out_vec4) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const int q4 = m.n_mels >> 2;
+        const int c4_df = NT / q4, c4_db = NT % q4;
+        int fo = th / q4, b4 = th % q4;
+        for (int idx = th; idx < tile_frames * q4; idx += NT) {
+            f4 v = *reinterpret_cast<const f4*>(otile + fo * ostr + 4 * b4);
+            if (m.db) {
+                v.x = amp_to_db(v.x, m.amin, m.log10_ref);
+                v.y = amp_to_db(v.y, m.amin, m.log10_ref);
+                v.z = amp_to_db(v.z, m.amin, m.log10_ref);
+                v.w = amp_to_db(v.w, m.amin, m.log10_ref);
+            }
+            const long long frame = f0 + fo;
+#if TAC_MEL_ABL == 3
+            if (frame < g.n_frames && v.x == 12345.678f)
+#else
+            if (frame < g.n_frames)
+#endif
+                *reinterpret_cast<f4*>(m.out + (row * g.n_frames + frame) * m.n_mels + 4 * b4) = v;
+            b4 += c4_db;
+            fo += c4_df;
+            if (b4 >= q4) { b4 -= q4; ++fo; }
+        }
+    } else {
+        const int c_df = NT / m.n_mels, c_dband = NT % m.n_mels;
+        int fo = th / m.n_mels, band = th % m.n_mels;
+        for (int idx = th; idx < tile_frames * m.n_mels; idx += NT) {
+            float v = otile[fo * ostr + band];
+            if (m.db) v = amp_to_db(v, m.amin, m.log10_ref);
+            const long long frame = f0 + fo;
+#if TAC_MEL_ABL == 3
+            if (frame < g.n_frames && v == 12345.678f) m.out[(row * g.n_frames + frame) * m.n_mels + band] = v;
+#else
+            if (frame < g.n_frames) m.out[(row * g.n_frames + frame) * m.n_mels + band] = v;
+#endif
+            band += c_dband;
+            fo += c_df;
+            if (band >= m.n_mels) { band -= m.n_mels; ++fo; }
+        }
+    }
+}
 
 template <int NC, int E, bool POW2, bool V4>
 __global__ void __launch_bounds__((MelCfg<NC, E, SP_TILE>::WAVES * 64), 2)
@@ -159,91 +251,14 @@ melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
 
         // ---------------- phase B: one private dot product per (frame, band)
 #if TAC_MEL_ABL != 2
-        {
-            const int nb = dg[0];
-            int4 dnext = *reinterpret_cast<const int4*>(dg + 4);                      // band, first bin, n8, weight offset
-            for (int b = 0; b < nb; ++b) {
-                const int4 d = dnext;
-                dnext = *reinterpret_cast<const int4*>(dg + 4 + 4 * (b + 1 < nb ? b + 1 : b));   // next band's descriptor in flight
-                const float* p = prow + d.y;
-                const float4* w4 = reinterpret_cast<const float4*>(wlds + d.w);
-                cf acc0 = mkc(0.0f, 0.0f), acc1 = mkc(0.0f, 0.0f);
-                // 8 taps per trip: 2 weight vectors (LDS broadcast) + 4 eight-byte row reads (bands start on even bins,
-                // tac_melbank_pack) feed 4 packed FMAs.  The loop is LDS-latency-bound at 2 waves/SIMD, so it is software
-                // pipelined: trip j+1's six reads are issued before trip j's FMAs (the last trip re-reads itself).
-#if TAC_SP_PB_PIPE
-                float4 wa = w4[0], wb = w4[1];
-                const cf* q = reinterpret_cast<const cf*>(p);
-                cf p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3];
-                for (int j = 0; j < d.z; ++j) {
-                    const int jn = j + 1 < d.z ? j + 1 : j;
-                    const float4 nwa = w4[2 * jn], nwb = w4[2 * jn + 1];
-                    const cf* qn = reinterpret_cast<const cf*>(p + 8 * jn);
-                    const cf n0 = qn[0], n1 = qn[1], n2 = qn[2], n3 = qn[3];
-                    acc0 = __builtin_elementwise_fma(mkc(wa.x, wa.y), p0, acc0);
-                    acc1 = __builtin_elementwise_fma(mkc(wa.z, wa.w), p1, acc1);
-                    acc0 = __builtin_elementwise_fma(mkc(wb.x, wb.y), p2, acc0);
-                    acc1 = __builtin_elementwise_fma(mkc(wb.z, wb.w), p3, acc1);
-                    wa = nwa; wb = nwb; p0 = n0; p1 = n1; p2 = n2; p3 = n3;
-                }
-#else
-                for (int j = 0; j < d.z; ++j) {               // A/B knob: no look-ahead
-                    const float4 wa = w4[2 * j], wb = w4[2 * j + 1];
-                    const cf* q = reinterpret_cast<const cf*>(p + 8 * j);
-                    const cf p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3];
-                    acc0 = __builtin_elementwise_fma(mkc(wa.x, wa.y), p0, acc0);
-                    acc1 = __builtin_elementwise_fma(mkc(wa.z, wa.w), p1, acc1);
-                    acc0 = __builtin_elementwise_fma(mkc(wb.x, wb.y), p2, acc0);
-                    acc1 = __builtin_elementwise_fma(mkc(wb.z, wb.w), p3, acc1);
-                }
-#endif
-                otile[fr * ostr + d.x] = (acc0.x + acc0.y) + (acc1.x + acc1.y);
-            }
-        }
+        sparse_phase_b(dg, prow, wlds, otile + fr * ostr);
 #endif
         st.mark(7);                                        // phase B
         __syncthreads();
         st.mark(11);                                       // barrier B
 
         // ---------------- phase C: dB epilogue + coalesced row stores of out[row][frame][0..M)
-        if (m.out_vec4) {
-            typedef float f4 __attribute__((ext_vector_type(4)));
-            int fo = c4_f0, b4 = c4_b0;
-            for (int idx = tid; idx < TILE * q4; idx += WAVES * 64) {
-                f4 v = *reinterpret_cast<const f4*>(otile + fo * ostr + 4 * b4);
-                if (m.db) {
-                    v.x = amp_to_db(v.x, m.amin, m.log10_ref);
-                    v.y = amp_to_db(v.y, m.amin, m.log10_ref);
-                    v.z = amp_to_db(v.z, m.amin, m.log10_ref);
-                    v.w = amp_to_db(v.w, m.amin, m.log10_ref);
-                }
-                const long long frame = f0 + fo;
-#if TAC_MEL_ABL == 3
-                if (frame < g.n_frames && v.x == 12345.678f)
-#else
-                if (frame < g.n_frames)
-#endif
-                    *reinterpret_cast<f4*>(m.out + (row * g.n_frames + frame) * m.n_mels + 4 * b4) = v;
-                b4 += c4_db;
-                fo += c4_df;
-                if (b4 >= q4) { b4 -= q4; ++fo; }
-            }
-        } else {
-            int fo = c_f0, band = c_band0;
-            for (int idx = tid; idx < TILE * m.n_mels; idx += WAVES * 64) {
-                float v = otile[fo * ostr + band];
-                if (m.db) v = amp_to_db(v, m.amin, m.log10_ref);
-                const long long frame = f0 + fo;
-#if TAC_MEL_ABL == 3
-                if (frame < g.n_frames && v == 12345.678f) m.out[(row * g.n_frames + frame) * m.n_mels + band] = v;
-#else
-                if (frame < g.n_frames) m.out[(row * g.n_frames + frame) * m.n_mels + band] = v;
-#endif
-                band += c_dband;
-                fo += c_df;
-                if (band >= m.n_mels) { band -= m.n_mels; ++fo; }
-            }
-        }
+        sparse_phase_c<WAVES * 64>(otile, ostr, tid, TILE, m, g, row, f0);
         // the barrier after the next phase A orders these otile reads before the next phase-B writes
     }
 #if TAC_SP_TIMING
@@ -280,7 +295,7 @@ melspec_sparse_split_kernel(FrameGeom g, Tables tb, SparseArgs m) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf* bufs = reinterpret_cast<cf*>(smem_raw);                                   // 16 frame buffers (8 per half)
     float* wlds = reinterpret_cast<float*>(bufs + 16 * F::PADDED);
-    const int ostr = m.n_mels | 1;
+    const int ostr = sparse_ostr(m.n_mels, m.out_vec4);
     float* otile = wlds + m.wtot;                                                 // [2][HT][ostr]
     int* dlds = reinterpret_cast<int*>(otile + ((2 * HT * ostr + 3) & ~3));       // [32][dstride]
     int* counters = dlds + 32 * m.dstride;                                        // [2]
@@ -296,7 +311,7 @@ melspec_sparse_split_kernel(FrameGeom g, Tables tb, SparseArgs m) {
     for (int i = tid; i < 32 * m.dstride; i += 512) dlds[i] = m.desc[i];
     if (tid < 2) counters[tid] = 0;
 
-    MelFftConsts<F, TAC_SP_HOISTW != 0> fftk;
+    MelFftConsts<F, TAC_SP_HOISTW != 0, TAC_SP_FACT != 0> fftk;
     fftk.load(tb, g, t, t);
     __syncthreads();
 
@@ -317,53 +332,28 @@ melspec_sparse_split_kernel(FrameGeom g, Tables tb, SparseArgs m) {
     const int fr = th & 7;                                                        // 8 lanes = the 8 frames share a band
     const int* dg = dlds + (th >> 3) * m.dstride;
     const float* prow = reinterpret_cast<const float*>(hbufs) + fr * PROW;
-    const int c_f0 = th / m.n_mels, c_band0 = th % m.n_mels;
-    const int c_df = 256 / m.n_mels, c_dband = 256 % m.n_mels;
 
+    cf raw[F::E];
+    bool pre_ok = false;
+    if (begin < end) {
+        const int r0 = begin / tiles_per_row;
+        pre_ok = prefetch_frame_raw_x<F>(raw, g, r0, (long long)(begin - r0 * tiles_per_row) * HT + wl * C::GPW, t, t, false);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    // the second half starts half a tile late so that the two waves of every SIMD are in different phases
+    NoStamp st;
     for (int tile = begin; tile < end; ++tile) {
         const int row = tile / tiles_per_row;
         const long long f0 = (long long)(tile - row * tiles_per_row) * HT;
-
-        mel_phase_a<C, POW2, 1, TAC_SP_HOISTW != 0>(g, hbufs, fftk, wl, 0, t, row, f0);
+        const int nt = tile + 1;
+        const int nr = nt / tiles_per_row;
+        const long long nf0 = nt < end ? (long long)(nt - nr * tiles_per_row) * HT : -1;
+        mel_phase_a<C, POW2, 1, TAC_SP_HOISTW != 0, NoStamp, true>(g, hbufs, fftk, wl, 0, t, row, f0, raw, &pre_ok, &st, nr, nf0,
+                                                                    t, false);
         half_barrier(hcnt, expected, lane);
-
-        {
-            const int nb = dg[0];
-            for (int b = 0; b < nb; ++b) {
-                const int4 d = *reinterpret_cast<const int4*>(dg + 4 + 4 * b);       // band, first bin, n8, weight offset
-                const float* p = prow + d.y;
-                const float4* w4 = reinterpret_cast<const float4*>(wlds + d.w);
-                float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
-                for (int j = 0; j < d.z; ++j) {
-                    const float4 wa = w4[2 * j], wb = w4[2 * j + 1];
-                    const float* q = p + 8 * j;
-                    const float p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3], p4 = q[4], p5 = q[5], p6 = q[6], p7 = q[7];
-                    acc0 = fmaf(wa.x, p0, acc0);
-                    acc1 = fmaf(wa.y, p1, acc1);
-                    acc2 = fmaf(wa.z, p2, acc2);
-                    acc3 = fmaf(wa.w, p3, acc3);
-                    acc0 = fmaf(wb.x, p4, acc0);
-                    acc1 = fmaf(wb.y, p5, acc1);
-                    acc2 = fmaf(wb.z, p6, acc2);
-                    acc3 = fmaf(wb.w, p7, acc3);
-                }
-                hot[fr * ostr + d.x] = (acc0 + acc1) + (acc2 + acc3);
-            }
-        }
+        sparse_phase_b(dg, prow, wlds, hot + fr * ostr);
         half_barrier(hcnt, expected, lane);
-
-        {
-            int fo = c_f0, band = c_band0;
-            for (int idx = th; idx < HT * m.n_mels; idx += 256) {
-                float v = hot[fo * ostr + band];
-                if (m.db) v = amp_to_db(v, m.amin, m.log10_ref);
-                const long long frame = f0 + fo;
-                if (frame < g.n_frames) m.out[(row * g.n_frames + frame) * m.n_mels + band] = v;
-                band += c_dband;
-                fo += c_df;
-                if (band >= m.n_mels) { band -= m.n_mels; ++fo; }
-            }
-        }
+        sparse_phase_c<256>(hot, ostr, th, HT, m, g, row, f0);
         // the half-barrier after the next phase A orders these output-tile reads before the next contraction's writes
     }
 }
@@ -402,7 +392,7 @@ static int launch_sparse(const FrameGeom& g, const Tables& tb, const SparseArgs&
     const bool pow2 = (power == 2.0f);
     if constexpr (C::F::G == 1 && C::WAVES == 8 && TAC_SP_SPLIT != 0) {
         const size_t lds2 = (size_t)16 * C::F::PADDED * sizeof(cf) + (size_t)m.wtot * 4 +
-                            (size_t)((2 * 8 * ostr + 3) & ~3) * 4 + (size_t)32 * m.dstride * 4 + 16;
+                            (size_t)((2 * 8 * ostr + 3) & ~3) * 4 + (size_t)32 * m.dstride * 4 + 16;   // ostr: sparse_ostr above
         if (lds2 <= 160 * 1024) {
             const long long tiles8 = g.rows * ((g.n_frames + 7) / 8);
             if (tiles8 >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
