@@ -10,7 +10,11 @@ stft = tac.STFT(2048, 512).cuda()
 spec = tac.Spectrogram(2048, 512, power=2.).cuda()
 mel = torch.nn.Sequential(*tac.Melspectrogram(num_mels=128, sample_rate=16000, fft_length=2048, hop_length=512),
                           tac.AmplitudeToDb()).cuda()
-fns = {'stft': lambda: tac.realize(stft(x)), 'spec': lambda: spec(x), 'mel': lambda: tac.realize(mel(x))}
+x4 = torch.rand(8, 8, 480000, device='cuda') * 2 - 1                       # cfg-4 slice: 4096/1024, magnitude
+stft4 = tac.STFT(4096, 1024).cuda()
+spec4 = tac.Spectrogram(4096, 1024).cuda()
+fns = {'stft': lambda: tac.realize(stft(x)), 'spec': lambda: spec(x), 'mel': lambda: tac.realize(mel(x)),
+       'stft4096': lambda: tac.realize(stft4(x4)), 'spec4096': lambda: spec4(x4)}
 for name in (sys.argv[1:] or ['stft', 'spec', 'mel']):
     fn = fns[name]
     t0 = time.perf_counter()

@@ -13,6 +13,18 @@
 
 namespace tac {
 
+// epilogue selection of the STFT-family kernels (stft_kernels.hip, stft_n4096.hip)
+struct StftEpilogue {
+    float* out;
+    int onesided;
+    int mode;        // 0 complex, 1 magnitude^power
+    float power;
+    int db;
+    float amin;
+    float log10_ref;
+};
+
+
 extern thread_local int g_last_hip_error;
 
 inline int hip_fail(hipError_t e) {

@@ -29,15 +29,6 @@ using StftStamp = NoStamp;
 
 constexpr int STFT_WAVES = 4;
 
-struct StftEpilogue {
-    float* out;
-    int onesided;
-    int mode;        // 0 complex, 1 magnitude^power
-    float power;
-    int db;
-    float amin;
-    float log10_ref;
-};
 
 // |X|^p (+ dB) for the general case, kept out of the unrolled per-bin code: the squared magnitudes are
 // parked in the frame's own LDS buffer and transformed by this ROLLED loop (one copy of powf/log10f in
@@ -297,7 +288,8 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 // (amplitude_to_db squares its input, functional.py:291-296).  0 = complex rows.
 template <int MODE>
 __device__ __forceinline__ float pipe_row_value(float norm2, const StftEpilogue& ep) {
-    float v = (MODE == 2 || MODE == 4) ? sqrtf(norm2) : norm2;
+    // |X|: the hardware square root (1 ulp) — the correctly rounded sequence costs ~10 instructions per bin
+    float v = (MODE == 2 || MODE == 4) ? __builtin_amdgcn_sqrtf(norm2) : norm2;
     if constexpr (MODE >= 3) v = amp_to_db(v, ep.amin, ep.log10_ref);
     return v;
 }
@@ -642,6 +634,11 @@ static int launch_stft(const FrameGeom& g, const Tables& tb, const StftEpilogue&
     return TAC_OK;
 }
 
+#ifndef TAC_N4096_TWO_HALF
+#define TAC_N4096_TWO_HALF 1   // 0: A/B knob, fft_length = 4096 always takes the generic 32-elements-per-lane kernel
+#endif
+int try_launch_n4096(const FrameGeom& g, const StftEpilogue& ep, int mode, hipStream_t stream);
+
 template <int MODE>
 static int dispatch_stft(int n_fft, const FrameGeom& g, const Tables& tb, const StftEpilogue& ep, hipStream_t s) {
     switch (n_fft) {
@@ -652,7 +649,13 @@ static int dispatch_stft(int n_fft, const FrameGeom& g, const Tables& tb, const 
         case 512: return launch_stft<256, 16, MODE>(g, tb, ep, s);
         case 1024: return launch_stft<512, 16, MODE>(g, tb, ep, s);
         case 2048: return launch_stft<1024, 16, MODE>(g, tb, ep, s);
-        case 4096: return launch_stft<2048, 32, MODE>(g, tb, ep, s);
+        case 4096: {
+#if TAC_N4096_TWO_HALF
+            const int rc = try_launch_n4096(g, ep, MODE, s);          // stft_n4096.hip: plain epilogues, aligned frames
+            if (rc != TAC_E_UNSUPPORTED) return rc;
+#endif
+            return launch_stft<2048, 32, MODE>(g, tb, ep, s);
+        }
         default: return TAC_E_UNSUPPORTED;
     }
 }

@@ -1,0 +1,271 @@
+// stft_n4096.hip — fft_length = 4096 (SURVEY cfg-4): one frame per wave from TWO 1024-point complex FFTs.
+//
+// A 4096-sample real frame is 2048 complex points z[n] = x[2n] + i·x[2n+1].  With 32 elements per lane the
+// single-wave 2048-point transform (stft_kernel<2048, 32>) keeps 64 data registers, cannot hoist its twiddles and
+// cannot afford the software pipelining of stft_pipe_kernel.  Decimating in time once more keeps everything inside
+// the register budget of the n_fft = 2048 kernel:
+//     A = FFT_1024(z[2m]),  B = FFT_1024(z[2m+1])                       (same WaveFft<1024, 16> code, run twice)
+//     Z[k]      = A[k] + W_2048^k · B[k]
+//     Z[2048-k] = A[1024-k] + conj(W_2048^k) · B[1024-k]                 (0 <= k < 1024, indices mod 1024)
+//     2·X[k] = ev + W_4096^k·(-i·d),  2·X[2048-k] = conj(ev - W_4096^k·(-i·d)),  ev/d = Z[k] ± conj(Z[2048-k])
+//     X[1024] = conj(A[0] - B[0])
+// i.e. the radix-2 combine is folded into the R2C split.  Per pair index k = t + 64·i the twiddles factor into one
+// lane register times compile-time constants: W_2048^k = W_2048^t·W_32^i, W_4096^k = W_4096^t·W_64^i.
+// One 16-byte load per lane fetches z[2m] and z[2m+1] together, so a frame is 16 dwordx4 requests; they are issued
+// one frame ahead, before the previous frame's (nontemporal, unconditional) row stores — the stft_pipe_kernel
+// recipe.  Two frame buffers per wave: 3-wave workgroups, two per CU.
+#include "host_common.hpp"
+
+namespace tac {
+
+constexpr int N4K_WAVES = 3;
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// multiply by W_64^i = exp(-2*pi*i*i/64), 0 <= i < 16 (compile-time after unrolling)
+__device__ __forceinline__ cf mul_w64(cf v, int i) {
+    constexpr float C[16] = {1.0000000000e+00f, 9.9518472667e-01f, 9.8078528040e-01f, 9.5694033573e-01f, 9.2387953251e-01f, 8.8192126435e-01f, 8.3146961230e-01f, 7.7301045336e-01f, 7.0710678119e-01f, 6.3439328416e-01f, 5.5557023302e-01f, 4.7139673683e-01f, 3.8268343237e-01f, 2.9028467725e-01f, 1.9509032202e-01f, 9.8017140330e-02f};
+    constexpr float S[16] = {-0.0000000000e+00f, -9.8017140330e-02f, -1.9509032202e-01f, -2.9028467725e-01f, -3.8268343237e-01f, -4.7139673683e-01f, -5.5557023302e-01f, -6.3439328416e-01f, -7.0710678119e-01f, -7.7301045336e-01f, -8.3146961230e-01f, -8.8192126435e-01f, -9.2387953251e-01f, -9.5694033573e-01f, -9.8078528040e-01f, -9.9518472667e-01f};
+    if (i == 0) return v;
+    return cmulc(v, C[i & 15], S[i & 15]);
+}
+
+// a · conj(w): (a.x·w.x + a.y·w.y, a.y·w.x - a.x·w.y)
+__device__ __forceinline__ cf cmul_conj(cf a, cf w) {
+#if TAC_PACKED
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));                 // a.x·(w.x, -w.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));   // + a.y·(w.y, w.x)
+    return r;
+#else
+    return mkc(a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y);
+#endif
+}
+
+// real-valued row epilogues: MODE 1 = |X|^2, 2 = |X|, 3 = |X|^2 in dB, 4 = |X| in dB; 0 = complex rows
+template <int MODE>
+__device__ __forceinline__ float n4k_row_value(float norm2, const StftEpilogue& ep) {
+    // |X|: the hardware square root (1 ulp) — the correctly rounded sequence costs ~10 instructions per bin
+    float v = (MODE == 2 || MODE == 4) ? __builtin_amdgcn_sqrtf(norm2) : norm2;
+    if constexpr (MODE >= 3) v = amp_to_db(v, ep.amin, ep.log10_ref);
+    return v;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(N4K_WAVES * 64, 2)
+stft_n4096_kernel(FrameGeom g, Tables tb1k, Tables tb4k, StftEpilogue ep) {
+    using F = WaveFft<1024, 16>;
+    constexpr int E = 16, NCH = 1024, NBINS = 2049;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf* smem = reinterpret_cast<cf*>(smem_raw);
+    const int t = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int WS = ((F::PADDED + 1) / 2) * 2;
+    cf* const bufA = smem + w * 2 * WS;
+    cf* const bufB = bufA + WS;
+    // window: for lane t and q < 16 the four window values of samples 4m .. 4m+3, m = t + 64q; 272-byte rows
+    constexpr int WROW = E + 1;
+    f4* const wl4 = reinterpret_cast<f4*>(smem + N4K_WAVES * 2 * WS);
+    for (int m = threadIdx.x; m < NCH; m += N4K_WAVES * 64) {
+        const cf wa = window_pair(g, 2 * m), wb = window_pair(g, 2 * m + 1);
+        wl4[(m & 63) * WROW + (m >> 6)] = f4{wa.x, wa.y, wb.x, wb.y};
+    }
+    cf tw[F::NTW];
+    F::load_twiddles(tw, tb1k.w_nc, t);
+    const cf w2k = tb4k.w_nc[t];                          // W_2048^t
+    const cf w4k = tb4k.w_n[t];                           // W_4096^t
+
+    const int T = (int)g.n_frames;
+    const int total = (int)g.rows * T;
+    const int chunk = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int begin = (int)blockIdx.x * chunk;
+    const int end = begin + chunk < total ? begin + chunk : total;
+    constexpr int LENF = (MODE == 0 ? 2 : 1) * NBINS;
+    constexpr int NST = ((LENF >> 2) + 63) / 64;          // 16-byte wave-stores per output row: 17 (complex) / 9
+    const float hscale = 0.5f * g.scale;
+
+    // one frame ahead: 16 requests of 16 bytes per lane (samples 4m .. 4m+3, m = t + 64q)
+    f4 raw[E];
+    auto prefetch = [&](int unit) -> bool {
+        const int urow = unit / T, uframe = unit - urow * T;
+        const long long start = (long long)uframe * g.hop - g.center_pad;
+        const bool ok = g.vec4_ok && start >= 0 && start + 4096 <= g.length;
+        if (ok) {
+            const f4* src = reinterpret_cast<const f4*>(g.wave + (long long)urow * g.row_stride + start);
+#pragma unroll
+            for (int q = 0; q < E; ++q) raw[q] = src[t + 64 * q];
+        }
+        return ok;
+    };
+    bool pre = false;
+    int unit = begin + w;
+    if (unit < end) pre = prefetch(unit);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): the loop is entered with nothing in flight
+    __syncthreads();
+
+    NoStamp st;
+    for (; unit < end; unit += N4K_WAVES) {
+        const int urow = unit / T;
+        const int uframe = unit - urow * T;
+        cf va[1][E], vb[1][E];
+        cf* const la[1] = {bufA};
+        cf* const lb[1] = {bufB};
+        if (pre) {
+            const f4* wp = wl4 + t * WROW;
+#pragma unroll
+            for (int q = 0; q < E; ++q) {
+                const f4 wv = wp[q];
+                va[0][q] = cmul_elem(mkc(raw[q].x, raw[q].y), mkc(wv.x, wv.y));
+                vb[0][q] = cmul_elem(mkc(raw[q].z, raw[q].w), mkc(wv.z, wv.w));
+            }
+        } else {
+            // frames touching the padding: gathered sample by sample through the frame buffers (rolled loop)
+            const float* rp = g.wave + (long long)urow * g.row_stride;
+            const int s0 = (int)((long long)uframe * g.hop - g.center_pad);
+            const int L = (int)g.length;
+#pragma unroll 1
+            for (int q = 0; q < E; ++q) {
+                const int m = t + 64 * q;
+                float smp[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    bool zero;
+                    const int j = padded_index(s0 + 4 * m + c, L, g.pad_mode, &zero);
+                    const float vsmp = rp[j];
+                    smp[c] = zero ? 0.0f : vsmp;
+                }
+                const cf wa = window_pair(g, 2 * m), wb = window_pair(g, 2 * m + 1);
+                bufA[lds_pad(m)] = mkc(smp[0] * wa.x, smp[1] * wa.y);
+                bufB[lds_pad(m)] = mkc(smp[2] * wb.x, smp[3] * wb.y);
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int q = 0; q < E; ++q) {
+                va[0][q] = bufA[lds_pad(t + 64 * q)];
+                vb[0][q] = bufB[lds_pad(t + 64 * q)];
+            }
+            wave_lds_fence();
+        }
+        F::template run<1>(va, la, tw, t, st, t);
+        F::template run<1>(vb, lb, tw, t, st, t);
+
+        // request the next frame now: it lands while this frame is combined, split, staged and stored
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const int nxt = unit + N4K_WAVES;
+            pre = false;
+            if (nxt < end) pre = prefetch(nxt);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        const long long g0 = ((long long)urow * T + uframe) * LENF;
+        const int a = (int)(g0 & 3);
+        float* const stage = reinterpret_cast<float*>(bufA) + a;     // LDS and global share their 16-byte phase
+        {
+            cf xa[E], xb[E];
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const int k = t + 64 * i;
+                const int m = (NCH - k) & (NCH - 1);
+                const cf ak = bufA[lds_pad(k)], bk = bufB[lds_pad(k)];
+                const cf am = bufA[lds_pad(m)], bm = bufB[lds_pad(m)];
+                const cf zk = cadd(ak, cmul(mul_w32(bk, i), w2k));                       // Z[k]
+                const cf zp = cadd(am, cmul_conj(mul_w32(bm, 32 - i), w2k));             // Z[2048-k]
+                const cf ev = cadd_conj(zk, zp), d = csub_conj(zk, zp);
+                const cf twd = cmul_rot(w4k, mul_w64(d, i));
+                xa[i] = cscale(cadd(ev, twd), hscale);
+                xb[i] = cscale(csub_then_conj(ev, twd), hscale);
+            }
+            const cf a0 = bufA[0], b0 = bufB[0];
+            const cf xm = mkc((a0.x - b0.x) * g.scale, -(a0.y - b0.y) * g.scale);         // X[1024] = conj(A[0] - B[0])
+            wave_lds_fence();                                         // every A, B of this frame is in registers
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const int k = t + 64 * i;
+                if constexpr (MODE == 0) {
+                    reinterpret_cast<cf*>(stage)[k] = xa[i];
+                    reinterpret_cast<cf*>(stage)[2048 - k] = xb[i];
+                } else {
+                    stage[k] = n4k_row_value<MODE>(cnorm2(xa[i]), ep);
+                    stage[2048 - k] = n4k_row_value<MODE>(cnorm2(xb[i]), ep);
+                }
+            }
+            if (t == 0) {
+                if constexpr (MODE == 0) reinterpret_cast<cf*>(stage)[1024] = xm;
+                else stage[1024] = n4k_row_value<MODE>(cnorm2(xm), ep);
+            }
+            wave_lds_fence();
+        }
+        // the row leaves as 1 + NST + 1 unconditional nontemporal stores (lanes past the end repeat a neighbour)
+        float* const gdst = ep.out + g0;
+        const int npre = (4 - a) & 3;
+        const int nchunks = (LENF - npre) >> 2;
+        {
+            const int hmax = (npre > 1 ? npre : 1) - 1;
+            const int hi = t < hmax ? t : hmax;
+            gdst[hi] = stage[hi];
+        }
+        const f4* const s4 = reinterpret_cast<const f4*>(stage + npre);
+        f4* const g4 = reinterpret_cast<f4*>(gdst + npre);
+        const int last = nchunks - 1;
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int c = (t + 64 * i) < last ? (t + 64 * i) : last;
+            __builtin_nontemporal_store(s4[c], g4 + c);
+        }
+        {
+            const int r = LENF - npre - 4 * nchunks;
+            const int rmax = (r > 1 ? r : 1) - 1;
+            const int ti = LENF - 1 - (t < rmax ? t : rmax);
+            gdst[ti] = stage[ti];
+        }
+        wave_lds_fence();   // next iteration's first-pass writes must follow these reads
+    }
+}
+
+template <int MODE>
+static int launch_n4096(const FrameGeom& g, const Tables& tb1k, const Tables& tb4k, const StftEpilogue& ep,
+                        hipStream_t stream) {
+    using F = WaveFft<1024, 16>;
+    const long long units = g.rows * g.n_frames;
+    if (units >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
+    constexpr int WS = ((F::PADDED + 1) / 2) * 2;
+    const size_t bytes = (size_t)N4K_WAVES * 2 * WS * sizeof(cf) + (size_t)64 * 17 * sizeof(f4);
+    long long blocks = (units + N4K_WAVES - 1) / N4K_WAVES;
+    const long long cap = (long long)device_cu_count() * 2;
+    if (blocks > cap) blocks = cap;
+    auto kern = stft_n4096_kernel<MODE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        TAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)bytes));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(N4K_WAVES * 64), bytes, stream, g, tb1k, tb4k, ep);
+    TAC_HIP(hipGetLastError());
+    return TAC_OK;
+}
+
+// Entry used by stft_kernels.hip's dispatcher: returns TAC_E_UNSUPPORTED when this form does not apply (two-sided
+// output, |X|^p with p outside {1, 2}, frames that are not 16-byte aligned) so that the generic kernel takes over.
+int try_launch_n4096(const FrameGeom& g, const StftEpilogue& ep, int mode, hipStream_t stream) {
+    if (!ep.onesided || !g.vec4_ok) return TAC_E_UNSUPPORTED;
+    int pmode = -1;
+    if (mode == 0) pmode = 0;
+    else if (ep.power == 2.0f) pmode = ep.db ? 3 : 1;
+    else if (ep.power == 1.0f) pmode = ep.db ? 4 : 2;
+    if (pmode < 0) return TAC_E_UNSUPPORTED;
+    Tables tb1k, tb4k;
+    int rc = get_tables(2048, &tb1k);
+    if (rc != TAC_OK) return rc;
+    rc = get_tables(4096, &tb4k);
+    if (rc != TAC_OK) return rc;
+    switch (pmode) {
+        case 0: return launch_n4096<0>(g, tb1k, tb4k, ep, stream);
+        case 1: return launch_n4096<1>(g, tb1k, tb4k, ep, stream);
+        case 2: return launch_n4096<2>(g, tb1k, tb4k, ep, stream);
+        case 3: return launch_n4096<3>(g, tb1k, tb4k, ep, stream);
+        default: return launch_n4096<4>(g, tb1k, tb4k, ep, stream);
+    }
+}
+
+}  // namespace tac
