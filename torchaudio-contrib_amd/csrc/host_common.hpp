@@ -24,6 +24,18 @@ struct StftEpilogue {
     float log10_ref;
 };
 
+#if defined(__HIPCC__)
+// Real-valued row epilogues of the pipelined STFT kernels: MODE 1 = |X|^2, 2 = |X|, 3 = |X|^2 in dB, 4 = |X| in dB
+// (amplitude_to_db squares its input, functional.py:291-296); 0 = complex rows.  |X| uses the hardware square root
+// (1 ulp): the correctly rounded sequence costs ~10 instructions per bin.
+template <int MODE>
+__device__ __forceinline__ float spectral_row_value(float norm2, const StftEpilogue& ep) {
+    float v = (MODE == 2 || MODE == 4) ? __builtin_amdgcn_sqrtf(norm2) : norm2;
+    if constexpr (MODE >= 3) v = amp_to_db(v, ep.amin, ep.log10_ref);
+    return v;
+}
+#endif
+
 
 extern thread_local int g_last_hip_error;
 

@@ -284,16 +284,6 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 // Here the NEXT frame's samples are requested before the current frame's stores, every store is unconditional
 // (clamped duplicate lanes instead of predication) so the compiler can wait with an exact vmcnt(#stores) while
 // the stores drain behind the next frame's butterflies, and the window comes from LDS (lgkmcnt, not vmcnt).
-// Real-valued row epilogues of the pipelined kernel: MODE 1 = |X|^2, 2 = |X|, 3 = |X|^2 in dB, 4 = |X| in dB
-// (amplitude_to_db squares its input, functional.py:291-296).  0 = complex rows.
-template <int MODE>
-__device__ __forceinline__ float pipe_row_value(float norm2, const StftEpilogue& ep) {
-    // |X|: the hardware square root (1 ulp) — the correctly rounded sequence costs ~10 instructions per bin
-    float v = (MODE == 2 || MODE == 4) ? __builtin_amdgcn_sqrtf(norm2) : norm2;
-    if constexpr (MODE >= 3) v = amp_to_db(v, ep.amin, ep.log10_ref);
-    return v;
-}
-
 // LEAN: the lane-dependent twiddles live in LDS (one conflict-free 144-byte row per lane, read where they are used)
 // and the R2C twiddles are one register x compile-time constants, which fits the kernel into 168 registers = three
 // waves per SIMD (three 4-wave workgroups per CU) instead of two.
@@ -470,13 +460,13 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
                     reinterpret_cast<cf*>(stage)[k] = xa[i];
                     reinterpret_cast<cf*>(stage)[NC - k] = xb[i];
                 } else {
-                    stage[k] = pipe_row_value<MODE>(cnorm2(xa[i]), ep);
-                    stage[NC - k] = pipe_row_value<MODE>(cnorm2(xb[i]), ep);
+                    stage[k] = spectral_row_value<MODE>(cnorm2(xa[i]), ep);
+                    stage[NC - k] = spectral_row_value<MODE>(cnorm2(xb[i]), ep);
                 }
             }
             if (t == 0) {
                 if constexpr (MODE == 0) reinterpret_cast<cf*>(stage)[NC / 2] = xm;
-                else stage[NC / 2] = pipe_row_value<MODE>(cnorm2(xm), ep);
+                else stage[NC / 2] = spectral_row_value<MODE>(cnorm2(xm), ep);
             }
             wave_lds_fence();
         }
@@ -638,6 +628,10 @@ static int launch_stft(const FrameGeom& g, const Tables& tb, const StftEpilogue&
 #define TAC_N4096_TWO_HALF 1   // 0: A/B knob, fft_length = 4096 always takes the generic 32-elements-per-lane kernel
 #endif
 int try_launch_n4096(const FrameGeom& g, const StftEpilogue& ep, int mode, hipStream_t stream);
+#ifndef TAC_STFT_SMALL_PIPE
+#define TAC_STFT_SMALL_PIPE 1  // 0: A/B knob, fft_length 512 / 1024 always take the generic kernel
+#endif
+int try_launch_small(int n_fft, const FrameGeom& g, const Tables& tb, const StftEpilogue& ep, int mode, hipStream_t stream);
 
 template <int MODE>
 static int dispatch_stft(int n_fft, const FrameGeom& g, const Tables& tb, const StftEpilogue& ep, hipStream_t s) {
@@ -646,8 +640,14 @@ static int dispatch_stft(int n_fft, const FrameGeom& g, const Tables& tb, const 
         case 64: return launch_stft<32, 16, MODE>(g, tb, ep, s);
         case 128: return launch_stft<64, 16, MODE>(g, tb, ep, s);
         case 256: return launch_stft<128, 16, MODE>(g, tb, ep, s);
-        case 512: return launch_stft<256, 16, MODE>(g, tb, ep, s);
-        case 1024: return launch_stft<512, 16, MODE>(g, tb, ep, s);
+        case 512:
+        case 1024: {
+#if TAC_STFT_SMALL_PIPE
+            const int rc = try_launch_small(n_fft, g, tb, ep, MODE, s);     // stft_small.hip: plain epilogues
+            if (rc != TAC_E_UNSUPPORTED) return rc;
+#endif
+            return n_fft == 512 ? launch_stft<256, 16, MODE>(g, tb, ep, s) : launch_stft<512, 16, MODE>(g, tb, ep, s);
+        }
         case 2048: return launch_stft<1024, 16, MODE>(g, tb, ep, s);
         case 4096: {
 #if TAC_N4096_TWO_HALF

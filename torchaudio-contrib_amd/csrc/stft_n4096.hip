@@ -41,15 +41,6 @@ __device__ __forceinline__ cf cmul_conj(cf a, cf w) {
 #endif
 }
 
-// real-valued row epilogues: MODE 1 = |X|^2, 2 = |X|, 3 = |X|^2 in dB, 4 = |X| in dB; 0 = complex rows
-template <int MODE>
-__device__ __forceinline__ float n4k_row_value(float norm2, const StftEpilogue& ep) {
-    // |X|: the hardware square root (1 ulp) — the correctly rounded sequence costs ~10 instructions per bin
-    float v = (MODE == 2 || MODE == 4) ? __builtin_amdgcn_sqrtf(norm2) : norm2;
-    if constexpr (MODE >= 3) v = amp_to_db(v, ep.amin, ep.log10_ref);
-    return v;
-}
-
 template <int MODE>
 __global__ void __launch_bounds__(N4K_WAVES * 64, 2)
 stft_n4096_kernel(FrameGeom g, Tables tb1k, Tables tb4k, StftEpilogue ep) {
@@ -185,13 +176,13 @@ stft_n4096_kernel(FrameGeom g, Tables tb1k, Tables tb4k, StftEpilogue ep) {
                     reinterpret_cast<cf*>(stage)[k] = xa[i];
                     reinterpret_cast<cf*>(stage)[2048 - k] = xb[i];
                 } else {
-                    stage[k] = n4k_row_value<MODE>(cnorm2(xa[i]), ep);
-                    stage[2048 - k] = n4k_row_value<MODE>(cnorm2(xb[i]), ep);
+                    stage[k] = spectral_row_value<MODE>(cnorm2(xa[i]), ep);
+                    stage[2048 - k] = spectral_row_value<MODE>(cnorm2(xb[i]), ep);
                 }
             }
             if (t == 0) {
                 if constexpr (MODE == 0) reinterpret_cast<cf*>(stage)[1024] = xm;
-                else stage[1024] = n4k_row_value<MODE>(cnorm2(xm), ep);
+                else stage[1024] = spectral_row_value<MODE>(cnorm2(xm), ep);
             }
             wave_lds_fence();
         }

@@ -1,0 +1,207 @@
+// stft_small.hip — the software-pipelined STFT / spectrogram kernel for fft_length 512 and 1024, where a wave
+// holds G = 4 or 2 frames (LPF = 16 or 32 lanes each, 16 complex elements per lane).
+//
+// Same recipe as stft_pipe_kernel (stft_kernels.hip): the NEXT unit's samples are requested before the current
+// unit's rows are stored, every store is unconditional and nontemporal (so the wait for the samples is an exact
+// vmcnt), the window comes from LDS, and the R2C split exchanges only the upper half of each spectrum.  A unit is
+// G consecutive frames of one row, so its G output rows are adjacent in memory and leave as ONE contiguous run of
+// 16-byte stores; a unit with frames in the padding, or past the end of its row, takes the gather path and clamps
+// its run to the live rows.
+#include "host_common.hpp"
+
+namespace tac {
+
+constexpr int SM_WAVES = 4;
+typedef float sm_f4 __attribute__((ext_vector_type(4)));
+
+template <int NC, int MODE>
+__global__ void __launch_bounds__(SM_WAVES * 64, 2)
+stft_small_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
+    constexpr int E = 16;
+    using F = WaveFft<NC, E>;
+    constexpr int LPF = F::LPF, G = F::G;
+    static_assert(G >= 2 && radix_at(NC, 0) == E, "several frames per wave, one first-pass butterfly per lane");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf* smem = reinterpret_cast<cf*>(smem_raw);
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sub = lane / LPF, t = lane % LPF;
+    constexpr int WAVE_SLOTS = ((G * F::PADDED + 1) / 2) * 2;
+    cf* const wbase = smem + w * WAVE_SLOTS;
+    cf* const lds = wbase + sub * F::PADDED;
+    // window pairs, one 144-byte row per first-pass column (8 conflict-free ds_read_b128 per lane)
+    constexpr int WROW = E + 2;
+    cf* const wlds = smem + SM_WAVES * WAVE_SLOTS;
+    for (int m = threadIdx.x; m < NC; m += SM_WAVES * 64) wlds[(m % LPF) * WROW + (m / LPF)] = window_pair(g, m);
+
+    cf tw[F::NTW];
+    cf ptw[F::NPAIR];
+    F::load_twiddles(tw, tb.w_nc, t);
+#pragma unroll
+    for (int i = 0; i < F::NPAIR; ++i) ptw[i] = tb.w_n[t + i * LPF];
+
+    const int T = (int)g.n_frames;
+    const int upr = (T + G - 1) / G;                       // units per row
+    const int total = (int)g.rows * upr;
+    const int chunk = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int begin = (int)blockIdx.x * chunk;
+    const int end = begin + chunk < total ? begin + chunk : total;
+    constexpr int LENF = (MODE == 0 ? 2 : 1) * (NC + 1);
+    constexpr int NST = (((G * LENF) >> 2) + 63) / 64;    // 16-byte wave-stores per unit
+    const float hscale = 0.5f * g.scale;                  // the R2C split returns 2·X
+
+    cf raw[E];
+    // every lane group requests its own frame; the unit takes the fast path only if ALL its frames are interior
+    auto prefetch = [&](int unit) -> bool {
+        const int urow = unit / upr;
+        const int frame = (unit - urow * upr) * G + sub;
+        const long long start = (long long)frame * g.hop - g.center_pad;
+        const bool ok = g.vec2_ok && frame < T && start >= 0 && start + F::N <= g.length;
+        const bool all_ok = __builtin_amdgcn_ballot_w64(ok) == ~0ull;
+        if (all_ok) {
+            const cf* src = reinterpret_cast<const cf*>(g.wave + (long long)urow * g.row_stride + start);
+#pragma unroll
+            for (int q = 0; q < E; ++q) raw[q] = src[t + q * LPF];
+        }
+        return all_ok;
+    };
+    bool pre = false;
+    int unit = begin + w;
+    if (unit < end) pre = prefetch(unit);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): the loop is entered with nothing in flight
+    __syncthreads();
+
+    NoStamp st;
+    for (; unit < end; unit += SM_WAVES) {
+        const int urow = unit / upr;
+        const int uframe0 = (unit - urow * upr) * G;
+        cf v[1][E];
+        cf* const ldsv[1] = {lds};
+        if (pre) {
+            const sm_f4* wp = reinterpret_cast<const sm_f4*>(wlds + t * WROW);
+            sm_f4 wv[E / 2];
+#pragma unroll
+            for (int i = 0; i < E / 2; ++i) wv[i] = wp[i];
+#pragma unroll
+            for (int i = 0; i < E / 2; ++i) {
+                v[0][2 * i] = cmul_elem(raw[2 * i], mkc(wv[i].x, wv[i].y));
+                v[0][2 * i + 1] = cmul_elem(raw[2 * i + 1], mkc(wv[i].z, wv[i].w));
+            }
+        } else {
+            load_frame<F, false>(v[0], g, nullptr, lds, urow, uframe0 + sub, t);    // padding / past-the-end frames
+        }
+        F::template run<1, NoStamp, true>(v, ldsv, tw, t, st, t);                    // lower-half spectrum stays in registers
+
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const int nxt = unit + SM_WAVES;
+            pre = false;
+            if (nxt < end) pre = prefetch(nxt);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        const long long g0 = ((long long)urow * T + uframe0) * LENF;
+        const int a = (int)(g0 & 3);
+        float* const stage = reinterpret_cast<float*>(wbase) + a;        // LDS and global share their 16-byte phase
+        float* const srow = stage + sub * LENF;
+        {
+            cf xa[F::NPAIR], xb[F::NPAIR], xm, unused;
+#pragma unroll
+            for (int i = 0; i < F::NPAIR; ++i) {
+                const int k = t + i * LPF;
+                const cf zk = v[0][F::reg_of_spectrum(i)];
+                const cf zm = (i == 0) ? F::r2c_partner(lds, k, zk) : lds[lds_pad(NC - k)];
+                F::r2c_split_x2(zk, zm, ptw[i], xa[i], xb[i]);
+                xa[i] = cscale(xa[i], hscale); xb[i] = cscale(xb[i], hscale);
+            }
+            F::r2c_pair(lds, NC / 2, mkc(0.0f, -1.0f), xm, unused);
+            xm = cscale(xm, hscale);
+            wave_lds_fence();                                             // every Z of this unit is in registers
+#pragma unroll
+            for (int i = 0; i < F::NPAIR; ++i) {
+                const int k = t + i * LPF;
+                if constexpr (MODE == 0) {
+                    reinterpret_cast<cf*>(srow)[k] = xa[i];
+                    reinterpret_cast<cf*>(srow)[NC - k] = xb[i];
+                } else {
+                    srow[k] = spectral_row_value<MODE>(cnorm2(xa[i]), ep);
+                    srow[NC - k] = spectral_row_value<MODE>(cnorm2(xb[i]), ep);
+                }
+            }
+            if (t == 0) {
+                if constexpr (MODE == 0) reinterpret_cast<cf*>(srow)[NC / 2] = xm;
+                else srow[NC / 2] = spectral_row_value<MODE>(cnorm2(xm), ep);
+            }
+            wave_lds_fence();
+        }
+        // the unit's live rows leave as 1 + NST + 1 unconditional nontemporal stores (lanes past the end repeat a neighbour)
+        const int nlive = (T - uframe0) < G ? (T - uframe0) : G;
+        const int len = nlive * LENF;
+        float* const gdst = ep.out + g0;
+        const int npre = (4 - a) & 3;
+        const int nchunks = (len - npre) >> 2;
+        {
+            const int hmax = (npre > 1 ? npre : 1) - 1;
+            const int hi = lane < hmax ? lane : hmax;
+            gdst[hi] = stage[hi];
+        }
+        const sm_f4* const s4 = reinterpret_cast<const sm_f4*>(stage + npre);
+        sm_f4* const g4 = reinterpret_cast<sm_f4*>(gdst + npre);
+        const int last = nchunks - 1;
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int c = (lane + 64 * i) < last ? (lane + 64 * i) : last;
+            __builtin_nontemporal_store(s4[c], g4 + c);
+        }
+        {
+            const int r = len - npre - 4 * nchunks;
+            const int rmax = (r > 1 ? r : 1) - 1;
+            const int ti = len - 1 - (lane < rmax ? lane : rmax);
+            gdst[ti] = stage[ti];
+        }
+        wave_lds_fence();   // next iteration's first-pass writes must follow these reads
+    }
+}
+
+template <int NC, int MODE>
+static int launch_small(const FrameGeom& g, const Tables& tb, const StftEpilogue& ep, hipStream_t stream) {
+    using F = WaveFft<NC, 16>;
+    const long long units = g.rows * ((g.n_frames + F::G - 1) / F::G);
+    if (units >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
+    constexpr int WAVE_SLOTS = ((F::G * F::PADDED + 1) / 2) * 2;
+    const size_t bytes = (size_t)SM_WAVES * WAVE_SLOTS * sizeof(cf) + (size_t)F::LPF * 18 * sizeof(cf);
+    long long blocks = (units + SM_WAVES - 1) / SM_WAVES;
+    const long long cap = (long long)device_cu_count() * 2;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((stft_small_kernel<NC, MODE>), dim3((unsigned)blocks), dim3(SM_WAVES * 64), bytes, stream, g, tb, ep);
+    TAC_HIP(hipGetLastError());
+    return TAC_OK;
+}
+
+template <int NC>
+static int launch_small_mode(int pmode, const FrameGeom& g, const Tables& tb, const StftEpilogue& ep, hipStream_t s) {
+    switch (pmode) {
+        case 0: return launch_small<NC, 0>(g, tb, ep, s);
+        case 1: return launch_small<NC, 1>(g, tb, ep, s);
+        case 2: return launch_small<NC, 2>(g, tb, ep, s);
+        case 3: return launch_small<NC, 3>(g, tb, ep, s);
+        default: return launch_small<NC, 4>(g, tb, ep, s);
+    }
+}
+
+// Entry used by stft_kernels.hip's dispatcher (fft_length 512 / 1024): TAC_E_UNSUPPORTED when this form does not
+// apply (two-sided output, |X|^p with p outside {1, 2}) so that the generic kernel takes over.
+int try_launch_small(int n_fft, const FrameGeom& g, const Tables& tb, const StftEpilogue& ep, int mode,
+                     hipStream_t stream) {
+    if (!ep.onesided) return TAC_E_UNSUPPORTED;
+    int pmode = -1;
+    if (mode == 0) pmode = 0;
+    else if (ep.power == 2.0f) pmode = ep.db ? 3 : 1;
+    else if (ep.power == 1.0f) pmode = ep.db ? 4 : 2;
+    if (pmode < 0) return TAC_E_UNSUPPORTED;
+    if (n_fft == 1024) return launch_small_mode<512>(pmode, g, tb, ep, stream);
+    if (n_fft == 512) return launch_small_mode<256>(pmode, g, tb, ep, stream);
+    return TAC_E_UNSUPPORTED;
+}
+
+}  // namespace tac
