@@ -16,10 +16,15 @@ spec4 = tac.Spectrogram(4096, 1024).cuda()
 x5 = torch.rand(256, 1, 160000, device='cuda') * 2 - 1
 stft512, spec512 = tac.STFT(512, 128).cuda(), tac.Spectrogram(512, 128, power=2.).cuda()
 stft1k, spec1k = tac.STFT(1024, 256).cuda(), tac.Spectrogram(1024, 256, power=2.).cuda()
+mel512 = torch.nn.Sequential(*tac.Melspectrogram(num_mels=80, sample_rate=16000, fft_length=512, hop_length=128),
+                             tac.AmplitudeToDb()).cuda()
+mel1k = torch.nn.Sequential(*tac.Melspectrogram(num_mels=80, sample_rate=16000, fft_length=1024, hop_length=256),
+                            tac.AmplitudeToDb()).cuda()
 fns = {'stft': lambda: tac.realize(stft(x)), 'spec': lambda: spec(x), 'mel': lambda: tac.realize(mel(x)),
        'stft4096': lambda: tac.realize(stft4(x4)), 'spec4096': lambda: spec4(x4),
        'stft512': lambda: tac.realize(stft512(x5)), 'spec512': lambda: spec512(x5),
-       'stft1024': lambda: tac.realize(stft1k(x5)), 'spec1024': lambda: spec1k(x5)}
+       'stft1024': lambda: tac.realize(stft1k(x5)), 'spec1024': lambda: spec1k(x5),
+       'mel512': lambda: tac.realize(mel512(x5)), 'mel1024': lambda: tac.realize(mel1k(x5))}
 for name in (sys.argv[1:] or ['stft', 'spec', 'mel']):
     fn = fns[name]
     t0 = time.perf_counter()

@@ -588,15 +588,18 @@ __device__ __forceinline__ bool prefetch_frame_raw(cf* raw, const FrameGeom& g, 
 // edge-frame path and pass 0's output placement.
 __device__ __forceinline__ int frame_col_of_lane(int t, bool vec4) { return vec4 ? (((t & 31) << 1) | (t >> 5)) : t; }
 
+// `frame` is per lane group when several frames share a wave (G > 1): the request is made for all of the wave's
+// frames or for none (wave ballot), so the caller's fast / gather decision stays wave-uniform.
 template <class F>
 __device__ __forceinline__ bool prefetch_frame_raw_x(cf* raw, const FrameGeom& g, long long row, long long frame,
                                                      int t, int col, bool vec4) {
-    static_assert(F::LPF == 64 && radix_at(F::NC, 0) == F::E, "wired for one frame per wave");
+    static_assert(radix_at(F::NC, 0) == F::E, "one first-pass butterfly per lane");
     const long long start = frame * (long long)g.hop - g.center_pad;
-    const bool ok = g.vec2_ok && frame < g.n_frames && start >= 0 && start + F::N <= g.length;
+    bool ok = g.vec2_ok && frame < g.n_frames && start >= 0 && start + F::N <= g.length;
+    if constexpr (F::G > 1) ok = __builtin_amdgcn_ballot_w64(ok) == ~0ull;
     if (ok) {
         const float* base = g.wave + row * g.row_stride + start;
-        if (vec4) {
+        if (vec4 && F::LPF == 64) {
             typedef float f4 __attribute__((ext_vector_type(4)));
             const f4* src = reinterpret_cast<const f4*>(base);
 #pragma unroll
@@ -608,7 +611,7 @@ __device__ __forceinline__ bool prefetch_frame_raw_x(cf* raw, const FrameGeom& g
         } else {
             const cf* src = reinterpret_cast<const cf*>(base);
 #pragma unroll
-            for (int q = 0; q < F::E; ++q) raw[q] = src[col + q * (F::NC / F::E)];
+            for (int q = 0; q < F::E; ++q) raw[q] = src[col + q * F::LPF];
         }
     }
     return ok;

@@ -116,11 +116,11 @@ __device__ __forceinline__ void mel_phase_a(const FrameGeom& g, cf* bufs, const 
 #endif
             st.mark(9);
             if constexpr (PIPE) {
-                static_assert(F::G == 1 && NF == 1, "pipelined phase A is wired for one frame per wave-round");
+                static_assert(NF == 1, "pipelined phase A advances one frame group per wave-round");
                 __builtin_amdgcn_sched_barrier(0);
                 const bool same_tile = rep + 1 < C::GPW;
                 const int nrow = same_tile ? row : next_row;
-                const long long nfi = w * C::GPW + (same_tile ? rep + 1 : 0);
+                const long long nfi = (long long)(w * C::GPW + (same_tile ? rep + 1 : 0)) * F::G + sub;
                 const long long nframe = (same_tile ? f0 : next_f0) + nfi;
                 pre_ok = false;
                 if ((same_tile || next_f0 >= 0) && nfi < TILE)

@@ -180,8 +180,8 @@ melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
     for (int i = tid; i < m.wtot; i += WAVES * 64) wlds[i] = m.wpack[i];
     for (int i = tid; i < WAVES * 4 * m.dstride; i += WAVES * 64) dlds[i] = m.desc[i];
 
-    constexpr bool PIPE = (F::G == 1) && (TAC_SP_PIPE != 0);
-    constexpr bool v4 = PIPE && V4;                       // frames fetched with 16-byte requests (fft_core.hpp)
+    constexpr bool PIPE = (TAC_SP_PIPE != 0);
+    constexpr bool v4 = PIPE && V4 && (F::G == 1);                       // frames fetched with 16-byte requests (fft_core.hpp)
     const int tcol = frame_col_of_lane(t, v4);
     MelFftConsts<F, TAC_SP_HOISTW != 0, (TAC_SP_FACT != 0) && (TAC_SP_PIPE != 0)> fftk;
     fftk.load(tb, g, t, tcol);
@@ -212,7 +212,7 @@ melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
     if constexpr (PREFETCH || PIPE) {
         if (begin < end) {
             const int r0 = begin / tiles_per_row;
-            const long long fr0 = (long long)(begin - r0 * tiles_per_row) * TILE + w * C::GPW;
+            const long long fr0 = (long long)(begin - r0 * tiles_per_row) * TILE + (long long)w * C::GPW * F::G + sub;
             if constexpr (PIPE) pre_ok = prefetch_frame_raw_x<F>(raw, g, r0, fr0, t, tcol, v4);
             else pre_ok = prefetch_frame_raw<F>(raw, g, r0, fr0, t);
         }
