@@ -124,6 +124,15 @@ int tac_apply_filterbank_f32(const float* spec, int64_t rows, int32_t n_freqs, i
                              const float* fb, const int32_t* fb_plan, int32_t n_mels,
                              float* out, void* stream);
 
+/* (4b) functional.apply_filterbank for a frame-major spectrogram (the bins of a frame contiguous, frames stride_t
+ *      floats apart — the layout the kernels of this library write) and a band-sparse bank packed with
+ *      tac_melbank_pack(fb, n_freqs, n_mels, n_fft = 0, ...): streams the spectrogram once and runs the fused
+ *      kernel's contraction.  out: frame-major [rows][n_frames][n_mels]. */
+int tac_apply_filterbank_sparse_f32(const float* spec, int64_t rows, int32_t n_freqs, int64_t n_frames,
+                                    int64_t stride_r, int64_t stride_t, const float* wpack,
+                                    const int32_t* desc, const int32_t* info_host, int32_t n_mels,
+                                    float* out, void* stream);
+
 /* (5) functional.complex_norm, functional.py:116-128: out[i] = |(x[2i], x[2i+1])|^power. */
 int tac_complex_norm_f32(const float* x, int64_t n, float power, float* out, void* stream);
 

@@ -291,6 +291,24 @@ def test_apply_filterbank_mel_sparse_plan(tac):
     assert rel_err(got, want) < 1e-5
 
 
+def test_apply_filterbank_streams_frame_major_spectrograms(tac):
+    """apply_filterbank on the strided (…, F, T) views the spectrogram kernels return takes the band-sparse streaming
+    kernel (packed rows fetched as 16-byte chunks): ragged last tiles, a frame count that leaves a chunk straddling
+    the row end, batches, band counts that are not multiples of four, and a sliced (non-packed) frame stride."""
+    for n_fft, hop, n_mels, length, rows in ((2048, 512, 128, 30000, (3, 1)), (1024, 256, 40, 7777, (2, 2)),
+                                              (512, 160, 13, 5000, (5,)), (2048, 512, 80, 160000, (4, 1))):
+        x = signals.uniform(rows + (length,), seed=91 + n_mels)
+        spec = tac.Spectrogram(n_fft, hop, power=2.).cuda()(dev(x))
+        assert spec.stride(-2) == 1                                   # frame-major view
+        fb = tac.create_mel_filter(n_fft // 2 + 1, n_mels, 0.0, 8000.0, bool(n_mels % 2)).cuda()
+        got = host(tac.apply_filterbank(spec, fb))
+        want = np.einsum('...ft,fm->...mt', host(spec).astype(np.float64), fb.cpu().numpy().astype(np.float64))
+        assert got.shape == want.shape and rel_err(got, want) < 1e-5, (n_fft, n_mels)
+        sliced = spec[..., 1:-2]                                      # frame stride != F*... still frame-major rows
+        got2 = host(tac.apply_filterbank(sliced, fb))
+        assert rel_err(got2, want[..., 1:-2]) < 1e-5, (n_fft, n_mels)
+
+
 @pytest.mark.parametrize('path', ['sparse', 'mfma'])
 def test_fused_kernels_on_custom_filterbanks(tac, path, monkeypatch):
     """Both fused contraction forms against float64 on banks that stress the packing: a band with no support, a band

@@ -1,0 +1,43 @@
+#!/usr/bin/env python
+"""Steady-state timings of the standalone kernels (not on the fused path) at cfg-2 / cfg-5 sizes, with the bytes each
+must move and the resulting fraction of the 8 TB/s HBM peak."""
+import math, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torchaudio_contrib_amd as tac
+
+
+def steady(fn, n=60):
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.4:
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in ev)
+    return ts[n // 2]
+
+
+x = torch.rand(256, 1, 160000, device='cuda') * 2 - 1
+z = tac.realize(tac.STFT(2048, 512).cuda()(x))                      # (256,1,1025,313,2) strided view
+p = tac.Spectrogram(2048, 512, power=2.).cuda()(x)                  # (256,1,1025,313)
+fb = tac.create_mel_filter(1025, 128, 0.0, 8000.0, False).cuda()
+adv = torch.linspace(0, math.pi * 512, 1025)[..., None].cuda()
+xm = torch.rand(1024, 1, 120000, device='cuda') * 2 - 1
+codes = tac.mu_law_encoding(xm, 256)
+cases = [
+    ('complex_norm (power 2)', lambda: tac.complex_norm(z, 2.0), z.numel() * 4 + z.numel() * 2),
+    ('magphase', lambda: tac.magphase(z, 1.0), z.numel() * 4 + z.numel() * 4),
+    ('apply_filterbank 1025x128', lambda: tac.apply_filterbank(p, fb), p.numel() * 4 + p.numel() // 1025 * 128 * 4),
+    ('amplitude_to_db', lambda: tac.amplitude_to_db(p), p.numel() * 8),
+    ('db_to_amplitude', lambda: tac.db_to_amplitude(p), p.numel() * 8),
+    ('phase_vocoder rate 1.3', lambda: tac.phase_vocoder(z, 1.3, adv), z.numel() * 4 + int(z.numel() / 1.3) * 4),
+    ('mu_law_encoding (cfg-5)', lambda: tac.mu_law_encoding(xm, 256), xm.numel() * 12),
+    ('mu_law_decoding (cfg-5)', lambda: tac.mu_law_decoding(codes, 256), xm.numel() * 12),
+]
+for name, fn, nbytes in cases:
+    ms = steady(fn)
+    print('%-28s %.4f ms   %7.1f MB   %5.2f TB/s  (%.0f %% of 8 TB/s)' % (name, ms, nbytes / 1e6, nbytes / ms / 1e9, 100 * nbytes / ms / 1e9 / 8))

@@ -358,6 +358,127 @@ melspec_sparse_split_kernel(FrameGeom g, Tables tb, SparseArgs m) {
     }
 }
 
+// ---------------------------------------------------------------- standalone band-sparse filterbank
+// functional.apply_filterbank (functional.py:172-184) for a frame-major spectrogram (bins of a frame contiguous: the
+// layout every kernel of this library writes) and a band-sparse bank: the fused kernel with phase A replaced by
+// "load 16 rows": an 8-wave workgroup holds 16 frames' rows in LDS, runs the same contraction (phase B) and epilogue
+// (phase C).  The next tile's rows are requested into registers before this tile's contraction and written to LDS
+// after it, so the kernel streams: spectrogram in (4·F bytes per frame), bands out.
+constexpr int FBS_WAVES = 8, FBS_TILE = 16, FBS_CHUNKS = 9;       // 9 x 512 16-byte chunks per tile: up to 1152 bins per frame
+
+__global__ void __launch_bounds__(FBS_WAVES * 64, 2)
+fb_sparse_kernel(const float* __restrict__ spec, long long rows, int n_freqs, long long n_frames, long long stride_r,
+                 long long stride_t, int prow_stride, SparseArgs m) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* ptile = reinterpret_cast<float*>(smem_raw);                            // [16][prow_stride]
+    float* wlds = ptile + FBS_TILE * prow_stride;
+    const int ostr = sparse_ostr(m.n_mels, m.out_vec4);
+    float* otile = wlds + m.wtot;
+    int* dlds = reinterpret_cast<int*>(otile + ((FBS_TILE * ostr + 3) & ~3));
+    const int tid = threadIdx.x;
+    for (int i = tid; i < m.wtot; i += FBS_WAVES * 64) wlds[i] = m.wpack[i];
+    for (int i = tid; i < FBS_WAVES * 4 * m.dstride; i += FBS_WAVES * 64) dlds[i] = m.desc[i];
+
+    FrameGeom g{};                                        // phase C only needs the frame count
+    g.n_frames = n_frames;
+    const int tiles_per_row = (int)((n_frames + FBS_TILE - 1) / FBS_TILE);
+    const int total_tiles = (int)rows * tiles_per_row;
+    const int chunk = (total_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int begin = (int)blockIdx.x * chunk;
+    const int end = begin + chunk < total_tiles ? begin + chunk : total_tiles;
+    const int fr = tid & 15;
+    const int* dg = dlds + (tid >> 4) * m.dstride;
+    const float* prow = ptile + fr * prow_stride;
+
+    // A tile's 16 rows are one contiguous span of 16*F floats when the frames are packed (stride_t == F, the layout
+    // the spectrogram kernels write): it is fetched as 16-byte chunks (global loads only need dword alignment) and
+    // scattered into the padded LDS rows; other frame strides fetch row by row.  Chunks past the end of the batch
+    // row are clamped (and zeroed at deposit time).
+    const bool packed = (stride_t == n_freqs);
+    typedef float fbs_f4 __attribute__((ext_vector_type(4)));
+    fbs_f4 nxt[FBS_CHUNKS];
+    auto request = [&](int tile) {
+        const int row = tile / tiles_per_row;
+        const long long f0 = (long long)(tile - row * tiles_per_row) * FBS_TILE;
+        const float* base = spec + row * stride_r;
+        const long long row_floats = packed ? n_frames * n_freqs : 0;
+#pragma unroll
+        for (int j = 0; j < FBS_CHUNKS; ++j) {
+            const int c = tid + FBS_WAVES * 64 * j;                      // chunk of the tile's span
+            if (packed) {
+                const long long e = f0 * n_freqs + 4LL * c;              // first element, relative to the batch row
+                if (e + 4 <= row_floats) {
+                    nxt[j] = *reinterpret_cast<const fbs_f4*>(base + e);
+                } else {                                                 // the one chunk that straddles the row's end, and
+                    fbs_f4 v;                                            // the dead ones behind it (zeroed at deposit)
+                    const long long lastel = row_floats - 1;
+                    v.x = base[e < lastel ? e : lastel];
+                    v.y = base[e + 1 < lastel ? e + 1 : lastel];
+                    v.z = base[e + 2 < lastel ? e + 2 : lastel];
+                    v.w = base[e + 3 < lastel ? e + 3 : lastel];
+                    nxt[j] = v;
+                }
+            } else {
+                // generic frame stride: chunk c covers bins 4*(c % q4r) .. of frame c / q4r, q4r chunks per row
+                const int q4r = (n_freqs + 3) >> 2;
+                const int fi = c / q4r, b0 = 4 * (c - fi * q4r);
+                long long frame = f0 + fi;
+                frame = frame < n_frames ? frame : n_frames - 1;
+                const float* src = base + frame * stride_t;
+                fbs_f4 v;
+                v.x = src[b0 < n_freqs ? b0 : n_freqs - 1];
+                v.y = src[b0 + 1 < n_freqs ? b0 + 1 : n_freqs - 1];
+                v.z = src[b0 + 2 < n_freqs ? b0 + 2 : n_freqs - 1];
+                v.w = src[b0 + 3 < n_freqs ? b0 + 3 : n_freqs - 1];
+                nxt[j] = v;
+            }
+        }
+    };
+    auto deposit = [&](int tile) {
+        const int row = tile / tiles_per_row;
+        const long long f0 = (long long)(tile - row * tiles_per_row) * FBS_TILE;
+        const int live = (int)((n_frames - f0) < FBS_TILE ? (n_frames - f0) : FBS_TILE);
+#pragma unroll
+        for (int j = 0; j < FBS_CHUNKS; ++j) {
+            const int c = tid + FBS_WAVES * 64 * j;
+            int fi, bin;
+            if (packed) {
+                fi = (4 * c) / n_freqs;
+                bin = 4 * c - fi * n_freqs;
+            } else {
+                const int q4r = (n_freqs + 3) >> 2;
+                fi = c / q4r;
+                bin = 4 * (c - fi * q4r);
+            }
+            const float vals[4] = {nxt[j].x, nxt[j].y, nxt[j].z, nxt[j].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (packed && bin >= n_freqs) { bin -= n_freqs; ++fi; }
+                if (fi < FBS_TILE && bin < n_freqs) ptile[fi * prow_stride + bin] = fi < live ? vals[i] : 0.0f;
+                ++bin;
+            }
+        }
+    };
+    // the contraction's 8-tap trips may read up to 7 bins past the row: zero them once
+    for (int i = tid; i < FBS_TILE * 8; i += FBS_WAVES * 64) {
+        const int col = n_freqs + (i & 7);
+        if (col < prow_stride) ptile[(i >> 3) * prow_stride + col] = 0.0f;
+    }
+    if (begin < end) request(begin);
+    for (int tile = begin; tile < end; ++tile) {
+        const int row = tile / tiles_per_row;
+        const long long f0 = (long long)(tile - row * tiles_per_row) * FBS_TILE;
+        deposit(tile);                                         // rows of this tile (requested during the previous one)
+        __syncthreads();
+        if (tile + 1 < end) request(tile + 1);            // in flight during the contraction
+        sparse_phase_b(dg, prow, wlds, otile + fr * ostr);
+        __syncthreads();
+        sparse_phase_c<FBS_WAVES * 64>(otile, ostr, tid, FBS_TILE, m, g, row, f0);
+        // the barrier after the next deposit orders these otile reads before the next contraction's writes, and the
+        // barrier above ordered this contraction's row reads before the next deposit
+    }
+}
+
 template <int NC, int E>
 static int sparse_groups() { return MelCfg<NC, E, SP_TILE>::WAVES * 4; }
 
@@ -433,8 +554,9 @@ int tac_melbank_pack(const float* fb, int32_t n_freqs, int32_t n_mels, int32_t n
                      int32_t wpack_cap, int32_t* desc, int32_t desc_cap, int32_t* info_host, void* stream) {
     using namespace tac;
     if (!fb || !wpack || !desc || !info_host || n_freqs <= 0 || n_mels <= 0) return TAC_E_INVALID;
-    const int groups = sparse_groups_for(n_fft);
-    if (groups == 0 || n_freqs != n_fft / 2 + 1) return TAC_E_UNSUPPORTED;
+    // n_fft == 0: pack for the standalone filterbank kernel (32 lane groups, any number of bins)
+    const int groups = n_fft == 0 ? FBS_WAVES * 4 : sparse_groups_for(n_fft);
+    if (groups == 0 || (n_fft != 0 && n_freqs != n_fft / 2 + 1)) return TAC_E_UNSUPPORTED;
     std::vector<float> h((size_t)n_freqs * n_mels);
     TAC_HIP(hipMemcpyAsync(h.data(), fb, h.size() * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
     TAC_HIP(hipStreamSynchronize((hipStream_t)stream));
@@ -520,6 +642,42 @@ int tac_melspec_sparse_f32(const float* wave, const float* window, const tac_stf
         case 2048: return launch_sparse<1024, 16>(g, tb, m, power, s);
         default: return TAC_E_UNSUPPORTED;
     }
+}
+
+int tac_apply_filterbank_sparse_f32(const float* spec, int64_t rows, int32_t n_freqs, int64_t n_frames,
+                                    int64_t stride_r, int64_t stride_t, const float* wpack, const int32_t* desc,
+                                    const int32_t* info_host, int32_t n_mels, float* out, void* stream) {
+    using namespace tac;
+    if (rows == 0 || n_frames == 0) return TAC_OK;
+    if (!spec || !wpack || !desc || !info_host || !out) return TAC_E_INVALID;
+    if (rows < 0 || n_freqs <= 0 || n_frames < 0 || n_mels <= 0) return TAC_E_INVALID;
+    if (info_host[2] != FBS_WAVES * 4) return TAC_E_INVALID;                       // pack built for another geometry
+    if ((long long)FBS_TILE * ((n_freqs + 3) / 4) > (long long)FBS_CHUNKS * FBS_WAVES * 64) return TAC_E_UNSUPPORTED;
+    int prow = n_freqs + 7;
+    prow += (34 - (prow & 31)) & 31;                                               // == 2 (mod 32): conflict-free, 8-byte rows
+    const int out_vec4 = ((n_mels & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0);
+    SparseArgs m{wpack, desc, info_host[0], info_host[1], n_mels, 0, 0.0f, 0.0f, out, out_vec4};
+    const int ostr = sparse_ostr(n_mels, out_vec4);
+    const size_t lds_bytes = (size_t)FBS_TILE * prow * 4 + (size_t)m.wtot * 4 + (size_t)((FBS_TILE * ostr + 3) & ~3) * 4 +
+                             (size_t)FBS_WAVES * 4 * m.dstride * 4;
+    if (lds_bytes > 160 * 1024) return TAC_E_UNSUPPORTED;
+    const long long tiles = rows * ((n_frames + FBS_TILE - 1) / FBS_TILE);
+    if (tiles >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
+    int per_cu = (int)(160 * 1024 / lds_bytes);
+    if (per_cu > 2) per_cu = 2;
+    long long blocks = (long long)device_cu_count() * per_cu;
+    if (blocks > tiles) blocks = tiles;
+    static bool attr_set = false;
+    if (!attr_set) {
+        TAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fb_sparse_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(fb_sparse_kernel, dim3((unsigned)blocks), dim3(FBS_WAVES * 64), lds_bytes, (hipStream_t)stream, spec,
+                       (long long)rows, (int)n_freqs, (long long)n_frames, (long long)stride_r, (long long)stride_t, prow,
+                       m);
+    TAC_HIP(hipGetLastError());
+    return TAC_OK;
 }
 
 }  // extern "C"

@@ -392,6 +392,19 @@ def apply_filterbank(mag_specgrams, filterbank):
     out = torch.empty(lead + (n_frames, n_mels), dtype=torch.float32, device=spec.device)
     if out.numel():
         rows = spec.reshape(-1, n_freqs, n_frames)
+        # frame-major spectrogram (what the kernels here produce) + band-sparse bank: stream it through the fused
+        # kernel's contraction; anything else goes through the fp32 MFMA GEMM
+        pack = _melbank_pack(fb, 0) if (rows.stride(1) == 1 and _MEL_PATH != 'mfma') else None
+        if pack is not None:
+            wpack, desc, info = pack
+            with torch.cuda.device(spec.device):
+                rc = _native.lib().tac_apply_filterbank_sparse_f32(
+                    _native.ptr(rows), rows.shape[0], n_freqs, n_frames, rows.stride(0) if rows.shape[0] > 1 else 0,
+                    rows.stride(2), _native.ptr(wpack), _native.ptr(desc), ctypes.cast(info, ctypes.c_void_p), n_mels,
+                    _native.ptr(out), _native.stream_ptr(spec.device))
+            if rc != _native.TAC_E_UNSUPPORTED:
+                _native.check(rc, 'tac_apply_filterbank_sparse_f32')
+                return out.transpose(-2, -1)
         plan, _ = _filterbank_plan(fb)
         with torch.cuda.device(spec.device):
             rc = _native.lib().tac_apply_filterbank_f32(
