@@ -190,6 +190,21 @@ def main():
             gbs = BATCH * CHANNELS * FRAMES * per_frame / (ms * 1e-3) / 1e9
             stages[name] = {'kernel_ms_mean': ms, 'kernel_ms_median': med, 'alg_bytes_per_frame': per_frame,
                             'achieved_GBs': gbs, 'frac_of_hbm_peak': gbs / HBM_PEAK_GBS}
+        # the filterbank stage as a dense fp32 MFMA GEMM (a random 1025 x 128 bank is not band-sparse, so
+        # apply_filterbank takes the GEMM kernel): executed flops = 2*F*M per frame against the 157.3 TFLOP/s f32 MFMA peak
+        fb_dense = torch.rand(f_bins, N_MELS, device=dev, generator=gen)
+        p_spec = spec(x)
+        fn = lambda: tac.apply_filterbank(p_spec, fb_dense)
+        t_w = time.perf_counter()
+        while time.perf_counter() - t_w < 0.3:
+            for _ in range(10):
+                fn()
+            torch.cuda.synchronize()
+        ms, med = event_ms(fn, 50)
+        flops = 2.0 * f_bins * N_MELS * BATCH * CHANNELS * FRAMES
+        stages['filterbank_mfma_dense'] = {'kernel_ms_mean': ms, 'kernel_ms_median': med, 'flops': flops,
+                                           'achieved_TFLOPs': flops / (ms * 1e-3) / 1e12,
+                                           'frac_of_f32_mfma_peak': flops / (ms * 1e-3) / 1e12 / 157.3}
         result['stages'] = stages
 
     if distributed:
