@@ -64,6 +64,10 @@ out.append('`bench.py` on the same box, HIP events on the launch stream, un-prof
            % (r['kernel_ms_mean'], r['kernel_ms_median'], r['achieved'], 100 * r['frac'],
               bench['stages']['stft_complex']['kernel_ms_median'], 100 * bench['stages']['stft_complex']['frac_of_hbm_peak'],
               bench['stages']['spectrogram_power']['kernel_ms_median'], 100 * bench['stages']['spectrogram_power']['frac_of_hbm_peak']))
+fm = bench.get('stages', {}).get('filterbank_mfma_dense')
+if fm:
+    out.append('Filterbank stage as a dense fp32 MFMA GEMM (`gemm_fb_kernel`, random 1025 x 128 bank, cfg-2 power spectrogram): '
+               '%.4f ms = %.1f TFLOP/s = %.0f %% of the 157.3 TFLOP/s f32 MFMA peak.' % (fm['kernel_ms_mean'], fm['achieved_TFLOPs'], 100 * fm['frac_of_f32_mfma_peak']))
 out.append('')
 out.append('Counters per launch (per frame = / 80 128):')
 out.append('')
