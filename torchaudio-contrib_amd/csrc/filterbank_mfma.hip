@@ -163,6 +163,12 @@ int tac_apply_filterbank_f32(const float* spec, int64_t rows, int32_t n_freqs, i
     using namespace tac;
     if (!spec || !fb || !out) return TAC_E_INVALID;
     if (rows <= 0 || n_freqs <= 0 || n_frames <= 0 || n_mels <= 0) return TAC_E_INVALID;
+    // rows whose frames continue each other in memory (the frame-major tensors the kernels here write) are one long
+    // run of frames: no partly filled 128-frame tile at the end of every row (313 frames per row: 18 % fewer tiles)
+    if (rows > 1 && stride_r == n_frames * stride_t) {
+        n_frames *= rows;
+        rows = 1;
+    }
     const long long frame_tiles = (n_frames + GM_TM - 1) / GM_TM;
     const int col_tiles = (n_mels + GM_TN - 1) / GM_TN;
     const long long blocks = rows * frame_tiles * col_tiles;
