@@ -20,8 +20,11 @@ namespace tac {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float gm_f4 __attribute__((ext_vector_type(4)));
 
-constexpr int GM_TM = 128, GM_TN = 128, GM_KC = 32, GM_LD = 132;
+constexpr int GM_TN = 128, GM_KC = 32, GM_LD = 132;
 
+// TM = frames per workgroup: 128 (each wave a 64 x 64 quadrant) or 64 (each wave 32 x 64) — the smaller tile halves
+// the work quantum when a problem is only a few tiles per CU (cfg-2: 2.4 tiles of 128 per CU, i.e. 3 rounds for 2.4)
+template <int GM_TM>
 __global__ void __launch_bounds__(256, 2)
 gemm_fb_kernel(const float* __restrict__ spec, long long stride_r, long long stride_f, long long stride_t, int n_freqs,
                long long n_frames, long long frame_tiles, int col_tiles, const float* __restrict__ fb,
@@ -31,7 +34,8 @@ gemm_fb_kernel(const float* __restrict__ spec, long long stride_r, long long str
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = w >> 1, wn = w & 1;                                          // the wave's 64 x 64 quadrant
+    constexpr int MI = GM_TM / 64;                                              // 32-row MFMA tiles per wave along M
+    const int wm = w >> 1, wn = w & 1;                                          // the wave's (32*MI) x 64 quadrant
     long long bid = blockIdx.x;
     const int ct = (int)(bid % col_tiles);
     bid /= col_tiles;
@@ -57,16 +61,17 @@ gemm_fb_kernel(const float* __restrict__ spec, long long stride_r, long long str
     }
 
     // global -> register staging of one chunk: A as 4 x (4 consecutive k of one frame), B as 4 x (4 consecutive columns)
-    const int a_i = tid & 127, a_kq = tid >> 7;                                 // frame within tile, k half (16 each)
+    constexpr int AJ = GM_TM / 32;                                              // 16-byte A loads per thread per chunk
+    const int a_i = tid & (GM_TM - 1), a_kq = tid / GM_TM;                      // frame within tile, k slice (4*AJ each)
     const int b_j4 = tid & 31, b_k = tid >> 5;                                  // column group, k row (0..7, +8 per step)
     const long long a_frame = f0 + a_i;
     const bool a_live = a_frame < n_frames;
     const float* a_src = srow + (a_live ? a_frame : n_frames - 1) * stride_t;
-    gm_f4 ra[4], rb[4];
+    gm_f4 ra[AJ], rb[4];
     auto fetch = [&](int kc) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = kc + a_kq * 16 + 4 * j;
+        for (int j = 0; j < AJ; ++j) {
+            const int k = kc + a_kq * (4 * AJ) + 4 * j;
             gm_f4 v;
             if (stride_f == 1 && k + 4 <= n_freqs) {
                 v = *reinterpret_cast<const gm_f4*>(a_src + k);                  // dword alignment is all a global load needs
@@ -99,8 +104,8 @@ gemm_fb_kernel(const float* __restrict__ spec, long long stride_r, long long str
     };
     auto deposit = [&]() {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = a_kq * 16 + 4 * j;
+        for (int j = 0; j < AJ; ++j) {
+            const int k = a_kq * (4 * AJ) + 4 * j;
             at_lds[(k + 0) * GM_LD + a_i] = ra[j].x;
             at_lds[(k + 1) * GM_LD + a_i] = ra[j].y;
             at_lds[(k + 2) * GM_LD + a_i] = ra[j].z;
@@ -111,9 +116,9 @@ gemm_fb_kernel(const float* __restrict__ spec, long long stride_r, long long str
             *reinterpret_cast<gm_f4*>(b_lds + (b_k + 8 * j) * GM_LD + 4 * b_j4) = rb[j];
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
@@ -129,24 +134,25 @@ gemm_fb_kernel(const float* __restrict__ spec, long long stride_r, long long str
 #pragma unroll
         for (int k2 = 0; k2 < GM_KC / 2; ++k2) {
             const int k = 2 * k2 + lk;
-            const float a0 = at_lds[k * GM_LD + wm * 64 + li], a1 = at_lds[k * GM_LD + wm * 64 + 32 + li];
             const float b0 = b_lds[k * GM_LD + wn * 64 + li], b1 = b_lds[k * GM_LD + wn * 64 + 32 + li];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const float a = at_lds[k * GM_LD + wm * (32 * MI) + 32 * mi + li];
+                acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[mi][0], 0, 0, 0);
+                acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[mi][1], 0, 0, 0);
+            }
         }
     }
     // D[i][j] of a 32 x 32 tile: j = lane % 32, i = 8*(r / 4) + 4*(lane / 32) + r % 4
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int nj = 0; nj < 2; ++nj) {
             const int col = c0 + wn * 64 + nj * 32 + li;
             if (col < n_mels) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const long long frame = f0 + wm * 64 + mi * 32 + 8 * (r >> 2) + 4 * lk + (r & 3);
+                    const long long frame = f0 + wm * (32 * MI) + mi * 32 + 8 * (r >> 2) + 4 * lk + (r & 3);
                     if (frame < n_frames) out[(row * n_frames + frame) * n_mels + col] = acc[mi][nj][r];
                 }
             }
@@ -169,13 +175,20 @@ int tac_apply_filterbank_f32(const float* spec, int64_t rows, int32_t n_freqs, i
         n_frames *= rows;
         rows = 1;
     }
-    const long long frame_tiles = (n_frames + GM_TM - 1) / GM_TM;
     const int col_tiles = (n_mels + GM_TN - 1) / GM_TN;
+    const long long tiles128 = rows * ((n_frames + 127) / 128) * col_tiles;
+    const int tm = tiles128 < 8LL * device_cu_count() ? 64 : 128;               // few tiles per CU: halve the quantum
+    const long long frame_tiles = (n_frames + tm - 1) / tm;
     const long long blocks = rows * frame_tiles * col_tiles;
     if (blocks > 0x7fffffffLL) return TAC_E_UNSUPPORTED;
-    hipLaunchKernelGGL(gemm_fb_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, spec,
-                       (long long)stride_r, (long long)stride_f, (long long)stride_t, n_freqs, (long long)n_frames,
-                       frame_tiles, col_tiles, fb, fb_plan, n_mels, out);
+    if (tm == 64)
+        hipLaunchKernelGGL(gemm_fb_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, spec,
+                           (long long)stride_r, (long long)stride_f, (long long)stride_t, n_freqs, (long long)n_frames,
+                           frame_tiles, col_tiles, fb, fb_plan, n_mels, out);
+    else
+        hipLaunchKernelGGL(gemm_fb_kernel<128>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, spec,
+                           (long long)stride_r, (long long)stride_f, (long long)stride_t, n_freqs, (long long)n_frames,
+                           frame_tiles, col_tiles, fb, fb_plan, n_mels, out);
     TAC_HIP(hipGetLastError());
     return TAC_OK;
 }
