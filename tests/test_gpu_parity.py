@@ -578,6 +578,15 @@ def test_mulaw_golden_bit_exact(tac, golden):
     assert torch.equal(layer_rt, allc)
 
 
+def test_mulaw_exhaustive_on_device(tac):
+    """Every float32 in [-1, 1] (2 x 1 065 353 217 bit patterns) through the n_quantize = 256 encoder against a
+    binary search in the reference's threshold tables: the estimate-and-correct kernel is exact everywhere."""
+    import subprocess, sys, os
+    tool = os.path.join(os.path.dirname(__file__), '..', 'tools', 'check_mulaw_exhaustive.py')
+    out = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and 'values: 0' in out.stdout, out.stdout + out.stderr
+
+
 def test_mulaw_thresholds_edges(tac, golden):
     g = golden('g5_mulaw')
     pos = g['thr256_pos_bits'].astype(np.uint32)

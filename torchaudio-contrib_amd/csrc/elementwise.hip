@@ -128,7 +128,7 @@ mulaw_encode_kernel(const float* __restrict__ x, long long n, float mu, float lo
         __syncthreads();
     }
     // |x| <= 1 with a threshold table: the code is the number of thresholds <= |x|'s bit pattern.  A cheap
-    // estimate (hardware log2, within +-1 code) picks the starting index and two branch-free compare steps in
+    // estimate (hardware log2, within +-1 code) picks the starting index and one branch-free compare step in
     // each direction make it exact; the precise closed form is only evaluated for out-of-range inputs.
     const float est_scale = 0.5f * mu / (log1p_mu * 1.4426950408889634f);         // codes per log2 unit
     auto encode = [&](float v) -> long long {
@@ -141,7 +141,7 @@ mulaw_encode_kernel(const float* __restrict__ x, long long n, float mu, float lo
         int cnt = (int)(__log2f(1.0f + mu * __uint_as_float((unsigned)bits)) * est_scale + 0.5f);
         cnt = cnt < 0 ? 0 : (cnt > nt ? nt : cnt);
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < 1; ++r) {       // one step each way: exhaustively verified on device (tools/check_mulaw_exhaustive.py)
             cnt += (cnt < nt && tb[cnt < nt ? cnt : nt - 1] <= bits) ? 1 : 0;
             cnt -= (cnt > 0 && tb[cnt > 0 ? cnt - 1 : 0] > bits) ? 1 : 0;
         }
