@@ -36,6 +36,9 @@ def parse():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-stages', action='store_true')
+    ap.add_argument('--dry-run-cpu', action='store_true',
+                    help='control-flow check without a GPU: gloo backend, CPU tensors, a tiny batch (tests/ use it to '
+                         'cover the --gpus N spawn / reduce / JSON path); the printed line is marked invalid')
     return ap.parse_args()
 
 
@@ -54,48 +57,91 @@ def event_ms(fn, iters):
     return sum(keep) / len(keep), times[len(times) // 2]
 
 
-def cpu_baseline():
-    """Time the CPU oracle (torch-CPU restatement of the reference op sequence) on a bounded sample.
-    The host may expose far more hardware threads than torch's CPU kernels scale to, so a few thread
-    counts are tried briefly and the best one is reported (cores = threads actually used)."""
+def cpu_baseline(x):
+    """Time the CPU oracle (torch-CPU restatement of the reference op sequence) on the IDENTICAL host tensor the GPU
+    run uses: all 256 rows with the best thread count, and a 1-thread figure on a slice of it.
+    The host may expose far more hardware threads than torch's CPU kernels scale to, so a few thread counts are tried
+    briefly and the best one is reported (cores = threads actually used)."""
     from oracle import torch_ref
     avail = os.cpu_count() or 1
-    rows = 64
-    g = torch.Generator().manual_seed(0)
-    x = torch.rand(rows, CHANNELS, LENGTH, generator=g) * 2 - 1
+    rows = x.shape[0]
 
-    def run():
-        return torch_ref.melspectrogram_db(x, n_fft=N_FFT, hop=HOP, num_mels=N_MELS, sample_rate=SR)
+    def run(t):
+        return torch_ref.melspectrogram_db(t, n_fft=N_FFT, hop=HOP, num_mels=N_MELS, sample_rate=SR)
 
     best, best_threads, reps_total = float('inf'), 1, 0
     t_all = time.perf_counter()
-    for threads in sorted({1, 8, 16, 32, 64, avail}):
-        if threads > avail or time.perf_counter() - t_all > 20.0:
+    for threads in sorted({8, 16, 32, 64, avail}, reverse=True):
+        if threads > avail or time.perf_counter() - t_all > 15.0:
             continue
         torch.set_num_threads(threads)
-        run()
+        run(x)
         for _ in range(3):
             t0 = time.perf_counter()
-            run()
+            run(x)
             dt = time.perf_counter() - t0
             reps_total += 1
             if dt < best:
                 best, best_threads = dt, threads
-    return {'value': rows * CHANNELS * FRAMES / best, 'unit': 'frames/s', 'cores': best_threads, 'kind': 'port',
-            'sample': '%d of the %d rows of the same workload (%dx%dx%d f32 uniform(-1,1), %d/%d/%d mel + dB), best of '
-                      '%d runs over thread counts up to %d (best at %d threads), torch %s CPU ops in the reference op '
-                      'order (oracle/torch_ref.py)'
-                      % (rows, BATCH, rows, CHANNELS, LENGTH, N_FFT, HOP, N_MELS, reps_total, avail, best_threads,
-                         torch.__version__)}
+    torch.set_num_threads(1)
+    one_rows = max(1, rows // 16)
+    run(x[:one_rows])
+    t0 = time.perf_counter()
+    run(x[:one_rows])
+    one = time.perf_counter() - t0
+    torch.set_num_threads(best_threads)
+    frames = x.shape[1] * FRAMES
+    return {'value': rows * frames / best, 'unit': 'frames/s', 'cores': best_threads, 'kind': 'port',
+            'single_thread_value': one_rows * frames / one,
+            'sample': 'the identical %dx%dx%d f32 uniform(-1,1) host tensor the GPU run was fed (all %d rows; %d/%d/%d '
+                      'mel + dB), best of %d runs over thread counts up to %d (best at %d threads); single_thread_value '
+                      'from the first %d rows at 1 thread; torch %s CPU ops in the reference op order '
+                      '(oracle/torch_ref.py)'
+                      % (rows, x.shape[1], x.shape[2], rows, N_FFT, HOP, N_MELS, reps_total, avail, best_threads,
+                         one_rows, torch.__version__)}
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        return sock.getsockname()[1]
+
+
+def _spawned(local_rank, a, port):
+    os.environ.update(RANK=str(local_rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(a.gpus),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    run(a)
 
 
 def main():
     a = parse()
+    if 'WORLD_SIZE' not in os.environ and a.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher — one process per GPU on this node, as torchrun would
+        if not a.dry_run_cpu and torch.cuda.device_count() < a.gpus:
+            raise SystemExit('bench.py: --gpus %d requested but only %d GPU(s) visible' % (a.gpus, torch.cuda.device_count()))
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        import torch.multiprocessing as mp
+        mp.spawn(_spawned, args=(a, _free_port()), nprocs=a.gpus, join=True)
+        return
+    run(a)
+
+
+def run(a):
+    global BATCH, LENGTH, FRAMES
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d — launch one rank per GPU' % (a.gpus, world))
     distributed = world > 1
     import torch.distributed as dist
+    if a.dry_run_cpu:
+        BATCH, LENGTH = 4, 8192
+        FRAMES = 1 + LENGTH // HOP
+        return dry_run_cpu(a, rank, world)
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit('bench.py: rank %d has no GPU (%d visible)' % (local_rank, torch.cuda.device_count()))
     if distributed:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local_rank)
@@ -107,13 +153,16 @@ def main():
     tac._native.lib()                                   # fail loudly without the HIP library
 
     gen = torch.Generator(device=dev).manual_seed(rank)
-    x = torch.rand(BATCH, CHANNELS, LENGTH, device=dev, generator=gen) * 2 - 1
+    x_host = torch.rand(BATCH, CHANNELS, LENGTH, generator=torch.Generator().manual_seed(rank)) * 2 - 1
+    x = x_host.to(dev)                          # generated once on the host: the CPU baseline times the same tensor
+    if rank != 0 or a.no_cpu_baseline:
+        x_host = None
     model = torch.nn.Sequential(
         *tac.Melspectrogram(num_mels=N_MELS, sample_rate=SR, fft_length=N_FFT, hop_length=HOP),
         tac.AmplitudeToDb()).to(dev)
 
     def step():
-        return tac.realize(model(x))
+        return model(x)                        # the reference's call site, nothing else (returns an ordinary tensor)
 
     def sync():
         torch.cuda.synchronize()
@@ -135,7 +184,7 @@ def main():
         y = step()
     sync()
     elapsed = time.perf_counter() - t0
-    assert tuple(y.shape) == (BATCH, CHANNELS, N_MELS, FRAMES)
+    assert type(y) is torch.Tensor and tuple(y.shape) == (BATCH, CHANNELS, N_MELS, FRAMES)
     if distributed:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -164,22 +213,25 @@ def main():
     # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in
     # separate passes, gfx950 x2 FETCH correction applied — tools/summarize_profiles.py); bench.py cannot run the
     # profiler on itself, so the field is filled from that artefact when it is present.
-    try:
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01', 'pmc_mel.json')))
+    for rnd in ('r02', 'r01'):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', rnd, 'pmc_mel.json')))
+        except Exception:
+            continue
         for kname, d in pmc.items():
             if 'melspec_sparse_kernel<1024' in kname and 'hbm_traffic_bytes_per_launch' in d:
                 result['roofline']['traffic'] = d['hbm_traffic_bytes_per_launch']
-                result['roofline']['traffic_source'] = 'profiles/r01/pmc_mel.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)'
-    except Exception:
-        pass
+                result['roofline']['traffic_source'] = ('profiles/%s/pmc_mel.json (rocprofv3 --pmc FETCH_SIZE / '
+                                                        'WRITE_SIZE)' % rnd)
+        if result['roofline']['traffic'] is not None:
+            break
 
     if rank == 0 and not a.no_stages:
         # secondary stages named by north_star, each one kernel: complex STFT and power spectrogram
-        stft_layer = tac.STFT(N_FFT, HOP).to(dev)
         spec = tac.Spectrogram(N_FFT, HOP, power=2.).to(dev)
         f_bins = N_FFT // 2 + 1
         stages = {}
-        for name, fn, per_frame in (('stft_complex', lambda: tac.realize(stft_layer(x)), 4 * HOP + 8 * f_bins),
+        for name, fn, per_frame in (('stft_complex', lambda: tac.stft(x, N_FFT, HOP), 4 * HOP + 8 * f_bins),
                                     ('spectrogram_power', lambda: spec(x), 4 * HOP + 4 * f_bins)):
             t_w = time.perf_counter()
             while time.perf_counter() - t_w < 0.3:           # same spin-up as the headline loop (clocks, TLB, allocator)
@@ -224,10 +276,41 @@ def main():
                                     'ms_per_step': float(tg.item()) / a.steps * 1e3}
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        result['cpu_baseline'] = cpu_baseline()
+        result['cpu_baseline'] = cpu_baseline(x_host)
     if rank == 0:
         print(json.dumps(result))
     if distributed:
+        dist.destroy_process_group()
+
+
+def dry_run_cpu(a, rank, world):
+    """The launcher / rendezvous / max-over-ranks / one-JSON-line control flow of run(), on CPU tensors over gloo."""
+    import torch.distributed as dist
+    import torchaudio_contrib_amd as tac
+    if world > 1:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    x = torch.rand(BATCH, CHANNELS, LENGTH, generator=torch.Generator().manual_seed(rank)) * 2 - 1
+    model = torch.nn.Sequential(
+        *tac.Melspectrogram(num_mels=N_MELS, sample_rate=SR, fft_length=N_FFT, hop_length=HOP), tac.AmplitudeToDb())
+    for _ in range(a.warmup):
+        model(x)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        y = model(x)
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        gathered = tac.distributed.all_gather_batch(y, total_rows=world * BATCH)
+        assert tuple(gathered.shape) == (world * BATCH, CHANNELS, N_MELS, FRAMES)
+    if rank == 0:
+        print(json.dumps({'metric': 'mel frames/sec', 'value': world * BATCH * CHANNELS * FRAMES * a.steps / float(t.item()),
+                          'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+                          'valid': False, 'data': 'dry run on CPU tensors (control flow only)'}))
+    if world > 1:
         dist.destroy_process_group()
 
 

@@ -116,7 +116,7 @@ int tac_filterbank_plan(const float* fb, int32_t n_freqs, int32_t n_mels, int32_
                         int32_t* plan_host, void* stream);
 
 /* (4) functional.apply_filterbank, functional.py:172-184: out[r][t][m] = sum_f spec[r][f][t]*fb[f][m]
- *     as an fp32 MFMA (v_mfma_f32_16x16x4_f32) tile with zero-block skipping driven by fb_plan
+ *     as an fp32 MFMA (v_mfma_f32_32x32x2_f32) tile with zero-block skipping driven by fb_plan
  *     (NULL = dense).  spec element (r, f, t) lives at spec[r*stride_r + f*stride_f + t*stride_t].
  *     out: float[rows][T][n_mels]. */
 int tac_apply_filterbank_f32(const float* spec, int64_t rows, int32_t n_freqs, int64_t n_frames,
@@ -150,6 +150,13 @@ int tac_phase_vocoder_f32(const float* spec, int64_t rows, int32_t n_freqs, int6
                           int64_t stride_r, int64_t stride_f, int64_t stride_t,
                           const float* phase_advance, const int32_t* idx0, const int32_t* idx1,
                           const float* alpha, int64_t n_out, float* out, void* stream);
+/*      The phase increment and its running sum are carried in float64 inside both kernels (the float32 recurrence is
+ *      ill-conditioned, which is why the reference's own test runs in float64, tests/test_functional.py:69-116);
+ *      the _f64 entry point is that float64 call site itself: same arguments with double data (strides in doubles). */
+int tac_phase_vocoder_f64(const double* spec, int64_t rows, int32_t n_freqs, int64_t n_frames,
+                          int64_t stride_r, int64_t stride_f, int64_t stride_t,
+                          const double* phase_advance, const int32_t* idx0, const int32_t* idx1,
+                          const double* alpha, int64_t n_out, double* out, void* stream);
 
 /* (6) functional.amplitude_to_db, functional.py:277-296: 10*(log10(max(x^2, amin)) - log10(ref)). */
 int tac_amplitude_to_db_f32(const float* x, int64_t n, float ref, float amin, float* out,
@@ -175,9 +182,12 @@ int tac_mulaw_encode_f32_i64(const float* x, int64_t n, int32_t n_quantize,
 int tac_mulaw_decode_i64_f32(const int64_t* codes, int64_t n, int32_t n_quantize,
                              const float* lut, float* out, void* stream);
 
-/* (8b) same for float-valued codes (the reference accepts float input, functional.py:349). */
-int tac_mulaw_decode_f32_f32(const float* codes, int64_t n, int32_t n_quantize, float* out,
-                             void* stream);
+/* (8b) same for float-valued codes (the reference accepts float input, functional.py:349, and its own test
+ *      bit-compares that form, tests/test_functional.py:182-193): a code that is an exact integer in
+ *      [0, n_quantize) is decoded through lut (optional, device, float[n_quantize]) like (8); everything else
+ *      through the closed form. */
+int tac_mulaw_decode_f32_f32(const float* codes, int64_t n, int32_t n_quantize, const float* lut,
+                             float* out, void* stream);
 
 #ifdef __cplusplus
 }

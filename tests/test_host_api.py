@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(tac):
     for name in declared:
         assert hasattr(h, name), name
     assert sorted(tac._native.EXPORTS) == declared
-    assert h.tac_abi_version() == 1
+    assert h.tac_abi_version() == 2
     assert h.tac_strerror(-3).decode().startswith('input too short')
 
 
@@ -43,15 +43,74 @@ def test_geometry_helpers(tac):
     assert ctypes.sizeof(tac._native.StftDesc) == 56
 
 
-def test_no_cpu_fallback(tac):
-    x = torch.zeros(1, 1, 4096)
-    for fn in (lambda: tac.stft(x, 512), lambda: tac.complex_norm(torch.zeros(3, 2)),
-               lambda: tac.amplitude_to_db(x), lambda: tac.mu_law_encoding(x),
-               lambda: tac.mu_law_decoding(torch.zeros(4, dtype=torch.long)),
-               lambda: tac.apply_filterbank(torch.zeros(1, 5, 7), torch.zeros(5, 3)),
-               lambda: tac.Melspectrogram(fft_length=512)(x)):
-        with pytest.raises(RuntimeError, match='HIP device'):
-            fn()
+def test_hip_route_fails_loudly_without_the_library(tac, monkeypatch, tmp_path):
+    """The HIP launchers have no fallback: with libtac_amd.so absent every one of them raises (they all go through
+    _native.lib()); and no launcher body mentions the stock-torch backend."""
+    monkeypatch.setattr(tac._native, 'LIB_PATH', str(tmp_path / 'missing.so'))
+    monkeypatch.setattr(tac._native, '_lib', None)
+    with pytest.raises(tac._native.NativeLibraryError, match='no CPU fallback'):
+        tac._native.lib()
+    src = open(os.path.join(ROOT, 'torchaudio-contrib_amd', '_hip.py')).read()
+    assert '_composite' not in src and 'torch.stft(' not in src and 'torch.fft' not in src and 'matmul' not in src
+    assert src.count('_native.lib()') >= 15
+
+
+def test_strict_mode_and_route_bookkeeping(tac):
+    """set_strict(True) turns the stock-torch route into an error; CPU tensors are not subject to it (they never
+    were candidates for the kernels)."""
+    from torchaudio_contrib_amd import _ops
+    assert _ops._hip_dtype(torch.zeros(2)) is None and _ops._hip_dtype(torch.zeros(2, dtype=torch.float16)) is None
+    assert _ops._hip_dtype(torch.zeros(2, dtype=torch.float64)) == 'dtype float64'
+    tac.set_strict(True)
+    try:
+        with pytest.raises(RuntimeError, match='strict mode'):
+            _ops._composite_route('stft', 'dtype float64')
+        assert tac.amplitude_to_db(torch.ones(3, dtype=torch.float64)).dtype == torch.float64   # CPU: unaffected
+    finally:
+        tac.set_strict(False)
+    with pytest.warns(tac.CompositeRouteWarning):
+        _ops._warned.discard(('stft', 'test reason'))
+        _ops._composite_route('stft', 'test reason')
+    assert _ops.composite_calls[('stft', 'test reason')] == 1
+
+
+def test_ops_are_registered_with_torch_library(tac):
+    """north_star: 'via PyTorch-ROCm custom ops' — every functional is a dispatcher op with CUDA, CPU, Meta and
+    Autograd entries."""
+    names = ['stft', 'spectrogram', 'melspectrogram', 'apply_filterbank', 'complex_norm', 'angle', 'magphase',
+             'phase_vocoder', 'amplitude_to_db', 'db_to_amplitude', 'mu_law_encoding', 'mu_law_decoding']
+    for n in names:
+        op = getattr(torch.ops.tac_amd, n).default
+        for key in ('CUDA', 'CPU', 'Meta'):
+            assert torch._C._dispatch_has_kernel_for_dispatch_key(op.name(), key), (n, key)
+    # FakeTensor propagation gives the shapes AND the strided layout the kernels return
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        x = torch.empty(3, 2, 16000)
+        z = tac.stft(x, 512, 128)
+        assert tuple(z.shape) == (3, 2, 257, 126, 2) and z.stride() == (2 * 126 * 514, 126 * 514, 2, 514, 1)
+        mel = tac.Melspectrogram(num_mels=40, sample_rate=16000, fft_length=512, hop_length=128)(x)
+        assert tuple(mel.shape) == (3, 2, 40, 126) and mel.stride()[-2:] == (1, 40)
+        assert tac.mu_law_encoding(x).dtype == torch.int64
+        assert tuple(tac.phase_vocoder(z, 1.3, torch.empty(257, 1)).shape) == (3, 2, 257, 97, 2)
+
+
+def test_torch_compile_traces_the_pipeline(tac):
+    """The factory pipeline is one graph node under torch.compile (fullgraph: no break on the custom op)."""
+    mel = tac.Melspectrogram(num_mels=32, sample_rate=16000, fft_length=256, hop_length=64)
+    full = torch.nn.Sequential(*mel, tac.AmplitudeToDb())
+    x = torch.randn(2, 1, 4000)
+    seen = []
+
+    def backend(gm, example_inputs):
+        seen.append([str(n.target) for n in gm.graph.nodes if n.op == 'call_function'])
+        return gm.forward
+    got = torch.compile(mel, backend=backend, fullgraph=True)(x)
+    assert [t.replace('.default', '') for t in seen[-1]] == ['tac_amd.melspectrogram'], seen
+    assert torch.equal(got, mel(x))
+    got = torch.compile(full, backend=backend, fullgraph=True)(x)
+    assert any('tac_amd.amplitude_to_db' in t for t in seen[-1]) and all('tac_amd' in t for t in seen[-1]), seen
+    assert torch.equal(got, full(x))
 
 
 def test_layer_contracts(tac):
@@ -170,6 +229,16 @@ assert torch.equal(all_gather_batch(shard_batch(even).clone(), total_rows=4), ev
 pipe = ShardedPipeline(torch.nn.Identity(), gather=True)
 assert torch.equal(pipe(whole), whole)
 assert torch.equal(ShardedPipeline(torch.nn.Identity(), gather=False)(whole), local)
+# fewer rows than ranks: rank 1 owns nothing but still enters the collective (no hang), result is the single row
+one = torch.arange(2 * 3 * 4, dtype=torch.float32).reshape(1, 2, 3, 4)
+assert shard_batch(one).shape[0] == (1 if rank == 0 else 0)
+assert torch.equal(ShardedPipeline(torch.nn.Identity(), gather=True)(one), one)
+mel = tac.Melspectrogram(num_mels=8, sample_rate=8000, fft_length=64, hop_length=16)
+wave = torch.arange(1 * 1 * 400, dtype=torch.float32).reshape(1, 1, 400).sin()
+assert torch.equal(ShardedPipeline(mel, gather=True)(wave), mel(wave))
+# a 2-D transposed local (M, T) view: dim 0 is not the physical dim 0, so it must not take the transposed fast path
+mt = torch.arange(6 * 5, dtype=torch.float32).reshape(5, 6).t()[2 * rank:2 * rank + 2]       # rows of a (6, 5) view
+assert torch.equal(all_gather_batch(mt, total_rows=4), torch.arange(30, dtype=torch.float32).reshape(5, 6).t()[:4])
 dist.barrier()
 dist.destroy_process_group()
 print('rank', rank, 'ok')
@@ -187,3 +256,28 @@ def test_gloo_world2_shard_and_allgather(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert 'rank %d ok' % r in o
+
+
+def test_bench_gpus_flag_is_real():
+    """`python bench.py --gpus N` is its own launcher (one rank per GPU) and refuses to run fewer ranks than asked:
+    the spawn / rendezvous / max-over-ranks / single-JSON-line control flow on CPU tensors over gloo, and the loud
+    failure when the GPUs are not there."""
+    import json
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    env.pop('WORLD_SIZE', None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run-cpu', '--steps', '2',
+                          '--warmup', '1'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env,
+                         timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['valid'] is False and rec['value'] > 0
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1'],
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
+        assert bad.returncode != 0 and 'GPU(s) visible' in bad.stderr and not bad.stdout.strip()
+    mismatch = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--dry-run-cpu'],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=dict(env, WORLD_SIZE='1', RANK='0'), timeout=300)
+    assert mismatch.returncode != 0 and 'WORLD_SIZE=1' in mismatch.stderr

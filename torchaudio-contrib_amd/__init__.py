@@ -5,6 +5,8 @@ Import surface mirrors ``torchaudio_contrib/__init__.py:1-2`` of the reference (
 the importable name is ``torchaudio_contrib_amd`` (see the loader shim at the repo root).
 """
 from . import _native
+from . import _ops
+from ._ops import set_strict, CompositeRouteWarning
 from ._lazy import realize, set_lazy_fusion, lazy_fusion_enabled, DeferredSpectral
 from . import functional
 from . import layers

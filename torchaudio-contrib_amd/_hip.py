@@ -1,0 +1,532 @@
+"""Launchers of the gfx950 kernels: the bodies of the ``tac_amd::*`` ops for float32 tensors on a HIP device.
+
+Every function takes fully resolved, already validated arguments (``functional.py`` fills in defaults;
+``_ops.py`` routes by device / dtype) and goes through the C ABI of ``include/tac_amd.h`` via ctypes — raw
+device pointers, sizes and the caller's current HIP stream.  PyTorch only provides the output allocation and
+the stream.  There is no fallback in here: a missing ``libtac_amd.so`` or a failing launch raises.
+"""
+import ctypes
+import math
+import os
+import threading
+
+import torch
+
+from . import _native
+
+_lock = threading.Lock()
+
+#: number of kernels launched through the C ABI since import, per entry point (tests assert on it so that a
+#: silently taken non-HIP route cannot pass as the HIP path)
+launches = {}
+
+
+def _count(name):
+    launches[name] = launches.get(name, 0) + 1
+
+
+# ----------------------------------------------------------------------------- STFT geometry
+class StftGeometry(object):
+    """Validated geometry of one stft call on one input layout (the checks ``torch.stft`` performs, reference
+    functional.py:99-107), cached per (shape, strides, parameters) so that a repeated call costs a dict lookup."""
+    __slots__ = ('lead', 'length', 'rows', 'row_stride', 'flatten', 'n_fft', 'hop', 'win_length', 'center',
+                 'pad_mode', 'normalized', 'onesided', 'n_frames', 'n_bins', 'fft_kernel', 'desc',
+                 'stft_shape', 'spec_shape')
+
+
+_geometry_cache = {}
+
+
+def stft_frames(length, n_fft, hop, center):
+    pad = n_fft // 2 if center else 0
+    return 1 + (length + 2 * pad - n_fft) // hop
+
+
+def check_stft_args(shape, n_fft, hop, win_length, center, pad_mode):
+    """The argument checks of ``torch.stft`` + ``F.pad`` that do not depend on the backend (same exception types:
+    the reference's tests expect ``RuntimeError`` for an input too short to reflect-pad,
+    reference tests/test_functional.py:31)."""
+    if len(shape) < 1 or any(int(s) == 0 for s in shape):
+        raise RuntimeError('stft: expected a non-empty tensor of shape (*, channel, time)')
+    length = int(shape[-1])
+    if n_fft <= 0 or hop <= 0:
+        raise RuntimeError('stft: expected 0 < n_fft and 0 < hop_length, got n_fft=%d hop_length=%d' % (n_fft, hop))
+    if not 0 < win_length <= n_fft:
+        raise RuntimeError('stft: expected 0 < win_length <= n_fft, got win_length=%d' % win_length)
+    if pad_mode not in _native.PAD_MODES:
+        raise NotImplementedError('stft: unsupported pad_mode %r' % (pad_mode,))
+    pad = n_fft // 2 if center else 0
+    if center and pad_mode == 'reflect' and pad >= length:
+        raise RuntimeError('stft: reflect padding (%d, %d) must be smaller than the signal length %d'
+                           % (pad, pad, length))
+    if center and pad_mode == 'circular' and pad > length:
+        raise RuntimeError('stft: circular padding (%d, %d) must not exceed the signal length %d'
+                           % (pad, pad, length))
+    if length + 2 * pad < n_fft:
+        raise RuntimeError('stft: expected n_fft <= padded signal length %d, got n_fft=%d' % (length + 2 * pad, n_fft))
+
+
+def fft_kernel_size(n_fft):
+    """power-of-two sizes in [32, 4096] take the wave-level FFT kernels; every other size up to 8192 is evaluated
+    as a windowed-DFT matrix product on the fp32 matrix cores (``_stft_dft``)."""
+    return (n_fft & (n_fft - 1)) == 0 and 32 <= n_fft <= 4096
+
+
+def hip_covers_n_fft(n_fft):
+    return fft_kernel_size(n_fft) or n_fft <= 8192
+
+
+def geometry(wave, n_fft, hop, win_length, center, pad_mode, normalized, onesided):
+    key = (tuple(wave.shape), tuple(wave.stride()), n_fft, hop, win_length, center, pad_mode, normalized, onesided)
+    g = _geometry_cache.get(key)
+    if g is not None:
+        return g
+    check_stft_args(wave.shape, n_fft, hop, win_length, center, pad_mode)
+    g = StftGeometry()
+    length = int(wave.shape[-1])
+    g.lead = tuple(int(s) for s in wave.shape[:-1])
+    g.length = length
+    g.rows = 1
+    for s in g.lead:
+        g.rows *= s
+    # can the rows be addressed as base + r * row_stride without a copy?
+    flat = wave.reshape(-1, length) if wave.dim() != 2 else wave
+    viewable = flat.data_ptr() == wave.data_ptr() and flat.stride(1) == 1 and \
+        (flat.shape[0] == 1 or flat.stride(0) >= length)
+    g.flatten = not viewable
+    g.row_stride = length if (g.flatten or flat.shape[0] == 1) else int(flat.stride(0))
+    g.n_fft, g.hop, g.win_length = n_fft, hop, win_length
+    g.center, g.pad_mode, g.normalized, g.onesided = bool(center), pad_mode, bool(normalized), bool(onesided)
+    g.n_frames = stft_frames(length, n_fft, hop, center)
+    g.n_bins = n_fft // 2 + 1 if onesided else n_fft
+    g.fft_kernel = fft_kernel_size(n_fft)
+    if not g.fft_kernel and n_fft > 8192:
+        raise NotImplementedError('stft: fft_length %d is outside the HIP path (power of two in [32, 4096], or any '
+                                  'length <= 8192 through the DFT-matrix kernel)' % n_fft)
+    g.desc = None if not g.fft_kernel else _native.StftDesc(
+        rows=g.rows, length=length, row_stride=g.row_stride, n_fft=n_fft, hop=hop, win_length=win_length,
+        center=1 if center else 0, pad_mode=_native.PAD_MODES[pad_mode], normalized=1 if normalized else 0,
+        onesided=1 if onesided else 0, reserved=0)
+    g.stft_shape = g.lead + (g.n_frames, g.n_bins, 2)
+    g.spec_shape = g.lead + (g.n_frames, g.n_bins)
+    with _lock:
+        if len(_geometry_cache) > 512:
+            _geometry_cache.clear()
+        _geometry_cache[key] = g
+    return g
+
+
+def _rows_of(wave, g):
+    """The tensor whose data pointer + g.row_stride addresses the rows (a copy only for layouts that cannot be)."""
+    return wave.reshape(-1, g.length).contiguous() if g.flatten else wave
+
+
+def _dft_matrix(window, n_fft, win_length, onesided, normalized):
+    """(N, 2F) float32 device matrix [w[n] cos(2 pi k n / N), -w[n] sin(2 pi k n / N)] for the DFT-matrix path,
+    built on the device in float64 (angles reduced exactly through (n*k) mod N in int64) and rounded once — a
+    constant table like the FFT twiddles, cached on the window tensor per (version, geometry)."""
+    cache = getattr(window, '_tac_dft', None)
+    key = (window._version, n_fft, win_length, bool(onesided), bool(normalized))
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    dev = window.device
+    w = torch.zeros(n_fft, dtype=torch.float64, device=dev)
+    off = (n_fft - win_length) // 2
+    w[off:off + win_length] = window.detach().double()
+    if normalized:
+        w = w / math.sqrt(n_fft)
+    n_bins = n_fft // 2 + 1 if onesided else n_fft
+    n = torch.arange(n_fft, dtype=torch.int64, device=dev)[:, None]
+    k = torch.arange(n_bins, dtype=torch.int64, device=dev)[None, :]
+    ang = ((n * k) % n_fft).double() * (2.0 * math.pi / n_fft)
+    mat = torch.stack([torch.cos(ang) * w[:, None], -torch.sin(ang) * w[:, None]], dim=-1)
+    mat = mat.to(torch.float32).reshape(n_fft, 2 * n_bins).contiguous()
+    try:
+        window._tac_dft = (key, mat)
+    except Exception:
+        pass
+    return mat
+
+
+def _stft_dft(wave, window, g):
+    """Any fft_length (non power of two, or 4096 < N <= 8192): the framed signal is never materialised — the
+    filterbank GEMM kernel reads frame t, sample n at ``padded[row, t*hop + n]`` (stride_f = 1, stride_t = hop)
+    and multiplies by the (N, 2F) windowed-DFT matrix on the fp32 matrix cores.  The padded copy is plain data
+    movement done by torch; everything arithmetic is the HIP kernel."""
+    x = wave.reshape(-1, g.length)
+    if g.center:
+        pad = g.n_fft // 2
+        x = torch.nn.functional.pad(x.unsqueeze(1), (pad, pad), mode=g.pad_mode).squeeze(1)
+    x = x.contiguous()
+    mat = _dft_matrix(window, g.n_fft, g.win_length, g.onesided, g.normalized)
+    out = torch.empty(g.stft_shape, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _native.lib().tac_apply_filterbank_f32(
+            _native.ptr(x), x.shape[0], g.n_fft, g.n_frames, x.stride(0), 1, g.hop,
+            _native.ptr(mat), None, 2 * g.n_bins, _native.ptr(out), _native.stream_ptr(x.device))
+    _native.check(rc, 'tac_apply_filterbank_f32 (DFT matrix)')
+    _count('tac_apply_filterbank_f32')
+    return out.transpose(-3, -2)
+
+
+def stft(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided):
+    g = geometry(wave, n_fft, hop, win_length, center, pad_mode, normalized, onesided)
+    if not g.fft_kernel:
+        return _stft_dft(wave, window, g)
+    src = _rows_of(wave, g)
+    out = torch.empty(g.stft_shape, dtype=torch.float32, device=wave.device)
+    with torch.cuda.device(wave.device):
+        rc = _native.lib().tac_stft_f32(_native.ptr(src), _native.ptr(window), g.desc, _native.ptr(out),
+                                        _native.stream_ptr(wave.device))
+    _native.check(rc, 'tac_stft_f32')
+    _count('tac_stft_f32')
+    return out.transpose(-3, -2)
+
+
+def spectrogram(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided, power, db, ref, amin):
+    g = geometry(wave, n_fft, hop, win_length, center, pad_mode, normalized, onesided)
+    if not g.fft_kernel:
+        mag = complex_norm(_stft_dft(wave, window, g), power)
+        return amplitude_to_db(mag, ref, amin) if db else mag
+    src = _rows_of(wave, g)
+    out = torch.empty(g.spec_shape, dtype=torch.float32, device=wave.device)
+    with torch.cuda.device(wave.device):
+        rc = _native.lib().tac_spectrogram_f32(
+            _native.ptr(src), _native.ptr(window), g.desc, float(power), 1 if db else 0, float(ref), float(amin),
+            _native.ptr(out), _native.stream_ptr(wave.device))
+    _native.check(rc, 'tac_spectrogram_f32')
+    _count('tac_spectrogram_f32')
+    return out.transpose(-2, -1)
+
+
+# A/B knob for the two fused Melspectrogram kernels: 'auto' (band-sparse when the bank allows it, else MFMA),
+# 'sparse', 'mfma'
+MEL_PATH = os.environ.get('TAC_MEL_PATH', 'auto')
+
+
+def _melbank_pack(fb, n_fft):
+    """(wpack, desc, info) device/host buffers of the band-sparse contraction for this filterbank and fft size, or
+    None when the bank is not band-sparse enough (then the MFMA kernels are used).  Built once per filterbank
+    version (one host sync) and cached on the tensor object."""
+    cache = getattr(fb, '_tac_pack', None)
+    if cache is None or cache[0] != fb._version:
+        cache = (fb._version, {})
+        try:
+            fb._tac_pack = cache
+        except Exception:
+            pass
+    if n_fft in cache[1]:
+        return cache[1][n_fft]
+    n_freqs, n_mels = fb.shape
+    wpack = torch.empty(3072, dtype=torch.float32, device=fb.device)
+    desc = torch.empty(4096, dtype=torch.int32, device=fb.device)
+    info = (ctypes.c_int32 * 4)()
+    with torch.cuda.device(fb.device):
+        rc = _native.lib().tac_melbank_pack(_native.ptr(fb), n_freqs, n_mels, n_fft, _native.ptr(wpack), 3072,
+                                            _native.ptr(desc), 4096, ctypes.cast(info, ctypes.c_void_p),
+                                            _native.stream_ptr(fb.device))
+    if rc == _native.TAC_E_UNSUPPORTED:
+        result = None
+    else:
+        _native.check(rc, 'tac_melbank_pack')
+        result = (wpack, desc, info)
+    cache[1][n_fft] = result
+    return result
+
+
+def _filterbank_plan(fb):
+    """(device int32 plan, host ctypes copy): non-zero bin range per 16-band tile, computed by a device kernel.
+    The plan rides on the filterbank tensor object itself (a module's constant buffer is scanned once — the only
+    host sync on the path — and rescanned when modified in place); keying a cache on ``data_ptr`` would go stale
+    when the allocator reuses an address."""
+    hit = getattr(fb, '_tac_plan', None)
+    if hit is not None and hit[0] == fb._version and hit[1].device == fb.device:
+        return hit[1], hit[2]
+    n_freqs, n_mels = fb.shape
+    n_ints = 2 * ((n_mels + 15) // 16)
+    plan = torch.empty(n_ints, dtype=torch.int32, device=fb.device)
+    host = (ctypes.c_int32 * n_ints)()
+    with torch.cuda.device(fb.device):
+        rc = _native.lib().tac_filterbank_plan(_native.ptr(fb), n_freqs, n_mels, _native.ptr(plan),
+                                               ctypes.cast(host, ctypes.c_void_p), _native.stream_ptr(fb.device))
+    _native.check(rc, 'tac_filterbank_plan')
+    try:
+        fb._tac_plan = (fb._version, plan, host)
+    except Exception:       # exotic tensor subclasses without attribute storage: just recompute next time
+        pass
+    return plan, host
+
+
+def _fused_mel_route(g, fb, power):
+    """'sparse' / 'mfma' when one fused kernel covers this geometry + filterbank, else None (then the caller chains
+    the spectrogram, filterbank and dB kernels)."""
+    if not (g.fft_kernel and g.onesided and g.n_fft <= 2048 and fb.dim() == 2 and fb.shape[0] == g.n_bins and
+            0 < fb.shape[1] <= 512 and fb.is_contiguous()):
+        return None
+    if power in (1.0, 2.0) and MEL_PATH != 'mfma' and _melbank_pack(fb, g.n_fft) is not None:
+        return 'sparse'
+    if MEL_PATH == 'sparse':
+        return None
+    _, host = _filterbank_plan(fb)
+    rc = _native.lib().tac_melspec_supported(g.desc, float(power), ctypes.cast(host, ctypes.c_void_p), fb.shape[1])
+    return 'mfma' if rc == _native.TAC_OK else None
+
+
+def melspectrogram(wave, window, fb, n_fft, hop, win_length, center, pad_mode, normalized, onesided, power, db, ref,
+                   amin):
+    g = geometry(wave, n_fft, hop, win_length, center, pad_mode, normalized, onesided)
+    if fb.dim() != 2 or fb.shape[0] != g.n_bins:
+        raise RuntimeError('apply_filterbank: size mismatch, spectrogram has %d bins, filterbank %s'
+                           % (g.n_bins, tuple(fb.shape)))
+    route = _fused_mel_route(g, fb, power)
+    if route is None:
+        spec = spectrogram(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided, power,
+                           False, 1.0, 1e-7)
+        mel = apply_filterbank(spec, fb)
+        return amplitude_to_db(mel, ref, amin) if db else mel
+    n_mels = fb.shape[1]
+    src = _rows_of(wave, g)
+    out = torch.empty(g.lead + (g.n_frames, n_mels), dtype=torch.float32, device=wave.device)
+    if route == 'sparse':          # band-sparse contraction (the faster form for triangular banks)
+        wpack, desc, info = _melbank_pack(fb, g.n_fft)
+        with torch.cuda.device(wave.device):
+            rc = _native.lib().tac_melspec_sparse_f32(
+                _native.ptr(src), _native.ptr(window), g.desc, float(power), _native.ptr(wpack), _native.ptr(desc),
+                ctypes.cast(info, ctypes.c_void_p), n_mels, 1 if db else 0, float(ref), float(amin),
+                _native.ptr(out), _native.stream_ptr(wave.device))
+        _native.check(rc, 'tac_melspec_sparse_f32')
+        _count('tac_melspec_sparse_f32')
+        return out.transpose(-2, -1)
+    _, plan_host = _filterbank_plan(fb)
+    with torch.cuda.device(wave.device):
+        rc = _native.lib().tac_melspec_f32(
+            _native.ptr(src), _native.ptr(window), g.desc, float(power), _native.ptr(fb),
+            ctypes.cast(plan_host, ctypes.c_void_p), n_mels, 1 if db else 0, float(ref), float(amin),
+            _native.ptr(out), _native.stream_ptr(wave.device))
+    _native.check(rc, 'tac_melspec_f32')
+    _count('tac_melspec_f32')
+    return out.transpose(-2, -1)
+
+
+# ----------------------------------------------------------------------------- filterbank
+def apply_filterbank(spec, fb):
+    fb = fb if fb.is_contiguous() else fb.contiguous()
+    n_freqs, n_frames = spec.shape[-2], spec.shape[-1]
+    lead = tuple(spec.shape[:-2])
+    n_mels = fb.shape[1]
+    out = torch.empty(lead + (n_frames, n_mels), dtype=torch.float32, device=spec.device)
+    if out.numel():
+        rows = spec.reshape(-1, n_freqs, n_frames)
+        # frame-major spectrogram (what the kernels here produce) + band-sparse bank: stream it through the fused
+        # kernel's contraction; anything else goes through the fp32 MFMA GEMM
+        pack = _melbank_pack(fb, 0) if (rows.stride(1) == 1 and MEL_PATH != 'mfma') else None
+        if pack is not None:
+            wpack, desc, info = pack
+            with torch.cuda.device(spec.device):
+                rc = _native.lib().tac_apply_filterbank_sparse_f32(
+                    _native.ptr(rows), rows.shape[0], n_freqs, n_frames, rows.stride(0) if rows.shape[0] > 1 else 0,
+                    rows.stride(2), _native.ptr(wpack), _native.ptr(desc), ctypes.cast(info, ctypes.c_void_p), n_mels,
+                    _native.ptr(out), _native.stream_ptr(spec.device))
+            if rc != _native.TAC_E_UNSUPPORTED:
+                _native.check(rc, 'tac_apply_filterbank_sparse_f32')
+                _count('tac_apply_filterbank_sparse_f32')
+                return out.transpose(-2, -1)
+        plan, _ = _filterbank_plan(fb)
+        with torch.cuda.device(spec.device):
+            rc = _native.lib().tac_apply_filterbank_f32(
+                _native.ptr(rows), rows.shape[0], n_freqs, n_frames, rows.stride(0), rows.stride(1),
+                rows.stride(2), _native.ptr(fb), _native.ptr(plan), n_mels, _native.ptr(out),
+                _native.stream_ptr(spec.device))
+        _native.check(rc, 'tac_apply_filterbank_f32')
+        _count('tac_apply_filterbank_f32')
+    return out.transpose(-2, -1)
+
+
+# ----------------------------------------------------------------------------- complex pairs
+def is_dense(x):
+    """True when x's elements tile one gap-free block of memory (in any dim order)."""
+    if x.is_contiguous():
+        return True
+    dims = sorted((st, n) for st, n in zip(x.stride(), x.shape) if n > 1)
+    expect = 1
+    for st, n in dims:
+        if st != expect:
+            return False
+        expect *= n
+    return True
+
+
+def _pairs(z):
+    """Dense view of a ``(*, 2)`` tensor whose storage order the elementwise kernels can walk pair by pair."""
+    if z.stride(-1) != 1 or not is_dense(z) or any(s % 2 for s, n in zip(z.stride()[:-1], z.shape[:-1]) if n > 1):
+        z = z.contiguous()
+    return z
+
+
+def _pair_output(z):
+    return torch.empty_strided(z.shape[:-1], tuple(s // 2 for s in z.stride()[:-1]), dtype=torch.float32,
+                               device=z.device)
+
+
+def complex_norm(z, power):
+    z = _pairs(z)
+    out = _pair_output(z)
+    n = out.numel()
+    if n:
+        with torch.cuda.device(z.device):
+            rc = _native.lib().tac_complex_norm_f32(_native.ptr(z), n, float(power), _native.ptr(out),
+                                                    _native.stream_ptr(z.device))
+        _native.check(rc, 'tac_complex_norm_f32')
+        _count('tac_complex_norm_f32')
+    return out
+
+
+def angle(z):
+    z = _pairs(z)
+    phase = _pair_output(z)
+    if phase.numel():
+        with torch.cuda.device(z.device):
+            rc = _native.lib().tac_magphase_f32(_native.ptr(z), phase.numel(), 1.0, None, _native.ptr(phase),
+                                                _native.stream_ptr(z.device))
+        _native.check(rc, 'tac_magphase_f32')
+        _count('tac_magphase_f32')
+    return phase
+
+
+def magphase(z, power):
+    z = _pairs(z)
+    mag, phase = _pair_output(z), _pair_output(z)
+    if phase.numel():
+        with torch.cuda.device(z.device):
+            rc = _native.lib().tac_magphase_f32(_native.ptr(z), phase.numel(), float(power), _native.ptr(mag),
+                                                _native.ptr(phase), _native.stream_ptr(z.device))
+        _native.check(rc, 'tac_magphase_f32')
+        _count('tac_magphase_f32')
+    return mag, phase
+
+
+_PV_GRID_CACHE = {}
+
+
+def _phase_vocoder_grid(n_frames, rate, device, dtype):
+    """Source-frame indices and interpolation weights of every output frame, evaluated exactly as the reference's CPU
+    path does (functional.py:233-247: ``torch.arange(0, T, rate)`` in the default dtype, ``% 1``, ``.long()``); which
+    frames get paired depends on that rounding, so it is computed with the same host ops and cached."""
+    key = (int(n_frames), float(rate), str(device), dtype, torch.get_default_dtype())
+    hit = _PV_GRID_CACHE.get(key)
+    if hit is None:
+        steps = torch.arange(0, n_frames, rate)
+        if len(_PV_GRID_CACHE) > 64:
+            _PV_GRID_CACHE.clear()
+        hit = (steps.long().to(torch.int32).to(device), (steps + 1).long().to(torch.int32).to(device),
+               torch.remainder(steps, torch.tensor(1., dtype=steps.dtype)).to(dtype).to(device))
+        _PV_GRID_CACHE[key] = hit
+    return hit
+
+
+def phase_vocoder_out_frames(n_frames, rate):
+    return int(torch.arange(0, n_frames, rate).numel())
+
+
+def phase_vocoder(spec, rate, phase_advance):
+    """float32 or float64 (the reference's own test runs this op in float64, tests/test_functional.py:69-116)."""
+    dtype = spec.dtype
+    n_freqs, n_frames = spec.shape[-3], spec.shape[-2]
+    pa = phase_advance.reshape(-1).to(dtype).contiguous()
+    lead = tuple(spec.shape[:-3])
+    idx0, idx1, alpha = _phase_vocoder_grid(n_frames, rate, spec.device, dtype)
+    n_out = idx0.numel()
+    if spec.stride(-1) != 1:
+        spec = spec.contiguous()
+    rows = spec.reshape((-1,) + tuple(spec.shape[-3:]))          # a view whenever the leading dims collapse
+    if any(st % 2 for st in rows.stride()[:-1]) or rows.data_ptr() % (2 * rows.element_size()):
+        rows = rows.contiguous()                                 # (re, im) pairs are fetched as one aligned access
+    out = torch.empty(lead + (n_out, n_freqs, 2), dtype=dtype, device=spec.device)
+    if out.numel() and n_frames:
+        name = 'tac_phase_vocoder_f64' if dtype == torch.float64 else 'tac_phase_vocoder_f32'
+        with torch.cuda.device(spec.device):
+            rc = getattr(_native.lib(), name)(
+                _native.ptr(rows), rows.shape[0], n_freqs, n_frames, rows.stride(0) if rows.shape[0] > 1 else 0,
+                rows.stride(1), rows.stride(2), _native.ptr(pa), _native.ptr(idx0), _native.ptr(idx1),
+                _native.ptr(alpha), n_out, _native.ptr(out), _native.stream_ptr(spec.device))
+        _native.check(rc, name)
+        _count(name)
+    return out.transpose(-3, -2)
+
+
+# ----------------------------------------------------------------------------- elementwise
+def _unary(x, name, launch):
+    x = x if is_dense(x) else x.contiguous()
+    out = torch.empty_like(x)
+    if x.numel():
+        with torch.cuda.device(x.device):
+            rc = launch(_native.lib(), _native.ptr(x), x.numel(), _native.ptr(out), _native.stream_ptr(x.device))
+        _native.check(rc, name)
+        _count(name)
+    return out
+
+
+def amplitude_to_db(x, ref, amin):
+    return _unary(x, 'tac_amplitude_to_db_f32',
+                  lambda h, p, n, o, s: h.tac_amplitude_to_db_f32(p, n, float(ref), float(amin), o, s))
+
+
+def db_to_amplitude(x, ref):
+    return _unary(x, 'tac_db_to_amplitude_f32', lambda h, p, n, o, s: h.tac_db_to_amplitude_f32(p, n, float(ref), o, s))
+
+
+_mulaw_consts = {}
+
+
+def _mulaw_tables(device):
+    key = str(device)
+    hit = _mulaw_consts.get(key)
+    if hit is None:
+        from . import _mulaw_tables as tab
+        thr = torch.tensor(list(tab.THR256_POS) + list(tab.THR256_NEG), dtype=torch.int32, device=device)
+        lut = torch.tensor(list(tab.LUT256_BITS), dtype=torch.int64).to(torch.int32).view(torch.float32)
+        hit = (thr, len(tab.THR256_POS), len(tab.THR256_NEG), tab.ZERO_CODE_256, lut.to(device))
+        with _lock:
+            _mulaw_consts[key] = hit
+    return hit
+
+
+def mu_law_encoding(x, n_quantize):
+    x = x if x.is_contiguous() else x.contiguous()
+    out = torch.empty(x.shape, dtype=torch.int64, device=x.device)
+    if x.numel():
+        if n_quantize == 256:
+            thr, n_pos, n_neg, zero, _ = _mulaw_tables(x.device)
+            thr_ptr = _native.ptr(thr)
+        else:
+            thr_ptr, n_pos, n_neg, zero = None, 0, 0, 0
+        with torch.cuda.device(x.device):
+            rc = _native.lib().tac_mulaw_encode_f32_i64(_native.ptr(x), x.numel(), n_quantize, thr_ptr, n_pos, n_neg,
+                                                        zero, _native.ptr(out), _native.stream_ptr(x.device))
+        _native.check(rc, 'tac_mulaw_encode_f32_i64')
+        _count('tac_mulaw_encode_f32_i64')
+    return out
+
+
+def mu_law_decoding_int(codes, n_quantize):
+    """int64 codes -> float32 (reference functional.py:348-354 with the default dtype)."""
+    codes = codes.to(torch.int64).contiguous()
+    out = torch.empty(codes.shape, dtype=torch.float32, device=codes.device)
+    if codes.numel():
+        lut_ptr = _native.ptr(_mulaw_tables(codes.device)[4]) if n_quantize == 256 else None
+        with torch.cuda.device(codes.device):
+            rc = _native.lib().tac_mulaw_decode_i64_f32(_native.ptr(codes), codes.numel(), n_quantize, lut_ptr,
+                                                        _native.ptr(out), _native.stream_ptr(codes.device))
+        _native.check(rc, 'tac_mulaw_decode_i64_f32')
+        _count('tac_mulaw_decode_i64_f32')
+    return out
+
+
+def mu_law_decoding_float(codes, n_quantize):
+    """float32 codes -> float32: integral codes in [0, 256) with n_quantize == 256 come from the reference's own
+    table (bit-exact, what reference tests/test_functional.py:182-193 bit-compares), everything else from the
+    closed form."""
+    lut = _mulaw_tables(codes.device)[4] if n_quantize == 256 else None
+    return _unary(codes, 'tac_mulaw_decode_f32_f32',
+                  lambda h, p, n, o, s: h.tac_mulaw_decode_f32_f32(p, n, n_quantize,
+                                                                   None if lut is None else _native.ptr(lut), o, s))

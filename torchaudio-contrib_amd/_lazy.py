@@ -1,13 +1,22 @@
 """Deferred evaluation so that a plain ``nn.Sequential`` of the reference's layers runs as ONE kernel.
 
-The reference composes Melspectrogram as ``Sequential(STFT, ComplexNorm(2), ApplyFilterbank)`` and
-users append ``AmplitudeToDb()`` themselves (``tests/test_layers.py:69`` unpacks the factory result
-with ``*``), so the fusion boundary cannot be a container we own.  Instead ``STFT.forward`` returns a
-``DeferredSpectral`` — a ``torch.Tensor`` wrapper subclass with the right shape / strides / dtype /
-device but no storage, holding the validated STFT plan.  ``ComplexNorm``, ``ApplyFilterbank`` and
-``AmplitudeToDb`` extend the recipe when handed one; anything else (any torch op, ``.cpu()``,
-printing, ``realize()``) materialises it through ``__torch_dispatch__`` by launching the single fused
-HIP kernel that covers the recorded chain.  Nothing here computes on the CPU.
+The reference composes Melspectrogram as ``Sequential(STFT, ComplexNorm(2), ApplyFilterbank)`` and users append
+``AmplitudeToDb()`` themselves (reference ``tests/test_layers.py:69`` unpacks the factory result with ``*``), so the
+fusion boundary cannot be a container we own.  Instead ``STFT.forward`` returns a ``DeferredSpectral`` — a
+``torch.Tensor`` wrapper subclass with the right shape / strides / dtype / device but no storage — and
+``ComplexNorm`` / ``ApplyFilterbank`` extend the recipe when handed one.  ``AmplitudeToDb`` is terminal (nothing can
+fuse behind it): it launches the single fused ``tac_amd::melspectrogram`` op at once and returns an ordinary
+tensor.  A recipe that is still pending when it reaches anything else (any torch op, ``.cpu()``, printing,
+``realize()``) is materialised through ``__torch_dispatch__``.
+
+Safety of the deferral (the reference is eager; these make the difference unobservable or loud):
+  * the recipe records the version counters and data pointers of the waveform, window and filterbank at
+    ``forward`` time; materialising after any of them was modified in place raises instead of returning features
+    of the wrong batch;
+  * the kernel is enqueued on the stream that was current at ``forward`` time; if another stream is current when
+    the value is needed, that stream is made to wait for it;
+  * tensors that require grad, CPU tensors, float64 and ``torch.compile`` tracing are never deferred — the layers
+    call the ops eagerly there.
 """
 import torch
 from torch.utils._pytree import tree_map
@@ -26,14 +35,52 @@ def lazy_fusion_enabled():
     return _enabled
 
 
+_DEFERRABLE = (torch.float32, torch.float16, torch.bfloat16)
+
+
+def can_defer(wave, window):
+    """Deferral applies to plain tensors on a HIP device that take the gfx950 kernels and carry no autograd state."""
+    if not _enabled or type(wave) is not torch.Tensor or not wave.is_cuda or wave.dtype not in _DEFERRABLE:
+        return False
+    if torch.compiler.is_compiling():
+        return False
+    if torch.is_grad_enabled() and (wave.requires_grad or window.requires_grad):
+        return False
+    return window.device == wave.device and window.dtype in _DEFERRABLE
+
+
+class _Source(object):
+    """The STFT call a recipe starts from, plus what is needed to detect that its inputs changed meanwhile."""
+    __slots__ = ('wave', 'window', 'args', 'stream', 'stamps', 'lead', 'n_frames', 'n_bins')
+
+    def __init__(self, wave, window, args):
+        self.wave, self.window, self.args = wave, window, args
+        self.stream = torch.cuda.current_stream(wave.device)
+        self.stamps = [(wave, wave._version, wave.data_ptr(), 'waveform'),
+                       (window, window._version, window.data_ptr(), 'window')]
+
+    def watch(self, tensor, what):
+        self.stamps.append((tensor, tensor._version, tensor.data_ptr(), what))
+
+    def check_unchanged(self):
+        for tensor, version, address, what in self.stamps:
+            if tensor._version != version or tensor.data_ptr() != address:
+                raise RuntimeError(
+                    'torchaudio_contrib_amd: the %s handed to STFT was modified in place before its deferred '
+                    'spectrogram was used (the fused kernel had not been launched yet).  Use the result — or call '
+                    'torchaudio_contrib_amd.realize() on it — before overwriting the input, finish the chain with '
+                    'AmplitudeToDb (which launches immediately), or disable deferral with set_lazy_fusion(False).'
+                    % what)
+
+
 class DeferredSpectral(torch.Tensor):
     """Result of an STFT-rooted layer chain that has not been launched yet."""
 
     @staticmethod
-    def __new__(cls, plan, stage, shape, strides, power=None, filterbank=None, db=None):
+    def __new__(cls, src, stage, shape, strides, power=None, filterbank=None, db=None):
         r = torch.Tensor._make_wrapper_subclass(cls, shape, strides=strides, dtype=torch.float32,
-                                                device=plan.wave.device, requires_grad=False)
-        r._plan = plan
+                                                device=src.wave.device, requires_grad=False)
+        r._src = src
         r._stage = stage            # 'stft' | 'spec' | 'mel'
         r._power = power
         r._fb = filterbank
@@ -43,40 +90,62 @@ class DeferredSpectral(torch.Tensor):
 
     # -- chain construction -----------------------------------------------------
     @classmethod
-    def from_plan(cls, plan):
-        shape = plan.lead + (plan.n_bins, plan.n_frames, 2)
-        return cls(plan, 'stft', shape, _transposed_strides(plan.lead, (plan.n_frames, plan.n_bins, 2), -3, -2))
+    def from_stft(cls, wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided):
+        src = _Source(wave, window, (n_fft, hop, win_length, center, pad_mode, normalized, onesided))
+        src.lead = tuple(wave.shape[:-1])
+        src.n_frames = 1 + (wave.shape[-1] + (2 * (n_fft // 2) if center else 0) - n_fft) // hop
+        src.n_bins = n_fft // 2 + 1 if onesided else n_fft
+        shape = src.lead + (src.n_bins, src.n_frames, 2)
+        return cls(src, 'stft', shape, _transposed_strides(src.lead, (src.n_frames, src.n_bins, 2), -3, -2))
 
     def pending(self):
         return self._value is None
 
     def with_norm(self, power):
-        p = self._plan
-        return DeferredSpectral(p, 'spec', p.lead + (p.n_bins, p.n_frames),
-                                _transposed_strides(p.lead, (p.n_frames, p.n_bins), -2, -1), power=power)
+        s = self._src
+        return DeferredSpectral(s, 'spec', s.lead + (s.n_bins, s.n_frames),
+                                _transposed_strides(s.lead, (s.n_frames, s.n_bins), -2, -1), power=power)
 
     def with_filterbank(self, fb):
-        p = self._plan
-        return DeferredSpectral(p, 'mel', p.lead + (fb.shape[1], p.n_frames),
-                                _transposed_strides(p.lead, (p.n_frames, fb.shape[1]), -2, -1),
+        s = self._src
+        s.watch(fb, 'filterbank')
+        return DeferredSpectral(s, 'mel', s.lead + (fb.shape[1], s.n_frames),
+                                _transposed_strides(s.lead, (s.n_frames, fb.shape[1]), -2, -1),
                                 power=self._power, filterbank=fb)
 
     def with_db(self, ref, amin):
-        return DeferredSpectral(self._plan, self._stage, tuple(self.shape), tuple(self.stride()),
+        return DeferredSpectral(self._src, self._stage, tuple(self.shape), tuple(self.stride()),
                                 power=self._power, filterbank=self._fb, db=(ref, amin))
 
     # -- materialisation --------------------------------------------------------
+    def _launch(self):
+        from ._ops import ops
+        s = self._src
+        ref, amin = self._db if self._db is not None else (1.0, 1e-7)
+        if self._stage == 'stft':
+            return ops.stft(s.wave, s.window, *s.args)
+        if self._stage == 'spec':
+            return ops.spectrogram(s.wave, s.window, *s.args, float(self._power), self._db is not None, float(ref),
+                                   float(amin))
+        return ops.melspectrogram(s.wave, s.window, self._fb, *s.args, float(self._power), self._db is not None,
+                                  float(ref), float(amin))
+
     def realize(self):
         if self._value is None:
-            p = self._plan
-            if self._stage == 'stft':
-                v = p.run_stft()
-            elif self._stage == 'spec':
-                v = p.run_spectrogram(self._power, self._db)
-            else:
-                v = p.run_melspec(self._power, self._fb, self._db)
+            s = self._src
+            s.check_unchanged()
+            now = torch.cuda.current_stream(s.wave.device)
+            if now == s.stream:
+                v = self._launch()
+            else:                               # enqueue where forward() was called, then order the consumer behind it
+                with torch.cuda.stream(s.stream):
+                    v = self._launch()
+                    done = torch.cuda.Event()
+                    done.record(s.stream)
+                now.wait_event(done)
+                v.record_stream(now)
             self._value = v
-            self._plan = None
+            self._src = None
             self._fb = None
         return self._value
 
@@ -105,8 +174,8 @@ def _transposed_strides(lead, tail, a, b):
 
 
 def realize(x):
-    """Materialise a deferred layer-chain result (no-op for ordinary tensors).  The kernel is enqueued
-    on the current HIP stream; like any CUDA/HIP op it completes asynchronously."""
+    """Materialise a deferred layer-chain result (no-op for ordinary tensors).  The kernel is enqueued on the HIP
+    stream that was current when the chain's STFT was called; like any HIP op it completes asynchronously."""
     if isinstance(x, DeferredSpectral):
         return x.realize()
     return x

@@ -27,7 +27,7 @@ EXPORTS = (
     'tac_strerror', 'tac_last_hip_error', 'tac_abi_version', 'tac_num_frames', 'tac_num_bins',
     'tac_stft_f32', 'tac_spectrogram_f32', 'tac_melspec_f32', 'tac_melspec_supported', 'tac_filterbank_plan',
     'tac_melbank_pack', 'tac_melspec_sparse_f32',
-    'tac_apply_filterbank_f32', 'tac_apply_filterbank_sparse_f32', 'tac_complex_norm_f32', 'tac_magphase_f32', 'tac_phase_vocoder_f32', 'tac_amplitude_to_db_f32',
+    'tac_apply_filterbank_f32', 'tac_apply_filterbank_sparse_f32', 'tac_complex_norm_f32', 'tac_magphase_f32', 'tac_phase_vocoder_f32', 'tac_phase_vocoder_f64', 'tac_amplitude_to_db_f32',
     'tac_db_to_amplitude_f32', 'tac_mulaw_encode_f32_i64', 'tac_mulaw_decode_i64_f32',
     'tac_mulaw_decode_f32_f32',
 )
@@ -102,14 +102,15 @@ def lib():
         h.tac_complex_norm_f32.argtypes = [_P, _I64, _F, _P, _P]
         h.tac_magphase_f32.argtypes = [_P, _I64, _F, _P, _P, _P]
         h.tac_phase_vocoder_f32.argtypes = [_P, _I64, _I32, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _I64, _P, _P]
+        h.tac_phase_vocoder_f64.argtypes = h.tac_phase_vocoder_f32.argtypes
         h.tac_amplitude_to_db_f32.argtypes = [_P, _I64, _F, _F, _P, _P]
         h.tac_db_to_amplitude_f32.argtypes = [_P, _I64, _F, _P, _P]
         h.tac_mulaw_encode_f32_i64.argtypes = [_P, _I64, _I32, _P, _I32, _I32, _I32, _P, _P]
         h.tac_mulaw_decode_i64_f32.argtypes = [_P, _I64, _I32, _P, _P, _P]
-        h.tac_mulaw_decode_f32_f32.argtypes = [_P, _I64, _I32, _P, _P]
+        h.tac_mulaw_decode_f32_f32.argtypes = [_P, _I64, _I32, _P, _P, _P]
         for name in EXPORTS:
             fn = getattr(h, name)
-            if name.endswith(('_f32', '_i64', '_plan', '_supported', '_pack')):
+            if name.endswith(('_f32', '_f64', '_i64', '_plan', '_supported', '_pack')):
                 fn.restype = ctypes.c_int
         _lib = h
     return _lib

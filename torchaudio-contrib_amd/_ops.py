@@ -1,0 +1,355 @@
+"""``torch.library`` registration of the path: every functional of the reference's API is one PyTorch custom op in
+the ``tac_amd`` namespace, so the dispatcher, ``torch.compile`` / FakeTensor tracing, autograd and the profiler
+see them by name.
+
+    op                      CUDA (= HIP on ROCm) kernel                 CPU kernel            Meta (fake)
+    tac_amd::stft           gfx950 kernels through the C ABI (_hip.py)  stock torch ops       shapes + strides
+    tac_amd::spectrogram        "      (STFT + |.|^p [+ dB] fused)      (_composite.py)
+    tac_amd::melspectrogram     "      (the whole chain in ONE kernel)
+    tac_amd::apply_filterbank, complex_norm, angle, magphase, phase_vocoder, amplitude_to_db, db_to_amplitude,
+    tac_amd::mu_law_encoding, mu_law_decoding                           likewise
+
+Routing on a HIP device: float32 (and float16/bfloat16, widened as ``torch.stft`` widens half input) always runs
+the hand-written kernels and raises if ``libtac_amd.so`` is missing.  float64 — which the gfx950 kernels do not
+compute — and fft sizes outside the kernels' range are evaluated by torch's own GPU operators
+(``_composite.py``) with a one-time ``CompositeRouteWarning``; ``set_strict(True)`` turns that route into an error
+(the GPU parity tests run strict, so nothing they check can have come from anywhere but the HIP kernels).
+
+Autograd: the fused Melspectrogram(+dB) chain has hand-written backward kernels (``tac_amd::melspectrogram_backward``);
+every other op differentiates by re-evaluating itself with torch ops under ``enable_grad`` (documented fallback).
+"""
+import warnings
+
+import torch
+from torch.library import Library
+
+from . import _composite as C
+from . import _hip as H
+
+NS = 'tac_amd'
+_lib = Library(NS, 'DEF')
+
+_strict = False
+_warned = set()
+#: how many op calls took the stock-torch route, per (op, reason) — introspection for tests / users
+composite_calls = {}
+
+
+class CompositeRouteWarning(UserWarning):
+    """An op was evaluated by stock torch operators instead of the gfx950 kernels (float64 input, unsupported size)."""
+
+
+def set_strict(flag):
+    """With strict on, a tensor on a HIP device is never handed to the stock-torch route: the call raises instead."""
+    global _strict
+    _strict = bool(flag)
+
+
+def strict():
+    return _strict
+
+
+def _composite_route(op, reason):
+    composite_calls[(op, reason)] = composite_calls.get((op, reason), 0) + 1
+    if _strict:
+        raise RuntimeError('tac_amd::%s: %s is outside the gfx950 kernels and strict mode forbids the stock-torch '
+                           'route' % (op, reason))
+    if (op, reason) not in _warned:
+        _warned.add((op, reason))
+        warnings.warn('tac_amd::%s: %s — evaluated by stock torch operators on the device, not by the gfx950 '
+                      'kernels' % (op, reason), CompositeRouteWarning, stacklevel=3)
+
+
+_WIDEN = (torch.float16, torch.bfloat16)
+
+
+def _f32(t):
+    return t.float() if t.dtype in _WIDEN else t
+
+
+def _hip_dtype(*tensors):
+    """None when the gfx950 kernels take these tensors (float32, or half widened), else the reason they do not."""
+    for t in tensors:
+        if t.dtype == torch.float32 or t.dtype in _WIDEN:
+            continue
+        return 'dtype %s' % str(t.dtype).replace('torch.', '')
+    return None
+
+
+def _same_device(op, *tensors):
+    dev = tensors[0].device
+    for t in tensors[1:]:
+        if t.device != dev:
+            raise RuntimeError('tac_amd::%s: tensors are on different devices (%s and %s)' % (op, dev, t.device))
+
+
+# ============================================================================= fake (meta) helpers
+def _swapped(lead, tail, dtype, device, a, b):
+    """empty(lead + tail).transpose(a, b): the frame-major physical layout every STFT-family kernel writes, returned
+    as the logical (.., freq, time[, 2]) view — the same strides the reference's own torch ops produce."""
+    return torch.empty(tuple(lead) + tuple(tail), dtype=dtype, device=device).transpose(a, b)
+
+
+def _out_dtype(t):
+    return torch.float32 if t.dtype in _WIDEN else t.dtype
+
+
+def _n_frames(length, n_fft, hop, center):
+    return 1 + (length + (2 * (n_fft // 2) if center else 0) - n_fft) // hop
+
+
+# ============================================================================= autograd by re-evaluation
+def _autograd_by_recompute(op, fn, n_tensors):
+    """Backward of an op without hand-written gradient kernels: re-evaluate it with differentiable torch operators
+    (``_composite``) on the saved inputs and differentiate that."""
+
+    def setup_context(ctx, inputs, output):
+        ctx.save_for_backward(*inputs[:n_tensors])
+        ctx.rest = tuple(inputs[n_tensors:])
+
+    def backward(ctx, *grads):
+        needs = ctx.needs_input_grad[:n_tensors]
+        with torch.enable_grad():
+            ins = [t.detach().requires_grad_(True) if (need and t.is_floating_point()) else t.detach()
+                   for t, need in zip(ctx.saved_tensors, needs)]
+            outs = fn(*ins, *ctx.rest)
+            outs = outs if isinstance(outs, tuple) else (outs,)
+            pairs = [(o, g) for o, g in zip(outs, grads) if g is not None and o.requires_grad]
+            wanted = [t for t in ins if t.requires_grad]
+            got = iter(torch.autograd.grad([o for o, _ in pairs], wanted, [g for _, g in pairs], allow_unused=True)
+                       if pairs and wanted else ())
+        result = [next(got, None) if t.requires_grad else None for t in ins]
+        return tuple(result) + (None,) * len(ctx.rest)
+
+    torch.library.register_autograd('%s::%s' % (NS, op), backward, setup_context=setup_context, lib=_lib)
+
+
+def _register(op, schema, cuda, cpu, fake, n_tensors, differentiable=True):
+    _lib.define(op + schema)
+    _lib.impl(op, cuda, 'CUDA')
+    _lib.impl(op, cpu, 'CPU')
+    torch.library.register_fake('%s::%s' % (NS, op), fake, lib=_lib)
+    if differentiable:
+        _autograd_by_recompute(op, cpu, n_tensors)
+
+
+# ============================================================================= stft
+_STFT_ARGS = 'int n_fft, int hop, int win_length, bool center, str pad_mode, bool normalized, bool onesided'
+
+
+def _stft_route(op, wave, n_fft, *others):
+    reason = _hip_dtype(wave, *others)
+    if reason is None and not H.hip_covers_n_fft(n_fft):
+        reason = 'fft_length %d' % n_fft
+    if reason is not None:
+        _composite_route(op, reason)
+    return reason
+
+
+def _stft_cuda(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided):
+    _same_device('stft', wave, window)
+    if _stft_route('stft', wave, n_fft, window) is not None:
+        return C.stft(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided)
+    return H.stft(_f32(wave), _f32(window).contiguous(), n_fft, hop, win_length, center, pad_mode, normalized,
+                  onesided)
+
+
+def _stft_fake(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided):
+    n_bins = n_fft // 2 + 1 if onesided else n_fft
+    frames = _n_frames(wave.shape[-1], n_fft, hop, center)
+    return _swapped(wave.shape[:-1], (frames, n_bins, 2), _out_dtype(wave), wave.device, -3, -2)
+
+
+_register('stft', '(Tensor wave, Tensor window, %s) -> Tensor' % _STFT_ARGS, _stft_cuda, C.stft, _stft_fake, 2)
+
+
+# ============================================================================= spectrogram (stft + |.|^p [+ dB])
+def _spectrogram_cuda(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided, power, db, ref,
+                      amin):
+    _same_device('spectrogram', wave, window)
+    if _stft_route('spectrogram', wave, n_fft, window) is not None:
+        return C.spectrogram(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided, power, db,
+                             ref, amin)
+    return H.spectrogram(_f32(wave), _f32(window).contiguous(), n_fft, hop, win_length, center, pad_mode, normalized,
+                         onesided, power, db, ref, amin)
+
+
+def _spectrogram_fake(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided, power, db, ref,
+                      amin):
+    n_bins = n_fft // 2 + 1 if onesided else n_fft
+    frames = _n_frames(wave.shape[-1], n_fft, hop, center)
+    return _swapped(wave.shape[:-1], (frames, n_bins), _out_dtype(wave), wave.device, -2, -1)
+
+
+_register('spectrogram', '(Tensor wave, Tensor window, %s, float power, bool db, float ref, float amin) -> Tensor'
+          % _STFT_ARGS, _spectrogram_cuda, C.spectrogram, _spectrogram_fake, 2)
+
+
+# ============================================================================= melspectrogram (the fused chain)
+def _melspectrogram_cuda(wave, window, bank, n_fft, hop, win_length, center, pad_mode, normalized, onesided, power,
+                         db, ref, amin):
+    _same_device('melspectrogram', wave, window, bank)
+    if _stft_route('melspectrogram', wave, n_fft, window, bank) is not None:
+        return C.melspectrogram(wave, window, bank, n_fft, hop, win_length, center, pad_mode, normalized, onesided,
+                                power, db, ref, amin)
+    return H.melspectrogram(_f32(wave), _f32(window).contiguous(), _f32(bank), n_fft, hop, win_length, center,
+                            pad_mode, normalized, onesided, power, db, ref, amin)
+
+
+def _melspectrogram_fake(wave, window, bank, n_fft, hop, win_length, center, pad_mode, normalized, onesided, power,
+                         db, ref, amin):
+    frames = _n_frames(wave.shape[-1], n_fft, hop, center)
+    return _swapped(wave.shape[:-1], (frames, bank.shape[1]), _out_dtype(wave), wave.device, -2, -1)
+
+
+_lib.define('melspectrogram(Tensor wave, Tensor window, Tensor filterbank, %s, float power, bool db, float ref, '
+            'float amin) -> Tensor' % _STFT_ARGS)
+_lib.impl('melspectrogram', _melspectrogram_cuda, 'CUDA')
+_lib.impl('melspectrogram', C.melspectrogram, 'CPU')
+torch.library.register_fake(NS + '::melspectrogram', _melspectrogram_fake, lib=_lib)
+_autograd_by_recompute('melspectrogram', C.melspectrogram, 3)
+
+
+# ============================================================================= apply_filterbank
+def _apply_filterbank_cuda(spec, bank):
+    _same_device('apply_filterbank', spec, bank)
+    if _hip_dtype(spec, bank) is not None:
+        _composite_route('apply_filterbank', _hip_dtype(spec, bank))
+        return C.apply_filterbank(spec, bank)
+    out = H.apply_filterbank(_f32(spec), _f32(bank))
+    return out if spec.dtype == out.dtype else out.to(spec.dtype)
+
+
+def _apply_filterbank_fake(spec, bank):
+    return _swapped(spec.shape[:-2], (spec.shape[-1], bank.shape[1]), spec.dtype, spec.device, -2, -1)
+
+
+_register('apply_filterbank', '(Tensor spec, Tensor filterbank) -> Tensor', _apply_filterbank_cuda,
+          C.apply_filterbank, _apply_filterbank_fake, 2)
+
+
+# ============================================================================= complex pairs
+def _pairwise_cuda(op, hip_fn, composite_fn):
+    def run(z, *args):
+        reason = _hip_dtype(z)
+        if reason is not None:
+            _composite_route(op, reason)
+            return composite_fn(z, *args)
+        out = hip_fn(_f32(z), *args)
+        if z.dtype in _WIDEN:
+            out = tuple(o.to(z.dtype) for o in out) if isinstance(out, tuple) else out.to(z.dtype)
+        return out
+    return run
+
+
+def _pair_meta(z):
+    """Layout of a per-pair result: the kernels keep the (dense) storage order of their input, halved."""
+    if z.stride(-1) == 1 and H.is_dense(z) and not any(s % 2 for s, n in zip(z.stride()[:-1], z.shape[:-1]) if n > 1):
+        return torch.empty_strided(z.shape[:-1], tuple(s // 2 for s in z.stride()[:-1]), dtype=z.dtype, device=z.device)
+    return torch.empty(z.shape[:-1], dtype=z.dtype, device=z.device)
+
+
+def _like_meta(x, dtype=None):
+    return torch.empty_like(x, dtype=dtype) if H.is_dense(x) else torch.empty(x.shape, dtype=dtype or x.dtype,
+                                                                              device=x.device)
+
+
+def _complex_norm_fake(z, power):
+    return _pair_meta(z)
+
+
+_register('complex_norm', '(Tensor z, float power) -> Tensor', _pairwise_cuda('complex_norm', H.complex_norm,
+                                                                               C.complex_norm),
+          C.complex_norm, _complex_norm_fake, 1)
+_register('angle', '(Tensor z) -> Tensor', _pairwise_cuda('angle', H.angle, C.angle), C.angle, _pair_meta, 1)
+_register('magphase', '(Tensor z, float power) -> (Tensor, Tensor)', _pairwise_cuda('magphase', H.magphase, C.magphase),
+          C.magphase, lambda z, power: (_pair_meta(z), _pair_meta(z)), 1)
+
+
+# ============================================================================= phase vocoder
+def _phase_vocoder_cuda(spec, phase_advance, rate):
+    _same_device('phase_vocoder', spec, phase_advance)
+    if spec.dtype == torch.float64 and phase_advance.is_floating_point():
+        return H.phase_vocoder(spec, rate, phase_advance)          # the float64 kernel (reference's own test dtype)
+    reason = _hip_dtype(spec, phase_advance)
+    if reason is not None:
+        _composite_route('phase_vocoder', reason)
+        return C.phase_vocoder(spec, rate, phase_advance)
+    out = H.phase_vocoder(_f32(spec), rate, _f32(phase_advance))
+    return out if spec.dtype == out.dtype else out.to(spec.dtype)
+
+
+def _phase_vocoder_cpu(spec, phase_advance, rate):
+    return C.phase_vocoder(spec, rate, phase_advance)
+
+
+def _phase_vocoder_fake(spec, phase_advance, rate):
+    n_out = H.phase_vocoder_out_frames(spec.shape[-2], rate)
+    return _swapped(spec.shape[:-3], (n_out, spec.shape[-3], 2), spec.dtype, spec.device, -3, -2)
+
+
+_register('phase_vocoder', '(Tensor spec, Tensor phase_advance, float rate) -> Tensor', _phase_vocoder_cuda,
+          _phase_vocoder_cpu, _phase_vocoder_fake, 2)
+
+
+# ============================================================================= dB
+def _unary_cuda(op, hip_fn, composite_fn):
+    def run(x, *args):
+        reason = _hip_dtype(x)
+        if reason is not None:
+            _composite_route(op, reason)
+            return composite_fn(x, *args)
+        out = hip_fn(_f32(x), *args)
+        return out if x.dtype == out.dtype else out.to(x.dtype)
+    return run
+
+
+_register('amplitude_to_db', '(Tensor x, float ref, float amin) -> Tensor',
+          _unary_cuda('amplitude_to_db', H.amplitude_to_db, C.amplitude_to_db), C.amplitude_to_db,
+          lambda x, ref, amin: _like_meta(x), 1)
+_register('db_to_amplitude', '(Tensor x, float ref) -> Tensor',
+          _unary_cuda('db_to_amplitude', H.db_to_amplitude, C.db_to_amplitude), C.db_to_amplitude,
+          lambda x, ref: _like_meta(x), 1)
+
+
+# ============================================================================= mu-law
+def _mu_law_encoding_cuda(x, n_quantize):
+    if not x.is_floating_point():
+        x = x.to(torch.float)                              # reference functional.py:329-330
+    reason = _hip_dtype(x)
+    if reason is not None:
+        _composite_route('mu_law_encoding', reason)
+        return C.mu_law_encoding(x, n_quantize)
+    return H.mu_law_encoding(_f32(x), n_quantize)
+
+
+_register('mu_law_encoding', '(Tensor x, int n_quantize) -> Tensor', _mu_law_encoding_cuda, C.mu_law_encoding,
+          lambda x, n_quantize: torch.empty(x.shape, dtype=torch.int64, device=x.device), 1, differentiable=False)
+
+
+def _mu_law_decoding_cuda(codes, n_quantize, dtype):
+    if not codes.is_floating_point():
+        if dtype == torch.float32:
+            return H.mu_law_decoding_int(codes, n_quantize)
+        if dtype in _WIDEN:
+            return H.mu_law_decoding_int(codes, n_quantize).to(dtype)
+        _composite_route('mu_law_decoding', 'dtype %s' % str(dtype).replace('torch.', ''))
+        return C.mu_law_decoding(codes, n_quantize, dtype)
+    reason = _hip_dtype(codes)
+    if reason is not None:
+        _composite_route('mu_law_decoding', reason)
+        return C.mu_law_decoding(codes, n_quantize, dtype)
+    out = H.mu_law_decoding_float(_f32(codes), n_quantize)
+    return out if codes.dtype == out.dtype else out.to(codes.dtype)
+
+
+def _mu_law_decoding_fake(codes, n_quantize, dtype):
+    if codes.is_floating_point():
+        return _like_meta(codes)
+    return torch.empty(codes.shape, dtype=dtype, device=codes.device)
+
+
+_register('mu_law_decoding', '(Tensor codes, int n_quantize, ScalarType dtype) -> Tensor', _mu_law_decoding_cuda,
+          C.mu_law_decoding, _mu_law_decoding_fake, 1)
+
+ops = getattr(torch.ops, NS)

@@ -195,9 +195,19 @@ mulaw_decode_i64_kernel(const long long* __restrict__ codes, long long n, int nq
     }
 }
 
+// float-valued codes: an integral code inside the table takes the table entry (the reference bit-compares exactly
+// this input, tests/test_functional.py:182-193: `waveform_mu.float()`), everything else the closed form
 struct MulawExpandOp {
     float mu, log1p_mu;
-    __device__ __forceinline__ float operator()(float c) const { return mulaw_expand(c, mu, log1p_mu); }
+    const float* lut;
+    int nq;
+    __device__ __forceinline__ float operator()(float c) const {
+        if (lut != nullptr && c >= 0.0f && c < (float)nq) {
+            const int i = (int)c;
+            if ((float)i == c) return lut[i];
+        }
+        return mulaw_expand(c, mu, log1p_mu);
+    }
 };
 
 template <class Op>
@@ -287,10 +297,11 @@ int tac_mulaw_decode_i64_f32(const int64_t* codes, int64_t n, int32_t n_quantize
     return TAC_OK;
 }
 
-int tac_mulaw_decode_f32_f32(const float* codes, int64_t n, int32_t n_quantize, float* out, void* stream) {
+int tac_mulaw_decode_f32_f32(const float* codes, int64_t n, int32_t n_quantize, const float* lut, float* out,
+                             void* stream) {
     if (n_quantize < 2) return TAC_E_INVALID;
     const float mu = (float)(n_quantize - 1);
-    return tac::launch_unary(codes, n, tac::MulawExpandOp{mu, tac::exact_log1pf(mu)}, out, stream);
+    return tac::launch_unary(codes, n, tac::MulawExpandOp{mu, tac::exact_log1pf(mu), lut, n_quantize}, out, stream);
 }
 
 }  // extern "C"

@@ -110,7 +110,7 @@ const char* tac_strerror(int code) {
 
 int tac_last_hip_error(void) { return tac::g_last_hip_error; }
 
-int tac_abi_version(void) { return 1; }
+int tac_abi_version(void) { return 2; }
 
 int64_t tac_num_frames(int64_t L, int n_fft, int hop, int center) {
     if (L <= 0 || n_fft <= 0 || hop <= 0) return 0;

@@ -13,40 +13,94 @@ namespace tac {
 
 constexpr int PV_THREADS = 256;
 
+// Precision.  The reference evaluates the recurrence in the dtype of its input, and in float32 that is
+// ill-conditioned: `angle_1 - angle_0 - phase_advance` is rounded at the magnitude of the phase advance (up to
+// pi*hop, i.e. several hundred radians: spacing 6e-5) and the running sum at its own magnitude (thousands of
+// radians: spacing 5e-4), which is why the reference's own test runs it in float64 (tests/test_functional.py:85-88).
+// Here the samples, arctangents, magnitudes and outputs have the precision of T, but the phase increment and the
+// running sum are always carried in float64, so a float32 call agrees with the float64 evaluation of the same
+// inputs to ~1e-6 instead of ~1e-3; T = double is the reference's float64 path as is.
+template <class T>
+struct pv_math;
+template <>
+struct pv_math<float> {
+    static __device__ __forceinline__ float atan2(float y, float x) { return atan2f(y, x); }
+    static __device__ __forceinline__ float hypot(float x, float y) { return sqrtf(x * x + y * y); }
+    static __device__ __forceinline__ void sincos(double a, float* s, float* c) {
+        const double turns = rint(a * 0.15915494309189535);
+        sincosf((float)(a - turns * 6.283185307179586), s, c);      // reduced in float64, evaluated in float32
+    }
+};
+template <>
+struct pv_math<double> {
+    static __device__ __forceinline__ double atan2(double y, double x) { return ::atan2(y, x); }
+    static __device__ __forceinline__ double hypot(double x, double y) { return sqrt(x * x + y * y); }
+    static __device__ __forceinline__ void sincos(double a, double* s, double* c) { ::sincos(a, s, c); }
+};
+
+template <class T>
 __global__ void __launch_bounds__(PV_THREADS)
-phase_vocoder_kernel(const float* __restrict__ spec, long long rows, int n_freqs, int n_frames, long long stride_r,
-                     long long stride_f, long long stride_t, const float* __restrict__ phase_advance,
-                     const int* __restrict__ idx0, const int* __restrict__ idx1, const float* __restrict__ alpha,
-                     int n_out, float* __restrict__ out) {
+phase_vocoder_kernel(const T* __restrict__ spec, long long rows, int n_freqs, int n_frames, long long stride_r,
+                     long long stride_f, long long stride_t, const T* __restrict__ phase_advance,
+                     const int* __restrict__ idx0, const int* __restrict__ idx1, const T* __restrict__ alpha,
+                     int n_out, T* __restrict__ out) {
+    using M = pv_math<T>;
+    typedef T T2 __attribute__((ext_vector_type(2)));      // one (re, im) pair = one 8- / 16-byte access
     const int fblocks = (n_freqs + PV_THREADS - 1) / PV_THREADS;
     const long long row = blockIdx.x / fblocks;
     const int f = (int)(blockIdx.x % fblocks) * PV_THREADS + threadIdx.x;
     if (row >= rows || f >= n_freqs) return;
-    const float* base = spec + row * stride_r + (long long)f * stride_f;
-    auto frame = [&](int t) -> cf {            // the two frames past the end are the reference's zero padding
-        if (t >= n_frames) return mkc(0.0f, 0.0f);
-        const float* p = base + (long long)t * stride_t;
-        return mkc(p[0], p[1]);
+    const T* base = spec + row * stride_r + (long long)f * stride_f;
+    T re0, im0, re1, im1;
+    auto frame = [&](int t, T& re, T& im) {     // the two frames past the end are the reference's zero padding
+        if (t >= n_frames) {
+            re = im = (T)0;
+            return;
+        }
+        const T2 v = *reinterpret_cast<const T2*>(base + (long long)t * stride_t);
+        re = v.x;
+        im = v.y;
     };
-    const float two_pi = 6.283185307179586f;   // float32(2*math.pi), as the reference's scalar ops see it
-    const float pa = phase_advance[f];
-    const cf z0 = frame(0);
-    float acc = atan2f(z0.y, z0.x);            // phase of the first input frame opens the running sum
-    float* o = out + (row * n_out * (long long)n_freqs + f) * 2;
+    const double two_pi = 6.283185307179586;
+    const double pa = (double)phase_advance[f];
+    frame(0, re0, im0);
+    double acc = (double)M::atan2(im0, re0);    // phase of the first input frame opens the running sum
+    T* o = out + (row * n_out * (long long)n_freqs + f) * 2;
     for (int i = 0; i < n_out; ++i) {
-#pragma clang fp contract(off)                 // the reference rounds every product before it adds: keep its op sequence
-        const cf a = frame(idx0[i]), b = frame(idx1[i]);
-        const float n0 = sqrtf(a.x * a.x + a.y * a.y), n1 = sqrtf(b.x * b.x + b.y * b.y);
-        const float w = alpha[i];
-        const float mag = w * n1 + (1.0f - w) * n0;
-        float sn, cs;
-        sincosf(acc, &sn, &cs);
-        *reinterpret_cast<cf*>(o) = mkc(mag * cs, mag * sn);
+        frame(idx0[i], re0, im0);
+        frame(idx1[i], re1, im1);
+        const T n0 = M::hypot(re0, im0), n1 = M::hypot(re1, im1);
+        const T w = alpha[i];
+        const T mag = w * n1 + ((T)1 - w) * n0;
+        T sn, cs;
+        M::sincos(acc, &sn, &cs);
+        T2 res;
+        res.x = mag * cs;
+        res.y = mag * sn;
+        *reinterpret_cast<T2*>(o) = res;
         o += 2 * (long long)n_freqs;
-        float ph = atan2f(b.y, b.x) - atan2f(a.y, a.x) - pa;
-        ph = ph - two_pi * rintf(ph / two_pi);
+        double ph = (double)M::atan2(im1, re1) - (double)M::atan2(im0, re0) - pa;
+        ph = ph - two_pi * rint(ph / two_pi);
         acc += ph + pa;
     }
+}
+
+template <class T>
+static int launch_phase_vocoder(const T* spec, int64_t rows, int32_t n_freqs, int64_t n_frames, int64_t stride_r,
+                                int64_t stride_f, int64_t stride_t, const T* phase_advance, const int32_t* idx0,
+                                const int32_t* idx1, const T* alpha, int64_t n_out, T* out, void* stream) {
+    if (rows == 0 || n_out == 0 || n_freqs == 0) return TAC_OK;
+    if (!spec || !phase_advance || !idx0 || !idx1 || !alpha || !out) return TAC_E_INVALID;
+    if (rows < 0 || n_freqs < 0 || n_frames <= 0 || n_out < 0) return TAC_E_INVALID;
+    if (n_frames >= 0x7fffffffLL || n_out >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
+    const long long fblocks = (n_freqs + PV_THREADS - 1) / PV_THREADS;
+    const long long blocks = rows * fblocks;
+    if (blocks >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
+    hipLaunchKernelGGL(phase_vocoder_kernel<T>, dim3((unsigned)blocks), dim3(PV_THREADS), 0, (hipStream_t)stream, spec,
+                       (long long)rows, (int)n_freqs, (int)n_frames, (long long)stride_r, (long long)stride_f,
+                       (long long)stride_t, phase_advance, idx0, idx1, alpha, (int)n_out, out);
+    TAC_HIP(hipGetLastError());
+    return TAC_OK;
 }
 
 }  // namespace tac
@@ -56,19 +110,15 @@ extern "C" {
 int tac_phase_vocoder_f32(const float* spec, int64_t rows, int32_t n_freqs, int64_t n_frames, int64_t stride_r,
                           int64_t stride_f, int64_t stride_t, const float* phase_advance, const int32_t* idx0,
                           const int32_t* idx1, const float* alpha, int64_t n_out, float* out, void* stream) {
-    using namespace tac;
-    if (rows == 0 || n_out == 0 || n_freqs == 0) return TAC_OK;
-    if (!spec || !phase_advance || !idx0 || !idx1 || !alpha || !out) return TAC_E_INVALID;
-    if (rows < 0 || n_freqs < 0 || n_frames <= 0 || n_out < 0) return TAC_E_INVALID;
-    if (n_frames >= 0x7fffffffLL || n_out >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
-    const long long fblocks = (n_freqs + PV_THREADS - 1) / PV_THREADS;
-    const long long blocks = rows * fblocks;
-    if (blocks >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
-    hipLaunchKernelGGL(phase_vocoder_kernel, dim3((unsigned)blocks), dim3(PV_THREADS), 0, (hipStream_t)stream, spec,
-                       (long long)rows, (int)n_freqs, (int)n_frames, (long long)stride_r, (long long)stride_f,
-                       (long long)stride_t, phase_advance, idx0, idx1, alpha, (int)n_out, out);
-    TAC_HIP(hipGetLastError());
-    return TAC_OK;
+    return tac::launch_phase_vocoder<float>(spec, rows, n_freqs, n_frames, stride_r, stride_f, stride_t, phase_advance,
+                                            idx0, idx1, alpha, n_out, out, stream);
+}
+
+int tac_phase_vocoder_f64(const double* spec, int64_t rows, int32_t n_freqs, int64_t n_frames, int64_t stride_r,
+                          int64_t stride_f, int64_t stride_t, const double* phase_advance, const int32_t* idx0,
+                          const int32_t* idx1, const double* alpha, int64_t n_out, double* out, void* stream) {
+    return tac::launch_phase_vocoder<double>(spec, rows, n_freqs, n_frames, stride_r, stride_f, stride_t, phase_advance,
+                                             idx0, idx1, alpha, n_out, out, stream);
 }
 
 }  // extern "C"

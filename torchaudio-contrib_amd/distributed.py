@@ -27,6 +27,16 @@ def shard_batch(x, world_size=None, rank=None):
     return x[b:e]
 
 
+def _row_major(t):
+    """Strides are those of a C-contiguous tensor of this shape (size-1 dims aside) — also meaningful for 0 rows."""
+    expect = 1
+    for n, st in zip(reversed(t.shape[1:]), reversed(t.stride()[1:])):
+        if n != 1 and st != expect:
+            return False
+        expect *= n
+    return t.shape[0] <= 1 or t.stride(0) == expect
+
+
 def all_gather_batch(local, total_rows=None, group=None):
     """Concatenate every rank's output shard along dim 0 with a single collective.
 
@@ -39,8 +49,12 @@ def all_gather_batch(local, total_rows=None, group=None):
     world = dist.get_world_size(group)
     if world == 1:
         return local
-    transposed = local.dim() >= 2 and not local.is_contiguous() and local.transpose(-2, -1).is_contiguous()
-    phys = local.transpose(-2, -1) if transposed else local.contiguous()
+    # dim 0 must stay dim 0 of the physical buffer: the (.., M, T) views of the layers qualify from 3-D upwards; for a
+    # 2-D (M, T) view the transpose IS dim 0, so that one is gathered through a contiguous copy instead
+    # (decided from the strides alone, so that a rank holding zero rows — for which torch reports every layout as
+    # contiguous — takes the same branch as its peers)
+    transposed = local.dim() >= 3 and not _row_major(local) and _row_major(local.transpose(-2, -1))
+    phys = local.transpose(-2, -1) if transposed else (local if _row_major(local) else local.contiguous())
     rows = phys.shape[0]
     if total_rows is None:
         cnt = torch.tensor([rows], dtype=torch.int64, device=phys.device)
@@ -52,13 +66,18 @@ def all_gather_batch(local, total_rows=None, group=None):
         out = torch.empty((total_rows,) + tuple(phys.shape[1:]), dtype=phys.dtype, device=phys.device)
         dist.all_gather_into_tensor(out, phys, group=group)
     else:
-        # uneven tail: still ONE collective — pad every shard to the largest, gather, drop the padding
+        # uneven tail (sizes differ by at most one row, a rank may even own none): still ONE collective — every rank
+        # contributes `biggest` rows (only the short ranks copy theirs into a padded buffer), then the padding rows
+        # are dropped with one compacting copy
         biggest = max(sizes)
-        padded = phys.new_zeros((biggest,) + tuple(phys.shape[1:]))
-        padded[:rows] = phys
+        if rows == biggest:
+            padded = phys.contiguous()
+        else:
+            padded = phys.new_empty((biggest,) + tuple(phys.shape[1:]))
+            padded[:rows] = phys
         buf = torch.empty((world * biggest,) + tuple(phys.shape[1:]), dtype=phys.dtype, device=phys.device)
         dist.all_gather_into_tensor(buf, padded, group=group)
-        out = torch.cat([buf[r * biggest:r * biggest + n] for r, n in enumerate(sizes)], dim=0)
+        out = torch.cat([buf[r * biggest:r * biggest + n] for r, n in enumerate(sizes) if n], dim=0)
     return out.transpose(-2, -1) if transposed else out
 
 
@@ -74,7 +93,14 @@ class ShardedPipeline(torch.nn.Module):
     def forward(self, whole_batch):
         world = dist.get_world_size(self.group)
         rank = dist.get_rank(self.group)
-        local = self.pipeline(shard_batch(whole_batch, world, rank))
+        shard = shard_batch(whole_batch, world, rank)
+        if shard.shape[0] == 0 and whole_batch.shape[0] > 0:
+            # fewer rows than ranks: this rank owns none.  It must still enter the collective (the others would hang
+            # until the RCCL timeout), so it runs the pipeline on one borrowed row to learn the output layout and
+            # contributes zero rows of it.
+            local = self.pipeline(whole_batch[:1])[:0]
+        else:
+            local = self.pipeline(shard)
         if not self.gather:
             from ._lazy import realize
             return realize(local)

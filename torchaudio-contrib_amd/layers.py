@@ -13,7 +13,8 @@ import torch
 import torch.nn as nn
 
 from . import functional as F
-from ._lazy import DeferredSpectral, lazy_fusion_enabled, realize
+from . import _hip
+from ._lazy import DeferredSpectral, can_defer, lazy_fusion_enabled, realize
 
 
 class _ModuleNoStateBuffers(nn.Module):
@@ -59,15 +60,16 @@ class STFT(_ModuleNoStateBuffers):
             window = torch.hann_window(fft_length if win_length is None else win_length)
         self.register_buffer('window', window)
 
-    def _plan(self, waveforms):
-        return F._StftPlan(waveforms, self.fft_length, self.hop_length, self.win_length, self.window,
-                           self.center, self.pad_mode, self.normalized, self.onesided)
-
     def forward(self, waveforms):
-        plan = self._plan(waveforms)                 # validates now, so errors surface here
-        if lazy_fusion_enabled():
-            return DeferredSpectral.from_plan(plan)
-        return plan.run_stft()
+        if torch.is_tensor(waveforms) and can_defer(waveforms, self.window):
+            # validate now, so errors surface here; the launch itself waits for the rest of the chain (_lazy.py)
+            n_fft, hop, win_length, window = F.resolve_stft_args(waveforms, self.fft_length, self.hop_length,
+                                                                 self.win_length, self.window)
+            _hip.check_stft_args(waveforms.shape, n_fft, hop, win_length, self.center, self.pad_mode)
+            return DeferredSpectral.from_stft(waveforms, window, n_fft, hop, win_length, bool(self.center),
+                                              self.pad_mode, bool(self.normalized), bool(self.onesided))
+        return F.stft(waveforms, self.fft_length, self.hop_length, self.win_length, self.window, self.center,
+                      self.pad_mode, self.normalized, self.onesided)
 
     def __repr__(self):
         head = '(fft_length={}, hop_length={}, win_length={})'.format(
@@ -104,10 +106,12 @@ class ApplyFilterbank(_ModuleNoStateBuffers):
 
     def forward(self, mag_specgrams):
         x = mag_specgrams
+        fb = self.filterbank
         if isinstance(x, DeferredSpectral) and x.pending() and x._stage == 'spec' and x._db is None \
-                and x._plan.can_fuse_mel(self.filterbank, x._power):
-            return x.with_filterbank(self.filterbank)
-        return F.apply_filterbank(x, self.filterbank)
+                and fb.dim() == 2 and fb.shape[0] == x.shape[-2] and fb.device == x.device \
+                and fb.dtype == torch.float32 and not (fb.requires_grad and torch.is_grad_enabled()):
+            return x.with_filterbank(fb)
+        return F.apply_filterbank(x, fb)
 
 
 class Filterbank(object):
@@ -172,10 +176,26 @@ class TimeStretch(_ModuleNoStateBuffers):
 
 
 class _FusedSequential(nn.Sequential):
-    """``nn.Sequential`` returned by the factories: children stay individually usable and
-    ``*``-unpackable; a whole-chain call launches the fused kernel and returns a real tensor."""
+    """``nn.Sequential`` returned by the factories: children stay individually usable and ``*``-unpackable; a
+    whole-chain call is ONE ``tac_amd::spectrogram`` / ``tac_amd::melspectrogram`` op (one kernel on a HIP device,
+    differentiable, traceable by ``torch.compile``) and returns an ordinary tensor."""
 
     def forward(self, input):
+        kids = list(self._modules.values())
+        if lazy_fusion_enabled() and torch.is_tensor(input) and 2 <= len(kids) <= 3 and type(kids[0]) is STFT and type(kids[1]) is ComplexNorm \
+                and (len(kids) == 2 or type(kids[2]) is ApplyFilterbank):
+            st = kids[0]
+            x = realize(input)
+            n_fft, hop, win_length, window = F.resolve_stft_args(x, st.fft_length, st.hop_length, st.win_length,
+                                                                 st.window)
+            _hip.check_stft_args(x.shape, n_fft, hop, win_length, st.center, st.pad_mode)
+            args = (n_fft, hop, win_length, bool(st.center), st.pad_mode, bool(st.normalized), bool(st.onesided),
+                    float(kids[1].power), False, 1.0, 1e-7)
+            if len(kids) == 2:
+                return F._op.spectrogram(x, window, *args)
+            fb = kids[2].filterbank
+            if fb.dim() == 2 and fb.shape[0] == (n_fft // 2 + 1 if st.onesided else n_fft) and fb.device == x.device:
+                return F._op.melspectrogram(x, window, fb, *args)
         return realize(super(_FusedSequential, self).forward(input))
 
 
@@ -217,7 +237,9 @@ class AmplitudeToDb(_ModuleNoStateBuffers):
 
     def forward(self, x):
         if isinstance(x, DeferredSpectral) and x.pending() and x._stage in ('spec', 'mel') and x._db is None:
-            return x.with_db(self.ref, self.amin)
+            # terminal stage: nothing can fuse behind the dB epilogue, so the fused kernel is launched now, on the
+            # stream of the STFT call, and the caller gets an ordinary tensor
+            return x.with_db(self.ref, self.amin).realize()
         return F.amplitude_to_db(x, ref=self.ref, amin=self.amin)
 
     def __repr__(self):
