@@ -31,7 +31,7 @@ class StftGeometry(object):
     functional.py:99-107), cached per (shape, strides, parameters) so that a repeated call costs a dict lookup."""
     __slots__ = ('lead', 'length', 'rows', 'row_stride', 'flatten', 'n_fft', 'hop', 'win_length', 'center',
                  'pad_mode', 'normalized', 'onesided', 'n_frames', 'n_bins', 'fft_kernel', 'desc',
-                 'stft_shape', 'spec_shape')
+                 'stft_shape', 'spec_shape', 'routes')
 
 
 _geometry_cache = {}
@@ -109,6 +109,7 @@ def geometry(wave, n_fft, hop, win_length, center, pad_mode, normalized, oneside
         onesided=1 if onesided else 0, reserved=0)
     g.stft_shape = g.lead + (g.n_frames, g.n_bins, 2)
     g.spec_shape = g.lead + (g.n_frames, g.n_bins)
+    g.routes = {}
     with _lock:
         if len(_geometry_cache) > 512:
             _geometry_cache.clear()
@@ -160,7 +161,7 @@ def _stft_dft(wave, window, g):
     x = x.contiguous()
     mat = _dft_matrix(window, g.n_fft, g.win_length, g.onesided, g.normalized)
     out = torch.empty(g.stft_shape, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _native.on_device(x.device):
         rc = _native.lib().tac_apply_filterbank_f32(
             _native.ptr(x), x.shape[0], g.n_fft, g.n_frames, x.stride(0), 1, g.hop,
             _native.ptr(mat), None, 2 * g.n_bins, _native.ptr(out), _native.stream_ptr(x.device))
@@ -175,7 +176,7 @@ def stft(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, one
         return _stft_dft(wave, window, g)
     src = _rows_of(wave, g)
     out = torch.empty(g.stft_shape, dtype=torch.float32, device=wave.device)
-    with torch.cuda.device(wave.device):
+    with _native.on_device(wave.device):
         rc = _native.lib().tac_stft_f32(_native.ptr(src), _native.ptr(window), g.desc, _native.ptr(out),
                                         _native.stream_ptr(wave.device))
     _native.check(rc, 'tac_stft_f32')
@@ -190,7 +191,7 @@ def spectrogram(wave, window, n_fft, hop, win_length, center, pad_mode, normaliz
         return amplitude_to_db(mag, ref, amin) if db else mag
     src = _rows_of(wave, g)
     out = torch.empty(g.spec_shape, dtype=torch.float32, device=wave.device)
-    with torch.cuda.device(wave.device):
+    with _native.on_device(wave.device):
         rc = _native.lib().tac_spectrogram_f32(
             _native.ptr(src), _native.ptr(window), g.desc, float(power), 1 if db else 0, float(ref), float(amin),
             _native.ptr(out), _native.stream_ptr(wave.device))
@@ -221,7 +222,7 @@ def _melbank_pack(fb, n_fft):
     wpack = torch.empty(3072, dtype=torch.float32, device=fb.device)
     desc = torch.empty(4096, dtype=torch.int32, device=fb.device)
     info = (ctypes.c_int32 * 4)()
-    with torch.cuda.device(fb.device):
+    with _native.on_device(fb.device):
         rc = _native.lib().tac_melbank_pack(_native.ptr(fb), n_freqs, n_mels, n_fft, _native.ptr(wpack), 3072,
                                             _native.ptr(desc), 4096, ctypes.cast(info, ctypes.c_void_p),
                                             _native.stream_ptr(fb.device))
@@ -246,7 +247,7 @@ def _filterbank_plan(fb):
     n_ints = 2 * ((n_mels + 15) // 16)
     plan = torch.empty(n_ints, dtype=torch.int32, device=fb.device)
     host = (ctypes.c_int32 * n_ints)()
-    with torch.cuda.device(fb.device):
+    with _native.on_device(fb.device):
         rc = _native.lib().tac_filterbank_plan(_native.ptr(fb), n_freqs, n_mels, _native.ptr(plan),
                                                ctypes.cast(host, ctypes.c_void_p), _native.stream_ptr(fb.device))
     _native.check(rc, 'tac_filterbank_plan')
@@ -278,7 +279,12 @@ def melspectrogram(wave, window, fb, n_fft, hop, win_length, center, pad_mode, n
     if fb.dim() != 2 or fb.shape[0] != g.n_bins:
         raise RuntimeError('apply_filterbank: size mismatch, spectrogram has %d bins, filterbank %s'
                            % (g.n_bins, tuple(fb.shape)))
-    route = _fused_mel_route(g, fb, power)
+    rkey = (id(fb), fb._version, power)
+    route = g.routes.get(rkey, 0)
+    if route == 0:
+        if len(g.routes) > 16:
+            g.routes.clear()
+        route = g.routes[rkey] = _fused_mel_route(g, fb, power)
     if route is None:
         spec = spectrogram(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided, power,
                            False, 1.0, 1e-7)
@@ -289,7 +295,7 @@ def melspectrogram(wave, window, fb, n_fft, hop, win_length, center, pad_mode, n
     out = torch.empty(g.lead + (g.n_frames, n_mels), dtype=torch.float32, device=wave.device)
     if route == 'sparse':          # band-sparse contraction (the faster form for triangular banks)
         wpack, desc, info = _melbank_pack(fb, g.n_fft)
-        with torch.cuda.device(wave.device):
+        with _native.on_device(wave.device):
             rc = _native.lib().tac_melspec_sparse_f32(
                 _native.ptr(src), _native.ptr(window), g.desc, float(power), _native.ptr(wpack), _native.ptr(desc),
                 ctypes.cast(info, ctypes.c_void_p), n_mels, 1 if db else 0, float(ref), float(amin),
@@ -298,7 +304,7 @@ def melspectrogram(wave, window, fb, n_fft, hop, win_length, center, pad_mode, n
         _count('tac_melspec_sparse_f32')
         return out.transpose(-2, -1)
     _, plan_host = _filterbank_plan(fb)
-    with torch.cuda.device(wave.device):
+    with _native.on_device(wave.device):
         rc = _native.lib().tac_melspec_f32(
             _native.ptr(src), _native.ptr(window), g.desc, float(power), _native.ptr(fb),
             ctypes.cast(plan_host, ctypes.c_void_p), n_mels, 1 if db else 0, float(ref), float(amin),
@@ -322,7 +328,7 @@ def apply_filterbank(spec, fb):
         pack = _melbank_pack(fb, 0) if (rows.stride(1) == 1 and MEL_PATH != 'mfma') else None
         if pack is not None:
             wpack, desc, info = pack
-            with torch.cuda.device(spec.device):
+            with _native.on_device(spec.device):
                 rc = _native.lib().tac_apply_filterbank_sparse_f32(
                     _native.ptr(rows), rows.shape[0], n_freqs, n_frames, rows.stride(0) if rows.shape[0] > 1 else 0,
                     rows.stride(2), _native.ptr(wpack), _native.ptr(desc), ctypes.cast(info, ctypes.c_void_p), n_mels,
@@ -332,7 +338,7 @@ def apply_filterbank(spec, fb):
                 _count('tac_apply_filterbank_sparse_f32')
                 return out.transpose(-2, -1)
         plan, _ = _filterbank_plan(fb)
-        with torch.cuda.device(spec.device):
+        with _native.on_device(spec.device):
             rc = _native.lib().tac_apply_filterbank_f32(
                 _native.ptr(rows), rows.shape[0], n_freqs, n_frames, rows.stride(0), rows.stride(1),
                 rows.stride(2), _native.ptr(fb), _native.ptr(plan), n_mels, _native.ptr(out),
@@ -373,7 +379,7 @@ def complex_norm(z, power):
     out = _pair_output(z)
     n = out.numel()
     if n:
-        with torch.cuda.device(z.device):
+        with _native.on_device(z.device):
             rc = _native.lib().tac_complex_norm_f32(_native.ptr(z), n, float(power), _native.ptr(out),
                                                     _native.stream_ptr(z.device))
         _native.check(rc, 'tac_complex_norm_f32')
@@ -385,7 +391,7 @@ def angle(z):
     z = _pairs(z)
     phase = _pair_output(z)
     if phase.numel():
-        with torch.cuda.device(z.device):
+        with _native.on_device(z.device):
             rc = _native.lib().tac_magphase_f32(_native.ptr(z), phase.numel(), 1.0, None, _native.ptr(phase),
                                                 _native.stream_ptr(z.device))
         _native.check(rc, 'tac_magphase_f32')
@@ -397,7 +403,7 @@ def magphase(z, power):
     z = _pairs(z)
     mag, phase = _pair_output(z), _pair_output(z)
     if phase.numel():
-        with torch.cuda.device(z.device):
+        with _native.on_device(z.device):
             rc = _native.lib().tac_magphase_f32(_native.ptr(z), phase.numel(), float(power), _native.ptr(mag),
                                                 _native.ptr(phase), _native.stream_ptr(z.device))
         _native.check(rc, 'tac_magphase_f32')
@@ -444,7 +450,7 @@ def phase_vocoder(spec, rate, phase_advance):
     out = torch.empty(lead + (n_out, n_freqs, 2), dtype=dtype, device=spec.device)
     if out.numel() and n_frames:
         name = 'tac_phase_vocoder_f64' if dtype == torch.float64 else 'tac_phase_vocoder_f32'
-        with torch.cuda.device(spec.device):
+        with _native.on_device(spec.device):
             rc = getattr(_native.lib(), name)(
                 _native.ptr(rows), rows.shape[0], n_freqs, n_frames, rows.stride(0) if rows.shape[0] > 1 else 0,
                 rows.stride(1), rows.stride(2), _native.ptr(pa), _native.ptr(idx0), _native.ptr(idx1),
@@ -459,7 +465,7 @@ def _unary(x, name, launch):
     x = x if is_dense(x) else x.contiguous()
     out = torch.empty_like(x)
     if x.numel():
-        with torch.cuda.device(x.device):
+        with _native.on_device(x.device):
             rc = launch(_native.lib(), _native.ptr(x), x.numel(), _native.ptr(out), _native.stream_ptr(x.device))
         _native.check(rc, name)
         _count(name)
@@ -500,7 +506,7 @@ def mu_law_encoding(x, n_quantize):
             thr_ptr = _native.ptr(thr)
         else:
             thr_ptr, n_pos, n_neg, zero = None, 0, 0, 0
-        with torch.cuda.device(x.device):
+        with _native.on_device(x.device):
             rc = _native.lib().tac_mulaw_encode_f32_i64(_native.ptr(x), x.numel(), n_quantize, thr_ptr, n_pos, n_neg,
                                                         zero, _native.ptr(out), _native.stream_ptr(x.device))
         _native.check(rc, 'tac_mulaw_encode_f32_i64')
@@ -514,7 +520,7 @@ def mu_law_decoding_int(codes, n_quantize):
     out = torch.empty(codes.shape, dtype=torch.float32, device=codes.device)
     if codes.numel():
         lut_ptr = _native.ptr(_mulaw_tables(codes.device)[4]) if n_quantize == 256 else None
-        with torch.cuda.device(codes.device):
+        with _native.on_device(codes.device):
             rc = _native.lib().tac_mulaw_decode_i64_f32(_native.ptr(codes), codes.numel(), n_quantize, lut_ptr,
                                                         _native.ptr(out), _native.stream_ptr(codes.device))
         _native.check(rc, 'tac_mulaw_decode_i64_f32')

@@ -42,7 +42,7 @@ def can_defer(wave, window):
     """Deferral applies to plain tensors on a HIP device that take the gfx950 kernels and carry no autograd state."""
     if not _enabled or type(wave) is not torch.Tensor or not wave.is_cuda or wave.dtype not in _DEFERRABLE:
         return False
-    if torch.compiler.is_compiling():
+    if torch.compiler.is_compiling() or torch._C._len_torch_dispatch_stack():
         return False
     if torch.is_grad_enabled() and (wave.requires_grad or window.requires_grad):
         return False
@@ -55,7 +55,7 @@ class _Source(object):
 
     def __init__(self, wave, window, args):
         self.wave, self.window, self.args = wave, window, args
-        self.stream = torch.cuda.current_stream(wave.device)
+        self.stream = torch._C._cuda_getCurrentRawStream(wave.device.index)      # hipStream_t of the forward call
         self.stamps = [(wave, wave._version, wave.data_ptr(), 'waveform'),
                        (window, window._version, window.data_ptr(), 'window')]
 
@@ -77,14 +77,13 @@ class DeferredSpectral(torch.Tensor):
     """Result of an STFT-rooted layer chain that has not been launched yet."""
 
     @staticmethod
-    def __new__(cls, src, stage, shape, strides, power=None, filterbank=None, db=None):
+    def __new__(cls, src, stage, shape, strides, power=None, filterbank=None):
         r = torch.Tensor._make_wrapper_subclass(cls, shape, strides=strides, dtype=torch.float32,
                                                 device=src.wave.device, requires_grad=False)
         r._src = src
         r._stage = stage            # 'stft' | 'spec' | 'mel'
         r._power = power
         r._fb = filterbank
-        r._db = db                  # None or (ref, amin)
         r._value = None
         return r
 
@@ -113,41 +112,46 @@ class DeferredSpectral(torch.Tensor):
                                 _transposed_strides(s.lead, (s.n_frames, fb.shape[1]), -2, -1),
                                 power=self._power, filterbank=fb)
 
-    def with_db(self, ref, amin):
-        return DeferredSpectral(self._src, self._stage, tuple(self.shape), tuple(self.stride()),
-                                power=self._power, filterbank=self._fb, db=(ref, amin))
-
     # -- materialisation --------------------------------------------------------
-    def _launch(self):
-        from ._ops import ops
+    def _launch(self, db):
+        from ._ops import call
         s = self._src
-        ref, amin = self._db if self._db is not None else (1.0, 1e-7)
+        ref, amin = db if db is not None else (1.0, 1e-7)
         if self._stage == 'stft':
-            return ops.stft(s.wave, s.window, *s.args)
+            return call('stft', s.wave, s.window, *s.args)
         if self._stage == 'spec':
-            return ops.spectrogram(s.wave, s.window, *s.args, float(self._power), self._db is not None, float(ref),
-                                   float(amin))
-        return ops.melspectrogram(s.wave, s.window, self._fb, *s.args, float(self._power), self._db is not None,
-                                  float(ref), float(amin))
+            return call('spectrogram', s.wave, s.window, *s.args, float(self._power), db is not None, float(ref),
+                        float(amin))
+        return call('melspectrogram', s.wave, s.window, self._fb, *s.args, float(self._power), db is not None,
+                    float(ref), float(amin))
 
-    def realize(self):
-        if self._value is None:
-            s = self._src
-            s.check_unchanged()
-            now = torch.cuda.current_stream(s.wave.device)
-            if now == s.stream:
-                v = self._launch()
-            else:                               # enqueue where forward() was called, then order the consumer behind it
-                with torch.cuda.stream(s.stream):
-                    v = self._launch()
-                    done = torch.cuda.Event()
-                    done.record(s.stream)
-                now.wait_event(done)
-                v.record_stream(now)
+    def realize(self, db=None):
+        """Launch the recorded chain (with an ``amplitude_to_db(ref, amin)`` epilogue when ``db`` is given) and return
+        an ordinary tensor; a chain without dB epilogue remembers its value."""
+        if self._value is not None:
+            if db is None:
+                return self._value
+            from ._ops import call
+            return call('amplitude_to_db', self._value, float(db[0]), float(db[1]))
+        s = self._src
+        s.check_unchanged()
+        device = s.wave.device
+        if torch._C._cuda_getCurrentRawStream(device.index) == s.stream:
+            v = self._launch(db)
+        else:                                   # enqueue where forward() was called, then order the consumer behind it
+            now = torch.cuda.current_stream(device)
+            then = torch.cuda.ExternalStream(s.stream, device=device) if s.stream else torch.cuda.default_stream(device)
+            with torch.cuda.stream(then):
+                v = self._launch(db)
+                done = torch.cuda.Event()
+                done.record(then)
+            now.wait_event(done)
+            v.record_stream(now)
+        if db is None:
             self._value = v
             self._src = None
             self._fb = None
-        return self._value
+        return v
 
     def __repr__(self):
         return 'DeferredSpectral(stage=%s, shape=%s, pending=%s)' % (self._stage, tuple(self.shape), self.pending())
@@ -159,8 +163,21 @@ class DeferredSpectral(torch.Tensor):
         return func(*tree_map(unwrap, args), **tree_map(unwrap, kwargs or {}))
 
 
+_stride_cache = {}
+
+
 def _transposed_strides(lead, tail, a, b):
-    """Strides of ``empty(lead + tail).transpose(a, b)``."""
+    """Strides of ``empty(lead + tail).transpose(a, b)`` (memoised: a pipeline asks for the same few every call)."""
+    key = (lead, tail, a, b)
+    hit = _stride_cache.get(key)
+    if hit is None:
+        if len(_stride_cache) > 256:
+            _stride_cache.clear()
+        hit = _stride_cache[key] = _compute_transposed_strides(lead, tail, a, b)
+    return hit
+
+
+def _compute_transposed_strides(lead, tail, a, b):
     shape = tuple(lead) + tuple(tail)
     strides = [0] * len(shape)
     acc = 1

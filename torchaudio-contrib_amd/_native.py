@@ -129,8 +129,29 @@ def check(rc, what):
     raise RuntimeError(msg)
 
 
+def raw_stream(device):
+    """hipStream_t of torch's current stream on `device` as an int (no Stream object is built)."""
+    return torch._C._cuda_getCurrentRawStream(device.index)
+
+
 def stream_ptr(device):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(device.index))
+
+
+class _NoGuard(object):
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def on_device(device):
+    """Context manager making `device` the current HIP device for a launch — free when it already is."""
+    return _NO_GUARD if torch._C._cuda_getDevice() == device.index else torch.cuda.device(device)
 
 
 def ptr(t):

@@ -124,7 +124,33 @@ def _autograd_by_recompute(op, fn, n_tensors):
     torch.library.register_autograd('%s::%s' % (NS, op), backward, setup_context=setup_context, lib=_lib)
 
 
+#: the CUDA-key kernels by op name: `call` below invokes them directly when the dispatcher has nothing to add
+cuda_kernels = {}
+
+
+def call(op, *args):
+    """Invoke ``tac_amd::<op>``.  In plain eager mode on HIP tensors without autograd state, tracing, dispatch modes or
+    an active profiler, the dispatcher would do nothing but box the arguments twice (~11 us per call through the
+    Python-kernel path) before reaching the CUDA-key kernel — so that kernel is called directly; every other situation
+    (CPU tensors, autograd, torch.compile / FakeTensor, functorch, profiling) goes through the registered op."""
+    if torch.compiler.is_compiling():
+        return getattr(ops, op)(*args)
+    grad = torch.is_grad_enabled()
+    direct = not (torch._C._len_torch_dispatch_stack() or torch.autograd._profiler_enabled()
+                  or torch._C._functorch.peek_interpreter_stack() is not None)
+    if direct:
+        for a in args:
+            if isinstance(a, torch.Tensor):
+                if type(a) is not torch.Tensor or not a.is_cuda or (grad and a.requires_grad):
+                    direct = False
+                    break
+    if direct:
+        return cuda_kernels[op](*args)
+    return getattr(ops, op)(*args)
+
+
 def _register(op, schema, cuda, cpu, fake, n_tensors, differentiable=True):
+    cuda_kernels[op] = cuda
     _lib.define(op + schema)
     _lib.impl(op, cuda, 'CUDA')
     _lib.impl(op, cpu, 'CPU')
@@ -202,6 +228,7 @@ def _melspectrogram_fake(wave, window, bank, n_fft, hop, win_length, center, pad
     return _swapped(wave.shape[:-1], (frames, bank.shape[1]), _out_dtype(wave), wave.device, -2, -1)
 
 
+cuda_kernels['melspectrogram'] = _melspectrogram_cuda
 _lib.define('melspectrogram(Tensor wave, Tensor window, Tensor filterbank, %s, float power, bool db, float ref, '
             'float amin) -> Tensor' % _STFT_ARGS)
 _lib.impl('melspectrogram', _melspectrogram_cuda, 'CUDA')

@@ -23,7 +23,7 @@ from ._lazy import realize as _realize
 __all__ = ['stft', 'complex_norm', 'create_mel_filter', 'apply_filterbank', 'angle', 'magphase',
            'phase_vocoder', 'amplitude_to_db', 'db_to_amplitude', 'mu_law_encoding', 'mu_law_decoding']
 
-_op = _ops.ops
+_call = _ops.call
 
 
 def _tensor(x, what):
@@ -81,14 +81,14 @@ def stft(waveforms, fft_length, hop_length=None, win_length=None, window=None,
     x = _tensor(waveforms, 'waveforms')
     n_fft, hop, win_length, window = resolve_stft_args(x, fft_length, hop_length, win_length, window)
     _hip.check_stft_args(x.shape, n_fft, hop, win_length, center, pad_mode)
-    return _op.stft(x, window, n_fft, hop, win_length, bool(center), pad_mode, bool(normalized), bool(onesided))
+    return _call('stft', x, window, n_fft, hop, win_length, bool(center), pad_mode, bool(normalized), bool(onesided))
 
 
 def complex_norm(complex_tensor, power=1.0):
     """``|z|**power`` over a trailing ``complex=2`` dim (reference: functional.py:116-128)."""
     z = _tensor(complex_tensor, 'complex_tensor')
     _check_pairs(z, 'complex_norm')
-    return _op.complex_norm(z, float(power))
+    return _call('complex_norm', z, float(power))
 
 
 def _hz_to_mel(hz, htk):
@@ -138,7 +138,7 @@ def apply_filterbank(mag_specgrams, filterbank):
                            % (tuple(spec.shape), tuple(fb.shape)))
     if fb.device != spec.device:
         raise RuntimeError('apply_filterbank: spectrogram and filterbank must be on the same device')
-    return _op.apply_filterbank(spec, fb)
+    return _call('apply_filterbank', spec, fb)
 
 
 def _check_pairs(z, what):
@@ -150,14 +150,14 @@ def angle(complex_tensor):
     """Phase ``atan2(im, re)`` of a ``(*, 2)`` tensor (reference: functional.py:187-191)."""
     z = _tensor(complex_tensor, 'complex_tensor')
     _check_pairs(z, 'angle')
-    return _op.angle(z)
+    return _call('angle', z)
 
 
 def magphase(complex_tensor, power=1.):
     """``(|z|**power, atan2(im, re))`` (reference: functional.py:194-201), both outputs from one pass over z."""
     z = _tensor(complex_tensor, 'complex_tensor')
     _check_pairs(z, 'magphase')
-    return _op.magphase(z, float(power))
+    return _call('magphase', z, float(power))
 
 
 def phase_vocoder(complex_specgrams, rate, phase_advance):
@@ -175,17 +175,17 @@ def phase_vocoder(complex_specgrams, rate, phase_advance):
         raise RuntimeError('phase_vocoder: spectrogram and phase_advance must be on the same device')
     if not rate > 0:
         raise ValueError('phase_vocoder: rate must be positive, got %r' % (rate,))
-    return _op.phase_vocoder(spec, pa, float(rate))
+    return _call('phase_vocoder', spec, pa, float(rate))
 
 
 def amplitude_to_db(x, ref=1.0, amin=1e-7):
     """``10·(log10(max(x², amin)) − log10(ref))`` — the reference squares its input (functional.py:277-296)."""
-    return _op.amplitude_to_db(_tensor(x, 'x'), float(ref), float(amin))
+    return _call('amplitude_to_db', _tensor(x, 'x'), float(ref), float(amin))
 
 
 def db_to_amplitude(x, ref=1.0):
     """``(10^(x/10 + log10 ref))^0.5`` (reference: functional.py:299-314)."""
-    return _op.db_to_amplitude(_tensor(x, 'x'), float(ref))
+    return _call('db_to_amplitude', _tensor(x, 'x'), float(ref))
 
 
 def mu_law_encoding(x, n_quantize=256):
@@ -195,11 +195,11 @@ def mu_law_encoding(x, n_quantize=256):
     and ``|x| <= 1`` the kernel compares against the 255 float32 thresholds extracted from the reference
     (``_mulaw_tables.py``), everything else evaluates the closed form with the exact float32 roundings of the
     reference's CPU path (``csrc/exact_math.hpp``)."""
-    return _op.mu_law_encoding(_tensor(x, 'x'), int(n_quantize))
+    return _call('mu_law_encoding', _tensor(x, 'x'), int(n_quantize))
 
 
 def mu_law_decoding(x_mu, n_quantize=256, dtype=torch.get_default_dtype()):
     """mu-law expansion (reference: functional.py:338-354).  On a HIP device codes that are integers in
     ``[0, 256)`` — int64 or float-typed — with ``n_quantize == 256`` are decoded through the reference's own
     256-entry table (bit-exact); everything else evaluates the closed form in fp32 (within 1 ulp of ``exp``)."""
-    return _op.mu_law_decoding(_tensor(x_mu, 'x_mu'), int(n_quantize), dtype)
+    return _call('mu_law_decoding', _tensor(x_mu, 'x_mu'), int(n_quantize), dtype)

@@ -107,7 +107,7 @@ class ApplyFilterbank(_ModuleNoStateBuffers):
     def forward(self, mag_specgrams):
         x = mag_specgrams
         fb = self.filterbank
-        if isinstance(x, DeferredSpectral) and x.pending() and x._stage == 'spec' and x._db is None \
+        if isinstance(x, DeferredSpectral) and x.pending() and x._stage == 'spec' \
                 and fb.dim() == 2 and fb.shape[0] == x.shape[-2] and fb.device == x.device \
                 and fb.dtype == torch.float32 and not (fb.requires_grad and torch.is_grad_enabled()):
             return x.with_filterbank(fb)
@@ -192,10 +192,10 @@ class _FusedSequential(nn.Sequential):
             args = (n_fft, hop, win_length, bool(st.center), st.pad_mode, bool(st.normalized), bool(st.onesided),
                     float(kids[1].power), False, 1.0, 1e-7)
             if len(kids) == 2:
-                return F._op.spectrogram(x, window, *args)
+                return F._call('spectrogram', x, window, *args)
             fb = kids[2].filterbank
             if fb.dim() == 2 and fb.shape[0] == (n_fft // 2 + 1 if st.onesided else n_fft) and fb.device == x.device:
-                return F._op.melspectrogram(x, window, fb, *args)
+                return F._call('melspectrogram', x, window, fb, *args)
         return realize(super(_FusedSequential, self).forward(input))
 
 
@@ -236,10 +236,10 @@ class AmplitudeToDb(_ModuleNoStateBuffers):
                            "ref:{} and amin:{}".format(ref, amin)
 
     def forward(self, x):
-        if isinstance(x, DeferredSpectral) and x.pending() and x._stage in ('spec', 'mel') and x._db is None:
+        if isinstance(x, DeferredSpectral) and x.pending() and x._stage in ('spec', 'mel'):
             # terminal stage: nothing can fuse behind the dB epilogue, so the fused kernel is launched now, on the
             # stream of the STFT call, and the caller gets an ordinary tensor
-            return x.with_db(self.ref, self.amin).realize()
+            return x.realize(db=(self.ref, self.amin))
         return F.amplitude_to_db(x, ref=self.ref, amin=self.amin)
 
     def __repr__(self):
