@@ -678,7 +678,7 @@ def test_mulaw_decode_float_codes_bit_exact(tac, golden):
     frac = host(tac.mu_law_decoding(torch.tensor([127.5, -1.0, 255.0, 256.0, 300.5]).cuda(), 256))
     y = np.array([127.5, -1.0, 255.0, 256.0, 300.5]) / 255 * 2 - 1
     want = np.sign(y) * (np.exp(np.abs(y) * np.log1p(255.0)) - 1) / 255
-    assert np.abs(frac - want).max() < 2e-7 * np.abs(want).max()
+    assert (np.abs(frac - want) <= 1e-6 * np.abs(want)).all()       # float32 evaluation of y*log1p(mu), amplified by exp
 
 
 def test_mulaw_decode_other_quantisations_ulp_bound(tac, golden):
