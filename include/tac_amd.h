@@ -97,7 +97,10 @@ int tac_melspec_f32(const float* wave, const float* window, const tac_stft_desc*
  *      lengths > 3072), in which case callers use (3).
  *      tac_melbank_pack: one-off per (filterbank, n_fft); copies fb to the host (synchronises `stream`), deals the
  *      bands to lane groups longest-first and uploads wpack (DEVICE float[wpack_cap >= 3072]) and desc (DEVICE
- *      int32[desc_cap >= 4096]); info_host: HOST int32[4] = {weight floats, desc stride, lane groups, max group load}. */
+ *      int32[desc_cap >= 4096]); info_host: HOST int32[8] = {weight floats, desc stride, lane groups, max group load, 0, 0, 0, 0};
+ *      for n_fft = 2048 the pack is the lane layout of the streaming kernel (lane l owns bands l, 64 + l, ...; at most
+ *      256 bands): wpack = float[steps][64][2] zero-padded pair weights, desc = int32[slots][64] first bins,
+ *      info_host = {weight floats, slots, 64, total steps, steps of slot 0..3}; wpack_cap >= 8192. */
 int tac_melbank_pack(const float* fb, int32_t n_freqs, int32_t n_mels, int32_t n_fft, float* wpack,
                      int32_t wpack_cap, int32_t* desc, int32_t desc_cap, int32_t* info_host, void* stream);
 int tac_melspec_sparse_f32(const float* wave, const float* window, const tac_stft_desc* d, float power,

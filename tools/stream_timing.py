@@ -1,0 +1,24 @@
+#!/usr/bin/env python
+"""Debug: with a -DTAC_ST_TIMING=1 build (TAC_AMD_LIB=...), per-wave cycle sums of the streaming mel kernel at cfg-2 by
+stage (either thread of the wave): s0 window + pass 0, s1 pass 1, s2 pass 2, s3 R2C + |X|^2 row (+ next request),
+s4 contraction + dB + store."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torchaudio_contrib_amd as tac
+x = torch.rand(256, 1, 160000, device='cuda') * 2 - 1
+m = torch.nn.Sequential(*tac.Melspectrogram(num_mels=128, sample_rate=16000, fft_length=2048, hop_length=512),
+                        tac.AmplitudeToDb()).cuda()
+for _ in range(3):
+    y = m(x)
+torch.cuda.synchronize()
+phys = y.transpose(-2, -1).contiguous().view(-1)
+t = phys[:256 * 8 * 8].view(256, 8, 8).cpu()
+frames = 256 * 313 / (256 * 8)
+tot = t[..., 0].mean()
+print('per wave: %.0f cycles total, %.1f frames -> %.0f cycles per frame (two frames in flight)' % (tot, frames, tot / frames))
+for k, name in ((1, 's0 window + pass 0 + exchange'), (2, 's12 pass 1, in-register exchange, pass 2'), (4, 's3 r2c + row + request'),
+                (5, 's4 contraction + dB + store')):
+    col = t[..., k]
+    print('%-32s %7.0f cycles/frame (%4.1f%%)  by wave: %s' % (name, col.mean() / frames, 100 * col.mean() / tot,
+                                                              ' '.join('%5.0f' % (v / frames) for v in col.mean(0))))

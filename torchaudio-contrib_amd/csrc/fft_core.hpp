@@ -361,65 +361,115 @@ struct WaveFft {
         run<NF>(v, lds, tw, t, st, t);
     }
 
+    // ---- one pass in three separately callable pieces (single frame): the streaming kernels interleave the pieces
+    // of two frames so that one frame's LDS round trip runs behind the other frame's butterflies.
+    // (1) operands of pass P (> 0) back from the exchange area into first-index order v[b*R + q]
+    template <int P>
+    __device__ static __forceinline__ void pass_readback(cf (&v)[E_], const cf* lds, int t) {
+        constexpr int R = radix_at(NC, P), NB = E / R;
+        static_assert(P > 0 && (NC / R) % 16 == 0, "read stride must keep the padding affine");
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            // NC/R is a multiple of 16 for every pass after the first, so pad(j + c) = pad(j) + pad(c):
+            // one address register per butterfly, the rest are DS immediate offsets.
+#if TAC_EXP_NOCONF
+            const cf* src = lds + (t + b * LPF);
+#pragma unroll
+            for (int q = 0; q < R; ++q) v[b * R + q] = src[q * (NC / R)];
+#else
+            const cf* src = lds + lds_pad(t + b * LPF);
+#pragma unroll
+            for (int q = 0; q < R; ++q) v[b * R + q] = src[lds_pad_c(q * (NC / R))];
+#endif
+        }
+    }
+    // (2) inter-pass twiddles (P > 0) and the radix-R butterflies of pass P
+    template <int P>
+    __device__ static __forceinline__ void pass_twiddle(cf (&v)[E_], const cf* tw) {
+        constexpr int R = radix_at(NC, P), OFF = twiddles_before(NC, E, P), NB = E / R;
+        if constexpr (P > 0) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int q = 1; q < R; ++q)
+                    v[b * R + q] = cmul(last_pass_const<P>(v[b * R + q], b * q * (32 / E)),
+                                        tw[OFF + (pass_shares_twiddles(NC, E, P) ? 0 : b) * (R - 1) + q - 1]);
+        }
+    }
+    template <int P>
+    __device__ static __forceinline__ void pass_butterflies(cf (&v)[E_]) {
+        constexpr int R = radix_at(NC, P), NB = E / R;
+        static_assert(NB >= 1, "radix larger than elements per lane");
+#pragma unroll
+        for (int b = 0; b < NB; ++b) Dft<R>::run(&v[b * R]);
+    }
+    // (3) outputs of pass P into the exchange area (HALF: the last pass keeps its lower-half outputs in registers)
+    template <int P, bool HALF>
+    __device__ static __forceinline__ void pass_write(const cf (&v)[E_], cf* lds, int t, int t0) {
+        constexpr int KLO = (HALF && TAC_FFT_HALF && pass_is_last(NC_, P)) ? radix_at(NC_, P) / 2 : 0;     // first output stored
+        constexpr int R = radix_at(NC, P), S = stride_at(NC, P), NB = E / R;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int j = (P == 0 ? t0 : t) + b * LPF;
+            if constexpr (S == 1) {
+                static_assert(R == 16, "first pass is radix 16");
+                cf* dst = lds + 17 * j;                          // pad(16 j + k) = 17 j + k, k < 16
+#pragma unroll
+                for (int k = KLO; k < R; ++k) dst[k] = v[b * R + k];
+            } else {
+                static_assert(S % 16 == 0, "write stride must keep the padding affine");
+                cf* dst = lds + lds_pad((j / S) * (S * R) + (j & (S - 1)));
+#pragma unroll
+                for (int k = KLO; k < R; ++k) dst[lds_pad_c(k * S)] = v[b * R + k];
+            }
+        }
+    }
+
+    // In-register form of the exchange between passes 1 and 2 of the 16 . 16 . 4 plan (NC = 1024, one frame per wave):
+    // the radix-4 butterfly b of lane t = u + 16 a needs outputs a + 4b of the four lanes u + 16 q, i.e. per b a 4 x 4
+    // transpose between four registers and the four 16-lane rows of the wave — two v_permlane32_swap and two
+    // v_permlane16_swap per dword instead of 16 LDS stores, 16 LDS loads and their round trip.
+    __device__ static __forceinline__ void swap_rows32(cf& x, cf& y) {       // x rows {2,3} <-> y rows {0,1}
+        const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x.x), __float_as_uint(y.x), false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x.y), __float_as_uint(y.y), false, false);
+        x = mkc(__uint_as_float(a[0]), __uint_as_float(b[0]));
+        y = mkc(__uint_as_float(a[1]), __uint_as_float(b[1]));
+    }
+    __device__ static __forceinline__ void swap_rows16(cf& x, cf& y) {       // x rows {1,3} <-> y rows {0,2}
+        const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x.x), __float_as_uint(y.x), false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(x.y), __float_as_uint(y.y), false, false);
+        x = mkc(__uint_as_float(a[0]), __uint_as_float(b[0]));
+        y = mkc(__uint_as_float(a[1]), __uint_as_float(b[1]));
+    }
+    __device__ static __forceinline__ void exchange_1_2_in_registers(cf (&v)[E_]) {
+        static_assert(NC_ == 1024 && E_ == 16 && radix_at(NC_, 1) == 16 && radix_at(NC_, 2) == 4,
+                      "wired for the 16 . 16 . 4 plan with 64 lanes per frame");
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            swap_rows32(v[4 * b + 0], v[4 * b + 2]);
+            swap_rows32(v[4 * b + 1], v[4 * b + 3]);
+            swap_rows16(v[4 * b + 0], v[4 * b + 1]);
+            swap_rows16(v[4 * b + 2], v[4 * b + 3]);
+        }
+    }
+
     template <int P, int NF, class ST, bool HALF = false>
     __device__ static __forceinline__ void pass(cf (&v)[NF][E_], cf* const (&lds)[NF], const cf* tw, int t, ST& st,
                                                 int t0) {
-        constexpr int KLO = (HALF && TAC_FFT_HALF && pass_is_last(NC_, P)) ? radix_at(NC_, P) / 2 : 0;     // first output stored
-        constexpr int R = radix_at(NC, P), S = stride_at(NC, P), OFF = twiddles_before(NC, E, P);
-        constexpr int NB = E / R;
-        static_assert(NB >= 1, "radix larger than elements per lane");
         if constexpr (P > 0) {
             wave_lds_fence();
 #pragma unroll
-            for (int f = 0; f < NF; ++f)
+            for (int f = 0; f < NF; ++f) pass_readback<P>(v[f], lds[f], t);
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    // NC/R is a multiple of 16 for every pass after the first, so pad(j + c) = pad(j) + pad(c):
-                    // one address register per butterfly, the rest are DS immediate offsets.
-                    static_assert((NC / R) % 16 == 0, "read stride must keep the padding affine");
-#if TAC_EXP_NOCONF
-                    const cf* src = lds[f] + (t + b * LPF);
-#pragma unroll
-                    for (int q = 0; q < R; ++q) v[f][b * R + q] = src[q * (NC / R)];
-#else
-                    const cf* src = lds[f] + lds_pad(t + b * LPF);
-#pragma unroll
-                    for (int q = 0; q < R; ++q) v[f][b * R + q] = src[lds_pad_c(q * (NC / R))];
-#endif
-                }
-#pragma unroll
-            for (int f = 0; f < NF; ++f)
-#pragma unroll
-                for (int b = 0; b < NB; ++b)
-#pragma unroll
-                    for (int q = 1; q < R; ++q)
-                        v[f][b * R + q] = cmul(last_pass_const<P>(v[f][b * R + q], b * q * (32 / E)),
-                                               tw[OFF + (pass_shares_twiddles(NC, E, P) ? 0 : b) * (R - 1) + q - 1]);
+            for (int f = 0; f < NF; ++f) pass_twiddle<P>(v[f], tw);
             st.mark(2 * P + 1);
         }
 #pragma unroll
-        for (int f = 0; f < NF; ++f)
-#pragma unroll
-            for (int b = 0; b < NB; ++b) Dft<R>::run(&v[f][b * R]);
+        for (int f = 0; f < NF; ++f) pass_butterflies<P>(v[f]);
         st.mark(2 * P + 2);
         wave_lds_fence();   // every lane's reads of this pass precede any lane's writes (same wave, in order)
 #pragma unroll
-        for (int f = 0; f < NF; ++f)
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const int j = (P == 0 ? t0 : t) + b * LPF;
-                if constexpr (S == 1) {
-                    static_assert(R == 16, "first pass is radix 16");
-                    cf* dst = lds[f] + 17 * j;                          // pad(16 j + k) = 17 j + k, k < 16
-#pragma unroll
-                    for (int k = KLO; k < R; ++k) dst[k] = v[f][b * R + k];
-                } else {
-                    static_assert(S % 16 == 0, "write stride must keep the padding affine");
-                    cf* dst = lds[f] + lds_pad((j / S) * (S * R) + (j & (S - 1)));
-#pragma unroll
-                    for (int k = KLO; k < R; ++k) dst[lds_pad_c(k * S)] = v[f][b * R + k];
-                }
-            }
+        for (int f = 0; f < NF; ++f) pass_write<P, HALF>(v[f], lds[f], t, t0);
         if constexpr (P + 1 < NPASS) pass<P + 1, NF, ST, HALF>(v, lds, tw, t, st, t0);
     }
 
@@ -668,6 +718,15 @@ __device__ __forceinline__ float amp_to_db(float x, float amin, float log10_ref)
     const float p = x * x;
     const float sq = (p == p) ? fmaxf(p, amin) : p;   // keep NaN: torch.clamp propagates it, fmaxf alone would return amin
     return 10.0f * (log10f(sq) - log10_ref);
+}
+
+// the same with the hardware base-2 logarithm (v_log_f32, ~1 ulp of log2): 10 log10(s) = 10 log10(2) log2(s).  The
+// hardware flushes denormal inputs, so callers take this form only when amin is a normal number (the clamp then keeps
+// the argument normal); absolute error ~1e-6 dB, against ~25 instructions for the correctly rounded log10f.
+__device__ __forceinline__ float amp_to_db_fast(float x, float amin, float ten_log10_ref) {
+    const float p = x * x;
+    const float sq = (p == p) ? fmaxf(p, amin) : p;
+    return __builtin_fmaf(3.0102999566398120f, __builtin_amdgcn_logf(sq), -ten_log10_ref);
 }
 
 }  // namespace tac

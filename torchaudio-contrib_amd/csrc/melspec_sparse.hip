@@ -16,6 +16,7 @@
 #include "mel_common.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <vector>
 
 #ifndef TAC_SP_PREFETCH
@@ -44,6 +45,13 @@
 #define TAC_SP_NF 1      // frames advanced together per wave in phase A (A/B knob; 2 fits since the packed-math core but measures 3-6 % slower)
 #endif
 
+#ifndef TAC_SP_STREAM
+#define TAC_SP_STREAM 1     // fft_length 2048: producer / consumer streaming kernel (melspec_stream.hpp); 0 = the three-phase kernel
+#endif
+
+#include "sparse_phase.hpp"
+#include "melspec_stream.hpp"
+
 namespace tac {
 
 constexpr int SP_TILE = 16;
@@ -64,50 +72,7 @@ struct SparseArgs {
 
 __host__ __device__ inline int sparse_ostr(int n_mels, int out_vec4) { return out_vec4 ? n_mels + 4 : (n_mels | 1); }
 
-// ---------------------------------------------------------------- phases B and C (shared by both kernel forms)
-// phase B: one private dot product per (frame, band) — this thread's lane group owns the band list at dg, its lane
-// within the group owns the frame whose power row starts at prow; results go to the frame's row of the output tile.
-__device__ __forceinline__ void sparse_phase_b(const int* dg, const float* prow, const float* wlds, float* orow) {
-    const int nb = dg[0];
-    int4 dnext = *reinterpret_cast<const int4*>(dg + 4);                      // band, first bin, n8, weight offset
-    for (int b = 0; b < nb; ++b) {
-        const int4 d = dnext;
-        dnext = *reinterpret_cast<const int4*>(dg + 4 + 4 * (b + 1 < nb ? b + 1 : b));   // next band's descriptor in flight
-        const float* p = prow + d.y;
-        const float4* w4 = reinterpret_cast<const float4*>(wlds + d.w);
-        cf acc0 = mkc(0.0f, 0.0f), acc1 = mkc(0.0f, 0.0f);
-        // 8 taps per trip: 2 weight vectors (LDS broadcast) + 4 eight-byte row reads (bands start on even bins,
-        // tac_melbank_pack) feed 4 packed FMAs.  The loop is LDS-latency-bound at 2 waves/SIMD, so it is software
-        // pipelined: trip j+1's six reads are issued before trip j's FMAs (the last trip re-reads itself).
-#if TAC_SP_PB_PIPE
-        float4 wa = w4[0], wb = w4[1];
-        const cf* q = reinterpret_cast<const cf*>(p);
-        cf p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3];
-        for (int j = 0; j < d.z; ++j) {
-            const int jn = j + 1 < d.z ? j + 1 : j;
-            const float4 nwa = w4[2 * jn], nwb = w4[2 * jn + 1];
-            const cf* qn = reinterpret_cast<const cf*>(p + 8 * jn);
-            const cf n0 = qn[0], n1 = qn[1], n2 = qn[2], n3 = qn[3];
-            acc0 = __builtin_elementwise_fma(mkc(wa.x, wa.y), p0, acc0);
-            acc1 = __builtin_elementwise_fma(mkc(wa.z, wa.w), p1, acc1);
-            acc0 = __builtin_elementwise_fma(mkc(wb.x, wb.y), p2, acc0);
-            acc1 = __builtin_elementwise_fma(mkc(wb.z, wb.w), p3, acc1);
-            wa = nwa; wb = nwb; p0 = n0; p1 = n1; p2 = n2; p3 = n3;
-        }
-#else
-        for (int j = 0; j < d.z; ++j) {               // A/B knob: no look-ahead
-            const float4 wa = w4[2 * j], wb = w4[2 * j + 1];
-            const cf* q = reinterpret_cast<const cf*>(p + 8 * j);
-            const cf p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3];
-            acc0 = __builtin_elementwise_fma(mkc(wa.x, wa.y), p0, acc0);
-            acc1 = __builtin_elementwise_fma(mkc(wa.z, wa.w), p1, acc1);
-            acc0 = __builtin_elementwise_fma(mkc(wb.x, wb.y), p2, acc0);
-            acc1 = __builtin_elementwise_fma(mkc(wb.z, wb.w), p3, acc1);
-        }
-#endif
-        orow[d.x] = (acc0.x + acc0.y) + (acc1.x + acc1.y);
-    }
-}
+// phase B lives in sparse_phase.hpp (shared with the streaming kernel)
 
 // phase C: dB epilogue + coalesced row stores of out[row][frame][0..M) by the NT threads that share the tile
 template <int NT>
@@ -157,7 +122,7 @@ __device__ __forceinline__ void sparse_phase_c(const float* otile, int ostr, int
 }
 
 template <int NC, int E, bool POW2, bool V4>
-__global__ void __launch_bounds__((MelCfg<NC, E, SP_TILE>::WAVES * 64), 2)
+__global__ void __launch_bounds__((MelCfg<NC, E, SP_TILE>::WAVES * 64), (MelCfg<NC, E, SP_TILE>::WAVES / 4))
 melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
     using C = MelCfg<NC, E, SP_TILE>;
     using F = typename C::F;
@@ -490,7 +455,7 @@ static int sparse_groups_for(int n_fft) {
         case 256: return sparse_groups<128, 16>();
         case 512: return sparse_groups<256, 16>();
         case 1024: return sparse_groups<512, 16>();
-        case 2048: return sparse_groups<1024, 16>();
+        case 2048: return TAC_SP_STREAM ? 64 : sparse_groups<1024, 16>();     // 64: one band per lane and slot (melspec_stream.hpp)
         default: return 0;
     }
 }
@@ -546,6 +511,95 @@ static int launch_sparse(const FrameGeom& g, const Tables& tb, const SparseArgs&
     return TAC_OK;
 }
 
+// fft_length 2048: the barrier-free streaming kernel (melspec_stream.hpp), one persistent workgroup per CU.
+// info_host: {weight floats, slots, 64, total steps, steps of slot 0..3} from tac_melbank_pack.
+template <int NC, int E>
+static int launch_stream(const FrameGeom& g, const Tables& tb, const SparseArgs& sm, const int32_t* info_host, float power,
+                         hipStream_t stream) {
+    const long long total = g.rows * g.n_frames;
+    if (total >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;                  // 32-bit global frame numbers in-kernel
+    if (g.length < 2 * NC) return TAC_E_UNSUPPORTED;                       // (its clamped sample requests need a whole frame)
+    const size_t lds_bytes = stream_lds_bytes<NC, E>(sm.wtot);
+    if (lds_bytes > 160 * 1024 || info_host[1] < 1 || info_host[1] > ST_MAX_SLOTS) return TAC_E_UNSUPPORTED;
+    StreamArgs m{sm.wpack, sm.desc, info_host[1], {info_host[4], info_host[5], info_host[6], info_host[7]}, sm.wtot,
+                 sm.n_mels, sm.db, sm.amin, sm.log10_ref, sm.out, total};
+    long long blocks = (total + 2 * ST_WAVES - 1) / (2 * ST_WAVES);
+    if (blocks > device_cu_count()) blocks = device_cu_count();
+    if (blocks < 1) blocks = 1;
+    const bool pow2 = (power == 2.0f), fullm = (sm.n_mels % 64) == 0;
+    auto kern = pow2 ? (fullm ? melspec_stream_kernel<NC, E, true, true> : melspec_stream_kernel<NC, E, true, false>)
+                     : (fullm ? melspec_stream_kernel<NC, E, false, true> : melspec_stream_kernel<NC, E, false, false>);
+    int dev = 0;
+    TAC_HIP(hipGetDevice(&dev));
+    static std::atomic<bool> attr_set[4][16];                             // per (kernel, device): cheap, so no lock
+    const int ki = pow2 * 2 + fullm;
+    if (dev < 0 || dev >= 16 || !attr_set[ki][dev].load(std::memory_order_acquire)) {
+        TAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024));
+        if (dev >= 0 && dev < 16) attr_set[ki][dev].store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(ST_WAVES * 64), lds_bytes, stream, g, tb, m);
+    TAC_HIP(hipGetLastError());
+    return TAC_OK;
+}
+
+// Lane layout of the streaming kernel: lane l owns bands l, 64 + l, ... (slot s = band / 64).  Every slot is one loop
+// of steps[s] four-tap steps (the longest band of the slot, in whole trips of four steps); shorter bands are
+// zero-padded, and a band whose padded run would leave the row buffer is shifted down (zeros in front) so that every
+// lane reads inside its row.
+static int pack_lanes(const std::vector<float>& h, int n_freqs, int n_mels, float* wpack, int wpack_cap, int32_t* desc,
+                      int desc_cap, int32_t* info_host, hipStream_t stream) {
+    const int nslot = (n_mels + 63) / 64;
+    if (nslot > ST_MAX_SLOTS || nslot * 64 > desc_cap) return TAC_E_UNSUPPORTED;
+    const int limit = StreamCfg<1024, 16>::PROW;                             // bins + zeroed slack of a row buffer
+    std::vector<int> lo(nslot * 64, 0), len(nslot * 64, 0);
+    int steps[ST_MAX_SLOTS] = {0, 0, 0, 0};
+    for (int m = 0; m < n_mels; ++m) {
+        int l0 = n_freqs, h0 = 0;
+        for (int f = 0; f < n_freqs; ++f)
+            if (h[(size_t)f * n_mels + m] != 0.0f) { l0 = f < l0 ? f : l0; h0 = f + 1; }
+        if (h0 > l0) {
+            lo[m] = l0 & ~3;
+            len[m] = h0 - lo[m];
+            steps[m / 64] = std::max(steps[m / 64], (len[m] + 3) / 4);
+        }
+    }
+    int total_steps = 0;
+    for (int s = 0; s < nslot; ++s) {
+        steps[s] = std::max(4, (steps[s] + 3) & ~3);                         // whole trips; an empty slot still runs one
+        if (4 * steps[s] > limit) return TAC_E_UNSUPPORTED;
+        total_steps += steps[s];
+    }
+    const long long wtot = 256LL * total_steps;
+    if (wtot > wpack_cap || stream_lds_bytes<1024, 16>((int)wtot) > 160 * 1024) return TAC_E_UNSUPPORTED;
+    std::vector<float> wp((size_t)wtot, 0.0f);
+    int base = 0;
+    for (int s = 0; s < nslot; ++s) {
+        for (int l = 0; l < 64; ++l) {
+            const int m = s * 64 + l;
+            int first = lo[m];
+            if (first + 4 * steps[s] > limit) first = (limit - 4 * steps[s]) & ~3;     // keep the padded run inside the row
+            for (int j = 0; j < steps[s]; ++j)
+                for (int u = 0; u < 4; ++u) {
+                    const int bin = first + 4 * j + u;
+                    const bool live = m < n_mels && bin >= lo[m] && bin < lo[m] + len[m] && bin < n_freqs;
+                    wp[((size_t)(base + j) * 64 + l) * 4 + u] = live ? h[(size_t)bin * n_mels + m] : 0.0f;
+                }
+            lo[m] = first;
+        }
+        base += steps[s];
+    }
+    TAC_HIP(hipMemcpyAsync(wpack, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+    TAC_HIP(hipMemcpyAsync(desc, lo.data(), lo.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    TAC_HIP(hipStreamSynchronize(stream));
+    info_host[0] = (int32_t)wtot;
+    info_host[1] = nslot;
+    info_host[2] = 64;
+    info_host[3] = total_steps;
+    for (int s = 0; s < ST_MAX_SLOTS; ++s) info_host[4 + s] = steps[s];
+    return TAC_OK;
+}
+
 }  // namespace tac
 
 extern "C" {
@@ -560,6 +614,8 @@ int tac_melbank_pack(const float* fb, int32_t n_freqs, int32_t n_mels, int32_t n
     std::vector<float> h((size_t)n_freqs * n_mels);
     TAC_HIP(hipMemcpyAsync(h.data(), fb, h.size() * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
     TAC_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (TAC_SP_STREAM && n_fft == 2048)
+        return pack_lanes(h, n_freqs, n_mels, wpack, wpack_cap, desc, desc_cap, info_host, (hipStream_t)stream);
     struct Band { int m, lo, len; };
     std::vector<Band> bands(n_mels);
     long long total = 0;
@@ -639,7 +695,7 @@ int tac_melspec_sparse_f32(const float* wave, const float* window, const tac_stf
         case 256: return launch_sparse<128, 16>(g, tb, m, power, s);
         case 512: return launch_sparse<256, 16>(g, tb, m, power, s);
         case 1024: return launch_sparse<512, 16>(g, tb, m, power, s);
-        case 2048: return launch_sparse<1024, 16>(g, tb, m, power, s);
+        case 2048: return TAC_SP_STREAM ? launch_stream<1024, 16>(g, tb, m, info_host, power, s) : launch_sparse<1024, 16>(g, tb, m, power, s);
         default: return TAC_E_UNSUPPORTED;
     }
 }

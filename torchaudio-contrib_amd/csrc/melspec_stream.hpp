@@ -1,0 +1,311 @@
+// melspec_stream.hpp — the fused Melspectrogram(+dB) chain (layers.py:307-381) for fft_length 2048 as a
+// barrier-free stream of frames: every wave of a persistent workgroup carries frames from samples to mel-dB rows
+// on its own, TWO frames at a time, half a frame apart.
+//
+// Why.  melspec_sparse_kernel runs its three phases (FFT -> band-sparse contraction -> dB rows) in lockstep between
+// workgroup barriers: all eight waves butterfly together (VALU busy, LDS idle), exchange together (LDS busy, VALU
+// idle) and contract together (LDS reads only).  Its counters say exactly that — VALU ~40 % and LDS ~37 % busy, taking
+// turns, with each of the 2 waves per SIMD sitting out its own LDS round trips (profiles/r01).  Here nothing is
+// shared between waves but the constant tables, so there is nothing to wait for:
+//
+//   * a wave interleaves the stages s0..s4 of two frames ("threads" A and B of the wave) in a fixed rotation; while one
+//     frame's exchange travels through the LDS the wave issues the other frame's butterflies.  The two frames share
+//     ONE exchange area: the LDS executes a wave's instructions in order and every read-back is issued directly behind
+//     the writes it depends on, so a frame's data is already on its way to registers when the other frame's writes
+//     arrive.  Samples are requested one whole frame ahead into a register buffer the two threads take turns with.
+//   * s3 leaves the frame's |X|^2 row in a private row buffer; s4 contracts it with the filterbank one band per lane
+//     (lane l owns bands l, 64 + l, ...: the weights sit in LDS as [step][lane] pairs, conflict-free, and the
+//     row reads of neighbouring bands are neighbouring addresses), applies the dB epilogue and stores the row of
+//     out[frame][0..M) as 256-byte runs straight from registers — no output tile, no hand-over, no s_barrier.
+//
+// Frames are numbered globally (row * T + frame): out[rows][T][M] is contiguous in that index, so a workgroup simply
+// owns a contiguous range of global frames, dealt round-robin to its 16 threads.
+#pragma once
+#include "mel_common.hpp"
+
+#ifndef TAC_ST_ABL
+#define TAC_ST_ABL 0        // ablation builds (wrong results): 1 no contraction stage, 2 no row stores, 3 no dB, 4 no sample loads, 5 conflict-free row reads
+#endif
+#ifndef TAC_ST_TIMING
+#define TAC_ST_TIMING 0     // 1: debug builds of tools/stream_timing.py — per-wave cycle sums overwrite the head of out[]
+#endif
+
+namespace tac {
+
+constexpr int ST_WAVES = 8;
+constexpr int ST_MAX_SLOTS = 4;              // bands per lane (n_mels <= 256)
+
+struct StreamArgs {
+    const float* wl;       // device: weights [sum of steps][64 lanes][4 consecutive bins]
+    const int* lo;         // device: first bin (multiple of 4) of lane l's band in slot s at [s * 64 + l]
+    int nslot;             // bands per lane = ceil(n_mels / 64)
+    int steps[ST_MAX_SLOTS];   // four-tap steps of each slot's loop (the longest band of the slot, rounded up to 4 steps)
+    int wtot;              // floats in wl = 256 * sum(steps)
+    int n_mels;
+    int db;
+    float amin;
+    float log10_ref;
+    float* out;            // [rows * T][M]
+    long long total;       // rows * T
+};
+
+template <int NC, int E>
+struct StreamCfg {
+    using F = WaveFft<NC, E>;
+    static constexpr int NBINS = NC + 1;
+    static constexpr int PROW0 = NBINS + 7;                                   // + slack for zero-weight taps past the row
+    static constexpr int PROW = (PROW0 + 3) & ~3;                             // rows stay 16-byte aligned
+    static_assert(F::G == 1, "one frame per wave-pass");
+};
+
+template <int NC, int E>
+__host__ __device__ inline size_t stream_lds_bytes(int wtot) {
+    using C = StreamCfg<NC, E>;
+    size_t b = (size_t)ST_WAVES * ((C::F::PADDED * sizeof(cf) + 15) & ~(size_t)15);
+    b += (size_t)ST_WAVES * 2 * C::PROW * 4;
+    b += ((size_t)wtot * 4 + 15) & ~(size_t)15;
+    return b;
+}
+
+template <int NC, int E, bool POW2, bool FULLM>
+__global__ void __launch_bounds__(ST_WAVES * 64, 2)
+melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
+    using C = StreamCfg<NC, E>;
+    using F = typename C::F;
+    constexpr int PROW = C::PROW, NBINS = C::NBINS, SLOTS = 2 * ST_WAVES;
+    constexpr int XA_BYTES = (F::PADDED * sizeof(cf) + 15) & ~15;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    cf* xa = reinterpret_cast<cf*>(smem_raw + (size_t)w * XA_BYTES);                 // this wave's exchange area
+    float* const rows_all = reinterpret_cast<float*>(smem_raw + (size_t)ST_WAVES * XA_BYTES);
+    float* rowA = rows_all + (size_t)(2 * w) * PROW;                                 // |X|^2 row of thread A / B
+    float* rowB = rowA + PROW;
+    float* wlds = rows_all + (size_t)ST_WAVES * 2 * PROW;
+
+    for (int i = tid; i < m.wtot; i += ST_WAVES * 64) wlds[i] = m.wl[i];
+    for (int i = tid; i < ST_WAVES * 2 * (PROW - NBINS); i += ST_WAVES * 64) {       // slack columns stay zero for good
+        const int r = i / (PROW - NBINS), c2 = i - r * (PROW - NBINS);
+        rows_all[(size_t)r * PROW + NBINS + c2] = 0.0f;
+    }
+
+    // this workgroup's contiguous range of global frames
+    const long long chunk = (m.total + gridDim.x - 1) / gridDim.x;
+    const long long begin = (long long)blockIdx.x * chunk;
+    const long long endl = begin + chunk < m.total ? begin + chunk : m.total;
+    const int nloc = endl > begin ? (int)(endl - begin) : 0;
+    const unsigned T = (unsigned)g.n_frames;
+
+    const int t = lane;
+    cf tw[F::NTW];
+    F::load_twiddles(tw, tb.w_nc, t);
+    const cf w0 = tb.w_n[t];                                           // R2C: W_N^{t + 64 i} = W_N^t * W_32^i
+    cf win[E];
+    load_window_regs<F>(win, g, t);
+    const float half = 0.5f * g.scale;                                 // 2X -> scale * X once, in the window
+#pragma unroll
+    for (int e = 0; e < E; ++e) win[e] = cscale(win[e], half);
+    int lo_s[ST_MAX_SLOTS];
+#pragma unroll
+    for (int s = 0; s < ST_MAX_SLOTS; ++s) lo_s[s] = s < m.nslot ? m.lo[s * 64 + lane] : 0;
+    __syncthreads();                                                   // the only barrier of the kernel (tables in place)
+
+#if TAC_ST_TIMING
+    float tstamp[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const long long tstart = clock64();
+    long long tlast = tstart;
+#define ST_MARK(k) do { const long long now_ = clock64(); tstamp[k] += (float)(now_ - tlast); tlast = now_; } while (0)
+#else
+#define ST_MARK(k) do { } while (0)
+#endif
+    cf vA[E], vB[E];
+    cf zmA[F::NPAIR], zmB[F::NPAIR], zmidA = mkc(0.f, 0.f), zmidB = mkc(0.f, 0.f);
+
+    // Request the samples of local frame i straight into the thread's (by then dead) data registers, three stages
+    // before they are used.  The sixteen loads are issued for EVERY frame — for a frame that touches the padding from a
+    // clamped, in-range address (its data is gathered at consumption time instead, mode 2) — and indices past the end of
+    // the range are clamped to its last frame, which is then simply computed and stored twice with identical values:
+    // the instruction stream is the same on every path, so hipcc's waitcnt pass can count (gfx950 has ONE in-order
+    // vmcnt for loads and stores; an uncounted wait for these loads would also wait for the row stores behind them).
+    auto request = [&](cf (&raw)[E], int i, int& mode, int& row, long long& fr) {
+        i = i < nloc ? i : nloc - 1;
+        const unsigned gf = (unsigned)(begin + i);
+        const unsigned r = gf / T;
+        row = (int)r;
+        fr = (long long)(gf - r * T);
+        const long long start = fr * (long long)g.hop - g.center_pad;
+        const bool ok = g.vec2_ok && start >= 0 && start + F::N <= g.length;
+        mode = ok ? 1 : 2;
+        long long cs = start < 0 ? 0 : start;
+        cs = cs + F::N <= g.length ? cs : g.length - F::N;             // host guarantees length >= N
+        const cf* src = reinterpret_cast<const cf*>(g.wave + (long long)row * g.row_stride + cs);
+        if (TAC_ST_ABL != 4) {
+#pragma unroll
+            for (int q = 0; q < E; ++q) raw[q] = src[t + q * F::LPF];
+        }
+    };
+    // s0: windowed samples -> pass-0 butterflies -> exchange 0 (write, read-back issued)
+    auto s0 = [&](cf (&v)[E], int mode, int row, long long fr) {
+        if (mode == 1) {
+            apply_window<F>(v, v, win);
+        } else {                                                       // edge / unaligned frame: gathered through the exchange
+            load_frame<F, true>(v, g, win, xa, row, fr, t);            // area with the plain window -> the 0.5*scale goes here
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] = cscale(v[e], half);
+        }
+    };
+    auto s0b = [&](cf (&v)[E]) {
+        F::template pass_butterflies<0>(v);
+        wave_lds_fence();
+        F::template pass_write<0, true>(v, xa, t, t);
+        wave_lds_fence();
+        F::template pass_readback<1>(v, xa, t);
+    };
+    // s12: pass 1, the in-register exchange, pass 2; the lower half of the spectrum stays in registers, the upper half
+    // travels to its R2C partners
+    auto s12 = [&](cf (&v)[E], cf (&zm)[F::NPAIR], cf& zmid) {
+        F::template pass_twiddle<1>(v, tw);
+        F::template pass_butterflies<1>(v);
+        F::exchange_1_2_in_registers(v);
+        F::template pass_twiddle<2>(v, tw);
+        F::template pass_butterflies<2>(v);
+        wave_lds_fence();
+        F::template pass_write<2, true>(v, xa, t, t);
+        wave_lds_fence();
+#pragma unroll
+        for (int p = 0; p < F::NPAIR; ++p) {
+            const int kk = t + p * F::LPF;
+            zm[p] = (p == 0) ? F::r2c_partner(xa, kk, v[F::reg_of_spectrum(0)]) : xa[lds_pad(NC - kk)];
+        }
+        zmid = xa[lds_pad(NC / 2)];
+    };
+    // s3: R2C split, |X|^p row into the thread's row buffer
+    auto s3 = [&](cf (&v)[E], cf (&zm)[F::NPAIR], cf zmid, float* prow) {
+        wave_lds_fence();
+#pragma unroll
+        for (int p = 0; p < F::NPAIR; ++p) {
+            const int kk = t + p * F::LPF;
+            cf xk, xm;
+            F::r2c_split_factored_x2(v[F::reg_of_spectrum(p)], zm[p], w0, p, xk, xm);
+            const float pa = cnorm2(xk), pb = cnorm2(xm);
+            prow[kk] = POW2 ? pa : __builtin_amdgcn_sqrtf(pa);
+            prow[NC - kk] = POW2 ? pb : __builtin_amdgcn_sqrtf(pb);
+        }
+        if (t == 0) {
+            const float pm = 4.0f * cnorm2(zmid);                       // X[NC/2] = conj(Z[NC/2]); Z carries the 0.5
+            prow[NC / 2] = POW2 ? pm : __builtin_amdgcn_sqrtf(pm);
+        }
+        wave_lds_fence();
+    };
+    // s4: filterbank contraction (one band per lane and slot; four taps per step: one 16-byte weight read, one 16-byte
+    // row read, two packed FMAs), dB, row store.  A trip is eight steps whose sixteen reads are all issued before the
+    // first FMA (the thread's data registers are free by now), so a slot costs one or two LDS round trips, not one per
+    // step; slot lengths are whole half-trips (tac_melbank_pack).
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    auto fma4 = [](f4 wv, f4 pv, cf& a0, cf& a1) {
+        a0 = __builtin_elementwise_fma(mkc(wv.x, wv.y), mkc(pv.x, pv.y), a0);
+        a1 = __builtin_elementwise_fma(mkc(wv.z, wv.w), mkc(pv.z, pv.w), a1);
+    };
+    const bool fast_db = m.amin >= 1.1754944e-38f;                      // (uniform) hardware log2 unless the clamp admits denormals
+    const float ten_log10_ref = 10.0f * m.log10_ref;
+    auto s4 = [&](const float* prow, int i) {
+        if (TAC_ST_ABL == 1) return;
+        i = i < nloc ? i : nloc - 1;
+        const f4* wp = reinterpret_cast<const f4*>(wlds) + lane;
+        float* orow = m.out + (begin + i) * (long long)m.n_mels + lane;
+#pragma unroll
+        for (int s = 0; s < ST_MAX_SLOTS; ++s) {
+            if (s < m.nslot) {
+                const f4* pp = reinterpret_cast<const f4*>(prow + (TAC_ST_ABL == 5 ? 4 * (lane & 15) : lo_s[s]));
+                const int n = m.steps[s];
+                cf acc0 = mkc(0.f, 0.f), acc1 = mkc(0.f, 0.f);
+                int j = 0;
+#pragma unroll 1
+                for (; j + 8 <= n; j += 8, wp += 512) {
+                    f4 wv[8], pv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        wv[u] = wp[u * 64];
+                        pv[u] = pp[j + u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) fma4(wv[u], pv[u], acc0, acc1);
+                }
+                if (j < n) {                                              // half trip
+                    f4 wv[4], pv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        wv[u] = wp[u * 64];
+                        pv[u] = pp[j + u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) fma4(wv[u], pv[u], acc0, acc1);
+                    wp += 256;
+                }
+                float v = (acc0.x + acc0.y) + (acc1.x + acc1.y);
+                if (m.db && TAC_ST_ABL != 3) v = fast_db ? amp_to_db_fast(v, m.amin, ten_log10_ref) : amp_to_db(v, m.amin, m.log10_ref);
+                if (TAC_ST_ABL == 2 ? v == 12345.678f : (FULLM || s * 64 + lane < m.n_mels)) orow[s * 64] = v;
+            }
+        }
+    };
+
+    // Frames of thread A: 2w + n*SLOTS, thread B: 2w + 1 + n*SLOTS.  Rotation of one iteration:
+    //   A.s0 | B.s3 + request | A.s12 | B.s4 | A.s3 + request | B.s0 | A.s4 | B.s12
+    // where B's s3 / s4 finish its frame n and its s0 / s12 start frame n + 1 (B's first frame is brought to that point
+    // before the loop).  A thread's next samples are requested as soon as its registers are free (after s3).  No branch
+    // inside the loop: every wave runs the same number of iterations, surplus frame numbers are clamped (request).
+    if (nloc > 0) {
+        const int iters = (nloc + SLOTS - 1) / SLOTS;
+        int modeA, rowA_, modeB, rowB_;
+        long long frA, frB;
+        int iA = 2 * w, iB = 2 * w + 1;
+        request(vB, iB, modeB, rowB_, frB);
+        request(vA, iA, modeA, rowA_, frA);
+        s0(vB, modeB, rowB_, frB);
+        s0b(vB);
+        s12(vB, zmB, zmidB);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0): the loop is entered with nothing in flight
+        ST_MARK(6);
+#pragma unroll 1
+        for (int n = 0; n < iters; ++n) {
+            s0(vA, modeA, rowA_, frA);
+            s0b(vA);
+            __builtin_amdgcn_sched_barrier(0);
+            ST_MARK(1);
+            s3(vB, zmB, zmidB, rowB);
+            request(vB, iB + SLOTS, modeB, rowB_, frB);
+            __builtin_amdgcn_sched_barrier(0);
+            ST_MARK(4);
+            s12(vA, zmA, zmidA);
+            __builtin_amdgcn_sched_barrier(0);
+            ST_MARK(2);
+            s4(rowB, iB);
+            __builtin_amdgcn_sched_barrier(0);
+            ST_MARK(5);
+            s3(vA, zmA, zmidA, rowA);
+            request(vA, iA + SLOTS, modeA, rowA_, frA);
+            __builtin_amdgcn_sched_barrier(0);
+            ST_MARK(4);
+            s0(vB, modeB, rowB_, frB);
+            s0b(vB);
+            __builtin_amdgcn_sched_barrier(0);
+            ST_MARK(1);
+            s4(rowA, iA);
+            __builtin_amdgcn_sched_barrier(0);
+            ST_MARK(5);
+            s12(vB, zmB, zmidB);
+            __builtin_amdgcn_sched_barrier(0);
+            ST_MARK(2);
+            iA += SLOTS;
+            iB += SLOTS;
+        }
+    }
+#if TAC_ST_TIMING
+    tstamp[0] = (float)(clock64() - tstart);
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) m.out[((long long)blockIdx.x * 8 + w) * 8 + i] = tstamp[i];
+#endif
+}
+
+}  // namespace tac
