@@ -192,6 +192,27 @@ int tac_mulaw_decode_i64_f32(const int64_t* codes, int64_t n, int32_t n_quantize
 int tac_mulaw_decode_f32_f32(const float* codes, int64_t n, int32_t n_quantize, const float* lut,
                              float* out, void* stream);
 
+/* (9) Gradients (the reference differentiates through stock torch ops).  All asynchronous on `stream`,
+ *     caller-allocated outputs, float32, the frame-major layouts of the forward entry points.
+ *     tac_stft_backward_f32: adjoint of (1) up to the overlap-add: grad_spec[rows][T][F][2] (one-sided) ->
+ *       grad_frames[rows][T][n_fft] = window[n] * scale * Re sum_k grad_spec[k] e^{+2 pi i k n / n_fft}  (one inverse
+ *       real FFT per frame on the same wave-level FFT as the forward pass).
+ *     tac_overlap_add_f32: adjoint of framing + padding: grad_wave[r][j] = sum of grad_frames over every (frame, tap)
+ *       that read sample j, reflect / replicate / circular images included (a gather: deterministic, no atomics).
+ *     tac_complex_norm_backward_f32: grad_z[i] = grad_out[i] * power * |z_i|^(power-2) * z_i (0 where z_i == 0),
+ *       functional.py:126-128.
+ *     tac_amplitude_to_db_backward_f32: grad_x = grad_out * 20 / (ln 10 * x) where x^2 >= amin, else 0,
+ *       functional.py:291-296.
+ *     The filterbank stage's adjoint is (4) with the transposed matrix. */
+int tac_stft_backward_f32(const float* grad_spec, const float* window, const tac_stft_desc* d,
+                          float* grad_frames, void* stream);
+int tac_overlap_add_f32(const float* grad_frames, const tac_stft_desc* d, float* grad_wave,
+                        int64_t grad_row_stride, void* stream);
+int tac_complex_norm_backward_f32(const float* z, const float* grad_out, int64_t n, float power,
+                                  float* grad_z, void* stream);
+int tac_amplitude_to_db_backward_f32(const float* x, const float* grad_out, int64_t n, float amin,
+                                     float* grad_x, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -792,8 +792,46 @@ def test_autograd_matches_the_reference_chain(tac, shape, n_fft, hop, mels):
                   torch.nn.Sequential(*mel, tac.AmplitudeToDb(amin=1e-5))):             # the unpacked idiom
         y = chain(xg)
         assert y.requires_grad and np.abs(host(y) - want_y.detach().numpy()).max() < DB_ABS
+        before = launches(tac)
         (got,) = torch.autograd.grad((y * dev(weight)).sum(), xg)
+        ran = launched_since(tac, before)
+        assert ran.get('tac_stft_backward_f32') == 1 and ran.get('tac_overlap_add_f32') == 1, ran   # the HIP gradient kernels
         assert rel_err(host(got), want.numpy()) < 1e-3
+
+
+@pytest.mark.parametrize('n_fft,hop,kw', [(512, 128, {}), (256, 64, dict(pad_mode='constant')), (1024, 300, dict(pad_mode='replicate')),
+                                          (128, 32, dict(pad_mode='circular', normalized=True)), (4096, 1024, {}),
+                                          (2048, 512, dict(center=False)), (512, 128, dict(win_length=400)), (64, 16, {})])
+def test_stft_gradient_kernels(tac, n_fft, hop, kw):
+    """Adjoint of the STFT kernels (inverse real FFT per frame + gather overlap-add) against torch.autograd through the
+    CPU restatement of the reference, every pad mode (the images of the padding carry gradient too), several frames per
+    wave (n_fft <= 1024), 32 elements per lane (n_fft = 4096); and of |.|^p and dB on their own."""
+    x = signals.audio_like((2, 2, 9000), seed=91)
+    gw = signals.uniform((2, 2, n_fft // 2 + 1, tac._hip.stft_frames(9000, n_fft, hop, kw.get('center', True)), 2), seed=92)
+    xc = torch.from_numpy(x).requires_grad_(True)
+    okw = {k: v for k, v in kw.items()}
+    (want,) = torch.autograd.grad((torch_ref.stft(xc, n_fft, hop, **okw) * torch.from_numpy(gw)).sum(), xc)
+    xg = dev(x).requires_grad_(True)
+    before = launches(tac)
+    (got,) = torch.autograd.grad((tac.stft(xg, n_fft, hop_length=hop, **kw) * dev(gw)).sum(), xg)
+    assert launched_since(tac, before).get('tac_stft_backward_f32') == 1
+    assert rel_err(host(got), want.numpy()) < 1e-5
+    # |z|^p and dB adjoints (elementwise kernels), incl. the zero of the norm and the clamp of the dB
+    z = signals.audio_like((3, 40, 17, 2), seed=93)
+    z[0, :3, :2] = 0.0
+    for power in (1.0, 2.0, 0.7):
+        zc = torch.from_numpy(z).requires_grad_(True)
+        (wz,) = torch.autograd.grad(torch_ref.complex_norm(zc, power).sum(), zc)
+        zg = dev(z).requires_grad_(True)
+        (gz,) = torch.autograd.grad(tac.complex_norm(zg, power).sum(), zg)
+        ok = np.isfinite(wz.numpy())                                  # torch gives NaN at z == 0 for power < 1; the kernel gives 0
+        assert rel_err(host(gz)[ok], wz.numpy()[ok]) < 1e-5 and np.isfinite(host(gz)).all()
+    a = signals.audio_like((4, 700), seed=94)
+    ac = torch.from_numpy(a).requires_grad_(True)
+    (wa,) = torch.autograd.grad(torch_ref.amplitude_to_db(ac, 2.0, 1e-3).sum(), ac)
+    ag = dev(a).requires_grad_(True)
+    (ga,) = torch.autograd.grad(tac.amplitude_to_db(ag, 2.0, 1e-3).sum(), ag)
+    assert rel_err(host(ga), wa.numpy()) < 1e-5
 
 
 def test_library_ops_pass_opcheck(tac):

@@ -315,7 +315,7 @@ def melspectrogram(wave, window, fb, n_fft, hop, win_length, center, pad_mode, n
 
 
 # ----------------------------------------------------------------------------- filterbank
-def apply_filterbank(spec, fb):
+def apply_filterbank(spec, fb, allow_sparse=True):
     fb = fb if fb.is_contiguous() else fb.contiguous()
     n_freqs, n_frames = spec.shape[-2], spec.shape[-1]
     lead = tuple(spec.shape[:-2])
@@ -325,7 +325,7 @@ def apply_filterbank(spec, fb):
         rows = spec.reshape(-1, n_freqs, n_frames)
         # frame-major spectrogram (what the kernels here produce) + band-sparse bank: stream it through the fused
         # kernel's contraction; anything else goes through the fp32 MFMA GEMM
-        pack = _melbank_pack(fb, 0) if (rows.stride(1) == 1 and MEL_PATH != 'mfma') else None
+        pack = _melbank_pack(fb, 0) if (allow_sparse and rows.stride(1) == 1 and MEL_PATH != 'mfma') else None
         if pack is not None:
             wpack, desc, info = pack
             with _native.on_device(spec.device):
@@ -536,3 +536,80 @@ def mu_law_decoding_float(codes, n_quantize):
     return _unary(codes, 'tac_mulaw_decode_f32_f32',
                   lambda h, p, n, o, s: h.tac_mulaw_decode_f32_f32(p, n, n_quantize,
                                                                    None if lut is None else _native.ptr(lut), o, s))
+
+
+# ----------------------------------------------------------------------------- gradients
+def transposed_bank(fb):
+    """(M, F) contiguous transpose of a filterbank, cached on the tensor per version (the adjoint of the filterbank
+    stage is the same GEMM kernel with this matrix)."""
+    hit = getattr(fb, '_tac_T', None)
+    if hit is not None and hit[0] == fb._version:
+        return hit[1]
+    t = fb.detach().t().contiguous()
+    try:
+        fb._tac_T = (fb._version, t)
+    except Exception:
+        pass
+    return t
+
+
+def apply_filterbank_backward(grad_out, fb):
+    """(*, M, T) gradient -> (*, F, T): the forward MFMA GEMM with the transposed bank."""
+    return apply_filterbank(grad_out, transposed_bank(fb), allow_sparse=False)
+
+
+def stft_backward(grad_spec, wave, window, n_fft, hop, win_length, center, pad_mode, normalized):
+    """grad of the one-sided stft output ``(*, F, T, 2)`` w.r.t. the waveform: one inverse real FFT per frame
+    (tac_stft_backward_f32) followed by the gather form of overlap-add (tac_overlap_add_f32)."""
+    g = geometry(wave, n_fft, hop, win_length, center, pad_mode, normalized, True)
+    gs = grad_spec.transpose(-3, -2)                                  # physical frame-major (*, T, F, 2)
+    gs = gs if gs.is_contiguous() else gs.contiguous()
+    frames = torch.empty((g.rows, g.n_frames, n_fft), dtype=torch.float32, device=wave.device)
+    out = torch.empty(tuple(wave.shape), dtype=torch.float32, device=wave.device)
+    desc = _native.StftDesc(rows=g.rows, length=g.length, row_stride=g.length, n_fft=n_fft, hop=hop,
+                            win_length=win_length, center=1 if center else 0, pad_mode=_native.PAD_MODES[pad_mode],
+                            normalized=1 if normalized else 0, onesided=1, reserved=0)
+    with _native.on_device(wave.device):
+        rc = _native.lib().tac_stft_backward_f32(_native.ptr(gs), _native.ptr(window), desc, _native.ptr(frames),
+                                                 _native.stream_ptr(wave.device))
+        _native.check(rc, 'tac_stft_backward_f32')
+        _count('tac_stft_backward_f32')
+        rc = _native.lib().tac_overlap_add_f32(_native.ptr(frames), desc, _native.ptr(out), g.length,
+                                               _native.stream_ptr(wave.device))
+        _native.check(rc, 'tac_overlap_add_f32')
+        _count('tac_overlap_add_f32')
+    return out
+
+
+def stft_backward_supported(n_fft, onesided):
+    return bool(onesided) and fft_kernel_size(n_fft)
+
+
+def complex_norm_backward(z, grad_out, power):
+    """(*, F, T, 2) pairs and (*, F, T) gradients in, (*, F, T, 2) out — all walked in z's dense storage order."""
+    z = _pairs(z)
+    go = torch.empty_strided(z.shape[:-1], tuple(s // 2 for s in z.stride()[:-1]), dtype=torch.float32, device=z.device)
+    go.copy_(grad_out)
+    gz = torch.empty_strided(z.shape, z.stride(), dtype=torch.float32, device=z.device)
+    n = go.numel()
+    if n:
+        with _native.on_device(z.device):
+            rc = _native.lib().tac_complex_norm_backward_f32(_native.ptr(z), _native.ptr(go), n, float(power),
+                                                             _native.ptr(gz), _native.stream_ptr(z.device))
+        _native.check(rc, 'tac_complex_norm_backward_f32')
+        _count('tac_complex_norm_backward_f32')
+    return gz
+
+
+def amplitude_to_db_backward(x, grad_out, amin):
+    x = x if is_dense(x) else x.contiguous()
+    go = torch.empty_like(x)
+    go.copy_(grad_out)
+    gx = torch.empty_like(x)
+    if x.numel():
+        with _native.on_device(x.device):
+            rc = _native.lib().tac_amplitude_to_db_backward_f32(_native.ptr(x), _native.ptr(go), x.numel(), float(amin),
+                                                                _native.ptr(gx), _native.stream_ptr(x.device))
+        _native.check(rc, 'tac_amplitude_to_db_backward_f32')
+        _count('tac_amplitude_to_db_backward_f32')
+    return gx

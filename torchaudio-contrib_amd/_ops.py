@@ -15,8 +15,11 @@ compute — and fft sizes outside the kernels' range are evaluated by torch's ow
 (``_composite.py``) with a one-time ``CompositeRouteWarning``; ``set_strict(True)`` turns that route into an error
 (the GPU parity tests run strict, so nothing they check can have come from anywhere but the HIP kernels).
 
-Autograd: the fused Melspectrogram(+dB) chain has hand-written backward kernels (``tac_amd::melspectrogram_backward``);
-every other op differentiates by re-evaluating itself with torch ops under ``enable_grad`` (documented fallback).
+Autograd: stft / spectrogram / melspectrogram / apply_filterbank / complex_norm / amplitude_to_db have hand-written
+gradient kernels for the signal path (csrc/backward.hip: inverse real FFT per frame + gather overlap-add, the
+filterbank GEMM with the transposed bank, elementwise adjoints; the fused ops recompute their spectrum instead of
+saving it).  Gradients w.r.t. the window / filterbank, float64, CPU tensors and the remaining ops differentiate by
+re-evaluating the op with torch operators under ``enable_grad``.
 """
 import warnings
 
@@ -98,10 +101,16 @@ def _n_frames(length, n_fft, hop, center):
     return 1 + (length + (2 * (n_fft // 2) if center else 0) - n_fft) // hop
 
 
-# ============================================================================= autograd by re-evaluation
-def _autograd_by_recompute(op, fn, n_tensors):
-    """Backward of an op without hand-written gradient kernels: re-evaluate it with differentiable torch operators
-    (``_composite``) on the saved inputs and differentiate that."""
+# ============================================================================= autograd
+def _plain_hip_f32(*tensors):
+    return all(t is not None and type(t) is torch.Tensor and t.is_cuda and t.dtype == torch.float32 for t in tensors)
+
+
+def _register_autograd(op, fn, n_tensors, hip_backward=None):
+    """Backward of ``tac_amd::<op>``.  ``hip_backward(tensors, rest, needs, grads)`` — the hand-written gradient
+    kernels (csrc/backward.hip) — is used when it applies (float32 on a HIP device, gradient asked for the signal
+    path only); it returns None otherwise and the op is then differentiated by re-evaluating it with differentiable
+    torch operators (``_composite``) on the saved inputs."""
 
     def setup_context(ctx, inputs, output):
         ctx.save_for_backward(*inputs[:n_tensors])
@@ -109,9 +118,15 @@ def _autograd_by_recompute(op, fn, n_tensors):
 
     def backward(ctx, *grads):
         needs = ctx.needs_input_grad[:n_tensors]
+        saved = ctx.saved_tensors
+        if hip_backward is not None and _plain_hip_f32(*saved) and all(g is None or _plain_hip_f32(g) for g in grads):
+            with torch.no_grad():
+                res = hip_backward(saved, ctx.rest, needs, grads)
+            if res is not None:
+                return tuple(res) + (None,) * len(ctx.rest)
         with torch.enable_grad():
             ins = [t.detach().requires_grad_(True) if (need and t.is_floating_point()) else t.detach()
-                   for t, need in zip(ctx.saved_tensors, needs)]
+                   for t, need in zip(saved, needs)]
             outs = fn(*ins, *ctx.rest)
             outs = outs if isinstance(outs, tuple) else (outs,)
             pairs = [(o, g) for o, g in zip(outs, grads) if g is not None and o.requires_grad]
@@ -122,6 +137,72 @@ def _autograd_by_recompute(op, fn, n_tensors):
         return tuple(result) + (None,) * len(ctx.rest)
 
     torch.library.register_autograd('%s::%s' % (NS, op), backward, setup_context=setup_context, lib=_lib)
+
+
+def _signal_path_only(needs):
+    """Gradient wanted for the first tensor (waveform / spectrogram) and for none of the constant tables."""
+    return bool(needs[0]) and not any(needs[1:])
+
+
+def _stft_hip_backward(saved, rest, needs, grads):
+    wave, window = saved
+    n_fft, hop, win_length, center, pad_mode, normalized, onesided = rest[:7]
+    if not _signal_path_only(needs) or not H.stft_backward_supported(n_fft, onesided) or grads[0] is None:
+        return None
+    return [H.stft_backward(grads[0], wave, window.contiguous(), n_fft, hop, win_length, center, pad_mode, normalized),
+            None]
+
+
+def _spectrogram_hip_backward(saved, rest, needs, grads):
+    wave, window = saved
+    n_fft, hop, win_length, center, pad_mode, normalized, onesided, power, db, ref, amin = rest
+    if not _signal_path_only(needs) or not H.stft_backward_supported(n_fft, onesided) or grads[0] is None:
+        return None
+    window = window.contiguous()
+    z = H.stft(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided)      # recomputed, not saved
+    g = grads[0]
+    if db:
+        g = H.amplitude_to_db_backward(H.complex_norm(z, power), g, amin)
+    gz = H.complex_norm_backward(z, g, power)
+    return [H.stft_backward(gz, wave, window, n_fft, hop, win_length, center, pad_mode, normalized), None]
+
+
+def _melspectrogram_hip_backward(saved, rest, needs, grads):
+    wave, window, bank = saved
+    n_fft, hop, win_length, center, pad_mode, normalized, onesided, power, db, ref, amin = rest
+    if not _signal_path_only(needs) or not H.stft_backward_supported(n_fft, onesided) or grads[0] is None:
+        return None
+    window = window.contiguous()
+    z = H.stft(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided)
+    g = grads[0]
+    if db:
+        mel = H.apply_filterbank(H.complex_norm(z, power), bank)
+        g = H.amplitude_to_db_backward(mel, g, amin)
+    gz = H.complex_norm_backward(z, H.apply_filterbank_backward(g, bank), power)
+    return [H.stft_backward(gz, wave, window, n_fft, hop, win_length, center, pad_mode, normalized), None, None]
+
+
+def _apply_filterbank_hip_backward(saved, rest, needs, grads):
+    if not _signal_path_only(needs) or grads[0] is None:
+        return None
+    return [H.apply_filterbank_backward(grads[0], saved[1]), None]
+
+
+def _complex_norm_hip_backward(saved, rest, needs, grads):
+    if grads[0] is None or saved[0].shape[-1] != 2:
+        return None
+    return [H.complex_norm_backward(saved[0], grads[0], rest[0])]
+
+
+def _amplitude_to_db_hip_backward(saved, rest, needs, grads):
+    if grads[0] is None:
+        return None
+    return [H.amplitude_to_db_backward(saved[0], grads[0], rest[1])]
+
+
+_HIP_BACKWARD = {'stft': _stft_hip_backward, 'spectrogram': _spectrogram_hip_backward,
+                 'melspectrogram': _melspectrogram_hip_backward, 'apply_filterbank': _apply_filterbank_hip_backward,
+                 'complex_norm': _complex_norm_hip_backward, 'amplitude_to_db': _amplitude_to_db_hip_backward}
 
 
 #: the CUDA-key kernels by op name: `call` below invokes them directly when the dispatcher has nothing to add
@@ -156,7 +237,7 @@ def _register(op, schema, cuda, cpu, fake, n_tensors, differentiable=True):
     _lib.impl(op, cpu, 'CPU')
     torch.library.register_fake('%s::%s' % (NS, op), fake, lib=_lib)
     if differentiable:
-        _autograd_by_recompute(op, cpu, n_tensors)
+        _register_autograd(op, cpu, n_tensors, _HIP_BACKWARD.get(op))
 
 
 # ============================================================================= stft
@@ -234,7 +315,7 @@ _lib.define('melspectrogram(Tensor wave, Tensor window, Tensor filterbank, %s, f
 _lib.impl('melspectrogram', _melspectrogram_cuda, 'CUDA')
 _lib.impl('melspectrogram', C.melspectrogram, 'CPU')
 torch.library.register_fake(NS + '::melspectrogram', _melspectrogram_fake, lib=_lib)
-_autograd_by_recompute('melspectrogram', C.melspectrogram, 3)
+_register_autograd('melspectrogram', C.melspectrogram, 3, _melspectrogram_hip_backward)
 
 
 # ============================================================================= apply_filterbank

@@ -26,6 +26,9 @@
 #ifndef TAC_ST_ABL
 #define TAC_ST_ABL 0        // ablation builds (wrong results): 1 no contraction stage, 2 no row stores, 3 no dB, 4 no sample loads, 5 conflict-free row reads
 #endif
+#ifndef TAC_ST_PRIO
+#define TAC_ST_PRIO 0       // A/B knob: 1 = static priority for the younger wave of each SIMD (waves 4-7), 2 = for the older
+#endif
 #ifndef TAC_ST_TIMING
 #define TAC_ST_TIMING 0     // 1: debug builds of tools/stream_timing.py — per-wave cycle sums overwrite the head of out[]
 #endif
@@ -255,6 +258,8 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     // where B's s3 / s4 finish its frame n and its s0 / s12 start frame n + 1 (B's first frame is brought to that point
     // before the loop).  A thread's next samples are requested as soon as its registers are free (after s3).  No branch
     // inside the loop: every wave runs the same number of iterations, surplus frame numbers are clamped (request).
+    if (TAC_ST_PRIO == 1 && w >= 4) __builtin_amdgcn_s_setprio(1);
+    if (TAC_ST_PRIO == 2 && w < 4) __builtin_amdgcn_s_setprio(1);
     if (nloc > 0) {
         const int iters = (nloc + SLOTS - 1) / SLOTS;
         int modeA, rowA_, modeB, rowB_;
