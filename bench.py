@@ -204,7 +204,7 @@ def run(a):
                                '%d mel (BASELINE configs[1])' % (BATCH, CHANNELS, SR, SECONDS, N_FFT, HOP, N_MELS),
                    'global_batch': world * BATCH, 'frames_per_step': frames_per_step,
                    'parallelism': 'batch-sharded x%d, no data-path collective' % world},
-        'roofline': {'kernel': 'melspec_sparse_kernel<1024,16,pow2> (fused STFT + power + band-sparse mel + dB)', 'bound': 'hbm',
+        'roofline': {'kernel': 'melspec_stream_kernel<1024,16,pow2,fullM> (fused STFT + power + band-sparse mel + dB, one launch per step)', 'bound': 'hbm',
                      'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                      'traffic': None, 'alg_bytes_per_launch': alg_bytes, 'kernel_ms_mean': mean_ms,
                      'kernel_ms_median': med_ms},
@@ -219,7 +219,8 @@ def run(a):
         except Exception:
             continue
         for kname, d in pmc.items():
-            if 'melspec_sparse_kernel<1024' in kname and 'hbm_traffic_bytes_per_launch' in d:
+            if ('melspec_stream_kernel<1024' in kname or 'melspec_sparse_kernel<1024' in kname) \
+                    and 'hbm_traffic_bytes_per_launch' in d:
                 result['roofline']['traffic'] = d['hbm_traffic_bytes_per_launch']
                 result['roofline']['traffic_source'] = ('profiles/%s/pmc_mel.json (rocprofv3 --pmc FETCH_SIZE / '
                                                         'WRITE_SIZE)' % rnd)

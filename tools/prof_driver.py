@@ -18,7 +18,7 @@ if what == 'mel':
     fn = lambda: m(x)
 elif what == 'stft':
     layer = tac.STFT(2048, 512).cuda()
-    fn = lambda: tac.realize(layer(x))
+    fn = lambda: tac.stft(x, 2048, 512)
 elif what == 'spec':
     s = tac.Spectrogram(2048, 512, power=2.).cuda()
     fn = lambda: s(x)
