@@ -213,6 +213,15 @@ int tac_complex_norm_backward_f32(const float* z, const float* grad_out, int64_t
 int tac_amplitude_to_db_backward_f32(const float* x, const float* grad_out, int64_t n, float amin,
                                      float* grad_x, void* stream);
 
+/* (10) hpss, beta_hpss.py:35-127: median-filter harmonic / percussive separation of a magnitude
+ *      spectrogram.  mag element (r, f, t) at mag[r*stride_r + f*stride_f + t*stride_t]; the four outputs use the same
+ *      strides.  kernel_f (percussive filter, along frequency) and kernel_t (harmonic filter, along time) odd, <= 32;
+ *      reflect padding (needs kernel/2 < size: TAC_E_SHORT_INPUT otherwise); masks soft ((h+eps)/(h+p+eps), eps 1e-6) or
+ *      hard (1.0 / 0.0); harm / perc may both be NULL (masks only). */
+int tac_hpss_f32(const float* mag, int64_t rows, int32_t n_freqs, int32_t n_frames, int64_t stride_r,
+                 int64_t stride_f, int64_t stride_t, int32_t kernel_f, int32_t kernel_t, float power,
+                 int hard, float* harm, float* perc, float* mask_harm, float* mask_perc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -143,6 +143,28 @@ def phase_vocoder(spec, rate, phase_advance):
     return torch.stack([mag * torch.cos(acc), mag * torch.sin(acc)], dim=-1)
 
 
+# --------------------------------------------------------------------------- hpss
+def hpss(mag, kernel_size=31, power=2.0, hard=False):
+    """beta_hpss.py:35-127 (int kernel_size) — column by column / row by row running medians of the reflect-padded
+    spectrogram, as the reference loops; returns (harm spec, perc spec, harm mask, perc mask)."""
+    k = int(kernel_size)
+    half = k // 2
+    padded = torch.nn.functional.pad(mag, (half, half, half, half), mode='reflect')
+    n_freqs, n_frames = mag.shape[2], mag.shape[3]
+    harm, perc = torch.empty_like(mag), torch.empty_like(mag)
+    for f in range(n_freqs):
+        perc[:, :, f, :] = padded[:, :, f:f + k, half:half + n_frames].median(dim=2)[0]
+    for t in range(n_frames):
+        harm[:, :, :, t] = padded[:, :, half:half + n_freqs, t:t + k].median(dim=3)[0]
+    if power != 1.0:
+        perc, harm = perc.pow(power), harm.pow(power)
+    if hard:
+        mh, mp = harm > perc, harm < perc
+    else:
+        mh, mp = (harm + 1e-6) / (harm + perc + 1e-6), (perc + 1e-6) / (harm + perc + 1e-6)
+    return mag * mh, mag * mp, mh, mp
+
+
 # --------------------------------------------------------------------------- pipelines
 def spectrogram(x, n_fft, hop=None, win_length=None, window=None, center=True,
                 pad_mode='reflect', normalized=False, onesided=True, power=1.0):

@@ -191,3 +191,25 @@ def test_autograd_through_the_ops_on_cpu(tac):
     spec = tac.Spectrogram(256, 64, power=2.).double()(x.detach())
     (gfb,) = torch.autograd.grad(tac.apply_filterbank(spec, fb).sum(), fb)
     assert rel_err(gfb.numpy(), spec.sum(-1).sum((0, 1)).unsqueeze(1).expand(129, 7).numpy()) <= 1e-9
+
+
+def test_hpss_on_cpu_matches_golden(tac, golden):
+    """beta_hpss.py:35-127 through the product API on CPU tensors: values, the None pair of mask_only, bool hard masks, the
+    layer and its repr."""
+    from test_oracle_golden import HPSS_CASES, hpss_input
+    g = golden('g8_hpss')
+    mag = T(hpss_input())
+    for k, power, hard in HPSS_CASES:
+        res = tac.hpss(mag, k, power, hard)
+        tag = 'k%d_p%g_%s' % (k, power, 'hard' if hard else 'soft')
+        for name, r in zip(('harm', 'perc', 'mask_harm', 'mask_perc'), res):
+            want = g[tag + '_' + name]
+            assert r.dtype == (torch.bool if hard and name.startswith('mask') else torch.float32)
+            assert np.abs(r.numpy().astype(np.float32) - want.astype(np.float32)).max() <= 1e-6 * max(1.0, np.abs(want).max())
+    a, b, mh, mp = tac.HPSS(kernel_size=7, power=1.0, mask_only=True)(mag)
+    assert a is None and b is None and np.array_equal(mh.numpy(), g['k7_p1_soft_mask_harm'])
+    assert repr(tac.HPSS()) == 'HPSS(kernel_size=31, power=2.0, hard=False, mask_only=False)'
+    with pytest.raises(TypeError):
+        tac.hpss(mag, 3.0)
+    with pytest.raises(RuntimeError):
+        tac.hpss(mag[..., :10], 31)                      # reflect padding wider than the spectrogram

@@ -852,6 +852,48 @@ def test_library_ops_pass_opcheck(tac):
     opcheck(torch.ops.tac_amd.phase_vocoder.default, (z, torch.linspace(0, 3.14 * 128, 257).cuda(), 1.3), test_utils=utils)
 
 
+def test_g8_hpss(tac, golden):
+    """hpss on the HIP kernel: golden outputs of the reference (the medians select existing values, so
+    harm / perc are exact up to pow and the mask quotient), the strided spectrogram the STFT kernels return, unequal
+    filter widths against a numpy restatement of the documented behaviour, and the stock-torch route for wide kernels."""
+    from test_oracle_golden import HPSS_CASES, hpss_input
+    g = golden('g8_hpss')
+    mag = hpss_input()
+    for k, power, hard in HPSS_CASES:
+        before = launches(tac)
+        res = tac.hpss(dev(mag), k, power, hard)
+        assert launched_since(tac, before) == {'tac_hpss_f32': 1}
+        tag = 'k%d_p%g_%s' % (k, power, 'hard' if hard else 'soft')
+        for name, r in zip(('harm', 'perc', 'mask_harm', 'mask_perc'), res):
+            want = g[tag + '_' + name].astype(np.float32)
+            assert r.dtype == (torch.bool if hard and name.startswith('mask') else torch.float32)
+            tol = (1e-6 if power in (1.0, 2.0) else 2e-6) * max(1.0, np.abs(want).max())     # powf within a few ulp
+            assert np.abs(host(r).astype(np.float32) - want).max() <= tol, (tag, name)
+    assert tac.HPSS(7, 1.0, mask_only=True).cuda()(dev(mag))[0] is None
+    # frame-major strided input (what Spectrogram returns) and unequal widths
+    x = dev(signals.audio_like((2, 1, 12000), seed=53))
+    spec = tac.Spectrogram(256, 64).cuda()(x)
+    assert not spec.is_contiguous()
+    h, p, mh, mp = tac.hpss(spec, (5, 9), 1.0)
+    s = host(spec).astype(np.float64)
+    padf = np.pad(s, ((0, 0), (0, 0), (2, 2), (0, 0)), mode='reflect')
+    padt = np.pad(s, ((0, 0), (0, 0), (0, 0), (4, 4)), mode='reflect')
+    perc = np.median(np.stack([padf[:, :, i:i + s.shape[2]] for i in range(5)], -1), -1)
+    harm = np.median(np.stack([padt[..., i:i + s.shape[3]] for i in range(9)], -1), -1)
+    want_mh = (harm + 1e-6) / (harm + perc + 1e-6)
+    assert np.abs(host(mh) - want_mh).max() < 1e-6 and np.abs(host(h) - s * want_mh).max() < 1e-6 * s.max()
+    assert mh.stride() == spec.stride()
+    tac.set_strict(False)
+    try:
+        tac._ops._warned.clear()
+        with pytest.warns(tac.CompositeRouteWarning, match='kernel_size'):
+            wide = tac.hpss(dev(mag), 41, 2.0)
+        want = torch_ref.hpss(torch.from_numpy(mag), 41, 2.0)
+        assert np.abs(host(wide[2]) - want[2].numpy()).max() < 1e-6
+    finally:
+        tac.set_strict(True)
+
+
 # ------------------------------------------------------------------ size-independent properties at BASELINE sizes
 def test_cfg2_full_size_properties(tac):
     """cfg-2 (256x1x160000, 2048/512/128): linearity of the power-mel map in amplitude², agreement of

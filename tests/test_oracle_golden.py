@@ -200,3 +200,23 @@ def test_g7_phase_vocoder(golden):
         got = torch_ref.phase_vocoder(z, rate, adv).numpy()
         want = g['pv_rate%g' % rate]
         assert got.shape == want.shape and rel_err(got, want) < 1e-6, rate
+
+
+HPSS_CASES = ((31, 2.0, False), (7, 1.0, False), (31, 2.0, True), (9, 0.5, False))
+
+
+def hpss_input():
+    return (np.abs(signals.audio_like((2, 2, 45, 60), seed=51)) + 0.01 * np.abs(signals.uniform((2, 2, 45, 60), seed=52))).astype(np.float32)
+
+
+def test_g8_hpss(golden):
+    """the loop-form restatement of beta_hpss.py:35-127 against the reference's outputs (median selection is exact, so the
+    enhanced spectrograms and masks agree to float rounding of pow / the mask quotient)."""
+    g = golden('g8_hpss')
+    mag = T(hpss_input())
+    for k, power, hard in HPSS_CASES:
+        res = torch_ref.hpss(mag, k, power, hard)
+        tag = 'k%d_p%g_%s' % (k, power, 'hard' if hard else 'soft')
+        for name, r in zip(('harm', 'perc', 'mask_harm', 'mask_perc'), res):
+            want = g[tag + '_' + name]
+            assert np.abs(r.numpy().astype(np.float32) - want.astype(np.float32)).max() <= 1e-6 * max(1.0, np.abs(want).max()), (tag, name)

@@ -234,13 +234,27 @@ def g7():
     np.savez_compressed(os.path.join(GOLD, 'g7_phase_vocoder.npz'), **out)
 
 
+def g8():
+    """hpss (beta_hpss.py:35-127) on a small magnitude spectrogram: soft and hard masks, two kernel sizes."""
+    sys.path.insert(0, os.environ.get('TAC_REFERENCE', '/root/reference'))
+    from torchaudio_contrib import beta_hpss
+    mag = np.abs(signals.audio_like((2, 2, 45, 60), seed=51)) + 0.01 * np.abs(signals.uniform((2, 2, 45, 60), seed=52))
+    out = {}
+    for k, power, hard in ((31, 2.0, False), (7, 1.0, False), (31, 2.0, True), (9, 0.5, False)):
+        res = beta_hpss.hpss(T(mag.astype(np.float32)), k, power, hard)
+        tag = 'k%d_p%g_%s' % (k, power, 'hard' if hard else 'soft')
+        for name, r in zip(('harm', 'perc', 'mask_harm', 'mask_perc'), res):
+            out[tag + '_' + name] = r.numpy().astype(np.float32 if not hard or name in ('harm', 'perc') else np.uint8)
+    np.savez_compressed(os.path.join(GOLD, 'g8_hpss.npz'), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--skip-scan', action='store_true', help='reuse thresholds from the existing g5 file')
     ap.add_argument('--only', default='')
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
-    jobs = {'g1': g1, 'g2': g2, 'g3': g3, 'g4': g4, 'g5': lambda: g5(a.skip_scan), 'g6': g6, 'g7': g7}
+    jobs = {'g1': g1, 'g2': g2, 'g3': g3, 'g4': g4, 'g5': lambda: g5(a.skip_scan), 'g6': g6, 'g7': g7, 'g8': g8}
     for name, fn in jobs.items():
         if a.only and name not in a.only.split(','):
             continue

@@ -13,10 +13,10 @@ from . import layers
 from .functional import *      # noqa: F401,F403
 from .functional import (stft, complex_norm, create_mel_filter, apply_filterbank, angle, magphase,
                          phase_vocoder, amplitude_to_db, db_to_amplitude, mu_law_encoding,
-                         mu_law_decoding)
+                         mu_law_decoding, hpss)
 from .layers import (STFT, ComplexNorm, ApplyFilterbank, Filterbank, MelFilterbank, TimeStretch,
                      Spectrogram, Melspectrogram, AmplitudeToDb, DbToAmplitude, MuLawEncoding,
-                     MuLawDecoding)
+                     MuLawDecoding, HPSS)
 from . import distributed
 
 __version__ = '0.1.0'

@@ -126,3 +126,26 @@ def phase_vocoder(spec, rate, phase_advance):
     running = step.cumsum(-1)
     length = frac * len_r + (1 - frac) * len_l
     return torch.stack([length * running.cos(), length * running.sin()], dim=-1)
+
+
+def hpss(mag, kernel_f, kernel_t, power, hard):
+    """reference beta_hpss.py:104-127 without its Python loops: reflect-pad both axes, running medians along frequency
+    (percussive) and time (harmonic) as ``unfold(...).median``, ``pow``, soft / hard masks.  Masks come back as floats
+    (the wrapper turns hard masks into bool like the reference)."""
+    shape = mag.shape
+    x = mag.reshape((-1, 1) + tuple(shape[-2:]))
+    hf, ht = kernel_f // 2, kernel_t // 2
+    padded = TF.pad(x, (ht, ht, hf, hf), mode='reflect')
+    n_freqs, n_frames = shape[-2], shape[-1]
+    perc = padded[..., ht:ht + n_frames].unfold(-2, kernel_f, 1).median(dim=-1).values
+    harm = padded[..., hf:hf + n_freqs, :].unfold(-1, kernel_t, 1).median(dim=-1).values
+    if power != 1.0:
+        perc, harm = perc.pow(power), harm.pow(power)
+    if hard:
+        mask_h, mask_p = (harm > perc).to(mag.dtype), (harm < perc).to(mag.dtype)
+    else:
+        eps = 1e-6
+        mask_h = (harm + eps) / (harm + perc + eps)
+        mask_p = (perc + eps) / (harm + perc + eps)
+    mask_h, mask_p = mask_h.reshape(shape), mask_p.reshape(shape)
+    return mag * mask_h, mag * mask_p, mask_h, mask_p

@@ -460,4 +460,19 @@ def _mu_law_decoding_fake(codes, n_quantize, dtype):
 _register('mu_law_decoding', '(Tensor codes, int n_quantize, ScalarType dtype) -> Tensor', _mu_law_decoding_cuda,
           C.mu_law_decoding, _mu_law_decoding_fake, 1)
 
+# ============================================================================= hpss
+def _hpss_cuda(mag, kernel_f, kernel_t, power, hard):
+    reason = _hip_dtype(mag)
+    if reason is None and not H.hpss_supported(kernel_f, kernel_t):
+        reason = 'kernel_size (%d, %d)' % (kernel_f, kernel_t)
+    if reason is not None:
+        _composite_route('hpss', reason)
+        return C.hpss(mag, kernel_f, kernel_t, power, hard)
+    outs = H.hpss(_f32(mag), kernel_f, kernel_t, power, hard)
+    return outs if mag.dtype == torch.float32 else tuple(o.to(mag.dtype) for o in outs)
+
+
+_register('hpss', '(Tensor mag, int kernel_f, int kernel_t, float power, bool hard) -> (Tensor, Tensor, Tensor, Tensor)',
+          _hpss_cuda, C.hpss, lambda mag, kernel_f, kernel_t, power, hard: tuple(_like_meta(mag) for _ in range(4)), 1)
+
 ops = getattr(torch.ops, NS)

@@ -21,7 +21,7 @@ from . import _ops
 from ._lazy import realize as _realize
 
 __all__ = ['stft', 'complex_norm', 'create_mel_filter', 'apply_filterbank', 'angle', 'magphase',
-           'phase_vocoder', 'amplitude_to_db', 'db_to_amplitude', 'mu_law_encoding', 'mu_law_decoding']
+           'phase_vocoder', 'amplitude_to_db', 'db_to_amplitude', 'mu_law_encoding', 'mu_law_decoding', 'hpss']
 
 _call = _ops.call
 
@@ -203,3 +203,27 @@ def mu_law_decoding(x_mu, n_quantize=256, dtype=torch.get_default_dtype()):
     ``[0, 256)`` — int64 or float-typed — with ``n_quantize == 256`` are decoded through the reference's own
     256-entry table (bit-exact); everything else evaluates the closed form in fp32 (within 1 ulp of ``exp``)."""
     return _call('mu_law_decoding', _tensor(x_mu, 'x_mu'), int(n_quantize), dtype)
+
+
+def hpss(mag_specgrams, kernel_size=31, power=2.0, hard=False, mask_only=False):
+    """Harmonic / percussive source separation by median filtering (reference: beta_hpss.py:35-127):
+    ``(harmonic spectrogram, percussive spectrogram, harmonic mask, percussive mask)`` of a magnitude spectrogram
+    ``(*, freq, time)``; with ``mask_only`` the first two are None.  ``kernel_size``: odd int, or ``(width along
+    frequency of the percussive filter, width along time of the harmonic filter)`` — the reference only runs with equal
+    widths (its padding and slicing mix the two up otherwise); here unequal widths do what its docstring describes.
+    Hard masks are bool tensors, as in the reference.  On a HIP device one kernel (csrc/hpss.hip) for widths <= 31."""
+    x = _tensor(mag_specgrams, 'mag_specgrams')
+    if not isinstance(kernel_size, (tuple, int)):
+        raise TypeError('kernel_size is expected to be either tuple of input, but it is: %s' % type(kernel_size))
+    kf, kt = (kernel_size, kernel_size) if isinstance(kernel_size, int) else kernel_size
+    if x.dim() < 2:
+        raise RuntimeError('hpss: expected (*, freq, time), got shape %s' % (tuple(x.shape),))
+    if kf // 2 >= x.shape[-2] or kt // 2 >= x.shape[-1]:
+        raise RuntimeError('hpss: reflect padding (%d, %d) must be smaller than the spectrogram size %s'
+                           % (kf // 2, kt // 2, tuple(x.shape[-2:])))
+    harm, perc, mask_h, mask_p = _call('hpss', x, int(kf), int(kt), float(power), bool(hard))
+    if hard:
+        mask_h, mask_p = mask_h > 0.5, mask_p > 0.5
+    if mask_only:
+        return None, None, mask_h, mask_p
+    return harm, perc, mask_h, mask_p

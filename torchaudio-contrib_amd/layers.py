@@ -286,3 +286,21 @@ class MuLawDecoding(_ModuleNoStateBuffers):
 
     def __repr__(self):
         return self.__class__.__name__ + '(n_quantize={})'.format(self.n_quantize)
+
+
+class HPSS(nn.Module):
+    """Harmonic / percussive separation layer (reference beta_hpss.py:12-32): wraps ``functional.hpss``."""
+
+    def __init__(self, kernel_size=31, power=2.0, hard=False, mask_only=False):
+        super(HPSS, self).__init__()
+        self.kernel_size = kernel_size
+        self.power = power
+        self.hard = hard
+        self.mask_only = mask_only
+
+    def forward(self, mag_specgrams):
+        return F.hpss(mag_specgrams, self.kernel_size, self.power, self.hard, self.mask_only)
+
+    def __repr__(self):
+        return self.__class__.__name__ + '(kernel_size={}, power={}, hard={}, mask_only={})'.format(
+            self.kernel_size, self.power, self.hard, self.mask_only)
