@@ -107,6 +107,23 @@ int tac_melspec_sparse_f32(const float* wave, const float* window, const tac_stf
                            const float* wpack, const int32_t* desc, const int32_t* info_host, int32_t n_mels,
                            int db, float db_ref, float db_amin, float* out, void* stream);
 
+/* (3c) The fused chain reading the waveform in its stored sample format (the step before the path —
+ *      PCM / mu-law decode, functional.py:338-354 — folded into the frame load, the samples are converted in registers):
+ *      TAC_SAMPLES_I16 = int16 PCM, value = sample * 2^-15; TAC_SAMPLES_MULAW_U8 / _I64 = 8-bit mu-law codes stored as
+ *      uint8 / int64 (what mu_law_encoding returns), value = decode_lut[code & 255] with decode_lut the DEVICE float[256]
+ *      table of (8).  d->row_stride and d->length count samples.  Served by the fft_length 2048 streaming kernel;
+ *      TAC_E_UNSUPPORTED otherwise (callers then convert with (8) / tac_pcm16_to_f32 and use (3b)). */
+#define TAC_SAMPLES_F32 0
+#define TAC_SAMPLES_I16 1
+#define TAC_SAMPLES_MULAW_U8 2
+#define TAC_SAMPLES_MULAW_I64 3
+int tac_melspec_sparse_coded_f32(const void* samples, int32_t sample_format, const float* decode_lut,
+                                 const float* window, const tac_stft_desc* d, float power, const float* wpack,
+                                 const int32_t* desc, const int32_t* info_host, int32_t n_mels, int db,
+                                 float db_ref, float db_amin, float* out, void* stream);
+/* int16 PCM -> float32 (x * 2^-15), for the kernels without a coded frame load */
+int tac_pcm16_to_f32(const int16_t* x, int64_t n, float* out, void* stream);
+
 /* TAC_OK when (3) can run this geometry + filterbank plan, TAC_E_UNSUPPORTED when it cannot
  * (no launch, no device access). */
 int tac_melspec_supported(const tac_stft_desc* d, float power, const int32_t* fb_plan_host,

@@ -213,3 +213,19 @@ def test_hpss_on_cpu_matches_golden(tac, golden):
         tac.hpss(mag, 3.0)
     with pytest.raises(RuntimeError):
         tac.hpss(mag[..., :10], 31)                      # reflect padding wider than the spectrogram
+
+
+def test_coded_waveforms_on_cpu(tac, golden):
+    """The step before the path through the product API on CPU tensors: mu-law codes -> MuLawDecoding ->
+    Melspectrogram -> AmplitudeToDb against the reference's golden outputs, and int16 PCM (value = sample * 2^-15)."""
+    g = golden('g9_mulaw_mel')
+    codes = T(g['codes'].astype(np.int64))
+    for n_fft, hop, mels in ((2048, 512, 128), (512, 128, 40)):
+        model = torch.nn.Sequential(tac.MuLawDecoding(256),
+                                    *tac.Melspectrogram(num_mels=mels, sample_rate=16000, fft_length=n_fft, hop_length=hop),
+                                    tac.AmplitudeToDb())
+        assert np.abs(model(codes).numpy() - g['mel_db_n%d' % n_fft]).max() <= 1e-4
+    pcm = T((signals.audio_like((2, 1, 9000), seed=62) * 20000).astype(np.int16))
+    mel = tac.Melspectrogram(num_mels=32, sample_rate=16000, fft_length=512, hop_length=128)
+    assert torch.equal(mel(pcm), mel(pcm.float() * (1.0 / 32768.0)))
+    assert tac.stft(pcm, 256).dtype == torch.float32

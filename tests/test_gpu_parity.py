@@ -894,6 +894,46 @@ def test_g8_hpss(tac, golden):
         tac.set_strict(True)
 
 
+def test_coded_waveforms_fused_into_the_frame_load(tac, golden):
+    """int16 PCM and 8-bit mu-law codes (uint8 or the int64 mu_law_encoding returns) are converted in
+    registers inside the fused kernel's frame load — ONE launch, the decoded waveform never exists — and agree with the
+    reference chain MuLawDecoding -> Melspectrogram -> AmplitudeToDb (golden g9); other fft sizes convert first."""
+    g = golden('g9_mulaw_mel')
+    for dtype in (torch.int64, torch.uint8):
+        codes = torch.from_numpy(g['codes']).to(dtype).cuda()
+        for n_fft, hop, mels, fused in ((2048, 512, 128, True), (512, 128, 40, False)):
+            model = torch.nn.Sequential(tac.MuLawDecoding(256),
+                                        *tac.Melspectrogram(num_mels=mels, sample_rate=16000, fft_length=n_fft, hop_length=hop),
+                                        tac.AmplitudeToDb()).cuda()
+            before = launches(tac)
+            y = model(codes)
+            ran = launched_since(tac, before)
+            assert type(y) is torch.Tensor
+            if fused:
+                assert ran == {'tac_melspec_sparse_coded_f32': 1}, ran
+            else:
+                assert 'tac_melspec_sparse_f32' in ran and any(k.startswith('tac_mulaw_decode') for k in ran), ran
+            assert np.abs(host(y) - g['mel_db_n%d' % n_fft]).max() < DB_ABS
+    # a decoded waveform used by anything else is an ordinary tensor with the table's bits
+    w = tac.MuLawDecoding(256)(torch.from_numpy(g['codes']).cuda())
+    assert isinstance(w, tac.DeferredWave) and np.array_equal(host(w + 0.0).view(np.uint32),
+                                                              golden('g5_mulaw')['lut256'].view(np.uint32)[g['codes']])
+    # int16 PCM: every frame position incl. the reflected edges, odd row offsets (unaligned pairs -> gather path), vs the
+    # float32 path on sample * 2^-15
+    pcm = (signals.audio_like((3, 2, 30001), seed=63) * 25000).astype(np.int16)
+    mel = torch.nn.Sequential(*tac.Melspectrogram(num_mels=128, sample_rate=16000, fft_length=2048, hop_length=512),
+                              tac.AmplitudeToDb()).cuda()
+    before = launches(tac)
+    got = mel(dev(pcm))
+    assert launched_since(tac, before) == {'tac_melspec_sparse_coded_f32': 1}
+    want = mel(dev(pcm.astype(np.float32) / 32768.0))
+    assert np.abs(host(got) - host(want)).max() < 1e-4
+    odd = dev(pcm)[:, :, 1:]                                            # row base no longer 4-byte aligned
+    assert np.abs(host(mel(odd)) - host(mel(dev(pcm.astype(np.float32)[:, :, 1:] / 32768.0)))).max() < 1e-4
+    z = tac.stft(dev(pcm), 512, 128)                                    # no coded frame load there: converted by a kernel first
+    assert rel_err(host(z), host(tac.stft(dev(pcm.astype(np.float32) / 32768.0), 512, 128))) < 1e-6
+
+
 # ------------------------------------------------------------------ size-independent properties at BASELINE sizes
 def test_cfg2_full_size_properties(tac):
     """cfg-2 (256x1x160000, 2048/512/128): linearity of the power-mel map in amplitude², agreement of

@@ -248,13 +248,27 @@ def g8():
     np.savez_compressed(os.path.join(GOLD, 'g8_hpss.npz'), **out)
 
 
+def g9():
+    """mu-law codes -> MuLawDecoding -> Melspectrogram -> AmplitudeToDb (layers.py:443-467, 307-381): the chain whose
+    decode step the streaming kernel folds into its frame load."""
+    x = T(signals.audio_like((2, 1, 20000), seed=61))
+    codes = ref.mu_law_encoding(x, 256)
+    wave = ref.mu_law_decoding(codes, 256)
+    out = {'codes': codes.numpy().astype(np.uint8)}
+    for n_fft, hop, mels in ((2048, 512, 128), (512, 128, 40)):
+        model = torch.nn.Sequential(*ref.Melspectrogram(num_mels=mels, sample_rate=16000, fft_length=n_fft, hop_length=hop),
+                                    ref.AmplitudeToDb())
+        out['mel_db_n%d' % n_fft] = np32(model(wave))
+    np.savez_compressed(os.path.join(GOLD, 'g9_mulaw_mel.npz'), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--skip-scan', action='store_true', help='reuse thresholds from the existing g5 file')
     ap.add_argument('--only', default='')
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
-    jobs = {'g1': g1, 'g2': g2, 'g3': g3, 'g4': g4, 'g5': lambda: g5(a.skip_scan), 'g6': g6, 'g7': g7, 'g8': g8}
+    jobs = {'g1': g1, 'g2': g2, 'g3': g3, 'g4': g4, 'g5': lambda: g5(a.skip_scan), 'g6': g6, 'g7': g7, 'g8': g8, 'g9': g9}
     for name, fn in jobs.items():
         if a.only and name not in a.only.split(','):
             continue

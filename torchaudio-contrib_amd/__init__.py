@@ -7,7 +7,7 @@ the importable name is ``torchaudio_contrib_amd`` (see the loader shim at the re
 from . import _native
 from . import _ops
 from ._ops import set_strict, CompositeRouteWarning
-from ._lazy import realize, set_lazy_fusion, lazy_fusion_enabled, DeferredSpectral
+from ._lazy import realize, set_lazy_fusion, lazy_fusion_enabled, DeferredSpectral, DeferredWave
 from . import functional
 from . import layers
 from .functional import *      # noqa: F401,F403

@@ -29,6 +29,8 @@ TWO_PI = 2.0 * math.pi
 def stft(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided):
     """reference functional.py:89-111: fold the leading dims into the FFT batch, ``torch.stft``, unfold; the
     complex result is handed back as the trailing-2 real view the reference's era of torch produced."""
+    if wave.dtype == torch.int16:                                # PCM: sample * 2^-15 (the package's convention)
+        wave = wave.to(torch.float32) * (1.0 / 32768.0)
     batch_shape = wave.shape[:-1]
     rows = wave.reshape(-1, wave.shape[-1])
     z = torch.stft(rows, n_fft, hop_length=hop, win_length=win_length, window=window, center=center,
@@ -149,3 +151,11 @@ def hpss(mag, kernel_f, kernel_t, power, hard):
         mask_p = (perc + eps) / (harm + perc + eps)
     mask_h, mask_p = mask_h.reshape(shape), mask_p.reshape(shape)
     return mag * mask_h, mag * mask_p, mask_h, mask_p
+
+
+def melspectrogram_mulaw(codes, window, bank, n_quantize, n_fft, hop, win_length, center, pad_mode, normalized, onesided,
+                         power, db, ref, amin):
+    """reference functional.py:338-354 followed by layers.py:307-381: decode, then the Melspectrogram chain."""
+    wave = mu_law_decoding(codes, n_quantize, torch.float32)
+    return melspectrogram(wave, window, bank, n_fft, hop, win_length, center, pad_mode, normalized, onesided, power, db,
+                          ref, amin)

@@ -639,3 +639,50 @@ def hpss(mag, kernel_f, kernel_t, power, hard):
         _native.check(rc, 'tac_hpss_f32')
         _count('tac_hpss_f32')
     return tuple(outs)
+
+
+# ----------------------------------------------------------------------------- coded waveforms (int16 PCM, mu-law codes)
+def pcm16_to_f32(x):
+    """int16 PCM -> float32 in [-1, 1): x * 2^-15 (for the kernels without a coded frame load)."""
+    x = x if x.is_contiguous() else x.contiguous()
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    if x.numel():
+        with _native.on_device(x.device):
+            rc = _native.lib().tac_pcm16_to_f32(_native.ptr(x), x.numel(), _native.ptr(out), _native.stream_ptr(x.device))
+        _native.check(rc, 'tac_pcm16_to_f32')
+        _count('tac_pcm16_to_f32')
+    return out
+
+
+_SAMPLE_FORMATS = {torch.int16: _native.SAMPLES_I16, torch.uint8: _native.SAMPLES_MULAW_U8,
+                   torch.int64: _native.SAMPLES_MULAW_I64}
+
+
+def melspectrogram_coded(samples, window, fb, n_fft, hop, win_length, center, pad_mode, normalized, onesided, power, db,
+                         ref, amin):
+    """The fused chain reading int16 PCM (value = sample * 2^-15) or 8-bit mu-law codes stored as uint8 / int64
+    (value = the reference's 256-entry decode table) straight from the stored samples, converted in registers inside
+    the frame load.  Returns None when the single-kernel route does not cover the configuration — the caller then
+    converts first and takes the float32 path."""
+    g = geometry(samples, n_fft, hop, win_length, center, pad_mode, normalized, onesided)
+    if not (g.fft_kernel and g.onesided and g.n_fft == 2048 and fb.dim() == 2 and fb.shape[0] == g.n_bins
+            and fb.is_contiguous() and power in (1.0, 2.0) and MEL_PATH != 'mfma'):
+        return None
+    pack = _melbank_pack(fb, g.n_fft)
+    if pack is None:
+        return None
+    wpack, desc, info = pack
+    fmt = _SAMPLE_FORMATS[samples.dtype]
+    lut = _mulaw_tables(samples.device)[4] if fmt != _native.SAMPLES_I16 else None
+    src = _rows_of(samples, g)
+    out = torch.empty(g.lead + (g.n_frames, fb.shape[1]), dtype=torch.float32, device=samples.device)
+    with _native.on_device(samples.device):
+        rc = _native.lib().tac_melspec_sparse_coded_f32(
+            _native.ptr(src), fmt, None if lut is None else _native.ptr(lut), _native.ptr(window), g.desc, float(power),
+            _native.ptr(wpack), _native.ptr(desc), ctypes.cast(info, ctypes.c_void_p), fb.shape[1], 1 if db else 0,
+            float(ref), float(amin), _native.ptr(out), _native.stream_ptr(samples.device))
+    if rc == _native.TAC_E_UNSUPPORTED:
+        return None
+    _native.check(rc, 'tac_melspec_sparse_coded_f32')
+    _count('tac_melspec_sparse_coded_f32')
+    return out.transpose(-2, -1)

@@ -36,11 +36,16 @@ def lazy_fusion_enabled():
 
 
 _DEFERRABLE = (torch.float32, torch.float16, torch.bfloat16)
+_DEFERRABLE_WAVE = _DEFERRABLE + (torch.int16,)                  # int16 = PCM, converted inside the frame load
+_CODES = (torch.uint8, torch.int64)                              # mu-law codes a deferred MuLawDecoding can carry
 
 
 def can_defer(wave, window):
     """Deferral applies to plain tensors on a HIP device that take the gfx950 kernels and carry no autograd state."""
-    if not _enabled or type(wave) is not torch.Tensor or not wave.is_cuda or wave.dtype not in _DEFERRABLE:
+    if isinstance(wave, DeferredWave):
+        return wave.pending() and window.device == wave.device and window.dtype in _DEFERRABLE \
+            and not (torch.is_grad_enabled() and window.requires_grad)
+    if not _enabled or type(wave) is not torch.Tensor or not wave.is_cuda or wave.dtype not in _DEFERRABLE_WAVE:
         return False
     if torch.compiler.is_compiling() or torch._C._len_torch_dispatch_stack():
         return False
@@ -49,11 +54,58 @@ def can_defer(wave, window):
     return window.device == wave.device and window.dtype in _DEFERRABLE
 
 
+def can_defer_codes(codes):
+    """mu-law codes whose decoding may wait for the STFT behind it (plain integer tensors on a HIP device)."""
+    return _enabled and type(codes) is torch.Tensor and codes.is_cuda and codes.dtype in _CODES \
+        and not torch.compiler.is_compiling() and not torch._C._len_torch_dispatch_stack()
+
+
+class DeferredWave(torch.Tensor):
+    """Result of ``MuLawDecoding`` that has not been decoded yet: when an ``STFT`` layer takes it, the codes are decoded
+    inside that kernel's frame load (through the reference's 256-entry table) and the waveform never exists in memory;
+    anything else materialises it with the ordinary decode kernel.  Same safety rules as ``DeferredSpectral``."""
+
+    @staticmethod
+    def __new__(cls, codes, n_quantize):
+        r = torch.Tensor._make_wrapper_subclass(cls, codes.shape, strides=codes.stride(), dtype=torch.float32,
+                                                device=codes.device, requires_grad=False)
+        r._codes = codes
+        r._nq = int(n_quantize)
+        r._stamp = (codes._version, codes.data_ptr())
+        r._value = None
+        return r
+
+    def pending(self):
+        return self._value is None
+
+    def realize(self):
+        if self._value is None:
+            if (self._codes._version, self._codes.data_ptr()) != self._stamp:
+                raise RuntimeError('torchaudio_contrib_amd: the mu-law codes handed to MuLawDecoding were modified in '
+                                   'place before the deferred waveform was used')
+            from ._ops import call
+            self._value = call('mu_law_decoding', self._codes, self._nq, torch.float32)
+            self._codes = None
+        return self._value
+
+    def __repr__(self):
+        return 'DeferredWave(shape=%s, pending=%s)' % (tuple(self.shape), self.pending())
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        def unwrap(a):
+            return a.realize() if isinstance(a, (DeferredWave, DeferredSpectral)) else a
+        return func(*tree_map(unwrap, args), **tree_map(unwrap, kwargs or {}))
+
+
 class _Source(object):
     """The STFT call a recipe starts from, plus what is needed to detect that its inputs changed meanwhile."""
-    __slots__ = ('wave', 'window', 'args', 'stream', 'stamps', 'lead', 'n_frames', 'n_bins')
+    __slots__ = ('wave', 'window', 'args', 'stream', 'stamps', 'lead', 'n_frames', 'n_bins', 'decode')
 
     def __init__(self, wave, window, args):
+        self.decode = None                      # n_quantize when `wave` holds mu-law codes (from a DeferredWave)
+        if isinstance(wave, DeferredWave):
+            self.decode, wave = wave._nq, wave._codes
         self.wave, self.window, self.args = wave, window, args
         self.stream = torch._C._cuda_getCurrentRawStream(wave.device.index)      # hipStream_t of the forward call
         self.stamps = [(wave, wave._version, wave.data_ptr(), 'waveform'),
@@ -91,6 +143,7 @@ class DeferredSpectral(torch.Tensor):
     @classmethod
     def from_stft(cls, wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided):
         src = _Source(wave, window, (n_fft, hop, win_length, center, pad_mode, normalized, onesided))
+        wave = src.wave
         src.lead = tuple(wave.shape[:-1])
         src.n_frames = 1 + (wave.shape[-1] + (2 * (n_fft // 2) if center else 0) - n_fft) // hop
         src.n_bins = n_fft // 2 + 1 if onesided else n_fft
@@ -117,12 +170,18 @@ class DeferredSpectral(torch.Tensor):
         from ._ops import call
         s = self._src
         ref, amin = db if db is not None else (1.0, 1e-7)
+        wave = s.wave
+        if s.decode is not None:
+            if self._stage == 'mel':            # codes decoded inside the fused kernel's frame load
+                return call('melspectrogram_mulaw', wave, s.window, self._fb, s.decode, *s.args, float(self._power),
+                            db is not None, float(ref), float(amin))
+            wave = call('mu_law_decoding', wave, s.decode, torch.float32)
         if self._stage == 'stft':
-            return call('stft', s.wave, s.window, *s.args)
+            return call('stft', wave, s.window, *s.args)
         if self._stage == 'spec':
-            return call('spectrogram', s.wave, s.window, *s.args, float(self._power), db is not None, float(ref),
+            return call('spectrogram', wave, s.window, *s.args, float(self._power), db is not None, float(ref),
                         float(amin))
-        return call('melspectrogram', s.wave, s.window, self._fb, *s.args, float(self._power), db is not None,
+        return call('melspectrogram', wave, s.window, self._fb, *s.args, float(self._power), db is not None,
                     float(ref), float(amin))
 
     def realize(self, db=None):
@@ -193,6 +252,6 @@ def _compute_transposed_strides(lead, tail, a, b):
 def realize(x):
     """Materialise a deferred layer-chain result (no-op for ordinary tensors).  The kernel is enqueued on the HIP
     stream that was current when the chain's STFT was called; like any HIP op it completes asynchronously."""
-    if isinstance(x, DeferredSpectral):
+    if isinstance(x, (DeferredSpectral, DeferredWave)):
         return x.realize()
     return x

@@ -22,6 +22,7 @@ TAC_E_SHORT_INPUT = -3
 TAC_E_LAUNCH = -4
 
 PAD_MODES = {'constant': 0, 'reflect': 1, 'replicate': 2, 'circular': 3}
+SAMPLES_F32, SAMPLES_I16, SAMPLES_MULAW_U8, SAMPLES_MULAW_I64 = 0, 1, 2, 3
 
 EXPORTS = (
     'tac_strerror', 'tac_last_hip_error', 'tac_abi_version', 'tac_num_frames', 'tac_num_bins',
@@ -30,7 +31,7 @@ EXPORTS = (
     'tac_apply_filterbank_f32', 'tac_apply_filterbank_sparse_f32', 'tac_complex_norm_f32', 'tac_magphase_f32', 'tac_phase_vocoder_f32', 'tac_phase_vocoder_f64', 'tac_amplitude_to_db_f32',
     'tac_db_to_amplitude_f32', 'tac_mulaw_encode_f32_i64', 'tac_mulaw_decode_i64_f32',
     'tac_mulaw_decode_f32_f32',
-    'tac_stft_backward_f32', 'tac_overlap_add_f32', 'tac_complex_norm_backward_f32', 'tac_amplitude_to_db_backward_f32', 'tac_hpss_f32',
+    'tac_stft_backward_f32', 'tac_overlap_add_f32', 'tac_complex_norm_backward_f32', 'tac_amplitude_to_db_backward_f32', 'tac_hpss_f32', 'tac_melspec_sparse_coded_f32', 'tac_pcm16_to_f32',
 )
 
 
@@ -113,10 +114,12 @@ def lib():
         h.tac_overlap_add_f32.argtypes = [_P, _DESC, _P, _I64, _P]
         h.tac_complex_norm_backward_f32.argtypes = [_P, _P, _I64, _F, _P, _P]
         h.tac_amplitude_to_db_backward_f32.argtypes = [_P, _P, _I64, _F, _P, _P]
+        h.tac_melspec_sparse_coded_f32.argtypes = [_P, _I32, _P, _P, _DESC, _F, _P, _P, _P, _I32, ctypes.c_int, _F, _F, _P, _P]
+        h.tac_pcm16_to_f32.argtypes = [_P, _I64, _P, _P]
         h.tac_hpss_f32.argtypes = [_P, _I64, _I32, _I32, _I64, _I64, _I64, _I32, _I32, _F, ctypes.c_int, _P, _P, _P, _P, _P]
         for name in EXPORTS:
             fn = getattr(h, name)
-            if name.endswith(('_f32', '_f64', '_i64', '_plan', '_supported', '_pack')):
+            if name.endswith(('_f32', '_f64', '_i64', '_plan', '_supported', '_pack')):   # every launcher returns a TAC_* code
                 fn.restype = ctypes.c_int
         _lib = h
     return _lib

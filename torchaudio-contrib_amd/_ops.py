@@ -94,7 +94,7 @@ def _swapped(lead, tail, dtype, device, a, b):
 
 
 def _out_dtype(t):
-    return torch.float32 if t.dtype in _WIDEN else t.dtype
+    return torch.float32 if (t.dtype in _WIDEN or t.dtype == torch.int16) else t.dtype
 
 
 def _n_frames(length, n_fft, hop, center):
@@ -244,8 +244,13 @@ def _register(op, schema, cuda, cpu, fake, n_tensors, differentiable=True):
 _STFT_ARGS = 'int n_fft, int hop, int win_length, bool center, str pad_mode, bool normalized, bool onesided'
 
 
+def _pcm(wave):
+    """int16 waveforms are PCM: sample * 2^-15 (converted by a HIP kernel where the frame load cannot do it)."""
+    return H.pcm16_to_f32(wave) if wave.dtype == torch.int16 else _f32(wave)
+
+
 def _stft_route(op, wave, n_fft, *others):
-    reason = _hip_dtype(wave, *others)
+    reason = _hip_dtype(*others) if wave.dtype == torch.int16 else _hip_dtype(wave, *others)
     if reason is None and not H.hip_covers_n_fft(n_fft):
         reason = 'fft_length %d' % n_fft
     if reason is not None:
@@ -257,7 +262,7 @@ def _stft_cuda(wave, window, n_fft, hop, win_length, center, pad_mode, normalize
     _same_device('stft', wave, window)
     if _stft_route('stft', wave, n_fft, window) is not None:
         return C.stft(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided)
-    return H.stft(_f32(wave), _f32(window).contiguous(), n_fft, hop, win_length, center, pad_mode, normalized,
+    return H.stft(_pcm(wave), _f32(window).contiguous(), n_fft, hop, win_length, center, pad_mode, normalized,
                   onesided)
 
 
@@ -277,7 +282,7 @@ def _spectrogram_cuda(wave, window, n_fft, hop, win_length, center, pad_mode, no
     if _stft_route('spectrogram', wave, n_fft, window) is not None:
         return C.spectrogram(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided, power, db,
                              ref, amin)
-    return H.spectrogram(_f32(wave), _f32(window).contiguous(), n_fft, hop, win_length, center, pad_mode, normalized,
+    return H.spectrogram(_pcm(wave), _f32(window).contiguous(), n_fft, hop, win_length, center, pad_mode, normalized,
                          onesided, power, db, ref, amin)
 
 
@@ -299,8 +304,14 @@ def _melspectrogram_cuda(wave, window, bank, n_fft, hop, win_length, center, pad
     if _stft_route('melspectrogram', wave, n_fft, window, bank) is not None:
         return C.melspectrogram(wave, window, bank, n_fft, hop, win_length, center, pad_mode, normalized, onesided,
                                 power, db, ref, amin)
-    return H.melspectrogram(_f32(wave), _f32(window).contiguous(), _f32(bank), n_fft, hop, win_length, center,
-                            pad_mode, normalized, onesided, power, db, ref, amin)
+    window, bank = _f32(window).contiguous(), _f32(bank)
+    if wave.dtype == torch.int16:                                        # PCM converted inside the frame load when one kernel covers it
+        fused = H.melspectrogram_coded(wave, window, bank, n_fft, hop, win_length, center, pad_mode, normalized, onesided,
+                                       power, db, ref, amin)
+        if fused is not None:
+            return fused
+    return H.melspectrogram(_pcm(wave), window, bank, n_fft, hop, win_length, center, pad_mode, normalized, onesided,
+                            power, db, ref, amin)
 
 
 def _melspectrogram_fake(wave, window, bank, n_fft, hop, win_length, center, pad_mode, normalized, onesided, power,
@@ -316,6 +327,39 @@ _lib.impl('melspectrogram', _melspectrogram_cuda, 'CUDA')
 _lib.impl('melspectrogram', C.melspectrogram, 'CPU')
 torch.library.register_fake(NS + '::melspectrogram', _melspectrogram_fake, lib=_lib)
 _register_autograd('melspectrogram', C.melspectrogram, 3, _melspectrogram_hip_backward)
+
+
+# ============================================================================= mu-law codes -> melspectrogram
+def _melspectrogram_mulaw_cuda(codes, window, bank, n_quantize, n_fft, hop, win_length, center, pad_mode, normalized,
+                               onesided, power, db, ref, amin):
+    _same_device('melspectrogram_mulaw', codes, window, bank)
+    reason = _hip_dtype(window, bank)
+    if reason is None and not H.hip_covers_n_fft(n_fft):
+        reason = 'fft_length %d' % n_fft
+    if reason is not None:
+        _composite_route('melspectrogram_mulaw', reason)
+        return C.melspectrogram_mulaw(codes, window, bank, n_quantize, n_fft, hop, win_length, center, pad_mode, normalized,
+                                      onesided, power, db, ref, amin)
+    window, bank = _f32(window).contiguous(), _f32(bank)
+    if n_quantize == 256 and codes.dtype in (torch.uint8, torch.int64):   # decoded inside the frame load
+        fused = H.melspectrogram_coded(codes, window, bank, n_fft, hop, win_length, center, pad_mode, normalized, onesided,
+                                       power, db, ref, amin)
+        if fused is not None:
+            return fused
+    wave = H.mu_law_decoding_int(codes, n_quantize) if not codes.is_floating_point() else H.mu_law_decoding_float(_f32(codes), n_quantize)
+    return H.melspectrogram(wave, window, bank, n_fft, hop, win_length, center, pad_mode, normalized, onesided, power, db,
+                            ref, amin)
+
+
+def _melspectrogram_mulaw_fake(codes, window, bank, n_quantize, n_fft, hop, win_length, center, pad_mode, normalized,
+                               onesided, power, db, ref, amin):
+    frames = _n_frames(codes.shape[-1], n_fft, hop, center)
+    return _swapped(codes.shape[:-1], (frames, bank.shape[1]), torch.float32, codes.device, -2, -1)
+
+
+_register('melspectrogram_mulaw', '(Tensor codes, Tensor window, Tensor filterbank, int n_quantize, %s, float power, bool db, '
+          'float ref, float amin) -> Tensor' % _STFT_ARGS, _melspectrogram_mulaw_cuda, C.melspectrogram_mulaw,
+          _melspectrogram_mulaw_fake, 3, differentiable=False)
 
 
 # ============================================================================= apply_filterbank

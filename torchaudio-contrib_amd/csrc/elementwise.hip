@@ -222,9 +222,23 @@ static int launch_unary(const float* x, int64_t n, Op op, float* out, void* stre
     return TAC_OK;
 }
 
+__global__ void __launch_bounds__(EW_THREADS) pcm16_kernel(const short* __restrict__ x, long long n, float* __restrict__ out) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) out[j] = (float)x[j] * (1.0f / 32768.0f);
+}
+
 }  // namespace tac
 
 extern "C" {
+
+int tac_pcm16_to_f32(const int16_t* x, int64_t n, float* out, void* stream) {
+    using namespace tac;
+    if (n == 0) return TAC_OK;
+    if (!x || !out || n < 0) return TAC_E_INVALID;
+    hipLaunchKernelGGL(pcm16_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, x, (long long)n, out);
+    TAC_HIP(hipGetLastError());
+    return TAC_OK;
+}
 
 int tac_complex_norm_f32(const float* x, int64_t n, float power, float* out, void* stream) {
     using namespace tac;

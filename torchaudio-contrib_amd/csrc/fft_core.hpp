@@ -553,17 +553,32 @@ __device__ __forceinline__ int padded_index(int i, int L, int mode, bool* zero) 
 // conditions make hipcc split the unrolled loads into one basic block each, which serialises their
 // latencies.  Interior frames: 16 cf loads from a wave-uniform base.  Frames touching the padding:
 // gathered through padded_index() four elements at a time in a rolled loop via the frame's LDS buffer.
+// Sample access of the gather path: float32 waveforms by default; the coded-input kernels (int16 PCM, mu-law codes)
+// pass a functor that converts on the way in (melspec_stream.hpp).
+struct FetchF32 {
+    const float* base;
+    __device__ __forceinline__ float operator()(long long row_offset, int j) const { return base[row_offset + j]; }
+};
+
 template <class F, bool HOIST_WIN>
 __device__ __forceinline__ void load_frame(cf* v, const FrameGeom& g, const cf* win, cf* lds, long long row,
                                            long long frame, int t) {
+    load_frame<F, HOIST_WIN, false>(v, g, win, lds, row, frame, t, FetchF32{g.wave});
+}
+
+// GATHER_ONLY: never take the vectorised interior path (which reads g.wave as float pairs)
+template <class F, bool HOIST_WIN, bool GATHER_ONLY, class Fetch>
+__device__ __forceinline__ void load_frame(cf* v, const FrameGeom& g, const cf* win, cf* lds, long long row,
+                                           long long frame, int t, Fetch fetch) {
     constexpr int R0 = radix_at(F::NC, 0);
     constexpr int NB = F::E / R0;
     const float* rp = g.wave + row * g.row_stride;
+    const long long row_offset = row * g.row_stride;
     const long long start = frame * (long long)g.hop - g.center_pad;
     if (frame >= g.n_frames) {
 #pragma unroll
         for (int e = 0; e < F::E; ++e) v[e] = mkc(0.0f, 0.0f);
-    } else if (g.vec2_ok && start >= 0 && start + F::N <= g.length) {
+    } else if (!GATHER_ONLY && g.vec2_ok && start >= 0 && start + F::N <= g.length) {
         const cf* src = reinterpret_cast<const cf*>(rp + start);
         cf s[F::E];
 #pragma unroll
@@ -594,7 +609,7 @@ __device__ __forceinline__ void load_frame(cf* v, const FrameGeom& g, const cf* 
             }
             float a[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) a[u] = rp[j[u]];
+            for (int u = 0; u < 8; ++u) a[u] = fetch(row_offset, j[u]);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const cf w = window_pair(g, mm[u]);

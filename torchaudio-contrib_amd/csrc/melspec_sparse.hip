@@ -513,22 +513,34 @@ static int launch_sparse(const FrameGeom& g, const Tables& tb, const SparseArgs&
 
 // fft_length 2048: the barrier-free streaming kernel (melspec_stream.hpp), one persistent workgroup per CU.
 // info_host: {weight floats, slots, 64, total steps, steps of slot 0..3} from tac_melbank_pack.
-template <int NC, int E>
-static int launch_stream(const FrameGeom& g, const Tables& tb, const SparseArgs& sm, const int32_t* info_host, float power,
-                         hipStream_t stream) {
+template <int NC, int E, int FMT>
+static int launch_stream(FrameGeom g, const Tables& tb, const SparseArgs& sm, const int32_t* info_host, float power,
+                         hipStream_t stream, const void* samples, const float* lut) {
     const long long total = g.rows * g.n_frames;
     if (total >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;                  // 32-bit global frame numbers in-kernel
     if (g.length < 2 * NC) return TAC_E_UNSUPPORTED;                       // (its clamped sample requests need a whole frame)
     const size_t lds_bytes = stream_lds_bytes<NC, E>(sm.wtot);
     if (lds_bytes > 160 * 1024 || info_host[1] < 1 || info_host[1] > ST_MAX_SLOTS) return TAC_E_UNSUPPORTED;
+    if (FMT != FMT_F32) {                                                  // sample pairs fetched as one access of the format
+        const uintptr_t pair = FMT == FMT_I16 ? 4 : (FMT == FMT_MULAW_U8 ? 2 : 8);
+        g.vec2_ok = ((g.hop & 1) == 0) && ((g.center_pad & 1) == 0) && ((g.row_stride & 1) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(samples) & (pair - 1)) == 0);
+    }
     StreamArgs m{sm.wpack, sm.desc, info_host[1], {info_host[4], info_host[5], info_host[6], info_host[7]}, sm.wtot,
-                 sm.n_mels, sm.db, sm.amin, sm.log10_ref, sm.out, total};
+                 sm.n_mels, sm.db, sm.amin, sm.log10_ref, sm.out, total, samples, lut};
     long long blocks = (total + 2 * ST_WAVES - 1) / (2 * ST_WAVES);
     if (blocks > device_cu_count()) blocks = device_cu_count();
     if (blocks < 1) blocks = 1;
-    const bool pow2 = (power == 2.0f), fullm = (sm.n_mels % 64) == 0;
-    auto kern = pow2 ? (fullm ? melspec_stream_kernel<NC, E, true, true> : melspec_stream_kernel<NC, E, true, false>)
-                     : (fullm ? melspec_stream_kernel<NC, E, false, true> : melspec_stream_kernel<NC, E, false, false>);
+    const bool pow2 = (power == 2.0f);
+    // the band predicate of the row stores is compiled out for whole slots of 64 bands (float32 input only: the coded
+    // formats keep one instantiation per power)
+    const bool fullm = FMT == FMT_F32 && (sm.n_mels % 64) == 0;
+    void (*kern)(FrameGeom, Tables, StreamArgs);
+    if constexpr (FMT == FMT_F32)
+        kern = pow2 ? (fullm ? melspec_stream_kernel<NC, E, true, true, FMT> : melspec_stream_kernel<NC, E, true, false, FMT>)
+                    : (fullm ? melspec_stream_kernel<NC, E, false, true, FMT> : melspec_stream_kernel<NC, E, false, false, FMT>);
+    else
+        kern = pow2 ? melspec_stream_kernel<NC, E, true, false, FMT> : melspec_stream_kernel<NC, E, false, false, FMT>;
     int dev = 0;
     TAC_HIP(hipGetDevice(&dev));
     static std::atomic<bool> attr_set[4][16];                             // per (kernel, device): cheap, so no lock
@@ -695,8 +707,36 @@ int tac_melspec_sparse_f32(const float* wave, const float* window, const tac_stf
         case 256: return launch_sparse<128, 16>(g, tb, m, power, s);
         case 512: return launch_sparse<256, 16>(g, tb, m, power, s);
         case 1024: return launch_sparse<512, 16>(g, tb, m, power, s);
-        case 2048: return TAC_SP_STREAM ? launch_stream<1024, 16>(g, tb, m, info_host, power, s) : launch_sparse<1024, 16>(g, tb, m, power, s);
+        case 2048: return TAC_SP_STREAM ? launch_stream<1024, 16, FMT_F32>(g, tb, m, info_host, power, s, wave, nullptr) : launch_sparse<1024, 16>(g, tb, m, power, s);
         default: return TAC_E_UNSUPPORTED;
+    }
+}
+
+int tac_melspec_sparse_coded_f32(const void* samples, int32_t sample_format, const float* decode_lut, const float* window,
+                                 const tac_stft_desc* d, float power, const float* wpack, const int32_t* desc,
+                                 const int32_t* info_host, int32_t n_mels, int db, float db_ref, float db_amin, float* out,
+                                 void* stream) {
+    using namespace tac;
+    if (!samples || !wpack || !desc || !info_host || !out || !d || n_mels <= 0) return TAC_E_INVALID;
+    if (sample_format < TAC_SAMPLES_F32 || sample_format > TAC_SAMPLES_MULAW_I64) return TAC_E_INVALID;
+    if (sample_format >= TAC_SAMPLES_MULAW_U8 && !decode_lut) return TAC_E_INVALID;
+    if (!TAC_SP_STREAM || !d->onesided || d->n_fft != 2048) return TAC_E_UNSUPPORTED;     // the streaming kernel only
+    if (power != 2.0f && power != 1.0f) return TAC_E_UNSUPPORTED;
+    if (info_host[2] != sparse_groups_for(d->n_fft)) return TAC_E_INVALID;
+    FrameGeom g;
+    int64_t T = 0;
+    int rc = make_geometry(static_cast<const float*>(samples), window, d, &g, &T);
+    if (rc != TAC_OK) return rc;
+    Tables tb;
+    rc = get_tables(d->n_fft, &tb);
+    if (rc != TAC_OK) return rc;
+    SparseArgs m{wpack, desc, info_host[0], info_host[1], n_mels, db ? 1 : 0, db_amin, db ? log10f(db_ref) : 0.0f, out, 0};
+    hipStream_t s = (hipStream_t)stream;
+    switch (sample_format) {
+        case TAC_SAMPLES_F32: return launch_stream<1024, 16, FMT_F32>(g, tb, m, info_host, power, s, samples, nullptr);
+        case TAC_SAMPLES_I16: return launch_stream<1024, 16, FMT_I16>(g, tb, m, info_host, power, s, samples, nullptr);
+        case TAC_SAMPLES_MULAW_U8: return launch_stream<1024, 16, FMT_MULAW_U8>(g, tb, m, info_host, power, s, samples, decode_lut);
+        default: return launch_stream<1024, 16, FMT_MULAW_I64>(g, tb, m, info_host, power, s, samples, decode_lut);
     }
 }
 

@@ -50,7 +50,12 @@ struct StreamArgs {
     float log10_ref;
     float* out;            // [rows * T][M]
     long long total;       // rows * T
+    const void* samples;   // the waveform in its own sample format (SampleFormat; g.wave when float32)
+    const float* lut;      // device float[256]: mu-law decode table for the coded formats
 };
+
+// sample formats of the frame load (tac_amd.h TAC_SAMPLES_*)
+enum { FMT_F32 = 0, FMT_I16 = 1, FMT_MULAW_U8 = 2, FMT_MULAW_I64 = 3 };
 
 template <int NC, int E>
 struct StreamCfg {
@@ -67,10 +72,10 @@ __host__ __device__ inline size_t stream_lds_bytes(int wtot) {
     size_t b = (size_t)ST_WAVES * ((C::F::PADDED * sizeof(cf) + 15) & ~(size_t)15);
     b += (size_t)ST_WAVES * 2 * C::PROW * 4;
     b += ((size_t)wtot * 4 + 15) & ~(size_t)15;
-    return b;
+    return b + 1024;                                                           // mu-law decode table
 }
 
-template <int NC, int E, bool POW2, bool FULLM>
+template <int NC, int E, bool POW2, bool FULLM, int FMT>
 __global__ void __launch_bounds__(ST_WAVES * 64, 2)
 melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     using C = StreamCfg<NC, E>;
@@ -87,7 +92,9 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     float* rowB = rowA + PROW;
     float* wlds = rows_all + (size_t)ST_WAVES * 2 * PROW;
 
+    float* lutlds = wlds + ((m.wtot + 3) & ~3);                                      // mu-law decode table (coded inputs)
     for (int i = tid; i < m.wtot; i += ST_WAVES * 64) wlds[i] = m.wl[i];
+    if (FMT >= FMT_MULAW_U8 && tid < 256) lutlds[tid] = m.lut[tid];
     for (int i = tid; i < ST_WAVES * 2 * (PROW - NBINS); i += ST_WAVES * 64) {       // slack columns stay zero for good
         const int r = i / (PROW - NBINS), c2 = i - r * (PROW - NBINS);
         rows_all[(size_t)r * PROW + NBINS + c2] = 0.0f;
@@ -106,9 +113,11 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     const cf w0 = tb.w_n[t];                                           // R2C: W_N^{t + 64 i} = W_N^t * W_32^i
     cf win[E];
     load_window_regs<F>(win, g, t);
-    const float half = 0.5f * g.scale;                                 // 2X -> scale * X once, in the window
+    // 2X -> scale * X once, in the window; int16 PCM samples are integers there, their 2^-15 goes in as well
+    const float half = 0.5f * g.scale;
+    const float win_scale = FMT == FMT_I16 ? half * (1.0f / 32768.0f) : half;
 #pragma unroll
-    for (int e = 0; e < E; ++e) win[e] = cscale(win[e], half);
+    for (int e = 0; e < E; ++e) win[e] = cscale(win[e], win_scale);
     int lo_s[ST_MAX_SLOTS];
 #pragma unroll
     for (int s = 0; s < ST_MAX_SLOTS; ++s) lo_s[s] = s < m.nslot ? m.lo[s * 64 + lane] : 0;
@@ -142,20 +151,70 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         mode = ok ? 1 : 2;
         long long cs = start < 0 ? 0 : start;
         cs = cs + F::N <= g.length ? cs : g.length - F::N;             // host guarantees length >= N
-        const cf* src = reinterpret_cast<const cf*>(g.wave + (long long)row * g.row_stride + cs);
+        const long long off = (long long)row * g.row_stride + cs;      // in samples
         if (TAC_ST_ABL != 4) {
+            if constexpr (FMT == FMT_F32) {
+                const cf* src = reinterpret_cast<const cf*>(static_cast<const float*>(m.samples) + off);
 #pragma unroll
-            for (int q = 0; q < E; ++q) raw[q] = src[t + q * F::LPF];
+                for (int q = 0; q < E; ++q) raw[q] = src[t + q * F::LPF];
+            } else if constexpr (FMT == FMT_I16) {                      // a pair of samples = one dword
+                const unsigned* src = reinterpret_cast<const unsigned*>(static_cast<const short*>(m.samples) + off);
+#pragma unroll
+                for (int q = 0; q < E; ++q) raw[q].x = __uint_as_float(src[t + q * F::LPF]);
+            } else if constexpr (FMT == FMT_MULAW_U8) {                 // a pair of codes = one 16-bit load
+                const unsigned short* src =
+                    reinterpret_cast<const unsigned short*>(static_cast<const unsigned char*>(m.samples) + off);
+#pragma unroll
+                for (int q = 0; q < E; ++q) raw[q].x = __uint_as_float((unsigned)src[t + q * F::LPF]);
+            } else {                                                    // int64 codes: the low dword of each
+                const int* src = reinterpret_cast<const int*>(static_cast<const long long*>(m.samples) + off);
+#pragma unroll
+                for (int q = 0; q < E; ++q) {
+                    raw[q].x = __int_as_float(src[4 * (t + q * F::LPF)]);
+                    raw[q].y = __int_as_float(src[4 * (t + q * F::LPF) + 2]);
+                }
+            }
+        }
+    };
+    // the requested registers as float sample pairs (still unwindowed): PCM integers / decoded codes
+    auto decode = [&](cf (&v)[E]) {
+        if constexpr (FMT == FMT_I16) {
+#pragma unroll
+            for (int q = 0; q < E; ++q) {
+                const int bits = __float_as_int(v[q].x);
+                v[q] = mkc((float)(short)(bits & 0xffff), (float)(bits >> 16));
+            }
+        } else if constexpr (FMT == FMT_MULAW_U8) {
+#pragma unroll
+            for (int q = 0; q < E; ++q) {
+                const unsigned bits = __float_as_uint(v[q].x);
+                v[q] = mkc(lutlds[bits & 0xffu], lutlds[(bits >> 8) & 0xffu]);
+            }
+        } else if constexpr (FMT == FMT_MULAW_I64) {
+#pragma unroll
+            for (int q = 0; q < E; ++q) v[q] = mkc(lutlds[__float_as_uint(v[q].x) & 0xffu], lutlds[__float_as_uint(v[q].y) & 0xffu]);
+        }
+    };
+    // sample access of the gather path (frames touching the padding), in the same units as `decode`
+    struct Fetch {
+        const void* base;
+        const float* lut;
+        __device__ __forceinline__ float operator()(long long row_offset, int j) const {
+            if constexpr (FMT == FMT_F32) return static_cast<const float*>(base)[row_offset + j];
+            else if constexpr (FMT == FMT_I16) return (float)static_cast<const short*>(base)[row_offset + j];
+            else if constexpr (FMT == FMT_MULAW_U8) return lut[static_cast<const unsigned char*>(base)[row_offset + j]];
+            else return lut[(unsigned)static_cast<const long long*>(base)[row_offset + j] & 0xffu];
         }
     };
     // s0: windowed samples -> pass-0 butterflies -> exchange 0 (write, read-back issued)
     auto s0 = [&](cf (&v)[E], int mode, int row, long long fr) {
         if (mode == 1) {
+            decode(v);
             apply_window<F>(v, v, win);
         } else {                                                       // edge / unaligned frame: gathered through the exchange
-            load_frame<F, true>(v, g, win, xa, row, fr, t);            // area with the plain window -> the 0.5*scale goes here
+            load_frame<F, true, true>(v, g, win, xa, row, fr, t, Fetch{m.samples, lutlds});   // area, plain window ->
 #pragma unroll
-            for (int e = 0; e < E; ++e) v[e] = cscale(v[e], half);
+            for (int e = 0; e < E; ++e) v[e] = cscale(v[e], win_scale);                       // the scale goes here
         }
     };
     auto s0b = [&](cf (&v)[E]) {

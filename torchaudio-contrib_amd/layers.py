@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from . import functional as F
 from . import _hip
-from ._lazy import DeferredSpectral, can_defer, lazy_fusion_enabled, realize
+from ._lazy import DeferredSpectral, DeferredWave, can_defer, can_defer_codes, lazy_fusion_enabled, realize
 
 
 class _ModuleNoStateBuffers(nn.Module):
@@ -282,6 +282,10 @@ class MuLawDecoding(_ModuleNoStateBuffers):
         self.n_quantize = n_quantize
 
     def forward(self, x_mu):
+        if torch.is_tensor(x_mu) and self.n_quantize == 256 and can_defer_codes(x_mu) \
+                and torch.get_default_dtype() == torch.float32:
+            # an STFT layer behind this one decodes the codes inside its frame load; anything else decodes now
+            return DeferredWave(x_mu, self.n_quantize)
         return F.mu_law_decoding(x_mu, self.n_quantize)
 
     def __repr__(self):
