@@ -155,9 +155,7 @@ static int launch_stft_backward(const FrameGeom& g, const Tables& tb, const floa
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     auto kern = stft_backward_kernel<NC, E>;
-    if (lds_bytes > 64 * 1024)
-        TAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds_bytes));
+    if (lds_bytes > 64 * 1024) TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds_bytes));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BW_WAVES * 64), lds_bytes, stream, g, tb, gspec, frames);
     TAC_HIP(hipGetLastError());
     return TAC_OK;

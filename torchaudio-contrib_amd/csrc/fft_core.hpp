@@ -37,9 +37,6 @@ __host__ __device__ __forceinline__ cf mkc(float x, float y) {
 #ifndef TAC_FFT_HALF
 #define TAC_FFT_HALF 1      // 0: A/B knob, the last pass stores every output and the R2C split reads both halves back
 #endif
-#ifndef TAC_EXP_NOCONF
-#define TAC_EXP_NOCONF 0   // timing experiment only (wrong results): pass read-backs and R2C reads without padding = conflict-free
-#endif
 #ifndef TAC_PACKED
 #define TAC_PACKED 1        // 0: A/B knob, the same algebra on scalar f32 ops
 #endif
@@ -372,15 +369,9 @@ struct WaveFft {
         for (int b = 0; b < NB; ++b) {
             // NC/R is a multiple of 16 for every pass after the first, so pad(j + c) = pad(j) + pad(c):
             // one address register per butterfly, the rest are DS immediate offsets.
-#if TAC_EXP_NOCONF
-            const cf* src = lds + (t + b * LPF);
-#pragma unroll
-            for (int q = 0; q < R; ++q) v[b * R + q] = src[q * (NC / R)];
-#else
             const cf* src = lds + lds_pad(t + b * LPF);
 #pragma unroll
             for (int q = 0; q < R; ++q) v[b * R + q] = src[lds_pad_c(q * (NC / R))];
-#endif
         }
     }
     // (2) inter-pass twiddles (P > 0) and the radix-R butterflies of pass P
@@ -477,11 +468,7 @@ struct WaveFft {
     // even/odd split is left to the caller's epilogue factor).  wk = exp(-2*pi*i*k/N).
     //   ev = zk + conj(zm), d = zk - conj(zm), tw = wk·(-i·d);  2X[k] = ev + tw, 2X[NC-k] = conj(ev - tw)
     __device__ static __forceinline__ void r2c_pair(const cf* lds, int k, cf wk, cf& xa, cf& xb) {
-#if TAC_EXP_NOCONF
-        r2c_split_x2(lds[k], lds[(NC - k) & (NC - 1)], wk, xa, xb);
-#else
         r2c_split_x2(lds[lds_pad(k)], lds[lds_pad((NC - k) & (NC - 1))], wk, xa, xb);
-#endif
     }
     // partner Z[NC-k] of pair index k = t + i*LPF from LDS; k == 0 pairs with itself (its slot is not stored under HALF)
     __device__ static __forceinline__ cf r2c_partner(const cf* lds, int k, cf zk) {

@@ -23,6 +23,21 @@ int device_cu_count() {
     return cached_cus;
 }
 
+hipError_t allow_dynamic_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, int> done;              // (kernel, device) -> bytes granted
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    auto key = std::make_pair(kernel, dev);
+    auto it = done.find(key);
+    if (it != done.end() && it->second >= bytes) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done[key] = bytes;
+    return e;
+}
+
 int get_tables(int n_fft, Tables* out) {
     static std::mutex mu;
     static std::map<std::pair<int, int>, Tables> cache;

@@ -59,6 +59,10 @@ int get_tables(int n_fft, Tables* out);
 
 int device_cu_count();
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) — a process that uses several GPUs sets it
+// on each of them; thread-safe.
+hipError_t allow_dynamic_lds(const void* kernel, int bytes);
+
 inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 // Validates a descriptor the way torch.stft does and fills the device-side geometry.

@@ -22,10 +22,7 @@ struct MelCfg {
     using F = WaveFft<NC, E>;
     static constexpr int TILE_FRAMES = TILE;
     static constexpr int GT = (TILE / F::G) >= 1 ? (TILE / F::G) : 1;      // lane-groups (waves' worth) per tile
-#ifndef TAC_MEL_WAVES16
-#define TAC_MEL_WAVES16 0     // A/B knob: one frame of the tile per wave, 16 waves (4 per SIMD, <= 128 registers each)
-#endif
-    static constexpr int WAVES = (TILE == 8) ? 4 : ((TAC_MEL_WAVES16 && GT >= 16) ? 16 : (GT >= 8 ? 8 : 4));
+    static constexpr int WAVES = (TILE == 8) ? 4 : (GT >= 8 ? 8 : 4);
     static constexpr int GPW = (GT / WAVES) >= 1 ? (GT / WAVES) : 1;       // groups (sequential FFT rounds) per wave
     static constexpr int NBUF = (WAVES * GPW * F::G) > TILE ? (WAVES * GPW * F::G) : TILE;
     static constexpr int PROW = 2 * F::PADDED;                             // floats between consecutive P rows

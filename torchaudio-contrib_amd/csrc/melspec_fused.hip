@@ -307,12 +307,7 @@ static int launch_mel_budget(const FrameGeom& g, const Tables& tb, MelArgs m, co
     if (blocks < 1) blocks = 1;
     const bool pow2 = (m.power == 2.0f);
     auto kern = pow2 ? melspec_kernel<NC, E, TILE, BUDGET, true> : melspec_kernel<NC, E, TILE, BUDGET, false>;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[pow2]) {
-        TAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set[pow2] = true;
-    }
+    TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::WAVES * 64), lds_bytes, stream, g, tb, m, plan);
     TAC_HIP(hipGetLastError());
     return TAC_OK;

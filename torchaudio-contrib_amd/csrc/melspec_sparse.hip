@@ -35,9 +35,6 @@
 #ifndef TAC_SP_TIMING
 #define TAC_SP_TIMING 0   // 1: debug builds of tools/mel_phase_timing.py — phase cycle sums overwrite the head of out[]
 #endif
-#ifndef TAC_SP_SPLIT
-#define TAC_SP_SPLIT 0     // N = 2048: two independent 4-wave halves per workgroup (A/B knob; steady state 0.188 vs 0.175 ms)
-#endif
 #ifndef TAC_SP_HOISTW
 #define TAC_SP_HOISTW 1    // keep the window in registers for the kernel's lifetime (A/B knob)
 #endif
@@ -234,95 +231,6 @@ melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
 #endif
 }
 
-// ---------------------------------------------------------------- split variant (G == 1, i.e. N = 2048)
-// The 8 waves of the workgroup form two independent 4-wave HALVES, each a complete pipeline over its own
-// 8-frame tiles (own 8 frame buffers, own output tile, shared weights).  A half synchronises with an LDS
-// arrival counter instead of s_barrier, so while one half waits for HBM, sits at its barrier or runs the
-// contraction / store phases, the other half's FFT owns the SIMDs: the two waves on every SIMD are never in the
-// same phase by construction.  (Two 4-wave workgroups per CU would need 2 x 88 KB of LDS; one workgroup with
-// two halves shares the weights and fits.)
-__device__ __forceinline__ void half_barrier(int* counter, int& expected, int lane) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    expected += 4;
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < expected)
-        __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-template <int NC, int E, bool POW2>
-__global__ void __launch_bounds__(512, 2)
-melspec_sparse_split_kernel(FrameGeom g, Tables tb, SparseArgs m) {
-    using C = MelCfg<NC, E, 8>;              // per half: 4 waves x 2 frames
-    using F = typename C::F;
-    static_assert(F::G == 1 && C::WAVES == 4 && C::GPW == 2, "split variant is wired for one frame per wave-round");
-    constexpr int PROW = C::PROW, HT = 8;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cf* bufs = reinterpret_cast<cf*>(smem_raw);                                   // 16 frame buffers (8 per half)
-    float* wlds = reinterpret_cast<float*>(bufs + 16 * F::PADDED);
-    const int ostr = sparse_ostr(m.n_mels, m.out_vec4);
-    float* otile = wlds + m.wtot;                                                 // [2][HT][ostr]
-    int* dlds = reinterpret_cast<int*>(otile + ((2 * HT * ostr + 3) & ~3));       // [32][dstride]
-    int* counters = dlds + 32 * m.dstride;                                        // [2]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = w >> 2, wl = w & 3;
-    const int t = lane;                       // G == 1: the whole wave is one frame
-    const int th = tid & 255;                 // thread index within the half
-
-    for (int i = tid; i < m.wtot; i += 512) wlds[i] = m.wpack[i];
-    for (int i = tid; i < 32 * m.dstride; i += 512) dlds[i] = m.desc[i];
-    if (tid < 2) counters[tid] = 0;
-
-    MelFftConsts<F, TAC_SP_HOISTW != 0, TAC_SP_FACT != 0> fftk;
-    fftk.load(tb, g, t, t);
-    __syncthreads();
-
-    const int tiles_per_row = (int)((g.n_frames + HT - 1) / HT);
-    const int total_tiles = (int)g.rows * tiles_per_row;
-    const int chunk = (total_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int wg_begin = (int)blockIdx.x * chunk;
-    const int wg_end = wg_begin + chunk < total_tiles ? wg_begin + chunk : total_tiles;
-    const int mid = wg_begin + (wg_end - wg_begin + 1) / 2;
-    const int begin = half == 0 ? wg_begin : mid;
-    const int end = half == 0 ? mid : wg_end;
-
-    cf* hbufs = bufs + half * HT * F::PADDED;
-    float* hot = otile + half * HT * ostr;
-    int* hcnt = counters + half;
-    int expected = 0;
-
-    const int fr = th & 7;                                                        // 8 lanes = the 8 frames share a band
-    const int* dg = dlds + (th >> 3) * m.dstride;
-    const float* prow = reinterpret_cast<const float*>(hbufs) + fr * PROW;
-
-    cf raw[F::E];
-    bool pre_ok = false;
-    if (begin < end) {
-        const int r0 = begin / tiles_per_row;
-        pre_ok = prefetch_frame_raw_x<F>(raw, g, r0, (long long)(begin - r0 * tiles_per_row) * HT + wl * C::GPW, t, t, false);
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    // the second half starts half a tile late so that the two waves of every SIMD are in different phases
-    NoStamp st;
-    for (int tile = begin; tile < end; ++tile) {
-        const int row = tile / tiles_per_row;
-        const long long f0 = (long long)(tile - row * tiles_per_row) * HT;
-        const int nt = tile + 1;
-        const int nr = nt / tiles_per_row;
-        const long long nf0 = nt < end ? (long long)(nt - nr * tiles_per_row) * HT : -1;
-        mel_phase_a<C, POW2, 1, TAC_SP_HOISTW != 0, NoStamp, true>(g, hbufs, fftk, wl, 0, t, row, f0, raw, &pre_ok, &st, nr, nf0,
-                                                                    t, false);
-        half_barrier(hcnt, expected, lane);
-        sparse_phase_b(dg, prow, wlds, hot + fr * ostr);
-        half_barrier(hcnt, expected, lane);
-        sparse_phase_c<256>(hot, ostr, th, HT, m, g, row, f0);
-        // the half-barrier after the next phase A orders these output-tile reads before the next contraction's writes
-    }
-}
-
 // ---------------------------------------------------------------- standalone band-sparse filterbank
 // functional.apply_filterbank (functional.py:172-184) for a frame-major spectrogram (bins of a frame contiguous: the
 // layout every kernel of this library writes) and a band-sparse bank: the fused kernel with phase A replaced by
@@ -476,36 +384,11 @@ static int launch_sparse(const FrameGeom& g, const Tables& tb, const SparseArgs&
     long long blocks = tiles < max_blocks ? tiles : max_blocks;
     if (blocks < 1) blocks = 1;
     const bool pow2 = (power == 2.0f);
-    if constexpr (C::F::G == 1 && C::WAVES == 8 && TAC_SP_SPLIT != 0) {
-        const size_t lds2 = (size_t)16 * C::F::PADDED * sizeof(cf) + (size_t)m.wtot * 4 +
-                            (size_t)((2 * 8 * ostr + 3) & ~3) * 4 + (size_t)32 * m.dstride * 4 + 16;   // ostr: sparse_ostr above
-        if (lds2 <= 160 * 1024) {
-            const long long tiles8 = g.rows * ((g.n_frames + 7) / 8);
-            if (tiles8 >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
-            long long nb = (tiles8 + 1) / 2 < (long long)device_cu_count() ? (tiles8 + 1) / 2 : (long long)device_cu_count();
-            if (nb < 1) nb = 1;
-            auto k2 = pow2 ? melspec_sparse_split_kernel<NC, E, true> : melspec_sparse_split_kernel<NC, E, false>;
-            static bool attr2[2] = {false, false};
-            if (!attr2[pow2]) {
-                TAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k2),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr2[pow2] = true;
-            }
-            hipLaunchKernelGGL(k2, dim3((unsigned)nb), dim3(512), lds2, stream, g, tb, m);
-            TAC_HIP(hipGetLastError());
-            return TAC_OK;
-        }
-    }
     constexpr bool CAN_V4 = (C::F::G == 1) && (TAC_SP_PIPE != 0) && (TAC_V4_LOADS != 0);
     const bool v4 = CAN_V4 && g.vec4_ok;
     auto kern = v4 ? (pow2 ? melspec_sparse_kernel<NC, E, true, CAN_V4> : melspec_sparse_kernel<NC, E, false, CAN_V4>)
                    : (pow2 ? melspec_sparse_kernel<NC, E, true, false> : melspec_sparse_kernel<NC, E, false, false>);
-    static bool attr_set[4] = {false, false, false, false};
-    if (!attr_set[pow2 + 2 * v4]) {
-        TAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set[pow2 + 2 * v4] = true;
-    }
+    TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::WAVES * 64), lds_bytes, stream, g, tb, m);
     TAC_HIP(hipGetLastError());
     return TAC_OK;
@@ -541,15 +424,7 @@ static int launch_stream(FrameGeom g, const Tables& tb, const SparseArgs& sm, co
                     : (fullm ? melspec_stream_kernel<NC, E, false, true, FMT> : melspec_stream_kernel<NC, E, false, false, FMT>);
     else
         kern = pow2 ? melspec_stream_kernel<NC, E, true, false, FMT> : melspec_stream_kernel<NC, E, false, false, FMT>;
-    int dev = 0;
-    TAC_HIP(hipGetDevice(&dev));
-    static std::atomic<bool> attr_set[4][16];                             // per (kernel, device): cheap, so no lock
-    const int ki = pow2 * 2 + fullm;
-    if (dev < 0 || dev >= 16 || !attr_set[ki][dev].load(std::memory_order_acquire)) {
-        TAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024));
-        if (dev >= 0 && dev < 16) attr_set[ki][dev].store(true, std::memory_order_release);
-    }
+    TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(ST_WAVES * 64), lds_bytes, stream, g, tb, m);
     TAC_HIP(hipGetLastError());
     return TAC_OK;
@@ -763,12 +638,7 @@ int tac_apply_filterbank_sparse_f32(const float* spec, int64_t rows, int32_t n_f
     if (per_cu > 2) per_cu = 2;
     long long blocks = (long long)device_cu_count() * per_cu;
     if (blocks > tiles) blocks = tiles;
-    static bool attr_set = false;
-    if (!attr_set) {
-        TAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fb_sparse_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(fb_sparse_kernel), 160 * 1024));
     hipLaunchKernelGGL(fb_sparse_kernel, dim3((unsigned)blocks), dim3(FBS_WAVES * 64), lds_bytes, (hipStream_t)stream, spec,
                        (long long)rows, (int)n_freqs, (long long)n_frames, (long long)stride_r, (long long)stride_t, prow,
                        m);

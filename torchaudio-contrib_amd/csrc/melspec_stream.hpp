@@ -23,12 +23,6 @@
 #pragma once
 #include "mel_common.hpp"
 
-#ifndef TAC_ST_ABL
-#define TAC_ST_ABL 0        // ablation builds (wrong results): 1 no contraction stage, 2 no row stores, 3 no dB, 4 no sample loads, 5 conflict-free row reads
-#endif
-#ifndef TAC_ST_PRIO
-#define TAC_ST_PRIO 0       // A/B knob: 1 = static priority for the younger wave of each SIMD (waves 4-7), 2 = for the older
-#endif
 #ifndef TAC_ST_TIMING
 #define TAC_ST_TIMING 0     // 1: debug builds of tools/stream_timing.py — per-wave cycle sums overwrite the head of out[]
 #endif
@@ -152,7 +146,7 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         long long cs = start < 0 ? 0 : start;
         cs = cs + F::N <= g.length ? cs : g.length - F::N;             // host guarantees length >= N
         const long long off = (long long)row * g.row_stride + cs;      // in samples
-        if (TAC_ST_ABL != 4) {
+        {
             if constexpr (FMT == FMT_F32) {
                 const cf* src = reinterpret_cast<const cf*>(static_cast<const float*>(m.samples) + off);
 #pragma unroll
@@ -272,14 +266,13 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     const bool fast_db = m.amin >= 1.1754944e-38f;                      // (uniform) hardware log2 unless the clamp admits denormals
     const float ten_log10_ref = 10.0f * m.log10_ref;
     auto s4 = [&](const float* prow, int i) {
-        if (TAC_ST_ABL == 1) return;
         i = i < nloc ? i : nloc - 1;
         const f4* wp = reinterpret_cast<const f4*>(wlds) + lane;
         float* orow = m.out + (begin + i) * (long long)m.n_mels + lane;
 #pragma unroll
         for (int s = 0; s < ST_MAX_SLOTS; ++s) {
             if (s < m.nslot) {
-                const f4* pp = reinterpret_cast<const f4*>(prow + (TAC_ST_ABL == 5 ? 4 * (lane & 15) : lo_s[s]));
+                const f4* pp = reinterpret_cast<const f4*>(prow + lo_s[s]);
                 const int n = m.steps[s];
                 cf acc0 = mkc(0.f, 0.f), acc1 = mkc(0.f, 0.f);
                 int j = 0;
@@ -306,8 +299,8 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
                     wp += 256;
                 }
                 float v = (acc0.x + acc0.y) + (acc1.x + acc1.y);
-                if (m.db && TAC_ST_ABL != 3) v = fast_db ? amp_to_db_fast(v, m.amin, ten_log10_ref) : amp_to_db(v, m.amin, m.log10_ref);
-                if (TAC_ST_ABL == 2 ? v == 12345.678f : (FULLM || s * 64 + lane < m.n_mels)) orow[s * 64] = v;
+                if (m.db) v = fast_db ? amp_to_db_fast(v, m.amin, ten_log10_ref) : amp_to_db(v, m.amin, m.log10_ref);
+                if (FULLM || s * 64 + lane < m.n_mels) orow[s * 64] = v;
             }
         }
     };
@@ -317,8 +310,6 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     // where B's s3 / s4 finish its frame n and its s0 / s12 start frame n + 1 (B's first frame is brought to that point
     // before the loop).  A thread's next samples are requested as soon as its registers are free (after s3).  No branch
     // inside the loop: every wave runs the same number of iterations, surplus frame numbers are clamped (request).
-    if (TAC_ST_PRIO == 1 && w >= 4) __builtin_amdgcn_s_setprio(1);
-    if (TAC_ST_PRIO == 2 && w < 4) __builtin_amdgcn_s_setprio(1);
     if (nloc > 0) {
         const int iters = (nloc + SLOTS - 1) / SLOTS;
         int modeA, rowA_, modeB, rowB_;

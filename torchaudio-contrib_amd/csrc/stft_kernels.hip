@@ -613,12 +613,7 @@ static int launch_stft(const FrameGeom& g, const Tables& tb, const StftEpilogue&
     long long blocks = want < max_blocks ? want : max_blocks;
     if (blocks < 1) blocks = 1;
     auto kern = stft_kernel<NC, E, MODE, NF, HOIST>;
-    static bool attr_set = false;
-    if (!attr_set && lds_bytes > 64 * 1024) {
-        TAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr_set = true;
-    }
+    if (lds_bytes > 64 * 1024) TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds_bytes));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(STFT_WAVES * 64), lds_bytes, stream, g, tb, ep);
     TAC_HIP(hipGetLastError());
     return TAC_OK;

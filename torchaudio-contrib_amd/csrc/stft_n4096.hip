@@ -225,12 +225,7 @@ static int launch_n4096(const FrameGeom& g, const Tables& tb1k, const Tables& tb
     const long long cap = (long long)device_cu_count() * 2;
     if (blocks > cap) blocks = cap;
     auto kern = stft_n4096_kernel<MODE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        TAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)bytes));
-        attr_set = true;
-    }
+    TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(N4K_WAVES * 64), bytes, stream, g, tb1k, tb4k, ep);
     TAC_HIP(hipGetLastError());
     return TAC_OK;
