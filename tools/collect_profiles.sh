@@ -16,4 +16,8 @@ for k in mel stft spec; do
   rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_${k}_mfma -o p -- python tools/prof_driver.py $k 3 > /dev/null 2>&1
   rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA --output-format csv -d $out/pmc_${k}_stall -o p -- python tools/prof_driver.py $k 3 > /dev/null 2>&1
 done
+# the filterbank stage on the matrix cores (dense bank): MFMA instruction / busy counters of gemm_fb_kernel
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_fb_mfma -o p -- python tools/prof_driver.py fb 3 > /dev/null 2>&1
+# backward of the fused chain: which kernels, how long
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_grad -o grad -- python tools/prof_driver.py grad 5 > $out/kt_grad.log 2>&1
 ls $out

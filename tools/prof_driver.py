@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Tiny driver for rocprofv3: launch one kernel family a few times at cfg-2 size.
-    python tools/prof_driver.py mel|stft|spec|mulaw [iters]"""
+    python tools/prof_driver.py mel|stft|spec|fb|grad|mulaw [iters]"""
 import os
 import sys
 
@@ -27,6 +27,20 @@ elif what == 'unfused':
     m = torch.nn.Sequential(*tac.Melspectrogram(num_mels=128, sample_rate=16000, fft_length=2048, hop_length=512),
                             tac.AmplitudeToDb()).cuda()
     fn = lambda: m(x)
+elif what == 'fb':
+    # the filterbank stage as a dense fp32 MFMA GEMM (a random bank is not band-sparse): north_star's MFMA-utilisation figure
+    spec = tac.Spectrogram(2048, 512, power=2.).cuda()(x)
+    fbd = torch.rand(1025, 128, device='cuda')
+    fn = lambda: tac.apply_filterbank(spec, fbd)
+elif what == 'grad':
+    # backward of the fused chain: recomputed spectrum + HIP gradient kernels
+    m = torch.nn.Sequential(*tac.Melspectrogram(num_mels=128, sample_rate=16000, fft_length=2048, hop_length=512),
+                            tac.AmplitudeToDb()).cuda()
+    xg = x.clone().requires_grad_(True)
+    def fn():
+        y = m(xg)
+        y.backward(torch.ones_like(y))
+        return y
 elif what == 'mulaw':
     xm = torch.rand(1024, 1, 120000, device='cuda') * 2 - 1
     fn = lambda: tac.mu_law_decoding(tac.mu_law_encoding(xm, 256), 256)

@@ -375,9 +375,10 @@ struct WaveFft {
         }
     }
     // (2) inter-pass twiddles (P > 0) and the radix-R butterflies of pass P
-    template <int P>
+    // REL: `tw` points at pass P's own twiddles (kernels that keep a pass's set somewhere else than the hoisted array)
+    template <int P, bool REL = false>
     __device__ static __forceinline__ void pass_twiddle(cf (&v)[E_], const cf* tw) {
-        constexpr int R = radix_at(NC, P), OFF = twiddles_before(NC, E, P), NB = E / R;
+        constexpr int R = radix_at(NC, P), OFF = REL ? 0 : twiddles_before(NC, E, P), NB = E / R;
         if constexpr (P > 0) {
 #pragma unroll
             for (int b = 0; b < NB; ++b)

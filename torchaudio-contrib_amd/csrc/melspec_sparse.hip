@@ -46,6 +46,10 @@
 #define TAC_SP_STREAM 1     // fft_length 2048: producer / consumer streaming kernel (melspec_stream.hpp); 0 = the three-phase kernel
 #endif
 
+#ifndef TAC_ST_FAST2
+#define TAC_ST_FAST2 1      // the (4, 16)-step specialisation of the streaming kernel; 0 = A/B knob
+#endif
+
 #include "sparse_phase.hpp"
 #include "melspec_stream.hpp"
 
@@ -418,12 +422,19 @@ static int launch_stream(FrameGeom g, const Tables& tb, const SparseArgs& sm, co
     // the band predicate of the row stores is compiled out for whole slots of 64 bands (float32 input only: the coded
     // formats keep one instantiation per power)
     const bool fullm = FMT == FMT_F32 && (sm.n_mels % 64) == 0;
+    // two slots of exactly (4, 16) steps — what tac_melbank_pack produces for 128-band mel banks — take the kernel whose
+    // contraction is unrolled for that shape (its first reads ride along with the other frame's FFT stage)
+    const bool fast2 = TAC_ST_FAST2 && fullm && info_host[1] == 2 && info_host[4] == ST_FAST_STEPS0 && info_host[5] == ST_FAST_STEPS1;
     void (*kern)(FrameGeom, Tables, StreamArgs);
-    if constexpr (FMT == FMT_F32)
-        kern = pow2 ? (fullm ? melspec_stream_kernel<NC, E, true, true, FMT> : melspec_stream_kernel<NC, E, true, false, FMT>)
-                    : (fullm ? melspec_stream_kernel<NC, E, false, true, FMT> : melspec_stream_kernel<NC, E, false, false, FMT>);
-    else
-        kern = pow2 ? melspec_stream_kernel<NC, E, true, false, FMT> : melspec_stream_kernel<NC, E, false, false, FMT>;
+    if constexpr (FMT == FMT_F32) {
+        if (fast2)
+            kern = pow2 ? melspec_stream_kernel<NC, E, true, true, FMT, true> : melspec_stream_kernel<NC, E, false, true, FMT, true>;
+        else
+            kern = pow2 ? (fullm ? melspec_stream_kernel<NC, E, true, true, FMT, false> : melspec_stream_kernel<NC, E, true, false, FMT, false>)
+                        : (fullm ? melspec_stream_kernel<NC, E, false, true, FMT, false> : melspec_stream_kernel<NC, E, false, false, FMT, false>);
+    } else {
+        kern = pow2 ? melspec_stream_kernel<NC, E, true, false, FMT, false> : melspec_stream_kernel<NC, E, false, false, FMT, false>;
+    }
     TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(ST_WAVES * 64), lds_bytes, stream, g, tb, m);
     TAC_HIP(hipGetLastError());
@@ -450,6 +461,10 @@ static int pack_lanes(const std::vector<float>& h, int n_freqs, int n_mels, floa
             len[m] = h0 - lo[m];
             steps[m / 64] = std::max(steps[m / 64], (len[m] + 3) / 4);
         }
+    }
+    if (nslot == 2 && steps[0] <= ST_FAST_STEPS0 && steps[1] <= ST_FAST_STEPS1) {   // the shape the FAST2 kernel is unrolled for
+        steps[0] = ST_FAST_STEPS0;
+        steps[1] = ST_FAST_STEPS1;
     }
     int total_steps = 0;
     for (int s = 0; s < nslot; ++s) {

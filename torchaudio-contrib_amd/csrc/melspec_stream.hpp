@@ -31,6 +31,16 @@ namespace tac {
 
 constexpr int ST_WAVES = 8;
 constexpr int ST_MAX_SLOTS = 4;              // bands per lane (n_mels <= 256)
+constexpr int ST_TW_STRIDE = 36;              // floats between the 16 pass-1 twiddle sets in LDS (144 B: conflict-free b128)
+constexpr int ST_TW_BYTES = 16 * ST_TW_STRIDE * 4;
+constexpr int ST_FAST_STEPS0 = 4, ST_FAST_STEPS1 = 16;   // slot lengths of the two-slot layout the FAST2 kernel is unrolled for
+#ifndef TAC_ST_RIDE1
+#define TAC_ST_RIDE1 4       // steps of slot 1 whose reads ride along with slot 0 (measured: 0 -> 0.1488 ms, 2..6 -> 0.146 ms, 8 spills)
+#endif
+#ifndef TAC_ST_BATCH
+#define TAC_ST_BATCH 6       // steps per round trip of the rest of slot 1 (12 or 16 at once spill: 0.18 / 0.30 ms)
+#endif
+constexpr int ST_RIDE = ST_FAST_STEPS0 + TAC_ST_RIDE1;     // steps issued at the end of s3
 
 struct StreamArgs {
     const float* wl;       // device: weights [sum of steps][64 lanes][4 consecutive bins]
@@ -66,10 +76,10 @@ __host__ __device__ inline size_t stream_lds_bytes(int wtot) {
     size_t b = (size_t)ST_WAVES * ((C::F::PADDED * sizeof(cf) + 15) & ~(size_t)15);
     b += (size_t)ST_WAVES * 2 * C::PROW * 4;
     b += ((size_t)wtot * 4 + 15) & ~(size_t)15;
-    return b + 1024;                                                           // mu-law decode table
+    return b + 1024 + ST_TW_BYTES;                                             // mu-law decode table, pass-1 twiddles
 }
 
-template <int NC, int E, bool POW2, bool FULLM, int FMT>
+template <int NC, int E, bool POW2, bool FULLM, int FMT, bool FAST2>
 __global__ void __launch_bounds__(ST_WAVES * 64, 2)
 melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     using C = StreamCfg<NC, E>;
@@ -89,6 +99,13 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     float* lutlds = wlds + ((m.wtot + 3) & ~3);                                      // mu-law decode table (coded inputs)
     for (int i = tid; i < m.wtot; i += ST_WAVES * 64) wlds[i] = m.wl[i];
     if (FMT >= FMT_MULAW_U8 && tid < 256) lutlds[tid] = m.lut[tid];
+    float* twlds = lutlds + 256;                                                     // pass-1 twiddles by (lane & 15) (FAST2)
+    if (FAST2 && tid < 16 * 16) {
+        const int js = tid >> 4, q = tid & 15;                                       // q = 0 is a pad slot
+        const cf wv = q ? tb.w_nc[js * q * (NC / 256)] : mkc(1.0f, 0.0f);
+        twlds[js * ST_TW_STRIDE + 2 * (q ? q - 1 : 15)] = wv.x;
+        twlds[js * ST_TW_STRIDE + 2 * (q ? q - 1 : 15) + 1] = wv.y;
+    }
     for (int i = tid; i < ST_WAVES * 2 * (PROW - NBINS); i += ST_WAVES * 64) {       // slack columns stay zero for good
         const int r = i / (PROW - NBINS), c2 = i - r * (PROW - NBINS);
         rows_all[(size_t)r * PROW + NBINS + c2] = 0.0f;
@@ -102,8 +119,18 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     const unsigned T = (unsigned)g.n_frames;
 
     const int t = lane;
-    cf tw[F::NTW];
-    F::load_twiddles(tw, tb.w_nc, t);
+    // inter-pass twiddles: pass 2's three stay in registers; pass 1's fifteen too, except in the FAST2 kernel, which
+    // re-reads them from LDS every frame (they are needed during s12 only) to make room for the contraction's
+    // ride-along reads
+    cf tw[FAST2 ? 3 : F::NTW];
+    if constexpr (FAST2) {
+        cf all[F::NTW];
+        F::load_twiddles(all, tb.w_nc, t);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) tw[q] = all[twiddles_before(NC, E, 2) + q];
+    } else {
+        F::load_twiddles(tw, tb.w_nc, t);
+    }
     const cf w0 = tb.w_n[t];                                           // R2C: W_N^{t + 64 i} = W_N^t * W_32^i
     cf win[E];
     load_window_regs<F>(win, g, t);
@@ -211,20 +238,32 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             for (int e = 0; e < E; ++e) v[e] = cscale(v[e], win_scale);                       // the scale goes here
         }
     };
-    auto s0b = [&](cf (&v)[E]) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    auto s0b = [&](cf (&v)[E], cf (&tw1)[16]) {
         F::template pass_butterflies<0>(v);
         wave_lds_fence();
         F::template pass_write<0, true>(v, xa, t, t);
         wave_lds_fence();
         F::template pass_readback<1>(v, xa, t);
+        if constexpr (FAST2) {                                          // pass 1's twiddles travel with its operands
+            const f4* tl = reinterpret_cast<const f4*>(twlds + (t & 15) * ST_TW_STRIDE);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const f4 x = tl[u];
+                tw1[2 * u] = mkc(x.x, x.y);
+                tw1[2 * u + 1] = mkc(x.z, x.w);
+            }
+        }
     };
     // s12: pass 1, the in-register exchange, pass 2; the lower half of the spectrum stays in registers, the upper half
     // travels to its R2C partners
-    auto s12 = [&](cf (&v)[E], cf (&zm)[F::NPAIR], cf& zmid) {
-        F::template pass_twiddle<1>(v, tw);
+    auto s12 = [&](cf (&v)[E], cf (&zm)[F::NPAIR], cf& zmid, const cf (&tw1)[16]) {
+        if constexpr (FAST2) F::template pass_twiddle<1, true>(v, tw1);
+        else F::template pass_twiddle<1>(v, tw);
         F::template pass_butterflies<1>(v);
         F::exchange_1_2_in_registers(v);
-        F::template pass_twiddle<2>(v, tw);
+        if constexpr (FAST2) F::template pass_twiddle<2, true>(v, tw);
+        else F::template pass_twiddle<2>(v, tw);
         F::template pass_butterflies<2>(v);
         wave_lds_fence();
         F::template pass_write<2, true>(v, xa, t, t);
@@ -254,17 +293,67 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         }
         wave_lds_fence();
     };
+    // FAST2 (two slots of 4 and 16 steps): the first eight steps' reads are issued right behind the row (end of s3) and
+    // ride along with the other frame's next stage; s4 finds them landed
+    auto s3_issue = [&](const float* prow, f4 (&cw)[ST_RIDE], f4 (&cp)[ST_RIDE]) {
+        const f4* wp = reinterpret_cast<const f4*>(wlds) + lane;
+        const f4* p0 = reinterpret_cast<const f4*>(prow + lo_s[0]);
+        const f4* p1 = reinterpret_cast<const f4*>(prow + lo_s[1]);
+#pragma unroll
+        for (int u = 0; u < ST_FAST_STEPS0; ++u) {
+            cw[u] = wp[u * 64];
+            cp[u] = p0[u];
+        }
+#pragma unroll
+        for (int u = 0; u < TAC_ST_RIDE1; ++u) {
+            cw[ST_FAST_STEPS0 + u] = wp[(ST_FAST_STEPS0 + u) * 64];
+            cp[ST_FAST_STEPS0 + u] = p1[u];
+        }
+    };
     // s4: filterbank contraction (one band per lane and slot; four taps per step: one 16-byte weight read, one 16-byte
     // row read, two packed FMAs), dB, row store.  A trip is eight steps whose sixteen reads are all issued before the
     // first FMA (the thread's data registers are free by now), so a slot costs one or two LDS round trips, not one per
     // step; slot lengths are whole half-trips (tac_melbank_pack).
-    typedef float f4 __attribute__((ext_vector_type(4)));
     auto fma4 = [](f4 wv, f4 pv, cf& a0, cf& a1) {
         a0 = __builtin_elementwise_fma(mkc(wv.x, wv.y), mkc(pv.x, pv.y), a0);
         a1 = __builtin_elementwise_fma(mkc(wv.z, wv.w), mkc(pv.z, pv.w), a1);
     };
     const bool fast_db = m.amin >= 1.1754944e-38f;                      // (uniform) hardware log2 unless the clamp admits denormals
     const float ten_log10_ref = 10.0f * m.log10_ref;
+    auto s4_fast = [&](const float* prow, int i, const f4 (&cw)[ST_RIDE], const f4 (&cp)[ST_RIDE]) {
+        i = i < nloc ? i : nloc - 1;
+        constexpr int REST = ST_FAST_STEPS1 - TAC_ST_RIDE1;
+        const f4* wp = reinterpret_cast<const f4*>(wlds) + lane + ST_RIDE * 64;
+        const f4* p1 = reinterpret_cast<const f4*>(prow + lo_s[1]) + TAC_ST_RIDE1;
+        cf a0 = mkc(0.f, 0.f), a1 = mkc(0.f, 0.f), b0 = mkc(0.f, 0.f), b1 = mkc(0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < ST_FAST_STEPS0; ++u) fma4(cw[u], cp[u], a0, a1);
+#pragma unroll
+        for (int u = 0; u < TAC_ST_RIDE1; ++u) fma4(cw[ST_FAST_STEPS0 + u], cp[ST_FAST_STEPS0 + u], b0, b1);
+#pragma unroll
+        for (int c0 = 0; c0 < REST; c0 += TAC_ST_BATCH) {               // the remaining steps of slot 1, TAC_ST_BATCH per round trip
+            f4 w2[TAC_ST_BATCH], q2[TAC_ST_BATCH];
+#pragma unroll
+            for (int u = 0; u < TAC_ST_BATCH; ++u) {
+                if (c0 + u < REST) {
+                    w2[u] = wp[(c0 + u) * 64];
+                    q2[u] = p1[c0 + u];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < TAC_ST_BATCH; ++u)
+                if (c0 + u < REST) fma4(w2[u], q2[u], b0, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float v0 = (a0.x + a0.y) + (a1.x + a1.y), v1 = (b0.x + b0.y) + (b1.x + b1.y);
+        if (m.db) {
+            v0 = fast_db ? amp_to_db_fast(v0, m.amin, ten_log10_ref) : amp_to_db(v0, m.amin, m.log10_ref);
+            v1 = fast_db ? amp_to_db_fast(v1, m.amin, ten_log10_ref) : amp_to_db(v1, m.amin, m.log10_ref);
+        }
+        float* orow = m.out + (begin + i) * (long long)m.n_mels + lane;
+        orow[0] = v0;
+        orow[64] = v1;
+    };
     auto s4 = [&](const float* prow, int i) {
         i = i < nloc ? i : nloc - 1;
         const f4* wp = reinterpret_cast<const f4*>(wlds) + lane;
@@ -307,6 +396,7 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
 
     // Frames of thread A: 2w + n*SLOTS, thread B: 2w + 1 + n*SLOTS.  Rotation of one iteration:
     //   A.s0 | B.s3 + request | A.s12 | B.s4 | A.s3 + request | B.s0 | A.s4 | B.s12
+    // (FAST2: s3 ends by issuing the first contraction reads instead, and the request follows s4)
     // where B's s3 / s4 finish its frame n and its s0 / s12 start frame n + 1 (B's first frame is brought to that point
     // before the loop).  A thread's next samples are requested as soon as its registers are free (after s3).  No branch
     // inside the loop: every wave runs the same number of iterations, surplus frame numbers are clamped (request).
@@ -315,41 +405,55 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         int modeA, rowA_, modeB, rowB_;
         long long frA, frB;
         int iA = 2 * w, iB = 2 * w + 1;
+        cf tw1A[16], tw1B[16];
+        f4 cwA[ST_RIDE], cpA[ST_RIDE], cwB[ST_RIDE], cpB[ST_RIDE];
         request(vB, iB, modeB, rowB_, frB);
         request(vA, iA, modeA, rowA_, frA);
         s0(vB, modeB, rowB_, frB);
-        s0b(vB);
-        s12(vB, zmB, zmidB);
+        s0b(vB, tw1B);
+        s12(vB, zmB, zmidB, tw1B);
         __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0): the loop is entered with nothing in flight
         ST_MARK(6);
 #pragma unroll 1
         for (int n = 0; n < iters; ++n) {
             s0(vA, modeA, rowA_, frA);
-            s0b(vA);
+            s0b(vA, tw1A);
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(1);
             s3(vB, zmB, zmidB, rowB);
-            request(vB, iB + SLOTS, modeB, rowB_, frB);
+            if constexpr (FAST2) s3_issue(rowB, cwB, cpB);
+            else request(vB, iB + SLOTS, modeB, rowB_, frB);
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(4);
-            s12(vA, zmA, zmidA);
+            s12(vA, zmA, zmidA, tw1A);
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(2);
-            s4(rowB, iB);
+            if constexpr (FAST2) {
+                s4_fast(rowB, iB, cwB, cpB);
+                request(vB, iB + SLOTS, modeB, rowB_, frB);             // the contraction used the frame's registers until here
+            } else {
+                s4(rowB, iB);
+            }
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(5);
             s3(vA, zmA, zmidA, rowA);
-            request(vA, iA + SLOTS, modeA, rowA_, frA);
+            if constexpr (FAST2) s3_issue(rowA, cwA, cpA);
+            else request(vA, iA + SLOTS, modeA, rowA_, frA);
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(4);
             s0(vB, modeB, rowB_, frB);
-            s0b(vB);
+            s0b(vB, tw1B);
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(1);
-            s4(rowA, iA);
+            if constexpr (FAST2) {
+                s4_fast(rowA, iA, cwA, cpA);
+                request(vA, iA + SLOTS, modeA, rowA_, frA);
+            } else {
+                s4(rowA, iA);
+            }
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(5);
-            s12(vB, zmB, zmidB);
+            s12(vB, zmB, zmidB, tw1B);
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(2);
             iA += SLOTS;
