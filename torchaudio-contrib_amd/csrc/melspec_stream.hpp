@@ -37,6 +37,9 @@ constexpr int ST_FAST_STEPS0 = 4, ST_FAST_STEPS1 = 16;   // slot lengths of the 
 #ifndef TAC_ST_RIDE1
 #define TAC_ST_RIDE1 4       // steps of slot 1 whose reads ride along with slot 0 (measured: 0 -> 0.1488 ms, 2..6 -> 0.146 ms, 8 spills)
 #endif
+#ifndef TAC_ST_FULLPTW
+#define TAC_ST_FULLPTW 1     // A/B: 1 = all eight R2C twiddles in registers instead of one register x compile-time constants
+#endif
 #ifndef TAC_ST_BATCH
 #define TAC_ST_BATCH 6       // steps per round trip of the rest of slot 1 (12 or 16 at once spill: 0.18 / 0.30 ms)
 #endif
@@ -76,7 +79,7 @@ __host__ __device__ inline size_t stream_lds_bytes(int wtot) {
     size_t b = (size_t)ST_WAVES * ((C::F::PADDED * sizeof(cf) + 15) & ~(size_t)15);
     b += (size_t)ST_WAVES * 2 * C::PROW * 4;
     b += ((size_t)wtot * 4 + 15) & ~(size_t)15;
-    return b + 1024 + ST_TW_BYTES;                                             // mu-law decode table, pass-1 twiddles
+    return b + 1024 + ST_TW_BYTES + 16;                                        // mu-law decode table, pass-1 twiddles, frame counter
 }
 
 template <int NC, int E, bool POW2, bool FULLM, int FMT, bool FAST2>
@@ -106,6 +109,8 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         twlds[js * ST_TW_STRIDE + 2 * (q ? q - 1 : 15)] = wv.x;
         twlds[js * ST_TW_STRIDE + 2 * (q ? q - 1 : 15) + 1] = wv.y;
     }
+    unsigned* const next_frame = reinterpret_cast<unsigned*>(twlds + ST_TW_BYTES / 4);   // the workgroup's frame counter
+    if (tid == 0) *next_frame = SLOTS;                                               // (the first SLOTS frames are dealt by wave number)
     for (int i = tid; i < ST_WAVES * 2 * (PROW - NBINS); i += ST_WAVES * 64) {       // slack columns stay zero for good
         const int r = i / (PROW - NBINS), c2 = i - r * (PROW - NBINS);
         rows_all[(size_t)r * PROW + NBINS + c2] = 0.0f;
@@ -132,6 +137,12 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         F::load_twiddles(tw, tb.w_nc, t);
     }
     const cf w0 = tb.w_n[t];                                           // R2C: W_N^{t + 64 i} = W_N^t * W_32^i
+    constexpr bool FULLPTW = FAST2 && TAC_ST_FULLPTW != 0;              // (the general kernel has no registers for them)
+    cf ptw[FULLPTW ? F::NPAIR : 1];
+    if constexpr (FULLPTW) {
+#pragma unroll
+        for (int p = 0; p < F::NPAIR; ++p) ptw[p] = tb.w_n[t + p * F::LPF];
+    }
     cf win[E];
     load_window_regs<F>(win, g, t);
     // 2X -> scale * X once, in the window; int16 PCM samples are integers there, their 2^-15 goes in as well
@@ -161,6 +172,17 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     // the range are clamped to its last frame, which is then simply computed and stored twice with identical values:
     // the instruction stream is the same on every path, so hipcc's waitcnt pass can count (gfx950 has ONE in-order
     // vmcnt for loads and stores; an uncounted wait for these loads would also wait for the row stores behind them).
+    // The workgroup's frames are taken from a shared counter, not dealt out in fixed strides: the two waves of a SIMD do
+    // not get equal shares of its issue slots (the older one wins the arbitration: measured 230 k vs 330 k cycles for the
+    // same 39 frames), so with equal shares the SIMD would run its last quarter with one wave and nothing to overlap.
+    // (two halves so that the counter's answer can travel with other LDS traffic: FAST2 asks at the end of s3 and
+    // looks at the answer after s4)
+    auto grab_ask = [&]() -> unsigned {
+        unsigned v = 0;
+        if (lane == 0) v = __hip_atomic_fetch_add(next_frame, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return v;
+    };
+    auto grab = [&]() -> int { return (int)__builtin_amdgcn_readfirstlane(grab_ask()); };
     auto request = [&](cf (&raw)[E], int i, int& mode, int& row, long long& fr) {
         i = i < nloc ? i : nloc - 1;
         const unsigned gf = (unsigned)(begin + i);
@@ -282,7 +304,8 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         for (int p = 0; p < F::NPAIR; ++p) {
             const int kk = t + p * F::LPF;
             cf xk, xm;
-            F::r2c_split_factored_x2(v[F::reg_of_spectrum(p)], zm[p], w0, p, xk, xm);
+            if constexpr (FULLPTW) F::r2c_split_x2(v[F::reg_of_spectrum(p)], zm[p], ptw[p], xk, xm);
+            else F::r2c_split_factored_x2(v[F::reg_of_spectrum(p)], zm[p], w0, p, xk, xm);
             const float pa = cnorm2(xk), pb = cnorm2(xm);
             prow[kk] = POW2 ? pa : __builtin_amdgcn_sqrtf(pa);
             prow[NC - kk] = POW2 ? pb : __builtin_amdgcn_sqrtf(pb);
@@ -394,17 +417,18 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         }
     };
 
-    // Frames of thread A: 2w + n*SLOTS, thread B: 2w + 1 + n*SLOTS.  Rotation of one iteration:
+    // First frames of thread A: 2w, of thread B: 2w + 1, then whatever the counter hands out.  Rotation of one iteration:
     //   A.s0 | B.s3 + request | A.s12 | B.s4 | A.s3 + request | B.s0 | A.s4 | B.s12
     // (FAST2: s3 ends by issuing the first contraction reads instead, and the request follows s4)
     // where B's s3 / s4 finish its frame n and its s0 / s12 start frame n + 1 (B's first frame is brought to that point
     // before the loop).  A thread's next samples are requested as soon as its registers are free (after s3).  No branch
-    // inside the loop: every wave runs the same number of iterations, surplus frame numbers are clamped (request).
+    // inside the loop: a wave stops when neither of its threads holds a frame of the range; a thread without one
+    // recomputes the last frame (request clamps) and stores identical values.
     if (nloc > 0) {
-        const int iters = (nloc + SLOTS - 1) / SLOTS;
         int modeA, rowA_, modeB, rowB_;
         long long frA, frB;
-        int iA = 2 * w, iB = 2 * w + 1;
+        int iA = 2 * w, iB = 2 * w + 1, nA = 0, nB = 0;
+        unsigned askA = 0, askB = 0;
         cf tw1A[16], tw1B[16];
         f4 cwA[ST_RIDE], cpA[ST_RIDE], cwB[ST_RIDE], cpB[ST_RIDE];
         request(vB, iB, modeB, rowB_, frB);
@@ -415,14 +439,19 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0): the loop is entered with nothing in flight
         ST_MARK(6);
 #pragma unroll 1
-        for (int n = 0; n < iters; ++n) {
+        while (iA < nloc || iB < nloc) {
             s0(vA, modeA, rowA_, frA);
             s0b(vA, tw1A);
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(1);
             s3(vB, zmB, zmidB, rowB);
-            if constexpr (FAST2) s3_issue(rowB, cwB, cpB);
-            else request(vB, iB + SLOTS, modeB, rowB_, frB);
+            if constexpr (FAST2) {
+                s3_issue(rowB, cwB, cpB);
+                askB = grab_ask();
+            } else {
+                nB = grab();
+                request(vB, nB, modeB, rowB_, frB);
+            }
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(4);
             s12(vA, zmA, zmidA, tw1A);
@@ -430,15 +459,22 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             ST_MARK(2);
             if constexpr (FAST2) {
                 s4_fast(rowB, iB, cwB, cpB);
-                request(vB, iB + SLOTS, modeB, rowB_, frB);             // the contraction used the frame's registers until here
+                iB = (int)__builtin_amdgcn_readfirstlane(askB);
+                request(vB, iB, modeB, rowB_, frB);                     // the contraction used the frame's registers until here
             } else {
                 s4(rowB, iB);
+                iB = nB;
             }
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(5);
             s3(vA, zmA, zmidA, rowA);
-            if constexpr (FAST2) s3_issue(rowA, cwA, cpA);
-            else request(vA, iA + SLOTS, modeA, rowA_, frA);
+            if constexpr (FAST2) {
+                s3_issue(rowA, cwA, cpA);
+                askA = grab_ask();
+            } else {
+                nA = grab();
+                request(vA, nA, modeA, rowA_, frA);
+            }
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(4);
             s0(vB, modeB, rowB_, frB);
@@ -447,17 +483,20 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             ST_MARK(1);
             if constexpr (FAST2) {
                 s4_fast(rowA, iA, cwA, cpA);
-                request(vA, iA + SLOTS, modeA, rowA_, frA);
+                iA = (int)__builtin_amdgcn_readfirstlane(askA);
+                request(vA, iA, modeA, rowA_, frA);
             } else {
                 s4(rowA, iA);
+                iA = nA;
             }
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(5);
             s12(vB, zmB, zmidB, tw1B);
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(2);
-            iA += SLOTS;
-            iB += SLOTS;
+#if TAC_ST_TIMING
+            tstamp[7] += 2.0f;
+#endif
         }
     }
 #if TAC_ST_TIMING
