@@ -287,8 +287,8 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 // LEAN: the lane-dependent twiddles live in LDS (one conflict-free 144-byte row per lane, read where they are used)
 // and the R2C twiddles are one register x compile-time constants, which fits the kernel into 168 registers = three
 // waves per SIMD (three 4-wave workgroups per CU) instead of two.
-template <int NC, int E, int MODE, bool V4, bool LEAN>
-__global__ void __launch_bounds__(STFT_WAVES * 64, LEAN ? 3 : 2)
+template <int NC, int E, int MODE, bool V4, bool LEAN, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, LEAN ? 3 : 2)
 stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
     using F = WaveFft<NC, E>;
     static_assert(F::G == 1 && radix_at(NC, 0) == E, "one frame per wave, single first-pass butterfly per lane");
@@ -299,9 +299,9 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
     constexpr int WAVE_SLOTS = ((F::PADDED + 1) / 2) * 2;
     cf* const lds = smem + w * WAVE_SLOTS;
     // window pairs, one 144-byte row per first-pass column: a lane's 16 values are 8 conflict-free ds_read_b128
-    cf* const wlds = reinterpret_cast<cf*>(smem + STFT_WAVES * WAVE_SLOTS);
+    cf* const wlds = reinterpret_cast<cf*>(smem + WAVES * WAVE_SLOTS);
     constexpr int WROW = E + 2;
-    for (int m = threadIdx.x; m < NC; m += STFT_WAVES * 64) wlds[(m & 63) * WROW + (m >> 6)] = window_pair(g, m);
+    for (int m = threadIdx.x; m < NC; m += WAVES * 64) wlds[(m & 63) * WROW + (m >> 6)] = window_pair(g, m);
     constexpr bool v4 = V4;                               // frames fetched with 16-byte requests (fft_core.hpp)
     const int col = frame_col_of_lane(t, v4);
 
@@ -333,6 +333,15 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
     constexpr int NST = ((LENF >> 2) + 63) / 64;          // 16-byte wave-stores per output row
     const float hscale = 0.5f * g.scale;                  // the R2C split returns 2·X
 
+    // Frames are taken from a workgroup counter, not dealt out in fixed strides: where two waves share a SIMD the older
+    // one wins the issue arbitration and would finish its share long before the other (melspec_stream.hpp).
+    unsigned* const next_unit = reinterpret_cast<unsigned*>(wlds + (LEAN ? 128 : 64) * WROW);
+    if (threadIdx.x == 0) *next_unit = (unsigned)(begin + WAVES);
+    auto grab = [&]() -> int {
+        unsigned v = 0;
+        if (t == 0) v = __hip_atomic_fetch_add(next_unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return (int)__builtin_amdgcn_readfirstlane(v);
+    };
     cf raw[E];
     bool pre = false;
     int unit = begin + w;
@@ -362,7 +371,8 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 #if TAC_STFT_TIMING
     st.init();
 #endif
-    for (; unit < end; unit += STFT_WAVES) {
+    while (unit < end) {
+        const int nxt = grab();
         st.mark(0);
         const int urow = unit / T;
         const int uframe = unit - urow * T;
@@ -402,7 +412,6 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
         // request the next frame now: it lands while this frame is split, staged and stored
         __builtin_amdgcn_sched_barrier(0);
         {
-            const int nxt = unit + STFT_WAVES;
             pre = false;
 #if TAC_PIPE_ABL == 3
             pre = nxt < end;
@@ -451,6 +460,7 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
                 orow[NC / 2] = cnorm2(xm);                            // every lane holds the same value
                 st.mark(10);
                 st.mark(11);
+                unit = nxt;
                 continue;
             }
 #pragma unroll
@@ -536,6 +546,7 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
         }
         wave_lds_fence();   // next iteration's first-pass writes must follow these reads
         st.mark(11);
+        unit = nxt;
     }
     if constexpr (LATE) {
         if (have_late) {
@@ -545,12 +556,15 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 #if TAC_STFT_TIMING
     __syncthreads();
     if (t == 0)
-        for (int i = 0; i < 12; ++i) ep.out[((long long)blockIdx.x * STFT_WAVES + w) * 16 + i] = st.acc[i];
+        for (int i = 0; i < 12; ++i) ep.out[((long long)blockIdx.x * WAVES + w) * 16 + i] = st.acc[i];
 #endif
 }
 
 #ifndef TAC_STFT_PIPE
 #define TAC_STFT_PIPE 1     // 0: A/B knob, n_fft = 2048 plain epilogues go through the generic kernel
+#endif
+#ifndef TAC_PIPE_WAVES
+#define TAC_PIPE_WAVES 8    // waves per workgroup of the pipelined kernel (4: two workgroups per CU, A/B knob)
 #endif
 #ifndef TAC_STFT_LEAN
 #define TAC_STFT_LEAN 0     // 1: three waves per SIMD with LDS-resident twiddles (A/B knob: measured equal to two, 0.163 vs 0.158 ms)
@@ -560,17 +574,22 @@ template <int NC, int E, int PMODE>
 static int launch_pipe(const FrameGeom& g, const Tables& tb, const StftEpilogue& ep, long long groups, hipStream_t stream) {
     using F = WaveFft<NC, E>;
     constexpr bool LEAN = TAC_STFT_LEAN != 0;
-    const size_t bytes = (size_t)STFT_WAVES * (((F::PADDED + 1) / 2) * 2) * sizeof(cf) +
-                         (size_t)(LEAN ? 128 : 64) * (E + 2) * sizeof(cf);
-    long long blocks = (groups + STFT_WAVES - 1) / STFT_WAVES;
-    const long long cap = (long long)device_cu_count() * (LEAN ? 3 : 2);
+    // one 8-wave workgroup per CU (both waves of every SIMD draw frames from the same counter); LEAN: three of 4 waves
+    constexpr int WAVES = LEAN ? 4 : TAC_PIPE_WAVES;
+    const size_t bytes = (size_t)WAVES * (((F::PADDED + 1) / 2) * 2) * sizeof(cf) +
+                         (size_t)(LEAN ? 128 : 64) * (E + 2) * sizeof(cf) + 16;
+    long long blocks = (groups + WAVES - 1) / WAVES;
+    const long long cap = (long long)device_cu_count() * (LEAN ? 3 : 8 / WAVES);
     if (blocks > cap) blocks = cap;
-    if (TAC_V4_LOADS && g.vec4_ok)
-        hipLaunchKernelGGL((stft_pipe_kernel<NC, E, PMODE, (TAC_V4_LOADS != 0), LEAN>), dim3((unsigned)blocks),
-                           dim3(STFT_WAVES * 64), bytes, stream, g, tb, ep);
-    else
-        hipLaunchKernelGGL((stft_pipe_kernel<NC, E, PMODE, false, LEAN>), dim3((unsigned)blocks), dim3(STFT_WAVES * 64),
-                           bytes, stream, g, tb, ep);
+    if (TAC_V4_LOADS && g.vec4_ok) {
+        auto kern = stft_pipe_kernel<NC, E, PMODE, (TAC_V4_LOADS != 0), LEAN, WAVES>;
+        TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes));
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), bytes, stream, g, tb, ep);
+    } else {
+        auto kern = stft_pipe_kernel<NC, E, PMODE, false, LEAN, WAVES>;
+        TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes));
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), bytes, stream, g, tb, ep);
+    }
     TAC_HIP(hipGetLastError());
     return TAC_OK;
 }
