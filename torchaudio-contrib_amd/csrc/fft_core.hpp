@@ -86,6 +86,14 @@ __device__ __forceinline__ cf cmul_rot(cf w, cf d) {
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(d), "v"(w), "v"(t));   // + d.x·(w.y, -w.x)
     return r;
 }
+// (|a + b|^2, |a - b|^2): the real parts of both sums in one register pair, the imaginary parts in another, so the
+// two squared magnitudes cost one packed multiply and one packed FMA
+__device__ __forceinline__ cf power_pair(cf a, cf b) {
+    cf re, im;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]" : "=v"(re) : "v"(a), "v"(b));
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1] neg_hi:[0,1]" : "=v"(im) : "v"(a), "v"(b));
+    return __builtin_elementwise_fma(im, im, re * re);
+}
 // a · (C + iS) with compile-time C, S: the constant pairs live in SGPRs
 __device__ __forceinline__ cf cmulc(cf a, float C, float S) { return mkc(a.x, a.x) * mkc(C, S) + mkc(a.y, a.y) * mkc(-S, C); }
 __device__ __forceinline__ cf cscale(cf a, float s) { return a * mkc(s, s); }
@@ -100,6 +108,10 @@ __device__ __forceinline__ cf csub_conj(cf a, cf b) { return mkc(a.x - b.x, a.y 
 __device__ __forceinline__ cf csub_then_conj(cf a, cf b) { return mkc(a.x - b.x, b.y - a.y); }
 __device__ __forceinline__ cf cmul(cf a, cf b) { return mkc(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ cf cmul_rot(cf w, cf d) { return cmul(w, mkc(d.y, -d.x)); }
+__device__ __forceinline__ cf power_pair(cf a, cf b) {
+    const float pr = a.x + b.x, pi = a.y + b.y, mr = a.x - b.x, mi = a.y - b.y;
+    return mkc(pr * pr + pi * pi, mr * mr + mi * mi);
+}
 __device__ __forceinline__ cf cmulc(cf a, float C, float S) { return cmul(a, mkc(C, S)); }
 __device__ __forceinline__ cf cscale(cf a, float s) { return mkc(a.x * s, a.y * s); }
 __device__ __forceinline__ cf cmul_elem(cf a, cf b) { return mkc(a.x * b.x, a.y * b.y); }
@@ -481,6 +493,16 @@ struct WaveFft {
         const cf tw = cmul_rot(wk, d);
         xa = cadd(ev, tw);
         xb = csub_then_conj(ev, tw);
+    }
+    // (|2X[k]|^2, |2X[NC-k]|^2) of the same split, without forming the two spectra
+    __device__ static __forceinline__ cf r2c_power_x2(cf zk, cf zm, cf wk) {
+        const cf ev = cadd_conj(zk, zm), d = csub_conj(zk, zm);
+        return power_pair(ev, cmul_rot(wk, d));
+    }
+    __device__ static __forceinline__ cf r2c_power_factored_x2(cf zk, cf zm, cf w0, int i) {
+        static_assert(E == 16, "factored R2C twiddles are wired for 2E = 32");
+        const cf ev = cadd_conj(zk, zm), d = csub_conj(zk, zm);
+        return power_pair(ev, (i == 0) ? cmul_rot(w0, d) : cmul(mul_w32(d, i + 8), w0));
     }
     // Pair index i uses W_N^{t + i*LPF} = W_N^t · W_{2E}^i: one lane-dependent register (w0 = W_N^t) and a
     // COMPILE-TIME constant per pair instead of E/2 hoisted twiddles (E == 16 only: W_32^i; -i = W_32^8).

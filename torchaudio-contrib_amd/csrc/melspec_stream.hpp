@@ -35,13 +35,13 @@ constexpr int ST_TW_STRIDE = 36;              // floats between the 16 pass-1 tw
 constexpr int ST_TW_BYTES = 16 * ST_TW_STRIDE * 4;
 constexpr int ST_FAST_STEPS0 = 4, ST_FAST_STEPS1 = 16;   // slot lengths of the two-slot layout the FAST2 kernel is unrolled for
 #ifndef TAC_ST_RIDE1
-#define TAC_ST_RIDE1 4       // steps of slot 1 whose reads ride along with slot 0 (measured: 0 -> 0.1488 ms, 2..6 -> 0.146 ms, 8 spills)
+#define TAC_ST_RIDE1 6       // steps of slot 1 whose reads ride along with slot 0 (paired rotation: 4 / 6 / 8 / 10 -> 0.1375 / 0.1361 / 0.1358 / 0.1376 ms)
 #endif
 #ifndef TAC_ST_FULLPTW
 #define TAC_ST_FULLPTW 1     // A/B: 1 = all eight R2C twiddles in registers instead of one register x compile-time constants
 #endif
 #ifndef TAC_ST_BATCH
-#define TAC_ST_BATCH 6       // steps per round trip of the rest of slot 1 (12 or 16 at once spill: 0.18 / 0.30 ms)
+#define TAC_ST_BATCH 5       // steps per round trip of the rest of slot 1 (a batch that no longer fits the registers spills: 8 + 6 -> 0.156 ms)
 #endif
 constexpr int ST_RIDE = ST_FAST_STEPS0 + TAC_ST_RIDE1;     // steps issued at the end of s3
 
@@ -255,19 +255,25 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             decode(v);
             apply_window<F>(v, v, win);
         } else {                                                       // edge / unaligned frame: gathered through the exchange
-            load_frame<F, true, true>(v, g, win, xa, row, fr, t, Fetch{m.samples, lutlds});   // area, plain window ->
+            int tz;                                                    // (an opaque copy of the lane number: this rare path's
+            asm volatile("v_mov_b32 %0, %1" : "=v"(tz) : "v"(t));      // address registers must not be hoisted out of the loop)
+            load_frame<F, true, true>(v, g, win, xa, row, fr, tz, Fetch{m.samples, lutlds});  // area, plain window ->
 #pragma unroll
             for (int e = 0; e < E; ++e) v[e] = cscale(v[e], win_scale);                       // the scale goes here
         }
     };
     typedef float f4 __attribute__((ext_vector_type(4)));
-    auto s0b = [&](cf (&v)[E], cf (&tw1)[16]) {
+    auto s0b = [&](cf (&v)[E]) {
         F::template pass_butterflies<0>(v);
         wave_lds_fence();
         F::template pass_write<0, true>(v, xa, t, t);
         wave_lds_fence();
         F::template pass_readback<1>(v, xa, t);
-        if constexpr (FAST2) {                                          // pass 1's twiddles travel with its operands
+    };
+    // FAST2: pass 1's twiddles are requested at the end of the stage that precedes the s12 they are for (one set of
+    // registers serves both threads)
+    auto tw1_issue = [&](cf (&tw1)[16]) {
+        if constexpr (FAST2) {
             const f4* tl = reinterpret_cast<const f4*>(twlds + (t & 15) * ST_TW_STRIDE);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -290,10 +296,13 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         wave_lds_fence();
         F::template pass_write<2, true>(v, xa, t, t);
         wave_lds_fence();
+        // partners Z[NC - t - 64 p]: one address register, the rest are immediates (pad(a - c) = pad(a) - pad(c) for
+        // multiples of 16); lane 0's first partner is Z[0] itself (its read lands one slot past the area and is dropped)
+        const cf* const pb = xa + lds_pad(NC - t);
 #pragma unroll
         for (int p = 0; p < F::NPAIR; ++p) {
-            const int kk = t + p * F::LPF;
-            zm[p] = (p == 0) ? F::r2c_partner(xa, kk, v[F::reg_of_spectrum(0)]) : xa[lds_pad(NC - kk)];
+            const cf z = pb[-lds_pad_c(p * F::LPF)];
+            zm[p] = (p == 0 && t == 0) ? v[F::reg_of_spectrum(0)] : z;
         }
         zmid = xa[lds_pad(NC / 2)];
     };
@@ -303,12 +312,10 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
 #pragma unroll
         for (int p = 0; p < F::NPAIR; ++p) {
             const int kk = t + p * F::LPF;
-            cf xk, xm;
-            if constexpr (FULLPTW) F::r2c_split_x2(v[F::reg_of_spectrum(p)], zm[p], ptw[p], xk, xm);
-            else F::r2c_split_factored_x2(v[F::reg_of_spectrum(p)], zm[p], w0, p, xk, xm);
-            const float pa = cnorm2(xk), pb = cnorm2(xm);
-            prow[kk] = POW2 ? pa : __builtin_amdgcn_sqrtf(pa);
-            prow[NC - kk] = POW2 ? pb : __builtin_amdgcn_sqrtf(pb);
+            const cf pw = FULLPTW ? F::r2c_power_x2(v[F::reg_of_spectrum(p)], zm[p], ptw[p])
+                                  : F::r2c_power_factored_x2(v[F::reg_of_spectrum(p)], zm[p], w0, p);
+            prow[kk] = POW2 ? pw.x : __builtin_amdgcn_sqrtf(pw.x);
+            prow[NC - kk] = POW2 ? pw.y : __builtin_amdgcn_sqrtf(pw.y);
         }
         if (t == 0) {
             const float pm = 4.0f * cnorm2(zmid);                       // X[NC/2] = conj(Z[NC/2]); Z carries the 0.5
@@ -343,19 +350,18 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     };
     const bool fast_db = m.amin >= 1.1754944e-38f;                      // (uniform) hardware log2 unless the clamp admits denormals
     const float ten_log10_ref = 10.0f * m.log10_ref;
-    auto s4_fast = [&](const float* prow, int i, const f4 (&cw)[ST_RIDE], const f4 (&cp)[ST_RIDE]) {
+    // `after_ride` runs once the ride-along steps are consumed (their registers are free again): the paired rotation
+    // issues the other thread's ride-along reads there.  The first batch of the rest is requested before the ride-along
+    // steps are consumed, so its round trip overlaps their FMAs.
+    auto s4_fast = [&](const float* prow, int i, const f4 (&cw)[ST_RIDE], const f4 (&cp)[ST_RIDE], auto&& after_ride) {
         i = i < nloc ? i : nloc - 1;
         constexpr int REST = ST_FAST_STEPS1 - TAC_ST_RIDE1;
+        constexpr int NB = (REST + TAC_ST_BATCH - 1) / TAC_ST_BATCH;
         const f4* wp = reinterpret_cast<const f4*>(wlds) + lane + ST_RIDE * 64;
         const f4* p1 = reinterpret_cast<const f4*>(prow + lo_s[1]) + TAC_ST_RIDE1;
         cf a0 = mkc(0.f, 0.f), a1 = mkc(0.f, 0.f), b0 = mkc(0.f, 0.f), b1 = mkc(0.f, 0.f);
-#pragma unroll
-        for (int u = 0; u < ST_FAST_STEPS0; ++u) fma4(cw[u], cp[u], a0, a1);
-#pragma unroll
-        for (int u = 0; u < TAC_ST_RIDE1; ++u) fma4(cw[ST_FAST_STEPS0 + u], cp[ST_FAST_STEPS0 + u], b0, b1);
-#pragma unroll
-        for (int c0 = 0; c0 < REST; c0 += TAC_ST_BATCH) {               // the remaining steps of slot 1, TAC_ST_BATCH per round trip
-            f4 w2[TAC_ST_BATCH], q2[TAC_ST_BATCH];
+        f4 w2[TAC_ST_BATCH], q2[TAC_ST_BATCH];
+        auto issue_batch = [&](int c0) {
 #pragma unroll
             for (int u = 0; u < TAC_ST_BATCH; ++u) {
                 if (c0 + u < REST) {
@@ -363,9 +369,26 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
                     q2[u] = p1[c0 + u];
                 }
             }
+        };
+        if constexpr (NB > 0) issue_batch(0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < ST_FAST_STEPS0; ++u) fma4(cw[u], cp[u], a0, a1);
+#pragma unroll
+        for (int u = 0; u < TAC_ST_RIDE1; ++u) fma4(cw[ST_FAST_STEPS0 + u], cp[ST_FAST_STEPS0 + u], b0, b1);
+        // the FMAs above must really be done (their operands' registers free) before after_ride's reads are issued:
+        // sched_barrier orders machine instructions only, LLVM's IR passes would sink the FMAs below the reads
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1) : : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        after_ride();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {                                  // the remaining steps of slot 1, TAC_ST_BATCH per round trip
 #pragma unroll
             for (int u = 0; u < TAC_ST_BATCH; ++u)
-                if (c0 + u < REST) fma4(w2[u], q2[u], b0, b1);
+                if (c * TAC_ST_BATCH + u < REST) fma4(w2[u], q2[u], b0, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 < NB) issue_batch((c + 1) * TAC_ST_BATCH);
             __builtin_amdgcn_sched_barrier(0);
         }
         float v0 = (a0.x + a0.y) + (a1.x + a1.y), v1 = (b0.x + b0.y) + (b1.x + b1.y);
@@ -418,10 +441,11 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     };
 
     // First frames of thread A: 2w, of thread B: 2w + 1, then whatever the counter hands out.  Rotation of one iteration:
-    //   A.s0 | B.s3 + request | A.s12 | B.s4 | A.s3 + request | B.s0 | A.s4 | B.s12
-    // (FAST2: s3 ends by issuing the first contraction reads instead, and the request follows s4)
-    // where B's s3 / s4 finish its frame n and its s0 / s12 start frame n + 1 (B's first frame is brought to that point
-    // before the loop).  A thread's next samples are requested as soon as its registers are free (after s3).  No branch
+    //   A.s0 | B.s12 | A.s12 | B.s3 + request | A.s3 + request | B.s4 | A.s4 | B.s0
+    // so every stage's LDS round trip was issued one other-thread stage earlier, and the FFT stages (the register peak)
+    // never run while contraction reads are in flight.  FAST2: B.s3 ends by issuing B's first contraction reads (they
+    // ride along with A.s3), B.s4 consumes them and then issues A's (which ride along with the rest of B.s4); the sample
+    // request follows s4.  B's first frame is brought to the point behind s0 before the loop.  No branch
     // inside the loop: a wave stops when neither of its threads holds a frame of the range; a thread without one
     // recomputes the last frame (request clamps) and stores identical values.
     if (nloc > 0) {
@@ -429,21 +453,28 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         long long frA, frB;
         int iA = 2 * w, iB = 2 * w + 1, nA = 0, nB = 0;
         unsigned askA = 0, askB = 0;
-        cf tw1A[16], tw1B[16];
+        cf tw1[16];
         f4 cwA[ST_RIDE], cpA[ST_RIDE], cwB[ST_RIDE], cpB[ST_RIDE];
         request(vB, iB, modeB, rowB_, frB);
         request(vA, iA, modeA, rowA_, frA);
         s0(vB, modeB, rowB_, frB);
-        s0b(vB, tw1B);
-        s12(vB, zmB, zmidB, tw1B);
+        s0b(vB);
         __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0): the loop is entered with nothing in flight
         ST_MARK(6);
 #pragma unroll 1
         while (iA < nloc || iB < nloc) {
             s0(vA, modeA, rowA_, frA);
-            s0b(vA, tw1A);
+            s0b(vA);
+            tw1_issue(tw1);
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(1);
+            s12(vB, zmB, zmidB, tw1);
+            tw1_issue(tw1);
+            __builtin_amdgcn_sched_barrier(0);
+            ST_MARK(2);
+            s12(vA, zmA, zmidA, tw1);
+            __builtin_amdgcn_sched_barrier(0);
+            ST_MARK(2);
             s3(vB, zmB, zmidB, rowB);
             if constexpr (FAST2) {
                 s3_issue(rowB, cwB, cpB);
@@ -454,11 +485,18 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             }
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(4);
-            s12(vA, zmA, zmidA, tw1A);
+            s3(vA, zmA, zmidA, rowA);
+            if constexpr (!FAST2) {
+                nA = grab();
+                request(vA, nA, modeA, rowA_, frA);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            ST_MARK(2);
+            ST_MARK(4);
             if constexpr (FAST2) {
-                s4_fast(rowB, iB, cwB, cpB);
+                s4_fast(rowB, iB, cwB, cpB, [&]() {
+                    s3_issue(rowA, cwA, cpA);
+                    askA = grab_ask();
+                });
                 iB = (int)__builtin_amdgcn_readfirstlane(askB);
                 request(vB, iB, modeB, rowB_, frB);                     // the contraction used the frame's registers until here
             } else {
@@ -467,22 +505,8 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             }
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(5);
-            s3(vA, zmA, zmidA, rowA);
             if constexpr (FAST2) {
-                s3_issue(rowA, cwA, cpA);
-                askA = grab_ask();
-            } else {
-                nA = grab();
-                request(vA, nA, modeA, rowA_, frA);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            ST_MARK(4);
-            s0(vB, modeB, rowB_, frB);
-            s0b(vB, tw1B);
-            __builtin_amdgcn_sched_barrier(0);
-            ST_MARK(1);
-            if constexpr (FAST2) {
-                s4_fast(rowA, iA, cwA, cpA);
+                s4_fast(rowA, iA, cwA, cpA, []() {});
                 iA = (int)__builtin_amdgcn_readfirstlane(askA);
                 request(vA, iA, modeA, rowA_, frA);
             } else {
@@ -491,9 +515,10 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             }
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(5);
-            s12(vB, zmB, zmidB, tw1B);
+            s0(vB, modeB, rowB_, frB);
+            s0b(vB);
             __builtin_amdgcn_sched_barrier(0);
-            ST_MARK(2);
+            ST_MARK(1);
 #if TAC_ST_TIMING
             tstamp[7] += 2.0f;
 #endif

@@ -12,6 +12,12 @@
 #define TAC_ABL 0      // ablation builds only (tools): 1 = no global loads, 2 = no stores, 3 = no FFT passes
 #endif
 
+#ifndef TAC_STFT_STREAM
+#define TAC_STFT_STREAM 0
+#endif
+#if TAC_STFT_STREAM
+#include "stft_stream.hpp"
+#endif
 #ifndef TAC_STFT_OCC
 #define TAC_STFT_OCC 2      // waves per SIMD the generic kernel is compiled for (A/B knob; 3 drops the hoisted twiddles)
 #endif
@@ -134,7 +140,10 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
                 // ds_read_b128 -> global_store_dwordx4, ~8 store instructions per frame instead of 34 narrow ones
                 // (the narrow stores were issue-bound: 0.22 of 0.44 ms at cfg-2).  The staging origin is shifted
                 // by the rows' misalignment so LDS and global addresses share their 16-byte phase.
-                constexpr int LENF = (MODE == 0 ? 2 : 1) * (NC + 1);
+            #ifndef TAC_PIPE_ABL_ALIGNED
+#define TAC_PIPE_ABL_ALIGNED 0   // ablation builds only (wrong results): rows of NC instead of NC + 1 elements, i.e. 128-byte aligned
+#endif
+    constexpr int LENF = (MODE == 0 ? 2 : 1) * (NC + (TAC_PIPE_ABL_ALIGNED ? 0 : 1));
                 const long long g0 = ((long long)urow * g.n_frames + uframe0) * LENF;
                 const int a = (int)(g0 & 3);
                 float* stage = reinterpret_cast<float*>(lds[0]) + a;
@@ -329,7 +338,10 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
     const int chunk = (total + (int)gridDim.x - 1) / (int)gridDim.x;
     const int begin = (int)blockIdx.x * chunk;
     const int end = begin + chunk < total ? begin + chunk : total;
-    constexpr int LENF = (MODE == 0 ? 2 : 1) * (NC + 1);
+#ifndef TAC_PIPE_ABL_ALIGNED
+#define TAC_PIPE_ABL_ALIGNED 0   // ablation builds only (wrong results): rows of NC instead of NC + 1 elements, i.e. 128-byte aligned
+#endif
+    constexpr int LENF = (MODE == 0 ? 2 : 1) * (NC + (TAC_PIPE_ABL_ALIGNED ? 0 : 1));
     constexpr int NST = ((LENF >> 2) + 63) / 64;          // 16-byte wave-stores per output row
     const float hscale = 0.5f * g.scale;                  // the R2C split returns 2·X
 
@@ -614,6 +626,17 @@ static int launch_stft(const FrameGeom& g, const Tables& tb, const StftEpilogue&
             else if (ep.power == 2.0f) pmode = ep.db ? 3 : 1;
             else if (ep.power == 1.0f) pmode = ep.db ? 4 : 2;
         }
+#if TAC_STFT_STREAM
+        if (g.length >= 2 * NC) {
+            switch (pmode) {
+                case 1: return launch_stft_stream<NC, E, 1>(g, tb, ep, stream);
+                case 2: return launch_stft_stream<NC, E, 2>(g, tb, ep, stream);
+                case 3: return launch_stft_stream<NC, E, 3>(g, tb, ep, stream);
+                case 4: return launch_stft_stream<NC, E, 4>(g, tb, ep, stream);
+                default: break;
+            }
+        }
+#endif
         switch (pmode) {
             case 0: return launch_pipe<NC, E, 0>(g, tb, ep, groups, stream);
             case 1: return launch_pipe<NC, E, 1>(g, tb, ep, groups, stream);
