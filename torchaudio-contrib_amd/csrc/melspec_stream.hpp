@@ -40,6 +40,9 @@ constexpr int ST_FAST_STEPS0 = 4, ST_FAST_STEPS1 = 16;   // slot lengths of the 
 #ifndef TAC_ST_FULLPTW
 #define TAC_ST_FULLPTW 1     // A/B: 1 = all eight R2C twiddles in registers instead of one register x compile-time constants
 #endif
+#ifndef TAC_ST_EARLYREQ
+#define TAC_ST_EARLYREQ 0    // FAST2: 1 = a thread's next samples are requested right behind its s3 (three stages ahead), 0 = behind its s4 (one); measured 0.1376 vs 0.1354 ms: the registers it takes from the ride-along reads cost more
+#endif
 #ifndef TAC_ST_BATCH
 #define TAC_ST_BATCH 5       // steps per round trip of the rest of slot 1 (a batch that no longer fits the registers spills: 8 + 6 -> 0.156 ms)
 #endif
@@ -453,6 +456,7 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         long long frA, frB;
         int iA = 2 * w, iB = 2 * w + 1, nA = 0, nB = 0;
         unsigned askA = 0, askB = 0;
+        constexpr bool EARLY = FAST2 && TAC_ST_EARLYREQ != 0;
         cf tw1[16];
         f4 cwA[ST_RIDE], cpA[ST_RIDE], cwB[ST_RIDE], cpB[ST_RIDE];
         request(vB, iB, modeB, rowB_, frB);
@@ -470,35 +474,41 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             ST_MARK(1);
             s12(vB, zmB, zmidB, tw1);
             tw1_issue(tw1);
+            if constexpr (EARLY) askB = grab_ask();
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(2);
             s12(vA, zmA, zmidA, tw1);
+            if constexpr (EARLY) askA = grab_ask();
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(2);
             s3(vB, zmB, zmidB, rowB);
             if constexpr (FAST2) {
                 s3_issue(rowB, cwB, cpB);
-                askB = grab_ask();
+                if constexpr (!EARLY) askB = grab_ask();
             } else {
                 nB = grab();
-                request(vB, nB, modeB, rowB_, frB);
             }
+            if constexpr (EARLY) nB = (int)__builtin_amdgcn_readfirstlane(askB);
+            if constexpr (EARLY || !FAST2) request(vB, nB, modeB, rowB_, frB);
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(4);
             s3(vA, zmA, zmidA, rowA);
-            if constexpr (!FAST2) {
-                nA = grab();
-                request(vA, nA, modeA, rowA_, frA);
-            }
+            if constexpr (!FAST2) nA = grab();
+            if constexpr (EARLY) nA = (int)__builtin_amdgcn_readfirstlane(askA);
+            if constexpr (EARLY || !FAST2) request(vA, nA, modeA, rowA_, frA);
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(4);
             if constexpr (FAST2) {
                 s4_fast(rowB, iB, cwB, cpB, [&]() {
                     s3_issue(rowA, cwA, cpA);
-                    askA = grab_ask();
+                    if constexpr (!EARLY) askA = grab_ask();
                 });
-                iB = (int)__builtin_amdgcn_readfirstlane(askB);
-                request(vB, iB, modeB, rowB_, frB);                     // the contraction used the frame's registers until here
+                if constexpr (EARLY) {
+                    iB = nB;
+                } else {
+                    iB = (int)__builtin_amdgcn_readfirstlane(askB);
+                    request(vB, iB, modeB, rowB_, frB);                 // the contraction used the frame's registers until here
+                }
             } else {
                 s4(rowB, iB);
                 iB = nB;
@@ -507,8 +517,12 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             ST_MARK(5);
             if constexpr (FAST2) {
                 s4_fast(rowA, iA, cwA, cpA, []() {});
-                iA = (int)__builtin_amdgcn_readfirstlane(askA);
-                request(vA, iA, modeA, rowA_, frA);
+                if constexpr (EARLY) {
+                    iA = nA;
+                } else {
+                    iA = (int)__builtin_amdgcn_readfirstlane(askA);
+                    request(vA, iA, modeA, rowA_, frA);
+                }
             } else {
                 s4(rowA, iA);
                 iA = nA;

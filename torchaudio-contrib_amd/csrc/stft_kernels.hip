@@ -53,8 +53,8 @@ __device__ __noinline__ void finish_power_row(const float* prow, float* obase, i
 
 // NF frames per wave can be advanced together (see WaveFft::run); with the inter-pass and R2C twiddles held
 // in registers the kernel sits at 2 waves/SIMD.  NF = 1 is what ships (see launch_stft).
-template <int NC, int E, int MODE, int NF, bool HOIST>
-__global__ void __launch_bounds__(STFT_WAVES * 64, TAC_STFT_OCC)
+template <int NC, int E, int MODE, int NF, bool HOIST, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, TAC_STFT_OCC)
 stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
     using F = WaveFft<NC, E>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -92,8 +92,19 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 #if TAC_STFT_TIMING
     st.init();
 #endif
-    for (int unit = begin + w; unit < end; unit += STFT_WAVES) {
+    // units are taken from a workgroup counter (behind the wave slots), not dealt out in fixed strides: the older of two
+    // waves that share a SIMD wins the issue arbitration and would finish its share long before the other
+    unsigned* const next_unit = reinterpret_cast<unsigned*>(smem + WAVES * WAVE_SLOTS);
+    if (threadIdx.x == 0) *next_unit = (unsigned)(begin + WAVES);
+    __syncthreads();
+    for (int unit = begin + w; unit < end;) {
         st.mark(0);                                         // loop overhead + previous iteration's store issue
+        int nxt_unit;
+        {
+            unsigned nv = 0;
+            if (lane == 0) nv = __hip_atomic_fetch_add(next_unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            nxt_unit = (int)__builtin_amdgcn_readfirstlane(nv);
+        }
         const int urow = unit / units_per_row;
         const long long uframe0 = (long long)(unit - urow * units_per_row) * FPU;
         cf v[NF][E];
@@ -274,11 +285,12 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
         }
         wave_lds_fence();   // next iteration's first-pass writes must follow these reads
         st.mark(11);                                        // output row streamed out (store issue)
+        unit = nxt_unit;
     }
 #if TAC_STFT_TIMING
     __syncthreads();
     if (lane == 0)
-        for (int i = 0; i < 12; ++i) ep.out[((long long)blockIdx.x * STFT_WAVES + w) * 16 + i] = st.acc[i];
+        for (int i = 0; i < 12; ++i) ep.out[((long long)blockIdx.x * WAVES + w) * 16 + i] = st.acc[i];
 #endif
 }
 
@@ -646,19 +658,30 @@ static int launch_stft(const FrameGeom& g, const Tables& tb, const StftEpilogue&
             default: break;
         }
     }
-    const size_t lds_bytes = (size_t)STFT_WAVES * (((NF * F::G * F::PADDED + 1) / 2) * 2) * sizeof(cf);
-    int per_cu = (int)(160 * 1024 / lds_bytes);
-    if (per_cu > TAC_STFT_OCC) per_cu = TAC_STFT_OCC;        // 256-register waves: two 4-wave workgroups fill a CU
+    // 256-register waves: eight waves fill a CU.  One 8-wave workgroup per CU (both waves of a SIMD draw units from the
+    // same counter) where its frame buffers fit the LDS and there is that much work, 4-wave workgroups otherwise.
+    constexpr size_t wave_bytes = (size_t)(((NF * F::G * F::PADDED + 1) / 2) * 2) * sizeof(cf);
+    constexpr bool WIDE_FITS = 2 * STFT_WAVES * wave_bytes + 16 <= 160 * 1024 && TAC_STFT_OCC == 2;
+    const bool wide = WIDE_FITS && groups >= 2LL * STFT_WAVES * device_cu_count();
+    const int waves = wide ? 2 * STFT_WAVES : STFT_WAVES;
+    const size_t lds_bytes = (size_t)waves * wave_bytes + 16;
+    int per_cu = wide ? 1 : (int)(160 * 1024 / lds_bytes);
+    if (per_cu > TAC_STFT_OCC) per_cu = TAC_STFT_OCC;
     if (per_cu < 1) per_cu = 1;
     long long max_blocks = (long long)device_cu_count() * per_cu;
-    long long want = (groups + STFT_WAVES - 1) / STFT_WAVES;
+    long long want = (groups + waves - 1) / waves;
     long long blocks = want < max_blocks ? want : max_blocks;
     if (blocks < 1) blocks = 1;
-    auto kern = stft_kernel<NC, E, MODE, NF, HOIST>;
-    if (lds_bytes > 64 * 1024) TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds_bytes));
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(STFT_WAVES * 64), lds_bytes, stream, g, tb, ep);
-    TAC_HIP(hipGetLastError());
-    return TAC_OK;
+    auto launch = [&](auto kern) {
+        if (lds_bytes > 64 * 1024) TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds_bytes));
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(waves * 64), lds_bytes, stream, g, tb, ep);
+        TAC_HIP(hipGetLastError());
+        return (int)TAC_OK;
+    };
+    if constexpr (WIDE_FITS) {
+        if (wide) return launch(stft_kernel<NC, E, MODE, NF, HOIST, 2 * STFT_WAVES>);
+    }
+    return launch(stft_kernel<NC, E, MODE, NF, HOIST, STFT_WAVES>);
 }
 
 #ifndef TAC_N4096_TWO_HALF

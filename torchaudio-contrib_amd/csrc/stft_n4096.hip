@@ -13,12 +13,13 @@
 // lane register times compile-time constants: W_2048^k = W_2048^t·W_32^i, W_4096^k = W_4096^t·W_64^i.
 // One 16-byte load per lane fetches z[2m] and z[2m+1] together, so a frame is 16 dwordx4 requests; they are issued
 // one frame ahead, before the previous frame's (nontemporal, unconditional) row stores — the stft_pipe_kernel
-// recipe.  Two frame buffers per wave: 3-wave workgroups, two per CU.
+// recipe.  Two frame buffers per wave: one 8-wave workgroup per CU (157 KB of LDS with the shared window table; round 1's
+// two 3-wave workgroups left two SIMDs with a single wave), frames drawn from a workgroup counter.
 #include "host_common.hpp"
 
 namespace tac {
 
-constexpr int N4K_WAVES = 3;
+constexpr int N4K_WAVES = 8;
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 // multiply by W_64^i = exp(-2*pi*i*i/64), 0 <= i < 16 (compile-time after unrolling)
@@ -87,6 +88,15 @@ stft_n4096_kernel(FrameGeom g, Tables tb1k, Tables tb4k, StftEpilogue ep) {
         }
         return ok;
     };
+    // frames are taken from a workgroup counter, not dealt out in fixed strides (the older of the two waves of a SIMD
+    // wins the issue arbitration and would finish a fixed share long before the other)
+    unsigned* const next_unit = reinterpret_cast<unsigned*>(wl4 + 64 * WROW);
+    if (threadIdx.x == 0) *next_unit = (unsigned)(begin + N4K_WAVES);
+    auto grab = [&]() -> int {
+        unsigned v = 0;
+        if (t == 0) v = __hip_atomic_fetch_add(next_unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return (int)__builtin_amdgcn_readfirstlane(v);
+    };
     bool pre = false;
     int unit = begin + w;
     if (unit < end) pre = prefetch(unit);
@@ -94,7 +104,8 @@ stft_n4096_kernel(FrameGeom g, Tables tb1k, Tables tb4k, StftEpilogue ep) {
     __syncthreads();
 
     NoStamp st;
-    for (; unit < end; unit += N4K_WAVES) {
+    while (unit < end) {
+        const int nxt = grab();
         const int urow = unit / T;
         const int uframe = unit - urow * T;
         cf va[1][E], vb[1][E];
@@ -142,7 +153,6 @@ stft_n4096_kernel(FrameGeom g, Tables tb1k, Tables tb4k, StftEpilogue ep) {
         // request the next frame now: it lands while this frame is combined, split, staged and stored
         __builtin_amdgcn_sched_barrier(0);
         {
-            const int nxt = unit + N4K_WAVES;
             pre = false;
             if (nxt < end) pre = prefetch(nxt);
         }
@@ -210,6 +220,7 @@ stft_n4096_kernel(FrameGeom g, Tables tb1k, Tables tb4k, StftEpilogue ep) {
             gdst[ti] = stage[ti];
         }
         wave_lds_fence();   // next iteration's first-pass writes must follow these reads
+        unit = nxt;
     }
 }
 
@@ -220,9 +231,9 @@ static int launch_n4096(const FrameGeom& g, const Tables& tb1k, const Tables& tb
     const long long units = g.rows * g.n_frames;
     if (units >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
     constexpr int WS = ((F::PADDED + 1) / 2) * 2;
-    const size_t bytes = (size_t)N4K_WAVES * 2 * WS * sizeof(cf) + (size_t)64 * 17 * sizeof(f4);
+    const size_t bytes = (size_t)N4K_WAVES * 2 * WS * sizeof(cf) + (size_t)64 * 17 * sizeof(f4) + 16;
     long long blocks = (units + N4K_WAVES - 1) / N4K_WAVES;
-    const long long cap = (long long)device_cu_count() * 2;
+    const long long cap = (long long)device_cu_count();      // one 8-wave workgroup per CU (157 KB of LDS)
     if (blocks > cap) blocks = cap;
     auto kern = stft_n4096_kernel<MODE>;
     TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes));
