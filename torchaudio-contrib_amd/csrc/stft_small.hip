@@ -11,7 +11,7 @@
 
 namespace tac {
 
-constexpr int SM_WAVES = 4;
+constexpr int SM_WAVES = 8;    // one workgroup per CU; its waves draw units from a workgroup counter (see stft_pipe_kernel)
 typedef float sm_f4 __attribute__((ext_vector_type(4)));
 
 template <int NC, int MODE>
@@ -65,6 +65,13 @@ stft_small_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
         }
         return all_ok;
     };
+    unsigned* const next_unit = reinterpret_cast<unsigned*>(wlds + LPF * WROW);
+    if (threadIdx.x == 0) *next_unit = (unsigned)(begin + SM_WAVES);
+    auto grab = [&]() -> int {
+        unsigned v = 0;
+        if (lane == 0) v = __hip_atomic_fetch_add(next_unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return (int)__builtin_amdgcn_readfirstlane(v);
+    };
     bool pre = false;
     int unit = begin + w;
     if (unit < end) pre = prefetch(unit);
@@ -72,7 +79,8 @@ stft_small_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
     __syncthreads();
 
     NoStamp st;
-    for (; unit < end; unit += SM_WAVES) {
+    while (unit < end) {
+        const int nxt = grab();
         const int urow = unit / upr;
         const int uframe0 = (unit - urow * upr) * G;
         cf v[1][E];
@@ -94,7 +102,6 @@ stft_small_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 
         __builtin_amdgcn_sched_barrier(0);
         {
-            const int nxt = unit + SM_WAVES;
             pre = false;
             if (nxt < end) pre = prefetch(nxt);
         }
@@ -160,6 +167,7 @@ stft_small_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
             gdst[ti] = stage[ti];
         }
         wave_lds_fence();   // next iteration's first-pass writes must follow these reads
+        unit = nxt;
     }
 }
 
@@ -169,11 +177,13 @@ static int launch_small(const FrameGeom& g, const Tables& tb, const StftEpilogue
     const long long units = g.rows * ((g.n_frames + F::G - 1) / F::G);
     if (units >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
     constexpr int WAVE_SLOTS = ((F::G * F::PADDED + 1) / 2) * 2;
-    const size_t bytes = (size_t)SM_WAVES * WAVE_SLOTS * sizeof(cf) + (size_t)F::LPF * 18 * sizeof(cf);
+    const size_t bytes = (size_t)SM_WAVES * WAVE_SLOTS * sizeof(cf) + (size_t)F::LPF * 18 * sizeof(cf) + 16;
     long long blocks = (units + SM_WAVES - 1) / SM_WAVES;
-    const long long cap = (long long)device_cu_count() * 2;
+    const long long cap = (long long)device_cu_count();
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL((stft_small_kernel<NC, MODE>), dim3((unsigned)blocks), dim3(SM_WAVES * 64), bytes, stream, g, tb, ep);
+    auto kern = stft_small_kernel<NC, MODE>;
+    if (bytes > 64 * 1024) TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SM_WAVES * 64), bytes, stream, g, tb, ep);
     TAC_HIP(hipGetLastError());
     return TAC_OK;
 }
