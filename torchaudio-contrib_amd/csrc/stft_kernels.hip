@@ -462,9 +462,14 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
                 const cf zk = v[0][F::reg_of_spectrum(i)];            // Z[k] never left this lane
                 const cf zm = (i == 0) ? F::r2c_partner(lds, k, zk) : lds[lds_pad(NC - k)];
 #endif
-                if constexpr (LEAN) F::r2c_split_factored_x2(zk, zm, ptw[0], i, xa[i], xb[i]);
-                else F::r2c_split_x2(zk, zm, ptw[i], xa[i], xb[i]);
-                xa[i] = cscale(xa[i], hscale); xb[i] = cscale(xb[i], hscale);
+                if constexpr (MODE != 0) {                            // xa[i] = (|X[k]|^2, |X[NC-k]|^2), no spectra formed
+                    const cf pw = LEAN ? F::r2c_power_factored_x2(zk, zm, ptw[0], i) : F::r2c_power_x2(zk, zm, ptw[i]);
+                    xa[i] = cscale(pw, hscale * hscale);
+                } else {
+                    if constexpr (LEAN) F::r2c_split_factored_x2(zk, zm, ptw[0], i, xa[i], xb[i]);
+                    else F::r2c_split_x2(zk, zm, ptw[i], xa[i], xb[i]);
+                    xa[i] = cscale(xa[i], hscale); xb[i] = cscale(xb[i], hscale);
+                }
             }
             F::r2c_pair(lds, NC / 2, mkc(0.0f, -1.0f), xm, unused);
             xm = cscale(xm, hscale);
@@ -478,8 +483,8 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 #pragma unroll
                 for (int i = 0; i < F::NPAIR; ++i) {
                     const int k = t + i * F::LPF;
-                    orow[k] = cnorm2(xa[i]);
-                    orow[NC - k] = cnorm2(xb[i]);
+                    orow[k] = xa[i].x;
+                    orow[NC - k] = xa[i].y;
                 }
                 orow[NC / 2] = cnorm2(xm);                            // every lane holds the same value
                 st.mark(10);
@@ -494,8 +499,8 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
                     reinterpret_cast<cf*>(stage)[k] = xa[i];
                     reinterpret_cast<cf*>(stage)[NC - k] = xb[i];
                 } else {
-                    stage[k] = spectral_row_value<MODE>(cnorm2(xa[i]), ep);
-                    stage[NC - k] = spectral_row_value<MODE>(cnorm2(xb[i]), ep);
+                    stage[k] = spectral_row_value<MODE>(xa[i].x, ep);
+                    stage[NC - k] = spectral_row_value<MODE>(xa[i].y, ep);
                 }
             }
             if (t == 0) {

@@ -173,8 +173,12 @@ stft_n4096_kernel(FrameGeom g, Tables tb1k, Tables tb4k, StftEpilogue ep) {
                 const cf zp = cadd(am, cmul_conj(mul_w32(bm, 32 - i), w2k));             // Z[2048-k]
                 const cf ev = cadd_conj(zk, zp), d = csub_conj(zk, zp);
                 const cf twd = cmul_rot(w4k, mul_w64(d, i));
-                xa[i] = cscale(cadd(ev, twd), hscale);
-                xb[i] = cscale(csub_then_conj(ev, twd), hscale);
+                if constexpr (MODE != 0) {                            // xa[i] = (|X[k]|^2, |X[2048-k]|^2), no spectra formed
+                    xa[i] = cscale(power_pair(ev, twd), hscale * hscale);
+                } else {
+                    xa[i] = cscale(cadd(ev, twd), hscale);
+                    xb[i] = cscale(csub_then_conj(ev, twd), hscale);
+                }
             }
             const cf a0 = bufA[0], b0 = bufB[0];
             const cf xm = mkc((a0.x - b0.x) * g.scale, -(a0.y - b0.y) * g.scale);         // X[1024] = conj(A[0] - B[0])
@@ -186,8 +190,8 @@ stft_n4096_kernel(FrameGeom g, Tables tb1k, Tables tb4k, StftEpilogue ep) {
                     reinterpret_cast<cf*>(stage)[k] = xa[i];
                     reinterpret_cast<cf*>(stage)[2048 - k] = xb[i];
                 } else {
-                    stage[k] = spectral_row_value<MODE>(cnorm2(xa[i]), ep);
-                    stage[2048 - k] = spectral_row_value<MODE>(cnorm2(xb[i]), ep);
+                    stage[k] = spectral_row_value<MODE>(xa[i].x, ep);
+                    stage[2048 - k] = spectral_row_value<MODE>(xa[i].y, ep);
                 }
             }
             if (t == 0) {

@@ -118,8 +118,12 @@ stft_small_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
                 const int k = t + i * LPF;
                 const cf zk = v[0][F::reg_of_spectrum(i)];
                 const cf zm = (i == 0) ? F::r2c_partner(lds, k, zk) : lds[lds_pad(NC - k)];
-                F::r2c_split_x2(zk, zm, ptw[i], xa[i], xb[i]);
-                xa[i] = cscale(xa[i], hscale); xb[i] = cscale(xb[i], hscale);
+                if constexpr (MODE != 0) {                                // xa[i] = (|X[k]|^2, |X[NC-k]|^2), no spectra formed
+                    xa[i] = cscale(F::r2c_power_x2(zk, zm, ptw[i]), hscale * hscale);
+                } else {
+                    F::r2c_split_x2(zk, zm, ptw[i], xa[i], xb[i]);
+                    xa[i] = cscale(xa[i], hscale); xb[i] = cscale(xb[i], hscale);
+                }
             }
             F::r2c_pair(lds, NC / 2, mkc(0.0f, -1.0f), xm, unused);
             xm = cscale(xm, hscale);
@@ -131,8 +135,8 @@ stft_small_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
                     reinterpret_cast<cf*>(srow)[k] = xa[i];
                     reinterpret_cast<cf*>(srow)[NC - k] = xb[i];
                 } else {
-                    srow[k] = spectral_row_value<MODE>(cnorm2(xa[i]), ep);
-                    srow[NC - k] = spectral_row_value<MODE>(cnorm2(xb[i]), ep);
+                    srow[k] = spectral_row_value<MODE>(xa[i].x, ep);
+                    srow[NC - k] = spectral_row_value<MODE>(xa[i].y, ep);
                 }
             }
             if (t == 0) {
