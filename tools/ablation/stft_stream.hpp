@@ -8,7 +8,7 @@
 // (t + 64p ascending, NC - t - 64p descending), i.e. every store instruction is one contiguous 256-byte (512-byte for
 // complex rows) run — nontemporal, the rows are written once and never re-read.
 #pragma once
-#include "host_common.hpp"
+#include "../../torchaudio-contrib_amd/csrc/host_common.hpp"
 
 #include <type_traits>
 
@@ -45,6 +45,14 @@ stft_stream_kernel(FrameGeom g, Tables tb, StftEpilogue ep, long long total) {
 #pragma unroll
     for (int e = 0; e < E; ++e) win[e] = cscale(win[e], half);
 
+    unsigned* const next_frame = reinterpret_cast<unsigned*>(smem_raw + (size_t)SS_WAVES * XA_BYTES);
+    if (threadIdx.x == 0) *next_frame = SLOTS;                          // frames beyond the first SLOTS come from this counter
+    __syncthreads();
+    auto grab = [&]() -> int {
+        unsigned v = 0;
+        if (lane == 0) v = __hip_atomic_fetch_add(next_frame, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return (int)__builtin_amdgcn_readfirstlane(v);
+    };
     cf vA[E], vB[E];
     cf zmA[F::NPAIR], zmB[F::NPAIR], zmidA = mkc(0.f, 0.f), zmidB = mkc(0.f, 0.f);
 
@@ -128,7 +136,6 @@ stft_stream_kernel(FrameGeom g, Tables tb, StftEpilogue ep, long long total) {
 
     if (nloc > 0) {
         RowT rlo[F::NPAIR], rhi[F::NPAIR], rmid;
-        const int iters = (nloc + SLOTS - 1) / SLOTS;
         int modeA, rowA, modeB, rowB;
         long long frA, frB;
         int iA = 2 * w, iB = 2 * w + 1;
@@ -137,7 +144,7 @@ stft_stream_kernel(FrameGeom g, Tables tb, StftEpilogue ep, long long total) {
         s0(vB, modeB, rowB, frB);
         __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0): the loop is entered with nothing in flight
 #pragma unroll 1
-        for (int n = 0; n < iters; ++n) {
+        while (iA < nloc || iB < nloc) {
             s0(vA, modeA, rowA, frA);
             __builtin_amdgcn_sched_barrier(0);
             s12(vB, zmB, zmidB);
@@ -145,17 +152,19 @@ stft_stream_kernel(FrameGeom g, Tables tb, StftEpilogue ep, long long total) {
             s12(vA, zmA, zmidA);
             __builtin_amdgcn_sched_barrier(0);
             s3(vB, zmB, zmidB, rlo, rhi, rmid);
-            request(vB, iB + SLOTS, modeB, rowB, frB);
+            const int nB = grab();
+            request(vB, nB, modeB, rowB, frB);
             store_rows(rlo, rhi, rmid, iB);
+            iB = nB;
             __builtin_amdgcn_sched_barrier(0);
             s3(vA, zmA, zmidA, rlo, rhi, rmid);
-            request(vA, iA + SLOTS, modeA, rowA, frA);
+            const int nA = grab();
+            request(vA, nA, modeA, rowA, frA);
             store_rows(rlo, rhi, rmid, iA);
+            iA = nA;
             __builtin_amdgcn_sched_barrier(0);
             s0(vB, modeB, rowB, frB);
             __builtin_amdgcn_sched_barrier(0);
-            iA += SLOTS;
-            iB += SLOTS;
         }
     }
 }
@@ -165,7 +174,7 @@ static int launch_stft_stream(const FrameGeom& g, const Tables& tb, const StftEp
     using F = WaveFft<NC, E>;
     const long long total = g.rows * g.n_frames;
     if (total >= 0x7fffffffLL || g.length < 2 * NC) return TAC_E_UNSUPPORTED;
-    const size_t lds_bytes = (size_t)SS_WAVES * ((F::PADDED * sizeof(cf) + 15) & ~(size_t)15);
+    const size_t lds_bytes = (size_t)SS_WAVES * ((F::PADDED * sizeof(cf) + 15) & ~(size_t)15) + 16;
     long long blocks = (total + 2 * SS_WAVES - 1) / (2 * SS_WAVES);
     if (blocks > device_cu_count()) blocks = device_cu_count();
     if (blocks < 1) blocks = 1;

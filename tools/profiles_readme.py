@@ -68,6 +68,17 @@ fm = bench.get('stages', {}).get('filterbank_mfma_dense')
 if fm:
     out.append('Filterbank stage as a dense fp32 MFMA GEMM (`gemm_fb_kernel`, random 1025 x 128 bank, cfg-2 power spectrogram): '
                '%.4f ms = %.1f TFLOP/s = %.0f %% of the 157.3 TFLOP/s f32 MFMA peak.' % (fm['kernel_ms_mean'], fm['achieved_TFLOPs'], 100 * fm['frac_of_f32_mfma_peak']))
+pf = os.path.join(d, 'pmc_fb.json')
+if os.path.exists(pf):
+    for name, c in json.load(open(pf)).items():
+        if 'gemm_fb_kernel' in name and c.get('SQ_INSTS_VALU_MFMA_F32'):
+            out.append('Matrix-core counters of that GEMM (`pmc_fb.json`, per launch): SQ_INSTS_VALU_MFMA_F32 = %.2f M '
+                       '(v_mfma_f32_32x32x2_f32, %.1f %% of its %.2f M VALU instructions), SQ_VALU_MFMA_BUSY_CYCLES / '
+                       '(4 SIMDs x SQ_BUSY_CU_CYCLES) = %.0f %% matrix-pipe utilisation.  The kernels of the measured hot path '
+                       'issue no MFMA (SQ_INSTS_VALU_MFMA_F32 = 0 in `pmc_mel.json`): the band-sparse contraction is 2 050 '
+                       'MACs per frame on the packed-f32 VALU; DESIGN.md §3.3 has the A/B against the MFMA form.'
+                       % (c['SQ_INSTS_VALU_MFMA_F32'] / 1e6, 100 * c['SQ_INSTS_VALU_MFMA_F32'] / c['SQ_INSTS_VALU'],
+                          c['SQ_INSTS_VALU'] / 1e6, 100 * c['SQ_VALU_MFMA_BUSY_CYCLES'] / (4 * c['SQ_BUSY_CU_CYCLES'])))
 out.append('')
 out.append('Counters per launch (per frame = / 80 128):')
 out.append('')
@@ -98,11 +109,22 @@ if all('SQ_WAIT_INST_ANY' in c for _, _, _, _, _, _, c in rows if c):
                       100 * c['SQ_ACTIVE_INST_ANY'] / wc, 100 * c['SQ_ACTIVE_INST_VALU'] / wc,
                       100 * c['SQ_ACTIVE_INST_LDS'] / wc, 100 * c['SQ_ACTIVE_INST_SCA'] / wc))
     out.append('')
-out.append('All three kernels run 2 waves/SIMD (8 waves per CU), no scratch.  The fused kernel writes nothing but the mel-dB '
-           'tensor; its fabric-side traffic is above the algorithmic bytes (the L2 misses part of the 4x frame overlap now that a '
-           'workgroup\'s 16 frames in flight are requested a whole frame ahead, and its 4-byte-per-lane row stores are counted '
-           'differently from round 1\'s 16-byte ones) — still 5x below what would make it HBM-bound.  '
+out.append('All three kernels run 2 waves/SIMD (one 8-wave workgroup per CU whose waves draw frames from a workgroup '
+           'counter), no scratch.  HBM traffic equals the algorithmic bytes to within 0.5 %: nothing is re-read, the fused '
+           'kernel is bound by its VALU + LDS instruction streams (stall table above), not by memory.  '
            'DESIGN.md §3.2/§3.3 hold the stage-stamp breakdowns, the ablations and the list of variants measured not to help.')
+pb = os.path.join(d, 'kernel_stats_backward.csv')
+if os.path.exists(pb):
+    out.append('')
+    out.append('`kernel_stats_backward.csv` — `rocprofv3 --kernel-trace --stats -- python tools/prof_driver.py grad 5`: one '
+               'forward + backward of `Melspectrogram -> AmplitudeToDb` at cfg-2 with `requires_grad` on the waveform (the '
+               'unfused forward that autograd needs, then the gradient kernels):')
+    out.append('')
+    out.append('| kernel | calls | average |')
+    out.append('|---|---|---|')
+    for r in csv.DictReader(open(pb)):
+        if 'tac::' in r['Name']:
+            out.append('| `%s` | %s | %.4f ms |' % (r['Name'].split('(')[0].replace('void ', ''), r['Calls'], float(r['AverageNs']) / 1e6))
 out.append('')
 out.append('Micro-benchmarks behind the design decisions (sources in `tools/ubench/`, outputs quoted in DESIGN.md): '
            '`valu_rate` (scalar vs packed f32 issue rates), `lds_rate` (LDS access shapes at 8 waves/CU), `hbm_rate` '

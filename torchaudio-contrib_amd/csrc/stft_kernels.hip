@@ -16,7 +16,7 @@
 #define TAC_STFT_STREAM 0
 #endif
 #if TAC_STFT_STREAM
-#include "stft_stream.hpp"
+#include "../../tools/ablation/stft_stream.hpp"   // parked variant, not built by default
 #endif
 #ifndef TAC_STFT_OCC
 #define TAC_STFT_OCC 2      // waves per SIMD the generic kernel is compiled for (A/B knob; 3 drops the hoisted twiddles)
