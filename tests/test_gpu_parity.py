@@ -1023,3 +1023,58 @@ def test_state_dict_and_buffers_follow_device(tac):
     assert list(m.state_dict().keys()) == []
     assert m[0].window.is_cuda and m[2].filterbank.is_cuda
     assert list(m.parameters()) == []
+
+
+def test_fft_length_400_kernel(tac, golden):
+    """fft_length 400 (25 ms at 16 kHz) runs on its own mixed-radix kernel (csrc/stft_n400.hip, 200 = 8 x 25: a
+    25-point transform per lane in registers, the 8-point one across lanes through DPP): complex rows, |X|, |X|^2 and
+    their dB forms against the float64 restatement and the reference's golden vector; every pad mode, short / centred
+    windows, odd lengths and strides (the sample-by-sample path), rows shorter than a unit; the forms the kernel does
+    not have (two-sided, |X|^p) still take the DFT-matrix route."""
+    base = signals.audio_like((1, 2, 20000), seed=4)
+    before = launches(tac)
+    z = tac.stft(dev(base[..., :6000]), 400, hop_length=160)
+    assert launched_since(tac, before) == {'tac_stft_f32': 1}
+    want = golden('g4_variants')['n400_h160']
+    assert tuple(z.shape) == want.shape
+    assert rel_err(host(z), want) < 5e-6
+    cases = [((3, 2, 16000), 160, {}), ((2, 1, 16001), 160, dict(pad_mode='constant')),
+             ((1, 3, 7777), 100, dict(pad_mode='replicate', win_length=320)),
+             ((2, 2, 9000), 200, dict(pad_mode='circular', normalized=True)),
+             ((1, 1, 5000), 160, dict(center=False)), ((5, 1, 999), 37, {}),          # odd hop: sample-by-sample path
+             ((1, 1, 400), 160, {}), ((2, 1, 1100), 160, dict(center=False))]
+    for shape, hop, kw in cases:
+        x = signals.audio_like(shape, seed=41 + hop)
+        before = launches(tac)
+        got = host(tac.stft(dev(x), 400, hop_length=hop, **kw))
+        assert launched_since(tac, before) == {'tac_stft_f32': 1}, (shape, hop, kw)
+        ref = numpy_ref.stft(x, 400, hop, **kw)
+        assert got.shape[:-1] == ref.shape, (shape, hop, kw)
+        assert rel_err(got[..., 0] + 1j * got[..., 1], ref) < 5e-6, (shape, hop, kw)
+    # a strided view of the rows (row stride odd: unaligned pairs)
+    buf = dev(signals.audio_like((4, 12001), seed=77))
+    view = buf[:, :12000]
+    got = host(tac.stft(view, 400, hop_length=160))
+    ref = numpy_ref.stft(host(view), 400, 160)
+    assert rel_err(got[..., 0] + 1j * got[..., 1], ref) < 5e-6
+    x = signals.audio_like((2, 2, 24000), seed=43)
+    for power in (1.0, 2.0):
+        before = launches(tac)
+        spec = tac.Spectrogram(400, hop_length=160, power=power).cuda()
+        got = host(spec(dev(x)))
+        assert launched_since(tac, before) == {'tac_spectrogram_f32': 1}
+        want_s = torch_ref.spectrogram(torch.from_numpy(x), 400, 160, power=power).numpy()
+        assert rel_err(got, want_s) < 1e-5, power
+        chain = torch.nn.Sequential(*tac.Spectrogram(400, hop_length=160, power=power), tac.AmplitudeToDb()).cuda()
+        got_db = host(chain(dev(x)))
+        want_db = torch_ref.amplitude_to_db(torch.from_numpy(want_s)).numpy()
+        big = want_s > 1e-6 * want_s.max()
+        assert np.abs(got_db - want_db)[big].max() < DB_ABS, power
+    # forms outside the kernel: DFT-matrix route
+    before = launches(tac)
+    got = host(tac.stft(dev(x), 400, hop_length=160, onesided=False))
+    assert 'tac_stft_f32' not in launched_since(tac, before)
+    ref = numpy_ref.stft(x, 400, 160, onesided=False)
+    assert rel_err(got[..., 0] + 1j * got[..., 1], ref) < 5e-6
+    got = host(tac.Spectrogram(400, hop_length=160, power=0.7).cuda()(dev(x)))
+    assert rel_err(got, torch_ref.spectrogram(torch.from_numpy(x), 400, 160, power=0.7).numpy()) < 1e-5

@@ -31,8 +31,8 @@ codes = tac.mu_law_encoding(xm, 256)
 stft400 = tac.STFT(400, 160).cuda()
 spec400 = tac.Spectrogram(400, 160, power=2.).cuda()
 cases = [
-    ('STFT n_fft=400 hop=160 (DFT path)', lambda: tac.realize(stft400(x)), x.numel() * 4 + 256 * 1001 * 201 * 8),
-    ('Spectrogram n_fft=400 (DFT path)', lambda: spec400(x), x.numel() * 4 + 256 * 1001 * 201 * 4),
+    ('STFT n_fft=400 hop=160 (mixed radix)', lambda: tac.realize(stft400(x)), x.numel() * 4 + 256 * 1001 * 201 * 8),
+    ('Spectrogram n_fft=400 (mixed radix)', lambda: spec400(x), x.numel() * 4 + 256 * 1001 * 201 * 4),
     ('complex_norm (power 2)', lambda: tac.complex_norm(z, 2.0), z.numel() * 4 + z.numel() * 2),
     ('magphase', lambda: tac.magphase(z, 1.0), z.numel() * 4 + z.numel() * 4),
     ('apply_filterbank 1025x128', lambda: tac.apply_filterbank(p, fb), p.numel() * 4 + p.numel() // 1025 * 128 * 4),

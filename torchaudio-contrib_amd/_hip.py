@@ -30,7 +30,7 @@ class StftGeometry(object):
     """Validated geometry of one stft call on one input layout (the checks ``torch.stft`` performs, reference
     functional.py:99-107), cached per (shape, strides, parameters) so that a repeated call costs a dict lookup."""
     __slots__ = ('lead', 'length', 'rows', 'row_stride', 'flatten', 'n_fft', 'hop', 'win_length', 'center',
-                 'pad_mode', 'normalized', 'onesided', 'n_frames', 'n_bins', 'fft_kernel', 'desc',
+                 'pad_mode', 'normalized', 'onesided', 'n_frames', 'n_bins', 'fft_kernel', 'mixed_radix', 'desc',
                  'stft_shape', 'spec_shape', 'routes')
 
 
@@ -68,8 +68,15 @@ def check_stft_args(shape, n_fft, hop, win_length, center, pad_mode):
 
 def fft_kernel_size(n_fft):
     """power-of-two sizes in [32, 4096] take the wave-level FFT kernels; every other size up to 8192 is evaluated
-    as a windowed-DFT matrix product on the fp32 matrix cores (``_stft_dft``)."""
+    as a windowed-DFT matrix product on the fp32 matrix cores (``_stft_dft``) — except the sizes of
+    ``mixed_radix_size``."""
     return (n_fft & (n_fft - 1)) == 0 and 32 <= n_fft <= 4096
+
+
+def mixed_radix_size(n_fft):
+    """fft_length 400 (25 ms at 16 kHz) has its own kernel (csrc/stft_n400.hip: 200 = 8 x 25) for the one-sided
+    complex / |X| / |X|^2 (+dB) rows; its other forms take the DFT-matrix route."""
+    return n_fft == 400
 
 
 def hip_covers_n_fft(n_fft):
@@ -103,7 +110,8 @@ def geometry(wave, n_fft, hop, win_length, center, pad_mode, normalized, oneside
     if not g.fft_kernel and n_fft > 8192:
         raise NotImplementedError('stft: fft_length %d is outside the HIP path (power of two in [32, 4096], or any '
                                   'length <= 8192 through the DFT-matrix kernel)' % n_fft)
-    g.desc = None if not g.fft_kernel else _native.StftDesc(
+    g.mixed_radix = mixed_radix_size(n_fft)
+    g.desc = None if not (g.fft_kernel or g.mixed_radix) else _native.StftDesc(
         rows=g.rows, length=length, row_stride=g.row_stride, n_fft=n_fft, hop=hop, win_length=win_length,
         center=1 if center else 0, pad_mode=_native.PAD_MODES[pad_mode], normalized=1 if normalized else 0,
         onesided=1 if onesided else 0, reserved=0)
@@ -172,7 +180,7 @@ def _stft_dft(wave, window, g):
 
 def stft(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided):
     g = geometry(wave, n_fft, hop, win_length, center, pad_mode, normalized, onesided)
-    if not g.fft_kernel:
+    if not (g.fft_kernel or (g.mixed_radix and g.onesided)):
         return _stft_dft(wave, window, g)
     src = _rows_of(wave, g)
     out = torch.empty(g.stft_shape, dtype=torch.float32, device=wave.device)
@@ -186,7 +194,7 @@ def stft(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, one
 
 def spectrogram(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided, power, db, ref, amin):
     g = geometry(wave, n_fft, hop, win_length, center, pad_mode, normalized, onesided)
-    if not g.fft_kernel:
+    if not (g.fft_kernel or (g.mixed_radix and g.onesided and power in (1.0, 2.0))):
         mag = complex_norm(_stft_dft(wave, window, g), power)
         return amplitude_to_db(mag, ref, amin) if db else mag
     src = _rows_of(wave, g)

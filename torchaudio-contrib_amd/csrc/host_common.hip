@@ -50,6 +50,10 @@ int get_tables(int n_fft, Tables* out) {
         *out = it->second;
         return TAC_OK;
     }
+    if (!is_pow2(n_fft)) {                      // sizes with their own tables (stft_n400.hip)
+        *out = Tables{nullptr, nullptr};
+        return TAC_OK;
+    }
     const int nc = n_fft / 2;
     const int n_post = nc / 2 + 1;
     std::vector<cf> host((size_t)nc + n_post);
@@ -79,7 +83,7 @@ int make_geometry(const float* wave, const float* window, const tac_stft_desc* d
     if (d->pad_mode < TAC_PAD_CONSTANT || d->pad_mode > TAC_PAD_CIRCULAR) return TAC_E_INVALID;
     if (d->row_stride < d->length) return TAC_E_INVALID;
     if (d->length >= 0x7fffffffLL - 2 * (int64_t)d->n_fft) return TAC_E_UNSUPPORTED;   // 32-bit sample indices in-kernel
-    if (!is_pow2(d->n_fft) || d->n_fft < 32 || d->n_fft > 4096) return TAC_E_UNSUPPORTED;
+    if ((!is_pow2(d->n_fft) || d->n_fft < 32 || d->n_fft > 4096) && d->n_fft != 400) return TAC_E_UNSUPPORTED;
     const int pad = d->center ? d->n_fft / 2 : 0;
     if (pad > 0) {
         // torch's reflect pad needs pad < L, circular needs pad <= L (functional.py:99-107 -> F.pad)

@@ -697,6 +697,7 @@ int try_launch_n4096(const FrameGeom& g, const StftEpilogue& ep, int mode, hipSt
 #define TAC_STFT_SMALL_PIPE 1  // 0: A/B knob, fft_length 512 / 1024 always take the generic kernel
 #endif
 int try_launch_small(int n_fft, const FrameGeom& g, const Tables& tb, const StftEpilogue& ep, int mode, hipStream_t stream);
+int try_launch_n400(const FrameGeom& g, const StftEpilogue& ep, int mode, hipStream_t stream);   // stft_n400.hip
 
 template <int MODE>
 static int dispatch_stft(int n_fft, const FrameGeom& g, const Tables& tb, const StftEpilogue& ep, hipStream_t s) {
@@ -721,6 +722,7 @@ static int dispatch_stft(int n_fft, const FrameGeom& g, const Tables& tb, const 
 #endif
             return launch_stft<2048, 32, MODE>(g, tb, ep, s);
         }
+        case 400: return try_launch_n400(g, ep, MODE, s);          // 200 = 8 x 25 mixed radix; plain one-sided epilogues
         default: return TAC_E_UNSUPPORTED;
     }
 }

@@ -1,0 +1,379 @@
+// stft_n400.hip — one-sided STFT / |X|^p (+dB) rows for fft_length 400 (25 ms at 16 kHz, the usual speech front end),
+// which is not a power of two: 400 real samples = 200 complex z[n], 200 = 8 · 25.
+//
+// A frame is held by EIGHT lanes (eight frames per wave); with n = e + 8m and k = k2 + 25·k1
+//     Z[k2 + 25 k1] = sum_e W_8^{e k1} · ( W_200^{e k2} · sum_m z[e + 8m] W_25^{m k2} ).
+//   (1) lane e transforms its 25 samples z[e + 8m] entirely in registers: 5 × 5 Cooley-Tukey, ten radix-5 butterflies,
+//       compile-time W_25 twiddles (no exchange);
+//   (2) multiplies by its W_200^{e k2} row (a 208-byte table row in LDS, conflict-free 16-byte reads);
+//   (3) the 8-point transform over e runs ACROSS the eight lanes: three radix-2 decimation-in-frequency stages whose
+//       partners come through DPP (row_half_mirror, quad_perm) — lane l holds e = l (l < 4) or 11 - l, which turns the
+//       pairings e ^ 4, e ^ 2, e ^ 1 into the lane pairings l ^ 7, l ^ 2, l ^ 1 that DPP can do; lane l ends with
+//       k1 = bitrev3(e).  No LDS, no barrier.
+//   (4) R2C split for the lane's own 25 bins: the partner Z[200 - k] sits in lane l ^ 4 (two DPP moves), register
+//       25 - k2; the k2 = 0 column pairs by ds_bpermute.  Bin 200 comes from the lane that holds bin 0.
+// The rest is the stft_small.hip recipe: a unit is eight consecutive frames of one row, so its rows are adjacent in
+// memory, are staged in LDS in output order and leave as one run of nontemporal 16-byte stores; the next unit's
+// samples are requested before the current unit's rows are stored; units whose frames touch the padding (or the end
+// of the row) gather sample by sample; one 8-wave workgroup per CU draws units from a workgroup counter.
+// Reference: torchaudio_contrib/functional.py:48-113 (stft), :116-128 (complex_norm), :277-296 (amplitude_to_db).
+#include "host_common.hpp"
+
+#include <cmath>
+#include <map>
+#include <mutex>
+#include <vector>
+
+namespace tac {
+
+constexpr int Q4_WAVES = 8;     // waves per workgroup
+constexpr int Q4_G = 8;         // frames per wave
+constexpr int Q4_M = 25;        // samples / bins per lane
+constexpr int Q4_ROW = 26;      // table row pitch in cf (208 B: eight rows hit eight different 16-byte bank groups)
+constexpr int Q4_BINS = 201;
+// floats of LDS per wave: the unit's eight complex rows (+ the 16-byte phase), which is also enough for the 64 x 25
+// complex values the gather path parks there
+constexpr int Q4_STAGE = ((Q4_G * 2 * Q4_BINS + 4 + 3) / 4) * 4;
+static_assert(Q4_STAGE >= 64 * Q4_M * 2, "staging area holds a gathered unit");
+typedef float q4_f4 __attribute__((ext_vector_type(4)));
+
+struct Q4Tables {
+    const cf* w200;             // [8][Q4_ROW]: W_200^{e(l) k2}
+    const cf* w400;             // [8][Q4_ROW]: W_400^{25 k1(l) + k2}
+};
+
+__host__ __device__ constexpr int q4_e_of(int l) { return l < 4 ? l : 11 - l; }
+__host__ __device__ constexpr int q4_bitrev3(int e) { return ((e & 1) << 2) | (e & 2) | ((e >> 2) & 1); }
+__host__ __device__ constexpr int q4_k1_of(int l) { return q4_bitrev3(q4_e_of(l)); }
+
+template <int CTRL>
+__device__ __forceinline__ cf q4_dpp(cf a) {
+    return mkc(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a.x), CTRL, 0xf, 0xf, false)),
+               __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a.y), CTRL, 0xf, 0xf, false)));
+}
+constexpr int Q4_HALF_MIRROR = 0x141;                      // lane l <- lane 7 - l of its group of eight
+constexpr int Q4_QUAD_XOR1 = 0xB1, Q4_QUAD_XOR2 = 0x4E, Q4_QUAD_XOR3 = 0x1B;   // quad_perm [1,0,3,2] / [2,3,0,1] / [3,2,1,0]
+
+// forward 5-point DFT in place
+__device__ __forceinline__ void q4_dft5(cf& x0, cf& x1, cf& x2, cf& x3, cf& x4) {
+    constexpr float C1 = 0.30901699437494745f, C2 = -0.80901699437494745f;
+    constexpr float S1 = 0.95105651629515353f, S2 = 0.58778525229247314f;
+    const cf t1 = cadd(x1, x4), t2 = cadd(x2, x3), t3 = csub(x1, x4), t4 = csub(x2, x3);
+    const cf a1 = __builtin_elementwise_fma(t2, mkc(C2, C2), __builtin_elementwise_fma(t1, mkc(C1, C1), x0));
+    const cf a2 = __builtin_elementwise_fma(t2, mkc(C1, C1), __builtin_elementwise_fma(t1, mkc(C2, C2), x0));
+    const cf b1 = __builtin_elementwise_fma(t4, mkc(S2, S2), t3 * mkc(S1, S1));
+    const cf b2 = __builtin_elementwise_fma(t4, mkc(-S1, -S1), t3 * mkc(S2, S2));
+    x0 = cadd(x0, cadd(t1, t2));
+    x1 = cadd_rot(a1, b1);                                 // a - i b
+    x4 = csub_rot(a1, b1);                                 // a + i b
+    x2 = cadd_rot(a2, b2);
+    x3 = csub_rot(a2, b2);
+}
+
+// W_25^j = (cos, -sin)(2 pi j / 25), j = 0 .. 16
+__device__ constexpr float Q4_COS25[17] = {1.000000000e+00f, 9.685831611e-01f, 8.763066800e-01f, 7.289686274e-01f,
+                                           5.358267950e-01f, 3.090169944e-01f, 6.279051953e-02f, -1.873813146e-01f,
+                                           -4.257792916e-01f, -6.374239897e-01f, -8.090169944e-01f, -9.297764859e-01f,
+                                           -9.921147013e-01f, -9.921147013e-01f, -9.297764859e-01f, -8.090169944e-01f,
+                                           -6.374239897e-01f};
+__device__ constexpr float Q4_SIN25[17] = {0.000000000e+00f, 2.486898872e-01f, 4.817536741e-01f, 6.845471059e-01f,
+                                           8.443279255e-01f, 9.510565163e-01f, 9.980267284e-01f, 9.822872507e-01f,
+                                           9.048270525e-01f, 7.705132428e-01f, 5.877852523e-01f, 3.681245527e-01f,
+                                           1.253332336e-01f, -1.253332336e-01f, -3.681245527e-01f, -5.877852523e-01f,
+                                           -7.705132428e-01f};
+
+// 25-point DFT in registers: v[m] -> v[k2], natural order in and out
+__device__ __forceinline__ void q4_dft25(cf (&v)[Q4_M]) {
+#pragma unroll
+    for (int m2 = 0; m2 < 5; ++m2) {                        // over m1 (m = 5 m1 + m2): A[m2][q1] lands in v[5 q1 + m2]
+        q4_dft5(v[m2], v[5 + m2], v[10 + m2], v[15 + m2], v[20 + m2]);
+#pragma unroll
+        for (int q1 = 1; q1 < 5; ++q1)
+            if (m2 > 0) v[5 * q1 + m2] = cmulc(v[5 * q1 + m2], Q4_COS25[m2 * q1], -Q4_SIN25[m2 * q1]);
+    }
+    cf y[Q4_M];
+#pragma unroll
+    for (int q1 = 0; q1 < 5; ++q1) {                        // over m2: Y[q1 + 5 q2]
+        cf b0 = v[5 * q1], b1 = v[5 * q1 + 1], b2 = v[5 * q1 + 2], b3 = v[5 * q1 + 3], b4 = v[5 * q1 + 4];
+        q4_dft5(b0, b1, b2, b3, b4);
+        y[q1] = b0; y[q1 + 5] = b1; y[q1 + 10] = b2; y[q1 + 15] = b3; y[q1 + 20] = b4;
+    }
+#pragma unroll
+    for (int k = 0; k < Q4_M; ++k) v[k] = y[k];
+}
+
+// one 208-byte table row -> 25 register values (twelve 16-byte reads and one 8-byte read)
+__device__ __forceinline__ void q4_read_row(const cf* row, cf (&r)[Q4_M]) {
+    const q4_f4* p = reinterpret_cast<const q4_f4*>(row);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const q4_f4 x = p[i];
+        r[2 * i] = mkc(x.x, x.y);
+        r[2 * i + 1] = mkc(x.z, x.w);
+    }
+    r[24] = row[24];
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(Q4_WAVES * 64, 2)
+stft_n400_kernel(FrameGeom g, Q4Tables tb, StftEpilogue ep) {
+    constexpr int LENF = (MODE == 0 ? 2 : 1) * Q4_BINS;
+    constexpr int STAGE = Q4_STAGE;                                        // floats per wave
+    constexpr int NST = (((Q4_G * LENF) >> 2) + 63) / 64;                  // 16-byte wave-stores per unit
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* const smem = reinterpret_cast<float*>(smem_raw);
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slot = lane >> 3, l = lane & 7;
+    const int e = l < 4 ? l : 11 - l;
+    const int k1 = ((e & 1) << 2) | (e & 2) | ((e >> 2) & 1);
+    float* const wstage = smem + w * STAGE;
+    cf* const tabs = reinterpret_cast<cf*>(smem + Q4_WAVES * STAGE);
+    cf* const winl = tabs;                                                 // [8][Q4_ROW] window pairs of samples e + 8m
+    cf* const w200l = tabs + 8 * Q4_ROW;
+    cf* const w400l = tabs + 16 * Q4_ROW;
+    unsigned* const next_unit = reinterpret_cast<unsigned*>(tabs + 24 * Q4_ROW);
+    for (int i = threadIdx.x; i < 8 * Q4_ROW; i += Q4_WAVES * 64) {
+        const int ll = i / Q4_ROW, m = i - ll * Q4_ROW;
+        const int ee = ll < 4 ? ll : 11 - ll;
+        winl[i] = m < Q4_M ? window_pair(g, ee + 8 * m) : mkc(0.0f, 0.0f);
+        w200l[i] = tb.w200[i];
+        w400l[i] = tb.w400[i];
+    }
+
+    // stage constants of the cross-lane 8-point transform: r = (partner + s * mine) * c
+    const float s1 = e >= 4 ? -1.0f : 1.0f, s2 = (e & 2) ? -1.0f : 1.0f, s3 = (e & 1) ? -1.0f : 1.0f;
+    const float R = 0.70710678118654752f;
+    cf c1 = mkc(1.0f, 0.0f), c2 = mkc(1.0f, 0.0f);
+    if (e == 5) c1 = mkc(R, -R);
+    if (e == 6) c1 = mkc(0.0f, -1.0f);
+    if (e == 7) c1 = mkc(-R, -R);
+    if ((e & 3) == 3) c2 = mkc(0.0f, -1.0f);
+    // source lane (byte address for ds_bpermute) of the k2 = 0 partner Z[25 * ((8 - k1) & 7)]
+    int p0lane = l;
+    if (l == 2) p0lane = 3;
+    if (l == 3) p0lane = 2;
+    if (l == 4) p0lane = 7;
+    if (l == 7) p0lane = 4;
+    if (l == 5) p0lane = 6;
+    if (l == 6) p0lane = 5;
+    const int p0addr = ((lane & ~7) | p0lane) << 2;
+
+    const int T = (int)g.n_frames;
+    const int upr = (T + Q4_G - 1) / Q4_G;                                 // units per row
+    const int total = (int)g.rows * upr;
+    const int chunk = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int begin = (int)blockIdx.x * chunk;
+    const int end = begin + chunk < total ? begin + chunk : total;
+    const float hscale = 0.5f * g.scale;                                   // the R2C split returns 2 X
+    if (threadIdx.x == 0) *next_unit = (unsigned)(begin + Q4_WAVES);
+    auto grab = [&]() -> int {
+        unsigned v = 0;
+        if (lane == 0) v = __hip_atomic_fetch_add(next_unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return (int)__builtin_amdgcn_readfirstlane(v);
+    };
+
+    cf raw[Q4_M];
+    // every lane group requests its own frame; a unit takes the fast path only if ALL its frames are interior
+    auto prefetch = [&](int unit) -> bool {
+        const int urow = unit / upr;
+        const int frame = (unit - urow * upr) * Q4_G + slot;
+        const long long start = (long long)frame * g.hop - g.center_pad;
+        const bool ok = g.vec2_ok && frame < T && start >= 0 && start + 400 <= g.length;
+        const bool all_ok = __builtin_amdgcn_ballot_w64(ok) == ~0ull;
+        if (all_ok) {
+            const cf* src = reinterpret_cast<const cf*>(g.wave + (long long)urow * g.row_stride + start) + e;
+#pragma unroll
+            for (int m = 0; m < Q4_M; ++m) raw[m] = src[8 * m];
+        }
+        return all_ok;
+    };
+    bool pre = false;
+    int unit = begin + w;
+    if (unit < end) pre = prefetch(unit);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                    // vmcnt(0): the loop is entered with nothing in flight
+    __syncthreads();
+
+    while (unit < end) {
+        const int nxt = grab();
+        const int urow = unit / upr;
+        const int uframe0 = (unit - urow * upr) * Q4_G;
+        cf v[Q4_M];
+        {
+            cf wn[Q4_M];
+            q4_read_row(winl + l * Q4_ROW, wn);
+            if (pre) {
+#pragma unroll
+                for (int m = 0; m < Q4_M; ++m) v[m] = cmul_elem(raw[m], wn[m]);
+            } else {
+                // frames touching the padding / past the end of the row: sample by sample (rolled loop)
+                const int frame = uframe0 + slot;
+                const float* rp = g.wave + (long long)urow * g.row_stride;
+                const int s0 = (int)((long long)frame * g.hop - g.center_pad);
+                const int L = (int)g.length;
+                const bool live = frame < T;
+#pragma unroll 1
+                for (int m = 0; m < Q4_M; ++m) {
+                    bool z0, z1;
+                    const int j0 = padded_index(s0 + 2 * (e + 8 * m), L, g.pad_mode, &z0);
+                    const int j1 = padded_index(s0 + 2 * (e + 8 * m) + 1, L, g.pad_mode, &z1);
+                    const float a0 = rp[j0], a1 = rp[j1];
+                    const cf wv = winl[l * Q4_ROW + m];
+                    // (registers are indexed at compile time only: the values travel through the unit's staging area)
+                    reinterpret_cast<cf*>(wstage)[lane * Q4_M + m] =
+                        mkc((live && !z0) ? a0 * wv.x : 0.0f, (live && !z1) ? a1 * wv.y : 0.0f);
+                }
+                wave_lds_fence();
+#pragma unroll
+                for (int m = 0; m < Q4_M; ++m) v[m] = reinterpret_cast<const cf*>(wstage)[lane * Q4_M + m];
+                wave_lds_fence();
+            }
+        }
+        q4_dft25(v);                                                       // (1)
+        {
+            cf tw[Q4_M];                                                   // (2)
+            q4_read_row(w200l + l * Q4_ROW, tw);
+#pragma unroll
+            for (int k = 1; k < Q4_M; ++k) v[k] = cmul(v[k], tw[k]);
+        }
+        // request the next unit now: it lands while this one is transformed across lanes, split, staged and stored
+        __builtin_amdgcn_sched_barrier(0);
+        pre = false;
+        if (nxt < end) pre = prefetch(nxt);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < Q4_M; ++k) {                                   // (3)
+            cf p = q4_dpp<Q4_HALF_MIRROR>(v[k]);
+            v[k] = cmul(__builtin_elementwise_fma(v[k], mkc(s1, s1), p), c1);
+            p = q4_dpp<Q4_QUAD_XOR2>(v[k]);
+            v[k] = cmul(__builtin_elementwise_fma(v[k], mkc(s2, s2), p), c2);
+            p = q4_dpp<Q4_QUAD_XOR1>(v[k]);
+            v[k] = __builtin_elementwise_fma(v[k], mkc(s3, s3), p);
+        }
+
+        const long long g0 = ((long long)urow * T + uframe0) * LENF;
+        const int a = (int)(g0 & 3);
+        float* const stage = wstage + a;                                   // LDS and global share their 16-byte phase
+        float* const srow = stage + slot * LENF;
+        {
+            cf tw[Q4_M];                                                   // (4)
+            q4_read_row(w400l + l * Q4_ROW, tw);
+            const cf z0p = mkc(__int_as_float(__builtin_amdgcn_ds_bpermute(p0addr, __float_as_int(v[0].x))),
+                               __int_as_float(__builtin_amdgcn_ds_bpermute(p0addr, __float_as_int(v[0].y))));
+            cf zp[Q4_M];
+            zp[0] = z0p;
+#pragma unroll
+            for (int k = 1; k < Q4_M; ++k) zp[k] = q4_dpp<Q4_QUAD_XOR3>(q4_dpp<Q4_HALF_MIRROR>(v[Q4_M - k]));   // lane l ^ 4
+#pragma unroll
+            for (int k = 0; k < Q4_M; ++k) {
+                const int bin = 25 * k1 + k;
+                const cf ev = cadd_conj(v[k], zp[k]), d = csub_conj(v[k], zp[k]);
+                const cf twd = cmul_rot(tw[k], d);
+                if constexpr (MODE == 0) {
+                    reinterpret_cast<cf*>(srow)[bin] = cscale(cadd(ev, twd), hscale);
+                    if (k == 0 && l == 0) reinterpret_cast<cf*>(srow)[200] = cscale(csub_then_conj(ev, twd), hscale);
+                } else {
+                    const cf pw = cscale(power_pair(ev, twd), hscale * hscale);       // (|X[k]|^2, |X[200 - k]|^2)
+                    srow[bin] = spectral_row_value<MODE>(pw.x, ep);
+                    if (k == 0 && l == 0) srow[200] = spectral_row_value<MODE>(pw.y, ep);
+                }
+            }
+            wave_lds_fence();
+        }
+        // the unit's live rows leave as 1 + NST + 1 unconditional nontemporal stores (lanes past the end repeat a neighbour)
+        const int nlive = (T - uframe0) < Q4_G ? (T - uframe0) : Q4_G;
+        const int len = nlive * LENF;
+        float* const gdst = ep.out + g0;
+        const int npre = (4 - a) & 3;
+        const int nchunks = (len - npre) >> 2;
+        {
+            const int hmax = (npre > 1 ? npre : 1) - 1;
+            const int hi = lane < hmax ? lane : hmax;
+            gdst[hi] = stage[hi];
+        }
+        const q4_f4* const s4 = reinterpret_cast<const q4_f4*>(stage + npre);
+        q4_f4* const g4 = reinterpret_cast<q4_f4*>(gdst + npre);
+        const int last = nchunks - 1;
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int c = (lane + 64 * i) < last ? (lane + 64 * i) : last;
+            __builtin_nontemporal_store(s4[c], g4 + c);
+        }
+        {
+            const int r = len - npre - 4 * nchunks;
+            const int rmax = (r > 1 ? r : 1) - 1;
+            const int ti = len - 1 - (lane < rmax ? lane : rmax);
+            gdst[ti] = stage[ti];
+        }
+        wave_lds_fence();   // the next unit's staging writes must follow these reads
+        unit = nxt;
+    }
+}
+
+// device tables, one set per device
+static int q4_tables(Q4Tables* out) {
+    static std::mutex mu;
+    static std::map<int, Q4Tables> cache;
+    int dev = 0;
+    TAC_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(dev);
+    if (it != cache.end()) {
+        *out = it->second;
+        return TAC_OK;
+    }
+    std::vector<cf> host(2 * 8 * Q4_ROW, mkc(0.0f, 0.0f));
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int l = 0; l < 8; ++l)
+        for (int k2 = 0; k2 < Q4_M; ++k2) {
+            const double a = -two_pi * (double)((q4_e_of(l) * k2) % 200) / 200.0;
+            const double b = -two_pi * (double)(25 * q4_k1_of(l) + k2) / 400.0;
+            host[l * Q4_ROW + k2] = mkc((float)std::cos(a), (float)std::sin(a));
+            host[8 * Q4_ROW + l * Q4_ROW + k2] = mkc((float)std::cos(b), (float)std::sin(b));
+        }
+    cf* dptr = nullptr;
+    TAC_HIP(hipMalloc((void**)&dptr, host.size() * sizeof(cf)));
+    TAC_HIP(hipMemcpy(dptr, host.data(), host.size() * sizeof(cf), hipMemcpyHostToDevice));
+    Q4Tables t{dptr, dptr + 8 * Q4_ROW};
+    cache[dev] = t;
+    *out = t;
+    return TAC_OK;
+}
+
+template <int MODE>
+static int launch_n400(const FrameGeom& g, const Q4Tables& tb, const StftEpilogue& ep, hipStream_t stream) {
+    const long long units = g.rows * ((g.n_frames + Q4_G - 1) / Q4_G);
+    if (units >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
+    const size_t bytes = (size_t)Q4_WAVES * Q4_STAGE * sizeof(float) + (size_t)24 * Q4_ROW * sizeof(cf) + 16;
+    long long blocks = (units + Q4_WAVES - 1) / Q4_WAVES;
+    const long long cap = (long long)device_cu_count();
+    if (blocks > cap) blocks = cap;
+    auto kern = stft_n400_kernel<MODE>;
+    if (bytes > 64 * 1024) TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Q4_WAVES * 64), bytes, stream, g, tb, ep);
+    TAC_HIP(hipGetLastError());
+    return TAC_OK;
+}
+
+// Entry used by stft_kernels.hip's dispatcher: TAC_E_UNSUPPORTED when this form does not apply (two-sided output,
+// |X|^p with p outside {1, 2}); the caller then evaluates the DFT as a matrix product.
+int try_launch_n400(const FrameGeom& g, const StftEpilogue& ep, int mode, hipStream_t stream) {
+    if (!ep.onesided) return TAC_E_UNSUPPORTED;
+    int pmode = -1;
+    if (mode == 0) pmode = 0;
+    else if (ep.power == 2.0f) pmode = ep.db ? 3 : 1;
+    else if (ep.power == 1.0f) pmode = ep.db ? 4 : 2;
+    if (pmode < 0) return TAC_E_UNSUPPORTED;
+    Q4Tables tb;
+    const int rc = q4_tables(&tb);
+    if (rc != TAC_OK) return rc;
+    switch (pmode) {
+        case 0: return launch_n400<0>(g, tb, ep, stream);
+        case 1: return launch_n400<1>(g, tb, ep, stream);
+        case 2: return launch_n400<2>(g, tb, ep, stream);
+        case 3: return launch_n400<3>(g, tb, ep, stream);
+        default: return launch_n400<4>(g, tb, ep, stream);
+    }
+}
+
+}  // namespace tac
