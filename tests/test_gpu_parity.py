@@ -1070,6 +1070,27 @@ def test_fft_length_400_kernel(tac, golden):
         want_db = torch_ref.amplitude_to_db(torch.from_numpy(want_s)).numpy()
         big = want_s > 1e-6 * want_s.max()
         assert np.abs(got_db - want_db)[big].max() < DB_ABS, power
+    # the fused chain Melspectrogram (-> AmplitudeToDb) at fft_length 400: one launch
+    for shape, n_mels, hop, kw in (((2, 2, 24000), 80, 160, {}), ((3, 1, 16001), 40, 160, dict(pad_mode='constant')),
+                                   ((1, 1, 5000), 128, 100, {}), ((4, 1, 3000), 5, 77, {}), ((1, 2, 8000), 23, 160, dict(center=False))):
+        xm = signals.audio_like(shape, seed=50 + n_mels)
+        mel = tac.Melspectrogram(num_mels=n_mels, sample_rate=16000, fft_length=400, hop_length=hop, **kw).cuda()
+        before = launches(tac)
+        got = host(tac.realize(mel(dev(xm))))
+        # (fewer than eight bands, or bands wider than the fused form's 32 taps: the three-kernel chain)
+        fused = {'tac_melspec_sparse_f32': 1} if n_mels not in (5, 23) else {'tac_spectrogram_f32': 1, 'tac_apply_filterbank_sparse_f32': 1}
+        assert launched_since(tac, before) == fused, (shape, n_mels)
+        want_m = torch_ref.melspectrogram(torch.from_numpy(xm), num_mels=n_mels, sample_rate=16000, n_fft=400, hop=hop,
+                                          **kw).numpy()
+        assert got.shape == want_m.shape
+        assert rel_err(got, want_m) < 1e-5, (shape, n_mels)
+        chain = torch.nn.Sequential(*mel, tac.AmplitudeToDb()).cuda()
+        before = launches(tac)
+        got_db = host(chain(dev(xm)))
+        assert ('tac_melspec_sparse_f32' in launched_since(tac, before)) == (n_mels not in (5, 23))
+        want_db = torch_ref.amplitude_to_db(torch.from_numpy(want_m)).numpy()
+        big = want_m > 1e-6 * want_m.max()
+        assert np.abs(got_db - want_db)[big].max() < DB_ABS, (shape, n_mels)
     # forms outside the kernel: DFT-matrix route
     before = launches(tac)
     got = host(tac.stft(dev(x), 400, hop_length=160, onesided=False))

@@ -269,9 +269,12 @@ def _filterbank_plan(fb):
 def _fused_mel_route(g, fb, power):
     """'sparse' / 'mfma' when one fused kernel covers this geometry + filterbank, else None (then the caller chains
     the spectrogram, filterbank and dB kernels)."""
-    if not (g.fft_kernel and g.onesided and g.n_fft <= 2048 and fb.dim() == 2 and fb.shape[0] == g.n_bins and
-            0 < fb.shape[1] <= 512 and fb.is_contiguous()):
+    if not ((g.fft_kernel or g.mixed_radix) and g.onesided and g.n_fft <= 2048 and fb.dim() == 2 and
+            fb.shape[0] == g.n_bins and 0 < fb.shape[1] <= 512 and fb.is_contiguous()):
         return None
+    if g.mixed_radix:       # fft_length 400: only the band-sparse form has a fused kernel
+        ok = power in (1.0, 2.0) and MEL_PATH != 'mfma' and _melbank_pack(fb, g.n_fft) is not None
+        return 'sparse' if ok else None
     if power in (1.0, 2.0) and MEL_PATH != 'mfma' and _melbank_pack(fb, g.n_fft) is not None:
         return 'sparse'
     if MEL_PATH == 'sparse':

@@ -55,6 +55,12 @@
 
 namespace tac {
 
+// stft_n400.hip: the fused chain for fft_length 400
+int launch_n400_mel(const FrameGeom& g, float power, const float* wpack, const int* desc, const int32_t* info_host,
+                    int n_mels, int db, float amin, float log10_ref, float* out, hipStream_t stream);
+int pack_n400(const std::vector<float>& h, int n_freqs, int n_mels, float* wpack, int wpack_cap, int32_t* desc,
+              int desc_cap, int32_t* info_host, hipStream_t stream);
+
 constexpr int SP_TILE = 16;
 constexpr int SP_MAX_W = 3072;               // floats of packed weights that may live in LDS (12 KB)
 
@@ -368,6 +374,7 @@ static int sparse_groups_for(int n_fft) {
         case 512: return sparse_groups<256, 16>();
         case 1024: return sparse_groups<512, 16>();
         case 2048: return TAC_SP_STREAM ? 64 : sparse_groups<1024, 16>();     // 64: one band per lane and slot (melspec_stream.hpp)
+        case 400: return 8;                                                  // eight lanes per frame (stft_n400.hip)
         default: return 0;
     }
 }
@@ -518,6 +525,7 @@ int tac_melbank_pack(const float* fb, int32_t n_freqs, int32_t n_mels, int32_t n
     TAC_HIP(hipStreamSynchronize((hipStream_t)stream));
     if (TAC_SP_STREAM && n_fft == 2048)
         return pack_lanes(h, n_freqs, n_mels, wpack, wpack_cap, desc, desc_cap, info_host, (hipStream_t)stream);
+    if (n_fft == 400) return pack_n400(h, n_freqs, n_mels, wpack, wpack_cap, desc, desc_cap, info_host, (hipStream_t)stream);
     struct Band { int m, lo, len; };
     std::vector<Band> bands(n_mels);
     long long total = 0;
@@ -584,6 +592,9 @@ int tac_melspec_sparse_f32(const float* wave, const float* window, const tac_stf
     int64_t T = 0;
     int rc = make_geometry(wave, window, d, &g, &T);
     if (rc != TAC_OK) return rc;
+    if (d->n_fft == 400)
+        return launch_n400_mel(g, power, wpack, desc, info_host, n_mels, db ? 1 : 0, db_amin, db ? log10f(db_ref) : 0.0f, out,
+                               (hipStream_t)stream);
     Tables tb;
     rc = get_tables(d->n_fft, &tb);
     if (rc != TAC_OK) return rc;
