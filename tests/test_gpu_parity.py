@@ -1077,7 +1077,7 @@ def test_fft_length_400_kernel(tac, golden):
         mel = tac.Melspectrogram(num_mels=n_mels, sample_rate=16000, fft_length=400, hop_length=hop, **kw).cuda()
         before = launches(tac)
         got = host(tac.realize(mel(dev(xm))))
-        # (fewer than eight bands, or bands wider than the fused form's 32 taps: the three-kernel chain)
+        # (fewer than eight bands, or bands wider than the fused form's 48 taps: the three-kernel chain)
         fused = {'tac_melspec_sparse_f32': 1} if n_mels not in (5, 23) else {'tac_spectrogram_f32': 1, 'tac_apply_filterbank_sparse_f32': 1}
         assert launched_since(tac, before) == fused, (shape, n_mels)
         want_m = torch_ref.melspectrogram(torch.from_numpy(xm), num_mels=n_mels, sample_rate=16000, n_fft=400, hop=hop,

@@ -1,0 +1,184 @@
+// mel_lanes.hpp — the band-sparse filterbank contraction of the kernels that keep a wave's |X|^p rows in LDS in output
+// order (stft_n400.hip: 8 lanes per frame; stft_small.hip: 16 / 32 lanes per frame), fused behind their R2C split:
+// Melspectrogram (-> AmplitudeToDb) in one launch (reference layers.py:307-381, functional.py:172-184, :277-296).
+//
+// Lane l of a frame's LANES owns bands l, LANES + l, 2 LANES + l, ... (band slot i = band / LANES); every band is S
+// four-tap steps (S = the longest band of the bank, a template parameter; shorter bands zero-padded, first bins rounded
+// down to a multiple of four, runs that would leave the row shifted down): one 16-byte weight read, one 16-byte row
+// read and two packed FMAs per step.  The contraction is latency, not work (a first version with one LDS round trip
+// per step took a third of the fft_length-400 kernel): slots are processed in groups of lm_group(S, FLY) whose reads
+// are all issued before the first FMA, and a group's first bins are read one group earlier.
+// pack_lane_mel builds:  desc = first bin [slot][lane], wpack = [slot][step][lane][4 taps], both zero-padded to whole
+// groups plus one.
+// (Measured and dropped: cutting the bands into equal 8-bin chunks dealt to the lanes in order, partial sums combined
+// with ds_add_f32 into the LDS row — no wasted taps, but the atomics cost more than the taps they save: 0.36 vs 0.157 ms
+// at 512 / 80 bands.)
+#pragma once
+#include "host_common.hpp"
+
+#include <algorithm>
+#include <vector>
+
+namespace tac {
+
+struct LaneMel {
+    const float* wpack;
+    const int* desc;
+    int nslot, wtot, n_mels, db;
+    float amin, log10_ref;
+    float* out;                 // [rows][T][n_mels]
+};
+
+constexpr int LM_MAX_MELS = 128, LM_MIN_MELS = 8, LM_MAX_STEPS = 12;
+constexpr int LM_MARK = 1000;                                              // info_host[2] = LM_MARK + lanes per frame
+typedef float lm_f4 __attribute__((ext_vector_type(4)));
+
+// slots per group: about FLY steps (8 registers each) in flight
+__host__ __device__ constexpr int lm_group(int S, int FLY) { return FLY / S < 1 ? 1 : (FLY / S > 8 ? 8 : FLY / S); }
+__host__ __device__ constexpr int lm_padded_slots(int nslot, int S, int FLY) {
+    return ((nslot + lm_group(S, FLY) - 1) / lm_group(S, FLY) + 1) * lm_group(S, FLY);
+}
+__host__ __device__ constexpr int lm_desc_ints(int lanes) { return lanes * (LM_MAX_MELS / lanes + 8); }
+// LDS of the fused form behind a kernel's own: first bins + packed weights
+inline size_t lm_lds_bytes(int lanes, int wtot) {
+    return (size_t)lm_desc_ints(lanes) * sizeof(int) + (((size_t)wtot + 3) & ~(size_t)3) * sizeof(float);
+}
+
+// tables into LDS (all threads of the workgroup; the caller's barrier follows)
+template <int S, int LANES, int FLY>
+__device__ __forceinline__ void lane_mel_load_tables(int* mlo, float* mwl, const LaneMel& mel, int tid, int nthreads) {
+    for (int i = tid; i < LANES * lm_padded_slots(mel.nslot, S, FLY); i += nthreads) mlo[i] = mel.desc[i];
+    for (int i = tid; i < mel.wtot; i += nthreads) mwl[i] = mel.wpack[i];
+}
+
+// One frame's row (srow: 16-byte aligned, `bins` values, at least three floats of slack behind them) -> its mel (dB) row
+template <int S, int LANES, int FLY>
+__device__ __forceinline__ void lane_mel_contract(float* srow, int bins, const int* mlo, const float* mwl, int l,
+                                                  const LaneMel& mel, float* mrow) {
+    constexpr int GS = lm_group(S, FLY);
+    const bool fast_db = mel.amin >= 1.1754944e-38f;                       // (uniform) hardware log2 unless the clamp admits denormals
+    const float ten_log10_ref = 10.0f * mel.log10_ref;
+    if (l < 3) srow[bins + l] = 0.0f;                                      // slack taps carry zero weights: keep them finite
+    wave_lds_fence();
+    int lo_g[GS];
+#pragma unroll
+    for (int q = 0; q < GS; ++q) lo_g[q] = mlo[LANES * q + l];
+#pragma unroll 1
+    for (int i0 = 0; i0 < mel.nslot; i0 += GS) {
+        lm_f4 wv[GS][S], pv[GS][S];
+        const lm_f4* wp = reinterpret_cast<const lm_f4*>(mwl) + i0 * (S * LANES) + l;
+#pragma unroll
+        for (int q = 0; q < GS; ++q) {
+            const lm_f4* pp = reinterpret_cast<const lm_f4*>(srow + lo_g[q]);
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                wv[q][j] = wp[(q * S + j) * LANES];
+                pv[q][j] = pp[j];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < GS; ++q) lo_g[q] = mlo[LANES * (i0 + GS + q) + l];         // the next group's (table padded by one group)
+#pragma unroll
+        for (int q = 0; q < GS; ++q) {
+            cf acc0 = mkc(0.0f, 0.0f), acc1 = mkc(0.0f, 0.0f);
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                acc0 = __builtin_elementwise_fma(mkc(wv[q][j].x, wv[q][j].y), mkc(pv[q][j].x, pv[q][j].y), acc0);
+                acc1 = __builtin_elementwise_fma(mkc(wv[q][j].z, wv[q][j].w), mkc(pv[q][j].z, pv[q][j].w), acc1);
+            }
+            float val = (acc0.x + acc0.y) + (acc1.x + acc1.y);
+            if (mel.db) val = fast_db ? amp_to_db_fast(val, mel.amin, ten_log10_ref) : amp_to_db(val, mel.amin, mel.log10_ref);
+            const int band = LANES * (i0 + q) + l;
+            if (band < mel.n_mels) mrow[band] = val;
+        }
+    }
+}
+
+// The unit's `len` staged floats (mstage shares the 16-byte phase of gdst) leave as 1 + NSTM + 1 unconditional
+// nontemporal stores — a FIXED number (surplus ones repeat the last chunk), so that the wait for the next unit's
+// samples, requested before them, stays a counted vmcnt.  len >= 8.
+template <int NSTM>
+__device__ __forceinline__ void lane_mel_store(const float* mstage, int am, int len, float* gdst, int lane) {
+    const int npre = (4 - am) & 3;
+    const int nchunks = (len - npre) >> 2;
+    {
+        const int hmax = (npre > 1 ? npre : 1) - 1;
+        const int hi = lane < hmax ? lane : hmax;
+        gdst[hi] = mstage[hi];
+    }
+    const lm_f4* const s4 = reinterpret_cast<const lm_f4*>(mstage + npre);
+    lm_f4* const g4 = reinterpret_cast<lm_f4*>(gdst + npre);
+    const int last = nchunks - 1;
+#pragma unroll
+    for (int i = 0; i < NSTM; ++i) {
+        const int c = (lane + 64 * i) < last ? (lane + 64 * i) : last;
+        __builtin_nontemporal_store(s4[c], g4 + c);
+    }
+    {
+        const int r = len - npre - 4 * nchunks;
+        const int rmax = (r > 1 ? r : 1) - 1;
+        const int ti = len - 1 - (lane < rmax ? lane : rmax);
+        gdst[ti] = mstage[ti];
+    }
+}
+
+// Host: the layout above for a (n_freqs x n_mels) bank `h`, `lanes` lanes per frame, rows of `pitch` floats, S a
+// multiple of `step_quantum`, groups sized for `fly` steps in flight (the kernel's FLY).
+// TAC_E_UNSUPPORTED when the bank does not fit (fewer than 8 / more than 128 bands, bands wider than 4 LM_MAX_STEPS).
+inline int pack_lane_mel(const std::vector<float>& h, int n_freqs, int n_mels, int lanes, int pitch, int step_quantum, int fly,
+                         size_t base_lds, float* wpack, int wpack_cap, int32_t* desc, int desc_cap, int32_t* info_host,
+                         hipStream_t stream) {
+    if (n_mels < LM_MIN_MELS || n_mels > LM_MAX_MELS) return TAC_E_UNSUPPORTED;
+    const int nslot = (n_mels + lanes - 1) / lanes;
+    std::vector<int> lo(nslot * lanes, 0), hi(nslot * lanes, 0);
+    int S = 1;
+    for (int m = 0; m < n_mels; ++m) {
+        int l0 = n_freqs, h0 = 0;
+        for (int f = 0; f < n_freqs; ++f)
+            if (h[(size_t)f * n_mels + m] != 0.0f) { l0 = f < l0 ? f : l0; h0 = f + 1; }
+        if (h0 > l0) {
+            lo[m] = l0;
+            hi[m] = h0;
+            S = std::max(S, (h0 - (l0 & ~3) + 3) / 4);
+        }
+    }
+    S = ((S + step_quantum - 1) / step_quantum) * step_quantum;            // (the kernels are instantiated for these values of S only)
+    if (S > LM_MAX_STEPS || 4 * S > pitch) return TAC_E_UNSUPPORTED;       // bands too wide: the unfused chain
+    const int pslot = lm_padded_slots(nslot, S, fly);
+    if (lanes * pslot > desc_cap || lanes * pslot > lm_desc_ints(lanes)) return TAC_E_UNSUPPORTED;
+    const long long wtot = 4LL * lanes * S * pslot;
+    if (wtot > wpack_cap || base_lds + lm_lds_bytes(lanes, (int)wtot) > 160 * 1024) return TAC_E_UNSUPPORTED;
+    std::vector<float> wp((size_t)wtot, 0.0f);
+    std::vector<int32_t> dd((size_t)lanes * pslot, 0);
+    for (int i = 0; i < nslot; ++i)
+        for (int l = 0; l < lanes; ++l) {
+            const int m = lanes * i + l;
+            int first = lo[m] & ~3;
+            if (first + 4 * S > pitch) first = pitch - 4 * S;              // keep the padded run inside the row
+            for (int j = 0; j < S; ++j)
+                for (int u = 0; u < 4; ++u) {
+                    const int bin = first + 4 * j + u;
+                    const bool live = m < n_mels && bin >= lo[m] && bin < hi[m];
+                    wp[(((size_t)i * S + j) * lanes + l) * 4 + u] = live ? h[(size_t)bin * n_mels + m] : 0.0f;
+                }
+            dd[lanes * i + l] = first;
+        }
+    TAC_HIP(hipMemcpyAsync(wpack, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+    TAC_HIP(hipMemcpyAsync(desc, dd.data(), dd.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    TAC_HIP(hipStreamSynchronize(stream));
+    info_host[0] = (int32_t)wtot;
+    info_host[1] = nslot;
+    info_host[2] = LM_MARK + lanes;
+    info_host[3] = S * nslot;
+    info_host[4] = S;
+    for (int i = 5; i < 8; ++i) info_host[i] = 0;
+    return TAC_OK;
+}
+
+// what a launcher checks before trusting a pack
+inline bool lane_mel_info_ok(const int32_t* info, int lanes, int fly) {
+    return info[2] == LM_MARK + lanes && info[1] >= 1 && info[1] <= LM_MAX_MELS / lanes + (LM_MAX_MELS % lanes ? 1 : 0) &&
+           info[4] >= 1 && info[4] <= LM_MAX_STEPS && info[0] == 4 * lanes * info[4] * lm_padded_slots(info[1], info[4], fly);
+}
+
+}  // namespace tac

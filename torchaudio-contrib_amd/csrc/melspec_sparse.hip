@@ -14,6 +14,7 @@
 // storage and the FFT phase gets 40 more registers.  Banks that are not band-sparse enough for the LDS budget
 // return TAC_E_UNSUPPORTED and take the MFMA kernels instead.
 #include "mel_common.hpp"
+#include "mel_lanes.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -60,6 +61,15 @@ int launch_n400_mel(const FrameGeom& g, float power, const float* wpack, const i
                     int n_mels, int db, float amin, float log10_ref, float* out, hipStream_t stream);
 int pack_n400(const std::vector<float>& h, int n_freqs, int n_mels, float* wpack, int wpack_cap, int32_t* desc,
               int desc_cap, int32_t* info_host, hipStream_t stream);
+// stft_small.hip: the same form for fft_length 512 / 1024 (the three-phase kernel below stays the fallback)
+int launch_small_mel_entry(int n_fft, const FrameGeom& g, const Tables& tb, float power, const float* wpack, const int* desc,
+                           const int32_t* info_host, int n_mels, int db, float amin, float log10_ref, float* out,
+                           hipStream_t stream);
+int pack_small(int n_fft, const std::vector<float>& h, int n_freqs, int n_mels, float* wpack, int wpack_cap, int32_t* desc,
+               int desc_cap, int32_t* info_host, hipStream_t stream);
+#ifndef TAC_SP_LANES
+#define TAC_SP_LANES 1      // fft_length 512 / 1024: the lane-layout fused form of stft_small.hip where the bank allows it (0: A/B knob)
+#endif
 
 constexpr int SP_TILE = 16;
 constexpr int SP_MAX_W = 3072;               // floats of packed weights that may live in LDS (12 KB)
@@ -374,7 +384,7 @@ static int sparse_groups_for(int n_fft) {
         case 512: return sparse_groups<256, 16>();
         case 1024: return sparse_groups<512, 16>();
         case 2048: return TAC_SP_STREAM ? 64 : sparse_groups<1024, 16>();     // 64: one band per lane and slot (melspec_stream.hpp)
-        case 400: return 8;                                                  // eight lanes per frame (stft_n400.hip)
+        case 400: return LM_MARK + 8;                                        // eight lanes per frame (stft_n400.hip, mel_lanes.hpp)
         default: return 0;
     }
 }
@@ -526,6 +536,10 @@ int tac_melbank_pack(const float* fb, int32_t n_freqs, int32_t n_mels, int32_t n
     if (TAC_SP_STREAM && n_fft == 2048)
         return pack_lanes(h, n_freqs, n_mels, wpack, wpack_cap, desc, desc_cap, info_host, (hipStream_t)stream);
     if (n_fft == 400) return pack_n400(h, n_freqs, n_mels, wpack, wpack_cap, desc, desc_cap, info_host, (hipStream_t)stream);
+    if (TAC_SP_LANES && (n_fft == 512 || n_fft == 1024)) {
+        const int rc = pack_small(n_fft, h, n_freqs, n_mels, wpack, wpack_cap, desc, desc_cap, info_host, (hipStream_t)stream);
+        if (rc != TAC_E_UNSUPPORTED) return rc;                             // else: the three-phase kernel's layout
+    }
     struct Band { int m, lo, len; };
     std::vector<Band> bands(n_mels);
     long long total = 0;
@@ -587,11 +601,20 @@ int tac_melspec_sparse_f32(const float* wave, const float* window, const tac_stf
     if (!wpack || !desc || !info_host || !out || !d || n_mels <= 0) return TAC_E_INVALID;
     if (!d->onesided || d->n_fft > 2048) return TAC_E_UNSUPPORTED;
     if (power != 2.0f && power != 1.0f) return TAC_E_UNSUPPORTED;
-    if (info_host[2] != sparse_groups_for(d->n_fft)) return TAC_E_INVALID;         // pack built for another geometry
+    const bool lanes_pack = info_host[2] >= LM_MARK;                               // mel_lanes.hpp layout
+    if (!lanes_pack && info_host[2] != sparse_groups_for(d->n_fft)) return TAC_E_INVALID;   // pack built for another geometry
     FrameGeom g;
     int64_t T = 0;
     int rc = make_geometry(wave, window, d, &g, &T);
     if (rc != TAC_OK) return rc;
+    if (lanes_pack && (d->n_fft == 512 || d->n_fft == 1024)) {
+        Tables tbs;
+        rc = get_tables(d->n_fft, &tbs);
+        if (rc != TAC_OK) return rc;
+        return launch_small_mel_entry(d->n_fft, g, tbs, power, wpack, desc, info_host, n_mels, db ? 1 : 0, db_amin,
+                                      db ? log10f(db_ref) : 0.0f, out, (hipStream_t)stream);
+    }
+    if (lanes_pack && d->n_fft != 400) return TAC_E_INVALID;
     if (d->n_fft == 400)
         return launch_n400_mel(g, power, wpack, desc, info_host, n_mels, db ? 1 : 0, db_amin, db ? log10f(db_ref) : 0.0f, out,
                                (hipStream_t)stream);

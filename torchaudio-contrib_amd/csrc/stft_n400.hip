@@ -18,6 +18,7 @@
 // of the row) gather sample by sample; one 8-wave workgroup per CU draws units from a workgroup counter.
 // Reference: torchaudio_contrib/functional.py:48-113 (stft), :116-128 (complex_norm), :277-296 (amplitude_to_db).
 #include "host_common.hpp"
+#include "mel_lanes.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -43,29 +44,12 @@ struct Q4Tables {
     const cf* w400;             // [8][Q4_ROW]: W_400^{25 k1(l) + k2}
 };
 
-// The fused Melspectrogram form (MEL): the unit's |X|^p rows stay in LDS and are contracted with a band-sparse
-// filterbank there.  Lane l of a frame's eight owns bands l, 8 + l, 16 + l, ... (band slot i = band / 8); every band is
-// S four-tap steps (S = the longest band of the bank, a template parameter; shorter bands zero-padded, first bins
-// rounded down to a multiple of four, runs that would leave the 204-float row shifted down): one 16-byte weight read,
-// one 16-byte row read and two packed FMAs per step.  The contraction is latency, not work (a first version with one
-// LDS round trip per step took a third of the kernel): slots are processed in groups of q4_group(S) whose 2·S·group
-// reads are all issued before the first FMA, and a group's first bins are read one group earlier.
-// pack_n400 builds:  desc = first bin [slot][lane], wpack = [slot][step][lane][4 taps], both zero-padded to whole groups
-// plus one.
-struct Q4Mel {
-    const float* wpack;
-    const int* desc;
-    int nslot, wtot, n_mels, db;
-    float amin, log10_ref;
-    float* out;                 // [rows][T][n_mels]
-};
-constexpr int Q4_MEL_PITCH = 204;                                    // floats between the power rows of the fused form (16-byte aligned rows)
-constexpr int Q4_MEL_OFF = Q4_G * Q4_MEL_PITCH + 8;                  // the mel rows are staged behind the power rows
-constexpr int Q4_MAX_MELS = 128, Q4_MAX_SLOTS = Q4_MAX_MELS / 8, Q4_MAX_STEPS = 8;
-__host__ __device__ constexpr int q4_group(int S) { return S <= 2 ? 8 : (S <= 4 ? 4 : (S <= 5 ? 3 : 2)); }       // slots per group: <= 16 steps in flight
-__host__ __device__ constexpr int q4_padded_slots(int nslot, int S) { return ((nslot + q4_group(S) - 1) / q4_group(S) + 1) * q4_group(S); }
-constexpr int Q4_DESC_INTS = 8 * (Q4_MAX_SLOTS + 8);
-static_assert(Q4_MEL_OFF + 4 + Q4_G * Q4_MAX_MELS <= Q4_STAGE, "mel rows fit the staging area");
+// The fused Melspectrogram form (MEL): the unit's |X|^p rows stay in LDS (204-float pitch) and are contracted with a
+// band-sparse filterbank there by the frame's eight lanes (mel_lanes.hpp); the mel rows are staged behind them.
+constexpr int Q4_MEL_PITCH = 204;
+constexpr int Q4_FLY = 16;                                            // contraction steps in flight (128 registers)
+constexpr int Q4_MEL_OFF = Q4_G * Q4_MEL_PITCH + 8;
+static_assert(Q4_MEL_OFF + 4 + Q4_G * LM_MAX_MELS <= Q4_STAGE, "mel rows fit the staging area");
 
 __host__ __device__ constexpr int q4_e_of(int l) { return l < 4 ? l : 11 - l; }
 __host__ __device__ constexpr int q4_bitrev3(int e) { return ((e & 1) << 2) | (e & 2) | ((e >> 2) & 1); }
@@ -141,7 +125,7 @@ __device__ __forceinline__ void q4_read_row(const cf* row, cf (&r)[Q4_M]) {
 
 template <int MODE, bool MEL, int S>
 __global__ void __launch_bounds__(Q4_WAVES * 64, 2)
-stft_n400_kernel(FrameGeom g, Q4Tables tb, StftEpilogue ep, Q4Mel mel) {
+stft_n400_kernel(FrameGeom g, Q4Tables tb, StftEpilogue ep, LaneMel mel) {
     constexpr int LENF = (MODE == 0 ? 2 : 1) * Q4_BINS;
     constexpr int STAGE = Q4_STAGE;                                        // floats per wave
     constexpr int NST = (((Q4_G * LENF) >> 2) + 63) / 64;                  // 16-byte wave-stores per unit
@@ -159,11 +143,8 @@ stft_n400_kernel(FrameGeom g, Q4Tables tb, StftEpilogue ep, Q4Mel mel) {
     cf* const w400l = tabs + 16 * Q4_ROW;
     unsigned* const next_unit = reinterpret_cast<unsigned*>(tabs + 24 * Q4_ROW);
     int* const mlo = reinterpret_cast<int*>(next_unit + 4);                // MEL: first bins [slot][lane]; the weights
-    float* const mwl = reinterpret_cast<float*>(mlo + Q4_DESC_INTS);
-    if constexpr (MEL) {
-        for (int i = threadIdx.x; i < 8 * q4_padded_slots(mel.nslot, S); i += Q4_WAVES * 64) mlo[i] = mel.desc[i];
-        for (int i = threadIdx.x; i < mel.wtot; i += Q4_WAVES * 64) mwl[i] = mel.wpack[i];
-    }
+    float* const mwl = reinterpret_cast<float*>(mlo + lm_desc_ints(8));
+    if constexpr (MEL) lane_mel_load_tables<S, 8, Q4_FLY>(mlo, mwl, mel, threadIdx.x, Q4_WAVES * 64);
     for (int i = threadIdx.x; i < 8 * Q4_ROW; i += Q4_WAVES * 64) {
         const int ll = i / Q4_ROW, m = i - ll * Q4_ROW;
         const int ee = ll < 4 ? ll : 11 - ll;
@@ -316,70 +297,9 @@ stft_n400_kernel(FrameGeom g, Q4Tables tb, StftEpilogue ep, Q4Mel mel) {
             // band-sparse contraction of the frame's row, dB, mel rows staged behind the power rows
             const int am = (int)(g0 & 3);
             float* const mstage = wstage + Q4_MEL_OFF + am;
-            float* const mrow = mstage + slot * mel.n_mels;
-            const bool fast_db = mel.amin >= 1.1754944e-38f;               // (uniform) hardware log2 unless the clamp admits denormals
-            const float ten_log10_ref = 10.0f * mel.log10_ref;
-            if (l >= 1 && l <= 3) srow[200 + l] = 0.0f;                    // slack taps carry zero weights: keep them finite
+            lane_mel_contract<S, 8, Q4_FLY>(srow, Q4_BINS, mlo, mwl, l, mel, mstage + slot * mel.n_mels);
             wave_lds_fence();
-            constexpr int GS = q4_group(S);
-            int lo_g[GS];
-#pragma unroll
-            for (int q = 0; q < GS; ++q) lo_g[q] = mlo[8 * q + l];
-#pragma unroll 1
-            for (int i0 = 0; i0 < mel.nslot; i0 += GS) {
-                q4_f4 wv[GS][S], pv[GS][S];
-                const q4_f4* wp = reinterpret_cast<const q4_f4*>(mwl) + i0 * (S * 8) + l;
-#pragma unroll
-                for (int q = 0; q < GS; ++q) {
-                    const q4_f4* pp = reinterpret_cast<const q4_f4*>(srow + lo_g[q]);
-#pragma unroll
-                    for (int j = 0; j < S; ++j) {
-                        wv[q][j] = wp[(q * S + j) * 8];
-                        pv[q][j] = pp[j];
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < GS; ++q) lo_g[q] = mlo[8 * (i0 + GS + q) + l];          // the next group's (table padded by one group)
-#pragma unroll
-                for (int q = 0; q < GS; ++q) {
-                    cf acc0 = mkc(0.0f, 0.0f), acc1 = mkc(0.0f, 0.0f);
-#pragma unroll
-                    for (int j = 0; j < S; ++j) {
-                        acc0 = __builtin_elementwise_fma(mkc(wv[q][j].x, wv[q][j].y), mkc(pv[q][j].x, pv[q][j].y), acc0);
-                        acc1 = __builtin_elementwise_fma(mkc(wv[q][j].z, wv[q][j].w), mkc(pv[q][j].z, pv[q][j].w), acc1);
-                    }
-                    float val = (acc0.x + acc0.y) + (acc1.x + acc1.y);
-                    if (mel.db) val = fast_db ? amp_to_db_fast(val, mel.amin, ten_log10_ref) : amp_to_db(val, mel.amin, mel.log10_ref);
-                    const int band = 8 * (i0 + q) + l;
-                    if (band < mel.n_mels) mrow[band] = val;
-                }
-            }
-            wave_lds_fence();
-            const int len = nlive * mel.n_mels;
-            float* const gdst = mel.out + g0;
-            const int npre = (4 - am) & 3;
-            const int nchunks = (len - npre) >> 2;
-            {
-                const int hmax = (npre > 1 ? npre : 1) - 1;
-                const int hi = lane < hmax ? lane : hmax;
-                gdst[hi] = mstage[hi];
-            }
-            const q4_f4* const s4 = reinterpret_cast<const q4_f4*>(mstage + npre);
-            q4_f4* const g4 = reinterpret_cast<q4_f4*>(gdst + npre);
-            const int last = nchunks - 1;                                  // >= 0: n_mels >= 8
-            // a FIXED number of unconditional stores (at most 8 x 128 floats = 4 wave-stores; surplus ones repeat the last
-            // chunk): the wait for the next unit's samples, requested before them, stays a counted vmcnt
-#pragma unroll
-            for (int i = 0; i < (Q4_G * Q4_MAX_MELS) / 256; ++i) {
-                const int c = (lane + 64 * i) < last ? (lane + 64 * i) : last;
-                __builtin_nontemporal_store(s4[c], g4 + c);
-            }
-            {
-                const int r = len - npre - 4 * nchunks;
-                const int rmax = (r > 1 ? r : 1) - 1;
-                const int ti = len - 1 - (lane < rmax ? lane : rmax);
-                gdst[ti] = mstage[ti];
-            }
+            lane_mel_store<(Q4_G * LM_MAX_MELS) / 256>(mstage, am, nlive * mel.n_mels, mel.out + g0, lane);
         } else {
         // the unit's live rows leave as 1 + NST + 1 unconditional nontemporal stores (lanes past the end repeat a neighbour)
         const int len = nlive * LENF;
@@ -411,10 +331,9 @@ stft_n400_kernel(FrameGeom g, Q4Tables tb, StftEpilogue ep, Q4Mel mel) {
     }
 }
 
-// dynamic LDS of the kernel: staging areas, the three tables, the unit counter, and (MEL) the packed weights
-static size_t q4_lds_bytes(int wtot) {
-    return (size_t)Q4_WAVES * Q4_STAGE * sizeof(float) + (size_t)24 * Q4_ROW * sizeof(cf) + 16 +
-           (size_t)Q4_DESC_INTS * sizeof(int) + (((size_t)wtot + 3) & ~(size_t)3) * sizeof(float);
+// dynamic LDS of the kernel: staging areas, the three tables, the unit counter (the fused form adds lm_lds_bytes)
+static size_t q4_lds_bytes(int) {
+    return (size_t)Q4_WAVES * Q4_STAGE * sizeof(float) + (size_t)24 * Q4_ROW * sizeof(cf) + 16;
 }
 
 // device tables, one set per device
@@ -457,16 +376,16 @@ static int launch_n400(const FrameGeom& g, const Q4Tables& tb, const StftEpilogu
     if (blocks > cap) blocks = cap;
     auto kern = stft_n400_kernel<MODE, false, 1>;
     if (bytes > 64 * 1024) TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes));
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Q4_WAVES * 64), bytes, stream, g, tb, ep, Q4Mel{});
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Q4_WAVES * 64), bytes, stream, g, tb, ep, LaneMel{});
     TAC_HIP(hipGetLastError());
     return TAC_OK;
 }
 
 template <int MODE, int S>
-static int launch_n400_mel_mode(const FrameGeom& g, const Q4Tables& tb, const Q4Mel& mel, hipStream_t stream) {
+static int launch_n400_mel_mode(const FrameGeom& g, const Q4Tables& tb, const LaneMel& mel, hipStream_t stream) {
     const long long units = g.rows * ((g.n_frames + Q4_G - 1) / Q4_G);
     if (units >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
-    const size_t bytes = q4_lds_bytes(mel.wtot);
+    const size_t bytes = q4_lds_bytes(0) + lm_lds_bytes(8, mel.wtot);
     if (bytes > 160 * 1024) return TAC_E_UNSUPPORTED;
     long long blocks = (units + Q4_WAVES - 1) / Q4_WAVES;
     const long long cap = (long long)device_cu_count();
@@ -482,70 +401,28 @@ static int launch_n400_mel_mode(const FrameGeom& g, const Q4Tables& tb, const Q4
 // The fused Melspectrogram (+dB) chain for fft_length 400 (melspec_sparse.hip's entry points call these).
 int launch_n400_mel(const FrameGeom& g, float power, const float* wpack, const int* desc, const int32_t* info_host,
                     int n_mels, int db, float amin, float log10_ref, float* out, hipStream_t stream) {
-    if (info_host[2] != 8 || info_host[1] < 1 || info_host[1] > Q4_MAX_SLOTS || info_host[4] < 1 || info_host[4] > Q4_MAX_STEPS ||
-        info_host[0] != 32 * info_host[4] * q4_padded_slots(info_host[1], info_host[4])) return TAC_E_INVALID;
-    if (n_mels < 8 || n_mels > Q4_MAX_MELS) return TAC_E_UNSUPPORTED;
+    if (!lane_mel_info_ok(info_host, 8, Q4_FLY)) return TAC_E_INVALID;
+    if (n_mels < LM_MIN_MELS || n_mels > LM_MAX_MELS) return TAC_E_UNSUPPORTED;
     Q4Tables tb;
     const int rc = q4_tables(&tb);
     if (rc != TAC_OK) return rc;
-    const Q4Mel mel{wpack, desc, info_host[1], info_host[0], n_mels, db, amin, log10_ref, out};
+    const LaneMel mel{wpack, desc, info_host[1], info_host[0], n_mels, db, amin, log10_ref, out};
     const bool p2 = power == 2.0f;
     switch (info_host[4]) {                                                // steps per band
 #define TAC_Q4_CASE(SS) case SS: return p2 ? launch_n400_mel_mode<1, SS>(g, tb, mel, stream) : launch_n400_mel_mode<2, SS>(g, tb, mel, stream);
         TAC_Q4_CASE(1) TAC_Q4_CASE(2) TAC_Q4_CASE(3) TAC_Q4_CASE(4) TAC_Q4_CASE(5) TAC_Q4_CASE(6) TAC_Q4_CASE(7) TAC_Q4_CASE(8)
+        TAC_Q4_CASE(9) TAC_Q4_CASE(10) TAC_Q4_CASE(11) TAC_Q4_CASE(12)
 #undef TAC_Q4_CASE
         default: return TAC_E_INVALID;
     }
 }
 
-// Band-slot layout of the fused form (see Q4Mel).  h: the (n_freqs x n_mels) bank on the host.
+// Band-slot layout of the fused form (mel_lanes.hpp).  h: the (n_freqs x n_mels) bank on the host.
 int pack_n400(const std::vector<float>& h, int n_freqs, int n_mels, float* wpack, int wpack_cap, int32_t* desc,
               int desc_cap, int32_t* info_host, hipStream_t stream) {
-    if (n_freqs != Q4_BINS || n_mels < 8 || n_mels > Q4_MAX_MELS) return TAC_E_UNSUPPORTED;
-    const int nslot = (n_mels + 7) / 8;
-    std::vector<int> lo(nslot * 8, 0), hi(nslot * 8, 0);
-    int S = 1;
-    for (int m = 0; m < n_mels; ++m) {
-        int l0 = n_freqs, h0 = 0;
-        for (int f = 0; f < n_freqs; ++f)
-            if (h[(size_t)f * n_mels + m] != 0.0f) { l0 = f < l0 ? f : l0; h0 = f + 1; }
-        if (h0 > l0) {
-            lo[m] = l0;
-            hi[m] = h0;
-            S = std::max(S, (h0 - (l0 & ~3) + 3) / 4);
-        }
-    }
-    if (S > Q4_MAX_STEPS) return TAC_E_UNSUPPORTED;                        // bands wider than 32 bins: the unfused chain
-    const int pslot = q4_padded_slots(nslot, S);
-    if (8 * pslot > desc_cap || 8 * pslot > Q4_DESC_INTS) return TAC_E_UNSUPPORTED;
-    const long long wtot = 32LL * S * pslot;
-    if (wtot > wpack_cap || q4_lds_bytes((int)wtot) > 160 * 1024) return TAC_E_UNSUPPORTED;      // not band-sparse enough
-    std::vector<float> wp((size_t)wtot, 0.0f);
-    std::vector<int32_t> dd((size_t)8 * pslot, 0);
-    for (int i = 0; i < nslot; ++i) {
-        for (int l = 0; l < 8; ++l) {
-            const int m = 8 * i + l;
-            int first = lo[m] & ~3;
-            if (first + 4 * S > Q4_MEL_PITCH) first = Q4_MEL_PITCH - 4 * S;                   // keep the padded run inside the row
-            for (int j = 0; j < S; ++j)
-                for (int u = 0; u < 4; ++u) {
-                    const int bin = first + 4 * j + u;
-                    const bool live = m < n_mels && bin >= lo[m] && bin < hi[m];
-                    wp[(((size_t)i * S + j) * 8 + l) * 4 + u] = live ? h[(size_t)bin * n_mels + m] : 0.0f;
-                }
-            dd[8 * i + l] = first;
-        }
-    }
-    TAC_HIP(hipMemcpyAsync(wpack, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice, stream));
-    TAC_HIP(hipMemcpyAsync(desc, dd.data(), dd.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-    TAC_HIP(hipStreamSynchronize(stream));
-    info_host[0] = (int32_t)wtot;
-    info_host[1] = nslot;
-    info_host[2] = 8;
-    info_host[3] = S * nslot;
-    info_host[4] = S;
-    for (int i = 5; i < 8; ++i) info_host[i] = 0;
-    return TAC_OK;
+    if (n_freqs != Q4_BINS) return TAC_E_UNSUPPORTED;
+    return pack_lane_mel(h, n_freqs, n_mels, 8, Q4_MEL_PITCH, 1, Q4_FLY, q4_lds_bytes(0), wpack, wpack_cap, desc, desc_cap, info_host,
+                         stream);
 }
 
 // Entry used by stft_kernels.hip's dispatcher: TAC_E_UNSUPPORTED when this form does not apply (two-sided output,

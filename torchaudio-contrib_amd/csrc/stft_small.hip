@@ -8,15 +8,22 @@
 // 16-byte stores; a unit with frames in the padding, or past the end of its row, takes the gather path and clamps
 // its run to the live rows.
 #include "host_common.hpp"
+#include "mel_lanes.hpp"
 
 namespace tac {
 
 constexpr int SM_WAVES = 8;    // one workgroup per CU; its waves draw units from a workgroup counter (see stft_pipe_kernel)
 typedef float sm_f4 __attribute__((ext_vector_type(4)));
 
-template <int NC, int MODE>
+// MEL: the fused Melspectrogram (-> AmplitudeToDb) form — the unit's |X|^p rows stay in LDS (pitch sm_mel_pitch) and
+// are contracted with a band-sparse filterbank there by the frame's LPF lanes (mel_lanes.hpp, S steps per band); the
+// mel rows are staged behind them and stored instead of the spectrogram rows.
+__host__ __device__ constexpr int sm_mel_pitch(int nc) { return (nc + 1 + 3 + 3) & ~3; }
+constexpr int SM_FLY = 6;       // contraction steps in flight: this kernel keeps its twiddles in registers, 48 more is what fits
+
+template <int NC, int MODE, bool MEL, int S>
 __global__ void __launch_bounds__(SM_WAVES * 64, 2)
-stft_small_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
+stft_small_kernel(FrameGeom g, Tables tb, StftEpilogue ep, LaneMel mel) {
     constexpr int E = 16;
     using F = WaveFft<NC, E>;
     constexpr int LPF = F::LPF, G = F::G;
@@ -67,6 +74,11 @@ stft_small_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
     };
     unsigned* const next_unit = reinterpret_cast<unsigned*>(wlds + LPF * WROW);
     if (threadIdx.x == 0) *next_unit = (unsigned)(begin + SM_WAVES);
+    constexpr int PITCH = sm_mel_pitch(NC), MEL_OFF = G * PITCH + 8;
+    static_assert(!MEL || MEL_OFF + 4 + G * LM_MAX_MELS <= 2 * WAVE_SLOTS, "mel rows fit the wave's area");
+    int* const mlo = reinterpret_cast<int*>(next_unit + 4);                // MEL: first bins [slot][lane]; the weights
+    float* const mwl = reinterpret_cast<float*>(mlo + lm_desc_ints(LPF));
+    if constexpr (MEL) lane_mel_load_tables<S, LPF, SM_FLY>(mlo, mwl, mel, threadIdx.x, SM_WAVES * 64);
     auto grab = [&]() -> int {
         unsigned v = 0;
         if (lane == 0) v = __hip_atomic_fetch_add(next_unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -107,10 +119,10 @@ stft_small_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
         }
         __builtin_amdgcn_sched_barrier(0);
 
-        const long long g0 = ((long long)urow * T + uframe0) * LENF;
-        const int a = (int)(g0 & 3);
+        const long long g0 = ((long long)urow * T + uframe0) * (MEL ? mel.n_mels : LENF);
+        const int a = MEL ? 0 : (int)(g0 & 3);
         float* const stage = reinterpret_cast<float*>(wbase) + a;        // LDS and global share their 16-byte phase
-        float* const srow = stage + sub * LENF;
+        float* const srow = stage + sub * (MEL ? PITCH : LENF);
         {
             cf xa[F::NPAIR], xb[F::NPAIR], xm, unused;
 #pragma unroll
@@ -145,8 +157,18 @@ stft_small_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
             }
             wave_lds_fence();
         }
-        // the unit's live rows leave as 1 + NST + 1 unconditional nontemporal stores (lanes past the end repeat a neighbour)
         const int nlive = (T - uframe0) < G ? (T - uframe0) : G;
+        if constexpr (MEL) {
+            const int am = (int)(g0 & 3);
+            float* const mstage = reinterpret_cast<float*>(wbase) + MEL_OFF + am;
+            lane_mel_contract<S, LPF, SM_FLY>(srow, NC + 1, mlo, mwl, t, mel, mstage + sub * mel.n_mels);
+            wave_lds_fence();
+            lane_mel_store<(G * LM_MAX_MELS + 255) / 256>(mstage, am, nlive * mel.n_mels, mel.out + g0, lane);
+            wave_lds_fence();   // next iteration's first-pass writes must follow these reads
+            unit = nxt;
+            continue;
+        }
+        // the unit's live rows leave as 1 + NST + 1 unconditional nontemporal stores (lanes past the end repeat a neighbour)
         const int len = nlive * LENF;
         float* const gdst = ep.out + g0;
         const int npre = (4 - a) & 3;
@@ -185,11 +207,68 @@ static int launch_small(const FrameGeom& g, const Tables& tb, const StftEpilogue
     long long blocks = (units + SM_WAVES - 1) / SM_WAVES;
     const long long cap = (long long)device_cu_count();
     if (blocks > cap) blocks = cap;
-    auto kern = stft_small_kernel<NC, MODE>;
+    auto kern = stft_small_kernel<NC, MODE, false, 1>;
     if (bytes > 64 * 1024) TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes));
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SM_WAVES * 64), bytes, stream, g, tb, ep);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SM_WAVES * 64), bytes, stream, g, tb, ep, LaneMel{});
     TAC_HIP(hipGetLastError());
     return TAC_OK;
+}
+
+template <int NC>
+static size_t small_lds_bytes() {
+    using F = WaveFft<NC, 16>;
+    constexpr int WAVE_SLOTS = ((F::G * F::PADDED + 1) / 2) * 2;
+    return (size_t)SM_WAVES * WAVE_SLOTS * sizeof(cf) + (size_t)F::LPF * 18 * sizeof(cf) + 16;
+}
+
+template <int NC, int MODE, int S>
+static int launch_small_mel(const FrameGeom& g, const Tables& tb, const LaneMel& mel, hipStream_t stream) {
+    using F = WaveFft<NC, 16>;
+    const long long units = g.rows * ((g.n_frames + F::G - 1) / F::G);
+    if (units >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
+    const size_t bytes = small_lds_bytes<NC>() + lm_lds_bytes(F::LPF, mel.wtot);
+    if (bytes > 160 * 1024) return TAC_E_UNSUPPORTED;
+    long long blocks = (units + SM_WAVES - 1) / SM_WAVES;
+    const long long cap = (long long)device_cu_count();
+    if (blocks > cap) blocks = cap;
+    auto kern = stft_small_kernel<NC, MODE, true, S>;
+    if (bytes > 64 * 1024) TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SM_WAVES * 64), bytes, stream, g, tb,
+                       StftEpilogue{nullptr, 1, 1, MODE == 1 ? 2.0f : 1.0f, 0, 0.0f, 0.0f}, mel);
+    TAC_HIP(hipGetLastError());
+    return TAC_OK;
+}
+
+template <int NC>
+static int launch_small_mel_nc(const FrameGeom& g, const Tables& tb, float power, const LaneMel& mel, int S, hipStream_t stream) {
+    const bool p2 = power == 2.0f;
+    switch (S) {                                                           // steps per band (pack_small: even values)
+#define TAC_SM_CASE(SS) case SS: return p2 ? launch_small_mel<NC, 1, SS>(g, tb, mel, stream) : launch_small_mel<NC, 2, SS>(g, tb, mel, stream);
+        TAC_SM_CASE(2) TAC_SM_CASE(4) TAC_SM_CASE(6) TAC_SM_CASE(8) TAC_SM_CASE(10) TAC_SM_CASE(12)
+#undef TAC_SM_CASE
+        default: return TAC_E_INVALID;
+    }
+}
+
+// The fused Melspectrogram (+dB) chain for fft_length 512 / 1024 (melspec_sparse.hip's entry points call these).
+int launch_small_mel_entry(int n_fft, const FrameGeom& g, const Tables& tb, float power, const float* wpack, const int* desc,
+                           const int32_t* info_host, int n_mels, int db, float amin, float log10_ref, float* out,
+                           hipStream_t stream) {
+    const int lanes = n_fft == 512 ? 16 : 32;
+    if ((n_fft != 512 && n_fft != 1024) || !lane_mel_info_ok(info_host, lanes, SM_FLY)) return TAC_E_INVALID;
+    if (n_mels < LM_MIN_MELS || n_mels > LM_MAX_MELS) return TAC_E_UNSUPPORTED;
+    const LaneMel mel{wpack, desc, info_host[1], info_host[0], n_mels, db, amin, log10_ref, out};
+    return n_fft == 512 ? launch_small_mel_nc<256>(g, tb, power, mel, info_host[4], stream)
+                        : launch_small_mel_nc<512>(g, tb, power, mel, info_host[4], stream);
+}
+
+int pack_small(int n_fft, const std::vector<float>& h, int n_freqs, int n_mels, float* wpack, int wpack_cap, int32_t* desc,
+               int desc_cap, int32_t* info_host, hipStream_t stream) {
+    if ((n_fft != 512 && n_fft != 1024) || n_freqs != n_fft / 2 + 1) return TAC_E_UNSUPPORTED;
+    const int lanes = n_fft == 512 ? 16 : 32;
+    const size_t base = n_fft == 512 ? small_lds_bytes<256>() : small_lds_bytes<512>();
+    return pack_lane_mel(h, n_freqs, n_mels, lanes, sm_mel_pitch(n_fft / 2), 2, SM_FLY, base, wpack, wpack_cap, desc, desc_cap,
+                         info_host, stream);
 }
 
 template <int NC>
