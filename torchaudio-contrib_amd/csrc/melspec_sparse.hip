@@ -492,11 +492,40 @@ static int pack_lanes(const std::vector<float>& h, int n_freqs, int n_mels, floa
     const long long wtot = 256LL * total_steps;
     if (wtot > wpack_cap || stream_lds_bytes<1024, 16>((int)wtot) > 160 * 1024) return TAC_E_UNSUPPORTED;
     std::vector<float> wp((size_t)wtot, 0.0f);
+#ifndef TAC_ST_BANK_GROUP
+#define TAC_ST_BANK_GROUP 8   // lanes whose 16-byte row reads should fall into different bank groups (0: no bank-aware placement)
+#endif
+    // Bank-aware placement: a slot runs more steps than most of its bands need, so a band's run may start up to that
+    // many quads earlier (zero weights in front).  Within every group of lanes that the LDS serves together, the starts
+    // are moved so that the 16-byte reads hit different bank groups (equal starts are one broadcast address).
+    std::vector<int> start(lo);
+    if (TAC_ST_BANK_GROUP > 0) {
+        constexpr int GB = TAC_ST_BANK_GROUP > 0 ? TAC_ST_BANK_GROUP : 1;
+        for (int s = 0; s < nslot; ++s)
+            for (int l0 = 0; l0 < 64; l0 += GB) {
+                bool used[8] = {false, false, false, false, false, false, false, false};
+                std::vector<int> taken;
+                for (int l = l0; l < l0 + GB && l < 64; ++l) {
+                    const int m = s * 64 + l;
+                    const int slack = std::min(steps[s] - (len[m] + 3) / 4, lo[m] / 4);
+                    int best = lo[m];
+                    bool placed = false;
+                    for (int d = 0; d <= slack && !placed; ++d) {
+                        const int cand = lo[m] - 4 * d;
+                        const bool same = std::find(taken.begin(), taken.end(), cand) != taken.end();
+                        if (same || !used[(cand / 4) & 7]) { best = cand; placed = true; }
+                    }
+                    start[m] = best;
+                    used[(best / 4) & 7] = true;
+                    taken.push_back(best);
+                }
+            }
+    }
     int base = 0;
     for (int s = 0; s < nslot; ++s) {
         for (int l = 0; l < 64; ++l) {
             const int m = s * 64 + l;
-            int first = lo[m];
+            int first = start[m];
             if (first + 4 * steps[s] > limit) first = (limit - 4 * steps[s]) & ~3;     // keep the padded run inside the row
             for (int j = 0; j < steps[s]; ++j)
                 for (int u = 0; u < 4; ++u) {
