@@ -326,20 +326,22 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         }
         wave_lds_fence();
     };
-    // FAST2 (two slots of 4 and 16 steps): the first eight steps' reads are issued right behind the row (end of s3) and
-    // ride along with the other frame's next stage; s4 finds them landed
-    auto s3_issue = [&](const float* prow, f4 (&cw)[ST_RIDE], f4 (&cp)[ST_RIDE]) {
+    // FAST2 (two slots of 4 and 16 steps): the first ten steps' reads are issued right behind the row (end of s3) and
+    // ride along with the other frame's next stage; s4 finds them landed.  The weights of those steps are read ONCE per
+    // pair of frames (B's issue): the paired rotation runs B.s4 and A.s4 back to back and both use the same weights, so
+    // A's issue (from inside B.s4) fetches its row only and A.s4 reuses B's weight registers.
+    auto s3_issue = [&](const float* prow, f4 (&cw)[ST_RIDE], f4 (&cp)[ST_RIDE], bool with_weights) {
         const f4* wp = reinterpret_cast<const f4*>(wlds) + lane;
         const f4* p0 = reinterpret_cast<const f4*>(prow + lo_s[0]);
         const f4* p1 = reinterpret_cast<const f4*>(prow + lo_s[1]);
 #pragma unroll
         for (int u = 0; u < ST_FAST_STEPS0; ++u) {
-            cw[u] = wp[u * 64];
+            if (with_weights) cw[u] = wp[u * 64];
             cp[u] = p0[u];
         }
 #pragma unroll
         for (int u = 0; u < TAC_ST_RIDE1; ++u) {
-            cw[ST_FAST_STEPS0 + u] = wp[(ST_FAST_STEPS0 + u) * 64];
+            if (with_weights) cw[ST_FAST_STEPS0 + u] = wp[(ST_FAST_STEPS0 + u) * 64];
             cp[ST_FAST_STEPS0 + u] = p1[u];
         }
     };
@@ -458,7 +460,7 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         unsigned askA = 0, askB = 0;
         constexpr bool EARLY = FAST2 && TAC_ST_EARLYREQ != 0;
         cf tw1[16];
-        f4 cwA[ST_RIDE], cpA[ST_RIDE], cwB[ST_RIDE], cpB[ST_RIDE];
+        f4 cw[ST_RIDE], cpA[ST_RIDE], cpB[ST_RIDE];
         request(vB, iB, modeB, rowB_, frB);
         request(vA, iA, modeA, rowA_, frA);
         s0(vB, modeB, rowB_, frB);
@@ -483,7 +485,7 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             ST_MARK(2);
             s3(vB, zmB, zmidB, rowB);
             if constexpr (FAST2) {
-                s3_issue(rowB, cwB, cpB);
+                s3_issue(rowB, cw, cpB, true);
                 if constexpr (!EARLY) askB = grab_ask();
             } else {
                 nB = grab();
@@ -499,8 +501,8 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(4);
             if constexpr (FAST2) {
-                s4_fast(rowB, iB, cwB, cpB, [&]() {
-                    s3_issue(rowA, cwA, cpA);
+                s4_fast(rowB, iB, cw, cpB, [&]() {
+                    s3_issue(rowA, cw, cpA, false);
                     if constexpr (!EARLY) askA = grab_ask();
                 });
                 if constexpr (EARLY) {
@@ -516,7 +518,7 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(5);
             if constexpr (FAST2) {
-                s4_fast(rowA, iA, cwA, cpA, []() {});
+                s4_fast(rowA, iA, cw, cpA, []() {});
                 if constexpr (EARLY) {
                     iA = nA;
                 } else {
