@@ -167,6 +167,18 @@ __device__ __forceinline__ void dft4(cf& a0, cf& a1, cf& a2, cf& a3) {
     a2 = csub(s02, s13);
     a3 = csub_rot(d02, d13);
 }
+// the same butterfly on lane-wise WINDOWED inputs x_i ∘ w_i: the window products are folded into the first stage
+// (one multiply + two FMAs per pair instead of two multiplies, an add and a subtract)
+__device__ __forceinline__ void dft4_windowed(cf& a0, cf& a1, cf& a2, cf& a3, cf w0, cf w1, cf w2, cf w3) {
+    const cf t0 = cmul_elem(a0, w0), t1 = cmul_elem(a1, w1);
+    const cf nw2 = mkc(-w2.x, -w2.y), nw3 = mkc(-w3.x, -w3.y);
+    cf s02 = __builtin_elementwise_fma(a2, w2, t0), d02 = __builtin_elementwise_fma(a2, nw2, t0);
+    cf s13 = __builtin_elementwise_fma(a3, w3, t1), d13 = __builtin_elementwise_fma(a3, nw3, t1);
+    a0 = cadd(s02, s13);
+    a1 = cadd_rot(d02, d13);
+    a2 = csub(s02, s13);
+    a3 = csub_rot(d02, d13);
+}
 // the same butterfly when input a2 still carries a pending factor (-i): a2 <- (-i)·a2 folded into the first stage
 __device__ __forceinline__ void dft4_rot2(cf& a0, cf& a1, cf& a2, cf& a3) {
     cf s02 = cadd_rot(a0, a2), d02 = csub_rot(a0, a2);
@@ -240,12 +252,17 @@ struct Dft<8> {
 template <>
 struct Dft<16> {
     // n = c + 4d, k = r + 4k':  X[r+4k'] = sum_c W4^{ck'} W16^{cr} (sum_d x[c+4d] W4^{dr})
-    __device__ static __forceinline__ void run(cf* v) {
+    __device__ static __forceinline__ void run(cf* v) { run_impl<false>(v, nullptr); }
+    // v holds raw samples, win[e] the lane's window pair of element e: transforms v ∘ win
+    __device__ static __forceinline__ void run_windowed(cf* v, const cf* win) { run_impl<true>(v, win); }
+    template <bool WINDOWED>
+    __device__ static __forceinline__ void run_impl(cf* v, const cf* win) {
         cf a[4][4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             a[c][0] = v[c]; a[c][1] = v[c + 4]; a[c][2] = v[c + 8]; a[c][3] = v[c + 12];
-            dft4(a[c][0], a[c][1], a[c][2], a[c][3]);
+            if constexpr (WINDOWED) dft4_windowed(a[c][0], a[c][1], a[c][2], a[c][3], win[c], win[c + 4], win[c + 8], win[c + 12]);
+            else dft4(a[c][0], a[c][1], a[c][2], a[c][3]);
         }
         a[1][1] = mul_w16<1>(a[1][1]); a[1][2] = mul_w16<2>(a[1][2]); a[1][3] = mul_w16<3>(a[1][3]);
         a[2][1] = mul_w16<2>(a[2][1]); /* a[2][2]·W16^4 = -i: folded into column 2's butterfly */ a[2][3] = mul_w16<6>(a[2][3]);

@@ -43,6 +43,9 @@ constexpr int ST_FAST_STEPS0 = 4, ST_FAST_STEPS1 = 16;   // slot lengths of the 
 #ifndef TAC_ST_EARLYREQ
 #define TAC_ST_EARLYREQ 0    // FAST2: 1 = a thread's next samples are requested right behind its s3 (three stages ahead), 0 = behind its s4 (one); measured 0.1376 vs 0.1354 ms: the registers it takes from the ride-along reads cost more
 #endif
+#ifndef TAC_ST_WINFOLD
+#define TAC_ST_WINFOLD 1     // the window multiplies folded into pass 0's first butterflies (-8 packed instructions per frame; 0: A/B knob)
+#endif
 #ifndef TAC_ST_BATCH
 #define TAC_ST_BATCH 5       // steps per round trip of the rest of slot 1 (a batch that no longer fits the registers spills: 8 + 6 -> 0.156 ms)
 #endif
@@ -256,7 +259,7 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     auto s0 = [&](cf (&v)[E], int mode, int row, long long fr) {
         if (mode == 1) {
             decode(v);
-            apply_window<F>(v, v, win);
+            if constexpr (!TAC_ST_WINFOLD) apply_window<F>(v, v, win);
         } else {                                                       // edge / unaligned frame: gathered through the exchange
             int tz;                                                    // (an opaque copy of the lane number: this rare path's
             asm volatile("v_mov_b32 %0, %1" : "=v"(tz) : "v"(t));      // address registers must not be hoisted out of the loop)
@@ -266,8 +269,10 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         }
     };
     typedef float f4 __attribute__((ext_vector_type(4)));
-    auto s0b = [&](cf (&v)[E]) {
-        F::template pass_butterflies<0>(v);
+    // (fast-path frames arrive unwindowed under TAC_ST_WINFOLD: the window is folded into pass 0's first butterflies)
+    auto s0b = [&](cf (&v)[E], int mode) {
+        if (TAC_ST_WINFOLD && mode == 1) Dft<16>::run_windowed(v, win);
+        else F::template pass_butterflies<0>(v);
         wave_lds_fence();
         F::template pass_write<0, true>(v, xa, t, t);
         wave_lds_fence();
@@ -464,13 +469,13 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         request(vB, iB, modeB, rowB_, frB);
         request(vA, iA, modeA, rowA_, frA);
         s0(vB, modeB, rowB_, frB);
-        s0b(vB);
+        s0b(vB, modeB);
         __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0): the loop is entered with nothing in flight
         ST_MARK(6);
 #pragma unroll 1
         while (iA < nloc || iB < nloc) {
             s0(vA, modeA, rowA_, frA);
-            s0b(vA);
+            s0b(vA, modeA);
             tw1_issue(tw1);
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(1);
@@ -532,7 +537,7 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(5);
             s0(vB, modeB, rowB_, frB);
-            s0b(vB);
+            s0b(vB, modeB);
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(1);
 #if TAC_ST_TIMING
