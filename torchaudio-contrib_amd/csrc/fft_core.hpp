@@ -79,6 +79,19 @@ __device__ __forceinline__ cf cmul(cf a, cf w) {
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
     return r;
 }
+// two independent products a·wa, b·wb with their instruction pairs interleaved: gfx950 needs a wait state between a
+// packed op and a dependent packed op that follows it directly, and hipcc fills it with an s_nop (an issue slot) when
+// the two asm statements of one cmul stay adjacent
+__device__ __forceinline__ void cmul_x2(cf& a, cf wa, cf& b, cf wb) {
+    cf t1, t2, r1, r2;
+    asm("v_pk_mul_f32 %0, %4, %5 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %1, %6, %7 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %2, %4, %5, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+        "v_pk_fma_f32 %3, %6, %7, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=&v"(t1), "=&v"(t2), "=&v"(r1), "=&v"(r2) : "v"(a), "v"(wa), "v"(b), "v"(wb));
+    a = r1;
+    b = r2;
+}
 // w · (-i·d): the R2C split's twiddled odd part, d = zk - conj(zm)
 __device__ __forceinline__ cf cmul_rot(cf w, cf d) {
     cf t, r;
@@ -93,6 +106,31 @@ __device__ __forceinline__ cf power_pair(cf a, cf b) {
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]" : "=v"(re) : "v"(a), "v"(b));
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1] neg_hi:[0,1]" : "=v"(im) : "v"(a), "v"(b));
     return __builtin_elementwise_fma(im, im, re * re);
+}
+// (|2X[k]|^2, |2X[NC-k]|^2) of TWO R2C pairs (zk, zm, wk) at once, the sixteen packed instructions interleaved so that no
+// instruction directly follows its producer (see cmul_x2):  ev = zk + conj(zm), d = zk - conj(zm), tw = wk·(-i·d),
+// power_pair(ev, tw)
+__device__ __forceinline__ void r2c_power_pair_x2(cf zk1, cf zm1, cf w1, cf zk2, cf zm2, cf w2, cf& p1, cf& p2) {
+    cf ev1, ev2, d1, d2, t1, t2, tw1, tw2, re1, re2, im1, im2, q1, q2;
+    asm("v_pk_add_f32 %0, %16, %17 neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %1, %19, %20 neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %2, %16, %17 neg_lo:[0,1]\n\t"
+        "v_pk_add_f32 %3, %19, %20 neg_lo:[0,1]\n\t"
+        "v_pk_mul_f32 %4, %2, %18 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_mul_f32 %5, %3, %21 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_fma_f32 %6, %2, %18, %4 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %7, %3, %21, %5 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[0,1,0]\n\t"
+        "v_pk_add_f32 %8, %0, %6 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %9, %1, %7 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %10, %0, %6 op_sel:[1,1] op_sel_hi:[1,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %11, %1, %7 op_sel:[1,1] op_sel_hi:[1,1] neg_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %12, %8, %8\n\t"
+        "v_pk_mul_f32 %13, %9, %9\n\t"
+        "v_pk_fma_f32 %14, %10, %10, %12\n\t"
+        "v_pk_fma_f32 %15, %11, %11, %13"
+        : "=&v"(ev1), "=&v"(ev2), "=&v"(d1), "=&v"(d2), "=&v"(t1), "=&v"(t2), "=&v"(tw1), "=&v"(tw2), "=&v"(re1), "=&v"(re2),
+          "=&v"(im1), "=&v"(im2), "=&v"(q1), "=&v"(q2), "=&v"(p1), "=&v"(p2)
+        : "v"(zk1), "v"(zm1), "v"(w1), "v"(zk2), "v"(zm2), "v"(w2));
 }
 // a · (C + iS) with compile-time C, S: the constant pairs live in SGPRs
 __device__ __forceinline__ cf cmulc(cf a, float C, float S) { return mkc(a.x, a.x) * mkc(C, S) + mkc(a.y, a.y) * mkc(-S, C); }
@@ -410,11 +448,19 @@ struct WaveFft {
         constexpr int R = radix_at(NC, P), OFF = REL ? 0 : twiddles_before(NC, E, P), NB = E / R;
         if constexpr (P > 0) {
 #pragma unroll
-            for (int b = 0; b < NB; ++b)
+            for (int b = 0; b < NB; ++b) {
+                const cf* twb = tw + OFF + (pass_shares_twiddles(NC, E, P) ? 0 : b) * (R - 1);
 #pragma unroll
-                for (int q = 1; q < R; ++q)
-                    v[b * R + q] = cmul(last_pass_const<P>(v[b * R + q], b * q * (32 / E)),
-                                        tw[OFF + (pass_shares_twiddles(NC, E, P) ? 0 : b) * (R - 1) + q - 1]);
+                for (int q = 1; q < R; ++q) v[b * R + q] = last_pass_const<P>(v[b * R + q], b * q * (32 / E));
+                if constexpr (TAC_PACKED) {                      // products in interleaved pairs (cmul_x2)
+#pragma unroll
+                    for (int q = 1; q + 1 < R; q += 2) cmul_x2(v[b * R + q], twb[q - 1], v[b * R + q + 1], twb[q]);
+                    if constexpr (((R - 1) & 1) != 0) v[b * R + R - 1] = cmul(v[b * R + R - 1], twb[R - 2]);
+                } else {
+#pragma unroll
+                    for (int q = 1; q < R; ++q) v[b * R + q] = cmul(v[b * R + q], twb[q - 1]);
+                }
+            }
         }
     }
     template <int P>

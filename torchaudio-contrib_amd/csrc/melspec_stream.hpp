@@ -317,13 +317,24 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     // s3: R2C split, |X|^p row into the thread's row buffer
     auto s3 = [&](cf (&v)[E], cf (&zm)[F::NPAIR], cf zmid, float* prow) {
         wave_lds_fence();
+        static_assert(F::NPAIR % 2 == 0, "R2C pairs are processed two at a time");
 #pragma unroll
-        for (int p = 0; p < F::NPAIR; ++p) {
-            const int kk = t + p * F::LPF;
-            const cf pw = FULLPTW ? F::r2c_power_x2(v[F::reg_of_spectrum(p)], zm[p], ptw[p])
-                                  : F::r2c_power_factored_x2(v[F::reg_of_spectrum(p)], zm[p], w0, p);
+        for (int p = 0; p < F::NPAIR; p += 2) {
+            const int kk = t + p * F::LPF, kk2 = kk + F::LPF;
+            cf pw, pw2;
+            if constexpr (FULLPTW && TAC_PACKED) {
+                r2c_power_pair_x2(v[F::reg_of_spectrum(p)], zm[p], ptw[p], v[F::reg_of_spectrum(p + 1)], zm[p + 1], ptw[p + 1], pw, pw2);
+            } else if constexpr (FULLPTW) {
+                pw = F::r2c_power_x2(v[F::reg_of_spectrum(p)], zm[p], ptw[p]);
+                pw2 = F::r2c_power_x2(v[F::reg_of_spectrum(p + 1)], zm[p + 1], ptw[p + 1]);
+            } else {
+                pw = F::r2c_power_factored_x2(v[F::reg_of_spectrum(p)], zm[p], w0, p);
+                pw2 = F::r2c_power_factored_x2(v[F::reg_of_spectrum(p + 1)], zm[p + 1], w0, p + 1);
+            }
             prow[kk] = POW2 ? pw.x : __builtin_amdgcn_sqrtf(pw.x);
             prow[NC - kk] = POW2 ? pw.y : __builtin_amdgcn_sqrtf(pw.y);
+            prow[kk2] = POW2 ? pw2.x : __builtin_amdgcn_sqrtf(pw2.x);
+            prow[NC - kk2] = POW2 ? pw2.y : __builtin_amdgcn_sqrtf(pw2.y);
         }
         if (t == 0) {
             const float pm = 4.0f * cnorm2(zmid);                       // X[NC/2] = conj(Z[NC/2]); Z carries the 0.5
