@@ -441,16 +441,20 @@ static int launch_stream(FrameGeom g, const Tables& tb, const SparseArgs& sm, co
     const bool fullm = FMT == FMT_F32 && (sm.n_mels % 64) == 0;
     // two slots of exactly (4, 16) steps — what tac_melbank_pack produces for 128-band mel banks — take the kernel whose
     // contraction is unrolled for that shape (its first reads ride along with the other frame's FFT stage)
-    const bool fast2 = TAC_ST_FAST2 && fullm && info_host[1] == 2 && info_host[4] == ST_FAST_STEPS0 && info_host[5] == ST_FAST_STEPS1;
+    const bool fast2 = TAC_ST_FAST2 && fullm && info_host[1] == 2 && info_host[4] == ST_FAST_STEPS0 &&
+                       (info_host[5] == ST_FAST_STEPS1 || info_host[5] == ST_FAST_STEPS1_SHORT);
+    const bool fshort = info_host[5] == ST_FAST_STEPS1_SHORT;
     void (*kern)(FrameGeom, Tables, StreamArgs);
     if constexpr (FMT == FMT_F32) {
-        if (fast2)
-            kern = pow2 ? melspec_stream_kernel<NC, E, true, true, FMT, true> : melspec_stream_kernel<NC, E, false, true, FMT, true>;
+        if (fast2 && fshort)
+            kern = pow2 ? melspec_stream_kernel<NC, E, true, true, FMT, ST_FAST_STEPS1_SHORT> : melspec_stream_kernel<NC, E, false, true, FMT, ST_FAST_STEPS1_SHORT>;
+        else if (fast2)
+            kern = pow2 ? melspec_stream_kernel<NC, E, true, true, FMT, ST_FAST_STEPS1> : melspec_stream_kernel<NC, E, false, true, FMT, ST_FAST_STEPS1>;
         else
-            kern = pow2 ? (fullm ? melspec_stream_kernel<NC, E, true, true, FMT, false> : melspec_stream_kernel<NC, E, true, false, FMT, false>)
-                        : (fullm ? melspec_stream_kernel<NC, E, false, true, FMT, false> : melspec_stream_kernel<NC, E, false, false, FMT, false>);
+            kern = pow2 ? (fullm ? melspec_stream_kernel<NC, E, true, true, FMT, 0> : melspec_stream_kernel<NC, E, true, false, FMT, 0>)
+                        : (fullm ? melspec_stream_kernel<NC, E, false, true, FMT, 0> : melspec_stream_kernel<NC, E, false, false, FMT, 0>);
     } else {
-        kern = pow2 ? melspec_stream_kernel<NC, E, true, false, FMT, false> : melspec_stream_kernel<NC, E, false, false, FMT, false>;
+        kern = pow2 ? melspec_stream_kernel<NC, E, true, false, FMT, 0> : melspec_stream_kernel<NC, E, false, false, FMT, 0>;
     }
     TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(ST_WAVES * 64), lds_bytes, stream, g, tb, m);
@@ -479,13 +483,14 @@ static int pack_lanes(const std::vector<float>& h, int n_freqs, int n_mels, floa
             steps[m / 64] = std::max(steps[m / 64], (len[m] + 3) / 4);
         }
     }
-    if (nslot == 2 && steps[0] <= ST_FAST_STEPS0 && steps[1] <= ST_FAST_STEPS1) {   // the shape the FAST2 kernel is unrolled for
+    const bool fast_shape = nslot == 2 && (n_mels % 64) == 0 && steps[0] <= ST_FAST_STEPS0 && steps[1] <= ST_FAST_STEPS1;
+    if (fast_shape) {                                                        // the shapes the FAST2 kernels are unrolled for
         steps[0] = ST_FAST_STEPS0;
-        steps[1] = ST_FAST_STEPS1;
+        steps[1] = steps[1] <= ST_FAST_STEPS1_SHORT ? ST_FAST_STEPS1_SHORT : ST_FAST_STEPS1;
     }
     int total_steps = 0;
     for (int s = 0; s < nslot; ++s) {
-        steps[s] = std::max(4, (steps[s] + 3) & ~3);                         // whole trips; an empty slot still runs one
+        if (!fast_shape) steps[s] = std::max(4, (steps[s] + 3) & ~3);        // whole trips; an empty slot still runs one
         if (4 * steps[s] > limit) return TAC_E_UNSUPPORTED;
         total_steps += steps[s];
     }

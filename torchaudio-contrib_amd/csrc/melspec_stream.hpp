@@ -34,6 +34,7 @@ constexpr int ST_MAX_SLOTS = 4;              // bands per lane (n_mels <= 256)
 constexpr int ST_TW_STRIDE = 36;              // floats between the 16 pass-1 twiddle sets in LDS (144 B: conflict-free b128)
 constexpr int ST_TW_BYTES = 16 * ST_TW_STRIDE * 4;
 constexpr int ST_FAST_STEPS0 = 4, ST_FAST_STEPS1 = 16;   // slot lengths of the two-slot layout the FAST2 kernel is unrolled for
+constexpr int ST_FAST_STEPS1_SHORT = 14;                 // ... and its second instantiation (no band of slot 1 beyond 56 bins: the standard 128-band bank)
 #ifndef TAC_ST_RIDE1
 #define TAC_ST_RIDE1 6       // steps of slot 1 whose reads ride along with slot 0 (paired rotation: 4 / 6 / 8 / 10 -> 0.1375 / 0.1361 / 0.1358 / 0.1376 ms)
 #endif
@@ -47,7 +48,7 @@ constexpr int ST_FAST_STEPS0 = 4, ST_FAST_STEPS1 = 16;   // slot lengths of the 
 #define TAC_ST_WINFOLD 1     // the window multiplies folded into pass 0's first butterflies (-8 packed instructions per frame; 0: A/B knob)
 #endif
 #ifndef TAC_ST_BATCH
-#define TAC_ST_BATCH 5       // steps per round trip of the rest of slot 1 (a batch that no longer fits the registers spills: 8 + 6 -> 0.156 ms)
+#define TAC_ST_BATCH 4       // steps per round trip of the rest of slot 1 (14-step layout: 4 + 4; a batch that no longer fits the registers spills: 8 + 6 -> 0.156 ms)
 #endif
 constexpr int ST_RIDE = ST_FAST_STEPS0 + TAC_ST_RIDE1;     // steps issued at the end of s3
 
@@ -88,7 +89,8 @@ __host__ __device__ inline size_t stream_lds_bytes(int wtot) {
     return b + 1024 + ST_TW_BYTES + 16;                                        // mu-law decode table, pass-1 twiddles, frame counter
 }
 
-template <int NC, int E, bool POW2, bool FULLM, int FMT, bool FAST2>
+// FAST2: 0 = the general kernel, otherwise the number of steps of slot 1 in the (4, FAST2)-step specialisation
+template <int NC, int E, bool POW2, bool FULLM, int FMT, int FAST2>
 __global__ void __launch_bounds__(ST_WAVES * 64, 2)
 melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     using C = StreamCfg<NC, E>;
@@ -376,7 +378,7 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     // steps are consumed, so its round trip overlaps their FMAs.
     auto s4_fast = [&](const float* prow, int i, const f4 (&cw)[ST_RIDE], const f4 (&cp)[ST_RIDE], auto&& after_ride) {
         i = i < nloc ? i : nloc - 1;
-        constexpr int REST = ST_FAST_STEPS1 - TAC_ST_RIDE1;
+        constexpr int REST = (FAST2 ? FAST2 : ST_FAST_STEPS1) - TAC_ST_RIDE1;
         constexpr int NB = (REST + TAC_ST_BATCH - 1) / TAC_ST_BATCH;
         const f4* wp = reinterpret_cast<const f4*>(wlds) + lane + ST_RIDE * 64;
         const f4* p1 = reinterpret_cast<const f4*>(prow + lo_s[1]) + TAC_ST_RIDE1;
@@ -443,7 +445,7 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
 #pragma unroll
                     for (int u = 0; u < 8; ++u) fma4(wv[u], pv[u], acc0, acc1);
                 }
-                if (j < n) {                                              // half trip
+                if (j + 4 <= n) {                                         // half trip
                     f4 wv[4], pv[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -453,7 +455,10 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) fma4(wv[u], pv[u], acc0, acc1);
                     wp += 256;
+                    j += 4;
                 }
+#pragma unroll 1
+                for (; j < n; ++j, wp += 64) fma4(wp[0], pp[j], acc0, acc1);   // (slot lengths that are not whole half-trips: the 14-step layout)
                 float v = (acc0.x + acc0.y) + (acc1.x + acc1.y);
                 if (m.db) v = fast_db ? amp_to_db_fast(v, m.amin, ten_log10_ref) : amp_to_db(v, m.amin, m.log10_ref);
                 if (FULLM || s * 64 + lane < m.n_mels) orow[s * 64] = v;
