@@ -8,16 +8,7 @@
 // waveform — no padded copy, no framed copy, no separate window multiply.
 #include "host_common.hpp"
 
-#ifndef TAC_ABL
-#define TAC_ABL 0      // ablation builds only (tools): 1 = no global loads, 2 = no stores, 3 = no FFT passes
-#endif
 
-#ifndef TAC_STFT_STREAM
-#define TAC_STFT_STREAM 0
-#endif
-#if TAC_STFT_STREAM
-#include "../../tools/ablation/stft_stream.hpp"   // parked variant, not built by default
-#endif
 #ifndef TAC_STFT_OCC
 #define TAC_STFT_OCC 2      // waves per SIMD the generic kernel is compiled for (A/B knob; 3 drops the hoisted twiddles)
 #endif
@@ -117,12 +108,7 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
         for (int f = 0; f < NF; ++f) {
             row[f] = urow;
             frame[f] = uframe0 + f * F::G + sub;            // may be >= T: load_frame() then yields zeros
-#if TAC_ABL == 1
-#pragma unroll
-            for (int e = 0; e < E; ++e) v[f][e] = mkc((float)(t + e) * win[e].x, (float)(unit + e) * win[e].y);
-#else
             load_frame<F, true>(v[f], g, win, lds[f], row[f], frame[f], t);
-#endif
         }
         if constexpr (!HOIST) {
             // twiddles only once the frame is windowed (the window's registers are free by then): N = 4096 keeps
@@ -130,31 +116,19 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
             __builtin_amdgcn_sched_barrier(0);
             F::load_twiddles(tw, tb.w_nc, tl);
         }
-#if TAC_ABL == 3
-        wave_lds_fence();
-#pragma unroll
-        for (int f = 0; f < NF; ++f)
-#pragma unroll
-            for (int e = 0; e < E; ++e) lds[f][lds_pad(t + e * F::LPF)] = v[f][e];
-        wave_lds_fence();
-#else
         st.mark(8);                                         // frame loaded (global latency) and windowed
         F::template run<NF>(v, lds, tw, t, st);
-#endif
         st.mark(9);                                         // last pass's spectrum written to LDS
         const bool simple = (MODE == 0) ? (ep.onesided != 0) : (ep.onesided && ep.power == 2.0f && !ep.db);
         bool done = false;
-        if constexpr (F::G == 1 && TAC_ABL != 2) {
+        if constexpr (F::G == 1) {
             if (simple) {
                 // Wide-store epilogue: the unit's NF output rows are adjacent in memory, so they are staged in
                 // output order in LDS (in place over the consumed spectra) and streamed out with 16-byte
                 // ds_read_b128 -> global_store_dwordx4, ~8 store instructions per frame instead of 34 narrow ones
                 // (the narrow stores were issue-bound: 0.22 of 0.44 ms at cfg-2).  The staging origin is shifted
                 // by the rows' misalignment so LDS and global addresses share their 16-byte phase.
-            #ifndef TAC_PIPE_ABL_ALIGNED
-#define TAC_PIPE_ABL_ALIGNED 0   // ablation builds only (wrong results): rows of NC instead of NC + 1 elements, i.e. 128-byte aligned
-#endif
-    constexpr int LENF = (MODE == 0 ? 2 : 1) * (NC + (TAC_PIPE_ABL_ALIGNED ? 0 : 1));
+    constexpr int LENF = (MODE == 0 ? 2 : 1) * (NC + 1);
                 const long long g0 = ((long long)urow * g.n_frames + uframe0) * LENF;
                 const int a = (int)(g0 & 3);
                 float* stage = reinterpret_cast<float*>(lds[0]) + a;
@@ -209,11 +183,7 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
             if (done) break;
-#if TAC_ABL == 2
-            const bool live = frame[f] < g.n_frames && g.scale == 12345.0f;   // never true: stores skipped, math kept
-#else
             const bool live = frame[f] < g.n_frames;
-#endif
             float* obase = ep.out + (row[f] * g.n_frames + (live ? frame[f] : 0)) * per_frame;
             cf* o2 = reinterpret_cast<cf*>(obase);
             float* prow = reinterpret_cast<float*>(lds[f]);
@@ -294,9 +264,6 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 #endif
 }
 
-#ifndef TAC_PIPE_ABL
-#define TAC_PIPE_ABL 0      // ablation builds only: 1 = no row stores, 2 = no FFT passes, 3 = no frame loads
-#endif
 // ---------------------------------------------------------------- software-pipelined variant
 // One frame per wave (n_fft = 2048) with the plain epilogue (one-sided complex, or |X|^2).  The phase stamps of
 // the kernel above (tools/stft_phase_timing.py) showed where a frame's ~13k cycles went: 40 % waiting for its
@@ -350,10 +317,7 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
     const int chunk = (total + (int)gridDim.x - 1) / (int)gridDim.x;
     const int begin = (int)blockIdx.x * chunk;
     const int end = begin + chunk < total ? begin + chunk : total;
-#ifndef TAC_PIPE_ABL_ALIGNED
-#define TAC_PIPE_ABL_ALIGNED 0   // ablation builds only (wrong results): rows of NC instead of NC + 1 elements, i.e. 128-byte aligned
-#endif
-    constexpr int LENF = (MODE == 0 ? 2 : 1) * (NC + (TAC_PIPE_ABL_ALIGNED ? 0 : 1));
+    constexpr int LENF = (MODE == 0 ? 2 : 1) * (NC + 1);
     constexpr int NST = ((LENF >> 2) + 63) / 64;          // 16-byte wave-stores per output row
     const float hscale = 0.5f * g.scale;                  // the R2C split returns 2·X
 
@@ -373,24 +337,7 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
     __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): the loop is entered with nothing in flight
     __syncthreads();
 
-#ifndef TAC_PIPE_LATE_STORES
-#define TAC_PIPE_LATE_STORES 0   // complex rows: hold back the second half of a row's stores until the next frame is windowed (A/B knob)
-#endif
-    constexpr bool LATE = (TAC_PIPE_LATE_STORES != 0) && (NST == 8);
-    float4 lb4 = {0, 0, 0, 0}, lb5 = lb4, lb6 = lb4, lb7 = lb4;
-    float4* lg4 = nullptr;
-    int lc4 = 0, lc5 = 0, lc6 = 0, lc7 = 0;
-    bool have_late = false;
 
-#ifndef TAC_PIPE_STAGGER
-#define TAC_PIPE_STAGGER 0   // N > 0: waves start N*64*k cycles apart (k = (block + wave) mod 4) so their store phases interleave
-#endif
-#if TAC_PIPE_STAGGER
-    {
-        const int k = ((int)blockIdx.x + w) & 3;
-        for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(TAC_PIPE_STAGGER);
-    }
-#endif
     StftStamp st;
 #if TAC_STFT_TIMING
     st.init();
@@ -417,33 +364,15 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
         } else {
             load_frame<F, false>(v[0], g, nullptr, lds, urow, uframe, col);   // frames touching the padding
         }
-        if constexpr (LATE) {
-            if (have_late) {
-                lg4[lc4] = lb4; lg4[lc5] = lb5; lg4[lc6] = lb6; lg4[lc7] = lb7;
-            }
-        }
         st.mark(8);
-#if TAC_PIPE_ABL == 2
-        wave_lds_fence();
-#pragma unroll
-        for (int e = 0; e < E; ++e) lds[lds_pad(t + e * F::LPF)] = v[0][e];
-        wave_lds_fence();
-#else
         F::template run<1, StftStamp, true>(v, ldsv, tw, t, st, col);       // lower-half spectrum stays in registers
-#endif
         st.mark(9);
 
         // request the next frame now: it lands while this frame is split, staged and stored
         __builtin_amdgcn_sched_barrier(0);
         {
             pre = false;
-#if TAC_PIPE_ABL == 3
-            pre = nxt < end;
-#pragma unroll
-            for (int q = 0; q < E; ++q) raw[q] = mkc((float)(t + q), (float)(unit - q));
-#else
             if (nxt < end) pre = prefetch_frame_raw_x<F>(raw, g, nxt / T, nxt % T, t, col, v4);
-#endif
         }
         __builtin_amdgcn_sched_barrier(0);
         st.mark(1);                                         // next frame's loads issued
@@ -456,12 +385,8 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 #pragma unroll
             for (int i = 0; i < F::NPAIR; ++i) {
                 const int k = t + i * F::LPF;
-#if TAC_PIPE_ABL == 2
-                const cf zk = lds[lds_pad(k)], zm = lds[lds_pad((NC - k) & (NC - 1))];
-#else
                 const cf zk = v[0][F::reg_of_spectrum(i)];            // Z[k] never left this lane
                 const cf zm = (i == 0) ? F::r2c_partner(lds, k, zk) : lds[lds_pad(NC - k)];
-#endif
                 if constexpr (MODE != 0) {                            // xa[i] = (|X[k]|^2, |X[NC-k]|^2), no spectra formed
                     const cf pw = LEAN ? F::r2c_power_factored_x2(zk, zm, ptw[0], i) : F::r2c_power_x2(zk, zm, ptw[i]);
                     xa[i] = cscale(pw, hscale * hscale);
@@ -475,23 +400,6 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
             xm = cscale(xm, hscale);
             wave_lds_fence();                                         // every Z of this frame is in registers
             st.mark(7);                                               // R2C split done
-#ifndef TAC_PIPE_DIRECT_POWER
-#define TAC_PIPE_DIRECT_POWER 0   // |X|^2 rows straight from registers (17 dword wave-stores) instead of LDS staging (A/B knob)
-#endif
-            if constexpr (MODE == 1 && TAC_PIPE_DIRECT_POWER != 0) {   // (|X|^2 rows only)
-                float* const orow = ep.out + g0;
-#pragma unroll
-                for (int i = 0; i < F::NPAIR; ++i) {
-                    const int k = t + i * F::LPF;
-                    orow[k] = xa[i].x;
-                    orow[NC - k] = xa[i].y;
-                }
-                orow[NC / 2] = cnorm2(xm);                            // every lane holds the same value
-                st.mark(10);
-                st.mark(11);
-                unit = nxt;
-                continue;
-            }
 #pragma unroll
             for (int i = 0; i < F::NPAIR; ++i) {
                 const int k = t + i * F::LPF;
@@ -514,9 +422,6 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
         float* const gdst = ep.out + g0;
         const int npre = (4 - a) & 3;
         const int nchunks = (LENF - npre) >> 2;
-#if TAC_PIPE_ABL == 1
-        if (hscale == 12345.0f)                           // never true: the row stores are skipped, everything else kept
-#endif
         {
         {
             const int hmax = (npre > 1 ? npre : 1) - 1;
@@ -529,21 +434,8 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
         const int last = nchunks - 1;
 #define TAC_ROW_IDX(i) const int c##i = (t + 64 * i) < last ? (t + 64 * i) : last;
 #define TAC_ROW_RD(i) const float4 b##i = s4[c##i];
-#ifndef TAC_PIPE_STORE_POLICY
-#define TAC_PIPE_STORE_POLICY 1   // cache policy of the row stores: 0 plain, 1 nt (default: the rows are written once and never re-read;
-                                  // measured 0.224 -> 0.158 ms on the complex STFT), 2 sc1 / 3 sc0 sc1 (write-through: 0.38 ms)
-#endif
-#if TAC_PIPE_STORE_POLICY == 0
-#define TAC_ROW_WR(i) g4[c##i] = b##i;
-#elif TAC_PIPE_STORE_POLICY == 1
 #define TAC_ROW_WR(i) __builtin_nontemporal_store(__builtin_bit_cast(__attribute__((ext_vector_type(4))) float, b##i), \
             reinterpret_cast<__attribute__((ext_vector_type(4))) float*>(&g4[c##i]));
-#else
-        const __amdgpu_buffer_rsrc_t rowrs = __builtin_amdgcn_make_buffer_rsrc(g4, 0, 0x7fffffff, 0x00020000);
-#define TAC_ROW_WR(i) __builtin_amdgcn_raw_buffer_store_b128(                                              \
-            __builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, b##i), rowrs, c##i * 16, 0, \
-            TAC_PIPE_STORE_POLICY == 2 ? 16 : 17);
-#endif
         TAC_ROW_IDX(0) TAC_ROW_IDX(1) TAC_ROW_IDX(2) TAC_ROW_IDX(3)
         TAC_ROW_RD(0) TAC_ROW_RD(1) TAC_ROW_RD(2) TAC_ROW_RD(3)
         if constexpr (NST == 8) {
@@ -551,14 +443,7 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
             TAC_ROW_RD(4) TAC_ROW_RD(5) TAC_ROW_RD(6) TAC_ROW_RD(7)
             __builtin_amdgcn_sched_barrier(0);            // all LDS reads in flight before the first store issues
             TAC_ROW_WR(0) TAC_ROW_WR(1) TAC_ROW_WR(2) TAC_ROW_WR(3)
-            if constexpr (LATE) {
-                lb4 = b4; lb5 = b5; lb6 = b6; lb7 = b7;
-                lc4 = c4; lc5 = c5; lc6 = c6; lc7 = c7;
-                lg4 = g4;
-                have_late = true;
-            } else {
-                TAC_ROW_WR(4) TAC_ROW_WR(5) TAC_ROW_WR(6) TAC_ROW_WR(7)
-            }
+            TAC_ROW_WR(4) TAC_ROW_WR(5) TAC_ROW_WR(6) TAC_ROW_WR(7)
         } else {
             __builtin_amdgcn_sched_barrier(0);
             TAC_ROW_WR(0) TAC_ROW_WR(1) TAC_ROW_WR(2) TAC_ROW_WR(3)
@@ -576,11 +461,6 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
         wave_lds_fence();   // next iteration's first-pass writes must follow these reads
         st.mark(11);
         unit = nxt;
-    }
-    if constexpr (LATE) {
-        if (have_late) {
-            lg4[lc4] = lb4; lg4[lc5] = lb5; lg4[lc6] = lb6; lg4[lc7] = lb7;
-        }
     }
 #if TAC_STFT_TIMING
     __syncthreads();
@@ -643,17 +523,6 @@ static int launch_stft(const FrameGeom& g, const Tables& tb, const StftEpilogue&
             else if (ep.power == 2.0f) pmode = ep.db ? 3 : 1;
             else if (ep.power == 1.0f) pmode = ep.db ? 4 : 2;
         }
-#if TAC_STFT_STREAM
-        if (g.length >= 2 * NC) {
-            switch (pmode) {
-                case 1: return launch_stft_stream<NC, E, 1>(g, tb, ep, stream);
-                case 2: return launch_stft_stream<NC, E, 2>(g, tb, ep, stream);
-                case 3: return launch_stft_stream<NC, E, 3>(g, tb, ep, stream);
-                case 4: return launch_stft_stream<NC, E, 4>(g, tb, ep, stream);
-                default: break;
-            }
-        }
-#endif
         switch (pmode) {
             case 0: return launch_pipe<NC, E, 0>(g, tb, ep, groups, stream);
             case 1: return launch_pipe<NC, E, 1>(g, tb, ep, groups, stream);
