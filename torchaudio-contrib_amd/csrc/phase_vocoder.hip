@@ -46,10 +46,12 @@ phase_vocoder_kernel(const T* __restrict__ spec, long long rows, int n_freqs, in
                      int n_out, T* __restrict__ out) {
     using M = pv_math<T>;
     typedef T T2 __attribute__((ext_vector_type(2)));      // one (re, im) pair = one 8- / 16-byte access
-    const int fblocks = (n_freqs + PV_THREADS - 1) / PV_THREADS;
-    const long long row = blockIdx.x / fblocks;
-    const int f = (int)(blockIdx.x % fblocks) * PV_THREADS + threadIdx.x;
-    if (row >= rows || f >= n_freqs) return;
+    // series are numbered row-major over (row, frequency): no partly filled workgroup per row (1025 bins would leave
+    // every fifth 256-thread group with a single live lane walking the whole time axis)
+    const long long sid = (long long)blockIdx.x * PV_THREADS + threadIdx.x;
+    if (sid >= rows * n_freqs) return;
+    const long long row = sid / n_freqs;
+    const int f = (int)(sid - row * n_freqs);
     const T* base = spec + row * stride_r + (long long)f * stride_f;
     T re0, im0, re1, im1;
     auto frame = [&](int t, T& re, T& im) {     // the two frames past the end are the reference's zero padding
@@ -66,10 +68,27 @@ phase_vocoder_kernel(const T* __restrict__ spec, long long rows, int n_freqs, in
     frame(0, re0, im0);
     double acc = (double)M::atan2(im0, re0);    // phase of the first input frame opens the running sum
     T* o = out + (row * n_out * (long long)n_freqs + f) * 2;
+    // The second frame of step i is the first frame of step i + 1 whenever the grid advances by one input frame (every
+    // step for rate <= 1, most steps up to rate 2): its phase and magnitude are kept instead of being loaded and
+    // evaluated again (the grid is wave-uniform, so is the branch; the values are the ones that would be recomputed).
+    int t_kept = -1;
+    T ang_kept = (T)0, n_kept = (T)0;
     for (int i = 0; i < n_out; ++i) {
-        frame(idx0[i], re0, im0);
-        frame(idx1[i], re1, im1);
-        const T n0 = M::hypot(re0, im0), n1 = M::hypot(re1, im1);
+        const int t0 = idx0[i], t1 = idx1[i];
+        T ang0, n0;
+        if (t0 == t_kept) {
+            ang0 = ang_kept;
+            n0 = n_kept;
+        } else {
+            frame(t0, re0, im0);
+            ang0 = M::atan2(im0, re0);
+            n0 = M::hypot(re0, im0);
+        }
+        frame(t1, re1, im1);
+        const T ang1 = M::atan2(im1, re1), n1 = M::hypot(re1, im1);
+        t_kept = t1;
+        ang_kept = ang1;
+        n_kept = n1;
         const T w = alpha[i];
         const T mag = w * n1 + ((T)1 - w) * n0;
         T sn, cs;
@@ -79,8 +98,10 @@ phase_vocoder_kernel(const T* __restrict__ spec, long long rows, int n_freqs, in
         res.y = mag * sn;
         *reinterpret_cast<T2*>(o) = res;
         o += 2 * (long long)n_freqs;
-        double ph = (double)M::atan2(im1, re1) - (double)M::atan2(im0, re0) - pa;
-        ph = ph - two_pi * rint(ph / two_pi);
+        double ph = (double)ang1 - (double)ang0 - pa;
+        // (a reciprocal instead of the reference's division: where the two round differently the wrapped phase moves by
+        // exactly one turn, which the sine and cosine of the running sum do not see)
+        ph = ph - two_pi * rint(ph * 0.15915494309189535);
         acc += ph + pa;
     }
 }
@@ -93,8 +114,7 @@ static int launch_phase_vocoder(const T* spec, int64_t rows, int32_t n_freqs, in
     if (!spec || !phase_advance || !idx0 || !idx1 || !alpha || !out) return TAC_E_INVALID;
     if (rows < 0 || n_freqs < 0 || n_frames <= 0 || n_out < 0) return TAC_E_INVALID;
     if (n_frames >= 0x7fffffffLL || n_out >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
-    const long long fblocks = (n_freqs + PV_THREADS - 1) / PV_THREADS;
-    const long long blocks = rows * fblocks;
+    const long long blocks = (rows * (long long)n_freqs + PV_THREADS - 1) / PV_THREADS;
     if (blocks >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
     hipLaunchKernelGGL(phase_vocoder_kernel<T>, dim3((unsigned)blocks), dim3(PV_THREADS), 0, (hipStream_t)stream, spec,
                        (long long)rows, (int)n_freqs, (int)n_frames, (long long)stride_r, (long long)stride_f,
