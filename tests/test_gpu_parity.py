@@ -793,14 +793,19 @@ def test_autograd_matches_the_reference_chain(tac, shape, n_fft, hop, mels):
     (want,) = torch.autograd.grad((want_y * torch.from_numpy(weight)).sum(), xc)
     xg = dev(x).requires_grad_(True)
     mel = tac.Melspectrogram(num_mels=mels, sample_rate=16000, fft_length=n_fft, hop_length=hop).cuda()
-    for chain in (torch.nn.Sequential(mel, tac.AmplitudeToDb(amin=1e-5)),               # factory container + dB
-                  torch.nn.Sequential(*mel, tac.AmplitudeToDb(amin=1e-5))):             # the unpacked idiom
+    for fused, chain in ((True, torch.nn.Sequential(mel, tac.AmplitudeToDb(amin=1e-5))),   # factory container + dB
+                         (False, torch.nn.Sequential(*mel, tac.AmplitudeToDb(amin=1e-5)))):  # the unpacked idiom: op by op
         y = chain(xg)
         assert y.requires_grad and np.abs(host(y) - want_y.detach().numpy()).max() < DB_ABS
         before = launches(tac)
         (got,) = torch.autograd.grad((y * dev(weight)).sum(), xg)
         ran = launched_since(tac, before)
-        assert ran.get('tac_stft_backward_f32') == 1 and ran.get('tac_overlap_add_f32') == 1, ran   # the HIP gradient kernels
+        # the HIP gradient kernels: the inverse-FFT kernel with the norm's adjoint folded into its load, the overlap-add
+        assert ran.get('tac_overlap_add_f32') == 1, ran
+        if fused:
+            assert ran.get('tac_stft_norm_backward_f32') == 1 and 'tac_complex_norm_backward_f32' not in ran, ran
+        else:
+            assert ran.get('tac_stft_backward_f32') == 1 and ran.get('tac_complex_norm_backward_f32') == 1, ran
         assert rel_err(host(got), want.numpy()) < 1e-3
 
 

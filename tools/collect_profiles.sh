@@ -20,4 +20,5 @@ done
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_fb_mfma -o p -- python tools/prof_driver.py fb 3 > /dev/null 2>&1
 # backward of the fused chain: which kernels, how long
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_grad -o grad -- python tools/prof_driver.py grad 5 > $out/kt_grad.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_gradf -o gradf -- python tools/prof_driver.py gradf 5 > $out/kt_gradf.log 2>&1
 ls $out

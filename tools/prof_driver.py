@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Tiny driver for rocprofv3: launch one kernel family a few times at cfg-2 size.
-    python tools/prof_driver.py mel|stft|spec|fb|grad|mulaw [iters]"""
+    python tools/prof_driver.py mel|stft|spec|fb|grad|gradf|mulaw [iters]"""
 import os
 import sys
 
@@ -33,8 +33,19 @@ elif what == 'fb':
     fbd = torch.rand(1025, 128, device='cuda')
     fn = lambda: tac.apply_filterbank(spec, fbd)
 elif what == 'grad':
-    # backward of the fused chain: recomputed spectrum + HIP gradient kernels
+    # forward + backward of the reference idiom with a waveform that requires grad: op by op (deferral is off for
+    # tensors in an autograd graph), HIP gradient kernels
     m = torch.nn.Sequential(*tac.Melspectrogram(num_mels=128, sample_rate=16000, fft_length=2048, hop_length=512),
+                            tac.AmplitudeToDb()).cuda()
+    xg = x.clone().requires_grad_(True)
+    def fn():
+        y = m(xg)
+        y.backward(torch.ones_like(y))
+        return y
+elif what == 'gradf':
+    # the same through the factory container (one tac_amd::melspectrogram op): fused forward kernel, and a backward whose
+    # inverse-FFT kernel forms the gradient spectrum on load
+    m = torch.nn.Sequential(tac.Melspectrogram(num_mels=128, sample_rate=16000, fft_length=2048, hop_length=512),
                             tac.AmplitudeToDb()).cuda()
     xg = x.clone().requires_grad_(True)
     def fn():

@@ -113,18 +113,28 @@ out.append('All three kernels run 2 waves/SIMD (one 8-wave workgroup per CU whos
            'counter), no scratch.  HBM traffic equals the algorithmic bytes to within 0.5 %: nothing is re-read, the fused '
            'kernel is bound by its VALU + LDS instruction streams (stall table above), not by memory.  '
            'DESIGN.md §3.2/§3.3 hold the stage-stamp breakdowns, the ablations and the list of variants measured not to help.')
-pb = os.path.join(d, 'kernel_stats_backward.csv')
-if os.path.exists(pb):
+for fname, what in (('kernel_stats_backward.csv',
+                     '`tools/prof_driver.py grad 5`: forward + backward of the reference idiom `Sequential(*Melspectrogram(...), '
+                     'AmplitudeToDb())` at cfg-2 with `requires_grad` on the waveform — op by op (tensors in an autograd graph '
+                     'are not deferred), HIP gradient kernels'),
+                    ('kernel_stats_backward_fused_op.csv',
+                     '`tools/prof_driver.py gradf 5`: the same through the factory container (`Melspectrogram(...)` called as '
+                     'ONE `tac_amd::melspectrogram` op): fused forward kernel; backward = spectrum recomputed, filterbank adjoint, '
+                     'inverse-FFT kernel that forms the gradient spectrum on load, overlap-add')):
+    pb = os.path.join(d, fname)
+    if not os.path.exists(pb):
+        continue
     out.append('')
-    out.append('`kernel_stats_backward.csv` — `rocprofv3 --kernel-trace --stats -- python tools/prof_driver.py grad 5`: one '
-               'forward + backward of `Melspectrogram -> AmplitudeToDb` at cfg-2 with `requires_grad` on the waveform (the '
-               'unfused forward that autograd needs, then the gradient kernels):')
+    out.append('`%s` — `rocprofv3 --kernel-trace --stats` of %s:' % (fname, what))
     out.append('')
     out.append('| kernel | calls | average |')
     out.append('|---|---|---|')
+    tot = 0.0
     for r in csv.DictReader(open(pb)):
-        if 'tac::' in r['Name']:
+        if 'tac::' in r['Name'] and int(r['Calls']) >= 5:
+            tot += float(r['AverageNs']) / 1e6
             out.append('| `%s` | %s | %.4f ms |' % (r['Name'].split('(')[0].replace('void ', ''), r['Calls'], float(r['AverageNs']) / 1e6))
+    out.append('| sum of the per-call averages | | %.3f ms |' % tot)
 out.append('')
 out.append('Micro-benchmarks behind the design decisions (sources in `tools/ubench/`, outputs quoted in DESIGN.md): '
            '`valu_rate` (scalar vs packed f32 issue rates), `lds_rate` (LDS access shapes at 8 waves/CU), `hbm_rate` '

@@ -26,10 +26,11 @@ for f in glob.glob(src + '/kt/**/*kernel_stats.csv', recursive=True):
                 w.writerow([r[0][:100] + '...'] + r[1:])
 if os.path.exists(src + '/bench_N1.json'):
     shutil.copy(src + '/bench_N1.json', dst + '/bench_N1.json')
-for f in glob.glob(src + '/kt_grad/**/*kernel_stats.csv', recursive=True):
-    rows = [r for r in csv.reader(open(f)) if r and (r[0] == 'Name' or 'tac::' in r[0])]
-    with open(os.path.join(dst, 'kernel_stats_backward.csv'), 'w') as o:
-        csv.writer(o).writerows([[r[0][:140]] + r[1:] for r in rows])
+for sub, name in (('kt_grad', 'kernel_stats_backward.csv'), ('kt_gradf', 'kernel_stats_backward_fused_op.csv')):
+    for f in glob.glob(src + '/' + sub + '/**/*kernel_stats.csv', recursive=True):
+        rows = [r for r in csv.reader(open(f)) if r and (r[0] == 'Name' or 'tac::' in r[0])]
+        with open(os.path.join(dst, name), 'w') as o:
+            csv.writer(o).writerows([[r[0][:140]] + r[1:] for r in rows])
 for k in ('mel', 'stft', 'spec', 'fb'):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(src + '/pmc_%s_*/**/*counter_collection.csv' % k, recursive=True):

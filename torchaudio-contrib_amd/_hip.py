@@ -569,22 +569,37 @@ def apply_filterbank_backward(grad_out, fb):
     return apply_filterbank(grad_out, transposed_bank(fb), allow_sparse=False)
 
 
-def stft_backward(grad_spec, wave, window, n_fft, hop, win_length, center, pad_mode, normalized):
+def stft_backward(grad_spec, wave, window, n_fft, hop, win_length, center, pad_mode, normalized, grad_norm=None,
+                  power=2.0):
     """grad of the one-sided stft output ``(*, F, T, 2)`` w.r.t. the waveform: one inverse real FFT per frame
-    (tac_stft_backward_f32) followed by the gather form of overlap-add (tac_overlap_add_f32)."""
+    (tac_stft_backward_f32) followed by the gather form of overlap-add (tac_overlap_add_f32).
+    With ``grad_norm`` (the gradient of ``complex_norm(spec, power)``, shape ``(*, F, T)``) ``grad_spec`` is the
+    spectrum itself and the norm's adjoint is folded into the load (tac_stft_norm_backward_f32)."""
     g = geometry(wave, n_fft, hop, win_length, center, pad_mode, normalized, True)
     gs = grad_spec.transpose(-3, -2)                                  # physical frame-major (*, T, F, 2)
     gs = gs if gs.is_contiguous() else gs.contiguous()
+    gn = None
+    if grad_norm is not None:
+        gn = grad_norm.transpose(-2, -1)                              # (*, T, F)
+        gn = gn if gn.is_contiguous() else gn.contiguous()
+        if gn.dtype != torch.float32:
+            gn = gn.float()
     frames = torch.empty((g.rows, g.n_frames, n_fft), dtype=torch.float32, device=wave.device)
     out = torch.empty(tuple(wave.shape), dtype=torch.float32, device=wave.device)
     desc = _native.StftDesc(rows=g.rows, length=g.length, row_stride=g.length, n_fft=n_fft, hop=hop,
                             win_length=win_length, center=1 if center else 0, pad_mode=_native.PAD_MODES[pad_mode],
                             normalized=1 if normalized else 0, onesided=1, reserved=0)
     with _native.on_device(wave.device):
-        rc = _native.lib().tac_stft_backward_f32(_native.ptr(gs), _native.ptr(window), desc, _native.ptr(frames),
-                                                 _native.stream_ptr(wave.device))
-        _native.check(rc, 'tac_stft_backward_f32')
-        _count('tac_stft_backward_f32')
+        if gn is None:
+            rc = _native.lib().tac_stft_backward_f32(_native.ptr(gs), _native.ptr(window), desc, _native.ptr(frames),
+                                                     _native.stream_ptr(wave.device))
+            _native.check(rc, 'tac_stft_backward_f32')
+            _count('tac_stft_backward_f32')
+        else:
+            rc = _native.lib().tac_stft_norm_backward_f32(_native.ptr(gs), _native.ptr(gn), float(power), _native.ptr(window),
+                                                          desc, _native.ptr(frames), _native.stream_ptr(wave.device))
+            _native.check(rc, 'tac_stft_norm_backward_f32')
+            _count('tac_stft_norm_backward_f32')
         rc = _native.lib().tac_overlap_add_f32(_native.ptr(frames), desc, _native.ptr(out), g.length,
                                                _native.stream_ptr(wave.device))
         _native.check(rc, 'tac_overlap_add_f32')

@@ -163,8 +163,9 @@ def _spectrogram_hip_backward(saved, rest, needs, grads):
     g = grads[0]
     if db:
         g = H.amplitude_to_db_backward(H.complex_norm(z, power), g, amin)
-    gz = H.complex_norm_backward(z, g, power)
-    return [H.stft_backward(gz, wave, window, n_fft, hop, win_length, center, pad_mode, normalized), None]
+    # the norm's adjoint is folded into the inverse-FFT kernel's load: no gradient spectrum in memory
+    return [H.stft_backward(z, wave, window, n_fft, hop, win_length, center, pad_mode, normalized, grad_norm=g, power=power),
+            None]
 
 
 def _melspectrogram_hip_backward(saved, rest, needs, grads):
@@ -175,11 +176,13 @@ def _melspectrogram_hip_backward(saved, rest, needs, grads):
     window = window.contiguous()
     z = H.stft(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided)
     g = grads[0]
-    if db:
-        mel = H.apply_filterbank(H.complex_norm(z, power), bank)
+    if db:      # the mel values the dB gradient needs come from the fused forward kernel (one launch), not from z
+        mel = H.melspectrogram(wave, window, bank, n_fft, hop, win_length, center, pad_mode, normalized, onesided, power,
+                               False, 1.0, 1e-7)
         g = H.amplitude_to_db_backward(mel, g, amin)
-    gz = H.complex_norm_backward(z, H.apply_filterbank_backward(g, bank), power)
-    return [H.stft_backward(gz, wave, window, n_fft, hop, win_length, center, pad_mode, normalized), None, None]
+    gp = H.apply_filterbank_backward(g, bank)
+    return [H.stft_backward(z, wave, window, n_fft, hop, win_length, center, pad_mode, normalized, grad_norm=gp, power=power),
+            None, None]
 
 
 def _apply_filterbank_hip_backward(saved, rest, needs, grads):
