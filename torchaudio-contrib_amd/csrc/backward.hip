@@ -142,22 +142,23 @@ stft_backward_kernel(FrameGeom g, Tables tb, const float* __restrict__ gspec, co
 __global__ void __launch_bounds__(256)
 overlap_add_kernel(FrameGeom g, int n_fft, const float* __restrict__ frames, float* __restrict__ gwave,
                    long long gwave_row_stride) {
-    const long long L = g.length;
-    const long long total = g.rows * L;
+    // positions inside a row are 32-bit (L < 2^31 - 2 n_fft, host-checked): only the final addresses are 64-bit — the
+    // 64-bit divisions of the first version were most of this kernel's time
+    const int L = (int)g.length, T = (int)g.n_frames;
     const int pad = g.center_pad, hop = g.hop;
+    const long long total = g.rows * (long long)L;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
-        const long long row = idx / L;
-        const long long j = idx - row * L;
-        const float* fr = frames + row * g.n_frames * n_fft;
+        const int row = (int)(idx / L);
+        const int j = (int)(idx - (long long)row * L);
+        const float* fr = frames + (long long)row * T * n_fft;
         float acc = 0.0f;
-        auto add_position = [&](long long i) {                          // i: position in the padded signal minus pad
-            const long long p = i + pad;                                // 0 <= p < L + 2 pad
-            long long t1 = p / hop;
-            if (t1 > g.n_frames - 1) t1 = g.n_frames - 1;
-            long long t0 = (p - n_fft + hop) / hop;                     // ceil((p - n_fft + 1) / hop)
-            if (p - n_fft + 1 <= 0) t0 = 0;
-            for (long long tt = t0; tt <= t1; ++tt) acc += fr[tt * n_fft + (p - tt * hop)];
+        auto add_position = [&](int i) {                                // i: position in the padded signal minus pad
+            const int p = i + pad;                                      // 0 <= p < L + 2 pad
+            int t1 = p / hop;
+            if (t1 > T - 1) t1 = T - 1;
+            int t0 = p - n_fft + 1 <= 0 ? 0 : (p - n_fft + hop) / hop;  // ceil((p - n_fft + 1) / hop)
+            for (int tt = t0; tt <= t1; ++tt) acc += fr[(long long)tt * n_fft + (p - tt * hop)];
         };
         add_position(j);
         if (pad > 0) {
@@ -165,8 +166,8 @@ overlap_add_kernel(FrameGeom g, int n_fft, const float* __restrict__ frames, flo
                 if (j >= 1 && j <= pad) add_position(-j);
                 if (j <= L - 2 && j >= L - 1 - pad) add_position(2 * (L - 1) - j);
             } else if (g.pad_mode == PAD_REPLICATE) {
-                if (j == 0) for (long long i = -pad; i < 0; ++i) add_position(i);
-                if (j == L - 1) for (long long i = L; i < L + pad; ++i) add_position(i);
+                if (j == 0) for (int i = -pad; i < 0; ++i) add_position(i);
+                if (j == L - 1) for (int i = L; i < L + pad; ++i) add_position(i);
             } else if (g.pad_mode == PAD_CIRCULAR) {
                 if (j >= L - pad) add_position(j - L);
                 if (j < pad) add_position(j + L);
@@ -176,6 +177,7 @@ overlap_add_kernel(FrameGeom g, int n_fft, const float* __restrict__ frames, flo
     }
 }
 
+// d/dz of |z|^power lives above (norm_pow_grad)
 __global__ void __launch_bounds__(256)
 complex_norm_backward_kernel(const float* __restrict__ z, const float* __restrict__ gout, long long n, float power,
                              float* __restrict__ gz) {
