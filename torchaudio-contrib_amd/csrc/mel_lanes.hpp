@@ -8,8 +8,8 @@
 // read and two packed FMAs per step.  The contraction is latency, not work (a first version with one LDS round trip
 // per step took a third of the fft_length-400 kernel): slots are processed in groups of lm_group(S, FLY) whose reads
 // are all issued before the first FMA, and a group's first bins are read one group earlier.
-// pack_lane_mel builds:  desc = first bin [slot][lane], wpack = [slot][step][lane][4 taps], both zero-padded to whole
-// groups plus one.
+// pack_lane_mel builds:  desc = first bin [slot][lane] (zero-padded to whole groups plus one), wpack =
+// [slot][step][lane][4 taps] (zero-padded to whole groups).
 // (Measured and dropped: cutting the bands into equal 8-bin chunks dealt to the lanes in order, partial sums combined
 // with ds_add_f32 into the LDS row — no wasted taps, but the atomics cost more than the taps they save: 0.36 vs 0.157 ms
 // at 512 / 80 bands.)
@@ -29,15 +29,18 @@ struct LaneMel {
     float* out;                 // [rows][T][n_mels]
 };
 
-constexpr int LM_MAX_MELS = 128, LM_MIN_MELS = 8, LM_MAX_STEPS = 12;
+constexpr int LM_MAX_MELS = 128, LM_MIN_MELS = 8, LM_MAX_STEPS = 12, LM_MAX_STEPS_WAVE = 16;   // (LANES = 64: one frame per wave, two slots)
 constexpr int LM_MARK = 1000;                                              // info_host[2] = LM_MARK + lanes per frame
 typedef float lm_f4 __attribute__((ext_vector_type(4)));
 
 // slots per group: about FLY steps (8 registers each) in flight
 __host__ __device__ constexpr int lm_group(int S, int FLY) { return FLY / S < 1 ? 1 : (FLY / S > 8 ? 8 : FLY / S); }
-__host__ __device__ constexpr int lm_padded_slots(int nslot, int S, int FLY) {
-    return ((nslot + lm_group(S, FLY) - 1) / lm_group(S, FLY) + 1) * lm_group(S, FLY);
+// slots the weights cover (whole groups) and slots the first-bin table covers (one group more: a group's first bins
+// are read a group ahead)
+__host__ __device__ constexpr int lm_weight_slots(int nslot, int S, int FLY) {
+    return ((nslot + lm_group(S, FLY) - 1) / lm_group(S, FLY)) * lm_group(S, FLY);
 }
+__host__ __device__ constexpr int lm_padded_slots(int nslot, int S, int FLY) { return lm_weight_slots(nslot, S, FLY) + lm_group(S, FLY); }
 __host__ __device__ constexpr int lm_desc_ints(int lanes) { return lanes * (LM_MAX_MELS / lanes + 8); }
 // LDS of the fused form behind a kernel's own: first bins + packed weights
 inline size_t lm_lds_bytes(int lanes, int wtot) {
@@ -126,7 +129,7 @@ __device__ __forceinline__ void lane_mel_store(const float* mstage, int am, int 
 // multiple of `step_quantum`, groups sized for `fly` steps in flight (the kernel's FLY).
 // TAC_E_UNSUPPORTED when the bank does not fit (fewer than 8 / more than 128 bands, bands wider than 4 LM_MAX_STEPS).
 inline int pack_lane_mel(const std::vector<float>& h, int n_freqs, int n_mels, int lanes, int pitch, int step_quantum, int fly,
-                         size_t base_lds, float* wpack, int wpack_cap, int32_t* desc, int desc_cap, int32_t* info_host,
+                         int max_steps, size_t base_lds, float* wpack, int wpack_cap, int32_t* desc, int desc_cap, int32_t* info_host,
                          hipStream_t stream) {
     if (n_mels < LM_MIN_MELS || n_mels > LM_MAX_MELS) return TAC_E_UNSUPPORTED;
     const int nslot = (n_mels + lanes - 1) / lanes;
@@ -143,10 +146,10 @@ inline int pack_lane_mel(const std::vector<float>& h, int n_freqs, int n_mels, i
         }
     }
     S = ((S + step_quantum - 1) / step_quantum) * step_quantum;            // (the kernels are instantiated for these values of S only)
-    if (S > LM_MAX_STEPS || 4 * S > pitch) return TAC_E_UNSUPPORTED;       // bands too wide: the unfused chain
+    if (S > max_steps || 4 * S > pitch) return TAC_E_UNSUPPORTED;          // bands too wide: the unfused chain
     const int pslot = lm_padded_slots(nslot, S, fly);
     if (lanes * pslot > desc_cap || lanes * pslot > lm_desc_ints(lanes)) return TAC_E_UNSUPPORTED;
-    const long long wtot = 4LL * lanes * S * pslot;
+    const long long wtot = 4LL * lanes * S * lm_weight_slots(nslot, S, fly);
     if (wtot > wpack_cap || base_lds + lm_lds_bytes(lanes, (int)wtot) > 160 * 1024) return TAC_E_UNSUPPORTED;
     std::vector<float> wp((size_t)wtot, 0.0f);
     std::vector<int32_t> dd((size_t)lanes * pslot, 0);
@@ -176,9 +179,9 @@ inline int pack_lane_mel(const std::vector<float>& h, int n_freqs, int n_mels, i
 }
 
 // what a launcher checks before trusting a pack
-inline bool lane_mel_info_ok(const int32_t* info, int lanes, int fly) {
+inline bool lane_mel_info_ok(const int32_t* info, int lanes, int fly, int max_steps = LM_MAX_STEPS) {
     return info[2] == LM_MARK + lanes && info[1] >= 1 && info[1] <= LM_MAX_MELS / lanes + (LM_MAX_MELS % lanes ? 1 : 0) &&
-           info[4] >= 1 && info[4] <= LM_MAX_STEPS && info[0] == 4 * lanes * info[4] * lm_padded_slots(info[1], info[4], fly);
+           info[4] >= 1 && info[4] <= max_steps && info[0] == 4 * lanes * info[4] * lm_weight_slots(info[1], info[4], fly);
 }
 
 }  // namespace tac

@@ -67,6 +67,9 @@ int launch_small_mel_entry(int n_fft, const FrameGeom& g, const Tables& tb, floa
                            hipStream_t stream);
 int pack_small(int n_fft, const std::vector<float>& h, int n_freqs, int n_mels, float* wpack, int wpack_cap, int32_t* desc,
                int desc_cap, int32_t* info_host, hipStream_t stream);
+#ifndef TAC_FB_LANES
+#define TAC_FB_LANES 1      // standalone apply_filterbank: the wave-autonomous lane-layout kernel where the bank allows it (0: A/B knob)
+#endif
 #ifndef TAC_SP_LANES
 #define TAC_SP_LANES 1      // fft_length 512 / 1024: the lane-layout fused form of stft_small.hip where the bank allows it (0: A/B knob)
 #endif
@@ -462,6 +465,104 @@ static int launch_stream(FrameGeom g, const Tables& tb, const SparseArgs& sm, co
     return TAC_OK;
 }
 
+// ---------------------------------------------------------------- standalone band-sparse filterbank, wave-autonomous form
+// functional.apply_filterbank on a frame-major spectrogram whose bank fits the lane layout of mel_lanes.hpp with one
+// frame per wave (LANES = 64: lane l owns bands l and 64 + l): every wave draws frames from a workgroup counter, parks
+// the frame's row in its own LDS buffer (16-byte chunks, the next frame's requested before this one is contracted),
+// contracts it and stores the band row — no workgroup barrier, no tile.  (fb_sparse_kernel above, round 1's 16-frame
+// tiles between barriers, stays the route for banks outside this layout and for other frame strides.)
+constexpr int FBL_WAVES = 8, FBL_FLY = 16, FBL_CHUNKS = 5;                  // up to 5 x 256 = 1280 bins per frame
+__host__ __device__ inline int fbl_pitch(int n_freqs) { return (n_freqs + 3 + 3) & ~3; }
+inline size_t fbl_base_lds(int n_freqs) { return (size_t)FBL_WAVES * (fbl_pitch(n_freqs) + LM_MAX_MELS + 4) * sizeof(float) + 16; }
+
+template <int S>
+__global__ void __launch_bounds__(FBL_WAVES * 64, 2)
+fb_lanes_kernel(const float* __restrict__ spec, long long rows, int n_freqs, long long n_frames, long long stride_r,
+                long long stride_t, LaneMel mel) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pitch = fbl_pitch(n_freqs);
+    float* const srow = reinterpret_cast<float*>(smem_raw) + (size_t)w * (pitch + LM_MAX_MELS + 4);
+    float* const mbuf = srow + pitch;                                        // the band row, staged at its 16-byte phase
+    unsigned* const next_frame = reinterpret_cast<unsigned*>(reinterpret_cast<float*>(smem_raw) +
+                                                             (size_t)FBL_WAVES * (pitch + LM_MAX_MELS + 4));
+    int* const mlo = reinterpret_cast<int*>(next_frame + 4);
+    float* const mwl = reinterpret_cast<float*>(mlo + lm_desc_ints(64));
+    lane_mel_load_tables<S, 64, FBL_FLY>(mlo, mwl, mel, threadIdx.x, FBL_WAVES * 64);
+
+    const long long total = rows * n_frames;
+    const long long chunk = (total + gridDim.x - 1) / gridDim.x;
+    const long long begin = (long long)blockIdx.x * chunk;
+    const long long endl = begin + chunk < total ? begin + chunk : total;
+    const int nloc = endl > begin ? (int)(endl - begin) : 0;
+    if (threadIdx.x == 0) *next_frame = FBL_WAVES;
+    __syncthreads();
+    auto grab = [&]() -> int {
+        unsigned v = 0;
+        if (lane == 0) v = __hip_atomic_fetch_add(next_frame, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return (int)__builtin_amdgcn_readfirstlane(v);
+    };
+    // a frame's row as 16-byte chunks (global loads only need dword alignment); chunks past the row are clamped to its
+    // last full one (the slack behind the bins is zeroed by the contraction)
+    const int nch = (n_freqs + 3) >> 2, lastc = (n_freqs >> 2) - 1;         // chunk `nch - 1` may straddle the row's end
+    f4 nxt[FBL_CHUNKS];
+    float tail[3];
+    auto request = [&](int i) {
+        const long long gf = begin + i;
+        const long long r = gf / n_frames;
+        const float* src = spec + r * stride_r + (gf - r * n_frames) * stride_t;
+#pragma unroll
+        for (int u = 0; u < FBL_CHUNKS; ++u) {
+            const int c = lane + 64 * u;
+            nxt[u] = *reinterpret_cast<const f4*>(src + 4 * (c < lastc ? c : lastc));
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) tail[u] = src[n_freqs - 1 - u];          // the (n_freqs mod 4) bins behind the last full chunk
+    };
+    auto deposit = [&]() {
+#pragma unroll
+        for (int u = 0; u < FBL_CHUNKS; ++u) {
+            const int c = lane + 64 * u;
+            if (c <= lastc) *reinterpret_cast<f4*>(srow + 4 * c) = nxt[u];
+        }
+        if (lane < 3 && n_freqs - 1 - lane > 4 * lastc + 3) srow[n_freqs - 1 - lane] = tail[lane == 0 ? 0 : (lane == 1 ? 1 : 2)];
+    };
+    int i = w;
+    if (i < nloc) request(i);
+    while (i < nloc) {
+        const int nx = grab();
+        wave_lds_fence();
+        deposit();
+        wave_lds_fence();
+        if (nx < nloc) request(nx);                                           // in flight during the contraction
+        const long long g0 = (begin + i) * (long long)mel.n_mels;
+        const int am = (int)(g0 & 3);
+        lane_mel_contract<S, 64, FBL_FLY>(srow, n_freqs, mlo, mwl, lane, mel, mbuf + am);
+        wave_lds_fence();
+        lane_mel_store<1>(mbuf + am, am, mel.n_mels, mel.out + g0, lane);
+        i = nx;
+    }
+}
+
+template <int S>
+static int launch_fb_lanes(const float* spec, long long rows, int n_freqs, long long n_frames, long long stride_r,
+                           long long stride_t, const LaneMel& mel, hipStream_t stream) {
+    const size_t bytes = fbl_base_lds(n_freqs) + lm_lds_bytes(64, mel.wtot);
+    if (bytes > 160 * 1024) return TAC_E_UNSUPPORTED;
+    const long long total = rows * n_frames;
+    if (total >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
+    long long blocks = (total + FBL_WAVES - 1) / FBL_WAVES;
+    if (blocks > device_cu_count()) blocks = device_cu_count();
+    auto kern = fb_lanes_kernel<S>;
+    if (bytes > 64 * 1024) TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(FBL_WAVES * 64), bytes, stream, spec, rows, n_freqs, n_frames, stride_r,
+                       stride_t, mel);
+    TAC_HIP(hipGetLastError());
+    return TAC_OK;
+}
+
 // Lane layout of the streaming kernel: lane l owns bands l, 64 + l, ... (slot s = band / 64).  Every slot is one loop
 // of steps[s] four-tap steps (the longest band of the slot, in whole trips of four steps); shorter bands are
 // zero-padded, and a band whose padded run would leave the row buffer is shifted down (zeros in front) so that every
@@ -569,6 +670,11 @@ int tac_melbank_pack(const float* fb, int32_t n_freqs, int32_t n_mels, int32_t n
     TAC_HIP(hipStreamSynchronize((hipStream_t)stream));
     if (TAC_SP_STREAM && n_fft == 2048)
         return pack_lanes(h, n_freqs, n_mels, wpack, wpack_cap, desc, desc_cap, info_host, (hipStream_t)stream);
+    if (TAC_FB_LANES && n_fft == 0 && n_freqs >= 8 && (n_freqs + 3) / 4 <= FBL_CHUNKS * 64) {   // standalone: one frame per wave
+        const int rc = pack_lane_mel(h, n_freqs, n_mels, 64, fbl_pitch(n_freqs), 2, FBL_FLY, LM_MAX_STEPS_WAVE, fbl_base_lds(n_freqs),
+                                     wpack, wpack_cap, desc, desc_cap, info_host, (hipStream_t)stream);
+        if (rc != TAC_E_UNSUPPORTED) return rc;                             // else: the tile kernel's layout
+    }
     if (n_fft == 400) return pack_n400(h, n_freqs, n_mels, wpack, wpack_cap, desc, desc_cap, info_host, (hipStream_t)stream);
     if (TAC_SP_LANES && (n_fft == 512 || n_fft == 1024)) {
         const int rc = pack_small(n_fft, h, n_freqs, n_mels, wpack, wpack_cap, desc, desc_cap, info_host, (hipStream_t)stream);
@@ -705,6 +811,18 @@ int tac_apply_filterbank_sparse_f32(const float* spec, int64_t rows, int32_t n_f
     if (rows == 0 || n_frames == 0) return TAC_OK;
     if (!spec || !wpack || !desc || !info_host || !out) return TAC_E_INVALID;
     if (rows < 0 || n_freqs <= 0 || n_frames < 0 || n_mels <= 0) return TAC_E_INVALID;
+    if (info_host[2] == LM_MARK + 64) {                                            // lane layout: the wave-autonomous kernel
+        if (!lane_mel_info_ok(info_host, 64, FBL_FLY, LM_MAX_STEPS_WAVE)) return TAC_E_INVALID;
+        if (n_mels < LM_MIN_MELS || n_mels > LM_MAX_MELS || (n_freqs + 3) / 4 > FBL_CHUNKS * 64) return TAC_E_UNSUPPORTED;
+        const LaneMel lm{wpack, desc, info_host[1], info_host[0], n_mels, 0, 0.0f, 0.0f, out};
+        const long long sr = rows > 1 ? stride_r : 0;
+        switch (info_host[4]) {
+#define TAC_FBL_CASE(SS) case SS: return launch_fb_lanes<SS>(spec, rows, n_freqs, n_frames, sr, stride_t, lm, (hipStream_t)stream);
+            TAC_FBL_CASE(2) TAC_FBL_CASE(4) TAC_FBL_CASE(6) TAC_FBL_CASE(8) TAC_FBL_CASE(10) TAC_FBL_CASE(12) TAC_FBL_CASE(14) TAC_FBL_CASE(16)
+#undef TAC_FBL_CASE
+            default: return TAC_E_INVALID;
+        }
+    }
     if (info_host[2] != FBS_WAVES * 4) return TAC_E_INVALID;                       // pack built for another geometry
     if ((long long)FBS_TILE * ((n_freqs + 3) / 4) > (long long)FBS_CHUNKS * FBS_WAVES * 64) return TAC_E_UNSUPPORTED;
     int prow = n_freqs + 7;

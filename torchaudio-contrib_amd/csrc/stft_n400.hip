@@ -421,7 +421,7 @@ int launch_n400_mel(const FrameGeom& g, float power, const float* wpack, const i
 int pack_n400(const std::vector<float>& h, int n_freqs, int n_mels, float* wpack, int wpack_cap, int32_t* desc,
               int desc_cap, int32_t* info_host, hipStream_t stream) {
     if (n_freqs != Q4_BINS) return TAC_E_UNSUPPORTED;
-    return pack_lane_mel(h, n_freqs, n_mels, 8, Q4_MEL_PITCH, 1, Q4_FLY, q4_lds_bytes(0), wpack, wpack_cap, desc, desc_cap, info_host,
+    return pack_lane_mel(h, n_freqs, n_mels, 8, Q4_MEL_PITCH, 1, Q4_FLY, LM_MAX_STEPS, q4_lds_bytes(0), wpack, wpack_cap, desc, desc_cap, info_host,
                          stream);
 }
 

@@ -267,7 +267,7 @@ int pack_small(int n_fft, const std::vector<float>& h, int n_freqs, int n_mels, 
     if ((n_fft != 512 && n_fft != 1024) || n_freqs != n_fft / 2 + 1) return TAC_E_UNSUPPORTED;
     const int lanes = n_fft == 512 ? 16 : 32;
     const size_t base = n_fft == 512 ? small_lds_bytes<256>() : small_lds_bytes<512>();
-    return pack_lane_mel(h, n_freqs, n_mels, lanes, sm_mel_pitch(n_fft / 2), 2, SM_FLY, base, wpack, wpack_cap, desc, desc_cap,
+    return pack_lane_mel(h, n_freqs, n_mels, lanes, sm_mel_pitch(n_fft / 2), 2, SM_FLY, LM_MAX_STEPS, base, wpack, wpack_cap, desc, desc_cap,
                          info_host, stream);
 }
 
