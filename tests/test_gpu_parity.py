@@ -319,10 +319,12 @@ def test_apply_filterbank_mel_sparse_plan(tac):
 
 def test_apply_filterbank_streams_frame_major_spectrograms(tac):
     """apply_filterbank on the strided (…, F, T) views the spectrogram kernels return takes the band-sparse streaming
-    kernel (packed rows fetched as 16-byte chunks): ragged last tiles, a frame count that leaves a chunk straddling
-    the row end, batches, band counts that are not multiples of four, and a sliced (non-packed) frame stride."""
+    kernels (the wave-autonomous lane-layout kernel where the bank fits it, the tile kernel otherwise — 13 bands, 2049
+    bins): bin counts that are not multiples of four, ragged tiles, batches, odd band counts, and a sliced (non-packed)
+    frame stride."""
     for n_fft, hop, n_mels, length, rows in ((2048, 512, 128, 30000, (3, 1)), (1024, 256, 40, 7777, (2, 2)),
-                                              (512, 160, 13, 5000, (5,)), (2048, 512, 80, 160000, (4, 1))):
+                                              (512, 160, 13, 5000, (5,)), (2048, 512, 80, 160000, (4, 1)),
+                                              (400, 160, 80, 9000, (2,)), (4096, 1024, 64, 40000, (2,)), (256, 64, 8, 3000, (3,))):
         x = signals.uniform(rows + (length,), seed=91 + n_mels)
         spec = tac.Spectrogram(n_fft, hop, power=2.).cuda()(dev(x))
         assert spec.stride(-2) == 1                                   # frame-major view
