@@ -113,6 +113,11 @@ def _mel_to_hz(mel, htk):
     return torch.where(mel >= knee_mel, knee_hz * torch.exp(step * (mel - knee_mel)), 0.0 + f_sp * mel)
 
 
+# the reference's (private) names of the two conversions, functional.py:5-45: call sites that import them keep working
+_hertz_to_mel = _hz_to_mel
+_mel_to_hertz = _mel_to_hz
+
+
 def create_mel_filter(num_freqs, num_mels, min_freq, max_freq, htk):
     """Dense ``(num_freqs, num_mels)`` triangular mel filterbank, Slaney (default) or HTK scale, no
     area normalisation, bin grid ``linspace(min_freq, max_freq, num_freqs)`` (reference:
