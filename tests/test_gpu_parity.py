@@ -795,20 +795,65 @@ def test_autograd_matches_the_reference_chain(tac, shape, n_fft, hop, mels):
     (want,) = torch.autograd.grad((want_y * torch.from_numpy(weight)).sum(), xc)
     xg = dev(x).requires_grad_(True)
     mel = tac.Melspectrogram(num_mels=mels, sample_rate=16000, fft_length=n_fft, hop_length=hop).cuda()
-    for fused, chain in ((True, torch.nn.Sequential(mel, tac.AmplitudeToDb(amin=1e-5))),   # factory container + dB
-                         (False, torch.nn.Sequential(*mel, tac.AmplitudeToDb(amin=1e-5)))):  # the unpacked idiom: op by op
+    for idiom, chain in ((False, torch.nn.Sequential(mel, tac.AmplitudeToDb(amin=1e-5))),   # factory container + dB
+                         (True, torch.nn.Sequential(*mel, tac.AmplitudeToDb(amin=1e-5)))):   # the unpacked (reference) idiom
+        before = launches(tac)
         y = chain(xg)
+        if idiom:       # deferred although the waveform requires grad: ONE fused forward kernel, dB included
+            assert launched_since(tac, before) == {'tac_melspec_sparse_f32': 1}
         assert y.requires_grad and np.abs(host(y) - want_y.detach().numpy()).max() < DB_ABS
         before = launches(tac)
         (got,) = torch.autograd.grad((y * dev(weight)).sum(), xg)
         ran = launched_since(tac, before)
         # the HIP gradient kernels: the inverse-FFT kernel with the norm's adjoint folded into its load, the overlap-add
+        # the fused op's backward either way: inverse-FFT kernel with the norm's adjoint folded in, overlap-add
         assert ran.get('tac_overlap_add_f32') == 1, ran
-        if fused:
-            assert ran.get('tac_stft_norm_backward_f32') == 1 and 'tac_complex_norm_backward_f32' not in ran, ran
-        else:
-            assert ran.get('tac_stft_backward_f32') == 1 and ran.get('tac_complex_norm_backward_f32') == 1, ran
+        assert ran.get('tac_stft_norm_backward_f32') == 1 and 'tac_complex_norm_backward_f32' not in ran, ran
         assert rel_err(host(got), want.numpy()) < 1e-3
+
+
+def test_deferred_results_carry_gradients(tac):
+    """A waveform that requires grad is deferred like any other (the reference idiom trains through the fused kernels);
+    whatever consumes a pending result — a terminal layer, a torch function, a method, a view, an in-place-free
+    expression, torch.autograd.grad on the pending result itself — gets the graph eager evaluation would have built."""
+    x = signals.audio_like((2, 1, 9000), seed=81)
+    n_fft, hop = 512, 128
+    xc = torch.from_numpy(x).requires_grad_(True)
+    zc = torch_ref.stft(xc, n_fft, hop)
+    stft = tac.STFT(n_fft, hop).cuda()
+    cases = [('pow-sum', lambda z: z.pow(2).sum()), ('transpose-mul', lambda z: (z.transpose(-2, -3) * 3.0).sum()),
+             ('index', lambda z: z[..., 5:40, :, 0].abs().sum()), ('torch-fn', lambda z: torch.sum(torch.tanh(z))),
+             ('reshape-matmul', lambda z: (z.reshape(z.shape[0], -1) @ torch.ones(z[0].numel(), 1, device=z.device, dtype=z.dtype)).sum()),
+             ('norm-layer', None)]
+    for name, fn in cases:
+        xg = dev(x).requires_grad_(True)
+        before = launches(tac)
+        z = stft(xg)
+        assert type(z) is tac._lazy.DeferredSpectral and z.pending() and z.requires_grad, name
+        assert tuple(z.shape) == tuple(zc.shape) and launched_since(tac, before) == {}, name      # metadata only, nothing ran
+        if fn is None:
+            m = tac.ComplexNorm(power=2.0)(z)                       # still pending, still carrying the gradient
+            assert type(m) is tac._lazy.DeferredSpectral and m.pending()
+            loss, want_loss = m.sum(), torch_ref.complex_norm(zc, 2.0).sum()
+            assert launched_since(tac, before).get('tac_spectrogram_f32') == 1
+        else:
+            loss, want_loss = fn(z), fn(zc)
+        assert loss.requires_grad and abs(float(loss.detach()) - float(want_loss.detach())) <= 1e-4 * abs(float(want_loss.detach())) + 1e-3, name
+        (got,) = torch.autograd.grad(loss, xg)
+        (want,) = torch.autograd.grad(want_loss, xc, retain_graph=True)
+        assert rel_err(host(got), want.numpy()) < 1e-4, name
+    # torch.autograd.grad / backward on the pending result itself
+    xg = dev(x).requires_grad_(True)
+    y = torch.nn.Sequential(*tac.Spectrogram(n_fft, hop, power=2.0)).cuda()(xg)
+    w = dev(signals.uniform(tuple(y.shape), seed=82))
+    (got,) = torch.autograd.grad(y, xg, grad_outputs=w)
+    yc = torch_ref.spectrogram(xc, n_fft, hop, power=2.0)
+    (want,) = torch.autograd.grad(yc, xc, grad_outputs=torch.from_numpy(host(w)))
+    assert rel_err(host(got), want.numpy()) < 1e-4
+    # no_grad: an ordinary deferred result, nothing recorded
+    with torch.no_grad():
+        z = stft(dev(x).requires_grad_(True))
+        assert not z.requires_grad and not (z * 2).requires_grad
 
 
 @pytest.mark.parametrize('n_fft,hop,kw', [(512, 128, {}), (256, 64, dict(pad_mode='constant')), (1024, 300, dict(pad_mode='replicate')),

@@ -33,8 +33,8 @@ elif what == 'fb':
     fbd = torch.rand(1025, 128, device='cuda')
     fn = lambda: tac.apply_filterbank(spec, fbd)
 elif what == 'grad':
-    # forward + backward of the reference idiom with a waveform that requires grad: op by op (deferral is off for
-    # tensors in an autograd graph), HIP gradient kernels
+    # forward + backward of the reference idiom with a waveform that requires grad: deferred like any other call (one
+    # fused forward kernel), differentiated through the tac_amd::melspectrogram op's HIP gradient kernels
     m = torch.nn.Sequential(*tac.Melspectrogram(num_mels=128, sample_rate=16000, fft_length=2048, hop_length=512),
                             tac.AmplitudeToDb()).cuda()
     xg = x.clone().requires_grad_(True)

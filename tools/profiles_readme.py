@@ -115,8 +115,9 @@ out.append('All three kernels run 2 waves/SIMD (one 8-wave workgroup per CU whos
            'DESIGN.md §3.2/§3.3 hold the stage-stamp breakdowns, the ablations and the list of variants measured not to help.')
 for fname, what in (('kernel_stats_backward.csv',
                      '`tools/prof_driver.py grad 5`: forward + backward of the reference idiom `Sequential(*Melspectrogram(...), '
-                     'AmplitudeToDb())` at cfg-2 with `requires_grad` on the waveform — op by op (tensors in an autograd graph '
-                     'are not deferred), HIP gradient kernels'),
+                     'AmplitudeToDb())` at cfg-2 with `requires_grad` on the waveform: the chain is deferred as usual (one fused '
+                     'forward kernel) and differentiates through the `tac_amd::melspectrogram` op — spectrum and mel values '
+                     'recomputed, filterbank adjoint, inverse-FFT kernel that forms the gradient spectrum on load, overlap-add'),
                     ('kernel_stats_backward_fused_op.csv',
                      '`tools/prof_driver.py gradf 5`: the same through the factory container (`Melspectrogram(...)` called as '
                      'ONE `tac_amd::melspectrogram` op): fused forward kernel; backward = spectrum recomputed, filterbank adjoint, '
@@ -132,9 +133,9 @@ for fname, what in (('kernel_stats_backward.csv',
     tot = 0.0
     for r in csv.DictReader(open(pb)):
         if 'tac::' in r['Name'] and int(r['Calls']) >= 5:
-            tot += float(r['AverageNs']) / 1e6
+            tot += float(r['TotalDurationNs']) / 5e6                  # five steps were profiled
             out.append('| `%s` | %s | %.4f ms |' % (r['Name'].split('(')[0].replace('void ', ''), r['Calls'], float(r['AverageNs']) / 1e6))
-    out.append('| sum of the per-call averages | | %.3f ms |' % tot)
+    out.append('| kernel time per step (total / 5 steps) | | %.3f ms |' % tot)
 out.append('')
 out.append('Micro-benchmarks behind the design decisions (sources in `tools/ubench/`, outputs quoted in DESIGN.md): '
            '`valu_rate` (scalar vs packed f32 issue rates), `lds_rate` (LDS access shapes at 8 waves/CU), `hbm_rate` '

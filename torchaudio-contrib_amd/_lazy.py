@@ -15,8 +15,13 @@ Safety of the deferral (the reference is eager; these make the difference unobse
     of the wrong batch;
   * the kernel is enqueued on the stream that was current at ``forward`` time; if another stream is current when
     the value is needed, that stream is made to wait for it;
-  * tensors that require grad, CPU tensors, float64 and ``torch.compile`` tracing are never deferred — the layers
-    call the ops eagerly there.
+  * CPU tensors, float64 and ``torch.compile`` tracing are never deferred — the layers call the ops eagerly there;
+  * a waveform that requires grad IS deferred (so that the reference idiom trains through the fused kernel and its
+    fused backward): the recipe is then materialised by the registered ``tac_amd::*`` op, whose autograd entry links the
+    result to the waveform.  ``AmplitudeToDb`` / ``realize()`` do that at module level; any other use of such a pending
+    result is caught by ``__torch_function__`` — i.e. ABOVE autograd — and replaced by the materialised tensor, so the
+    graph is the one eager evaluation would have built.  (``__torch_dispatch__`` runs below autograd: a value
+    materialised there would be cut off from the waveform, so reaching it with a gradient-carrying recipe raises.)
 """
 import torch
 from torch.utils._pytree import tree_map
@@ -49,7 +54,9 @@ def can_defer(wave, window):
         return False
     if torch.compiler.is_compiling() or torch._C._len_torch_dispatch_stack():
         return False
-    if torch.is_grad_enabled() and (wave.requires_grad or window.requires_grad):
+    if torch.is_grad_enabled() and window.requires_grad:
+        return False
+    if torch.is_grad_enabled() and wave.requires_grad and not wave.dtype.is_floating_point:
         return False
     return window.device == wave.device and window.dtype in _DEFERRABLE
 
@@ -100,10 +107,12 @@ class DeferredWave(torch.Tensor):
 
 class _Source(object):
     """The STFT call a recipe starts from, plus what is needed to detect that its inputs changed meanwhile."""
-    __slots__ = ('wave', 'window', 'args', 'stream', 'stamps', 'lead', 'n_frames', 'n_bins', 'decode')
+    __slots__ = ('wave', 'window', 'args', 'stream', 'stamps', 'lead', 'n_frames', 'n_bins', 'decode', 'grad')
 
     def __init__(self, wave, window, args):
         self.decode = None                      # n_quantize when `wave` holds mu-law codes (from a DeferredWave)
+        # gradient flows through this recipe: it must be materialised above autograd (see the module docstring)
+        self.grad = bool(torch.is_grad_enabled() and isinstance(wave, torch.Tensor) and wave.requires_grad)
         if isinstance(wave, DeferredWave):
             self.decode, wave = wave._nq, wave._codes
         self.wave, self.window, self.args = wave, window, args
@@ -131,8 +140,9 @@ class DeferredSpectral(torch.Tensor):
     @staticmethod
     def __new__(cls, src, stage, shape, strides, power=None, filterbank=None):
         r = torch.Tensor._make_wrapper_subclass(cls, shape, strides=strides, dtype=torch.float32,
-                                                device=src.wave.device, requires_grad=False)
+                                                device=src.wave.device, requires_grad=src.grad)
         r._src = src
+        r._tracks_grad = src.grad
         r._stage = stage            # 'stft' | 'spec' | 'mel'
         r._power = power
         r._fb = filterbank
@@ -161,6 +171,8 @@ class DeferredSpectral(torch.Tensor):
     def with_filterbank(self, fb):
         s = self._src
         s.watch(fb, 'filterbank')
+        if torch.is_grad_enabled() and fb.requires_grad:
+            s.grad = True
         return DeferredSpectral(s, 'mel', s.lead + (fb.shape[1], s.n_frames),
                                 _transposed_strides(s.lead, (s.n_frames, fb.shape[1]), -2, -1),
                                 power=self._power, filterbank=fb)
@@ -216,10 +228,68 @@ class DeferredSpectral(torch.Tensor):
         return 'DeferredSpectral(stage=%s, shape=%s, pending=%s)' % (self._stage, tuple(self.shape), self.pending())
 
     @classmethod
-    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if not torch.is_grad_enabled() or _is_metadata_query(func) or not _carries_grad(args, kwargs):
+            # what a subclass without __torch_function__ gets: the function runs as is (no re-wrapping of its results)
+            # and pending recipes are materialised by __torch_dispatch__
+            with torch._C.DisableTorchFunctionSubclass():
+                return func(*args, **kwargs)
+        # a gradient flows through the recipe: hand the caller's function the materialised tensor(s) here, above
+        # autograd, so that it records the graph eager evaluation would have recorded
         def unwrap(a):
             return a.realize() if isinstance(a, DeferredSpectral) else a
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*tree_map(unwrap, args), **tree_map(unwrap, kwargs))
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        def unwrap(a):
+            if isinstance(a, DeferredSpectral):
+                if a._tracks_grad and torch.is_grad_enabled():
+                    raise RuntimeError(
+                        'torchaudio_contrib_amd: a deferred spectrogram whose waveform requires grad reached %s below '
+                        'autograd; materialise it first with torchaudio_contrib_amd.realize(x) (or disable deferral '
+                        'with set_lazy_fusion(False))' % (func,))
+                return a.realize()
+            return a
         return func(*tree_map(unwrap, args), **tree_map(unwrap, kwargs or {}))
+
+
+#: attribute getters and methods that only read what the wrapper itself carries (shape, strides, dtype, device, autograd
+#: flags): they never need the value
+_METADATA_PROPERTIES = frozenset((
+    'shape', 'device', 'dtype', 'layout', 'ndim', 'requires_grad', 'grad', 'grad_fn', 'is_leaf', 'is_cuda', 'is_cpu',
+    'is_meta', 'is_sparse', 'is_sparse_csr', 'is_quantized', 'is_mkldnn', 'is_nested', 'is_xpu', 'is_mps', 'is_xla',
+    'is_vulkan', 'is_ort', 'is_ipu', 'is_mtia', 'is_maia', 'names', 'itemsize', 'nbytes', 'output_nr', '_version', '_base',
+    'name', 'retains_grad', '_grad', '_grad_fn'))
+_METADATA_METHODS = frozenset((
+    'size', 'dim', 'ndimension', 'stride', 'numel', 'nelement', 'is_contiguous', 'storage_offset', 'element_size',
+    'is_floating_point', 'is_complex', 'is_signed', 'get_device', 'is_pinned', 'is_inference', 'is_shared', '__len__',
+    '__repr__', '__hash__', 'has_names', '_is_view', 'is_conj', 'is_neg', 'sym_size', 'sym_stride', 'sym_numel',
+    'sym_storage_offset', 'dim_order'))
+
+
+def _is_metadata_query(func):
+    name = getattr(func, '__name__', '')
+    if name == '__get__':
+        return getattr(getattr(func, '__self__', None), '__name__', '') in _METADATA_PROPERTIES
+    if name == '__set__':
+        return True
+    return name in _METADATA_METHODS
+
+
+def _carries_grad(args, kwargs):
+    found = []
+
+    def look(a):
+        if isinstance(a, DeferredSpectral) and a._tracks_grad:
+            found.append(a)
+        return a
+    tree_map(look, args)
+    if not found and kwargs:
+        tree_map(look, kwargs)
+    return bool(found)
 
 
 _stride_cache = {}
