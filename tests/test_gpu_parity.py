@@ -854,6 +854,22 @@ def test_deferred_results_carry_gradients(tac):
     with torch.no_grad():
         z = stft(dev(x).requires_grad_(True))
         assert not z.requires_grad and not (z * 2).requires_grad
+    # a filterbank that requires grad behind a gradient-carrying pending spectrogram: both gradients, against the same
+    # chain on CPU tensors (the filterbank gradient takes the documented torch-operator route, hence non-strict)
+    tac.set_strict(False)
+    try:
+        xg = dev(x).requires_grad_(True)
+        mel = tac.Melspectrogram(num_mels=40, sample_rate=16000, fft_length=n_fft, hop_length=hop).cuda()
+        mel[2].filterbank.requires_grad_(True)
+        torch.nn.Sequential(*mel, tac.AmplitudeToDb())(xg).sum().backward()
+        xr = torch.from_numpy(x).requires_grad_(True)
+        melc = tac.Melspectrogram(num_mels=40, sample_rate=16000, fft_length=n_fft, hop_length=hop)
+        melc[2].filterbank.requires_grad_(True)
+        torch.nn.Sequential(*melc, tac.AmplitudeToDb())(xr).sum().backward()
+        assert rel_err(host(xg.grad), xr.grad.numpy()) < 1e-5
+        assert rel_err(host(mel[2].filterbank.grad), melc[2].filterbank.grad.numpy()) < 1e-5
+    finally:
+        tac.set_strict(True)
 
 
 @pytest.mark.parametrize('n_fft,hop,kw', [(512, 128, {}), (256, 64, dict(pad_mode='constant')), (1024, 300, dict(pad_mode='replicate')),
