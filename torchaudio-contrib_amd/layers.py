@@ -107,8 +107,9 @@ class ApplyFilterbank(_ModuleNoStateBuffers):
     def forward(self, mag_specgrams):
         x = mag_specgrams
         fb = self.filterbank
+        # (the recipe's own record of bins / device: attribute access on the wrapper goes through __torch_function__)
         if isinstance(x, DeferredSpectral) and x.pending() and x._stage == 'spec' \
-                and fb.dim() == 2 and fb.shape[0] == x.shape[-2] and fb.device == x.device \
+                and fb.dim() == 2 and fb.shape[0] == x._src.n_bins and fb.device == x._src.wave.device \
                 and fb.dtype == torch.float32 and not (fb.requires_grad and torch.is_grad_enabled()):
             return x.with_filterbank(fb)
         return F.apply_filterbank(x, fb)
