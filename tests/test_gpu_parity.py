@@ -225,6 +225,31 @@ def test_non_power_of_two_and_large_n_fft(tac, golden):
         tac.set_strict(True)
 
 
+def test_tiny_inputs_every_kernel_family(tac):
+    """One frame, a handful of frames, fewer frames than waves, a single row: the persistent kernels' frame counters,
+    clamped duplicate frames and sample-by-sample edge paths at their smallest sizes (every FFT size class; complex,
+    |X|^2 dB and fused mel)."""
+    for n in (64, 256, 400, 512, 1024, 2048, 4096):
+        hop = n // 4
+        for length, center in ((n, False), (n + hop, False), (n, True), (3 * n + 5, True)):
+            for rows in ((1, 1), (3, 1)):
+                x = signals.audio_like(rows + (length,), seed=n + length)
+                got = host(tac.stft(dev(x), n, hop_length=hop, center=center))
+                ref = numpy_ref.stft(x, n, hop, center=center)
+                assert got.shape[:-1] == ref.shape, (n, length, center, rows)
+                assert rel_err(got[..., 0] + 1j * got[..., 1], ref) < 5e-6, (n, length, center, rows)
+                spec = host(torch.nn.Sequential(*tac.Spectrogram(n, hop, center=center, power=2.), tac.AmplitudeToDb()).cuda()(dev(x)))
+                want = 10.0 * np.log10(np.maximum((np.abs(ref) ** 2) ** 2, 1e-7))
+                big = np.abs(ref) ** 2 > 1e-6 * (np.abs(ref) ** 2).max()
+                assert np.abs(spec - want)[big].max() < DB_ABS, (n, length, center, rows)
+                if n >= 256:
+                    mel = tac.Melspectrogram(num_mels=40, sample_rate=16000, fft_length=n, hop_length=hop, center=center).cuda()
+                    gm = host(tac.realize(mel(dev(x))))
+                    wm = torch_ref.melspectrogram(torch.from_numpy(x), num_mels=40, sample_rate=16000, n_fft=n, hop=hop,
+                                                  center=center).numpy()
+                    assert gm.shape == wm.shape and rel_err(gm, wm) < 2e-5, (n, length, center, rows)
+
+
 def test_short_input_raises_runtime_error(tac):
     # reference: strict-xfail RuntimeError for (1,100) with n_fft=512 reflect (tests/test_functional.py:31)
     with pytest.raises(RuntimeError):
