@@ -423,6 +423,31 @@ def test_filterbank_buffer_replaced_in_place_is_repacked(tac):
     assert np.abs(y3[:, :, :16]).max() == 0.0 and rel_err(y3[:, :, 16:], y2[:, :, 16:]) < 1e-6
 
 
+def test_route_cache_survives_object_id_reuse(tac):
+    """The fused-kernel route is remembered per filterbank OBJECT: a new tensor that happens to get the ``id`` of a
+    collected one (CPython reuses addresses) must be routed on its own contents.  Forced here by planting an entry under
+    the new tensor's id that claims the band-sparse form for a dense bank."""
+    import weakref
+    x = dev(signals.audio_like((2, 1, 9000), seed=44))
+    window = torch.hann_window(512, device='cuda')
+    dense = dev(signals.uniform((257, 24), seed=45))
+    other = torch.zeros(1)
+    g = tac._hip.geometry(x, 512, 128, 512, True, 'reflect', False, True)
+    g.routes[(id(dense), dense._version, 2.0, tac._hip.MEL_PATH)] = (weakref.ref(other), 'sparse')
+    y = tac._hip.melspectrogram(x, window, dense, 512, 128, 512, True, 'reflect', False, True, 2.0, False, 1.0, 1e-10)
+    p = np.abs(numpy_ref.stft(host(x), 512, 128)) ** 2
+    assert rel_err(host(y), np.einsum('...ft,fm->...mt', p, host(dense).astype(np.float64))) < 1e-5
+    for _ in range(20):                              # and the natural form of it: banks created and dropped in a loop
+        sparse_mod = tac.Melspectrogram(num_mels=32, sample_rate=16000, fft_length=512, hop_length=128).cuda()
+        a = host(sparse_mod(x))
+        del sparse_mod
+        fb = dev(signals.uniform((257, 32), seed=46))
+        b = host(tac.realize(tac.apply_filterbank(tac.complex_norm(tac.stft(x, 512, 128, window=window), 2.0), fb)))
+        assert rel_err(b, np.einsum('...ft,fm->...mt', p, host(fb).astype(np.float64))) < 1e-5
+        del fb
+    assert np.isfinite(a).all()
+
+
 def test_amplitude_db_known_answers(tac, golden):
     amp = torch.tensor([0.000001, 0.0001, 0.1, 1.0, 10.0, 1000000.0]).sqrt().cuda()
     db = torch.tensor([-60.0, -40.0, -10.0, 0.0, 10.0, 60.0])

@@ -9,6 +9,7 @@ import ctypes
 import math
 import os
 import threading
+import weakref
 
 import torch
 
@@ -290,12 +291,17 @@ def melspectrogram(wave, window, fb, n_fft, hop, win_length, center, pad_mode, n
     if fb.dim() != 2 or fb.shape[0] != g.n_bins:
         raise RuntimeError('apply_filterbank: size mismatch, spectrogram has %d bins, filterbank %s'
                            % (g.n_bins, tuple(fb.shape)))
-    rkey = (id(fb), fb._version, power)
-    route = g.routes.get(rkey, 0)
-    if route == 0:
+    # the route is cached per (filterbank object, version, power); ``id`` alone could be reused by a NEW tensor once
+    # the old one is collected, so the entry carries a weak reference that must still point at this very object
+    rkey = (id(fb), fb._version, power, MEL_PATH)
+    hit = g.routes.get(rkey)
+    if hit is not None and hit[0]() is fb:
+        route = hit[1]
+    else:
         if len(g.routes) > 16:
             g.routes.clear()
-        route = g.routes[rkey] = _fused_mel_route(g, fb, power)
+        route = _fused_mel_route(g, fb, power)
+        g.routes[rkey] = (weakref.ref(fb), route)
     if route is None:
         spec = spectrogram(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided, power,
                            False, 1.0, 1e-7)
