@@ -34,14 +34,7 @@ __host__ __device__ __forceinline__ cf mkc(float x, float y) {
     return r;
 }
 
-#ifndef TAC_FFT_HALF
-#define TAC_FFT_HALF 1      // 0: A/B knob, the last pass stores every output and the R2C split reads both halves back
-#endif
-#ifndef TAC_PACKED
-#define TAC_PACKED 1        // 0: A/B knob, the same algebra on scalar f32 ops
-#endif
-
-#if TAC_PACKED
+// Complex arithmetic on register pairs with the packed-f32 VALU ops (v_pk_*_f32 and their op_sel / neg modifiers).
 __device__ __forceinline__ cf cadd(cf a, cf b) { return a + b; }
 __device__ __forceinline__ cf csub(cf a, cf b) { return a - b; }
 // a + (-i)·b and a - (-i)·b
@@ -136,24 +129,6 @@ __device__ __forceinline__ void r2c_power_pair_x2(cf zk1, cf zm1, cf w1, cf zk2,
 __device__ __forceinline__ cf cmulc(cf a, float C, float S) { return mkc(a.x, a.x) * mkc(C, S) + mkc(a.y, a.y) * mkc(-S, C); }
 __device__ __forceinline__ cf cscale(cf a, float s) { return a * mkc(s, s); }
 __device__ __forceinline__ cf cmul_elem(cf a, cf b) { return a * b; }        // lane-wise product (window)
-#else
-__device__ __forceinline__ cf cadd(cf a, cf b) { return mkc(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ cf csub(cf a, cf b) { return mkc(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ cf cadd_rot(cf a, cf b) { return mkc(a.x + b.y, a.y - b.x); }
-__device__ __forceinline__ cf csub_rot(cf a, cf b) { return mkc(a.x - b.y, a.y + b.x); }
-__device__ __forceinline__ cf cadd_conj(cf a, cf b) { return mkc(a.x + b.x, a.y - b.y); }
-__device__ __forceinline__ cf csub_conj(cf a, cf b) { return mkc(a.x - b.x, a.y + b.y); }
-__device__ __forceinline__ cf csub_then_conj(cf a, cf b) { return mkc(a.x - b.x, b.y - a.y); }
-__device__ __forceinline__ cf cmul(cf a, cf b) { return mkc(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ cf cmul_rot(cf w, cf d) { return cmul(w, mkc(d.y, -d.x)); }
-__device__ __forceinline__ cf power_pair(cf a, cf b) {
-    const float pr = a.x + b.x, pi = a.y + b.y, mr = a.x - b.x, mi = a.y - b.y;
-    return mkc(pr * pr + pi * pi, mr * mr + mi * mi);
-}
-__device__ __forceinline__ cf cmulc(cf a, float C, float S) { return cmul(a, mkc(C, S)); }
-__device__ __forceinline__ cf cscale(cf a, float s) { return mkc(a.x * s, a.y * s); }
-__device__ __forceinline__ cf cmul_elem(cf a, cf b) { return mkc(a.x * b.x, a.y * b.y); }
-#endif
 // a * (-i)
 __device__ __forceinline__ cf mul_neg_i(cf a) { return mkc(a.y, -a.x); }
 __device__ __forceinline__ float cnorm2(cf a) { return a.x * a.x + a.y * a.y; }
@@ -452,14 +427,9 @@ struct WaveFft {
                 const cf* twb = tw + OFF + (pass_shares_twiddles(NC, E, P) ? 0 : b) * (R - 1);
 #pragma unroll
                 for (int q = 1; q < R; ++q) v[b * R + q] = last_pass_const<P>(v[b * R + q], b * q * (32 / E));
-                if constexpr (TAC_PACKED) {                      // products in interleaved pairs (cmul_x2)
 #pragma unroll
-                    for (int q = 1; q + 1 < R; q += 2) cmul_x2(v[b * R + q], twb[q - 1], v[b * R + q + 1], twb[q]);
-                    if constexpr (((R - 1) & 1) != 0) v[b * R + R - 1] = cmul(v[b * R + R - 1], twb[R - 2]);
-                } else {
-#pragma unroll
-                    for (int q = 1; q < R; ++q) v[b * R + q] = cmul(v[b * R + q], twb[q - 1]);
-                }
+                for (int q = 1; q + 1 < R; q += 2) cmul_x2(v[b * R + q], twb[q - 1], v[b * R + q + 1], twb[q]);   // interleaved pairs
+                if constexpr (((R - 1) & 1) != 0) v[b * R + R - 1] = cmul(v[b * R + R - 1], twb[R - 2]);
             }
         }
     }
@@ -473,7 +443,7 @@ struct WaveFft {
     // (3) outputs of pass P into the exchange area (HALF: the last pass keeps its lower-half outputs in registers)
     template <int P, bool HALF>
     __device__ static __forceinline__ void pass_write(const cf (&v)[E_], cf* lds, int t, int t0) {
-        constexpr int KLO = (HALF && TAC_FFT_HALF && pass_is_last(NC_, P)) ? radix_at(NC_, P) / 2 : 0;     // first output stored
+        constexpr int KLO = (HALF && pass_is_last(NC_, P)) ? radix_at(NC_, P) / 2 : 0;     // first output stored
         constexpr int R = radix_at(NC, P), S = stride_at(NC, P), NB = E / R;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
@@ -698,74 +668,24 @@ __device__ __forceinline__ void load_frame(cf* v, const FrameGeom& g, const cf* 
     }
 }
 
-// ---- split-phase variant for software prefetch: issue the raw (unwindowed) loads of an interior frame
-// early, apply the window when the frame is consumed.  Returns false (nothing loaded) for frames that
-// touch the padding or lie past the end — those go through load_frame() at consumption time.
+// ---- split-phase frame load: issue the raw (unwindowed) loads of an interior frame early, apply the window when the
+// frame is consumed.  Returns false (nothing loaded) for frames that touch the padding or lie past the end — those go
+// through load_frame() at consumption time.  `frame` is per lane group when several frames share a wave (G > 1): the
+// request is made for all of the wave's frames or for none (wave ballot), so the caller's fast / gather decision
+// stays wave-uniform.  (Fetching with 16-byte requests + v_permlane32_swap measured neutral and was dropped:
+// tools/ablation/.)
 template <class F>
-__device__ __forceinline__ bool prefetch_frame_raw(cf* raw, const FrameGeom& g, long long row, long long frame,
-                                                   int t) {
-    constexpr int R0 = radix_at(F::NC, 0);
-    constexpr int NB = F::E / R0;
-    const long long start = frame * (long long)g.hop - g.center_pad;
-    const bool ok = g.vec2_ok && frame < g.n_frames && start >= 0 && start + F::N <= g.length;
-    if (ok) {
-        const cf* src = reinterpret_cast<const cf*>(g.wave + row * g.row_stride + start);
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-            for (int q = 0; q < R0; ++q) raw[b * R0 + q] = src[t + b * F::LPF + q * (F::NC / R0)];
-    }
-    return ok;
-}
-
-// ---- 16-byte variant for one-frame-per-wave geometries (LPF == 64): 8 dwordx4 requests per frame instead of 16
-// dwordx2 (the address path, not bandwidth, is what a frame's loads queue on).  Lane t's request i covers complex
-// elements 2t + 128i and 2t + 128i + 1, i.e. columns (2t mod 64, +1) at q = 2i + (t >= 32): one v_permlane32_swap per
-// register (frame_raw_unswizzle, at consumption time) leaves lane t < 32 with column 2t and lane t >= 32 with column
-// 2(t-32)+1, each for all q — the lane -> column map frame_col_of_lane(), which callers use for the window, the
-// edge-frame path and pass 0's output placement.
-__device__ __forceinline__ int frame_col_of_lane(int t, bool vec4) { return vec4 ? (((t & 31) << 1) | (t >> 5)) : t; }
-
-// `frame` is per lane group when several frames share a wave (G > 1): the request is made for all of the wave's
-// frames or for none (wave ballot), so the caller's fast / gather decision stays wave-uniform.
-template <class F>
-__device__ __forceinline__ bool prefetch_frame_raw_x(cf* raw, const FrameGeom& g, long long row, long long frame,
-                                                     int t, int col, bool vec4) {
+__device__ __forceinline__ bool prefetch_frame_raw_x(cf* raw, const FrameGeom& g, long long row, long long frame, int t) {
     static_assert(radix_at(F::NC, 0) == F::E, "one first-pass butterfly per lane");
     const long long start = frame * (long long)g.hop - g.center_pad;
     bool ok = g.vec2_ok && frame < g.n_frames && start >= 0 && start + F::N <= g.length;
     if constexpr (F::G > 1) ok = __builtin_amdgcn_ballot_w64(ok) == ~0ull;
     if (ok) {
-        const float* base = g.wave + row * g.row_stride + start;
-        if (vec4 && F::LPF == 64) {
-            typedef float f4 __attribute__((ext_vector_type(4)));
-            const f4* src = reinterpret_cast<const f4*>(base);
+        const cf* src = reinterpret_cast<const cf*>(g.wave + row * g.row_stride + start);
 #pragma unroll
-            for (int i = 0; i < F::E / 2; ++i) {
-                const f4 x = src[t + i * 64];
-                raw[2 * i] = mkc(x.x, x.y);
-                raw[2 * i + 1] = mkc(x.z, x.w);
-            }
-        } else {
-            const cf* src = reinterpret_cast<const cf*>(base);
-#pragma unroll
-            for (int q = 0; q < F::E; ++q) raw[q] = src[col + q * F::LPF];
-        }
+        for (int q = 0; q < F::E; ++q) raw[q] = src[t + q * F::LPF];
     }
     return ok;
-}
-
-template <class F>
-__device__ __forceinline__ void frame_raw_unswizzle(cf* raw, bool vec4) {
-    if (vec4) {
-#pragma unroll
-        for (int i = 0; i < F::E / 2; ++i) {
-            const auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(raw[2 * i].x), __float_as_uint(raw[2 * i + 1].x), false, false);
-            const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(raw[2 * i].y), __float_as_uint(raw[2 * i + 1].y), false, false);
-            raw[2 * i] = mkc(__uint_as_float(sx[0]), __uint_as_float(sy[0]));
-            raw[2 * i + 1] = mkc(__uint_as_float(sx[1]), __uint_as_float(sy[1]));
-        }
-    }
 }
 
 template <class F>

@@ -6,11 +6,6 @@
 #include "../../include/tac_amd.h"
 #include "fft_core.hpp"
 
-#ifndef TAC_V4_LOADS
-#define TAC_V4_LOADS 0      // 1: fetch frames with 16-byte requests + v_permlane32_swap (A/B knob: measured neutral for the
-                            // STFT kernels and slower for the fused mel kernel, whose register budget it breaks)
-#endif
-
 namespace tac {
 
 // epilogue selection of the STFT-family kernels (stft_kernels.hip, stft_n4096.hip)

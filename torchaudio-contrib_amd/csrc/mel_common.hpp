@@ -3,13 +3,6 @@
 #pragma once
 #include "host_common.hpp"
 
-#ifndef TAC_MEL_PRIO
-#define TAC_MEL_PRIO 1     // hand the SIMD priority to the younger wave for a tile's second frame (steady-state timing: -1.5 %)
-#endif
-#ifndef TAC_MEL_ABL
-#define TAC_MEL_ABL 0    // ablation builds only: 1 = skip phase A math, 2 = skip phase B, 3 = skip phase C stores
-#endif
-
 namespace tac {
 
 constexpr int MEL_STEP_BUDGET = 384;         // K-steps per workgroup held in registers during MFMA phase B
@@ -43,9 +36,8 @@ struct MelFftConsts {
     cf tw[F::NTW];
     cf ptw[FACT ? 1 : F::NPAIR];
     cf win[HOISTW ? F::E : 1];            // window pairs of this lane's elements (kernels with spare registers)
-    // tcol: the lane's first-pass column (== t unless frames are fetched with 16-byte requests, fft_core.hpp)
-    __device__ __forceinline__ void load(const Tables& tb, const FrameGeom& g, int t, int tcol) {
-        if constexpr (HOISTW) load_window_regs<F>(win, g, tcol);
+    __device__ __forceinline__ void load(const Tables& tb, const FrameGeom& g, int t) {
+        if constexpr (HOISTW) load_window_regs<F>(win, g, t);
         F::load_twiddles(tw, tb.w_nc, t);
         if constexpr (FACT) {
             ptw[0] = tb.w_n[t];
@@ -57,21 +49,17 @@ struct MelFftConsts {
 };
 
 // Phase A of one tile: every wave FFTs its frames and overwrites each frame buffer with the power row.
-// NFA = frames advanced together per wave (1, or 2 when the wave owns two frames of the tile and the kernel has
-// the registers for it: the second in-flight frame hides the LDS round trips of the first).
-// pre_raw / pre_ok: optional software prefetch of the wave's FIRST frame of this tile (raw samples requested
-// during the previous tile's contraction / store phases; G == 1 geometries only).
+// (Advancing two of a wave's frames together fits the registers since the packed-math core but measures 3-6 % slower.)
 // PIPE (G == 1 kernels): every frame's raw samples are requested one frame ahead — right after the previous frame's
 // butterflies, before its R2C/power epilogue — so the HBM/L2 round trip never opens a frame.  raw/pre_ok carry the
 // request across calls; (next_row, next_f0) name the tile whose first frame of this wave follows this tile's last
 // (next_f0 < 0: none).  The frame loop is fully unrolled so the compiler can count the stores between a request
 // and its use (gfx950's single in-order vmcnt: an uncounted wait would also wait for those stores' acknowledgements).
-template <class C, bool POW2, int NFA = 1, bool HOISTW = false, class ST = NoStamp, bool PIPE = false, class K = void>
+template <class C, bool POW2, bool HOISTW = false, class ST = NoStamp, bool PIPE = false, class K = void>
 __device__ __forceinline__ void mel_phase_a(const FrameGeom& g, cf* bufs, const K& k,
                                             int w, int sub, int t, int row, long long f0,
                                             cf* pre_raw = nullptr, bool* pre_ok_p = nullptr, ST* stp = nullptr,
-                                            int next_row = 0, long long next_f0 = -1, int tcol = -1, bool vec4 = false) {
-    if (tcol < 0) tcol = t;
+                                            int next_row = 0, long long next_f0 = -1) {
     ST st_local;
     ST& st = stp ? *stp : st_local;
     bool pre_ok = pre_ok_p ? *pre_ok_p : false;
@@ -79,41 +67,36 @@ __device__ __forceinline__ void mel_phase_a(const FrameGeom& g, cf* bufs, const 
     constexpr int NC = F::NC, E = F::E, NBINS = NC + 1, TILE = C::TILE_FRAMES;
     constexpr bool FACT = K::FACT;
     static_assert(K::HOIST_WINDOW == HOISTW, "window hoisting of the constants and the caller disagree");
-    constexpr int NF = (C::GPW % NFA == 0) ? NFA : 1;
+    constexpr int NF = 1;                                 // frames in flight per wave (WaveFft::run's batch)
     const cf* tw = k.tw;
     const cf* ptw = k.ptw;
     const bool wave_has_frames = (w * C::GPW * F::G) < TILE;
     if (wave_has_frames) {
 #pragma unroll PIPE ? C::GPW : 1
         for (int rep = 0; rep < C::GPW; rep += NF) {
-#if TAC_MEL_PRIO
             // the older wave of a SIMD wins VALU arbitration, so after the first frame the younger one is behind:
-            // it gets the priority for the tile's second frame and both reach the barrier together
+            // it gets the priority for the tile's second frame and both reach the barrier together (-1.5 %)
             if (PIPE && C::WAVES == 8 && rep + NF >= C::GPW) { if (w >= 4) __builtin_amdgcn_s_setprio(2); }
-#endif
             cf* lds[NF];
             int fi[NF];
             cf v[NF][E];
             int tl = t;
             asm volatile("" : "+v"(tl));      // launder: window loads stay inside the loop (register budget)
             cf winl[HOISTW ? 1 : F::E];
-            if constexpr (!HOISTW) load_window_regs<F>(winl, g, PIPE ? tcol : tl);
+            if constexpr (!HOISTW) load_window_regs<F>(winl, g, PIPE ? t : tl);
             const cf* win = HOISTW ? k.win : winl;
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
                 fi[f] = ((w * C::GPW + rep + f) * F::G) + sub;              // frame index within the tile
                 lds[f] = bufs + fi[f] * F::PADDED;
-                if (f == 0 && (PIPE || rep == 0) && pre_ok) {
-                    if constexpr (PIPE) frame_raw_unswizzle<F>(pre_raw, vec4);
+                if (PIPE && pre_ok) {
                     apply_window<F>(v[f], pre_raw, win);
                 } else {
-                    load_frame<F, true>(v[f], g, win, lds[f], row, (fi[f] < TILE) ? f0 + fi[f] : g.n_frames, PIPE ? tcol : t);
+                    load_frame<F, true>(v[f], g, win, lds[f], row, (fi[f] < TILE) ? f0 + fi[f] : g.n_frames, t);
                 }
             }
             st.mark(8);
-#if TAC_MEL_ABL != 1
-            F::template run<NF, ST, true>(v, lds, tw, t, st, PIPE ? tcol : t);   // lower-half spectrum stays in registers
-#endif
+            F::template run<NF, ST, true>(v, lds, tw, t, st, t);   // lower-half spectrum stays in registers
             st.mark(9);
             if constexpr (PIPE) {
                 static_assert(NF == 1, "pipelined phase A advances one frame group per wave-round");
@@ -124,7 +107,7 @@ __device__ __forceinline__ void mel_phase_a(const FrameGeom& g, cf* bufs, const 
                 const long long nframe = (same_tile ? f0 : next_f0) + nfi;
                 pre_ok = false;
                 if ((same_tile || next_f0 >= 0) && nfi < TILE)
-                    pre_ok = prefetch_frame_raw_x<F>(pre_raw, g, nrow, nframe, t, tcol, vec4);
+                    pre_ok = prefetch_frame_raw_x<F>(pre_raw, g, nrow, nframe, t);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -163,9 +146,7 @@ __device__ __forceinline__ void mel_phase_a(const FrameGeom& g, cf* bufs, const 
             st.mark(10);
         }
     }
-#if TAC_MEL_PRIO
     if (PIPE && C::WAVES == 8) __builtin_amdgcn_s_setprio(0);
-#endif
     if (pre_ok_p) *pre_ok_p = pre_ok;
 }
 

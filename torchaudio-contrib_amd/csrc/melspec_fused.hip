@@ -18,15 +18,10 @@
 //            then the MFMA chain runs.  Shares write partial tiles to LDS slots in a fixed order
 //   phase C  fixed-order sum of a tile's partials (deterministic), optional dB epilogue, coalesced
 //            row stores of out[row][frame][0..M)
-// Two geometries are compiled: TILE = 16 with one 8-wave workgroup per CU (155 KB LDS, the default), and an
-// experimental TILE = 8 with 4-wave workgroups at 78 KB so that TWO workgroups share a CU and one group's
-// MFMA / reduction / store phases could run under the other's FFT VALU work.  Measured at cfg-2 the second
-// form is slower (0.52 ms vs 0.37 ms: per-tile costs — weight burst, barriers, reduction — double while half
-// of every MFMA's 16 rows is wasted), so it is kept only as the TAC_MEL_TILE2048 A/B knob.
+// TILE = 16 frames with one 8-wave workgroup per CU (155 KB LDS at N = 2048).  (TILE = 8 with 4-wave workgroups at 78 KB,
+// so that TWO workgroups share a CU and one group's MFMA / reduction / store phases run under the other's FFT VALU
+// work, measured slower at cfg-2 — 0.52 ms vs 0.37 ms: per-tile costs double while half of every MFMA's 16 rows is wasted.)
 #include "mel_common.hpp"
-#ifndef TAC_MEL_TILE2048
-#define TAC_MEL_TILE2048 16  // frames per tile at N = 2048 (A/B knob: 8 or 16; measured 0.52 ms vs 0.37 ms at cfg-2)
-#endif
 
 namespace tac {
 
@@ -151,7 +146,7 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
     const int slot0 = __builtin_amdgcn_readfirstlane(tab->wave_slot0[w]);
 
     MelFftConsts<F> fftk;
-    fftk.load(tb, g, t, t);
+    fftk.load(tb, g, t);
 
     const int tiles_per_row = (int)((g.n_frames + TILE - 1) / TILE);
     const int total_tiles = (int)g.rows * tiles_per_row;
@@ -176,7 +171,6 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
     // this wave's filter weights for phase B (its share never changes): loaded ONCE, register-resident for the
     // kernel's lifetime — steady-state phase B touches no global memory (measured 0.38 -> 0.32 ms at cfg-2)
     float breg[CAP];
-#if TAC_MEL_ABL != 2
 #pragma unroll
     for (int i = 0; i < CAP; ++i) {
         const int st = tab->step[w][i];
@@ -187,7 +181,6 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
             breg[i] = ok ? fbl[ok ? u : 0] : 0.0f;
         }
     }
-#endif
 #if TAC_MEL_TIMING
     float tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = clock64();
@@ -205,7 +198,6 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
 
         // ---------------- phase B: block-sparse P·fb on the matrix cores.  Steps past the share's end carry
         // zero weights (and read P[.][0]), so the chain needs no validity branch — only the flush points branch.
-#if TAC_MEL_ABL != 2
         {
             f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
             int slot = slot0;
@@ -230,7 +222,6 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
                 }
             }
         }
-#endif
         TAC_STAMP(3);
         __syncthreads();
         TAC_STAMP(4);
@@ -253,11 +244,7 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
                     float v = sum[r];
                     if (m.db) v = amp_to_db(v, m.amin, m.log10_ref);
                     const long long frame = f0 + fg * 4 + r;
-#if TAC_MEL_ABL == 3
-                    if (frame < g.n_frames && v == 12345.678f) m.out[(row * g.n_frames + frame) * m.n_mels + band] = v;
-#else
                     if (frame < g.n_frames) m.out[(row * g.n_frames + frame) * m.n_mels + band] = v;
-#endif
                 }
                 band += c_dband;
                 fg += c_dfg;
@@ -333,7 +320,7 @@ static int dispatch_mel(int n_fft, const FrameGeom& g, const Tables& tb, const M
         case 256: return launch_mel<128, 16, 16>(g, tb, m, plan, s, query_only);
         case 512: return launch_mel<256, 16, 16>(g, tb, m, plan, s, query_only);
         case 1024: return launch_mel<512, 16, 16>(g, tb, m, plan, s, query_only);
-        case 2048: return launch_mel<1024, 16, TAC_MEL_TILE2048>(g, tb, m, plan, s, query_only);
+        case 2048: return launch_mel<1024, 16, 16>(g, tb, m, plan, s, query_only);
         default: return TAC_E_UNSUPPORTED;
     }
 }

@@ -20,35 +20,8 @@
 #include <atomic>
 #include <vector>
 
-#ifndef TAC_SP_PREFETCH
-#define TAC_SP_PREFETCH 0   // prefetch the next tile's first frame per wave during phases B/C (A/B knob; measured neutral)
-#endif
-#ifndef TAC_SP_PIPE
-#define TAC_SP_PIPE 1       // one-frame-per-wave geometries: request every frame's samples one frame ahead (mel_common.hpp)
-#endif
-#ifndef TAC_SP_FACT
-#define TAC_SP_FACT 1       // R2C twiddles as one lane register x compile-time W_32^i: frees 14 registers for the prefetch at the
-                            // cost of 7 constant multiplies per frame (0: hoist all eight — 0.9 % faster but spills 28 B per lane)
-#endif
-#ifndef TAC_SP_PB_PIPE
-#define TAC_SP_PB_PIPE 1    // software-pipelined contraction loop (0: A/B knob, plain loop)
-#endif
 #ifndef TAC_SP_TIMING
 #define TAC_SP_TIMING 0   // 1: debug builds of tools/mel_phase_timing.py — phase cycle sums overwrite the head of out[]
-#endif
-#ifndef TAC_SP_HOISTW
-#define TAC_SP_HOISTW 1    // keep the window in registers for the kernel's lifetime (A/B knob)
-#endif
-#ifndef TAC_SP_NF
-#define TAC_SP_NF 1      // frames advanced together per wave in phase A (A/B knob; 2 fits since the packed-math core but measures 3-6 % slower)
-#endif
-
-#ifndef TAC_SP_STREAM
-#define TAC_SP_STREAM 1     // fft_length 2048: producer / consumer streaming kernel (melspec_stream.hpp); 0 = the three-phase kernel
-#endif
-
-#ifndef TAC_ST_FAST2
-#define TAC_ST_FAST2 1      // the (4, 16)-step specialisation of the streaming kernel; 0 = A/B knob
 #endif
 
 #include "sparse_phase.hpp"
@@ -67,12 +40,6 @@ int launch_small_mel_entry(int n_fft, const FrameGeom& g, const Tables& tb, floa
                            hipStream_t stream);
 int pack_small(int n_fft, const std::vector<float>& h, int n_freqs, int n_mels, float* wpack, int wpack_cap, int32_t* desc,
                int desc_cap, int32_t* info_host, hipStream_t stream);
-#ifndef TAC_FB_LANES
-#define TAC_FB_LANES 1      // standalone apply_filterbank: the wave-autonomous lane-layout kernel where the bank allows it (0: A/B knob)
-#endif
-#ifndef TAC_SP_LANES
-#define TAC_SP_LANES 1      // fft_length 512 / 1024: the lane-layout fused form of stft_small.hip where the bank allows it (0: A/B knob)
-#endif
 
 constexpr int SP_TILE = 16;
 constexpr int SP_MAX_W = 3072;               // floats of packed weights that may live in LDS (12 KB)
@@ -112,11 +79,7 @@ __device__ __forceinline__ void sparse_phase_c(const float* otile, int ostr, int
                 v.w = amp_to_db(v.w, m.amin, m.log10_ref);
             }
             const long long frame = f0 + fo;
-#if TAC_MEL_ABL == 3
-            if (frame < g.n_frames && v.x == 12345.678f)
-#else
             if (frame < g.n_frames)
-#endif
                 *reinterpret_cast<f4*>(m.out + (row * g.n_frames + frame) * m.n_mels + 4 * b4) = v;
             b4 += c4_db;
             fo += c4_df;
@@ -129,11 +92,7 @@ __device__ __forceinline__ void sparse_phase_c(const float* otile, int ostr, int
             float v = otile[fo * ostr + band];
             if (m.db) v = amp_to_db(v, m.amin, m.log10_ref);
             const long long frame = f0 + fo;
-#if TAC_MEL_ABL == 3
-            if (frame < g.n_frames && v == 12345.678f) m.out[(row * g.n_frames + frame) * m.n_mels + band] = v;
-#else
             if (frame < g.n_frames) m.out[(row * g.n_frames + frame) * m.n_mels + band] = v;
-#endif
             band += c_dband;
             fo += c_df;
             if (band >= m.n_mels) { band -= m.n_mels; ++fo; }
@@ -141,7 +100,7 @@ __device__ __forceinline__ void sparse_phase_c(const float* otile, int ostr, int
     }
 }
 
-template <int NC, int E, bool POW2, bool V4>
+template <int NC, int E, bool POW2>
 __global__ void __launch_bounds__((MelCfg<NC, E, SP_TILE>::WAVES * 64), (MelCfg<NC, E, SP_TILE>::WAVES / 4))
 melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
     using C = MelCfg<NC, E, SP_TILE>;
@@ -165,11 +124,10 @@ melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
     for (int i = tid; i < m.wtot; i += WAVES * 64) wlds[i] = m.wpack[i];
     for (int i = tid; i < WAVES * 4 * m.dstride; i += WAVES * 64) dlds[i] = m.desc[i];
 
-    constexpr bool PIPE = (TAC_SP_PIPE != 0);
-    constexpr bool v4 = PIPE && V4 && (F::G == 1);                       // frames fetched with 16-byte requests (fft_core.hpp)
-    const int tcol = frame_col_of_lane(t, v4);
-    MelFftConsts<F, TAC_SP_HOISTW != 0, (TAC_SP_FACT != 0) && (TAC_SP_PIPE != 0)> fftk;
-    fftk.load(tb, g, t, tcol);
+    // register-resident for the kernel's lifetime: the window, the pass twiddles, and the R2C twiddles as ONE lane
+    // register x compile-time W_32^i (hoisting all eight is 0.9 % faster but spills 28 B per lane)
+    MelFftConsts<F, true, true> fftk;
+    fftk.load(tb, g, t);
     __syncthreads();
 
     const int tiles_per_row = (int)((g.n_frames + TILE - 1) / TILE);
@@ -189,20 +147,15 @@ melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
     const int c4_f0 = q4 ? tid / q4 : 0, c4_b0 = q4 ? tid % q4 : 0;
     const int c4_df = q4 ? (WAVES * 64) / q4 : 0, c4_db = q4 ? (WAVES * 64) % q4 : 0;
 
-    // software prefetch of this wave's first frame of the NEXT tile (raw samples, 32 registers that are idle during
-    // the contraction and store phases): its HBM/L2 round trip is hidden instead of opening every phase A
-    constexpr bool PREFETCH = !PIPE && (F::G == 1) && (TAC_SP_PREFETCH != 0);
-    cf raw[(PREFETCH || PIPE) ? F::E : 1];
+    // every frame's raw samples are requested one frame ahead (mel_common.hpp); the first request opens the pipeline
+    cf raw[F::E];
     bool pre_ok = false;
-    if constexpr (PREFETCH || PIPE) {
-        if (begin < end) {
-            const int r0 = begin / tiles_per_row;
-            const long long fr0 = (long long)(begin - r0 * tiles_per_row) * TILE + (long long)w * C::GPW * F::G + sub;
-            if constexpr (PIPE) pre_ok = prefetch_frame_raw_x<F>(raw, g, r0, fr0, t, tcol, v4);
-            else pre_ok = prefetch_frame_raw<F>(raw, g, r0, fr0, t);
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the tile loop is entered with nothing in flight
+    if (begin < end) {
+        const int r0 = begin / tiles_per_row;
+        const long long fr0 = (long long)(begin - r0 * tiles_per_row) * TILE + (long long)w * C::GPW * F::G + sub;
+        pre_ok = prefetch_frame_raw_x<F>(raw, g, r0, fr0, t);
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the tile loop is entered with nothing in flight
 
 #if TAC_SP_TIMING
     CycleStamp st;
@@ -216,28 +169,17 @@ melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
         st.mark(0);
 
         // ---------------- phase A: FFT, then overwrite each frame buffer with its |X|^p row (mel_common.hpp)
-        if constexpr (PIPE) {
+        {
             const int nt = tile + 1;
             const int nr = nt / tiles_per_row;
             const long long nf0 = nt < end ? (long long)(nt - nr * tiles_per_row) * TILE : -1;
-            mel_phase_a<C, POW2, 1, TAC_SP_HOISTW != 0, decltype(st), true>(g, bufs, fftk, w, sub, t, row, f0, raw, &pre_ok,
-                                                                             &st, nr, nf0, tcol, v4);
-        } else {
-            mel_phase_a<C, POW2, TAC_SP_NF, TAC_SP_HOISTW != 0>(g, bufs, fftk, w, sub, t, row, f0, raw, &pre_ok, &st);
-        }
-        if constexpr (PREFETCH) {
-            const int nt = tile + 1;
-            const int nr = nt / tiles_per_row;
-            pre_ok = (nt < end) &&
-                     prefetch_frame_raw<F>(raw, g, nr, (long long)(nt - nr * tiles_per_row) * TILE + w * C::GPW, t);
+            mel_phase_a<C, POW2, true, decltype(st), true>(g, bufs, fftk, w, sub, t, row, f0, raw, &pre_ok, &st, nr, nf0);
         }
         __syncthreads();
         st.mark(1);                                        // barrier A (waiting for the slowest wave's FFTs)
 
         // ---------------- phase B: one private dot product per (frame, band)
-#if TAC_MEL_ABL != 2
         sparse_phase_b(dg, prow, wlds, otile + fr * ostr);
-#endif
         st.mark(7);                                        // phase B
         __syncthreads();
         st.mark(11);                                       // barrier B
@@ -386,7 +328,7 @@ static int sparse_groups_for(int n_fft) {
         case 256: return sparse_groups<128, 16>();
         case 512: return sparse_groups<256, 16>();
         case 1024: return sparse_groups<512, 16>();
-        case 2048: return TAC_SP_STREAM ? 64 : sparse_groups<1024, 16>();     // 64: one band per lane and slot (melspec_stream.hpp)
+        case 2048: return 64;                                                // one band per lane and slot (melspec_stream.hpp)
         case 400: return LM_MARK + 8;                                        // eight lanes per frame (stft_n400.hip, mel_lanes.hpp)
         default: return 0;
     }
@@ -408,10 +350,7 @@ static int launch_sparse(const FrameGeom& g, const Tables& tb, const SparseArgs&
     long long blocks = tiles < max_blocks ? tiles : max_blocks;
     if (blocks < 1) blocks = 1;
     const bool pow2 = (power == 2.0f);
-    constexpr bool CAN_V4 = (C::F::G == 1) && (TAC_SP_PIPE != 0) && (TAC_V4_LOADS != 0);
-    const bool v4 = CAN_V4 && g.vec4_ok;
-    auto kern = v4 ? (pow2 ? melspec_sparse_kernel<NC, E, true, CAN_V4> : melspec_sparse_kernel<NC, E, false, CAN_V4>)
-                   : (pow2 ? melspec_sparse_kernel<NC, E, true, false> : melspec_sparse_kernel<NC, E, false, false>);
+    auto kern = pow2 ? melspec_sparse_kernel<NC, E, true> : melspec_sparse_kernel<NC, E, false>;
     TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::WAVES * 64), lds_bytes, stream, g, tb, m);
     TAC_HIP(hipGetLastError());
@@ -444,7 +383,7 @@ static int launch_stream(FrameGeom g, const Tables& tb, const SparseArgs& sm, co
     const bool fullm = FMT == FMT_F32 && (sm.n_mels % 64) == 0;
     // two slots of exactly (4, 16) steps — what tac_melbank_pack produces for 128-band mel banks — take the kernel whose
     // contraction is unrolled for that shape (its first reads ride along with the other frame's FFT stage)
-    const bool fast2 = TAC_ST_FAST2 && fullm && info_host[1] == 2 && info_host[4] == ST_FAST_STEPS0 &&
+    const bool fast2 = fullm && info_host[1] == 2 && info_host[4] == ST_FAST_STEPS0 &&
                        (info_host[5] == ST_FAST_STEPS1 || info_host[5] == ST_FAST_STEPS1_SHORT);
     const bool fshort = info_host[5] == ST_FAST_STEPS1_SHORT;
     void (*kern)(FrameGeom, Tables, StreamArgs);
@@ -598,15 +537,12 @@ static int pack_lanes(const std::vector<float>& h, int n_freqs, int n_mels, floa
     const long long wtot = 256LL * total_steps;
     if (wtot > wpack_cap || stream_lds_bytes<1024, 16>((int)wtot) > 160 * 1024) return TAC_E_UNSUPPORTED;
     std::vector<float> wp((size_t)wtot, 0.0f);
-#ifndef TAC_ST_BANK_GROUP
-#define TAC_ST_BANK_GROUP 8   // lanes whose 16-byte row reads should fall into different bank groups (0: no bank-aware placement)
-#endif
     // Bank-aware placement: a slot runs more steps than most of its bands need, so a band's run may start up to that
     // many quads earlier (zero weights in front).  Within every group of lanes that the LDS serves together, the starts
     // are moved so that the 16-byte reads hit different bank groups (equal starts are one broadcast address).
     std::vector<int> start(lo);
-    if (TAC_ST_BANK_GROUP > 0) {
-        constexpr int GB = TAC_ST_BANK_GROUP > 0 ? TAC_ST_BANK_GROUP : 1;
+    {
+        constexpr int GB = 8;         // lanes whose 16-byte row reads should fall into different bank groups
         for (int s = 0; s < nslot; ++s)
             for (int l0 = 0; l0 < 64; l0 += GB) {
                 bool used[8] = {false, false, false, false, false, false, false, false};
@@ -668,15 +604,15 @@ int tac_melbank_pack(const float* fb, int32_t n_freqs, int32_t n_mels, int32_t n
     std::vector<float> h((size_t)n_freqs * n_mels);
     TAC_HIP(hipMemcpyAsync(h.data(), fb, h.size() * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
     TAC_HIP(hipStreamSynchronize((hipStream_t)stream));
-    if (TAC_SP_STREAM && n_fft == 2048)
+    if (n_fft == 2048)
         return pack_lanes(h, n_freqs, n_mels, wpack, wpack_cap, desc, desc_cap, info_host, (hipStream_t)stream);
-    if (TAC_FB_LANES && n_fft == 0 && n_freqs >= 8 && (n_freqs + 3) / 4 <= FBL_CHUNKS * 64) {   // standalone: one frame per wave
+    if (n_fft == 0 && n_freqs >= 8 && (n_freqs + 3) / 4 <= FBL_CHUNKS * 64) {   // standalone: one frame per wave
         const int rc = pack_lane_mel(h, n_freqs, n_mels, 64, fbl_pitch(n_freqs), 2, FBL_FLY, LM_MAX_STEPS_WAVE, fbl_base_lds(n_freqs),
                                      wpack, wpack_cap, desc, desc_cap, info_host, (hipStream_t)stream);
         if (rc != TAC_E_UNSUPPORTED) return rc;                             // else: the tile kernel's layout
     }
     if (n_fft == 400) return pack_n400(h, n_freqs, n_mels, wpack, wpack_cap, desc, desc_cap, info_host, (hipStream_t)stream);
-    if (TAC_SP_LANES && (n_fft == 512 || n_fft == 1024)) {
+    if (n_fft == 512 || n_fft == 1024) {
         const int rc = pack_small(n_fft, h, n_freqs, n_mels, wpack, wpack_cap, desc, desc_cap, info_host, (hipStream_t)stream);
         if (rc != TAC_E_UNSUPPORTED) return rc;                             // else: the three-phase kernel's layout
     }
@@ -771,7 +707,7 @@ int tac_melspec_sparse_f32(const float* wave, const float* window, const tac_stf
         case 256: return launch_sparse<128, 16>(g, tb, m, power, s);
         case 512: return launch_sparse<256, 16>(g, tb, m, power, s);
         case 1024: return launch_sparse<512, 16>(g, tb, m, power, s);
-        case 2048: return TAC_SP_STREAM ? launch_stream<1024, 16, FMT_F32>(g, tb, m, info_host, power, s, wave, nullptr) : launch_sparse<1024, 16>(g, tb, m, power, s);
+        case 2048: return launch_stream<1024, 16, FMT_F32>(g, tb, m, info_host, power, s, wave, nullptr);
         default: return TAC_E_UNSUPPORTED;
     }
 }
@@ -784,7 +720,7 @@ int tac_melspec_sparse_coded_f32(const void* samples, int32_t sample_format, con
     if (!samples || !wpack || !desc || !info_host || !out || !d || n_mels <= 0) return TAC_E_INVALID;
     if (sample_format < TAC_SAMPLES_F32 || sample_format > TAC_SAMPLES_MULAW_I64) return TAC_E_INVALID;
     if (sample_format >= TAC_SAMPLES_MULAW_U8 && !decode_lut) return TAC_E_INVALID;
-    if (!TAC_SP_STREAM || !d->onesided || d->n_fft != 2048) return TAC_E_UNSUPPORTED;     // the streaming kernel only
+    if (!d->onesided || d->n_fft != 2048) return TAC_E_UNSUPPORTED;     // the streaming kernel only
     if (power != 2.0f && power != 1.0f) return TAC_E_UNSUPPORTED;
     if (info_host[2] != sparse_groups_for(d->n_fft)) return TAC_E_INVALID;
     FrameGeom g;

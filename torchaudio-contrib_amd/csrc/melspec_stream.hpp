@@ -35,22 +35,12 @@ constexpr int ST_TW_STRIDE = 36;              // floats between the 16 pass-1 tw
 constexpr int ST_TW_BYTES = 16 * ST_TW_STRIDE * 4;
 constexpr int ST_FAST_STEPS0 = 4, ST_FAST_STEPS1 = 16;   // slot lengths of the two-slot layout the FAST2 kernel is unrolled for
 constexpr int ST_FAST_STEPS1_SHORT = 14;                 // ... and its second instantiation (no band of slot 1 beyond 56 bins: the standard 128-band bank)
-#ifndef TAC_ST_RIDE1
-#define TAC_ST_RIDE1 6       // steps of slot 1 whose reads ride along with slot 0 (paired rotation: 4 / 6 / 8 / 10 -> 0.1375 / 0.1361 / 0.1358 / 0.1376 ms)
-#endif
-#ifndef TAC_ST_FULLPTW
-#define TAC_ST_FULLPTW 1     // A/B: 1 = all eight R2C twiddles in registers instead of one register x compile-time constants
-#endif
-#ifndef TAC_ST_EARLYREQ
-#define TAC_ST_EARLYREQ 0    // FAST2: 1 = a thread's next samples are requested right behind its s3 (three stages ahead), 0 = behind its s4 (one); measured 0.1376 vs 0.1354 ms: the registers it takes from the ride-along reads cost more
-#endif
-#ifndef TAC_ST_WINFOLD
-#define TAC_ST_WINFOLD 1     // the window multiplies folded into pass 0's first butterflies (-8 packed instructions per frame; 0: A/B knob)
-#endif
-#ifndef TAC_ST_BATCH
-#define TAC_ST_BATCH 4       // steps per round trip of the rest of slot 1 (14-step layout: 4 + 4; a batch that no longer fits the registers spills: 8 + 6 -> 0.156 ms)
-#endif
-constexpr int ST_RIDE = ST_FAST_STEPS0 + TAC_ST_RIDE1;     // steps issued at the end of s3
+// FAST2 tuning, measured at cfg-2 (DESIGN.md §3.3 has the sweeps):
+constexpr int ST_RIDE1 = 6;      // steps of slot 1 whose reads ride along with slot 0 (4 / 6 / 8 / 10 -> 0.1375 / 0.1361 / 0.1358 / 0.1376 ms)
+constexpr int ST_BATCH = 4;      // steps per round trip of the rest of slot 1 (14-step layout: 4 + 4; 8 + 6 no longer fits the registers: 0.156 ms)
+constexpr int ST_RIDE = ST_FAST_STEPS0 + ST_RIDE1;     // steps issued at the end of s3
+// A thread's next samples are requested behind its s4 (one stage ahead); requesting them behind its s3 (three ahead)
+// takes registers from the ride-along reads and measured 0.1376 vs 0.1354 ms.
 
 struct StreamArgs {
     const float* wl;       // device: weights [sum of steps][64 lanes][4 consecutive bins]
@@ -145,7 +135,7 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         F::load_twiddles(tw, tb.w_nc, t);
     }
     const cf w0 = tb.w_n[t];                                           // R2C: W_N^{t + 64 i} = W_N^t * W_32^i
-    constexpr bool FULLPTW = FAST2 && TAC_ST_FULLPTW != 0;              // (the general kernel has no registers for them)
+    constexpr bool FULLPTW = FAST2 != 0;       // all eight R2C twiddles in registers (the general kernel has no room: one x constants)
     cf ptw[FULLPTW ? F::NPAIR : 1];
     if constexpr (FULLPTW) {
 #pragma unroll
@@ -261,7 +251,6 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     auto s0 = [&](cf (&v)[E], int mode, int row, long long fr) {
         if (mode == 1) {
             decode(v);
-            if constexpr (!TAC_ST_WINFOLD) apply_window<F>(v, v, win);
         } else {                                                       // edge / unaligned frame: gathered through the exchange
             int tz;                                                    // (an opaque copy of the lane number: this rare path's
             asm volatile("v_mov_b32 %0, %1" : "=v"(tz) : "v"(t));      // address registers must not be hoisted out of the loop)
@@ -271,9 +260,9 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         }
     };
     typedef float f4 __attribute__((ext_vector_type(4)));
-    // (fast-path frames arrive unwindowed under TAC_ST_WINFOLD: the window is folded into pass 0's first butterflies)
+    // (fast-path frames arrive unwindowed: the window is folded into pass 0's first butterflies, -8 packed instructions)
     auto s0b = [&](cf (&v)[E], int mode) {
-        if (TAC_ST_WINFOLD && mode == 1) Dft<16>::run_windowed(v, win);
+        if (mode == 1) Dft<16>::run_windowed(v, win);
         else F::template pass_butterflies<0>(v);
         wave_lds_fence();
         F::template pass_write<0, true>(v, xa, t, t);
@@ -324,11 +313,8 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         for (int p = 0; p < F::NPAIR; p += 2) {
             const int kk = t + p * F::LPF, kk2 = kk + F::LPF;
             cf pw, pw2;
-            if constexpr (FULLPTW && TAC_PACKED) {
+            if constexpr (FULLPTW) {
                 r2c_power_pair_x2(v[F::reg_of_spectrum(p)], zm[p], ptw[p], v[F::reg_of_spectrum(p + 1)], zm[p + 1], ptw[p + 1], pw, pw2);
-            } else if constexpr (FULLPTW) {
-                pw = F::r2c_power_x2(v[F::reg_of_spectrum(p)], zm[p], ptw[p]);
-                pw2 = F::r2c_power_x2(v[F::reg_of_spectrum(p + 1)], zm[p + 1], ptw[p + 1]);
             } else {
                 pw = F::r2c_power_factored_x2(v[F::reg_of_spectrum(p)], zm[p], w0, p);
                 pw2 = F::r2c_power_factored_x2(v[F::reg_of_spectrum(p + 1)], zm[p + 1], w0, p + 1);
@@ -358,7 +344,7 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             cp[u] = p0[u];
         }
 #pragma unroll
-        for (int u = 0; u < TAC_ST_RIDE1; ++u) {
+        for (int u = 0; u < ST_RIDE1; ++u) {
             if (with_weights) cw[ST_FAST_STEPS0 + u] = wp[(ST_FAST_STEPS0 + u) * 64];
             cp[ST_FAST_STEPS0 + u] = p1[u];
         }
@@ -378,15 +364,15 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     // steps are consumed, so its round trip overlaps their FMAs.
     auto s4_fast = [&](const float* prow, int i, const f4 (&cw)[ST_RIDE], const f4 (&cp)[ST_RIDE], auto&& after_ride) {
         i = i < nloc ? i : nloc - 1;
-        constexpr int REST = (FAST2 ? FAST2 : ST_FAST_STEPS1) - TAC_ST_RIDE1;
-        constexpr int NB = (REST + TAC_ST_BATCH - 1) / TAC_ST_BATCH;
+        constexpr int REST = (FAST2 ? FAST2 : ST_FAST_STEPS1) - ST_RIDE1;
+        constexpr int NB = (REST + ST_BATCH - 1) / ST_BATCH;
         const f4* wp = reinterpret_cast<const f4*>(wlds) + lane + ST_RIDE * 64;
-        const f4* p1 = reinterpret_cast<const f4*>(prow + lo_s[1]) + TAC_ST_RIDE1;
+        const f4* p1 = reinterpret_cast<const f4*>(prow + lo_s[1]) + ST_RIDE1;
         cf a0 = mkc(0.f, 0.f), a1 = mkc(0.f, 0.f), b0 = mkc(0.f, 0.f), b1 = mkc(0.f, 0.f);
-        f4 w2[TAC_ST_BATCH], q2[TAC_ST_BATCH];
+        f4 w2[ST_BATCH], q2[ST_BATCH];
         auto issue_batch = [&](int c0) {
 #pragma unroll
-            for (int u = 0; u < TAC_ST_BATCH; ++u) {
+            for (int u = 0; u < ST_BATCH; ++u) {
                 if (c0 + u < REST) {
                     w2[u] = wp[(c0 + u) * 64];
                     q2[u] = p1[c0 + u];
@@ -398,7 +384,7 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
 #pragma unroll
         for (int u = 0; u < ST_FAST_STEPS0; ++u) fma4(cw[u], cp[u], a0, a1);
 #pragma unroll
-        for (int u = 0; u < TAC_ST_RIDE1; ++u) fma4(cw[ST_FAST_STEPS0 + u], cp[ST_FAST_STEPS0 + u], b0, b1);
+        for (int u = 0; u < ST_RIDE1; ++u) fma4(cw[ST_FAST_STEPS0 + u], cp[ST_FAST_STEPS0 + u], b0, b1);
         // the FMAs above must really be done (their operands' registers free) before after_ride's reads are issued:
         // sched_barrier orders machine instructions only, LLVM's IR passes would sink the FMAs below the reads
         asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1) : : "memory");
@@ -406,12 +392,12 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         after_ride();
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int c = 0; c < NB; ++c) {                                  // the remaining steps of slot 1, TAC_ST_BATCH per round trip
+        for (int c = 0; c < NB; ++c) {                                  // the remaining steps of slot 1, ST_BATCH per round trip
 #pragma unroll
-            for (int u = 0; u < TAC_ST_BATCH; ++u)
-                if (c * TAC_ST_BATCH + u < REST) fma4(w2[u], q2[u], b0, b1);
+            for (int u = 0; u < ST_BATCH; ++u)
+                if (c * ST_BATCH + u < REST) fma4(w2[u], q2[u], b0, b1);
             __builtin_amdgcn_sched_barrier(0);
-            if (c + 1 < NB) issue_batch((c + 1) * TAC_ST_BATCH);
+            if (c + 1 < NB) issue_batch((c + 1) * ST_BATCH);
             __builtin_amdgcn_sched_barrier(0);
         }
         float v0 = (a0.x + a0.y) + (a1.x + a1.y), v1 = (b0.x + b0.y) + (b1.x + b1.y);
@@ -479,7 +465,6 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         long long frA, frB;
         int iA = 2 * w, iB = 2 * w + 1, nA = 0, nB = 0;
         unsigned askA = 0, askB = 0;
-        constexpr bool EARLY = FAST2 && TAC_ST_EARLYREQ != 0;
         cf tw1[16];
         f4 cw[ST_RIDE], cpA[ST_RIDE], cpB[ST_RIDE];
         request(vB, iB, modeB, rowB_, frB);
@@ -497,41 +482,35 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             ST_MARK(1);
             s12(vB, zmB, zmidB, tw1);
             tw1_issue(tw1);
-            if constexpr (EARLY) askB = grab_ask();
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(2);
             s12(vA, zmA, zmidA, tw1);
-            if constexpr (EARLY) askA = grab_ask();
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(2);
             s3(vB, zmB, zmidB, rowB);
             if constexpr (FAST2) {
                 s3_issue(rowB, cw, cpB, true);
-                if constexpr (!EARLY) askB = grab_ask();
+                askB = grab_ask();
             } else {
                 nB = grab();
+                request(vB, nB, modeB, rowB_, frB);
             }
-            if constexpr (EARLY) nB = (int)__builtin_amdgcn_readfirstlane(askB);
-            if constexpr (EARLY || !FAST2) request(vB, nB, modeB, rowB_, frB);
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(4);
             s3(vA, zmA, zmidA, rowA);
-            if constexpr (!FAST2) nA = grab();
-            if constexpr (EARLY) nA = (int)__builtin_amdgcn_readfirstlane(askA);
-            if constexpr (EARLY || !FAST2) request(vA, nA, modeA, rowA_, frA);
+            if constexpr (!FAST2) {
+                nA = grab();
+                request(vA, nA, modeA, rowA_, frA);
+            }
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(4);
             if constexpr (FAST2) {
                 s4_fast(rowB, iB, cw, cpB, [&]() {
                     s3_issue(rowA, cw, cpA, false);
-                    if constexpr (!EARLY) askA = grab_ask();
+                    askA = grab_ask();
                 });
-                if constexpr (EARLY) {
-                    iB = nB;
-                } else {
-                    iB = (int)__builtin_amdgcn_readfirstlane(askB);
-                    request(vB, iB, modeB, rowB_, frB);                 // the contraction used the frame's registers until here
-                }
+                iB = (int)__builtin_amdgcn_readfirstlane(askB);
+                request(vB, iB, modeB, rowB_, frB);                     // the contraction used the frame's registers until here
             } else {
                 s4(rowB, iB);
                 iB = nB;
@@ -540,12 +519,8 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             ST_MARK(5);
             if constexpr (FAST2) {
                 s4_fast(rowA, iA, cw, cpA, []() {});
-                if constexpr (EARLY) {
-                    iA = nA;
-                } else {
-                    iA = (int)__builtin_amdgcn_readfirstlane(askA);
-                    request(vA, iA, modeA, rowA_, frA);
-                }
+                iA = (int)__builtin_amdgcn_readfirstlane(askA);
+                request(vA, iA, modeA, rowA_, frA);
             } else {
                 s4(rowA, iA);
                 iA = nA;

@@ -2,10 +2,6 @@
 #pragma once
 #include "mel_common.hpp"
 
-#ifndef TAC_SP_PB_PIPE
-#define TAC_SP_PB_PIPE 1    // software-pipelined contraction loop (0: A/B knob, plain loop)
-#endif
-
 namespace tac {
 
 // phase B: one private dot product per (frame, band) — this thread's lane group owns the band list at dg, its lane
@@ -22,7 +18,6 @@ __device__ __forceinline__ void sparse_phase_b(const int* dg, const float* prow,
         // 8 taps per trip: 2 weight vectors (LDS broadcast) + 4 eight-byte row reads (bands start on even bins,
         // tac_melbank_pack) feed 4 packed FMAs.  The loop is LDS-latency-bound at 2 waves/SIMD, so it is software
         // pipelined: trip j+1's six reads are issued before trip j's FMAs (the last trip re-reads itself).
-#if TAC_SP_PB_PIPE
         float4 wa = w4[0], wb = w4[1];
         const cf* q = reinterpret_cast<const cf*>(p);
         cf p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3];
@@ -37,17 +32,6 @@ __device__ __forceinline__ void sparse_phase_b(const int* dg, const float* prow,
             acc1 = __builtin_elementwise_fma(mkc(wb.z, wb.w), p3, acc1);
             wa = nwa; wb = nwb; p0 = n0; p1 = n1; p2 = n2; p3 = n3;
         }
-#else
-        for (int j = 0; j < d.z; ++j) {               // A/B knob: no look-ahead
-            const float4 wa = w4[2 * j], wb = w4[2 * j + 1];
-            const cf* q = reinterpret_cast<const cf*>(p + 8 * j);
-            const cf p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3];
-            acc0 = __builtin_elementwise_fma(mkc(wa.x, wa.y), p0, acc0);
-            acc1 = __builtin_elementwise_fma(mkc(wa.z, wa.w), p1, acc1);
-            acc0 = __builtin_elementwise_fma(mkc(wb.x, wb.y), p2, acc0);
-            acc1 = __builtin_elementwise_fma(mkc(wb.z, wb.w), p3, acc1);
-        }
-#endif
         orow[d.x] = (acc0.x + acc0.y) + (acc1.x + acc1.y);
     }
 }

@@ -9,9 +9,6 @@
 #include "host_common.hpp"
 
 
-#ifndef TAC_STFT_OCC
-#define TAC_STFT_OCC 2      // waves per SIMD the generic kernel is compiled for (A/B knob; 3 drops the hoisted twiddles)
-#endif
 #ifndef TAC_STFT_TIMING
 #define TAC_STFT_TIMING 0   // 1: debug builds of tools/stft_phase_timing.py — per-phase cycle sums overwrite the head of out[]
 #endif
@@ -45,7 +42,7 @@ __device__ __noinline__ void finish_power_row(const float* prow, float* obase, i
 // NF frames per wave can be advanced together (see WaveFft::run); with the inter-pass and R2C twiddles held
 // in registers the kernel sits at 2 waves/SIMD.  NF = 1 is what ships (see launch_stft).
 template <int NC, int E, int MODE, int NF, bool HOIST, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64, TAC_STFT_OCC)
+__global__ void __launch_bounds__(WAVES * 64, 2)
 stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
     using F = WaveFft<NC, E>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -272,11 +269,9 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 // Here the NEXT frame's samples are requested before the current frame's stores, every store is unconditional
 // (clamped duplicate lanes instead of predication) so the compiler can wait with an exact vmcnt(#stores) while
 // the stores drain behind the next frame's butterflies, and the window comes from LDS (lgkmcnt, not vmcnt).
-// LEAN: the lane-dependent twiddles live in LDS (one conflict-free 144-byte row per lane, read where they are used)
-// and the R2C twiddles are one register x compile-time constants, which fits the kernel into 168 registers = three
-// waves per SIMD (three 4-wave workgroups per CU) instead of two.
-template <int NC, int E, int MODE, bool V4, bool LEAN, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64, LEAN ? 3 : 2)
+// (A three-waves-per-SIMD form with the twiddles in LDS measured equal, 0.163 vs 0.158 ms, and was dropped: tools/ablation/.)
+template <int NC, int E, int MODE, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, 2)
 stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
     using F = WaveFft<NC, E>;
     static_assert(F::G == 1 && radix_at(NC, 0) == E, "one frame per wave, single first-pass butterfly per lane");
@@ -290,27 +285,12 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
     cf* const wlds = reinterpret_cast<cf*>(smem + WAVES * WAVE_SLOTS);
     constexpr int WROW = E + 2;
     for (int m = threadIdx.x; m < NC; m += WAVES * 64) wlds[(m & 63) * WROW + (m >> 6)] = window_pair(g, m);
-    constexpr bool v4 = V4;                               // frames fetched with 16-byte requests (fft_core.hpp)
-    const int col = frame_col_of_lane(t, v4);
 
-    static_assert(!LEAN || F::NTW == E + 2, "lean twiddle rows share the window rows' conflict-free 144-byte pitch");
-    cf twr[LEAN ? 1 : F::NTW];
-    cf ptw[LEAN ? 1 : F::NPAIR];
-    cf* const twl = wlds + 64 * WROW + t * WROW;          // LEAN: this lane's twiddle row
-    if constexpr (LEAN) {
-        if (threadIdx.x < 64) {
-            cf tmp[F::NTW];
-            F::load_twiddles(tmp, tb.w_nc, t);
+    cf tw[F::NTW];
+    cf ptw[F::NPAIR];
+    F::load_twiddles(tw, tb.w_nc, t);
 #pragma unroll
-            for (int i = 0; i < F::NTW; ++i) twl[i] = tmp[i];
-        }
-        ptw[0] = tb.w_n[t];
-    } else {
-        F::load_twiddles(twr, tb.w_nc, t);
-#pragma unroll
-        for (int i = 0; i < F::NPAIR; ++i) ptw[i] = tb.w_n[t + i * F::LPF];
-    }
-    const cf* const tw = LEAN ? twl : twr;
+    for (int i = 0; i < F::NPAIR; ++i) ptw[i] = tb.w_n[t + i * F::LPF];
 
     const int T = (int)g.n_frames;
     const int total = (int)g.rows * T;
@@ -323,7 +303,7 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 
     // Frames are taken from a workgroup counter, not dealt out in fixed strides: where two waves share a SIMD the older
     // one wins the issue arbitration and would finish its share long before the other (melspec_stream.hpp).
-    unsigned* const next_unit = reinterpret_cast<unsigned*>(wlds + (LEAN ? 128 : 64) * WROW);
+    unsigned* const next_unit = reinterpret_cast<unsigned*>(wlds + 64 * WROW);
     if (threadIdx.x == 0) *next_unit = (unsigned)(begin + WAVES);
     auto grab = [&]() -> int {
         unsigned v = 0;
@@ -333,7 +313,7 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
     cf raw[E];
     bool pre = false;
     int unit = begin + w;
-    if (unit < end) pre = prefetch_frame_raw_x<F>(raw, g, unit / T, unit % T, t, col, v4);
+    if (unit < end) pre = prefetch_frame_raw_x<F>(raw, g, unit / T, unit % T, t);
     __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): the loop is entered with nothing in flight
     __syncthreads();
 
@@ -351,28 +331,27 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
         cf* const ldsv[1] = {lds};
         if (pre) {
             typedef float f4 __attribute__((ext_vector_type(4)));
-            const f4* wp = reinterpret_cast<const f4*>(wlds + col * WROW);
+            const f4* wp = reinterpret_cast<const f4*>(wlds + t * WROW);
             f4 wv[E / 2];
 #pragma unroll
             for (int i = 0; i < E / 2; ++i) wv[i] = wp[i];
-            frame_raw_unswizzle<F>(raw, v4);
 #pragma unroll
             for (int i = 0; i < E / 2; ++i) {
                 v[0][2 * i] = cmul_elem(raw[2 * i], mkc(wv[i].x, wv[i].y));
                 v[0][2 * i + 1] = cmul_elem(raw[2 * i + 1], mkc(wv[i].z, wv[i].w));
             }
         } else {
-            load_frame<F, false>(v[0], g, nullptr, lds, urow, uframe, col);   // frames touching the padding
+            load_frame<F, false>(v[0], g, nullptr, lds, urow, uframe, t);   // frames touching the padding
         }
         st.mark(8);
-        F::template run<1, StftStamp, true>(v, ldsv, tw, t, st, col);       // lower-half spectrum stays in registers
+        F::template run<1, StftStamp, true>(v, ldsv, tw, t, st, t);         // lower-half spectrum stays in registers
         st.mark(9);
 
         // request the next frame now: it lands while this frame is split, staged and stored
         __builtin_amdgcn_sched_barrier(0);
         {
             pre = false;
-            if (nxt < end) pre = prefetch_frame_raw_x<F>(raw, g, nxt / T, nxt % T, t, col, v4);
+            if (nxt < end) pre = prefetch_frame_raw_x<F>(raw, g, nxt / T, nxt % T, t);
         }
         __builtin_amdgcn_sched_barrier(0);
         st.mark(1);                                         // next frame's loads issued
@@ -388,11 +367,10 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
                 const cf zk = v[0][F::reg_of_spectrum(i)];            // Z[k] never left this lane
                 const cf zm = (i == 0) ? F::r2c_partner(lds, k, zk) : lds[lds_pad(NC - k)];
                 if constexpr (MODE != 0) {                            // xa[i] = (|X[k]|^2, |X[NC-k]|^2), no spectra formed
-                    const cf pw = LEAN ? F::r2c_power_factored_x2(zk, zm, ptw[0], i) : F::r2c_power_x2(zk, zm, ptw[i]);
+                    const cf pw = F::r2c_power_x2(zk, zm, ptw[i]);
                     xa[i] = cscale(pw, hscale * hscale);
                 } else {
-                    if constexpr (LEAN) F::r2c_split_factored_x2(zk, zm, ptw[0], i, xa[i], xb[i]);
-                    else F::r2c_split_x2(zk, zm, ptw[i], xa[i], xb[i]);
+                    F::r2c_split_x2(zk, zm, ptw[i], xa[i], xb[i]);
                     xa[i] = cscale(xa[i], hscale); xb[i] = cscale(xb[i], hscale);
                 }
             }
@@ -469,36 +447,19 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 #endif
 }
 
-#ifndef TAC_STFT_PIPE
-#define TAC_STFT_PIPE 1     // 0: A/B knob, n_fft = 2048 plain epilogues go through the generic kernel
-#endif
-#ifndef TAC_PIPE_WAVES
-#define TAC_PIPE_WAVES 8    // waves per workgroup of the pipelined kernel (4: two workgroups per CU, A/B knob)
-#endif
-#ifndef TAC_STFT_LEAN
-#define TAC_STFT_LEAN 0     // 1: three waves per SIMD with LDS-resident twiddles (A/B knob: measured equal to two, 0.163 vs 0.158 ms)
-#endif
+constexpr int PIPE_WAVES = 8;      // one 8-wave workgroup per CU: both waves of every SIMD draw frames from the same counter
 
 template <int NC, int E, int PMODE>
 static int launch_pipe(const FrameGeom& g, const Tables& tb, const StftEpilogue& ep, long long groups, hipStream_t stream) {
     using F = WaveFft<NC, E>;
-    constexpr bool LEAN = TAC_STFT_LEAN != 0;
-    // one 8-wave workgroup per CU (both waves of every SIMD draw frames from the same counter); LEAN: three of 4 waves
-    constexpr int WAVES = LEAN ? 4 : TAC_PIPE_WAVES;
-    const size_t bytes = (size_t)WAVES * (((F::PADDED + 1) / 2) * 2) * sizeof(cf) +
-                         (size_t)(LEAN ? 128 : 64) * (E + 2) * sizeof(cf) + 16;
+    constexpr int WAVES = PIPE_WAVES;
+    const size_t bytes = (size_t)WAVES * (((F::PADDED + 1) / 2) * 2) * sizeof(cf) + (size_t)64 * (E + 2) * sizeof(cf) + 16;
     long long blocks = (groups + WAVES - 1) / WAVES;
-    const long long cap = (long long)device_cu_count() * (LEAN ? 3 : 8 / WAVES);
+    const long long cap = (long long)device_cu_count() * (8 / WAVES);
     if (blocks > cap) blocks = cap;
-    if (TAC_V4_LOADS && g.vec4_ok) {
-        auto kern = stft_pipe_kernel<NC, E, PMODE, (TAC_V4_LOADS != 0), LEAN, WAVES>;
-        TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes));
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), bytes, stream, g, tb, ep);
-    } else {
-        auto kern = stft_pipe_kernel<NC, E, PMODE, false, LEAN, WAVES>;
-        TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes));
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), bytes, stream, g, tb, ep);
-    }
+    auto kern = stft_pipe_kernel<NC, E, PMODE, WAVES>;
+    TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), bytes, stream, g, tb, ep);
     TAC_HIP(hipGetLastError());
     return TAC_OK;
 }
@@ -508,14 +469,11 @@ static int launch_stft(const FrameGeom& g, const Tables& tb, const StftEpilogue&
     using F = WaveFft<NC, E>;
     // frames in flight per wave (generic kernel): two fit since the packed-math core (223 registers, no scratch) and
     // measure 3 % faster without the pipelining; one is what ships
-#ifndef TAC_STFT_NF
-#define TAC_STFT_NF 1
-#endif
-    constexpr int NF = (E <= 16) ? TAC_STFT_NF : 1;
-    constexpr bool HOIST = (E <= 16) && (TAC_STFT_OCC <= 2);
+    constexpr int NF = 1;
+    constexpr bool HOIST = (E <= 16);
     const long long groups = g.rows * ((g.n_frames + NF * F::G - 1) / (NF * F::G));     // wave-iterations
     if (groups >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
-    if constexpr (TAC_STFT_PIPE && F::G == 1 && E == 16) {
+    if constexpr (F::G == 1 && E == 16) {
         // pipelined kernel: one-sided complex rows, or |X| / |X|^2 rows with or without the dB epilogue
         int pmode = -1;
         if (ep.onesided) {
@@ -535,12 +493,12 @@ static int launch_stft(const FrameGeom& g, const Tables& tb, const StftEpilogue&
     // 256-register waves: eight waves fill a CU.  One 8-wave workgroup per CU (both waves of a SIMD draw units from the
     // same counter) where its frame buffers fit the LDS and there is that much work, 4-wave workgroups otherwise.
     constexpr size_t wave_bytes = (size_t)(((NF * F::G * F::PADDED + 1) / 2) * 2) * sizeof(cf);
-    constexpr bool WIDE_FITS = 2 * STFT_WAVES * wave_bytes + 16 <= 160 * 1024 && TAC_STFT_OCC == 2;
+    constexpr bool WIDE_FITS = 2 * STFT_WAVES * wave_bytes + 16 <= 160 * 1024;
     const bool wide = WIDE_FITS && groups >= 2LL * STFT_WAVES * device_cu_count();
     const int waves = wide ? 2 * STFT_WAVES : STFT_WAVES;
     const size_t lds_bytes = (size_t)waves * wave_bytes + 16;
     int per_cu = wide ? 1 : (int)(160 * 1024 / lds_bytes);
-    if (per_cu > TAC_STFT_OCC) per_cu = TAC_STFT_OCC;
+    if (per_cu > 2) per_cu = 2;
     if (per_cu < 1) per_cu = 1;
     long long max_blocks = (long long)device_cu_count() * per_cu;
     long long want = (groups + waves - 1) / waves;
@@ -558,13 +516,7 @@ static int launch_stft(const FrameGeom& g, const Tables& tb, const StftEpilogue&
     return launch(stft_kernel<NC, E, MODE, NF, HOIST, STFT_WAVES>);
 }
 
-#ifndef TAC_N4096_TWO_HALF
-#define TAC_N4096_TWO_HALF 1   // 0: A/B knob, fft_length = 4096 always takes the generic 32-elements-per-lane kernel
-#endif
 int try_launch_n4096(const FrameGeom& g, const StftEpilogue& ep, int mode, hipStream_t stream);
-#ifndef TAC_STFT_SMALL_PIPE
-#define TAC_STFT_SMALL_PIPE 1  // 0: A/B knob, fft_length 512 / 1024 always take the generic kernel
-#endif
 int try_launch_small(int n_fft, const FrameGeom& g, const Tables& tb, const StftEpilogue& ep, int mode, hipStream_t stream);
 int try_launch_n400(const FrameGeom& g, const StftEpilogue& ep, int mode, hipStream_t stream);   // stft_n400.hip
 
@@ -577,18 +529,14 @@ static int dispatch_stft(int n_fft, const FrameGeom& g, const Tables& tb, const 
         case 256: return launch_stft<128, 16, MODE>(g, tb, ep, s);
         case 512:
         case 1024: {
-#if TAC_STFT_SMALL_PIPE
             const int rc = try_launch_small(n_fft, g, tb, ep, MODE, s);     // stft_small.hip: plain epilogues
             if (rc != TAC_E_UNSUPPORTED) return rc;
-#endif
             return n_fft == 512 ? launch_stft<256, 16, MODE>(g, tb, ep, s) : launch_stft<512, 16, MODE>(g, tb, ep, s);
         }
         case 2048: return launch_stft<1024, 16, MODE>(g, tb, ep, s);
         case 4096: {
-#if TAC_N4096_TWO_HALF
             const int rc = try_launch_n4096(g, ep, MODE, s);          // stft_n4096.hip: plain epilogues, aligned frames
             if (rc != TAC_E_UNSUPPORTED) return rc;
-#endif
             return launch_stft<2048, 32, MODE>(g, tb, ep, s);
         }
         case 400: return try_launch_n400(g, ep, MODE, s);          // 200 = 8 x 25 mixed radix; plain one-sided epilogues

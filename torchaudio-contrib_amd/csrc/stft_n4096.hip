@@ -32,14 +32,10 @@ __device__ __forceinline__ cf mul_w64(cf v, int i) {
 
 // a · conj(w): (a.x·w.x + a.y·w.y, a.y·w.x - a.x·w.y)
 __device__ __forceinline__ cf cmul_conj(cf a, cf w) {
-#if TAC_PACKED
     cf t, r;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));                 // a.x·(w.x, -w.y)
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));   // + a.y·(w.y, w.x)
     return r;
-#else
-    return mkc(a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y);
-#endif
 }
 
 template <int MODE>
