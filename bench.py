@@ -273,17 +273,20 @@ def run(a):
         # optional whole-batch output: one RCCL all-gather of the (B/N, C, M, T) shards
         def step_gather():
             return tac.distributed.all_gather_batch(model(x), total_rows=world * BATCH)
-        for _ in range(3):
-            step_gather()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            step_gather()
-        sync()
-        tg = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
-        result['with_allgather'] = {'value': frames_per_step * a.steps / float(tg.item()), 'unit': 'frames/s',
-                                    'ms_per_step': float(tg.item()) / a.steps * 1e3}
+        try:        # a secondary figure: a failure here must not cost the headline line above
+            for _ in range(3):
+                step_gather()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                step_gather()
+            sync()
+            tg = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+            result['with_allgather'] = {'value': frames_per_step * a.steps / float(tg.item()), 'unit': 'frames/s',
+                                        'ms_per_step': float(tg.item()) / a.steps * 1e3}
+        except Exception as exc:            # noqa: BLE001 — reported in the line, not swallowed
+            result['with_allgather'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(x_host)
