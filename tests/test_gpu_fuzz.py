@@ -159,3 +159,43 @@ def test_fuzz_apply_filterbank(tac):
             tag = ('fb', case, name, n_freqs, n_mels, lead, n_frames, kind)
             assert got.shape == want.shape, tag
             assert rel_err(got, want) < 1e-5, tag
+
+
+def test_fuzz_gradients(tac):
+    """Gradients w.r.t. the waveform through the HIP backward kernels (csrc/backward.hip) against torch.autograd through
+    the CPU restatement of the reference chain, over random STFT arguments: the complex STFT (linear), the power
+    spectrogram, the mel chain and mel + dB."""
+    rng = np.random.default_rng(5000 + SEED)
+    for case in range(max(8, CASES // 2)):
+        n, hop, win_length, center, pad_mode, lead, length = draw_stft_args(
+            rng, [64, 256, 400, 512, 1024, 2048, 4096] + ([300] if case % 5 == 0 else []), max_rows=3, max_len_factor=6)
+        normalized = bool(rng.random() < 0.3)
+        kind = ['stft', 'power', 'mel', 'mel_db'][case % 4]
+        num_mels = int(rng.choice([13, 40, 80, 128]))
+        if num_mels > n // 4:
+            num_mels = max(2, n // 8)
+        x = signals.audio_like(lead + (length,), seed=9900 + case + 7919 * SEED)
+        xc = torch.from_numpy(x).requires_grad_(True)
+        xg = dev(x).requires_grad_(True)
+        kw = dict(win_length=win_length, center=center, pad_mode=pad_mode, normalized=normalized)
+        if kind == 'stft':
+            want_y = torch_ref.stft(xc, n, hop, **kw)
+            y = tac.STFT(n, hop, **kw).cuda()(xg)
+        elif kind == 'power':
+            want_y = torch_ref.complex_norm(torch_ref.stft(xc, n, hop, **kw), 2.0)
+            y = tac.Spectrogram(n, hop, power=2.0, **kw).cuda()(xg)
+        else:
+            want_y = torch_ref.melspectrogram(xc, num_mels=num_mels, sample_rate=16000, n_fft=n, hop=hop, **kw)
+            chain = tac.Melspectrogram(num_mels=num_mels, sample_rate=16000, fft_length=n, hop_length=hop, **kw)
+            if kind == 'mel_db':
+                floor = 1e-3 * float(want_y.detach().max())          # clamp well above cancellation level
+                ref = max(1.0, 2.0 * floor * floor)                  # (the layer insists on ref > amin, layers.py:369)
+                want_y = torch_ref.amplitude_to_db(want_y, ref=ref, amin=floor * floor)
+                chain = torch.nn.Sequential(*chain, tac.AmplitudeToDb(ref=ref, amin=floor * floor))
+            y = chain.cuda()(xg)
+        tag = ('grad', case, kind, n, hop, kw, num_mels, lead, length)
+        assert tuple(y.shape) == tuple(want_y.shape), tag
+        w = signals.uniform(tuple(want_y.shape), seed=9950 + case)
+        (want,) = torch.autograd.grad((want_y * torch.from_numpy(w)).sum(), xc)
+        (got,) = torch.autograd.grad((y * dev(w)).sum(), xg)
+        assert rel_err(host(got), want.numpy()) < (1e-3 if kind == 'mel_db' else 1e-4), tag
