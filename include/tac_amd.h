@@ -217,6 +217,9 @@ int tac_mulaw_decode_f32_f32(const float* codes, int64_t n, int32_t n_quantize, 
  *     tac_stft_norm_backward_f32: the same with the gradient spectrum formed on load from the spectrum itself,
  *       spec[rows][T][F][2], and the gradient of |spec|^power, grad_norm[rows][T][F] (the adjoint of
  *       functional.py:116-128 folded in: Spectrogram's backward in one pass, no gradient spectrum in memory).
+ *     tac_spectrogram_backward_f32: the same with NO spectrum in memory: the frame is re-read from the waveform
+ *       (wave / d exactly as given to (2)), transformed again in the kernel, and the spectrum values the norm's adjoint
+ *       needs are formed from the FFT's exchange area while the inverse's operands are gathered.
  *     tac_overlap_add_f32: adjoint of framing + padding: grad_wave[r][j] = sum of grad_frames over every (frame, tap)
  *       that read sample j, reflect / replicate / circular images included (a gather: deterministic, no atomics).
  *     tac_complex_norm_backward_f32: grad_z[i] = grad_out[i] * power * |z_i|^(power-2) * z_i (0 where z_i == 0),
@@ -228,6 +231,8 @@ int tac_stft_backward_f32(const float* grad_spec, const float* window, const tac
                           float* grad_frames, void* stream);
 int tac_stft_norm_backward_f32(const float* spec, const float* grad_norm, float power, const float* window,
                                const tac_stft_desc* d, float* grad_frames, void* stream);
+int tac_spectrogram_backward_f32(const float* wave, const float* window, const tac_stft_desc* d,
+                                 const float* grad_norm, float power, float* grad_frames, void* stream);
 int tac_overlap_add_f32(const float* grad_frames, const tac_stft_desc* d, float* grad_wave,
                         int64_t grad_row_stride, void* stream);
 int tac_complex_norm_backward_f32(const float* z, const float* grad_out, int64_t n, float power,

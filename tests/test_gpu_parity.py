@@ -858,7 +858,9 @@ def test_autograd_matches_the_reference_chain(tac, shape, n_fft, hop, mels):
         # the HIP gradient kernels: the inverse-FFT kernel with the norm's adjoint folded into its load, the overlap-add
         # the fused op's backward either way: inverse-FFT kernel with the norm's adjoint folded in, overlap-add
         assert ran.get('tac_overlap_add_f32') == 1, ran
-        assert ran.get('tac_stft_norm_backward_f32') == 1 and 'tac_complex_norm_backward_f32' not in ran, ran
+        # ... which transforms the frames again itself: no stft launch, no spectrum or gradient spectrum in memory
+        assert ran.get('tac_spectrogram_backward_f32') == 1 and 'tac_stft_f32' not in ran, ran
+        assert 'tac_complex_norm_backward_f32' not in ran and 'tac_stft_norm_backward_f32' not in ran, ran
         assert rel_err(host(got), want.numpy()) < 1e-3
 
 

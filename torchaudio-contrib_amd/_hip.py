@@ -580,10 +580,14 @@ def stft_backward(grad_spec, wave, window, n_fft, hop, win_length, center, pad_m
     """grad of the one-sided stft output ``(*, F, T, 2)`` w.r.t. the waveform: one inverse real FFT per frame
     (tac_stft_backward_f32) followed by the gather form of overlap-add (tac_overlap_add_f32).
     With ``grad_norm`` (the gradient of ``complex_norm(spec, power)``, shape ``(*, F, T)``) ``grad_spec`` is the
-    spectrum itself and the norm's adjoint is folded into the load (tac_stft_norm_backward_f32)."""
+    spectrum itself and the norm's adjoint is folded into the load (tac_stft_norm_backward_f32) — or ``None``: the
+    kernel then transforms the frames of ``wave`` again itself and no spectrum exists in memory
+    (tac_spectrogram_backward_f32)."""
     g = geometry(wave, n_fft, hop, win_length, center, pad_mode, normalized, True)
-    gs = grad_spec.transpose(-3, -2)                                  # physical frame-major (*, T, F, 2)
-    gs = gs if gs.is_contiguous() else gs.contiguous()
+    gs = None
+    if grad_spec is not None:
+        gs = grad_spec.transpose(-3, -2)                              # physical frame-major (*, T, F, 2)
+        gs = gs if gs.is_contiguous() else gs.contiguous()
     gn = None
     if grad_norm is not None:
         gn = grad_norm.transpose(-2, -1)                              # (*, T, F)
@@ -601,6 +605,12 @@ def stft_backward(grad_spec, wave, window, n_fft, hop, win_length, center, pad_m
                                                      _native.stream_ptr(wave.device))
             _native.check(rc, 'tac_stft_backward_f32')
             _count('tac_stft_backward_f32')
+        elif gs is None:
+            rc = _native.lib().tac_spectrogram_backward_f32(_native.ptr(_rows_of(wave, g)), _native.ptr(window), g.desc,
+                                                            _native.ptr(gn), float(power), _native.ptr(frames),
+                                                            _native.stream_ptr(wave.device))
+            _native.check(rc, 'tac_spectrogram_backward_f32')
+            _count('tac_spectrogram_backward_f32')
         else:
             rc = _native.lib().tac_stft_norm_backward_f32(_native.ptr(gs), _native.ptr(gn), float(power), _native.ptr(window),
                                                           desc, _native.ptr(frames), _native.stream_ptr(wave.device))
@@ -615,6 +625,12 @@ def stft_backward(grad_spec, wave, window, n_fft, hop, win_length, center, pad_m
 
 def stft_backward_supported(n_fft, onesided):
     return bool(onesided) and fft_kernel_size(n_fft)
+
+
+def backward_recomputes_spectrum(n_fft):
+    """Sizes whose spectrogram backward kernel transforms the frames again itself (16 elements per lane; at 4096 the
+    second transform does not fit the registers and the spectrum is recomputed into memory by the stft kernel)."""
+    return n_fft <= 2048
 
 
 def complex_norm_backward(z, grad_out, power):

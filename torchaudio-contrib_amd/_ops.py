@@ -159,11 +159,14 @@ def _spectrogram_hip_backward(saved, rest, needs, grads):
     if not _signal_path_only(needs) or not H.stft_backward_supported(n_fft, onesided) or grads[0] is None:
         return None
     window = window.contiguous()
-    z = H.stft(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided)      # recomputed, not saved
     g = grads[0]
-    if db:
-        g = H.amplitude_to_db_backward(H.complex_norm(z, power), g, amin)
-    # the norm's adjoint is folded into the inverse-FFT kernel's load: no gradient spectrum in memory
+    if db:      # the |z|^power values the dB gradient needs: one fused forward launch (nothing was saved)
+        g = H.amplitude_to_db_backward(H.spectrogram(wave, window, n_fft, hop, win_length, center, pad_mode, normalized,
+                                                     onesided, power, False, 1.0, 1e-7), g, amin)
+    # the backward kernel transforms the frames again itself and folds the norm's adjoint into the inverse FFT's load:
+    # neither the spectrum nor a gradient spectrum exists in memory (fft_length 4096: the spectrum is recomputed first)
+    z = None if H.backward_recomputes_spectrum(n_fft) else \
+        H.stft(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided)
     return [H.stft_backward(z, wave, window, n_fft, hop, win_length, center, pad_mode, normalized, grad_norm=g, power=power),
             None]
 
@@ -174,13 +177,14 @@ def _melspectrogram_hip_backward(saved, rest, needs, grads):
     if not _signal_path_only(needs) or not H.stft_backward_supported(n_fft, onesided) or grads[0] is None:
         return None
     window = window.contiguous()
-    z = H.stft(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided)
     g = grads[0]
-    if db:      # the mel values the dB gradient needs come from the fused forward kernel (one launch), not from z
+    if db:      # the mel values the dB gradient needs come from the fused forward kernel (one launch)
         mel = H.melspectrogram(wave, window, bank, n_fft, hop, win_length, center, pad_mode, normalized, onesided, power,
                                False, 1.0, 1e-7)
         g = H.amplitude_to_db_backward(mel, g, amin)
     gp = H.apply_filterbank_backward(g, bank)
+    z = None if H.backward_recomputes_spectrum(n_fft) else \
+        H.stft(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided)
     return [H.stft_backward(z, wave, window, n_fft, hop, win_length, center, pad_mode, normalized, grad_norm=gp, power=power),
             None, None]
 

@@ -21,25 +21,38 @@ constexpr int BW_WAVES = 4;
 //   conj(Z[k]) = (conj(H[k]) + H[NC-k]) - i w_k (conj(H[k]) - H[NC-k]),  w_k = e^{-2 pi i k / N}
 //   R = FFT_NC(conj Z);  y[2m] = Re R[m],  y[2m+1] = -Im R[m].
 // d/dz of |z|^power (norm then pow, functional.py:126-128): g * power * |z|^(power-2) * z, 0 at z == 0
+__device__ __noinline__ float norm_pow_factor_general(float s, float power) {      // one copy of powf per kernel
+    return power * powf(sqrtf(s), power - 2.0f);
+}
+template <bool POW2 = false>
 __device__ __forceinline__ cf norm_pow_grad(cf v, float gout, float power) {
     const float s = v.x * v.x + v.y * v.y;
     float f;
-    if (power == 2.0f) f = 2.0f;
+    if (POW2 || power == 2.0f) f = 2.0f;
     else if (s == 0.0f) f = 0.0f;
     else if (power == 1.0f) f = 1.0f / sqrtf(s);
-    else f = power * powf(sqrtf(s), power - 2.0f);
+    else f = norm_pow_factor_general(s, power);
     f *= gout;
     return mkc(f * v.x, f * v.y);
 }
 
-// NORM: `gspec` is the spectrum z itself and `gnorm` the gradient of |z|^power: the gradient spectrum
+// SRC_NORM: `gspec` is the spectrum z itself and `gnorm` the gradient of |z|^power: the gradient spectrum
 // gnorm * d|z|^power/dz is formed on load (tac_stft_norm_backward_f32: the adjoint of Spectrogram in one pass, no
-// gradient spectrum in memory)
-template <int NC, int E, bool NORM>
+// gradient spectrum in memory).
+// SRC_WAVE: there is no spectrum in memory either — the frame is fetched from the WAVEFORM (g.wave), windowed and
+// transformed by the same wave-level FFT, z[k] is formed from the exchange area by the R2C split as the inverse's operands
+// are gathered, and the inverse FFT then runs in the same buffer (tac_spectrogram_backward_f32: per frame 4·hop bytes of
+// samples + 4·F of gradient in, 4·N of frame gradient out; the recomputation costs one FFT and saves writing and reading
+// 8·F bytes of spectrum per frame plus a launch).
+enum { SRC_GRAD = 0, SRC_NORM = 1, SRC_WAVE = 2 };
+
+// POW2: power == 2 (the Melspectrogram chain, layers.py:335): the adjoint's factor is the constant 2
+template <int NC, int E, int SRC, bool POW2>
 __global__ void __launch_bounds__(BW_WAVES * 64, 2)
 stft_backward_kernel(FrameGeom g, Tables tb, const float* __restrict__ gspec, const float* __restrict__ gnorm, float power,
                      float* __restrict__ frames) {
     using F = WaveFft<NC, E>;
+    constexpr bool NORM = (SRC != SRC_GRAD);
     constexpr int N = 2 * NC, NBINS = NC + 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63;
@@ -48,6 +61,15 @@ stft_backward_kernel(FrameGeom g, Tables tb, const float* __restrict__ gspec, co
     const int t = lane % F::LPF;
     constexpr int WAVE_SLOTS = ((F::G * F::PADDED + 1) / 2) * 2;
     cf* lds = reinterpret_cast<cf*>(smem_raw) + w * WAVE_SLOTS + sub * F::PADDED;
+    // SRC_WAVE: the window pairs and the R2C / C2R twiddles w_k (k <= NC/2) live in LDS behind the exchange areas — the
+    // kernel reads each of them twice per frame, and as global (L1 / L2) loads they were most of a frame's latency
+    cf* const win_lds = reinterpret_cast<cf*>(smem_raw) + BW_WAVES * WAVE_SLOTS;
+    cf* const wk_lds = win_lds + NC;
+    if constexpr (SRC == SRC_WAVE) {
+        for (int m = threadIdx.x; m < NC; m += BW_WAVES * 64) win_lds[m] = window_pair(g, m);
+        for (int k = threadIdx.x; k <= NC / 2; k += BW_WAVES * 64) wk_lds[k] = tb.w_n[k];
+        __syncthreads();
+    }
 
     const long long groups_per_row = (g.n_frames + F::G - 1) / F::G;
     const long long total = g.rows * groups_per_row;
@@ -57,9 +79,10 @@ stft_backward_kernel(FrameGeom g, Tables tb, const float* __restrict__ gspec, co
     // inter-pass twiddles, the C2R twiddles of the lane's sixteen (k, NC - k) pairs, its sixteen window pairs
     constexpr bool HOIST = (E == 16);
     constexpr bool HOIST_WIN = HOIST && !NORM;             // (the NORM form keeps 32 more loads in flight per frame)
-    cf tw_h[HOIST ? F::NTW : 1], wk_h[HOIST ? E : 1], win_h[HOIST_WIN ? E : 1];
-    if constexpr (HOIST) {
-        F::load_twiddles(tw_h, tb.w_nc, t);
+    constexpr bool HOIST_WK = HOIST && SRC != SRC_WAVE;    // (the forward transform's window needs those registers)
+    cf tw_h[HOIST ? F::NTW : 1], wk_h[HOIST_WK ? E : 1], win_h[HOIST_WIN ? E : 1];
+    if constexpr (HOIST) F::load_twiddles(tw_h, tb.w_nc, t);
+    if constexpr (HOIST_WK) {
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -68,6 +91,8 @@ stft_backward_kernel(FrameGeom g, Tables tb, const float* __restrict__ gspec, co
                 const cf wk = tb.w_n[k <= NC / 2 ? k : NC - k];            // w_{NC-k} = -conj(w_k)
                 wk_h[b * R0 + q] = k <= NC / 2 ? wk : mkc(-wk.x, wk.y);
             }
+    }
+    if constexpr (HOIST) {
         if constexpr (HOIST_WIN) {
 #pragma unroll
             for (int j = 0; j < E; ++j) {
@@ -76,7 +101,46 @@ stft_backward_kernel(FrameGeom g, Tables tb, const float* __restrict__ gspec, co
             }
         }
     }
-    for (long long unit = (long long)blockIdx.x * BW_WAVES + w; unit < total; unit += (long long)gridDim.x * BW_WAVES) {
+    // SRC_WAVE: the next unit's samples (raw, unwindowed) and gradient row are requested while this unit's inverse
+    // transform runs — neither HBM round trip opens a frame
+    cf raw[SRC == SRC_WAVE ? E : 1];
+    float gk[SRC == SRC_WAVE ? E : 1], gm[SRC == SRC_WAVE ? E : 1];
+    bool pre = false;
+    // (Every load is issued unconditionally, from a clamped address where the unit does not exist or its frame touches the
+    // padding: a conditional request would keep the previous unit's 64 registers alive through the whole iteration.)
+    const bool can_prefetch = g.vec2_ok && g.length >= N;                   // wave-uniform
+    auto request = [&](long long u) {
+        if constexpr (SRC == SRC_WAVE) {
+            const long long uu = u < total ? u : total - 1;
+            const long long r = uu / groups_per_row;
+            const long long f = (uu - r * groups_per_row) * F::G + sub;
+            const bool lv = f < g.n_frames;
+            const float* gn = gnorm + (r * g.n_frames + (lv ? f : 0)) * NBINS;
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int q = 0; q < R0; ++q) {
+                    const int k = t + b * F::LPF + q * (NC / R0);
+                    gk[b * R0 + q] = gn[k];
+                    gm[b * R0 + q] = gn[NC - k];
+                }
+            const long long start = f * (long long)g.hop - g.center_pad;
+            bool ok = can_prefetch && lv && start >= 0 && start + N <= g.length;
+            if constexpr (F::G > 1) ok = __builtin_amdgcn_ballot_w64(ok) == ~0ull;      // all of the wave's frames or none
+            const cf* src = reinterpret_cast<const cf*>(g.wave + r * g.row_stride + (ok ? start : 0));
+            if (can_prefetch) {
+#pragma unroll
+                for (int q = 0; q < E; ++q) raw[q] = src[t + q * F::LPF];
+            } else {
+#pragma unroll
+                for (int q = 0; q < E; ++q) raw[q] = mkc(0.0f, 0.0f);
+            }
+            pre = ok;
+        }
+    };
+    const long long stride = (long long)gridDim.x * BW_WAVES;
+    request((long long)blockIdx.x * BW_WAVES + w);
+    for (long long unit = (long long)blockIdx.x * BW_WAVES + w; unit < total; unit += stride) {
         const long long row = unit / groups_per_row;
         const long long frame = (unit - row * groups_per_row) * F::G + sub;
         const bool live = frame < g.n_frames;
@@ -86,34 +150,76 @@ stft_backward_kernel(FrameGeom g, Tables tb, const float* __restrict__ gspec, co
         if constexpr (!HOIST) F::load_twiddles(tw_l, tb.w_nc, t);
         const cf* const tw = HOIST ? tw_h : tw_l;
         cf v[1][E];
+        cf* const ldsv[1] = {lds};
+        if constexpr (SRC == SRC_WAVE) {
+            // forward transform of this frame: Z (the FFT of the packed real frame) in natural order in the exchange area
+            int tl = t;
+            asm volatile("" : "+v"(tl));          // launder: the window reads stay inside the loop (register budget)
+            cf win[E];
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int q = 0; q < R0; ++q) win[b * R0 + q] = win_lds[tl + b * F::LPF + q * (NC / R0)];
+            if (pre) apply_window<F>(v[0], raw, win);
+            else load_frame<F, true>(v[0], g, win, lds, row, live ? frame : g.n_frames, t);  // edge frames; past the end: zeros
+            F::template run<1>(v, ldsv, tw, t);
+        }
+        const float xscale = 0.5f * g.scale;                                               // the R2C split returns 2·X
+        int tg = t;
+        // SRC_WAVE: the operand addresses (twiddle table, exchange area) are recomputed from an opaque copy of the lane
+        // number every iteration — as loop invariants they would occupy (and spill) 48 registers
+        if constexpr (SRC == SRC_WAVE) asm volatile("" : "+v"(tg));
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int q = 0; q < R0; ++q) {
-                const int k = t + b * F::LPF + q * (NC / R0);              // first-pass order (fft_core.hpp)
-                cf hk = G[k], hm = G[NC - k];
-                if constexpr (NORM) {
-                    hk = norm_pow_grad(hk, GN[k], power);
-                    hm = norm_pow_grad(hm, GN[NC - k], power);
+                const int k = tg + b * F::LPF + q * (NC / R0);             // first-pass order (fft_core.hpp)
+                cf wkk;
+                if constexpr (HOIST_WK) {
+                    wkk = wk_h[b * R0 + q];
+                } else {
+                    const int kt = k <= NC / 2 ? k : NC - k;                // w_{NC-k} = -conj(w_k)
+                    const cf wk = (SRC == SRC_WAVE) ? wk_lds[kt] : tb.w_n[kt];
+                    wkk = k <= NC / 2 ? wk : mkc(-wk.x, wk.y);
+                }
+                cf hk, hm;
+                if constexpr (SRC == SRC_WAVE) {
+                    F::r2c_pair(lds, k, wkk, hk, hm);                       // 2·z[k], 2·z[NC-k] of this frame
+                    hk = cscale(hk, xscale);
+                    hm = cscale(hm, xscale);
+                } else {
+                    hk = G[k];
+                    hm = G[NC - k];
+                }
+                if constexpr (SRC == SRC_WAVE) {
+                    hk = norm_pow_grad<POW2>(hk, gk[b * R0 + q], power);
+                    hm = norm_pow_grad<POW2>(hm, gm[b * R0 + q], power);
+                } else if constexpr (NORM) {
+                    hk = norm_pow_grad<POW2>(hk, GN[k], power);
+                    hm = norm_pow_grad<POW2>(hm, GN[NC - k], power);
                 }
                 if (k == 0) {
                     hk = mkc(2.0f * hk.x, 0.0f);
                     hm = mkc(2.0f * hm.x, 0.0f);
                 }
                 if (!live) hk = hm = mkc(0.0f, 0.0f);
-                cf wkk;
-                if constexpr (HOIST) {
-                    wkk = wk_h[b * R0 + q];
-                } else {
-                    const cf wk = tb.w_n[k <= NC / 2 ? k : NC - k];        // w_{NC-k} = -conj(w_k)
-                    wkk = k <= NC / 2 ? wk : mkc(-wk.x, wk.y);
-                }
                 const cf s = mkc(hk.x + hm.x, hm.y - hk.y);                 // conj(H[k]) + H[NC-k]
                 const cf d = mkc(hk.x - hm.x, -hk.y - hm.y);                // conj(H[k]) - H[NC-k]
                 const cf wd = mkc(wkk.x * d.x - wkk.y * d.y, wkk.x * d.y + wkk.y * d.x);
                 v[0][b * R0 + q] = mkc(s.x + wd.y, s.y - wd.x);             // s - i * (w d)
+                // (eight pairs' exchange-area reads in flight at a time: all sixteen at once no longer fit the registers; the
+                // empty asm pins each operand's arithmetic here — LLVM's IR passes otherwise sink it below the barrier)
+                if constexpr (SRC == SRC_WAVE) {
+                    asm volatile("" : "+v"(v[0][b * R0 + q]));
+                    if ((q & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                }
             }
-        cf* const ldsv[1] = {lds};
+        if constexpr (SRC == SRC_WAVE) {
+            wave_lds_fence();                                               // every Z read precedes the inverse's first writes
+            __builtin_amdgcn_sched_barrier(0);
+            request(unit + stride);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         F::template run<1>(v, ldsv, tw, t);                                 // R[] in natural order at lds[lds_pad(i)]
         float* out = frames + (row * g.n_frames + frame) * N;
         if (live) {
@@ -128,7 +234,7 @@ stft_backward_kernel(FrameGeom g, Tables tb, const float* __restrict__ gspec, co
 #pragma unroll 4
                 for (int m = t; m < NC; m += F::LPF) {
                     const cf r = lds[lds_pad(m)];
-                    const cf wn = window_pair(g, m);
+                    const cf wn = (SRC == SRC_WAVE) ? win_lds[m] : window_pair(g, m);
                     *reinterpret_cast<cf*>(out + 2 * m) = mkc(r.x * wn.x * wscale, -r.y * wn.y * wscale);
                 }
             }
@@ -197,15 +303,27 @@ amplitude_to_db_backward_kernel(const float* __restrict__ x, const float* __rest
 
 template <int NC, int E>
 static int launch_stft_backward(const FrameGeom& g, const Tables& tb, const float* gspec, const float* gnorm, float power,
-                                float* frames, hipStream_t stream) {
+                                float* frames, hipStream_t stream, bool from_wave) {
     using F = WaveFft<NC, E>;
-    const size_t lds_bytes = (size_t)BW_WAVES * (((F::G * F::PADDED + 1) / 2) * 2) * sizeof(cf);
+    const size_t lds_bytes = (size_t)BW_WAVES * (((F::G * F::PADDED + 1) / 2) * 2) * sizeof(cf) +
+                             (from_wave ? (size_t)(NC + NC / 2 + 2) * sizeof(cf) : 0);
     const long long groups = g.rows * ((g.n_frames + F::G - 1) / F::G);
     long long blocks = (groups + BW_WAVES - 1) / BW_WAVES;
     const long long cap = (long long)device_cu_count() * 2;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    auto kern = gnorm ? stft_backward_kernel<NC, E, true> : stft_backward_kernel<NC, E, false>;
+    const bool pow2 = (power == 2.0f);
+    void (*kern)(FrameGeom, Tables, const float*, const float*, float, float*);
+    if (from_wave) {
+        if constexpr (radix_at(NC, 0) == E)
+            kern = pow2 ? stft_backward_kernel<NC, E, SRC_WAVE, true> : stft_backward_kernel<NC, E, SRC_WAVE, false>;
+        else
+            return TAC_E_UNSUPPORTED;                  // (32 elements per lane: no registers for two transforms)
+    } else if (gnorm) {
+        kern = pow2 ? stft_backward_kernel<NC, E, SRC_NORM, true> : stft_backward_kernel<NC, E, SRC_NORM, false>;
+    } else {
+        kern = stft_backward_kernel<NC, E, SRC_GRAD, false>;
+    }
     if (lds_bytes > 64 * 1024) TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds_bytes));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BW_WAVES * 64), lds_bytes, stream, g, tb, gspec, gnorm, power, frames);
     TAC_HIP(hipGetLastError());
@@ -213,12 +331,13 @@ static int launch_stft_backward(const FrameGeom& g, const Tables& tb, const floa
 }
 
 static int stft_backward_entry(const float* spec, const float* gnorm, float power, const float* window, const tac_stft_desc* d,
-                               float* grad_frames, void* stream) {
+                               float* grad_frames, void* stream, bool from_wave = false) {
     if (!spec || !grad_frames || !d) return TAC_E_INVALID;
     if (!d->onesided) return TAC_E_UNSUPPORTED;
     FrameGeom g;
     int64_t T = 0;
-    // the geometry helper wants a waveform pointer for its alignment flags only; the spectrum stands in
+    // from_wave: `spec` IS the waveform.  Otherwise the geometry helper wants a waveform pointer for its alignment flags
+    // only and the spectrum stands in.
     int rc = make_geometry(spec, window, d, &g, &T);
     if (rc != TAC_OK) return rc;
     Tables tb;
@@ -226,14 +345,14 @@ static int stft_backward_entry(const float* spec, const float* gnorm, float powe
     if (rc != TAC_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     switch (d->n_fft) {
-        case 32: return launch_stft_backward<16, 16>(g, tb, spec, gnorm, power, grad_frames, s);
-        case 64: return launch_stft_backward<32, 16>(g, tb, spec, gnorm, power, grad_frames, s);
-        case 128: return launch_stft_backward<64, 16>(g, tb, spec, gnorm, power, grad_frames, s);
-        case 256: return launch_stft_backward<128, 16>(g, tb, spec, gnorm, power, grad_frames, s);
-        case 512: return launch_stft_backward<256, 16>(g, tb, spec, gnorm, power, grad_frames, s);
-        case 1024: return launch_stft_backward<512, 16>(g, tb, spec, gnorm, power, grad_frames, s);
-        case 2048: return launch_stft_backward<1024, 16>(g, tb, spec, gnorm, power, grad_frames, s);
-        case 4096: return launch_stft_backward<2048, 32>(g, tb, spec, gnorm, power, grad_frames, s);
+        case 32: return launch_stft_backward<16, 16>(g, tb, spec, gnorm, power, grad_frames, s, from_wave);
+        case 64: return launch_stft_backward<32, 16>(g, tb, spec, gnorm, power, grad_frames, s, from_wave);
+        case 128: return launch_stft_backward<64, 16>(g, tb, spec, gnorm, power, grad_frames, s, from_wave);
+        case 256: return launch_stft_backward<128, 16>(g, tb, spec, gnorm, power, grad_frames, s, from_wave);
+        case 512: return launch_stft_backward<256, 16>(g, tb, spec, gnorm, power, grad_frames, s, from_wave);
+        case 1024: return launch_stft_backward<512, 16>(g, tb, spec, gnorm, power, grad_frames, s, from_wave);
+        case 2048: return launch_stft_backward<1024, 16>(g, tb, spec, gnorm, power, grad_frames, s, from_wave);
+        case 4096: return launch_stft_backward<2048, 32>(g, tb, spec, gnorm, power, grad_frames, s, from_wave);
         default: return TAC_E_UNSUPPORTED;
     }
 }
@@ -257,6 +376,12 @@ int tac_stft_norm_backward_f32(const float* spec, const float* grad_norm, float 
                                const tac_stft_desc* d, float* grad_frames, void* stream) {
     if (!grad_norm) return TAC_E_INVALID;
     return tac::stft_backward_entry(spec, grad_norm, power, window, d, grad_frames, stream);
+}
+
+int tac_spectrogram_backward_f32(const float* wave, const float* window, const tac_stft_desc* d, const float* grad_norm,
+                                 float power, float* grad_frames, void* stream) {
+    if (!grad_norm) return TAC_E_INVALID;
+    return tac::stft_backward_entry(wave, grad_norm, power, window, d, grad_frames, stream, true);
 }
 
 int tac_overlap_add_f32(const float* grad_frames, const tac_stft_desc* d, float* grad_wave, int64_t grad_row_stride,
