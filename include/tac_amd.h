@@ -220,6 +220,11 @@ int tac_mulaw_decode_f32_f32(const float* codes, int64_t n, int32_t n_quantize, 
  *     tac_spectrogram_backward_f32: the same with NO spectrum in memory: the frame is re-read from the waveform
  *       (wave / d exactly as given to (2)), transformed again in the kernel, and the spectrum values the norm's adjoint
  *       needs are formed from the FFT's exchange area while the inverse's operands are gathered.
+ *     tac_spectrogram_backward_ola_f32: the whole adjoint of (2) — tac_spectrogram_backward_f32 + tac_overlap_add_f32 —
+ *       for fft_length 2048 with a hop that is a multiple of 128 (TAC_E_UNSUPPORTED otherwise): every wave walks a run of
+ *       consecutive frames and keeps their overlap-add in LDS, so no frame gradients exist in memory.  `workspace`
+ *       (device) must hold tac_spectrogram_backward_ola_workspace(d) bytes (that call returns a negative TAC_E_* code
+ *       for geometries the form does not cover); grad_wave[r][j] at grad_wave + r * grad_row_stride + j.
  *     tac_overlap_add_f32: adjoint of framing + padding: grad_wave[r][j] = sum of grad_frames over every (frame, tap)
  *       that read sample j, reflect / replicate / circular images included (a gather: deterministic, no atomics).
  *     tac_complex_norm_backward_f32: grad_z[i] = grad_out[i] * power * |z_i|^(power-2) * z_i (0 where z_i == 0),
@@ -233,6 +238,10 @@ int tac_stft_norm_backward_f32(const float* spec, const float* grad_norm, float 
                                const tac_stft_desc* d, float* grad_frames, void* stream);
 int tac_spectrogram_backward_f32(const float* wave, const float* window, const tac_stft_desc* d,
                                  const float* grad_norm, float power, float* grad_frames, void* stream);
+int64_t tac_spectrogram_backward_ola_workspace(const tac_stft_desc* d);
+int tac_spectrogram_backward_ola_f32(const float* wave, const float* window, const tac_stft_desc* d,
+                                     const float* grad_norm, float power, void* workspace, int64_t workspace_bytes,
+                                     float* grad_wave, int64_t grad_row_stride, void* stream);
 int tac_overlap_add_f32(const float* grad_frames, const tac_stft_desc* d, float* grad_wave,
                         int64_t grad_row_stride, void* stream);
 int tac_complex_norm_backward_f32(const float* z, const float* grad_out, int64_t n, float power,

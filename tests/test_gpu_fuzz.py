@@ -199,3 +199,48 @@ def test_fuzz_gradients(tac):
         (want,) = torch.autograd.grad((want_y * torch.from_numpy(w)).sum(), xc)
         (got,) = torch.autograd.grad((y * dev(w)).sum(), xg)
         assert rel_err(host(got), want.numpy()) < (1e-3 if kind == 'mel_db' else 1e-4), tag
+
+
+def test_fuzz_gradients_overlap_add_in_lds(tac):
+    """The fft_length 2048 / hop = 128·H backward form (csrc/backward.hip: overlap-add in an LDS ring over segments of
+    consecutive frames, partial sums at segment borders folded afterwards) over every H, pad mode, centring, short windows
+    and signal lengths from one frame to hundreds (one to many segments per row)."""
+    rng = np.random.default_rng(6000 + SEED)
+    n = 2048
+    for case in range(max(12, CASES // 2)):
+        hop = 128 * int(rng.integers(1, 17)) if case % 3 else 512
+        win_length = n if rng.random() < 0.6 else int(rng.integers(n // 4, n + 1))
+        center = bool(rng.random() < 0.75)
+        pad_mode = str(rng.choice(['reflect', 'constant', 'replicate', 'circular']))
+        normalized = bool(rng.random() < 0.3)
+        lead = tuple(int(v) for v in rng.integers(1, 4, size=int(rng.integers(1, 3))))
+        lo = n + 1 if center else n
+        length = int(rng.integers(lo, lo + int(rng.choice([3, 40, 400])) * hop + 7))
+        kind = ['power', 'mel', 'mel_db', 'magnitude'][case % 4]
+        x = signals.audio_like(lead + (length,), seed=9700 + case + 7919 * SEED)
+        xc = torch.from_numpy(x).requires_grad_(True)
+        xg = dev(x).requires_grad_(True)
+        kw = dict(win_length=win_length, center=center, pad_mode=pad_mode, normalized=normalized)
+        before = dict(tac._hip.launches)
+        if kind in ('power', 'magnitude'):
+            power = 2.0 if kind == 'power' else 1.0
+            want_y = torch_ref.complex_norm(torch_ref.stft(xc, n, hop, **kw), power)
+            y = tac.Spectrogram(n, hop, power=power, **kw).cuda()(xg)
+        else:
+            want_y = torch_ref.melspectrogram(xc, num_mels=64, sample_rate=16000, n_fft=n, hop=hop, **kw)
+            chain = tac.Melspectrogram(num_mels=64, sample_rate=16000, fft_length=n, hop_length=hop, **kw)
+            if kind == 'mel_db':
+                floor = 1e-3 * float(want_y.detach().max())
+                ref = max(1.0, 2.0 * floor * floor)
+                want_y = torch_ref.amplitude_to_db(want_y, ref=ref, amin=floor * floor)
+                chain = torch.nn.Sequential(*chain, tac.AmplitudeToDb(ref=ref, amin=floor * floor))
+            y = chain.cuda()(xg)
+        tag = ('grad-ola', case, kind, hop, kw, lead, length)
+        w = signals.uniform(tuple(want_y.shape), seed=9750 + case)
+        if kind == 'magnitude':            # |z| is not differentiable at 0: weight only bins that carry signal
+            w = w * (want_y.detach().numpy() > 1e-3 * float(want_y.detach().max()))
+        (want,) = torch.autograd.grad((want_y * torch.from_numpy(w)).sum(), xc)
+        (got,) = torch.autograd.grad((y * dev(w.astype(np.float32))).sum(), xg)
+        ran = {k: v - before.get(k, 0) for k, v in tac._hip.launches.items() if v != before.get(k, 0)}
+        assert ran.get('tac_spectrogram_backward_ola_f32') == 1 and 'tac_overlap_add_f32' not in ran, (tag, ran)
+        assert rel_err(host(got), want.numpy()) < (1e-3 if kind in ('mel_db', 'magnitude') else 1e-4), tag

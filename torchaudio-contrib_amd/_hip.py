@@ -594,8 +594,20 @@ def stft_backward(grad_spec, wave, window, n_fft, hop, win_length, center, pad_m
         gn = gn if gn.is_contiguous() else gn.contiguous()
         if gn.dtype != torch.float32:
             gn = gn.float()
-    frames = torch.empty((g.rows, g.n_frames, n_fft), dtype=torch.float32, device=wave.device)
     out = torch.empty(tuple(wave.shape), dtype=torch.float32, device=wave.device)
+    if gs is None and g.desc is not None:
+        # fft_length 2048, hop a multiple of 128: overlap-add inside the kernel (LDS), no frame gradients in memory
+        need = _native.lib().tac_spectrogram_backward_ola_workspace(g.desc)
+        if need >= 0:
+            work = torch.empty(max(int(need), 4) // 4, dtype=torch.float32, device=wave.device)
+            with _native.on_device(wave.device):
+                rc = _native.lib().tac_spectrogram_backward_ola_f32(
+                    _native.ptr(_rows_of(wave, g)), _native.ptr(window), g.desc, _native.ptr(gn), float(power),
+                    _native.ptr(work), int(need), _native.ptr(out), g.length, _native.stream_ptr(wave.device))
+            _native.check(rc, 'tac_spectrogram_backward_ola_f32')
+            _count('tac_spectrogram_backward_ola_f32')
+            return out
+    frames = torch.empty((g.rows, g.n_frames, n_fft), dtype=torch.float32, device=wave.device)
     desc = _native.StftDesc(rows=g.rows, length=g.length, row_stride=g.length, n_fft=n_fft, hop=hop,
                             win_length=win_length, center=1 if center else 0, pad_mode=_native.PAD_MODES[pad_mode],
                             normalized=1 if normalized else 0, onesided=1, reserved=0)

@@ -12,6 +12,8 @@
 // The filterbank stage's adjoint is the forward GEMM with the transposed matrix (tac_apply_filterbank_f32).
 #include "host_common.hpp"
 
+#include <algorithm>
+
 namespace tac {
 
 constexpr int BW_WAVES = 4;
@@ -243,6 +245,212 @@ stft_backward_kernel(FrameGeom g, Tables tb, const float* __restrict__ gspec, co
     }
 }
 
+// ---------------------------------------------------------------- Spectrogram backward with the overlap-add in LDS
+// fft_length 2048, hop a multiple of 128 (tac_spectrogram_backward_ola_f32).  The kernel above writes 4·N bytes of frame
+// gradient per frame and overlap_add_kernel reads them back: 16 of the 20 bytes per sample the pair moves.  Here a wave
+// walks a SEGMENT of consecutive frames of one row and keeps the running overlap-add of the last N positions in a ring
+// in LDS: after frame f is added, positions [f·hop, (f+1)·hop) of the padded signal are complete and leave for
+// gpad[row][·]; the slots they occupied take the next frame's newest positions.  hop = 128·H makes the position class
+// of an output (complete / still open / new) a function of the register index j alone, and the ring slot a rotation
+// of it.  Segment borders: a segment's first N - hop positions miss the previous segment's last frames — that
+// segment writes what it has for them (its ring at the end) to edge[row][segment][·] and ola_fold_kernel, which maps
+// the padded gradient back onto the waveform (reflect / replicate / circular images), adds the two partial sums:
+// every value has exactly one writer, no atomics, deterministic.
+constexpr int OLA_WAVES = 4;
+constexpr int OLA_NC = 1024, OLA_E = 16, OLA_N = 2048;
+
+struct OlaPlan {
+    int seg_frames;       // S: frames per segment (>= (N - hop) / hop, so that a tail never reaches past the next segment)
+    int segs_per_row;
+    long long pad_len;    // floats per row of gpad (= length + 2·center_pad)
+};
+
+template <bool POW2>
+__global__ void __launch_bounds__(OLA_WAVES * 64, 2)
+spectrogram_backward_ola_kernel(FrameGeom g, Tables tb, const float* __restrict__ gnorm, float power,
+                                float* __restrict__ gpad, float* __restrict__ edge, OlaPlan plan) {
+    using F = WaveFft<OLA_NC, OLA_E>;
+    constexpr int NC = OLA_NC, E = OLA_E, N = OLA_N, NBINS = NC + 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int t = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int WAVE_SLOTS = ((F::PADDED + 1) / 2) * 2;
+    cf* const lds = reinterpret_cast<cf*>(smem_raw) + w * WAVE_SLOTS;
+    cf* const ring = reinterpret_cast<cf*>(smem_raw) + OLA_WAVES * WAVE_SLOTS + w * NC;      // N floats per wave
+    cf* const win_lds = reinterpret_cast<cf*>(smem_raw) + OLA_WAVES * (WAVE_SLOTS + NC);
+    cf* const wk_lds = win_lds + NC;
+    for (int m = threadIdx.x; m < NC; m += OLA_WAVES * 64) win_lds[m] = window_pair(g, m);
+    for (int k = threadIdx.x; k <= NC / 2; k += OLA_WAVES * 64) wk_lds[k] = tb.w_n[k];
+    __syncthreads();
+
+    const int T = (int)g.n_frames, hop = g.hop, H = hop >> 7, S = plan.seg_frames, spr = plan.segs_per_row;
+    const long long nseg_total = g.rows * (long long)spr;
+    const long long stride = (long long)gridDim.x * OLA_WAVES;
+    const float wscale = 0.5f * g.scale, xscale = 0.5f * g.scale;
+    cf tw[F::NTW];
+    F::load_twiddles(tw, tb.w_nc, t);
+
+    long long seg = (long long)blockIdx.x * OLA_WAVES + w;
+    if (seg >= nseg_total) return;
+    int row = (int)(seg / spr), sidx = (int)(seg - (long long)row * spr);
+    int f0 = sidx * S, f1 = f0 + S < T ? f0 + S : T, f = f0;
+
+    cf raw[E];
+    float gk[E], gm[E];
+    bool pre = false;
+    const bool can_prefetch = g.vec2_ok && g.length >= N;
+    auto request = [&](int r, int fr) {                     // samples + gradient row of (row r, frame fr), unconditionally
+        const float* gn = gnorm + ((long long)r * T + fr) * NBINS;
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            const int k = t + q * (NC / E);
+            gk[q] = gn[k];
+            gm[q] = gn[NC - k];
+        }
+        const long long start = (long long)fr * hop - g.center_pad;
+        const bool ok = can_prefetch && start >= 0 && start + N <= g.length;
+        const cf* src = reinterpret_cast<const cf*>(g.wave + r * g.row_stride + (ok ? start : 0));
+        if (can_prefetch) {
+#pragma unroll
+            for (int q = 0; q < E; ++q) raw[q] = src[t + q * F::LPF];
+        } else {
+#pragma unroll
+            for (int q = 0; q < E; ++q) raw[q] = mkc(0.0f, 0.0f);
+        }
+        pre = ok;
+    };
+    request(row, f);
+    while (true) {
+        // the item after this one: next frame of the segment, or the first frame of this wave's next segment
+        long long nseg = seg;
+        int nrow = row, nsidx = sidx, nf0 = f0, nf1 = f1, nf = f + 1;
+        bool more = true;
+        if (nf >= f1) {
+            nseg = seg + stride;
+            if (nseg >= nseg_total) {
+                more = false;
+                nf = f;
+            } else {
+                nrow = (int)(nseg / spr);
+                nsidx = (int)(nseg - (long long)nrow * spr);
+                nf0 = nsidx * S;
+                nf1 = nf0 + S < T ? nf0 + S : T;
+                nf = nf0;
+            }
+        }
+        const bool first = (f == f0), last = (f + 1 == f1);
+
+        // ---- forward transform of the frame
+        cf v[1][E];
+        cf* const ldsv[1] = {lds};
+        {
+            int tl = t;
+            asm volatile("" : "+v"(tl));
+            cf win[E];
+#pragma unroll
+            for (int q = 0; q < E; ++q) win[q] = win_lds[tl + q * (NC / E)];
+            if (pre) apply_window<F>(v[0], raw, win);
+            else load_frame<F, true>(v[0], g, win, lds, row, f, t);
+            F::template run<1>(v, ldsv, tw, t);
+        }
+        // ---- gradient spectrum -> operands of the inverse transform (see stft_backward_kernel)
+        int tg = t;
+        asm volatile("" : "+v"(tg));
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            const int k = tg + q * (NC / E);
+            const int kt = k <= NC / 2 ? k : NC - k;
+            const cf wk = wk_lds[kt];
+            const cf wkk = k <= NC / 2 ? wk : mkc(-wk.x, wk.y);
+            cf hk, hm;
+            F::r2c_pair(lds, k, wkk, hk, hm);
+            hk = norm_pow_grad<POW2>(cscale(hk, xscale), gk[q], power);
+            hm = norm_pow_grad<POW2>(cscale(hm, xscale), gm[q], power);
+            if (k == 0) {
+                hk = mkc(2.0f * hk.x, 0.0f);
+                hm = mkc(2.0f * hm.x, 0.0f);
+            }
+            const cf sm = mkc(hk.x + hm.x, hm.y - hk.y);
+            const cf d = mkc(hk.x - hm.x, -hk.y - hm.y);
+            const cf wd = mkc(wkk.x * d.x - wkk.y * d.y, wkk.x * d.y + wkk.y * d.x);
+            v[0][q] = mkc(sm.x + wd.y, sm.y - wd.x);
+            asm volatile("" : "+v"(v[0][q]));
+            if ((q & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+        wave_lds_fence();
+        __builtin_amdgcn_sched_barrier(0);
+        request(nrow, nf);
+        __builtin_amdgcn_sched_barrier(0);
+        F::template run<1>(v, ldsv, tw, t);                 // R[] in natural order at lds[lds_pad(i)]
+
+        // ---- windowed frame gradient into the ring; complete positions out
+        const int rot = (int)(((long long)f * H) & 15);
+        float* const prow = gpad + (long long)row * plan.pad_len + (long long)f * hop;           // position f·hop
+        const bool row_end = (f1 == T);
+        float* const tail = row_end ? prow : edge + ((long long)row * (spr - 1) + sidx) * (N - hop) - hop;   // + n
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const int m = t + j * 64;                                       // samples n = 2m, 2m + 1 of the frame
+            const cf r = lds[lds_pad(m)];
+            const cf wn = win_lds[m];
+            cf acc = mkc(r.x * wn.x * wscale, -r.y * wn.y * wscale);
+            cf* const slot = ring + (((j + rot) & 15) << 6) + t;
+            if (!(first || j >= 16 - H)) {
+                const cf old = *slot;
+                acc = mkc(acc.x + old.x, acc.y + old.y);
+            }
+            if (j < H) *reinterpret_cast<cf*>(prow + 2 * m) = acc;          // complete
+            else if (last) *reinterpret_cast<cf*>(tail + 2 * m) = acc;      // the segment's open positions
+            else *slot = acc;
+        }
+        wave_lds_fence();
+        if (!more) break;
+        seg = nseg; row = nrow; sidx = nsidx; f0 = nf0; f1 = nf1; f = nf;
+    }
+}
+
+// g_wave[row][j] = sum over the padded positions i with source(i) == j of P[row][i + pad], where
+// P = gpad + (inside a segment's first N - hop positions) the previous segment's edge sums; positions no frame covers are 0.
+__global__ void __launch_bounds__(256)
+ola_fold_kernel(FrameGeom g, const float* __restrict__ gpad, const float* __restrict__ edge, OlaPlan plan,
+                float* __restrict__ gwave, long long gwave_row_stride) {
+    const int L = (int)g.length, T = (int)g.n_frames;
+    const int pad = g.center_pad, hop = g.hop;
+    const int covered = (T - 1) * hop + OLA_N;             // positions [0, covered) are touched by some frame
+    const int seg_span = plan.seg_frames * hop, open = OLA_N - hop, spr = plan.segs_per_row;
+    const long long total = g.rows * (long long)L;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(idx / L);
+        const int j = (int)(idx - (long long)row * L);
+        const float* prow = gpad + (long long)row * plan.pad_len;
+        const float* erow = edge + (long long)row * (spr - 1) * open;
+        float acc = 0.0f;
+        auto add_position = [&](int i) {
+            const int p = i + pad;
+            if (p < 0 || p >= covered) return;
+            float v = prow[p];
+            const int s = p / seg_span, o = p - s * seg_span;
+            if (s >= 1 && s < spr && o < open) v += erow[(long long)(s - 1) * open + o];
+            acc += v;
+        };
+        add_position(j);
+        if (pad > 0) {
+            if (g.pad_mode == PAD_REFLECT) {
+                if (j >= 1 && j <= pad) add_position(-j);
+                if (j <= L - 2 && j >= L - 1 - pad) add_position(2 * (L - 1) - j);
+            } else if (g.pad_mode == PAD_REPLICATE) {
+                if (j == 0) for (int i = -pad; i < 0; ++i) add_position(i);
+                if (j == L - 1) for (int i = L; i < L + pad; ++i) add_position(i);
+            } else if (g.pad_mode == PAD_CIRCULAR) {
+                if (j >= L - pad) add_position(j - L);
+                if (j < pad) add_position(j + L);
+            }
+        }
+        gwave[row * gwave_row_stride + j] = acc;
+    }
+}
+
 // g_wave[row][j] = sum over padded positions i with source(i) == j of sum over frames t covering i of
 // frames[row][t][i + pad - t*hop]   (source(): torch.nn.functional.pad semantics, fft_core.hpp padded_index).
 __global__ void __launch_bounds__(256)
@@ -357,6 +565,27 @@ static int stft_backward_entry(const float* spec, const float* gnorm, float powe
     }
 }
 
+// segmentation of the LDS overlap-add form; TAC_E_UNSUPPORTED for geometries it does not cover
+static int ola_plan(const tac_stft_desc* d, const FrameGeom& g, OlaPlan* plan) {
+    if (d->n_fft != OLA_N || !d->onesided || d->hop <= 0 || (d->hop & 127) || d->hop > OLA_N) return TAC_E_UNSUPPORTED;
+    if (g.length >= 0x7fffffffLL - 2 * OLA_N || g.n_frames < 1 || g.n_frames >= 0x7fffffffLL / OLA_N) return TAC_E_UNSUPPORTED;
+    const int T = (int)g.n_frames;
+    const int s_min = std::max(1, (OLA_N - d->hop + d->hop - 1) / d->hop);
+    const long long target = (long long)device_cu_count() * 2 * OLA_WAVES;          // one segment per resident wave
+    long long spr = (target + g.rows - 1) / g.rows;
+    spr = std::max(1LL, std::min(spr, (long long)std::max(1, T / s_min)));
+    int S = (int)((T + spr - 1) / spr);
+    if (S < s_min) S = s_min;
+    plan->seg_frames = S;
+    plan->segs_per_row = (T + S - 1) / S;
+    plan->pad_len = g.length + 2LL * g.center_pad;
+    return TAC_OK;
+}
+
+static long long ola_workspace_floats(const FrameGeom& g, const OlaPlan& plan, int hop) {
+    return g.rows * plan.pad_len + g.rows * (long long)(plan.segs_per_row - 1) * (OLA_N - hop);
+}
+
 static unsigned bw_blocks(long long n) {
     long long want = (n + 255) / 256, cap = (long long)device_cu_count() * 16;
     if (want < 1) want = 1;
@@ -382,6 +611,57 @@ int tac_spectrogram_backward_f32(const float* wave, const float* window, const t
                                  float power, float* grad_frames, void* stream) {
     if (!grad_norm) return TAC_E_INVALID;
     return tac::stft_backward_entry(wave, grad_norm, power, window, d, grad_frames, stream, true);
+}
+
+int64_t tac_spectrogram_backward_ola_workspace(const tac_stft_desc* d) {
+    using namespace tac;
+    if (!d) return TAC_E_INVALID;
+    FrameGeom g;
+    int64_t T = 0;
+    float dummy = 0.0f;
+    int rc = make_geometry(&dummy, &dummy, d, &g, &T);
+    if (rc != TAC_OK) return rc;
+    OlaPlan plan;
+    rc = ola_plan(d, g, &plan);
+    if (rc != TAC_OK) return rc;
+    return (int64_t)ola_workspace_floats(g, plan, d->hop) * (int64_t)sizeof(float);
+}
+
+int tac_spectrogram_backward_ola_f32(const float* wave, const float* window, const tac_stft_desc* d, const float* grad_norm,
+                                     float power, void* workspace, int64_t workspace_bytes, float* grad_wave,
+                                     int64_t grad_row_stride, void* stream) {
+    using namespace tac;
+    if (!wave || !window || !d || !grad_norm || !workspace || !grad_wave) return TAC_E_INVALID;
+    FrameGeom g;
+    int64_t T = 0;
+    int rc = make_geometry(wave, window, d, &g, &T);
+    if (rc != TAC_OK) return rc;
+    OlaPlan plan;
+    rc = ola_plan(d, g, &plan);
+    if (rc != TAC_OK) return rc;
+    if (workspace_bytes < (int64_t)(ola_workspace_floats(g, plan, d->hop) * (long long)sizeof(float))) return TAC_E_INVALID;
+    Tables tb;
+    rc = get_tables(d->n_fft, &tb);
+    if (rc != TAC_OK) return rc;
+    float* gpad = static_cast<float*>(workspace);
+    float* edge = gpad + g.rows * plan.pad_len;
+    using F = WaveFft<OLA_NC, OLA_E>;
+    const size_t lds_bytes = (size_t)OLA_WAVES * ((((F::PADDED + 1) / 2) * 2) + OLA_NC) * sizeof(cf) +
+                             (size_t)(OLA_NC + OLA_NC / 2 + 2) * sizeof(cf);
+    const long long nseg = g.rows * (long long)plan.segs_per_row;
+    long long blocks = (nseg + OLA_WAVES - 1) / OLA_WAVES;
+    const long long cap = (long long)device_cu_count() * 2;
+    if (blocks > cap) blocks = cap;
+    auto kern = power == 2.0f ? spectrogram_backward_ola_kernel<true> : spectrogram_backward_ola_kernel<false>;
+    TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds_bytes));
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(OLA_WAVES * 64), lds_bytes, s, g, tb, grad_norm, power, gpad, edge,
+                       plan);
+    TAC_HIP(hipGetLastError());
+    hipLaunchKernelGGL(ola_fold_kernel, dim3(bw_blocks(g.rows * g.length)), dim3(256), 0, s, g, gpad, edge, plan, grad_wave,
+                       (long long)grad_row_stride);
+    TAC_HIP(hipGetLastError());
+    return TAC_OK;
 }
 
 int tac_overlap_add_f32(const float* grad_frames, const tac_stft_desc* d, float* grad_wave, int64_t grad_row_stride,
