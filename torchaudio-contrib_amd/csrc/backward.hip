@@ -418,19 +418,17 @@ ola_fold_kernel(FrameGeom g, const float* __restrict__ gpad, const float* __rest
     const int pad = g.center_pad, hop = g.hop;
     const int covered = (T - 1) * hop + OLA_N;             // positions [0, covered) are touched by some frame
     const int seg_span = plan.seg_frames * hop, open = OLA_N - hop, spr = plan.segs_per_row;
-    const long long total = g.rows * (long long)L;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const int row = (int)(idx / L);
-        const int j = (int)(idx - (long long)row * L);
-        const float* prow = gpad + (long long)row * plan.pad_len;
-        const float* erow = edge + (long long)row * (spr - 1) * open;
+    // grid: x over the samples of a row, y over rows — no division by L per sample, 32-bit positions.  A thread owns four
+    // consecutive samples; where none of them has a padding image or straddles a segment-border zone they move as one
+    // 16-byte access (global accesses need dword alignment only).
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    auto one = [&](const float* prow, const float* erow, int j) -> float {
         float acc = 0.0f;
         auto add_position = [&](int i) {
             const int p = i + pad;
             if (p < 0 || p >= covered) return;
             float v = prow[p];
-            const int s = p / seg_span, o = p - s * seg_span;
+            const int s = (int)((unsigned)p / (unsigned)seg_span), o = p - s * seg_span;
             if (s >= 1 && s < spr && o < open) v += erow[(long long)(s - 1) * open + o];
             acc += v;
         };
@@ -447,7 +445,25 @@ ola_fold_kernel(FrameGeom g, const float* __restrict__ gpad, const float* __rest
                 if (j < pad) add_position(j + L);
             }
         }
-        gwave[row * gwave_row_stride + j] = acc;
+        return acc;
+    };
+    for (long long row = blockIdx.y; row < g.rows; row += gridDim.y) {
+        const float* prow = gpad + row * plan.pad_len;
+        const float* erow = edge + row * (spr - 1) * open;
+        float* orow = gwave + row * gwave_row_stride;
+        for (int j = 4 * (int)(blockIdx.x * blockDim.x + threadIdx.x); j < L; j += 4 * (int)(gridDim.x * blockDim.x)) {
+            const int p = j + pad;
+            const int s = (int)((unsigned)p / (unsigned)seg_span), o = p - s * seg_span;
+            const bool images = pad > 0 && (j <= pad || j + 3 >= L - 1 - pad);      // some sample has a padding image
+            const bool in_zone = s >= 1 && s < spr && o + 3 < open, out_zone = s < 1 || s >= spr || (o >= open && o + 3 < seg_span);
+            if (j + 3 < L && p + 3 < covered && !images && (in_zone || out_zone)) {
+                f4u v = *reinterpret_cast<const f4u*>(prow + p);
+                if (in_zone) v += *reinterpret_cast<const f4u*>(erow + (long long)(s - 1) * open + o);
+                *reinterpret_cast<f4u*>(orow + j) = v;
+            } else {
+                for (int u = 0; u < 4 && j + u < L; ++u) orow[j + u] = one(prow, erow, j + u);
+            }
+        }
     }
 }
 
@@ -658,7 +674,11 @@ int tac_spectrogram_backward_ola_f32(const float* wave, const float* window, con
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(OLA_WAVES * 64), lds_bytes, s, g, tb, grad_norm, power, gpad, edge,
                        plan);
     TAC_HIP(hipGetLastError());
-    hipLaunchKernelGGL(ola_fold_kernel, dim3(bw_blocks(g.rows * g.length)), dim3(256), 0, s, g, gpad, edge, plan, grad_wave,
+    // ~16 workgroups per CU in flight, each thread walking its row with a stride: rows on y, a row's samples on x
+    const unsigned fold_y = (unsigned)std::min<long long>(g.rows, 65535);
+    const long long per_row = std::max<long long>(1, (long long)device_cu_count() * 16 / fold_y);
+    const unsigned fold_x = (unsigned)std::min<long long>((g.length + 1023) / 1024, per_row);
+    hipLaunchKernelGGL(ola_fold_kernel, dim3(fold_x, fold_y), dim3(256), 0, s, g, gpad, edge, plan, grad_wave,
                        (long long)grad_row_stride);
     TAC_HIP(hipGetLastError());
     return TAC_OK;
