@@ -849,8 +849,9 @@ def test_autograd_matches_the_reference_chain(tac, shape, n_fft, hop, mels):
                          (True, torch.nn.Sequential(*mel, tac.AmplitudeToDb(amin=1e-5)))):   # the unpacked (reference) idiom
         before = launches(tac)
         y = chain(xg)
-        if idiom:       # deferred although the waveform requires grad: ONE fused forward kernel, dB included
-            assert launched_since(tac, before) == {'tac_melspec_sparse_f32': 1}
+        if idiom:       # deferred although the waveform requires grad: ONE fused forward kernel + the dB op, which keeps
+            #             the linear mel values its gradient needs (fused in, backward would have to recompute them)
+            assert launched_since(tac, before) == {'tac_melspec_sparse_f32': 1, 'tac_amplitude_to_db_f32': 1}
         assert y.requires_grad and np.abs(host(y) - want_y.detach().numpy()).max() < DB_ABS
         before = launches(tac)
         (got,) = torch.autograd.grad((y * dev(weight)).sum(), xg)

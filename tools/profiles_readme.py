@@ -116,8 +116,8 @@ out.append('All three kernels run 2 waves/SIMD (one 8-wave workgroup per CU whos
 for fname, what in (('kernel_stats_backward.csv',
                      '`tools/prof_driver.py grad 5`: forward + backward of the reference idiom `Sequential(*Melspectrogram(...), '
                      'AmplitudeToDb())` at cfg-2 with `requires_grad` on the waveform: the chain is deferred as usual (one fused '
-                     'forward kernel) and differentiates through the `tac_amd::melspectrogram` op — mel values recomputed by the '
-                     'fused forward kernel (dB gradient), filterbank adjoint, ONE backward kernel that re-transforms the frames, '
+                     'forward kernel for the linear mel values + the dB op, which keeps them for its gradient) and differentiates through '
+                     'the `tac_amd::melspectrogram` op — filterbank adjoint, ONE backward kernel that re-transforms the frames, '
                      'forms the gradient spectrum, inverse-transforms and overlap-adds in LDS, and the unpadding / border fold'),
                     ('kernel_stats_backward_fused_op.csv',
                      '`tools/prof_driver.py gradf 5`: the same through the factory container (`Melspectrogram(...)` called as '

@@ -181,6 +181,11 @@ class DeferredSpectral(torch.Tensor):
     def _launch(self, db):
         from ._ops import call
         s = self._src
+        if db is not None and self._tracks_grad and torch.is_grad_enabled() and self._stage in ('spec', 'mel'):
+            # training: the dB gradient needs the linear values.  Fused into one op they would have to be recomputed in
+            # backward (a second launch of the fused kernel, 0.15 ms at cfg-2); as two ops the dB op saves its input
+            # (one tiny extra kernel forward, n_mels x frames floats kept) and backward recomputes nothing.
+            return call('amplitude_to_db', self._launch(None), float(db[0]), float(db[1]))
         ref, amin = db if db is not None else (1.0, 1e-7)
         wave = s.wave
         if s.decode is not None:
