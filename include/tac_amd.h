@@ -231,7 +231,11 @@ int tac_mulaw_decode_f32_f32(const float* codes, int64_t n, int32_t n_quantize, 
  *       functional.py:126-128.
  *     tac_amplitude_to_db_backward_f32: grad_x = grad_out * 20 / (ln 10 * x) where x^2 >= amin, else 0,
  *       functional.py:291-296.
- *     The filterbank stage's adjoint is (4) with the transposed matrix. */
+ *     The filterbank stage's adjoint is (4) with the transposed matrix — or, for banks with at most two non-zero
+ *     weights per bin (every triangular mel bank), tac_apply_filterbank_adjoint_f32: grad_spec[i][f] = w0[f] *
+ *     grad_mel[i][band0[f]] + w1[f] * grad_mel[i][band1[f]] over i < rows*T frame-major rows, with the per-bin table
+ *     built on the device by tac_filterbank_adjoint_pack (table: 16 * n_freqs + 16 bytes, device; *max_nonzeros_host
+ *     receives the non-zero count of the fullest bin — the table is only valid when that is <= 2; synchronous). */
 int tac_stft_backward_f32(const float* grad_spec, const float* window, const tac_stft_desc* d,
                           float* grad_frames, void* stream);
 int tac_stft_norm_backward_f32(const float* spec, const float* grad_norm, float power, const float* window,
@@ -242,6 +246,10 @@ int64_t tac_spectrogram_backward_ola_workspace(const tac_stft_desc* d);
 int tac_spectrogram_backward_ola_f32(const float* wave, const float* window, const tac_stft_desc* d,
                                      const float* grad_norm, float power, void* workspace, int64_t workspace_bytes,
                                      float* grad_wave, int64_t grad_row_stride, void* stream);
+int tac_filterbank_adjoint_pack(const float* fb, int32_t n_freqs, int32_t n_mels, void* table,
+                                int32_t* max_nonzeros_host, void* stream);
+int tac_apply_filterbank_adjoint_f32(const float* grad_mel, int64_t rows_times_frames, int32_t n_mels,
+                                     const void* table, int32_t n_freqs, float* grad_spec, void* stream);
 int tac_overlap_add_f32(const float* grad_frames, const tac_stft_desc* d, float* grad_wave,
                         int64_t grad_row_stride, void* stream);
 int tac_complex_norm_backward_f32(const float* z, const float* grad_out, int64_t n, float power,

@@ -867,6 +867,28 @@ def test_autograd_matches_the_reference_chain(tac, shape, n_fft, hop, mels):
         assert rel_err(host(got), want.numpy()) < 1e-3
 
 
+def test_filterbank_adjoint_forms(tac):
+    """Gradient of apply_filterbank w.r.t. the spectrogram (functional.py:183-184 under autograd): banks with at most two
+    non-zero weights per bin (mel banks) take the per-bin table kernel, anything else the GEMM with the transposed bank;
+    both against float64."""
+    for n_freqs, n_mels, shape in ((1025, 128, (3, 1025, 77)), (257, 40, (2, 2, 257, 31)), (201, 23, (201, 9)),
+                                   (2049, 80, (1, 2049, 40))):
+        spec = dev(np.abs(signals.uniform(shape, seed=91)) + 0.1).requires_grad_(True)
+        w = signals.uniform(shape[:-2] + (n_mels, shape[-1]), seed=92)
+        mel_fb = tac.create_mel_filter(n_freqs, n_mels, 0.0, 8000.0, False).cuda()
+        dense_fb = dev(signals.uniform((n_freqs, n_mels), seed=93))
+        three = mel_fb.clone()
+        three[5, :3] = torch.tensor([0.25, 0.5, 0.125])              # one bin with three bands: not a two-entry table
+        for fb, entry in ((mel_fb, 'tac_apply_filterbank_adjoint_f32'), (dense_fb, 'tac_apply_filterbank_f32'),
+                          (three, 'tac_apply_filterbank_f32')):
+            y = tac.apply_filterbank(spec, fb)
+            before = launches(tac)
+            (got,) = torch.autograd.grad((tac.realize(y) * dev(w)).sum(), spec)
+            assert launched_since(tac, before) == {entry: 1}, (n_freqs, entry)
+            want = np.einsum('...mt,fm->...ft', w.astype(np.float64), host(fb).astype(np.float64))
+            assert rel_err(host(got), want) < 1e-5, (n_freqs, entry)
+
+
 def test_deferred_results_carry_gradients(tac):
     """A waveform that requires grad is deferred like any other (the reference idiom trains through the fused kernels);
     whatever consumes a pending result — a terminal layer, a torch function, a method, a view, an in-place-free

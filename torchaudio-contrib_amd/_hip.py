@@ -570,8 +570,52 @@ def transposed_bank(fb):
     return t
 
 
+def _adjoint_table(fb):
+    """Per-bin {w0, w1, band0, band1} table of a bank with at most two non-zero weights per bin (every triangular mel
+    bank), built on the device once per filterbank version (one host sync) and cached on the tensor; None otherwise."""
+    hit = getattr(fb, '_tac_adj', None)
+    if hit is not None and hit[0] == fb._version:
+        return hit[1]
+    n_freqs, n_mels = fb.shape
+    table = None
+    if n_mels <= 512 and 16 * n_freqs + 4 * 4 * n_mels <= 64 * 1024:
+        table = torch.empty(4 * n_freqs + 4, dtype=torch.float32, device=fb.device)
+        nnz = ctypes.c_int32(0)
+        with _native.on_device(fb.device):
+            rc = _native.lib().tac_filterbank_adjoint_pack(_native.ptr(fb), n_freqs, n_mels, _native.ptr(table),
+                                                           ctypes.cast(ctypes.pointer(nnz), ctypes.c_void_p),
+                                                           _native.stream_ptr(fb.device))
+        _native.check(rc, 'tac_filterbank_adjoint_pack')
+        if nnz.value > 2:
+            table = None
+    try:
+        fb._tac_adj = (fb._version, table)
+    except Exception:
+        pass
+    return table
+
+
 def apply_filterbank_backward(grad_out, fb):
-    """(*, M, T) gradient -> (*, F, T): the forward MFMA GEMM with the transposed bank."""
+    """(*, M, T) gradient -> (*, F, T): two multiply-adds per output through the per-bin table of a bank with at most
+    two non-zero weights per bin (tac_apply_filterbank_adjoint_f32); any other bank: the forward MFMA GEMM with the
+    transposed bank."""
+    fbc = fb if fb.is_contiguous() else fb.contiguous()
+    table = _adjoint_table(fbc) if (grad_out.dim() >= 2 and MEL_PATH != 'mfma') else None
+    if table is not None:
+        n_freqs, n_mels = fbc.shape
+        gm = grad_out.transpose(-2, -1)                               # physical frame-major (*, T, M)
+        gm = gm if gm.is_contiguous() else gm.contiguous()
+        if gm.dtype != torch.float32:
+            gm = gm.float()
+        out = torch.empty(tuple(gm.shape[:-1]) + (n_freqs,), dtype=torch.float32, device=gm.device)
+        with _native.on_device(gm.device):
+            rc = _native.lib().tac_apply_filterbank_adjoint_f32(_native.ptr(gm), gm.numel() // n_mels, n_mels,
+                                                                _native.ptr(table), n_freqs, _native.ptr(out),
+                                                                _native.stream_ptr(gm.device))
+        if rc != _native.TAC_E_UNSUPPORTED:
+            _native.check(rc, 'tac_apply_filterbank_adjoint_f32')
+            _count('tac_apply_filterbank_adjoint_f32')
+            return out.transpose(-2, -1)
     return apply_filterbank(grad_out, transposed_bank(fb), allow_sparse=False)
 
 

@@ -581,6 +581,75 @@ static int stft_backward_entry(const float* spec, const float* gnorm, float powe
     }
 }
 
+// ---------------------------------------------------------------- band-sparse adjoint of the filterbank stage
+// d/d spec of spec·fb (functional.py:183-184) is grad_mel·fb^T.  A mel bank has at most two non-zero weights per BIN
+// (the falling edge of one triangle, the rising edge of the next), so the adjoint is two multiply-adds per output instead
+// of a GEMM row: fb_adjoint_pack_kernel builds {w0, w1, band0, band1} per bin on the device (and counts the non-zeros of
+// the fullest bin: banks with more than two keep the GEMM), fb_adjoint_kernel streams frames through it — a wave per
+// frame, the frame's mel-gradient row in LDS, 4·F bytes out per frame: write-bound.
+struct AdjEntry { float w0, w1; int b0, b1; };
+
+__global__ void __launch_bounds__(256)
+fb_adjoint_pack_kernel(const float* __restrict__ fb, int n_freqs, int n_mels, AdjEntry* __restrict__ table,
+                       int* __restrict__ max_nnz) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_freqs) return;
+    AdjEntry e{0.0f, 0.0f, 0, 0};
+    int n = 0;
+    for (int m = 0; m < n_mels; ++m) {
+        const float wv = fb[(long long)f * n_mels + m];
+        if (wv != 0.0f) {
+            if (n == 0) { e.w0 = wv; e.b0 = m; }
+            else if (n == 1) { e.w1 = wv; e.b1 = m; }
+            ++n;
+        }
+    }
+    table[f] = e;
+    atomicMax(max_nnz, n);
+}
+
+constexpr int ADJ_WAVES = 4;
+
+__global__ void __launch_bounds__(ADJ_WAVES * 64)
+fb_adjoint_kernel(const float* __restrict__ gmel, long long n_rows_frames, int n_mels, const AdjEntry* __restrict__ table,
+                  int n_freqs, float* __restrict__ gspec) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    AdjEntry* const tl = reinterpret_cast<AdjEntry*>(smem_raw);                       // [n_freqs]
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* const grow = reinterpret_cast<float*>(tl + n_freqs) + w * n_mels;          // this wave's mel-gradient row
+    for (int f = threadIdx.x; f < n_freqs; f += ADJ_WAVES * 64) tl[f] = table[f];
+    __syncthreads();
+    const long long stride = (long long)gridDim.x * ADJ_WAVES;
+    const int per_lane = (n_mels + 63) >> 6;                                          // <= 8 (n_mels <= 512)
+    float nxt[8];
+    long long u = (long long)blockIdx.x * ADJ_WAVES + w;
+    auto fetch = [&](long long unit) {
+        const float* src = gmel + (unit < n_rows_frames ? unit : n_rows_frames - 1) * n_mels;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = lane + 64 * i;
+            nxt[i] = (i < per_lane && m < n_mels) ? src[m] : 0.0f;
+        }
+    };
+    if (u < n_rows_frames) fetch(u);
+    for (; u < n_rows_frames; u += stride) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = lane + 64 * i;
+            if (i < per_lane && m < n_mels) grow[m] = nxt[i];
+        }
+        fetch(u + stride);                                          // the next frame's row travels behind this frame's work
+        wave_lds_fence();
+        float* out = gspec + u * n_freqs;
+        for (int f = lane; f < n_freqs; f += 64) {
+            const AdjEntry e = tl[f];
+            out[f] = __builtin_fmaf(e.w0, grow[e.b0], e.w1 * grow[e.b1]);
+        }
+        wave_lds_fence();
+    }
+}
+
 // segmentation of the LDS overlap-add form; TAC_E_UNSUPPORTED for geometries it does not cover
 static int ola_plan(const tac_stft_desc* d, const FrameGeom& g, OlaPlan* plan) {
     if (d->n_fft != OLA_N || !d->onesided || d->hop <= 0 || (d->hop & 127) || d->hop > OLA_N) return TAC_E_UNSUPPORTED;
@@ -627,6 +696,40 @@ int tac_spectrogram_backward_f32(const float* wave, const float* window, const t
                                  float power, float* grad_frames, void* stream) {
     if (!grad_norm) return TAC_E_INVALID;
     return tac::stft_backward_entry(wave, grad_norm, power, window, d, grad_frames, stream, true);
+}
+
+int tac_filterbank_adjoint_pack(const float* fb, int32_t n_freqs, int32_t n_mels, void* table, int32_t* max_nonzeros_host,
+                                void* stream) {
+    using namespace tac;
+    if (!fb || !table || !max_nonzeros_host || n_freqs <= 0 || n_mels <= 0) return TAC_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    // the counter sits behind the table (caller allocates 16·n_freqs + 16 bytes)
+    int* counter = reinterpret_cast<int*>(static_cast<AdjEntry*>(table) + n_freqs);
+    TAC_HIP(hipMemsetAsync(counter, 0, sizeof(int), s));
+    hipLaunchKernelGGL(fb_adjoint_pack_kernel, dim3((unsigned)((n_freqs + 255) / 256)), dim3(256), 0, s, fb, (int)n_freqs,
+                       (int)n_mels, static_cast<AdjEntry*>(table), counter);
+    TAC_HIP(hipGetLastError());
+    TAC_HIP(hipMemcpyAsync(max_nonzeros_host, counter, sizeof(int), hipMemcpyDeviceToHost, s));
+    TAC_HIP(hipStreamSynchronize(s));
+    return TAC_OK;
+}
+
+int tac_apply_filterbank_adjoint_f32(const float* grad_mel, int64_t rows_times_frames, int32_t n_mels, const void* table,
+                                     int32_t n_freqs, float* grad_spec, void* stream) {
+    using namespace tac;
+    if (rows_times_frames == 0) return TAC_OK;
+    if (!grad_mel || !table || !grad_spec || rows_times_frames < 0 || n_mels <= 0 || n_freqs <= 0) return TAC_E_INVALID;
+    if (n_mels > 512) return TAC_E_UNSUPPORTED;
+    const size_t lds_bytes = (size_t)n_freqs * sizeof(AdjEntry) + (size_t)ADJ_WAVES * n_mels * sizeof(float);
+    if (lds_bytes > 64 * 1024) return TAC_E_UNSUPPORTED;
+    long long blocks = (rows_times_frames + ADJ_WAVES - 1) / ADJ_WAVES;
+    const long long cap = (long long)device_cu_count() * 4;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(fb_adjoint_kernel, dim3((unsigned)blocks), dim3(ADJ_WAVES * 64), lds_bytes, (hipStream_t)stream,
+                       grad_mel, (long long)rows_times_frames, (int)n_mels, static_cast<const AdjEntry*>(table), (int)n_freqs,
+                       grad_spec);
+    TAC_HIP(hipGetLastError());
+    return TAC_OK;
 }
 
 int64_t tac_spectrogram_backward_ola_workspace(const tac_stft_desc* d) {
