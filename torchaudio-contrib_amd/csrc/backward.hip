@@ -8,8 +8,15 @@
 //   tac_overlap_add_f32          frame gradients -> g_wave[rows][L]: the adjoint of framing + padding as a GATHER
 //                                (every output sample sums the <= 3 padded positions that map to it over the frames
 //                                covering them), so it is deterministic and needs no atomics.
+//   tac_stft_norm_backward_f32 / tac_spectrogram_backward_f32   the same kernel forming the gradient spectrum on load —
+//                                from the spectrum and the gradient of |z|^p, or with the spectrum itself recomputed
+//                                from the waveform inside the kernel (nothing but 4·F bytes of gradient read per frame).
+//   tac_spectrogram_backward_ola_f32   fft_length 2048, hop = 128·H: that kernel with the overlap-add in an LDS ring
+//                                over segments of consecutive frames + ola_fold_kernel (unpadding, segment borders):
+//                                the whole adjoint of Spectrogram with no per-frame data in memory.
 //   tac_complex_norm_backward_f32, tac_amplitude_to_db_backward_f32   elementwise.
-// The filterbank stage's adjoint is the forward GEMM with the transposed matrix (tac_apply_filterbank_f32).
+//   tac_apply_filterbank_adjoint_f32   the filterbank stage's adjoint for banks with <= 2 non-zero weights per bin (mel
+//                                banks); other banks: the forward GEMM with the transposed matrix (tac_apply_filterbank_f32).
 #include "host_common.hpp"
 
 #include <algorithm>
