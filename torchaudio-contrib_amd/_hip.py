@@ -579,10 +579,11 @@ def _adjoint_table(fb):
     n_freqs, n_mels = fb.shape
     table = None
     if n_mels <= 512 and 16 * n_freqs + 4 * 4 * n_mels <= 64 * 1024:
+        src = fb if fb.is_contiguous() else fb.contiguous()         # (the cache stays on the caller's tensor object)
         table = torch.empty(4 * n_freqs + 4, dtype=torch.float32, device=fb.device)
         nnz = ctypes.c_int32(0)
         with _native.on_device(fb.device):
-            rc = _native.lib().tac_filterbank_adjoint_pack(_native.ptr(fb), n_freqs, n_mels, _native.ptr(table),
+            rc = _native.lib().tac_filterbank_adjoint_pack(_native.ptr(src), n_freqs, n_mels, _native.ptr(table),
                                                            ctypes.cast(ctypes.pointer(nnz), ctypes.c_void_p),
                                                            _native.stream_ptr(fb.device))
         _native.check(rc, 'tac_filterbank_adjoint_pack')
@@ -599,10 +600,9 @@ def apply_filterbank_backward(grad_out, fb):
     """(*, M, T) gradient -> (*, F, T): two multiply-adds per output through the per-bin table of a bank with at most
     two non-zero weights per bin (tac_apply_filterbank_adjoint_f32); any other bank: the forward MFMA GEMM with the
     transposed bank."""
-    fbc = fb if fb.is_contiguous() else fb.contiguous()
-    table = _adjoint_table(fbc) if (grad_out.dim() >= 2 and MEL_PATH != 'mfma') else None
+    table = _adjoint_table(fb) if (grad_out.dim() >= 2 and fb.dim() == 2 and MEL_PATH != 'mfma') else None
     if table is not None:
-        n_freqs, n_mels = fbc.shape
+        n_freqs, n_mels = fb.shape
         gm = grad_out.transpose(-2, -1)                               # physical frame-major (*, T, M)
         gm = gm if gm.is_contiguous() else gm.contiguous()
         if gm.dtype != torch.float32:
