@@ -221,8 +221,9 @@ int tac_mulaw_decode_f32_f32(const float* codes, int64_t n, int32_t n_quantize, 
  *       (wave / d exactly as given to (2)), transformed again in the kernel, and the spectrum values the norm's adjoint
  *       needs are formed from the FFT's exchange area while the inverse's operands are gathered.
  *     tac_spectrogram_backward_ola_f32: the whole adjoint of (2) — tac_spectrogram_backward_f32 + tac_overlap_add_f32 —
- *       for fft_length 2048 with a hop that is a multiple of 128 (TAC_E_UNSUPPORTED otherwise): every wave walks a run of
- *       consecutive frames and keeps their overlap-add in LDS, so no frame gradients exist in memory.  `workspace`
+ *       for fft_length 256 / 512 / 1024 / 2048 with a hop that is a multiple of fft_length / 16 (TAC_E_UNSUPPORTED
+ *       otherwise): every wave walks runs of consecutive frames and keeps their overlap-add in LDS, so no frame gradients
+ *       exist in memory.  `workspace`
  *       (device) must hold tac_spectrogram_backward_ola_workspace(d) bytes (that call returns a negative TAC_E_* code
  *       for geometries the form does not cover); grad_wave[r][j] at grad_wave + r * grad_row_stride + j.
  *     tac_overlap_add_f32: adjoint of framing + padding: grad_wave[r][j] = sum of grad_frames over every (frame, tap)

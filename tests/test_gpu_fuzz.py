@@ -202,13 +202,14 @@ def test_fuzz_gradients(tac):
 
 
 def test_fuzz_gradients_overlap_add_in_lds(tac):
-    """The fft_length 2048 / hop = 128·H backward form (csrc/backward.hip: overlap-add in an LDS ring over segments of
-    consecutive frames, partial sums at segment borders folded afterwards) over every H, pad mode, centring, short windows
-    and signal lengths from one frame to hundreds (one to many segments per row)."""
+    """The hop = (fft_length / 16)·H backward form for fft_length 256 / 512 / 1024 / 2048 (csrc/backward.hip: overlap-add in
+    an LDS ring over segments of consecutive frames, partial sums at segment borders folded afterwards) over every H, pad
+    mode, centring, short windows and signal lengths from one frame to hundreds (one to many segments per row, ragged
+    segment lengths inside a wave for the sizes that carry several frames per wave)."""
     rng = np.random.default_rng(6000 + SEED)
-    n = 2048
-    for case in range(max(12, CASES // 2)):
-        hop = 128 * int(rng.integers(1, 17)) if case % 3 else 512
+    for case in range(max(16, CASES // 2)):
+        n = int(rng.choice([2048, 1024, 512, 256]))
+        hop = (n // 16) * int(rng.integers(1, 17)) if case % 3 else n // 4
         win_length = n if rng.random() < 0.6 else int(rng.integers(n // 4, n + 1))
         center = bool(rng.random() < 0.75)
         pad_mode = str(rng.choice(['reflect', 'constant', 'replicate', 'circular']))
@@ -227,15 +228,16 @@ def test_fuzz_gradients_overlap_add_in_lds(tac):
             want_y = torch_ref.complex_norm(torch_ref.stft(xc, n, hop, **kw), power)
             y = tac.Spectrogram(n, hop, power=power, **kw).cuda()(xg)
         else:
-            want_y = torch_ref.melspectrogram(xc, num_mels=64, sample_rate=16000, n_fft=n, hop=hop, **kw)
-            chain = tac.Melspectrogram(num_mels=64, sample_rate=16000, fft_length=n, hop_length=hop, **kw)
+            mels = min(64, n // 8)
+            want_y = torch_ref.melspectrogram(xc, num_mels=mels, sample_rate=16000, n_fft=n, hop=hop, **kw)
+            chain = tac.Melspectrogram(num_mels=mels, sample_rate=16000, fft_length=n, hop_length=hop, **kw)
             if kind == 'mel_db':
                 floor = 1e-3 * float(want_y.detach().max())
                 ref = max(1.0, 2.0 * floor * floor)
                 want_y = torch_ref.amplitude_to_db(want_y, ref=ref, amin=floor * floor)
                 chain = torch.nn.Sequential(*chain, tac.AmplitudeToDb(ref=ref, amin=floor * floor))
             y = chain.cuda()(xg)
-        tag = ('grad-ola', case, kind, hop, kw, lead, length)
+        tag = ('grad-ola', case, kind, n, hop, kw, lead, length)
         w = signals.uniform(tuple(want_y.shape), seed=9750 + case)
         if kind == 'magnitude':            # |z| is not differentiable at 0: weight only bins that carry signal
             w = w * (want_y.detach().numpy() > 1e-3 * float(want_y.detach().max()))

@@ -270,6 +270,7 @@ struct OlaPlan {
     int seg_frames;       // S: frames per segment (>= (N - hop) / hop, so that a tail never reaches past the next segment)
     int segs_per_row;
     long long pad_len;    // floats per row of gpad (= length + 2·center_pad)
+    int n_fft;
 };
 
 template <bool POW2>
@@ -416,6 +417,127 @@ spectrogram_backward_ola_kernel(FrameGeom g, Tables tb, const float* __restrict_
     }
 }
 
+// The same for fft_length 256 / 512 / 1024, where a wave carries G = 64 / LPF frames side by side: its G lane groups walk G
+// different SEGMENTS (each with its own ring), so nothing in the ring update crosses lane groups; hop is a multiple of
+// 2·LPF = n_fft / 16.  A group whose segment is shorter than its neighbours' idles (recomputes, stores nothing) until the
+// longest is done.  Frame, row and the "last frame of the segment" flag are per lane here, so this form has no
+// one-frame-ahead requests and more predication than the fft_length 2048 kernel above.
+template <int NC, bool POW2>
+__global__ void __launch_bounds__(OLA_WAVES * 64, 2)
+spectrogram_backward_ola_multi_kernel(FrameGeom g, Tables tb, const float* __restrict__ gnorm, float power,
+                                      float* __restrict__ gpad, float* __restrict__ edge, OlaPlan plan) {
+    using F = WaveFft<NC, OLA_E>;
+    constexpr int E = OLA_E, N = 2 * NC, NBINS = NC + 1, G = F::G, LPF = F::LPF;
+    static_assert(G > 1 && radix_at(NC, 0) == E, "several frames per wave, one first-pass butterfly per lane");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sub = lane / LPF, t = lane % LPF;
+    constexpr int WAVE_SLOTS = ((G * F::PADDED + 1) / 2) * 2;
+    cf* const lds = reinterpret_cast<cf*>(smem_raw) + w * WAVE_SLOTS + sub * F::PADDED;
+    cf* const ring = reinterpret_cast<cf*>(smem_raw) + OLA_WAVES * WAVE_SLOTS + (w * G + sub) * NC;   // N floats per stream
+    cf* const win_lds = reinterpret_cast<cf*>(smem_raw) + OLA_WAVES * (WAVE_SLOTS + G * NC);
+    cf* const wk_lds = win_lds + NC;
+    for (int m = threadIdx.x; m < NC; m += OLA_WAVES * 64) win_lds[m] = window_pair(g, m);
+    for (int k = threadIdx.x; k <= NC / 2; k += OLA_WAVES * 64) wk_lds[k] = tb.w_n[k];
+    __syncthreads();
+
+    const int T = (int)g.n_frames, hop = g.hop, H = hop / (2 * LPF), S = plan.seg_frames, spr = plan.segs_per_row;
+    const long long nseg_total = g.rows * (long long)spr;
+    const long long ngroups = (nseg_total + G - 1) / G;
+    const float wscale = 0.5f * g.scale, xscale = 0.5f * g.scale;
+    cf tw[F::NTW];
+    F::load_twiddles(tw, tb.w_nc, t);
+    cf* const ldsv[1] = {lds};
+
+    for (long long gi = (long long)blockIdx.x * OLA_WAVES + w; gi < ngroups; gi += (long long)gridDim.x * OLA_WAVES) {
+        const long long seg = gi * G + sub;
+        const bool seg_ok = seg < nseg_total;
+        const long long segc = seg_ok ? seg : nseg_total - 1;
+        const int row = (int)(segc / spr), sidx = (int)(segc - (long long)row * spr);
+        const int f0 = sidx * S, f1 = f0 + S < T ? f0 + S : T;
+        const int len_lane = seg_ok ? f1 - f0 : 0;
+        int len = 0;                                                       // the longest of the wave's segments
+#pragma unroll
+        for (int s2 = 0; s2 < G; ++s2) {
+            const int l2 = __builtin_amdgcn_readlane(len_lane, s2 * LPF);
+            len = l2 > len ? l2 : len;
+        }
+        const bool row_end = (f1 == T);
+        for (int i = 0; i < len; ++i) {
+            const bool live = i < len_lane, last = (i + 1 == len_lane), first = (i == 0);
+            const int f = live ? f0 + i : f0;
+            // the frame's gradient row is requested first: its HBM round trip runs behind the forward transform
+            const float* gn = gnorm + ((long long)row * T + f) * NBINS;
+            float gk[E], gm[E];
+#pragma unroll
+            for (int q = 0; q < E; ++q) {
+                gk[q] = gn[t + q * (NC / E)];
+                gm[q] = gn[NC - t - q * (NC / E)];
+            }
+            // ---- forward transform of the frame
+            cf v[1][E];
+            {
+                int tl = t;
+                asm volatile("" : "+v"(tl));
+                cf win[E];
+#pragma unroll
+                for (int q = 0; q < E; ++q) win[q] = win_lds[tl + q * (NC / E)];
+                load_frame<F, true>(v[0], g, win, lds, row, f, t);
+                F::template run<1>(v, ldsv, tw, t);
+            }
+            // ---- gradient spectrum -> operands of the inverse transform
+            int tg = t;
+            asm volatile("" : "+v"(tg));
+#pragma unroll
+            for (int q = 0; q < E; ++q) {
+                const int k = tg + q * (NC / E);
+                const int kt = k <= NC / 2 ? k : NC - k;
+                const cf wk = wk_lds[kt];
+                const cf wkk = k <= NC / 2 ? wk : mkc(-wk.x, wk.y);
+                cf hk, hm;
+                F::r2c_pair(lds, k, wkk, hk, hm);
+                hk = norm_pow_grad<POW2>(cscale(hk, xscale), gk[q], power);
+                hm = norm_pow_grad<POW2>(cscale(hm, xscale), gm[q], power);
+                if (k == 0) {
+                    hk = mkc(2.0f * hk.x, 0.0f);
+                    hm = mkc(2.0f * hm.x, 0.0f);
+                }
+                const cf sm = mkc(hk.x + hm.x, hm.y - hk.y);
+                const cf d = mkc(hk.x - hm.x, -hk.y - hm.y);
+                const cf wd = mkc(wkk.x * d.x - wkk.y * d.y, wkk.x * d.y + wkk.y * d.x);
+                v[0][q] = mkc(sm.x + wd.y, sm.y - wd.x);
+                asm volatile("" : "+v"(v[0][q]));
+                if ((q & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+            wave_lds_fence();
+            F::template run<1>(v, ldsv, tw, t);
+            // ---- windowed frame gradient into this stream's ring; complete positions out
+            const int rot = (int)(((long long)f * H) & 15);
+            float* const prow = gpad + (long long)row * plan.pad_len + (long long)f * hop;
+            float* const tail = row_end ? prow : edge + ((long long)row * (spr - 1) + sidx) * (N - hop) - hop;
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const int m = t + j * LPF;
+                const cf r = lds[lds_pad(m)];
+                const cf wn = win_lds[m];
+                cf acc = mkc(r.x * wn.x * wscale, -r.y * wn.y * wscale);
+                cf* const slot = ring + ((j + rot) & 15) * LPF + t;
+                if (!(first || j >= 16 - H)) {
+                    const cf old = *slot;
+                    acc = mkc(acc.x + old.x, acc.y + old.y);
+                }
+                if (live) {
+                    if (j < H) *reinterpret_cast<cf*>(prow + 2 * m) = acc;
+                    else if (last) *reinterpret_cast<cf*>(tail + 2 * m) = acc;
+                    else *slot = acc;
+                }
+            }
+            wave_lds_fence();
+        }
+    }
+}
+
 // g_wave[row][j] = sum over the padded positions i with source(i) == j of P[row][i + pad], where
 // P = gpad + (inside a segment's first N - hop positions) the previous segment's edge sums; positions no frame covers are 0.
 __global__ void __launch_bounds__(256)
@@ -423,8 +545,8 @@ ola_fold_kernel(FrameGeom g, const float* __restrict__ gpad, const float* __rest
                 float* __restrict__ gwave, long long gwave_row_stride) {
     const int L = (int)g.length, T = (int)g.n_frames;
     const int pad = g.center_pad, hop = g.hop;
-    const int covered = (T - 1) * hop + OLA_N;             // positions [0, covered) are touched by some frame
-    const int seg_span = plan.seg_frames * hop, open = OLA_N - hop, spr = plan.segs_per_row;
+    const int covered = (T - 1) * hop + plan.n_fft;        // positions [0, covered) are touched by some frame
+    const int seg_span = plan.seg_frames * hop, open = plan.n_fft - hop, spr = plan.segs_per_row;
     // grid: x over the samples of a row, y over rows — no division by L per sample, 32-bit positions.  A thread owns four
     // consecutive samples; where none of them has a padding image or straddles a segment-border zone they move as one
     // 16-byte access (global accesses need dword alignment only).
@@ -659,11 +781,14 @@ fb_adjoint_kernel(const float* __restrict__ gmel, long long n_rows_frames, int n
 
 // segmentation of the LDS overlap-add form; TAC_E_UNSUPPORTED for geometries it does not cover
 static int ola_plan(const tac_stft_desc* d, const FrameGeom& g, OlaPlan* plan) {
-    if (d->n_fft != OLA_N || !d->onesided || d->hop <= 0 || (d->hop & 127) || d->hop > OLA_N) return TAC_E_UNSUPPORTED;
-    if (g.length >= 0x7fffffffLL - 2 * OLA_N || g.n_frames < 1 || g.n_frames >= 0x7fffffffLL / OLA_N) return TAC_E_UNSUPPORTED;
+    const int n = d->n_fft;
+    if (n != 2048 && n != 1024 && n != 512 && n != 256) return TAC_E_UNSUPPORTED;
+    if (!d->onesided || d->hop <= 0 || (d->hop % (n / 16)) || d->hop > n) return TAC_E_UNSUPPORTED;
+    if (g.length >= 0x7fffffffLL - 2 * n || g.n_frames < 1 || g.n_frames >= 0x7fffffffLL / n) return TAC_E_UNSUPPORTED;
     const int T = (int)g.n_frames;
-    const int s_min = std::max(1, (OLA_N - d->hop + d->hop - 1) / d->hop);
-    const long long target = (long long)device_cu_count() * 2 * OLA_WAVES;          // one segment per resident wave
+    const int s_min = std::max(1, (n - d->hop + d->hop - 1) / d->hop);
+    // one segment per resident frame stream (a wave carries 2048 / n_fft of them)
+    const long long target = (long long)device_cu_count() * 2 * OLA_WAVES * (OLA_N / n);
     long long spr = (target + g.rows - 1) / g.rows;
     spr = std::max(1LL, std::min(spr, (long long)std::max(1, T / s_min)));
     int S = (int)((T + spr - 1) / spr);
@@ -671,11 +796,12 @@ static int ola_plan(const tac_stft_desc* d, const FrameGeom& g, OlaPlan* plan) {
     plan->seg_frames = S;
     plan->segs_per_row = (T + S - 1) / S;
     plan->pad_len = g.length + 2LL * g.center_pad;
+    plan->n_fft = n;
     return TAC_OK;
 }
 
 static long long ola_workspace_floats(const FrameGeom& g, const OlaPlan& plan, int hop) {
-    return g.rows * plan.pad_len + g.rows * (long long)(plan.segs_per_row - 1) * (OLA_N - hop);
+    return g.rows * plan.pad_len + g.rows * (long long)(plan.segs_per_row - 1) * (plan.n_fft - hop);
 }
 
 static unsigned bw_blocks(long long n) {
@@ -771,19 +897,53 @@ int tac_spectrogram_backward_ola_f32(const float* wave, const float* window, con
     if (rc != TAC_OK) return rc;
     float* gpad = static_cast<float*>(workspace);
     float* edge = gpad + g.rows * plan.pad_len;
-    using F = WaveFft<OLA_NC, OLA_E>;
-    const size_t lds_bytes = (size_t)OLA_WAVES * ((((F::PADDED + 1) / 2) * 2) + OLA_NC) * sizeof(cf) +
-                             (size_t)(OLA_NC + OLA_NC / 2 + 2) * sizeof(cf);
-    const long long nseg = g.rows * (long long)plan.segs_per_row;
-    long long blocks = (nseg + OLA_WAVES - 1) / OLA_WAVES;
-    const long long cap = (long long)device_cu_count() * 2;
-    if (blocks > cap) blocks = cap;
-    auto kern = power == 2.0f ? spectrogram_backward_ola_kernel<true> : spectrogram_backward_ola_kernel<false>;
-    TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds_bytes));
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(OLA_WAVES * 64), lds_bytes, s, g, tb, grad_norm, power, gpad, edge,
-                       plan);
-    TAC_HIP(hipGetLastError());
+    const bool pow2 = (power == 2.0f);
+    auto launch = [&](auto kern, size_t lds_bytes, int streams_per_wave) -> int {
+        const long long nwork = (g.rows * (long long)plan.segs_per_row + streams_per_wave - 1) / streams_per_wave;
+        long long blocks = (nwork + OLA_WAVES - 1) / OLA_WAVES;
+        const long long cap = (long long)device_cu_count() * 2;
+        if (blocks > cap) blocks = cap;
+        TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds_bytes));
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(OLA_WAVES * 64), lds_bytes, s, g, tb, grad_norm, power, gpad,
+                           edge, plan);
+        TAC_HIP(hipGetLastError());
+        return TAC_OK;
+    };
+    // LDS: per wave the exchange area(s) of its frame(s) + N floats of ring per frame stream (8 KB either way), then the
+    // window pairs and the R2C twiddles
+    auto lds_for = [](int nc, int padded, int gframes) {
+        return (size_t)OLA_WAVES * ((size_t)(((gframes * padded + 1) / 2) * 2) + (size_t)gframes * nc) * sizeof(cf) +
+               (size_t)(nc + nc / 2 + 2) * sizeof(cf);
+    };
+    switch (d->n_fft) {
+        case 2048: {
+            using F = WaveFft<OLA_NC, OLA_E>;
+            rc = pow2 ? launch(spectrogram_backward_ola_kernel<true>, lds_for(OLA_NC, F::PADDED, 1), 1)
+                      : launch(spectrogram_backward_ola_kernel<false>, lds_for(OLA_NC, F::PADDED, 1), 1);
+            break;
+        }
+        case 1024: {
+            using F = WaveFft<512, OLA_E>;
+            rc = pow2 ? launch(spectrogram_backward_ola_multi_kernel<512, true>, lds_for(512, F::PADDED, F::G), F::G)
+                      : launch(spectrogram_backward_ola_multi_kernel<512, false>, lds_for(512, F::PADDED, F::G), F::G);
+            break;
+        }
+        case 512: {
+            using F = WaveFft<256, OLA_E>;
+            rc = pow2 ? launch(spectrogram_backward_ola_multi_kernel<256, true>, lds_for(256, F::PADDED, F::G), F::G)
+                      : launch(spectrogram_backward_ola_multi_kernel<256, false>, lds_for(256, F::PADDED, F::G), F::G);
+            break;
+        }
+        case 256: {
+            using F = WaveFft<128, OLA_E>;
+            rc = pow2 ? launch(spectrogram_backward_ola_multi_kernel<128, true>, lds_for(128, F::PADDED, F::G), F::G)
+                      : launch(spectrogram_backward_ola_multi_kernel<128, false>, lds_for(128, F::PADDED, F::G), F::G);
+            break;
+        }
+        default: return TAC_E_UNSUPPORTED;
+    }
+    if (rc != TAC_OK) return rc;
     // ~16 workgroups per CU in flight, each thread walking its row with a stride: rows on y, a row's samples on x
     const unsigned fold_y = (unsigned)std::min<long long>(g.rows, 65535);
     const long long per_row = std::max<long long>(1, (long long)device_cu_count() * 16 / fold_y);
