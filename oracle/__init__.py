@@ -16,6 +16,6 @@ Two independent restatements of the reference algorithm live here:
   used to cross-check ``torch_ref`` and the HIP kernels.
 
 Pinning: both are checked against golden vectors captured from the *unmodified*
-reference imported from ``/root/reference`` (``tools/make_golden.py``, fixtures in
+reference imported from ``/root/reference`` (``tests/golden/make_golden.py``, fixtures in
 ``tests/golden/``) by ``tests/test_oracle_golden.py``.
 """

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Generate tests/golden/*.npz from the UNMODIFIED reference (this container only).
 
-    PYTHONPATH=/root/reference python tools/make_golden.py [--skip-scan]
+    PYTHONPATH=/root/reference python tests/golden/make_golden.py [--skip-scan]
 
 The reference calls ``torch.stft`` without ``return_complex`` (functional.py:99-107), which
 torch>=2 rejects; the shim below (installed in THIS process only, reference untouched)
@@ -18,7 +18,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 GOLD = os.path.join(ROOT, 'tests', 'golden')
 

@@ -3,7 +3,7 @@
 The reference's test-suite is CPU-only (reference tests/test_layers.py:1-3) and BASELINE configs[0] is a CPU
 configuration, so "call sites drop in unchanged" includes CPU tensors and float64.  Each test restates one of the
 reference's librosa-free checks (cited) and pins the values to the golden vectors captured from the unmodified
-reference (tools/make_golden.py): on a CPU tensor the ``tac_amd::*`` ops dispatch to the package's stock-torch
+reference (tests/golden/make_golden.py): on a CPU tensor the ``tac_amd::*`` ops dispatch to the package's stock-torch
 kernels (``_composite.py``), which keep the reference's operator order — so the agreement is to float rounding.
 The same call sites on a HIP device are the subject of tests/test_gpu_parity.py.
 """

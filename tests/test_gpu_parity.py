@@ -686,7 +686,7 @@ def test_mulaw_thresholds_edges(tac, golden):
     g = golden('g5_mulaw')
     pos = g['thr256_pos_bits'].astype(np.uint32)
     neg = g['thr256_neg_bits'].astype(np.uint32)
-    # exactly at, and one ulp below, every threshold; plus +-0, +-1 (same vector as tools/make_golden.py)
+    # exactly at, and one ulp below, every threshold; plus +-0, +-1 (same vector as tests/golden/make_golden.py)
     mags = np.concatenate([pos, pos - 1, neg, neg - 1, [0, 0x3f800000]]).astype(np.uint32)
     xs = np.concatenate([mags.view(np.float32), -(mags.view(np.float32))])
     got = host(tac.mu_law_encoding(dev(xs), 256))

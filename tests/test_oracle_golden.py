@@ -1,5 +1,5 @@
 """not-gpu: pin the CPU oracle against the golden vectors captured from the unmodified reference
-(tools/make_golden.py).  If these fail the oracle may not be used to judge the HIP path."""
+(tests/golden/make_golden.py).  If these fail the oracle may not be used to judge the HIP path."""
 import numpy as np
 import pytest
 import torch
