@@ -41,8 +41,15 @@ __device__ __forceinline__ cf norm_pow_grad(cf v, float gout, float power) {
     else if (s == 0.0f) f = 0.0f;
     else if (power == 1.0f) f = 1.0f / sqrtf(s);
     else f = norm_pow_factor_general(s, power);
-    f *= gout;
-    return mkc(f * v.x, f * v.y);
+    return cscale(v, f * gout);
+}
+
+// Operand of the inverse transform from a pair of the gradient spectrum:  conj(Z[k]) = (conj H[k] + H[NC-k]) - i w_k (conj H[k]
+// - H[NC-k]), on the packed-f32 helpers of fft_core.hpp (5 instructions; written out on scalar components it was 14)
+__device__ __forceinline__ cf c2r_operand(cf hk, cf hm, cf wk) {
+    const cf s = cadd_conj(hm, hk);               // H[NC-k] + conj H[k]
+    const cf nd = csub_conj(hm, hk);              // H[NC-k] - conj H[k]
+    return csub_rot(s, cmul(nd, wk));             // s + i w (H[NC-k] - conj H[k])
 }
 
 // SRC_NORM: `gspec` is the spectrum z itself and `gnorm` the gradient of |z|^power: the gradient spectrum
@@ -207,15 +214,14 @@ stft_backward_kernel(FrameGeom g, Tables tb, const float* __restrict__ gspec, co
                     hk = norm_pow_grad<POW2>(hk, GN[k], power);
                     hm = norm_pow_grad<POW2>(hm, GN[NC - k], power);
                 }
-                if (k == 0) {
-                    hk = mkc(2.0f * hk.x, 0.0f);
-                    hm = mkc(2.0f * hm.x, 0.0f);
+                if (b == 0 && q == 0) {                                    // (k == 0 can only be the lane's first element)
+                    if (k == 0) {
+                        hk = mkc(2.0f * hk.x, 0.0f);
+                        hm = mkc(2.0f * hm.x, 0.0f);
+                    }
                 }
                 if (!live) hk = hm = mkc(0.0f, 0.0f);
-                const cf s = mkc(hk.x + hm.x, hm.y - hk.y);                 // conj(H[k]) + H[NC-k]
-                const cf d = mkc(hk.x - hm.x, -hk.y - hm.y);                // conj(H[k]) - H[NC-k]
-                const cf wd = mkc(wkk.x * d.x - wkk.y * d.y, wkk.x * d.y + wkk.y * d.x);
-                v[0][b * R0 + q] = mkc(s.x + wd.y, s.y - wd.x);             // s - i * (w d)
+                v[0][b * R0 + q] = c2r_operand(hk, hm, wkk);
                 // (eight pairs' exchange-area reads in flight at a time: all sixteen at once no longer fit the registers; the
                 // empty asm pins each operand's arithmetic here — LLVM's IR passes otherwise sink it below the barrier)
                 if constexpr (SRC == SRC_WAVE) {
@@ -374,14 +380,13 @@ spectrogram_backward_ola_kernel(FrameGeom g, Tables tb, const float* __restrict_
             F::r2c_pair(lds, k, wkk, hk, hm);
             hk = norm_pow_grad<POW2>(cscale(hk, xscale), gk[q], power);
             hm = norm_pow_grad<POW2>(cscale(hm, xscale), gm[q], power);
-            if (k == 0) {
-                hk = mkc(2.0f * hk.x, 0.0f);
-                hm = mkc(2.0f * hm.x, 0.0f);
+            if (q == 0) {
+                if (k == 0) {
+                    hk = mkc(2.0f * hk.x, 0.0f);
+                    hm = mkc(2.0f * hm.x, 0.0f);
+                }
             }
-            const cf sm = mkc(hk.x + hm.x, hm.y - hk.y);
-            const cf d = mkc(hk.x - hm.x, -hk.y - hm.y);
-            const cf wd = mkc(wkk.x * d.x - wkk.y * d.y, wkk.x * d.y + wkk.y * d.x);
-            v[0][q] = mkc(sm.x + wd.y, sm.y - wd.x);
+            v[0][q] = c2r_operand(hk, hm, wkk);
             asm volatile("" : "+v"(v[0][q]));
             if ((q & 7) == 7) __builtin_amdgcn_sched_barrier(0);
         }
@@ -401,11 +406,11 @@ spectrogram_backward_ola_kernel(FrameGeom g, Tables tb, const float* __restrict_
             const int m = t + j * 64;                                       // samples n = 2m, 2m + 1 of the frame
             const cf r = lds[lds_pad(m)];
             const cf wn = win_lds[m];
-            cf acc = mkc(r.x * wn.x * wscale, -r.y * wn.y * wscale);
+            cf acc = cmul_elem(cmul_elem(r, wn), mkc(wscale, -wscale));     // (Re, -Im) R[m] · window / 2
             cf* const slot = ring + (((j + rot) & 15) << 6) + t;
             if (!(first || j >= 16 - H)) {
                 const cf old = *slot;
-                acc = mkc(acc.x + old.x, acc.y + old.y);
+                acc = cadd(acc, old);
             }
             if (j < H) *reinterpret_cast<cf*>(prow + 2 * m) = acc;          // complete
             else if (last) *reinterpret_cast<cf*>(tail + 2 * m) = acc;      // the segment's open positions
@@ -499,14 +504,13 @@ spectrogram_backward_ola_multi_kernel(FrameGeom g, Tables tb, const float* __res
                 F::r2c_pair(lds, k, wkk, hk, hm);
                 hk = norm_pow_grad<POW2>(cscale(hk, xscale), gk[q], power);
                 hm = norm_pow_grad<POW2>(cscale(hm, xscale), gm[q], power);
-                if (k == 0) {
-                    hk = mkc(2.0f * hk.x, 0.0f);
-                    hm = mkc(2.0f * hm.x, 0.0f);
+                if (q == 0) {
+                    if (k == 0) {
+                        hk = mkc(2.0f * hk.x, 0.0f);
+                        hm = mkc(2.0f * hm.x, 0.0f);
+                    }
                 }
-                const cf sm = mkc(hk.x + hm.x, hm.y - hk.y);
-                const cf d = mkc(hk.x - hm.x, -hk.y - hm.y);
-                const cf wd = mkc(wkk.x * d.x - wkk.y * d.y, wkk.x * d.y + wkk.y * d.x);
-                v[0][q] = mkc(sm.x + wd.y, sm.y - wd.x);
+                v[0][q] = c2r_operand(hk, hm, wkk);
                 asm volatile("" : "+v"(v[0][q]));
                 if ((q & 7) == 7) __builtin_amdgcn_sched_barrier(0);
             }
@@ -521,11 +525,11 @@ spectrogram_backward_ola_multi_kernel(FrameGeom g, Tables tb, const float* __res
                 const int m = t + j * LPF;
                 const cf r = lds[lds_pad(m)];
                 const cf wn = win_lds[m];
-                cf acc = mkc(r.x * wn.x * wscale, -r.y * wn.y * wscale);
+                cf acc = cmul_elem(cmul_elem(r, wn), mkc(wscale, -wscale));     // (Re, -Im) R[m] · window / 2
                 cf* const slot = ring + ((j + rot) & 15) * LPF + t;
                 if (!(first || j >= 16 - H)) {
                     const cf old = *slot;
-                    acc = mkc(acc.x + old.x, acc.y + old.y);
+                    acc = cadd(acc, old);
                 }
                 if (live) {
                     if (j < H) *reinterpret_cast<cf*>(prow + 2 * m) = acc;
