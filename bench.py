@@ -27,6 +27,12 @@ BATCH, CHANNELS, SECONDS = 256, 1, 10
 LENGTH = SR * SECONDS
 FRAMES = 1 + LENGTH // HOP                         # 313
 HBM_PEAK_GBS = 8000.0                              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# BASELINE configs[2] per rank: 2048 x 1ch x 44.1 kHz x 30 s batch-sharded over 8 GPUs = 256 rows of 1 323 000 samples
+CFG3_SR, CFG3_LENGTH = 44100, 44100 * 30
+# The timed steps walk over NBUF distinct device-resident input batches (NBUF x 163.8 MB = 655 MB > the 256 MiB
+# Infinity Cache), so a step's samples cannot have stayed on-die from the step before: the headline and the stage
+# figures are HBM numbers.  The same loop over ONE batch (which fits the Infinity Cache) is reported beside them.
+NBUF = 4
 
 
 def parse():
@@ -36,6 +42,11 @@ def parse():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-stages', action='store_true')
+    ap.add_argument('--config', choices=('cfg2', 'cfg3'), default='cfg2',
+                    help='cfg2 (default): BASELINE configs[1], 256 x 16 kHz x 10 s per GPU — the configuration the metric '
+                         'is quoted on, at every N (weak scaling).  cfg3: configs[2]\'s per-GPU shard, 256 x 44.1 kHz x '
+                         '30 s, as the headline.  With --gpus > 1 and cfg2 the cfg-3 shard is measured as an extra '
+                         '"cfg3" object (compute only and with its 338.7 MB/rank all-gather).')
     ap.add_argument('--dry-run-cpu', action='store_true',
                     help='control-flow check without a GPU: gloo backend, CPU tensors, a tiny batch (tests/ use it to '
                          'cover the --gpus N spawn / reduce / JSON path); the printed line is marked invalid')
@@ -127,6 +138,26 @@ def main():
     run(a)
 
 
+def spin(fn, seconds):
+    """bring the GPU out of its idle clocks (not timed, fixed wall budget)"""
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < seconds:
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+
+
+def rotating(make, xs):
+    """fn() that runs make(x) on the next buffer of xs each call"""
+    state = [0]
+
+    def fn():
+        i = state[0]
+        state[0] = (i + 1) % len(xs)
+        return make(xs[i])
+    return fn
+
+
 def run(a):
     global BATCH, LENGTH, FRAMES
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -152,17 +183,28 @@ def run(a):
     import torchaudio_contrib_amd as tac
     tac._native.lib()                                   # fail loudly without the HIP library
 
-    gen = torch.Generator(device=dev).manual_seed(rank)
-    x_host = torch.rand(BATCH, CHANNELS, LENGTH, generator=torch.Generator().manual_seed(rank)) * 2 - 1
-    x = x_host.to(dev)                          # generated once on the host: the CPU baseline times the same tensor
-    if rank != 0 or a.no_cpu_baseline:
-        x_host = None
-    model = torch.nn.Sequential(
-        *tac.Melspectrogram(num_mels=N_MELS, sample_rate=SR, fft_length=N_FFT, hop_length=HOP),
-        tac.AmplitudeToDb()).to(dev)
+    sr, length, seconds, label = SR, LENGTH, SECONDS, 'BASELINE configs[1]'
+    if a.config == 'cfg3':
+        sr, length, seconds, label = CFG3_SR, CFG3_LENGTH, 30, 'BASELINE configs[2], one GPU\'s shard'
+    frames = 1 + length // HOP
+    nbuf = NBUF if a.config == 'cfg2' else 1            # (one cfg-3 shard is 1.35 GB: far beyond the Infinity Cache)
 
-    def step():
-        return model(x)                        # the reference's call site, nothing else (returns an ordinary tensor)
+    gen = torch.Generator(device=dev).manual_seed(rank)
+    x_host = torch.rand(BATCH, CHANNELS, length, generator=torch.Generator().manual_seed(rank)) * 2 - 1
+    xs = [x_host.to(dev)]                       # generated once on the host: the CPU baseline times the same tensor
+    for _ in range(1, nbuf):
+        xs.append(torch.rand(BATCH, CHANNELS, length, device=dev, generator=gen) * 2 - 1)
+    x = xs[0]
+    if rank != 0 or a.no_cpu_baseline or a.config != 'cfg2':
+        x_host = None
+
+    def pipeline(rate):
+        return torch.nn.Sequential(
+            *tac.Melspectrogram(num_mels=N_MELS, sample_rate=rate, fft_length=N_FFT, hop_length=HOP),
+            tac.AmplitudeToDb()).to(dev)
+
+    model = pipeline(sr)
+    step = rotating(model, xs)                 # the reference's call site, nothing else (returns an ordinary tensor)
 
     def sync():
         torch.cuda.synchronize()
@@ -170,47 +212,48 @@ def run(a):
             dist.barrier()
             torch.cuda.synchronize()
 
-    # bring the GPU out of its idle clocks before the contract's W warm-up steps (not timed, fixed wall budget)
-    t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < 0.5:
-        for _ in range(20):
-            step()
-        torch.cuda.synchronize()
+    def timed(fn, steps):
+        """(wall seconds of `steps` calls between barriers — max over ranks —, HIP-event ms per call, last result):
+        HIP events on the launch stream bracket the same region: a step is ONE kernel launch and the launches are back
+        to back, so region time / K is that kernel's average launch duration over the timed region"""
+        sync()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(steps):
+            y = fn()
+        ev1.record()
+        sync()
+        elapsed = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, ev0.elapsed_time(ev1) / steps, y
+
+    spin(step, 0.5)
     for _ in range(a.warmup):
         y = step()
-    sync()
-    # HIP events on the launch stream bracket the timed region as well: a step is ONE kernel launch and the launches are
-    # back to back, so (region time / K) is that kernel's average launch duration over the timed region
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(a.steps):
-        y = step()
-    ev1.record()
-    sync()
-    elapsed = time.perf_counter() - t0
-    region_ms = ev0.elapsed_time(ev1) / a.steps
-    assert type(y) is torch.Tensor and tuple(y.shape) == (BATCH, CHANNELS, N_MELS, FRAMES)
-    if distributed:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    frames_per_step = world * BATCH * CHANNELS * FRAMES
+    elapsed, region_ms, y = timed(step, a.steps)
+    assert type(y) is torch.Tensor and tuple(y.shape) == (BATCH, CHANNELS, N_MELS, frames)
+    frames_per_step = world * BATCH * CHANNELS * frames
     value = frames_per_step * a.steps / elapsed
 
     # ---- roofline of the dominant kernel (the fused melspec kernel is the only launch in a step)
     per_launch_mean_ms, med_ms = event_ms(step, min(a.steps, 50))      # (event pairs around single launches: + ~3 us each)
     mean_ms = region_ms
-    alg_bytes = BATCH * CHANNELS * FRAMES * (4 * HOP + 4 * N_MELS)      # 2560 B/frame
+    alg_bytes = BATCH * CHANNELS * frames * (4 * HOP + 4 * N_MELS)      # SURVEY §8(d): 2560 B/frame
     achieved = alg_bytes / (mean_ms * 1e-3) / 1e9
     result = {
         'metric': 'mel frames/sec', 'value': value, 'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps,
         'warmup': a.warmup, 'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'Melspectrogram+AmplitudeToDb batch=%d/GPU x %dch x %dHz x %ds, fft_len=%d hop=%d '
-                               '%d mel (BASELINE configs[1])' % (BATCH, CHANNELS, SR, SECONDS, N_FFT, HOP, N_MELS),
+                               '%d mel (%s)' % (BATCH, CHANNELS, sr, seconds, N_FFT, HOP, N_MELS, label),
                    'global_batch': world * BATCH, 'frames_per_step': frames_per_step,
-                   'parallelism': 'batch-sharded x%d, no data-path collective' % world},
+                   'parallelism': 'batch-sharded x%d, no data-path collective' % world,
+                   'input_buffers': '%d distinct device-resident batches of %.1f MB visited round-robin (%.0f MB > the '
+                                    '256 MiB Infinity Cache)' % (nbuf, x.numel() * 4 / 1e6, nbuf * x.numel() * 4 / 1e6)},
         'roofline': {'kernel': 'melspec_stream_kernel<1024,16,pow2,fullM> (fused STFT + power + band-sparse mel + dB, one launch per step)', 'bound': 'hbm',
                      'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                      'traffic': None, 'alg_bytes_per_launch': alg_bytes, 'kernel_ms_mean': mean_ms,
@@ -218,11 +261,19 @@ def run(a):
                      'timing': 'one HIP event pair on the launch stream around the K timed steps (one launch per step) / K; '
                                'kernel_ms_per_launch_events / kernel_ms_median: event pairs around single launches'},
     }
+    if nbuf > 1:
+        # the same loop re-reading ONE batch (163.8 MB: it fits the Infinity Cache) — what rounds 1 and 2 reported
+        one = lambda: model(x)
+        spin(one, 0.2)
+        e1, ms1, _ = timed(one, a.steps)
+        result['single_buffer'] = {'value': frames_per_step * a.steps / e1, 'ms_per_step': e1 / a.steps * 1e3,
+                                   'kernel_ms_mean': ms1,
+                                   'note': 'same steps on one re-read input batch (Infinity-Cache resident)'}
 
     # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in
     # separate passes, gfx950 x2 FETCH correction applied — tools/summarize_profiles.py); bench.py cannot run the
     # profiler on itself, so the field is filled from that artefact when it is present.
-    for rnd in ('r02', 'r01'):
+    for rnd in ('r03', 'r02', 'r01'):
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', rnd, 'pmc_mel.json')))
         except Exception:
@@ -236,59 +287,70 @@ def run(a):
         if result['roofline']['traffic'] is not None:
             break
 
-    if rank == 0 and not a.no_stages:
-        # secondary stages named by north_star, each one kernel: complex STFT and power spectrogram
+    if rank == 0 and not a.no_stages and a.config == 'cfg2':
+        # secondary stages named by north_star, each one kernel: complex STFT and power spectrogram — on the rotating
+        # batches, and on one re-read batch beside it
         spec = tac.Spectrogram(N_FFT, HOP, power=2.).to(dev)
         f_bins = N_FFT // 2 + 1
         stages = {}
-        for name, fn, per_frame in (('stft_complex', lambda: tac.stft(x, N_FFT, HOP), 4 * HOP + 8 * f_bins),
-                                    ('spectrogram_power', lambda: spec(x), 4 * HOP + 4 * f_bins)):
-            t_w = time.perf_counter()
-            while time.perf_counter() - t_w < 0.3:           # same spin-up as the headline loop (clocks, TLB, allocator)
-                for _ in range(10):
-                    fn()
-                torch.cuda.synchronize()
+        for name, make, per_frame in (('stft_complex', lambda t: tac.stft(t, N_FFT, HOP), 4 * HOP + 8 * f_bins),
+                                      ('spectrogram_power', spec, 4 * HOP + 4 * f_bins)):
+            fn = rotating(make, xs)
+            spin(fn, 0.3)                                    # same spin-up as the headline loop (clocks, TLB, allocator)
             ms, med = event_ms(fn, 50)
-            gbs = BATCH * CHANNELS * FRAMES * per_frame / (ms * 1e-3) / 1e9
+            ms1, _ = event_ms(lambda: make(x), 50)
+            gbs = BATCH * CHANNELS * frames * per_frame / (ms * 1e-3) / 1e9
             stages[name] = {'kernel_ms_mean': ms, 'kernel_ms_median': med, 'alg_bytes_per_frame': per_frame,
-                            'achieved_GBs': gbs, 'frac_of_hbm_peak': gbs / HBM_PEAK_GBS}
+                            'achieved_GBs': gbs, 'frac_of_hbm_peak': gbs / HBM_PEAK_GBS,
+                            'single_buffer_kernel_ms_mean': ms1}
         # the filterbank stage as a dense fp32 MFMA GEMM (a random 1025 x 128 bank is not band-sparse, so
         # apply_filterbank takes the GEMM kernel): executed flops = 2*F*M per frame against the 157.3 TFLOP/s f32 MFMA peak
         fb_dense = torch.rand(f_bins, N_MELS, device=dev, generator=gen)
         p_spec = spec(x)
         fn = lambda: tac.apply_filterbank(p_spec, fb_dense)
-        t_w = time.perf_counter()
-        while time.perf_counter() - t_w < 0.3:
-            for _ in range(10):
-                fn()
-            torch.cuda.synchronize()
+        spin(fn, 0.3)
         ms, med = event_ms(fn, 50)
-        flops = 2.0 * f_bins * N_MELS * BATCH * CHANNELS * FRAMES
+        flops = 2.0 * f_bins * N_MELS * BATCH * CHANNELS * frames
         stages['filterbank_mfma_dense'] = {'kernel_ms_mean': ms, 'kernel_ms_median': med, 'flops': flops,
                                            'achieved_TFLOPs': flops / (ms * 1e-3) / 1e12,
                                            'frac_of_f32_mfma_peak': flops / (ms * 1e-3) / 1e12 / 157.3}
+        del p_spec
         result['stages'] = stages
 
-    if distributed:
-        # optional whole-batch output: one RCCL all-gather of the (B/N, C, M, T) shards
-        def step_gather():
-            return tac.distributed.all_gather_batch(model(x), total_rows=world * BATCH)
+    def gather_leg(mdl, inputs, rows_total, frames_step, steps):
+        """compute + ONE RCCL all-gather of the (B/N, C, M, T) output shards"""
+        fn = rotating(lambda t: tac.distributed.all_gather_batch(mdl(t), total_rows=rows_total), inputs)
         try:        # a secondary figure: a failure here must not cost the headline line above
             for _ in range(3):
-                step_gather()
-            sync()
-            t0 = time.perf_counter()
-            for _ in range(a.steps):
-                step_gather()
-            sync()
-            tg = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
-            result['with_allgather'] = {'value': frames_per_step * a.steps / float(tg.item()), 'unit': 'frames/s',
-                                        'ms_per_step': float(tg.item()) / a.steps * 1e3}
+                fn()
+            eg, _, _ = timed(fn, steps)
+            return {'value': frames_step * steps / eg, 'unit': 'frames/s', 'ms_per_step': eg / steps * 1e3}
         except Exception as exc:            # noqa: BLE001 — reported in the line, not swallowed
-            result['with_allgather'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
+            return {'error': '%s: %s' % (type(exc).__name__, exc)}
 
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if distributed:
+        result['with_allgather'] = gather_leg(model, xs, world * BATCH, frames_per_step, a.steps)
+        if a.config == 'cfg2':
+            # BASELINE configs[2]: every rank's 256 x 1 323 000 shard (sr 44 100), compute only and with the one
+            # all-gather SURVEY §8e says dominates there (338.7 MB per rank)
+            del xs[1:]
+            try:
+                x3 = [torch.rand(BATCH, CHANNELS, CFG3_LENGTH, device=dev, generator=gen) * 2 - 1]
+                m3 = pipeline(CFG3_SR)
+                f3 = world * BATCH * CHANNELS * (1 + CFG3_LENGTH // HOP)
+                k3 = max(5, a.steps // 5)
+                s3 = rotating(m3, x3)
+                spin(s3, 0.2)
+                e3, ms3, _ = timed(s3, k3)
+                result['cfg3'] = {'workload': 'batch=%d/GPU x 1ch x %dHz x 30s (BASELINE configs[2] sharded over %d GPUs)'
+                                              % (BATCH, CFG3_SR, world), 'steps': k3,
+                                  'value': f3 * k3 / e3, 'unit': 'frames/s', 'ms_per_step': e3 / k3 * 1e3,
+                                  'kernel_ms_mean': ms3,
+                                  'with_allgather': gather_leg(m3, x3, world * BATCH, f3, k3)}
+            except Exception as exc:        # noqa: BLE001
+                result['cfg3'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
+
+    if rank == 0 and world == 1 and x_host is not None:
         result['cpu_baseline'] = cpu_baseline(x_host)
     if rank == 0:
         print(json.dumps(result))

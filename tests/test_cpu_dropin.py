@@ -229,3 +229,68 @@ def test_coded_waveforms_on_cpu(tac, golden):
     mel = tac.Melspectrogram(num_mels=32, sample_rate=16000, fft_length=512, hop_length=128)
     assert torch.equal(mel(pcm), mel(pcm.float() * (1.0 / 32768.0)))
     assert tac.stft(pcm, 256).dtype == torch.float32
+
+
+def test_double_backward_matches_the_reference_chain(tac):
+    """The reference is stock torch operators, hence twice differentiable (a gradient penalty on d out / d waveform):
+    ``create_graph=True`` through the tac_amd ops must give a gradient that is itself differentiable, with the values
+    of the same chain written directly with torch operators (oracle/torch_ref.py)."""
+    from oracle import torch_ref
+    x = torch.randn(2, 1, 3000, dtype=torch.float64)
+
+    def penalty(chain, t):
+        t = t.clone().requires_grad_(True)
+        (g,) = torch.autograd.grad(chain(t).sum(), t, create_graph=True)
+        assert g.requires_grad
+        (g ** 2).sum().backward()
+        return g.detach(), t.grad
+
+    fb = tac.create_mel_filter(129, 12, 0.0, 4000.0, False).double()
+    win = torch.hann_window(256, dtype=torch.float64)
+    g1, h1 = penalty(lambda t: tac.amplitude_to_db(tac.apply_filterbank(tac.complex_norm(tac.stft(t, 256, 64, window=win), 2.0), fb), 1.0, 1e-4), x)
+    g2, h2 = penalty(lambda t: torch_ref.amplitude_to_db(torch_ref.apply_filterbank(
+        torch_ref.complex_norm(torch_ref.stft(t, 256, 64, window=win), 2.0), fb), 1.0, 1e-4), x)
+    assert rel_err(g1.numpy(), g2.numpy()) <= 1e-9 and rel_err(h1.numpy(), h2.numpy()) <= 1e-9
+    assert float(h1.abs().max()) > 0
+    # through the fused op of the factory pipeline as well
+    mel = tac.Melspectrogram(num_mels=12, sample_rate=8000, fft_length=256, hop_length=64).double()
+    g3, h3 = penalty(mel, x)
+    g4, h4 = penalty(lambda t: torch_ref.apply_filterbank(torch_ref.complex_norm(torch_ref.stft(t, 256, 64, window=mel[0].window), 2.0), fb), x)
+    assert rel_err(g3.numpy(), g4.numpy()) <= 1e-9 and rel_err(h3.numpy(), h4.numpy()) <= 1e-9
+
+
+def test_default_window_survives_inference_mode(tac):
+    """A default Hann window first built inside ``torch.inference_mode()`` must not poison a later training call
+    ('Inference tensors cannot be saved for backward')."""
+    from torchaudio_contrib_amd import functional as TF
+    TF._window_cache.clear()
+    x = torch.randn(1, 1, 2000)
+    with torch.inference_mode():
+        tac.stft(x, 200)
+    y = tac.complex_norm(tac.stft(x.clone().requires_grad_(True), 200), 2.0)
+    y.sum().backward()
+
+
+def test_hpss_even_kernel_takes_the_first_n_windows(tac):
+    """beta_hpss.py:84-91 with an even width: n + 1 windows fit the n + 2 (k // 2) padded positions and the reference's
+    loops use the first n of them."""
+    from oracle import torch_ref
+    mag = torch.rand(2, 1, 20, 17)
+    for k in (4, 6):
+        got = tac.hpss(mag, k, 2.0, False)
+        want = torch_ref.hpss(mag, k, 2.0, False)
+        for a, b in zip(got, want):
+            assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+
+
+def test_phase_vocoder_wants_the_reference_shape_of_phase_advance(tac):
+    """functional.py:204-274 broadcasts ``phase_advance`` against (..., num_freqs, time'): (num_freqs, 1) works, a flat
+    (num_freqs,) does not — on every route; a non-positive rate raises RuntimeError (torch.arange's)."""
+    z = torch.randn(2, 9, 12, 2)
+    adv = torch.linspace(0, math.pi * 4, 9)
+    assert tuple(tac.phase_vocoder(z, 1.5, adv[:, None]).shape) == (2, 9, 8, 2)
+    assert tuple(tac.phase_vocoder(z, 1.5, adv[None, :, None]).shape) == (2, 9, 8, 2)
+    with pytest.raises(RuntimeError):
+        tac.phase_vocoder(z, 1.5, adv)
+    with pytest.raises(RuntimeError):
+        tac.phase_vocoder(z, 0.0, adv[:, None])

@@ -1044,6 +1044,58 @@ def test_g8_hpss(tac, golden):
         tac.set_strict(True)
 
 
+def test_hpss_tile_kernel_every_width_both_layouts_and_nan(tac):
+    """The 64 x 64 tile kernel (equal odd widths 9 ... 31, shared-sort medians, csrc/hpss.hip) against a numpy restatement
+    of beta_hpss.py:104-127: every width it is instantiated for, sizes that are not multiples of the tile (and smaller
+    than it), the contiguous (F, T) layout and the frame-major strided layout the STFT kernels return; medians select
+    existing values, so the enhanced spectrograms are compared exactly.  A NaN poisons exactly the windows that hold
+    it, as torch.median does (the CPU route of the same call is the witness)."""
+    rng = np.random.default_rng(7)
+
+    def ref_medians(s, k):
+        h = k // 2
+        padf = np.pad(s, ((0, 0), (h, h), (0, 0)), mode='reflect')
+        padt = np.pad(s, ((0, 0), (0, 0), (h, h)), mode='reflect')
+        perc = np.sort(np.stack([padf[:, i:i + s.shape[1]] for i in range(k)], -1), -1)[..., h]
+        harm = np.sort(np.stack([padt[..., i:i + s.shape[2]] for i in range(k)], -1), -1)[..., h]
+        return harm, perc
+
+    for k, (rows, F, T) in zip(range(9, 33, 2), [(2, 70, 131), (1, 16, 200), (3, 129, 64), (1, 65, 65), (2, 40, 33),
+                                                  (1, 257, 90), (2, 64, 64), (1, 100, 17), (1, 33, 300), (2, 127, 129),
+                                                  (1, 513, 70), (2, 150, 97)]):
+        if k // 2 >= min(F, T):
+            continue
+        s = (rng.random((rows, F, T), dtype=np.float32) * rng.integers(1, 4, (rows, F, T))).astype(np.float32)   # ties included
+        harm, perc = ref_medians(s, k)
+        for layout in ('contiguous', 'frame-major'):
+            x = dev(s) if layout == 'contiguous' else dev(np.ascontiguousarray(s.transpose(0, 2, 1))).transpose(1, 2)
+            assert x.is_contiguous() == (layout == 'contiguous')
+            before = launches(tac)
+            h, p, mh, mp = tac.hpss(x, k, 1.0, False)
+            assert launched_since(tac, before) == {'tac_hpss_f32': 1}
+            assert mh.stride() == x.stride()
+            want_mh = (harm + np.float32(1e-6)) / (harm + perc + np.float32(1e-6))
+            want_mp = (perc + np.float32(1e-6)) / (harm + perc + np.float32(1e-6))
+            assert np.abs(host(mh) - want_mh).max() <= 2e-7 and np.abs(host(mp) - want_mp).max() <= 2e-7, (k, layout)
+            assert np.abs(host(h) - s * want_mh).max() <= 4e-7 * s.max(), (k, layout)
+            hard = tac.hpss(x, k, 2.0, True)
+            assert np.array_equal(host(hard[2]), harm > perc) and np.array_equal(host(hard[3]), harm < perc), (k, layout)
+    # NaN: the windows that contain it, and only those
+    s = rng.random((1, 90, 80), dtype=np.float32)
+    s[0, 40, 33] = np.nan
+    s[0, 2, 70] = np.nan
+    for k in (9, 31):
+        got = tac.hpss(dev(s), k, 2.0, False)
+        want = tac.hpss(torch.from_numpy(s), k, 2.0, False)                  # CPU route: torch.median
+        for a, b in zip(got, want):
+            assert np.array_equal(np.isnan(host(a)), np.isnan(b.numpy())), k
+            ok = ~np.isnan(b.numpy())
+            assert np.abs(host(a)[ok] - b.numpy()[ok]).max() <= 1e-6
+        got5 = tac.hpss(dev(s), (5, 9), 2.0, False)                          # the general one-thread-per-element kernel
+        want5 = tac.hpss(torch.from_numpy(s), (5, 9), 2.0, False)
+        assert np.array_equal(np.isnan(host(got5[2])), np.isnan(want5[2].numpy()))
+
+
 def test_coded_waveforms_fused_into_the_frame_load(tac, golden):
     """int16 PCM and 8-bit mu-law codes (uint8 or the int64 mu_law_encoding returns) are converted in
     registers inside the fused kernel's frame load — ONE launch, the decoded waveform never exists — and agree with the

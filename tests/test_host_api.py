@@ -296,3 +296,60 @@ def test_bench_gpus_flag_is_real():
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                               env=dict(env, WORLD_SIZE='1', RANK='0'), timeout=300)
     assert mismatch.returncode != 0 and 'WORLD_SIZE=1' in mismatch.stderr
+
+
+_MEDIAN_CHECK = r'''
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <algorithm>
+#include <vector>
+#include "median_run.hpp"
+template <int K> int check(int trials) {
+    int bad = 0;
+    for (int t = 0; t < trials; ++t) {
+        float w[K + 3];
+        const int mode = t % 4;
+        for (int i = 0; i < K + 3; ++i) {
+            if (mode == 0) w[i] = (float)rand() / RAND_MAX;
+            else if (mode == 1) w[i] = (float)(rand() % 5);                 // many ties
+            else if (mode == 2) w[i] = (rand() % 7 == 0) ? INFINITY : (float)(rand() % 100);
+            else w[i] = (float)i * ((t & 8) ? 1.f : -1.f);                  // sorted / reversed
+        }
+        float med[4];
+        median_run4<K>(w, med);
+        for (int j = 0; j < 4; ++j) {
+            std::vector<float> v(w + j, w + j + K);
+            std::nth_element(v.begin(), v.begin() + K / 2, v.end());
+            if (v[K / 2] != med[j]) ++bad;
+        }
+    }
+    return bad;
+}
+int main() {
+    int b = check<9>(4000) + check<11>(4000) + check<13>(4000) + check<15>(4000) + check<17>(4000) + check<19>(4000) +
+            check<21>(4000) + check<23>(4000) + check<25>(4000) + check<27>(4000) + check<29>(4000) + check<31>(4000);
+    float a[32];
+    for (int t = 0; t < 2000; ++t) {
+        for (int i = 0; i < 32; ++i) a[i] = (float)(rand() % 50);
+        std::vector<float> v(a, a + 32);
+        std::sort(v.begin(), v.end());
+        sort_net<32>(a);
+        for (int i = 0; i < 32; ++i) b += a[i] != v[i];
+    }
+    printf("bad=%d\n", b);
+    return b != 0;
+}
+'''
+
+
+def test_median_run_matches_nth_element(tmp_path):
+    """csrc/median_run.hpp (the HPSS kernel's register sorting network and its shared-sort median selection of four
+    overlapping windows) is plain C++: compiled for the host and checked against std::nth_element for every width the
+    tile kernel is instantiated for — random values, heavy ties, infinities, sorted and reversed runs."""
+    src = tmp_path / 'check.cpp'
+    src.write_text(_MEDIAN_CHECK)
+    exe = str(tmp_path / 'check')
+    subprocess.run(['g++', '-O1', '-I', os.path.join(ROOT, 'torchaudio-contrib_amd', 'csrc'), '-o', exe, str(src)], check=True)
+    out = subprocess.run([exe], stdout=subprocess.PIPE, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == 'bad=0', out.stdout

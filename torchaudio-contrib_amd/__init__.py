@@ -7,6 +7,7 @@ the importable name is ``torchaudio_contrib_amd`` (see the loader shim at the re
 from . import _native
 from . import _ops
 from ._ops import set_strict, CompositeRouteWarning
+from ._hip import invalidate
 from ._lazy import realize, set_lazy_fusion, lazy_fusion_enabled, DeferredSpectral, DeferredWave
 from . import functional
 from . import layers

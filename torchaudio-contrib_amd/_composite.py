@@ -139,8 +139,10 @@ def hpss(mag, kernel_f, kernel_t, power, hard):
     hf, ht = kernel_f // 2, kernel_t // 2
     padded = TF.pad(x, (ht, ht, hf, hf), mode='reflect')
     n_freqs, n_frames = shape[-2], shape[-1]
-    perc = padded[..., ht:ht + n_frames].unfold(-2, kernel_f, 1).median(dim=-1).values
-    harm = padded[..., hf:hf + n_freqs, :].unfold(-1, kernel_t, 1).median(dim=-1).values
+    # (an even width leaves n + 1 windows over the n + 2 (k // 2) padded positions; the reference's loops take the
+    # first n, beta_hpss.py:84-91)
+    perc = padded[..., ht:ht + n_frames].unfold(-2, kernel_f, 1)[..., :n_freqs, :, :].median(dim=-1).values
+    harm = padded[..., hf:hf + n_freqs, :].unfold(-1, kernel_t, 1)[..., :n_frames, :].median(dim=-1).values
     if power != 1.0:
         perc, harm = perc.pow(power), harm.pow(power)
     if hard:

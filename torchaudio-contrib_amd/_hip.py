@@ -26,6 +26,47 @@ def _count(name):
     launches[name] = launches.get(name, 0) + 1
 
 
+# ----------------------------------------------------------------------------- constant-table caches
+# Everything derived from a window / filterbank (packed weights, tile plans, transposes, adjoint tables, DFT matrices)
+# is cached ON the tensor object and stamped with what identifies its contents cheaply: the version counter (every
+# in-place torch op bumps it), the data pointer (``set_`` / ``.data = other``) and the invalidation epoch below.
+# Writes that PyTorch itself does not record — ``t.data.mul_(2)`` (``.data`` has its own version counter), writes
+# through an alias created before the cache, ``from_dlpack`` / raw-pointer writers — cannot be seen without reading the
+# tensor back on every call; after such a write call ``invalidate(t)`` (or ``invalidate()`` for everything).
+_epoch = 0
+_CACHE_ATTRS = ('_tac_pack', '_tac_plan', '_tac_T', '_tac_adj', '_tac_dft')
+
+
+def _stamp(t):
+    return (t._version, t.data_ptr(), _epoch)
+
+
+def invalidate(tensor=None):
+    """Forget the tables derived from ``tensor`` (a window or filterbank), or — without an argument — from every
+    tensor: they are rebuilt from the current contents on the next call.  Needed only after a write PyTorch's version
+    counter does not see (``t.data.mul_(2)``, raw-pointer writes); ordinary in-place ops are detected by themselves."""
+    global _epoch
+    if tensor is None:
+        with _lock:
+            _epoch += 1
+            _geometry_routes_clear()
+        return
+    for name in _CACHE_ATTRS:
+        if hasattr(tensor, name):
+            try:
+                delattr(tensor, name)
+            except Exception:
+                pass
+    with _lock:
+        _epoch += 1                   # routes cached per geometry carry the epoch as well
+        _geometry_routes_clear()
+
+
+def _geometry_routes_clear():
+    for g in _geometry_cache.values():
+        g.routes.clear()
+
+
 # ----------------------------------------------------------------------------- STFT geometry
 class StftGeometry(object):
     """Validated geometry of one stft call on one input layout (the checks ``torch.stft`` performs, reference
@@ -136,7 +177,7 @@ def _dft_matrix(window, n_fft, win_length, onesided, normalized):
     built on the device in float64 (angles reduced exactly through (n*k) mod N in int64) and rounded once — a
     constant table like the FFT twiddles, cached on the window tensor per (version, geometry)."""
     cache = getattr(window, '_tac_dft', None)
-    key = (window._version, n_fft, win_length, bool(onesided), bool(normalized))
+    key = (_stamp(window), n_fft, win_length, bool(onesided), bool(normalized))
     if cache is not None and cache[0] == key:
         return cache[1]
     dev = window.device
@@ -219,8 +260,8 @@ def _melbank_pack(fb, n_fft):
     None when the bank is not band-sparse enough (then the MFMA kernels are used).  Built once per filterbank
     version (one host sync) and cached on the tensor object."""
     cache = getattr(fb, '_tac_pack', None)
-    if cache is None or cache[0] != fb._version:
-        cache = (fb._version, {})
+    if cache is None or cache[0] != _stamp(fb):
+        cache = (_stamp(fb), {})
         try:
             fb._tac_pack = cache
         except Exception:
@@ -250,7 +291,7 @@ def _filterbank_plan(fb):
     host sync on the path — and rescanned when modified in place); keying a cache on ``data_ptr`` would go stale
     when the allocator reuses an address."""
     hit = getattr(fb, '_tac_plan', None)
-    if hit is not None and hit[0] == fb._version and hit[1].device == fb.device:
+    if hit is not None and hit[0] == _stamp(fb) and hit[1].device == fb.device:
         return hit[1], hit[2]
     n_freqs, n_mels = fb.shape
     n_ints = 2 * ((n_mels + 15) // 16)
@@ -261,7 +302,7 @@ def _filterbank_plan(fb):
                                                ctypes.cast(host, ctypes.c_void_p), _native.stream_ptr(fb.device))
     _native.check(rc, 'tac_filterbank_plan')
     try:
-        fb._tac_plan = (fb._version, plan, host)
+        fb._tac_plan = (_stamp(fb), plan, host)
     except Exception:       # exotic tensor subclasses without attribute storage: just recompute next time
         pass
     return plan, host
@@ -293,7 +334,7 @@ def melspectrogram(wave, window, fb, n_fft, hop, win_length, center, pad_mode, n
                            % (g.n_bins, tuple(fb.shape)))
     # the route is cached per (filterbank object, version, power); ``id`` alone could be reused by a NEW tensor once
     # the old one is collected, so the entry carries a weak reference that must still point at this very object
-    rkey = (id(fb), fb._version, power, MEL_PATH)
+    rkey = (id(fb), _stamp(fb), power, MEL_PATH)
     hit = g.routes.get(rkey)
     if hit is not None and hit[0]() is fb:
         route = hit[1]
@@ -560,11 +601,11 @@ def transposed_bank(fb):
     """(M, F) contiguous transpose of a filterbank, cached on the tensor per version (the adjoint of the filterbank
     stage is the same GEMM kernel with this matrix)."""
     hit = getattr(fb, '_tac_T', None)
-    if hit is not None and hit[0] == fb._version:
+    if hit is not None and hit[0] == _stamp(fb):
         return hit[1]
     t = fb.detach().t().contiguous()
     try:
-        fb._tac_T = (fb._version, t)
+        fb._tac_T = (_stamp(fb), t)
     except Exception:
         pass
     return t
@@ -574,7 +615,7 @@ def _adjoint_table(fb):
     """Per-bin {w0, w1, band0, band1} table of a bank with at most two non-zero weights per bin (every triangular mel
     bank), built on the device once per filterbank version (one host sync) and cached on the tensor; None otherwise."""
     hit = getattr(fb, '_tac_adj', None)
-    if hit is not None and hit[0] == fb._version:
+    if hit is not None and hit[0] == _stamp(fb):
         return hit[1]
     n_freqs, n_mels = fb.shape
     table = None
@@ -590,7 +631,7 @@ def _adjoint_table(fb):
         if nnz.value > 2:
             table = None
     try:
-        fb._tac_adj = (fb._version, table)
+        fb._tac_adj = (_stamp(fb), table)
     except Exception:
         pass
     return table

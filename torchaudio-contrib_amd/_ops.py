@@ -108,9 +108,16 @@ def _plain_hip_f32(*tensors):
 
 def _register_autograd(op, fn, n_tensors, hip_backward=None):
     """Backward of ``tac_amd::<op>``.  ``hip_backward(tensors, rest, needs, grads)`` — the hand-written gradient
-    kernels (csrc/backward.hip) — is used when it applies (float32 on a HIP device, gradient asked for the signal
-    path only); it returns None otherwise and the op is then differentiated by re-evaluating it with differentiable
-    torch operators (``_composite``) on the saved inputs."""
+    kernels (csrc/backward.hip) — is used when it applies (float32 on a HIP device); it returns None otherwise and
+    the op is then differentiated by re-evaluating it with differentiable torch operators (``_composite``) on the
+    saved inputs.  That second route is the only one on CPU tensors; on a HIP device it is announced like every other
+    use of stock torch operators there (``CompositeRouteWarning``, an error under ``set_strict(True)``, counted in
+    ``composite_calls``).
+
+    Double backward (``create_graph=True``; the reference, being stock torch operators, is twice differentiable): the
+    gradient kernels produce values without a graph, so a backward pass that is itself recorded re-evaluates the op
+    with torch operators on the SAVED tensors — still attached to the caller's graph — and differentiates that with
+    ``create_graph=True``."""
 
     def setup_context(ctx, inputs, output):
         ctx.save_for_backward(*inputs[:n_tensors])
@@ -119,21 +126,36 @@ def _register_autograd(op, fn, n_tensors, hip_backward=None):
     def backward(ctx, *grads):
         needs = ctx.needs_input_grad[:n_tensors]
         saved = ctx.saved_tensors
-        if hip_backward is not None and _plain_hip_f32(*saved) and all(g is None or _plain_hip_f32(g) for g in grads):
-            with torch.no_grad():
-                res = hip_backward(saved, ctx.rest, needs, grads)
-            if res is not None:
-                return tuple(res) + (None,) * len(ctx.rest)
+        second_order = torch.is_grad_enabled()
+        why = 'double backward (create_graph=True)' if second_order else None
+        if why is None and hip_backward is not None:
+            if _plain_hip_f32(*saved) and all(g is None or _plain_hip_f32(g) for g in grads):
+                with torch.no_grad():
+                    res = hip_backward(saved, ctx.rest, needs, grads)
+                if res is not None:
+                    return tuple(res) + (None,) * len(ctx.rest)
+                why = 'this gradient has no gfx950 kernel'
+            else:
+                why = _hip_dtype(*[t for t in tuple(saved) + tuple(grads) if t is not None]) or 'tensor subclass'
+        elif why is None:
+            why = 'the op has no gradient kernel'
+        if any(t.is_cuda for t in saved):
+            _composite_route(op, 'backward: ' + why)
         with torch.enable_grad():
-            ins = [t.detach().requires_grad_(True) if (need and t.is_floating_point()) else t.detach()
-                   for t, need in zip(saved, needs)]
+            if second_order:        # keep the graph: the saved tensors are the caller's own
+                ins = list(saved)
+                wanted = [t for t, need in zip(ins, needs) if need and t.requires_grad]
+            else:
+                ins = [t.detach().requires_grad_(True) if (need and t.is_floating_point()) else t.detach()
+                       for t, need in zip(saved, needs)]
+                wanted = [t for t in ins if t.requires_grad]
             outs = fn(*ins, *ctx.rest)
             outs = outs if isinstance(outs, tuple) else (outs,)
             pairs = [(o, g) for o, g in zip(outs, grads) if g is not None and o.requires_grad]
-            wanted = [t for t in ins if t.requires_grad]
-            got = iter(torch.autograd.grad([o for o, _ in pairs], wanted, [g for _, g in pairs], allow_unused=True)
-                       if pairs and wanted else ())
-        result = [next(got, None) if t.requires_grad else None for t in ins]
+            got = torch.autograd.grad([o for o, _ in pairs], wanted, [g for _, g in pairs], allow_unused=True,
+                                      create_graph=second_order) if pairs and wanted else ()
+        by_id = {id(t): g for t, g in zip(wanted, got)}
+        result = [by_id.get(id(t)) for t in ins]
         return tuple(result) + (None,) * len(ctx.rest)
 
     torch.library.register_autograd('%s::%s' % (NS, op), backward, setup_context=setup_context, lib=_lib)

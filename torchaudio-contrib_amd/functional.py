@@ -44,7 +44,10 @@ def default_window(n, like):
     key = (n, str(like.device), dtype)
     w = _window_cache.get(key)
     if w is None:
-        w = torch.hann_window(n, dtype=dtype, device=like.device)
+        # built outside inference mode whatever the caller's mode: an inference tensor in the cache could not be saved for
+        # a later call's backward ("Inference tensors cannot be saved for backward")
+        with torch.inference_mode(False):
+            w = torch.hann_window(n, dtype=dtype, device=like.device)
         if len(_window_cache) > 64:
             _window_cache.clear()
         _window_cache[key] = w
@@ -173,13 +176,16 @@ def phase_vocoder(complex_specgrams, rate, phase_advance):
     if spec.dim() < 3 or spec.shape[-1] != 2:
         raise RuntimeError('phase_vocoder: expected (*, num_freqs, time, 2), got shape %s' % (tuple(spec.shape),))
     pa = _tensor(phase_advance, 'phase_advance')
-    if pa.numel() != spec.shape[-3]:
-        raise RuntimeError('phase_vocoder: phase_advance has %d entries for %d frequency bins'
-                           % (pa.numel(), spec.shape[-3]))
+    # the reference broadcasts phase_advance against (..., num_freqs, time'): it must be (num_freqs, 1) (or a leading-1
+    # variant of it) there, and every route here — HIP kernel, torch operators, fake — sees it in that one shape
+    if pa.numel() != spec.shape[-3] or pa.dim() < 2 or pa.shape[-1] != 1 or pa.shape[-2] != spec.shape[-3]:
+        raise RuntimeError('phase_vocoder: phase_advance must have shape (num_freqs, 1) = (%d, 1), got %s'
+                           % (spec.shape[-3], tuple(pa.shape)))
+    pa = pa.reshape(spec.shape[-3], 1)
     if pa.device != spec.device:
         raise RuntimeError('phase_vocoder: spectrogram and phase_advance must be on the same device')
-    if not rate > 0:
-        raise ValueError('phase_vocoder: rate must be positive, got %r' % (rate,))
+    if not rate > 0:                 # the reference's torch.arange(0, T, rate) raises RuntimeError for such a step
+        raise RuntimeError('phase_vocoder: rate must be positive, got %r' % (rate,))
     return _call('phase_vocoder', spec, pa, float(rate))
 
 
