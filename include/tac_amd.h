@@ -255,6 +255,21 @@ int tac_overlap_add_f32(const float* grad_frames, const tac_stft_desc* d, float*
                         int64_t grad_row_stride, void* stream);
 int tac_complex_norm_backward_f32(const float* z, const float* grad_out, int64_t n, float power,
                                   float* grad_z, void* stream);
+/* (9b) The general gradient routes (every fft_length, two-sided outputs, gradients of the window and the filterbank —
+ *     functional.py:99-107, 183-184 differentiate through every argument):
+ *     tac_overlap_add_f32 above takes ANY fft_length (framing only).
+ *     tac_fold_twosided_f32: gradient of a two-sided output grad[frames][n_fft][width] (width 2: complex pairs, 1: |X|^p)
+ *       folded onto the n_fft/2+1 one-sided bins: out[k] = grad[k] + grad[n_fft-k] (imaginary parts: minus).
+ *     tac_window_grad_partials / tac_window_grad_f32: with grad_frames_unwindowed[rows][T][n_fft] the gradient w.r.t.
+ *       the windowed frames (tac_stft_backward_f32 run with a window of ones), partial[p][n] = the sum over the p-th
+ *       chunk of (row, frame) of grad_frames * padded signal; tac_sum_slabs_f32 adds the n_partials rows up.
+ *     tac_sum_slabs_f32: out[i] = sum_s x[s][i] in slab order. */
+int tac_fold_twosided_f32(const float* grad, int64_t n_frames_total, int32_t n_fft, int32_t width, float* out,
+                          void* stream);
+int64_t tac_window_grad_partials(const tac_stft_desc* d);
+int tac_window_grad_f32(const float* grad_frames_unwindowed, const float* wave, const tac_stft_desc* d,
+                        float* partial, int64_t n_partials, void* stream);
+int tac_sum_slabs_f32(const float* x, int64_t n_slabs, int64_t slab_elems, float* out, void* stream);
 int tac_amplitude_to_db_backward_f32(const float* x, const float* grad_out, int64_t n, float amin,
                                      float* grad_x, void* stream);
 

@@ -867,6 +867,102 @@ def test_autograd_matches_the_reference_chain(tac, shape, n_fft, hop, mels):
         assert rel_err(host(got), want.numpy()) < 1e-3
 
 
+@pytest.mark.parametrize('n_fft,hop,win_length,onesided,center,pad_mode,normalized', [
+    (400, 160, None, True, True, 'reflect', False),       # the speech front end (mixed-radix forward kernel)
+    (400, 100, 320, False, True, 'constant', True),       # ... two-sided, short window, normalized
+    (300, 75, None, True, True, 'reflect', False),        # DFT-matrix size
+    (250, 100, 200, True, False, 'reflect', False),       # ... not centred, short window
+    (512, 128, None, False, True, 'replicate', False),    # two-sided power of two
+    (2048, 500, 1500, True, True, 'circular', False),     # window gradient at an FFT size, hop not a multiple of 128
+    (4500, 1125, None, True, True, 'reflect', False),     # beyond the FFT kernels: DFT matrix
+])
+def test_general_gradient_routes_under_strict(tac, n_fft, hop, win_length, onesided, center, pad_mode, normalized):
+    """The reference differentiates through every argument with stock torch (functional.py:99-107, 183-184).  Under
+    set_strict(True) — the stock-torch route is an error — gradients w.r.t. the waveform, the WINDOW and the FILTERBANK
+    come from the HIP entry points for every fft_length the forward kernels cover (FFT sizes, 400, DFT-matrix sizes),
+    one- and two-sided, and agree with torch.autograd through the CPU oracle."""
+    assert tac._ops.strict()
+    shape = (2, 2, 3 * n_fft + 37)
+    x = signals.audio_like(shape, seed=301)
+    wl = n_fft if win_length is None else win_length
+    win = (np.hanning(wl + 2)[1:-1] + 0.1).astype(np.float32)
+    n_bins = n_fft // 2 + 1 if onesided else n_fft
+    n_mels = 24
+    fb = np.abs(signals.uniform((n_bins, n_mels), seed=302)).astype(np.float32)
+    kw = dict(hop_length=hop, win_length=win_length, center=center, pad_mode=pad_mode, normalized=normalized, onesided=onesided)
+
+    def chains(mod, xt, wt, ft):
+        z = mod.stft(xt, n_fft, window=wt, **kw)
+        p = mod.complex_norm(z, 2.0)
+        m = mod.apply_filterbank(p, ft)
+        return z, p, mod.amplitude_to_db(m, 1.0, 1e-3)
+
+    class RefMod:                                          # the oracle under the product's argument names
+        stft = staticmethod(lambda xt, n, window, hop_length, win_length, center, pad_mode, normalized, onesided:
+                            torch_ref.stft(xt, n, hop_length, win_length, window, center, pad_mode, normalized, onesided))
+        complex_norm = staticmethod(torch_ref.complex_norm)
+        apply_filterbank = staticmethod(torch_ref.apply_filterbank)
+        amplitude_to_db = staticmethod(torch_ref.amplitude_to_db)
+
+    cx, cw, cf = (torch.from_numpy(a).double().requires_grad_(True) for a in (x, win, fb))
+    gx, gw, gf = (dev(a).requires_grad_(True) for a in (x, win, fb))
+    outs_ref = chains(RefMod, cx, cw, cf)
+    outs_got = chains(tac, gx, gw, gf)
+    for stage, (yr, yg) in enumerate(zip(outs_ref, outs_got)):
+        wgt = signals.uniform(tuple(yr.shape), seed=310 + stage)
+        ins_r, ins_g = ((cx, cw), (gx, gw)) if stage < 2 else ((cx, cw, cf), (gx, gw, gf))
+        want = torch.autograd.grad((yr * torch.from_numpy(wgt).double()).sum(), ins_r, retain_graph=True)
+        before = launches(tac)
+        got = torch.autograd.grad((tac.realize(yg) * dev(wgt)).sum(), ins_g, retain_graph=True)
+        ran = launched_since(tac, before)
+        assert 'tac_overlap_add_f32' in ran and 'tac_window_grad_f32' in ran, ran
+        for name, a, b in zip(('waveform', 'window', 'filterbank'), got, want):
+            assert rel_err(host(a), b.numpy()) < 1e-4, (stage, name)
+    # waveform only at fft_length 400: still no stock-torch route, whatever the op
+    routed = dict(tac._ops.composite_calls)
+    y = tac.Spectrogram(400, 160, power=2.).cuda()(gx)
+    (g1,) = torch.autograd.grad(y.sum(), gx)
+    assert tac._ops.composite_calls == routed
+    # the fused op with a learnable filterbank and window
+    mel = tac.Melspectrogram(num_mels=20, sample_rate=16000, fft_length=512, hop_length=128).cuda()
+    mel[0].window.requires_grad_(True)
+    mel[2].filterbank.requires_grad_(True)
+    xs = dev(signals.audio_like((2, 1, 6000), seed=303))
+    before = launches(tac)
+    gwin, gbank = torch.autograd.grad(tac.realize(mel(xs)).sum(), (mel[0].window, mel[2].filterbank))
+    cwin, cbank = mel[0].window.detach().cpu().double().requires_grad_(True), mel[2].filterbank.detach().cpu().double().requires_grad_(True)
+    ref = torch_ref.apply_filterbank(torch_ref.complex_norm(torch_ref.stft(xs.cpu().double(), 512, 128, window=cwin), 2.0), cbank)
+    rwin, rbank = torch.autograd.grad(ref.sum(), (cwin, cbank))
+    assert rel_err(host(gwin), rwin.numpy()) < 1e-4 and rel_err(host(gbank), rbank.numpy()) < 1e-4
+
+
+def test_backward_without_a_kernel_is_announced(tac):
+    """What still differentiates through stock torch operators on the device (ops without gradient kernels, double
+    backward) says so: an error under strict mode, a CompositeRouteWarning and a composite_calls entry otherwise."""
+    z = dev(signals.uniform((2, 33, 20, 2), seed=305)).requires_grad_(True)
+    adv = dev(np.linspace(0, np.pi * 8, 33, dtype=np.float32)[:, None])
+    y = tac.phase_vocoder(z, 1.25, adv)
+    with pytest.raises(RuntimeError, match='strict mode'):
+        y.sum().backward()
+    x = dev(signals.audio_like((1, 1, 3000), seed=306)).requires_grad_(True)
+    with pytest.raises(RuntimeError, match='strict mode'):
+        torch.autograd.grad(torch.autograd.grad(tac.Spectrogram(256, 64, power=2.).cuda()(x).sum(), x, create_graph=True)[0].pow(2).sum(), x)
+    tac.set_strict(False)
+    try:
+        tac._ops._warned.clear()
+        with pytest.warns(tac.CompositeRouteWarning, match='backward'):
+            (g,) = torch.autograd.grad(tac.Spectrogram(256, 64, power=2.).cuda()(x).sum(), x, create_graph=True)
+        assert g.requires_grad
+        (h,) = torch.autograd.grad(g.pow(2).sum(), x)
+        xc = x.detach().cpu().double().requires_grad_(True)
+        (gc,) = torch.autograd.grad(torch_ref.complex_norm(torch_ref.stft(xc, 256, 64), 2.0).sum(), xc, create_graph=True)
+        (hc,) = torch.autograd.grad(gc.pow(2).sum(), xc)
+        assert rel_err(host(h), hc.numpy()) < 1e-4
+        assert any(k[1].startswith('backward: double backward') for k in tac._ops.composite_calls)
+    finally:
+        tac.set_strict(True)
+
+
 def test_filterbank_adjoint_forms(tac):
     """Gradient of apply_filterbank w.r.t. the spectrogram (functional.py:183-184 under autograd): banks with at most two
     non-zero weights per bin (mel banks) take the per-bin table kernel, anything else the GEMM with the transposed bank;

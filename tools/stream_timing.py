@@ -18,7 +18,7 @@ frames = 256 * 313 / (256 * 8)
 tot = t[..., 0].mean()
 print('per wave: %.0f cycles total, %.1f frames -> %.0f cycles per frame (two frames in flight)' % (tot, frames, tot / frames))
 print('total by wave: ' + ' '.join('%7.0f' % v for v in t[..., 0].mean(0)))
-for k, name in ((1, 's0 window + pass 0 + exchange'), (2, 's12 pass 1, in-register exchange, pass 2'), (4, 's3 r2c + row + request'),
+for k, name in ((3, 'wait for the samples (vmcnt)'), (1, 's0 window + pass 0 + exchange'), (2, 's12 pass 1, in-register exchange, pass 2'), (4, 's3 r2c + row + request'),
                 (5, 's4 contraction + dB + store')):
     col = t[..., k]
     print('%-32s %7.0f cycles/frame (%4.1f%%)  by wave: %s' % (name, col.mean() / frames, 100 * col.mean() / tot,

@@ -24,6 +24,7 @@ def steady(fn, n=60):
 x = torch.rand(256, 1, 160000, device='cuda') * 2 - 1
 z = tac.realize(tac.STFT(2048, 512).cuda()(x))                      # (256,1,1025,313,2) strided view
 p = tac.Spectrogram(2048, 512, power=2.).cuda()(x)                  # (256,1,1025,313)
+pc = p.contiguous()
 fb = tac.create_mel_filter(1025, 128, 0.0, 8000.0, False).cuda()
 adv = torch.linspace(0, math.pi * 512, 1025)[..., None].cuda()
 xm = torch.rand(1024, 1, 120000, device='cuda') * 2 - 1
@@ -41,7 +42,13 @@ cases = [
     ('phase_vocoder rate 1.3', lambda: tac.phase_vocoder(z, 1.3, adv), z.numel() * 4 + int(z.numel() / 1.3) * 4),
     ('mu_law_encoding (cfg-5)', lambda: tac.mu_law_encoding(xm, 256), xm.numel() * 12),
     ('mu_law_decoding (cfg-5)', lambda: tac.mu_law_decoding(codes, 256), xm.numel() * 12),
+    ('hpss k=31 (frame-major |X|^2)', lambda: tac.hpss(p, 31, 2.0), p.numel() * 20),
+    ('hpss k=31 (contiguous)', lambda: tac.hpss(pc, 31, 2.0), p.numel() * 20),
+    ('hpss k=(5, 9) (general kernel)', lambda: tac.hpss(pc, (5, 9), 2.0), p.numel() * 20),
 ]
+only = sys.argv[1:]
 for name, fn, nbytes in cases:
+    if only and not any(o in name for o in only):
+        continue
     ms = steady(fn)
     print('%-28s %.4f ms   %7.1f MB   %5.2f TB/s  (%.0f %% of 8 TB/s)' % (name, ms, nbytes / 1e6, nbytes / ms / 1e9, 100 * nbytes / ms / 1e9 / 8))

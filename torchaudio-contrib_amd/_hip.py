@@ -34,7 +34,7 @@ def _count(name):
 # through an alias created before the cache, ``from_dlpack`` / raw-pointer writers — cannot be seen without reading the
 # tensor back on every call; after such a write call ``invalidate(t)`` (or ``invalidate()`` for everything).
 _epoch = 0
-_CACHE_ATTRS = ('_tac_pack', '_tac_plan', '_tac_T', '_tac_adj', '_tac_dft')
+_CACHE_ATTRS = ('_tac_pack', '_tac_plan', '_tac_T', '_tac_adj', '_tac_dft', '_tac_dftT')
 
 
 def _stamp(t):
@@ -717,6 +717,152 @@ def stft_backward(grad_spec, wave, window, n_fft, hop, win_length, center, pad_m
                                                _native.stream_ptr(wave.device))
         _native.check(rc, 'tac_overlap_add_f32')
         _count('tac_overlap_add_f32')
+    return out
+
+
+# ---- the general gradient routes: every fft_length the forward kernels cover, two-sided outputs, and the gradients of
+# the window and the filterbank (the reference differentiates through every argument, functional.py:99-107, 183-184).
+# Built from the unfused pieces — inverse FFT per frame or the DFT-matrix GEMM with the transposed matrix, gather
+# overlap-add, a frames x samples reduction for the window, the MFMA GEMM for the filterbank — so frame gradients do go
+# through memory here; the fused backward kernels above remain the route of the common case (gradient of the waveform
+# only, one-sided power-of-two sizes).
+def fold_twosided(grad, n_fft, width):
+    """physical frame-major gradient of a two-sided output (*, T, n_fft[, 2]) -> the one-sided bins (*, T, F[, 2])."""
+    n_bins = n_fft // 2 + 1
+    lead = tuple(grad.shape[:-2]) if width == 2 else tuple(grad.shape[:-1])
+    out = torch.empty(lead + ((n_bins, 2) if width == 2 else (n_bins,)), dtype=torch.float32, device=grad.device)
+    frames = out.numel() // (n_bins * width)
+    with _native.on_device(grad.device):
+        rc = _native.lib().tac_fold_twosided_f32(_native.ptr(grad), frames, n_fft, width, _native.ptr(out),
+                                                 _native.stream_ptr(grad.device))
+    _native.check(rc, 'tac_fold_twosided_f32')
+    _count('tac_fold_twosided_f32')
+    return out
+
+
+def sum_slabs(x):
+    """(S, ...) -> (...): the slabs added up in order (deterministic)."""
+    out = torch.empty(tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+    with _native.on_device(x.device):
+        rc = _native.lib().tac_sum_slabs_f32(_native.ptr(x), x.shape[0], out.numel(), _native.ptr(out),
+                                             _native.stream_ptr(x.device))
+    _native.check(rc, 'tac_sum_slabs_f32')
+    _count('tac_sum_slabs_f32')
+    return out
+
+
+_ones_cache = {}
+
+
+def _ones_window(device, n):
+    key = (str(device), n)
+    w = _ones_cache.get(key)
+    if w is None:
+        with torch.inference_mode(False):
+            w = torch.ones(n, dtype=torch.float32, device=device)
+        _ones_cache[key] = w
+    return w
+
+
+def _dft_matrix_t(window, n_fft, win_length, normalized):
+    """(2F, N) transpose of the one-sided windowed-DFT matrix: the adjoint of ``_stft_dft`` is the same GEMM with it."""
+    cache = getattr(window, '_tac_dftT', None)
+    key = (_stamp(window), n_fft, win_length, bool(normalized))
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    mat = _dft_matrix(window, n_fft, win_length, True, normalized).t().contiguous()
+    try:
+        window._tac_dftT = (key, mat)
+    except Exception:
+        pass
+    return mat
+
+
+def _desc(g, row_stride=None, onesided=None):
+    return _native.StftDesc(rows=g.rows, length=g.length, row_stride=g.length if row_stride is None else row_stride,
+                            n_fft=g.n_fft, hop=g.hop, win_length=g.win_length, center=1 if g.center else 0,
+                            pad_mode=_native.PAD_MODES[g.pad_mode], normalized=1 if g.normalized else 0,
+                            onesided=(1 if g.onesided else 0) if onesided is None else onesided, reserved=0)
+
+
+def _frame_gradients(gs, window, g):
+    """one-sided gradient spectrum (rows, T, F, 2) -> frame gradients (rows, T, n_fft), window and scale applied."""
+    frames = torch.empty((g.rows, g.n_frames, g.n_fft), dtype=torch.float32, device=gs.device)
+    with _native.on_device(gs.device):
+        if g.fft_kernel:
+            rc = _native.lib().tac_stft_backward_f32(_native.ptr(gs), _native.ptr(window), _desc(g, onesided=1),
+                                                     _native.ptr(frames), _native.stream_ptr(gs.device))
+            _native.check(rc, 'tac_stft_backward_f32')
+            _count('tac_stft_backward_f32')
+        else:
+            n_cols = 2 * (g.n_fft // 2 + 1)
+            mat_t = _dft_matrix_t(window, g.n_fft, g.win_length, g.normalized)
+            rc = _native.lib().tac_apply_filterbank_f32(
+                _native.ptr(gs), g.rows, n_cols, g.n_frames, g.n_frames * n_cols, 1, n_cols, _native.ptr(mat_t), None,
+                g.n_fft, _native.ptr(frames), _native.stream_ptr(gs.device))
+            _native.check(rc, 'tac_apply_filterbank_f32 (DFT matrix, adjoint)')
+            _count('tac_apply_filterbank_f32')
+    return frames
+
+
+def stft_backward_general(grad_spec, wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided,
+                          need_wave=True, need_window=False):
+    """(grad_wave, grad_window) from the gradient of the complex stft output ``(*, n_bins, T, 2)`` — any fft_length up
+    to 8192, one- or two-sided."""
+    g = geometry(wave, n_fft, hop, win_length, center, pad_mode, normalized, onesided)
+    gs = grad_spec.transpose(-3, -2)                                   # physical frame-major (*, T, n_bins, 2)
+    gs = gs if (gs.is_contiguous() and gs.dtype == torch.float32) else gs.contiguous().float()
+    if not g.onesided:
+        gs = fold_twosided(gs, n_fft, 2)
+    window = window if window.is_contiguous() else window.contiguous()
+    dev = wave.device
+    grad_wave = grad_window = None
+    if need_wave:
+        frames = _frame_gradients(gs, window, g)
+        grad_wave = torch.empty(tuple(wave.shape), dtype=torch.float32, device=dev)
+        with _native.on_device(dev):
+            rc = _native.lib().tac_overlap_add_f32(_native.ptr(frames), _desc(g), _native.ptr(grad_wave), g.length,
+                                                   _native.stream_ptr(dev))
+        _native.check(rc, 'tac_overlap_add_f32')
+        _count('tac_overlap_add_f32')
+        del frames
+    if need_window:
+        unwindowed = _frame_gradients(gs, _ones_window(dev, win_length), g)
+        src = _rows_of(wave, g)
+        desc = _desc(g, row_stride=g.row_stride)
+        n_part = int(_native.lib().tac_window_grad_partials(desc))
+        if n_part < 0:
+            _native.check(n_part, 'tac_window_grad_partials')
+        partial = torch.empty((n_part, n_fft), dtype=torch.float32, device=dev)
+        with _native.on_device(dev):
+            rc = _native.lib().tac_window_grad_f32(_native.ptr(unwindowed), _native.ptr(src), desc, _native.ptr(partial),
+                                                   n_part, _native.stream_ptr(dev))
+        _native.check(rc, 'tac_window_grad_f32')
+        _count('tac_window_grad_f32')
+        off = (n_fft - win_length) // 2
+        grad_window = sum_slabs(partial)[off:off + win_length]
+    return grad_wave, grad_window
+
+
+def filterbank_grad(spec, grad_out):
+    """d/d filterbank of ``apply_filterbank(spec, fb)``: grad_fb[f][m] = sum over (*, t) of spec[.., f, t] *
+    grad_out[.., m, t] — one fp32 MFMA GEMM whose contraction runs over every frame of the batch."""
+    sp = spec.transpose(-2, -1)                                        # (*, T, F)
+    sp = sp if (sp.is_contiguous() and sp.dtype == torch.float32) else sp.contiguous().float()
+    gm = grad_out.transpose(-2, -1)                                    # (*, T, M)
+    gm = gm if (gm.is_contiguous() and gm.dtype == torch.float32) else gm.contiguous().float()
+    n_freqs, n_mels = sp.shape[-1], gm.shape[-1]
+    total = sp.numel() // n_freqs
+    if total >= 2 ** 31:
+        raise NotImplementedError('filterbank gradient: more than 2^31 frames in one call')
+    out = torch.empty((n_freqs, n_mels), dtype=torch.float32, device=sp.device)
+    if total == 0:
+        return out.zero_()
+    with _native.on_device(sp.device):
+        rc = _native.lib().tac_apply_filterbank_f32(_native.ptr(sp), 1, total, n_freqs, 0, n_freqs, 1, _native.ptr(gm), None,
+                                                    n_mels, _native.ptr(out), _native.stream_ptr(sp.device))
+    _native.check(rc, 'tac_apply_filterbank_f32 (filterbank gradient)')
+    _count('tac_apply_filterbank_f32')
     return out
 
 

@@ -32,6 +32,7 @@ EXPORTS = (
     'tac_db_to_amplitude_f32', 'tac_mulaw_encode_f32_i64', 'tac_mulaw_decode_i64_f32',
     'tac_mulaw_decode_f32_f32',
     'tac_stft_backward_f32', 'tac_stft_norm_backward_f32', 'tac_spectrogram_backward_f32', 'tac_spectrogram_backward_ola_workspace', 'tac_spectrogram_backward_ola_f32', 'tac_filterbank_adjoint_pack', 'tac_apply_filterbank_adjoint_f32', 'tac_overlap_add_f32', 'tac_complex_norm_backward_f32', 'tac_amplitude_to_db_backward_f32', 'tac_hpss_f32', 'tac_melspec_sparse_coded_f32', 'tac_pcm16_to_f32',
+    'tac_fold_twosided_f32', 'tac_window_grad_partials', 'tac_window_grad_f32', 'tac_sum_slabs_f32',
 )
 
 
@@ -123,6 +124,11 @@ def lib():
         h.tac_amplitude_to_db_backward_f32.argtypes = [_P, _P, _I64, _F, _P, _P]
         h.tac_melspec_sparse_coded_f32.argtypes = [_P, _I32, _P, _P, _DESC, _F, _P, _P, _P, _I32, ctypes.c_int, _F, _F, _P, _P]
         h.tac_pcm16_to_f32.argtypes = [_P, _I64, _P, _P]
+        h.tac_fold_twosided_f32.argtypes = [_P, _I64, _I32, _I32, _P, _P]
+        h.tac_window_grad_partials.argtypes = [_DESC]
+        h.tac_window_grad_partials.restype = _I64
+        h.tac_window_grad_f32.argtypes = [_P, _P, _DESC, _P, _I64, _P]
+        h.tac_sum_slabs_f32.argtypes = [_P, _I64, _I64, _P, _P]
         h.tac_hpss_f32.argtypes = [_P, _I64, _I32, _I32, _I64, _I64, _I64, _I32, _I32, _F, ctypes.c_int, _P, _P, _P, _P, _P]
         for name in EXPORTS:
             fn = getattr(h, name)

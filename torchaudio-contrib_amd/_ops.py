@@ -166,25 +166,44 @@ def _signal_path_only(needs):
     return bool(needs[0]) and not any(needs[1:])
 
 
+def _fast_backward(needs, n_fft, onesided):
+    """the fused backward kernels: gradient of the waveform only, one-sided power-of-two fft_length"""
+    return _signal_path_only(needs) and H.stft_backward_supported(n_fft, onesided)
+
+
 def _stft_hip_backward(saved, rest, needs, grads):
     wave, window = saved
     n_fft, hop, win_length, center, pad_mode, normalized, onesided = rest[:7]
-    if not _signal_path_only(needs) or not H.stft_backward_supported(n_fft, onesided) or grads[0] is None:
+    if grads[0] is None or not H.hip_covers_n_fft(n_fft):
         return None
-    return [H.stft_backward(grads[0], wave, window.contiguous(), n_fft, hop, win_length, center, pad_mode, normalized),
-            None]
+    window = window.contiguous()
+    if _fast_backward(needs, n_fft, onesided):
+        return [H.stft_backward(grads[0], wave, window, n_fft, hop, win_length, center, pad_mode, normalized), None]
+    return list(H.stft_backward_general(grads[0], wave, window, n_fft, hop, win_length, center, pad_mode, normalized,
+                                        onesided, bool(needs[0]), bool(needs[1])))
+
+
+def _spectrogram_general_backward(wave, window, geo, power, g, need_wave, need_window):
+    """spectrum recomputed by the forward kernel, the norm's adjoint, then the general stft adjoint"""
+    n_fft, hop, win_length, center, pad_mode, normalized, onesided = geo
+    z = H.stft(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided)
+    gz = H.complex_norm_backward(z, g, power)
+    return H.stft_backward_general(gz, wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided,
+                                   need_wave, need_window)
 
 
 def _spectrogram_hip_backward(saved, rest, needs, grads):
     wave, window = saved
     n_fft, hop, win_length, center, pad_mode, normalized, onesided, power, db, ref, amin = rest
-    if not _signal_path_only(needs) or not H.stft_backward_supported(n_fft, onesided) or grads[0] is None:
+    if grads[0] is None or not H.hip_covers_n_fft(n_fft):
         return None
     window = window.contiguous()
     g = grads[0]
     if db:      # the |z|^power values the dB gradient needs: one fused forward launch (nothing was saved)
         g = H.amplitude_to_db_backward(H.spectrogram(wave, window, n_fft, hop, win_length, center, pad_mode, normalized,
                                                      onesided, power, False, 1.0, 1e-7), g, amin)
+    if not _fast_backward(needs, n_fft, onesided):
+        return list(_spectrogram_general_backward(wave, window, rest[:7], power, g, bool(needs[0]), bool(needs[1])))
     # the backward kernel transforms the frames again itself and folds the norm's adjoint into the inverse FFT's load:
     # neither the spectrum nor a gradient spectrum exists in memory (fft_length 4096: the spectrum is recomputed first)
     z = None if H.backward_recomputes_spectrum(n_fft) else \
@@ -196,7 +215,7 @@ def _spectrogram_hip_backward(saved, rest, needs, grads):
 def _melspectrogram_hip_backward(saved, rest, needs, grads):
     wave, window, bank = saved
     n_fft, hop, win_length, center, pad_mode, normalized, onesided, power, db, ref, amin = rest
-    if not _signal_path_only(needs) or not H.stft_backward_supported(n_fft, onesided) or grads[0] is None:
+    if grads[0] is None or not H.hip_covers_n_fft(n_fft):
         return None
     window = window.contiguous()
     g = grads[0]
@@ -204,17 +223,28 @@ def _melspectrogram_hip_backward(saved, rest, needs, grads):
         mel = H.melspectrogram(wave, window, bank, n_fft, hop, win_length, center, pad_mode, normalized, onesided, power,
                                False, 1.0, 1e-7)
         g = H.amplitude_to_db_backward(mel, g, amin)
+    grad_bank = None
+    if needs[2]:
+        grad_bank = H.filterbank_grad(H.spectrogram(wave, window, n_fft, hop, win_length, center, pad_mode, normalized,
+                                                    onesided, power, False, 1.0, 1e-7), g)
+    if not (needs[0] or needs[1]):
+        return [None, None, grad_bank]
     gp = H.apply_filterbank_backward(g, bank)
+    if not _fast_backward(needs[:2], n_fft, onesided):
+        gw, gwin = _spectrogram_general_backward(wave, window, rest[:7], power, gp, bool(needs[0]), bool(needs[1]))
+        return [gw, gwin, grad_bank]
     z = None if H.backward_recomputes_spectrum(n_fft) else \
         H.stft(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided)
     return [H.stft_backward(z, wave, window, n_fft, hop, win_length, center, pad_mode, normalized, grad_norm=gp, power=power),
-            None, None]
+            None, grad_bank]
 
 
 def _apply_filterbank_hip_backward(saved, rest, needs, grads):
-    if not _signal_path_only(needs) or grads[0] is None:
+    if grads[0] is None:
         return None
-    return [H.apply_filterbank_backward(grads[0], saved[1]), None]
+    spec, bank = saved
+    return [H.apply_filterbank_backward(grads[0], bank) if needs[0] else None,
+            H.filterbank_grad(spec, grads[0]) if needs[1] else None]
 
 
 def _complex_norm_hip_backward(saved, rest, needs, grads):

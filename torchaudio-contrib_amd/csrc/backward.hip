@@ -640,6 +640,31 @@ overlap_add_kernel(FrameGeom g, int n_fft, const float* __restrict__ frames, flo
     }
 }
 
+// Gradient of the window (functional.py:99-107 differentiates through every argument): with gfr the gradient w.r.t.
+// the WINDOWED frame, g_window[n] = sum over (row, frame) of gfr[row][t][n] * padded[row][t*hop + n].  A workgroup owns
+// a chunk of consecutive frames of the flattened (row, frame) index and writes one partial row of n_fft sums
+// (tac_sum_slabs_f32 adds the partial rows up: fixed order, deterministic).
+__global__ void __launch_bounds__(256)
+window_grad_kernel(FrameGeom g, int n_fft, const float* __restrict__ gfr, long long frames_per_block,
+                   float* __restrict__ partial) {
+    const int L = (int)g.length, T = (int)g.n_frames;
+    const long long total = g.rows * (long long)T;
+    const long long f0 = (long long)blockIdx.x * frames_per_block;
+    const long long f1 = f0 + frames_per_block < total ? f0 + frames_per_block : total;
+    for (int n = threadIdx.x; n < n_fft; n += blockDim.x) {
+        float acc = 0.0f;
+        for (long long fi = f0; fi < f1; ++fi) {
+            const long long row = fi / T;
+            const int t = (int)(fi - row * T);
+            bool zero;
+            const int j = padded_index(t * g.hop + n - g.center_pad, L, g.pad_mode, &zero);
+            const float x = zero ? 0.0f : g.wave[row * g.row_stride + j];
+            acc = __builtin_fmaf(gfr[fi * n_fft + n], x, acc);
+        }
+        partial[(long long)blockIdx.x * n_fft + n] = acc;
+    }
+}
+
 // d/dz of |z|^power lives above (norm_pow_grad)
 __global__ void __launch_bounds__(256)
 complex_norm_backward_kernel(const float* __restrict__ z, const float* __restrict__ gout, long long n, float power,
@@ -965,10 +990,36 @@ int tac_overlap_add_f32(const float* grad_frames, const tac_stft_desc* d, float*
     FrameGeom g;
     int64_t T = 0;
     float dummy_window = 0.0f;
-    int rc = make_geometry(grad_frames, &dummy_window, d, &g, &T);
+    int rc = make_geometry(grad_frames, &dummy_window, d, &g, &T, true);     // framing only: any fft_length
     if (rc != TAC_OK) return rc;
     hipLaunchKernelGGL(overlap_add_kernel, dim3(bw_blocks(g.rows * g.length)), dim3(256), 0, (hipStream_t)stream, g,
                        (int)d->n_fft, grad_frames, grad_wave, (long long)grad_row_stride);
+    TAC_HIP(hipGetLastError());
+    return TAC_OK;
+}
+
+int64_t tac_window_grad_partials(const tac_stft_desc* d) {
+    if (!d || d->rows <= 0 || d->n_fft <= 0) return TAC_E_INVALID;
+    const int64_t T = tac_num_frames(d->length, d->n_fft, d->hop, d->center);
+    if (T <= 0) return TAC_E_SHORT_INPUT;
+    const int64_t total = d->rows * T;
+    const int64_t want = (int64_t)tac::device_cu_count() * 4;
+    return total < want ? total : want;
+}
+
+int tac_window_grad_f32(const float* grad_frames_unwindowed, const float* wave, const tac_stft_desc* d, float* partial,
+                        int64_t n_partials, void* stream) {
+    using namespace tac;
+    if (!grad_frames_unwindowed || !wave || !d || !partial || n_partials <= 0) return TAC_E_INVALID;
+    FrameGeom g;
+    int64_t T = 0;
+    float dummy_window = 0.0f;
+    int rc = make_geometry(wave, &dummy_window, d, &g, &T, true);
+    if (rc != TAC_OK) return rc;
+    const long long total = g.rows * (long long)T;
+    const long long per = (total + n_partials - 1) / n_partials;
+    hipLaunchKernelGGL(window_grad_kernel, dim3((unsigned)n_partials), dim3(256), 0, (hipStream_t)stream, g, (int)d->n_fft,
+                       grad_frames_unwindowed, per, partial);
     TAC_HIP(hipGetLastError());
     return TAC_OK;
 }

@@ -227,6 +227,36 @@ __global__ void __launch_bounds__(EW_THREADS) pcm16_kernel(const short* __restri
     for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) out[j] = (float)x[j] * (1.0f / 32768.0f);
 }
 
+// Gradient of a TWO-sided output folded onto the one-sided bins the gradient kernels take: for a real signal
+// X[N - k] = conj(X[k]), so d/dx through bin N - k equals d/dx through bin k with the imaginary part's gradient negated
+// (width 2: (re, im) pairs of the complex stft; width 1: |X|^p values, which simply add).  Bins 0 and N/2 have no twin.
+__global__ void __launch_bounds__(EW_THREADS)
+fold_twosided_kernel(const float* __restrict__ grad, long long n, int n_fft, int n_bins, int width, float* __restrict__ out) {
+    const long long per_frame = (long long)n_bins * width;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long frame = i / per_frame;
+        const int r = (int)(i - frame * per_frame);
+        const int k = r / width, c = r - k * width;
+        const float* src = grad + frame * (long long)n_fft * width;
+        float v = src[(long long)k * width + c];
+        if (k > 0 && 2 * k != n_fft) {
+            const float twin = src[(long long)(n_fft - k) * width + c];
+            v += (c == 1) ? -twin : twin;
+        }
+        out[i] = v;
+    }
+}
+
+// out[i] = sum over slabs s of x[s][i], added in slab order (deterministic)
+__global__ void __launch_bounds__(EW_THREADS)
+sum_slabs_kernel(const float* __restrict__ x, long long n_slabs, long long slab_elems, float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < slab_elems; i += (long long)gridDim.x * blockDim.x) {
+        float acc = 0.0f;
+        for (long long s2 = 0; s2 < n_slabs; ++s2) acc += x[s2 * slab_elems + i];
+        out[i] = acc;
+    }
+}
+
 }  // namespace tac
 
 extern "C" {
@@ -316,6 +346,30 @@ int tac_mulaw_decode_f32_f32(const float* codes, int64_t n, int32_t n_quantize, 
     if (n_quantize < 2) return TAC_E_INVALID;
     const float mu = (float)(n_quantize - 1);
     return tac::launch_unary(codes, n, tac::MulawExpandOp{mu, tac::exact_log1pf(mu), lut, n_quantize}, out, stream);
+}
+
+// ---- helpers of the general gradient routes (gradients of two-sided outputs, of the window and of the filterbank)
+int tac_fold_twosided_f32(const float* grad, int64_t n_frames_total, int32_t n_fft, int32_t width, float* out,
+                          void* stream) {
+    using namespace tac;
+    if (n_frames_total == 0) return TAC_OK;
+    if (!grad || !out || n_frames_total < 0 || n_fft < 1 || (width != 1 && width != 2)) return TAC_E_INVALID;
+    const int n_bins = n_fft / 2 + 1;
+    const long long n = (long long)n_frames_total * n_bins * width;
+    hipLaunchKernelGGL(fold_twosided_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, grad, n, n_fft,
+                       n_bins, width, out);
+    TAC_HIP(hipGetLastError());
+    return TAC_OK;
+}
+
+int tac_sum_slabs_f32(const float* x, int64_t n_slabs, int64_t slab_elems, float* out, void* stream) {
+    using namespace tac;
+    if (slab_elems == 0) return TAC_OK;
+    if (!x || !out || n_slabs < 1 || slab_elems < 0) return TAC_E_INVALID;
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3(ew_blocks(slab_elems)), dim3(EW_THREADS), 0, (hipStream_t)stream, x,
+                       (long long)n_slabs, (long long)slab_elems, out);
+    TAC_HIP(hipGetLastError());
+    return TAC_OK;
 }
 
 }  // extern "C"

@@ -76,14 +76,14 @@ int get_tables(int n_fft, Tables* out) {
 }
 
 int make_geometry(const float* wave, const float* window, const tac_stft_desc* d, FrameGeom* g,
-                  int64_t* n_frames) {
+                  int64_t* n_frames, bool any_size) {
     if (!wave || !window || !d || !g) return TAC_E_INVALID;
     if (d->rows <= 0 || d->length <= 0 || d->hop <= 0 || d->n_fft <= 0) return TAC_E_INVALID;
     if (d->win_length <= 0 || d->win_length > d->n_fft) return TAC_E_INVALID;
     if (d->pad_mode < TAC_PAD_CONSTANT || d->pad_mode > TAC_PAD_CIRCULAR) return TAC_E_INVALID;
     if (d->row_stride < d->length) return TAC_E_INVALID;
     if (d->length >= 0x7fffffffLL - 2 * (int64_t)d->n_fft) return TAC_E_UNSUPPORTED;   // 32-bit sample indices in-kernel
-    if ((!is_pow2(d->n_fft) || d->n_fft < 32 || d->n_fft > 4096) && d->n_fft != 400) return TAC_E_UNSUPPORTED;
+    if (!any_size && (!is_pow2(d->n_fft) || d->n_fft < 32 || d->n_fft > 4096) && d->n_fft != 400) return TAC_E_UNSUPPORTED;
     const int pad = d->center ? d->n_fft / 2 : 0;
     if (pad > 0) {
         // torch's reflect pad needs pad < L, circular needs pad <= L (functional.py:99-107 -> F.pad)

@@ -62,7 +62,8 @@ inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 // Validates a descriptor the way torch.stft does and fills the device-side geometry.
 // Returns TAC_OK or an error code.  T is written to *n_frames.
+// any_size: framing only (overlap-add, window gradient) — accepts every fft_length, not just the FFT kernels' sizes
 int make_geometry(const float* wave, const float* window, const tac_stft_desc* d, FrameGeom* g,
-                  int64_t* n_frames);
+                  int64_t* n_frames, bool any_size = false);
 
 }  // namespace tac

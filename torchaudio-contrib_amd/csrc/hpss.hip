@@ -141,6 +141,9 @@ hpss_tile_kernel(const float* __restrict__ x, int NA, int NB, long long sr, long
                 hpss_masks(harm, perc, power, hard, mh, mp);
                 const long long o = row * sr + (long long)a * sa + (long long)b * sb;
                 const float v = w[HALF + j];                           // the window's own centre tap
+#ifdef TAC_HPSS_ABL_NOSTORE
+                if (mh + mp != 123.0f) continue;
+#endif
                 mh_o[o] = mh;
                 mp_o[o] = mp;
                 if (harm_o) {

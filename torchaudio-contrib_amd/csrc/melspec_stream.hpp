@@ -249,6 +249,11 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     };
     // s0: windowed samples -> pass-0 butterflies -> exchange 0 (write, read-back issued)
     auto s0 = [&](cf (&v)[E], int mode, int row, long long fr) {
+#if TAC_ST_TIMING
+        ST_MARK(1);                                                    // (diagnostic split: what precedes the wait for the samples ...
+        asm volatile("" : : "v"(v[E - 1]), "v"(v[0]));                 //  ... the wait itself (loads return in order) ...
+        ST_MARK(3);                                                    //  ... is booked under stamp 3)
+#endif
         if (mode == 1) {
             decode(v);
         } else {                                                       // edge / unaligned frame: gathered through the exchange
