@@ -936,6 +936,54 @@ def test_general_gradient_routes_under_strict(tac, n_fft, hop, win_length, onesi
     assert rel_err(host(gwin), rwin.numpy()) < 1e-4 and rel_err(host(gbank), rbank.numpy()) < 1e-4
 
 
+def test_fft_length_400_trains_on_the_mixed_radix_kernels(tac):
+    """The 25 ms speech front end (fft_length 400, hop 160) under strict mode: Spectrogram, the 80-band Melspectrogram
+    and the complex stft differentiate w.r.t. the waveform through the inverse form of the mixed-radix kernel
+    (stft_n400_backward_kernel: the 8 x 25 transform on conjugated data) + the gather overlap-add — launch counters
+    asserted — and agree with torch.autograd through the CPU oracle."""
+    assert tac._ops.strict()
+    x = signals.audio_like((3, 1, 16000), seed=331)
+    xc = torch.from_numpy(x).double().requires_grad_(True)
+    xg = dev(x).requires_grad_(True)
+    # power spectrogram
+    for power in (2.0, 1.0):
+        want_y = torch_ref.complex_norm(torch_ref.stft(xc, 400, 160), power)
+        wgt = signals.uniform(tuple(want_y.shape), seed=332)
+        (want,) = torch.autograd.grad((want_y * torch.from_numpy(wgt).double()).sum(), xc)
+        y = tac.Spectrogram(400, 160, power=power).cuda()(xg)
+        before = launches(tac)
+        (got,) = torch.autograd.grad((y * dev(wgt)).sum(), xg)
+        ran = launched_since(tac, before)
+        assert ran == {'tac_stft_f32': 1, 'tac_stft_norm_backward_f32': 1, 'tac_overlap_add_f32': 1}, ran
+        assert rel_err(host(got), want.numpy()) < 1e-4, power
+    # the fused 80-band chain with its dB epilogue (the reference idiom)
+    chain = torch.nn.Sequential(*tac.Melspectrogram(num_mels=80, sample_rate=16000, fft_length=400, hop_length=160),
+                                tac.AmplitudeToDb(amin=1e-5)).cuda()
+    xc32 = torch.from_numpy(x).requires_grad_(True)
+    want_y = torch_ref.melspectrogram_db(xc32, amin=1e-5, n_fft=400, hop=160, num_mels=80, sample_rate=16000)
+    wgt = signals.uniform(tuple(want_y.shape), seed=333)
+    (want,) = torch.autograd.grad((want_y * torch.from_numpy(wgt)).sum(), xc32)
+    y = chain(xg)
+    before = launches(tac)
+    (got,) = torch.autograd.grad((y * dev(wgt)).sum(), xg)
+    ran = launched_since(tac, before)
+    assert ran.get('tac_stft_norm_backward_f32') == 1 and ran.get('tac_overlap_add_f32') == 1 and 'tac_apply_filterbank_f32' not in ran, ran
+    assert rel_err(host(got), want.numpy()) < 1e-3
+    # complex stft, an odd number of frames per unit, short window, not centred
+    xs = signals.audio_like((2, 2, 2011), seed=334)
+    win = (np.hanning(302)[1:-1] + 0.2).astype(np.float32)
+    xsc, wc = torch.from_numpy(xs).double().requires_grad_(True), torch.from_numpy(win).double()
+    want_z = torch_ref.stft(xsc, 400, 77, 300, wc, False, 'reflect', True)
+    wz = signals.uniform(tuple(want_z.shape), seed=335)
+    (want,) = torch.autograd.grad((want_z * torch.from_numpy(wz).double()).sum(), xsc)
+    xsg = dev(xs).requires_grad_(True)
+    z = tac.stft(xsg, 400, 77, 300, dev(win), False, 'reflect', True)
+    before = launches(tac)
+    (got,) = torch.autograd.grad((z * dev(wz)).sum(), xsg)
+    assert launched_since(tac, before) == {'tac_stft_backward_f32': 1, 'tac_overlap_add_f32': 1}
+    assert rel_err(host(got), want.numpy()) < 1e-5
+
+
 def test_backward_without_a_kernel_is_announced(tac):
     """What still differentiates through stock torch operators on the device (ops without gradient kernels, double
     backward) says so: an error under strict mode, a CompositeRouteWarning and a composite_calls entry otherwise."""

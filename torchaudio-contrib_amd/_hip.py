@@ -789,7 +789,7 @@ def _frame_gradients(gs, window, g):
     """one-sided gradient spectrum (rows, T, F, 2) -> frame gradients (rows, T, n_fft), window and scale applied."""
     frames = torch.empty((g.rows, g.n_frames, g.n_fft), dtype=torch.float32, device=gs.device)
     with _native.on_device(gs.device):
-        if g.fft_kernel:
+        if g.fft_kernel or g.mixed_radix:
             rc = _native.lib().tac_stft_backward_f32(_native.ptr(gs), _native.ptr(window), _desc(g, onesided=1),
                                                      _native.ptr(frames), _native.stream_ptr(gs.device))
             _native.check(rc, 'tac_stft_backward_f32')
@@ -867,13 +867,15 @@ def filterbank_grad(spec, grad_out):
 
 
 def stft_backward_supported(n_fft, onesided):
-    return bool(onesided) and fft_kernel_size(n_fft)
+    """one-sided power-of-two sizes and fft_length 400: an inverse-FFT kernel per frame (csrc/backward.hip,
+    csrc/stft_n400.hip); everything else takes ``stft_backward_general``"""
+    return bool(onesided) and (fft_kernel_size(n_fft) or mixed_radix_size(n_fft))
 
 
 def backward_recomputes_spectrum(n_fft):
     """Sizes whose spectrogram backward kernel transforms the frames again itself (16 elements per lane; at 4096 the
     second transform does not fit the registers and the spectrum is recomputed into memory by the stft kernel)."""
-    return n_fft <= 2048
+    return fft_kernel_size(n_fft) and n_fft <= 2048
 
 
 def complex_norm_backward(z, grad_out, power):

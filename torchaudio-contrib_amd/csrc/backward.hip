@@ -23,35 +23,16 @@
 
 namespace tac {
 
+int launch_n400_backward(const FrameGeom& g, const float* gspec, const float* gnorm, float power, float* frames,
+                         hipStream_t stream);                     // stft_n400.hip
+
 constexpr int BW_WAVES = 4;
 
 // One frame (group) per wave-iteration.  y[n] = Re sum_{k=0}^{N/2} G[k] e^{+2 pi i k n / N}:
 //   H[k] = G[k] (0 < k < NC), H[0] = 2 Re G[0], H[NC] = 2 Re G[NC]            (the common 1/2 is folded into the window)
 //   conj(Z[k]) = (conj(H[k]) + H[NC-k]) - i w_k (conj(H[k]) - H[NC-k]),  w_k = e^{-2 pi i k / N}
 //   R = FFT_NC(conj Z);  y[2m] = Re R[m],  y[2m+1] = -Im R[m].
-// d/dz of |z|^power (norm then pow, functional.py:126-128): g * power * |z|^(power-2) * z, 0 at z == 0
-__device__ __noinline__ float norm_pow_factor_general(float s, float power) {      // one copy of powf per kernel
-    return power * powf(sqrtf(s), power - 2.0f);
-}
-template <bool POW2 = false>
-__device__ __forceinline__ cf norm_pow_grad(cf v, float gout, float power) {
-    const float s = v.x * v.x + v.y * v.y;
-    float f;
-    if (POW2 || power == 2.0f) f = 2.0f;
-    else if (s == 0.0f) f = 0.0f;
-    else if (power == 1.0f) f = 1.0f / sqrtf(s);
-    else f = norm_pow_factor_general(s, power);
-    return cscale(v, f * gout);
-}
-
-// Operand of the inverse transform from a pair of the gradient spectrum:  conj(Z[k]) = (conj H[k] + H[NC-k]) - i w_k (conj H[k]
-// - H[NC-k]), on the packed-f32 helpers of fft_core.hpp (5 instructions; written out on scalar components it was 14)
-__device__ __forceinline__ cf c2r_operand(cf hk, cf hm, cf wk) {
-    const cf s = cadd_conj(hm, hk);               // H[NC-k] + conj H[k]
-    const cf nd = csub_conj(hm, hk);              // H[NC-k] - conj H[k]
-    return csub_rot(s, cmul(nd, wk));             // s + i w (H[NC-k] - conj H[k])
-}
-
+// (norm_pow_grad and c2r_operand: fft_core.hpp, shared with the fft_length-400 form in stft_n400.hip)
 // SRC_NORM: `gspec` is the spectrum z itself and `gnorm` the gradient of |z|^power: the gradient spectrum
 // gnorm * d|z|^power/dz is formed on load (tac_stft_norm_backward_f32: the adjoint of Spectrogram in one pass, no
 // gradient spectrum in memory).
@@ -60,7 +41,6 @@ __device__ __forceinline__ cf c2r_operand(cf hk, cf hm, cf wk) {
 // are gathered, and the inverse FFT then runs in the same buffer (tac_spectrogram_backward_f32: per frame 4·hop bytes of
 // samples + 4·F of gradient in, 4·N of frame gradient out; the recomputation costs one FFT and saves writing and reading
 // 8·F bytes of spectrum per frame plus a launch).
-enum { SRC_GRAD = 0, SRC_NORM = 1, SRC_WAVE = 2 };
 
 // POW2: power == 2 (the Melspectrogram chain, layers.py:335): the adjoint's factor is the constant 2
 template <int NC, int E, int SRC, bool POW2>
@@ -722,10 +702,12 @@ static int stft_backward_entry(const float* spec, const float* gnorm, float powe
     // only and the spectrum stands in.
     int rc = make_geometry(spec, window, d, &g, &T);
     if (rc != TAC_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->n_fft == 400)                                   // the mixed-radix form (stft_n400.hip); no in-kernel recomputation
+        return from_wave ? TAC_E_UNSUPPORTED : launch_n400_backward(g, spec, gnorm, power, grad_frames, s);
     Tables tb;
     rc = get_tables(d->n_fft, &tb);
     if (rc != TAC_OK) return rc;
-    hipStream_t s = (hipStream_t)stream;
     switch (d->n_fft) {
         case 32: return launch_stft_backward<16, 16>(g, tb, spec, gnorm, power, grad_frames, s, from_wave);
         case 64: return launch_stft_backward<32, 16>(g, tb, spec, gnorm, power, grad_frames, s, from_wave);

@@ -548,6 +548,35 @@ struct WaveFft {
     }
 };
 
+// ---------------------------------------------------------------- gradient helpers (backward.hip, stft_n400.hip)
+// sources of the inverse transform's gradient spectrum: given, formed from the spectrum and the gradient of |z|^power, or
+// with the spectrum itself recomputed from the waveform inside the kernel
+enum { SRC_GRAD = 0, SRC_NORM = 1, SRC_WAVE = 2 };
+
+// d/dz of |z|^power (norm then pow, functional.py:126-128): g * power * |z|^(power-2) * z, 0 at z == 0
+__device__ __noinline__ inline float norm_pow_factor_general(float s, float power) {      // one copy of powf per kernel
+    return power * powf(sqrtf(s), power - 2.0f);
+}
+template <bool POW2 = false>
+__device__ __forceinline__ cf norm_pow_grad(cf v, float gout, float power) {
+    const float s = v.x * v.x + v.y * v.y;
+    float f;
+    if (POW2 || power == 2.0f) f = 2.0f;
+    else if (s == 0.0f) f = 0.0f;
+    else if (power == 1.0f) f = 1.0f / sqrtf(s);
+    else f = norm_pow_factor_general(s, power);
+    return cscale(v, f * gout);
+}
+
+// Operand of the inverse transform from a pair of the gradient spectrum:  conj(Z[k]) = (conj H[k] + H[NC-k]) - i w_k (conj H[k]
+// - H[NC-k]), on the packed-f32 helpers of fft_core.hpp (5 instructions; written out on scalar components it was 14)
+__device__ __forceinline__ cf c2r_operand(cf hk, cf hm, cf wk) {
+    const cf s = cadd_conj(hm, hk);               // H[NC-k] + conj H[k]
+    const cf nd = csub_conj(hm, hk);              // H[NC-k] - conj H[k]
+    return csub_rot(s, cmul(nd, wk));             // s + i w (H[NC-k] - conj H[k])
+}
+
+
 // ---------------------------------------------------------------- framing
 enum { PAD_CONSTANT = 0, PAD_REFLECT = 1, PAD_REPLICATE = 2, PAD_CIRCULAR = 3 };
 

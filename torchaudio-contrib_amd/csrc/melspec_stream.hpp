@@ -23,6 +23,9 @@
 #pragma once
 #include "mel_common.hpp"
 
+#ifndef TAC_EXP_TW1_EARLY
+#define TAC_EXP_TW1_EARLY 0  // experiment: pass-1 twiddle reads issued ahead of the stage's LDS write burst
+#endif
 #ifndef TAC_ST_TIMING
 #define TAC_ST_TIMING 0     // 1: debug builds of tools/stream_timing.py — per-wave cycle sums overwrite the head of out[]
 #endif
@@ -266,10 +269,11 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     };
     typedef float f4 __attribute__((ext_vector_type(4)));
     // (fast-path frames arrive unwindowed: the window is folded into pass 0's first butterflies, -8 packed instructions)
-    auto s0b = [&](cf (&v)[E], int mode) {
+    auto s0b = [&](cf (&v)[E], int mode, auto&& before_writes) {
         if (mode == 1) Dft<16>::run_windowed(v, win);
         else F::template pass_butterflies<0>(v);
         wave_lds_fence();
+        before_writes();
         F::template pass_write<0, true>(v, xa, t, t);
         wave_lds_fence();
         F::template pass_readback<1>(v, xa, t);
@@ -289,7 +293,7 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     };
     // s12: pass 1, the in-register exchange, pass 2; the lower half of the spectrum stays in registers, the upper half
     // travels to its R2C partners
-    auto s12 = [&](cf (&v)[E], cf (&zm)[F::NPAIR], cf& zmid, const cf (&tw1)[16]) {
+    auto s12 = [&](cf (&v)[E], cf (&zm)[F::NPAIR], cf& zmid, cf (&tw1)[16], bool reload_tw1) {
         if constexpr (FAST2) F::template pass_twiddle<1, true>(v, tw1);
         else F::template pass_twiddle<1>(v, tw);
         F::template pass_butterflies<1>(v);
@@ -298,6 +302,9 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         else F::template pass_twiddle<2>(v, tw);
         F::template pass_butterflies<2>(v);
         wave_lds_fence();
+#if TAC_EXP_TW1_EARLY
+        if (reload_tw1) tw1_issue(tw1);                                // for the other thread's s12: ahead of this stage's LDS burst
+#endif
         F::template pass_write<2, true>(v, xa, t, t);
         wave_lds_fence();
         // partners Z[NC - t - 64 p]: one address register, the rest are immediates (pad(a - c) = pad(a) - pad(c) for
@@ -475,21 +482,27 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         request(vB, iB, modeB, rowB_, frB);
         request(vA, iA, modeA, rowA_, frA);
         s0(vB, modeB, rowB_, frB);
-        s0b(vB, modeB);
+        s0b(vB, modeB, []() {});
         __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0): the loop is entered with nothing in flight
         ST_MARK(6);
 #pragma unroll 1
         while (iA < nloc || iB < nloc) {
             s0(vA, modeA, rowA_, frA);
-            s0b(vA, modeA);
+#if TAC_EXP_TW1_EARLY
+            s0b(vA, modeA, [&]() { tw1_issue(tw1); });
+#else
+            s0b(vA, modeA, []() {});
             tw1_issue(tw1);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(1);
-            s12(vB, zmB, zmidB, tw1);
+            s12(vB, zmB, zmidB, tw1, true);
+#if !TAC_EXP_TW1_EARLY
             tw1_issue(tw1);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(2);
-            s12(vA, zmA, zmidA, tw1);
+            s12(vA, zmA, zmidA, tw1, false);
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(2);
             s3(vB, zmB, zmidB, rowB);
@@ -533,7 +546,7 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(5);
             s0(vB, modeB, rowB_, frB);
-            s0b(vB, modeB);
+            s0b(vB, modeB, []() {});
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(1);
 #if TAC_ST_TIMING

@@ -42,6 +42,7 @@ typedef float q4_f4 __attribute__((ext_vector_type(4)));
 struct Q4Tables {
     const cf* w200;             // [8][Q4_ROW]: W_200^{e(l) k2}
     const cf* w400;             // [8][Q4_ROW]: W_400^{25 k1(l) + k2}
+    const cf* w400b;            // [8][Q4_ROW]: W_400^{e(l) + 8 m} — the C2R twiddles in the transform's INPUT layout (backward)
 };
 
 // The fused Melspectrogram form (MEL): the unit's |X|^p rows stay in LDS (204-float pitch) and are contracted with a
@@ -348,7 +349,7 @@ static int q4_tables(Q4Tables* out) {
         *out = it->second;
         return TAC_OK;
     }
-    std::vector<cf> host(2 * 8 * Q4_ROW, mkc(0.0f, 0.0f));
+    std::vector<cf> host(3 * 8 * Q4_ROW, mkc(0.0f, 0.0f));
     const double two_pi = 6.283185307179586476925286766559;
     for (int l = 0; l < 8; ++l)
         for (int k2 = 0; k2 < Q4_M; ++k2) {
@@ -356,11 +357,13 @@ static int q4_tables(Q4Tables* out) {
             const double b = -two_pi * (double)(25 * q4_k1_of(l) + k2) / 400.0;
             host[l * Q4_ROW + k2] = mkc((float)std::cos(a), (float)std::sin(a));
             host[8 * Q4_ROW + l * Q4_ROW + k2] = mkc((float)std::cos(b), (float)std::sin(b));
+            const double c = -two_pi * (double)(q4_e_of(l) + 8 * k2) / 400.0;
+            host[16 * Q4_ROW + l * Q4_ROW + k2] = mkc((float)std::cos(c), (float)std::sin(c));
         }
     cf* dptr = nullptr;
     TAC_HIP(hipMalloc((void**)&dptr, host.size() * sizeof(cf)));
     TAC_HIP(hipMemcpy(dptr, host.data(), host.size() * sizeof(cf), hipMemcpyHostToDevice));
-    Q4Tables t{dptr, dptr + 8 * Q4_ROW};
+    Q4Tables t{dptr, dptr + 8 * Q4_ROW, dptr + 16 * Q4_ROW};
     cache[dev] = t;
     *out = t;
     return TAC_OK;
@@ -423,6 +426,173 @@ int pack_n400(const std::vector<float>& h, int n_freqs, int n_mels, float* wpack
     if (n_freqs != Q4_BINS) return TAC_E_UNSUPPORTED;
     return pack_lane_mel(h, n_freqs, n_mels, 8, Q4_MEL_PITCH, 1, Q4_FLY, LM_MAX_STEPS, q4_lds_bytes(0), wpack, wpack_cap, desc, desc_cap, info_host,
                          stream);
+}
+
+// ---------------------------------------------------------------- gradient: the inverse real transform per frame
+// grad_frames[row][t][n] = window[n] * scale * Re sum_{k=0}^{200} G[k] e^{+2 pi i k n / 400}  (tac_amd.h (9)) for
+// fft_length 400, on the same mixed-radix core run on conjugated data (the scheme of backward.hip's power-of-two kernel):
+//   H[k] = G[k] (0 < k < 200), H[0] = 2 Re G[0], H[200] = 2 Re G[200];   conj Z[k] = c2r_operand(H[k], H[200 - k], W_400^k)
+//   R = FFT_200(conj Z);   y[2m] = Re R[m], y[2m + 1] = -Im R[m], times window / 2.
+// The core takes its input index p = e + 8 m in lane e, register m — here the FREQUENCY index k — and leaves output index
+// 25 k1 + k2 in lane k1, register k2 — here the sample pair m: every lane ends with fifty consecutive samples of its frame.
+// A unit is eight consecutive frames of one row: their gradient rows (SRC_NORM: spectrum rows + rows of the gradient of
+// |z|^power, the norm's adjoint formed on the way in) are adjacent in memory and are parked in the wave's staging area,
+// which then takes the unit's eight frame gradients and leaves as 16-byte stores.
+template <int SRC, bool POW2>
+__global__ void __launch_bounds__(Q4_WAVES * 64, 2)
+stft_n400_backward_kernel(FrameGeom g, Q4Tables tb, const float* __restrict__ gspec, const float* __restrict__ gnorm,
+                          float power, float* __restrict__ frames) {
+    constexpr int STAGE = Q4_STAGE;
+    constexpr int ROWC = Q4_BINS;                                          // complex per staged gradient row
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* const smem = reinterpret_cast<float*>(smem_raw);
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slot = lane >> 3, l = lane & 7;
+    const int e = l < 4 ? l : 11 - l;
+    const int k1 = ((e & 1) << 2) | (e & 2) | ((e >> 2) & 1);
+    cf* const wstage = reinterpret_cast<cf*>(smem + w * STAGE);
+    cf* const tabs = reinterpret_cast<cf*>(smem + Q4_WAVES * STAGE);
+    cf* const winl = tabs;                                                 // [8][Q4_ROW] window pairs of samples 2 (25 k1 + k2), + 1
+    cf* const w200l = tabs + 8 * Q4_ROW;
+    cf* const w400l = tabs + 16 * Q4_ROW;                                  // input layout: W_400^{e + 8 m}
+    unsigned* const next_unit = reinterpret_cast<unsigned*>(tabs + 24 * Q4_ROW);
+    const float wscale = 0.5f * g.scale;
+    for (int i = threadIdx.x; i < 8 * Q4_ROW; i += Q4_WAVES * 64) {
+        const int ll = i / Q4_ROW, m = i - ll * Q4_ROW;
+        const cf wn = m < Q4_M ? window_pair(g, 25 * q4_k1_of(ll) + m) : mkc(0.0f, 0.0f);
+        winl[i] = mkc(wn.x * wscale, -wn.y * wscale);                      // (y[2m + 1] = -Im R[m])
+        w200l[i] = tb.w200[i];
+        w400l[i] = tb.w400b[i];
+    }
+    const float s1 = e >= 4 ? -1.0f : 1.0f, s2 = (e & 2) ? -1.0f : 1.0f, s3 = (e & 1) ? -1.0f : 1.0f;
+    const float R = 0.70710678118654752f;
+    cf c1 = mkc(1.0f, 0.0f), c2 = mkc(1.0f, 0.0f);
+    if (e == 5) c1 = mkc(R, -R);
+    if (e == 6) c1 = mkc(0.0f, -1.0f);
+    if (e == 7) c1 = mkc(-R, -R);
+    if ((e & 3) == 3) c2 = mkc(0.0f, -1.0f);
+
+    const int T = (int)g.n_frames;
+    const int upr = (T + Q4_G - 1) / Q4_G;
+    const int total = (int)g.rows * upr;
+    const int chunk = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int begin = (int)blockIdx.x * chunk;
+    const int end = begin + chunk < total ? begin + chunk : total;
+    if (threadIdx.x == 0) *next_unit = (unsigned)(begin + Q4_WAVES);
+    __syncthreads();
+    auto grab = [&]() -> int {
+        unsigned v = 0;
+        if (lane == 0) v = __hip_atomic_fetch_add(next_unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return (int)__builtin_amdgcn_readfirstlane(v);
+    };
+    constexpr int NLD = (Q4_G * ROWC + 63) / 64;                           // complex values a lane parks per unit
+    int unit = begin + w;
+    while (unit < end) {
+        const int nxt = grab();
+        const int urow = unit / upr;
+        const int uframe0 = (unit - urow * upr) * Q4_G;
+        const int nlive = (T - uframe0) < Q4_G ? (T - uframe0) : Q4_G;
+        const long long f0 = (long long)urow * T + uframe0;                // first frame of the unit (global frame index)
+        // (1) the unit's gradient rows -> staging area (rows past the end of the waveform's frames: zeros)
+        {
+            const cf* src = reinterpret_cast<const cf*>(gspec) + f0 * ROWC;
+            const float* gn = (SRC == SRC_NORM) ? gnorm + f0 * ROWC : nullptr;
+            const int live = nlive * ROWC;
+            cf val[NLD];
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int idx = lane + 64 * i;
+                const int c = idx < live ? idx : live - 1;
+                val[i] = src[c];
+                if constexpr (SRC == SRC_NORM) val[i] = norm_pow_grad<POW2>(val[i], gn[c], power);
+            }
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int idx = lane + 64 * i;
+                if (idx < Q4_G * ROWC) {
+                    cf x = idx < live ? val[i] : mkc(0.0f, 0.0f);
+                    const int k = idx % ROWC;
+                    if (k == 0 || k == 200) x = mkc(2.0f * x.x, 0.0f);      // H[0] = 2 Re G[0], H[200] = 2 Re G[200]
+                    wstage[idx] = x;
+                }
+            }
+        }
+        wave_lds_fence();
+        // (2) operands of the inverse transform: conj Z[e + 8 m]
+        cf v[Q4_M];
+        {
+            cf tw[Q4_M];
+            q4_read_row(w400l + l * Q4_ROW, tw);
+            const cf* row = wstage + slot * ROWC;
+#pragma unroll
+            for (int m = 0; m < Q4_M; ++m) {
+                const cf hk = row[e + 8 * m], hm = row[200 - e - 8 * m];
+                v[m] = c2r_operand(hk, hm, tw[m]);
+            }
+        }
+        q4_dft25(v);
+        {
+            cf tw[Q4_M];
+            q4_read_row(w200l + l * Q4_ROW, tw);
+#pragma unroll
+            for (int k = 1; k < Q4_M; ++k) v[k] = cmul(v[k], tw[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < Q4_M; ++k) {
+            cf p = q4_dpp<Q4_HALF_MIRROR>(v[k]);
+            v[k] = cmul(__builtin_elementwise_fma(v[k], mkc(s1, s1), p), c1);
+            p = q4_dpp<Q4_QUAD_XOR2>(v[k]);
+            v[k] = cmul(__builtin_elementwise_fma(v[k], mkc(s2, s2), p), c2);
+            p = q4_dpp<Q4_QUAD_XOR1>(v[k]);
+            v[k] = __builtin_elementwise_fma(v[k], mkc(s3, s3), p);
+        }
+        wave_lds_fence();                                                  // every lane's row reads precede the frame writes
+        // (3) windowed sample pairs 25 k1 + k2 of the frame -> staging area (frame-major: 200 pairs per frame)
+        {
+            cf wn[Q4_M];
+            q4_read_row(winl + l * Q4_ROW, wn);
+            cf* fr = wstage + slot * 200 + 25 * k1;
+#pragma unroll
+            for (int k = 0; k < Q4_M; ++k) fr[k] = cmul_elem(v[k], wn[k]);
+        }
+        wave_lds_fence();
+        // (4) the live frames leave as 16-byte stores (a frame is 1600 bytes: the unit's run is 16-byte aligned)
+        {
+            const q4_f4* s4 = reinterpret_cast<const q4_f4*>(wstage);
+            q4_f4* g4 = reinterpret_cast<q4_f4*>(frames + f0 * 400);
+            const int nch = nlive * 100;
+#pragma unroll
+            for (int i = 0; i < (Q4_G * 100 + 63) / 64; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nch) g4[c] = s4[c];
+            }
+        }
+        wave_lds_fence();
+        unit = nxt;
+    }
+}
+
+// tac_stft_backward_f32 / tac_stft_norm_backward_f32 for fft_length 400 (backward.hip's dispatcher calls this)
+int launch_n400_backward(const FrameGeom& g, const float* gspec, const float* gnorm, float power, float* frames,
+                         hipStream_t stream) {
+    Q4Tables tb;
+    const int rc = q4_tables(&tb);
+    if (rc != TAC_OK) return rc;
+    if ((reinterpret_cast<uintptr_t>(gspec) & 7u) || (reinterpret_cast<uintptr_t>(frames) & 15u)) return TAC_E_UNSUPPORTED;
+    const long long units = g.rows * ((g.n_frames + Q4_G - 1) / Q4_G);
+    if (units >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
+    const size_t bytes = q4_lds_bytes(0);
+    long long blocks = (units + Q4_WAVES - 1) / Q4_WAVES;
+    const long long cap = (long long)device_cu_count();
+    if (blocks > cap) blocks = cap;
+    void (*kern)(FrameGeom, Q4Tables, const float*, const float*, float, float*);
+    if (!gnorm) kern = stft_n400_backward_kernel<SRC_GRAD, false>;
+    else kern = power == 2.0f ? stft_n400_backward_kernel<SRC_NORM, true> : stft_n400_backward_kernel<SRC_NORM, false>;
+    if (bytes > 64 * 1024) TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Q4_WAVES * 64), bytes, stream, g, tb, gspec, gnorm, power, frames);
+    TAC_HIP(hipGetLastError());
+    return TAC_OK;
 }
 
 // Entry used by stft_kernels.hip's dispatcher: TAC_E_UNSUPPORTED when this form does not apply (two-sided output,
