@@ -152,6 +152,12 @@ int tac_apply_filterbank_sparse_f32(const float* spec, int64_t rows, int32_t n_f
                                     int64_t stride_r, int64_t stride_t, const float* wpack,
                                     const int32_t* desc, const int32_t* info_host, int32_t n_mels,
                                     float* out, void* stream);
+/* ... followed by functional.amplitude_to_db (db != 0: 10 (log10(max(x^2, db_amin)) - log10 db_ref)) in the same pass: the
+ *      filterbank + dB tail of Melspectrogram -> AmplitudeToDb for the sizes without a fully fused kernel (fft_length 4096). */
+int tac_apply_filterbank_sparse_db_f32(const float* spec, int64_t rows, int32_t n_freqs, int64_t n_frames,
+                                       int64_t stride_r, int64_t stride_t, const float* wpack, const int32_t* desc,
+                                       const int32_t* info_host, int32_t n_mels, int db, float db_ref, float db_amin,
+                                       float* out, void* stream);
 
 /* (5) functional.complex_norm, functional.py:116-128: out[i] = |(x[2i], x[2i+1])|^power. */
 int tac_complex_norm_f32(const float* x, int64_t n, float power, float* out, void* stream);

@@ -262,13 +262,24 @@ def g9():
     np.savez_compressed(os.path.join(GOLD, 'g9_mulaw_mel.npz'), **out)
 
 
+def g10():
+    """Melspectrogram (-> AmplitudeToDb) at fft_length 4096 (layers.py:307-381; BASELINE configs[3]'s geometry with the
+    mel tail of configs[2]: 44.1 kHz, 128 bands over 2049 bins, bands up to 129 bins wide)."""
+    x = T(signals.audio_like((2, 2, 30000), seed=71))
+    mel = ref.Melspectrogram(num_mels=128, sample_rate=44100, fft_length=4096, hop_length=1024)
+    out = {'mel': np32(mel(x)), 'mel_db': np32(torch.nn.Sequential(*mel, ref.AmplitudeToDb())(x))}
+    mel80 = ref.Melspectrogram(num_mels=80, sample_rate=48000, fft_length=4096, hop_length=1024, htk=True, min_freq=50.0)
+    out['mel80_htk'] = np32(mel80(x))
+    np.savez_compressed(os.path.join(GOLD, 'g10_mel4096.npz'), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--skip-scan', action='store_true', help='reuse thresholds from the existing g5 file')
     ap.add_argument('--only', default='')
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
-    jobs = {'g1': g1, 'g2': g2, 'g3': g3, 'g4': g4, 'g5': lambda: g5(a.skip_scan), 'g6': g6, 'g7': g7, 'g8': g8, 'g9': g9}
+    jobs = {'g1': g1, 'g2': g2, 'g3': g3, 'g4': g4, 'g5': lambda: g5(a.skip_scan), 'g6': g6, 'g7': g7, 'g8': g8, 'g9': g9, 'g10': g10}
     for name, fn in jobs.items():
         if a.only and name not in a.only.split(','):
             continue

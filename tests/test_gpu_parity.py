@@ -1240,6 +1240,32 @@ def test_hpss_tile_kernel_every_width_both_layouts_and_nan(tac):
         assert np.array_equal(np.isnan(host(got5[2])), np.isnan(want5[2].numpy()))
 
 
+def test_g10_melspectrogram_fft_length_4096(tac, golden):
+    """Melspectrogram (-> AmplitudeToDb) at fft_length 4096 against the reference's outputs (golden g10): no fully fused
+    kernel fits the LDS at this size (two 1024-point exchange areas per wave + 41 KB of weights), so the chain is TWO
+    launches — the 4096-point spectrogram kernel and the band-sparse streaming filterbank kernel with the dB epilogue
+    riding on it (round 2: three, with the dense MFMA GEMM in the middle).  Also the standalone apply_filterbank on
+    2049-bin rows, dB off."""
+    g = golden('g10_mel4096')
+    x = dev(signals.audio_like((2, 2, 30000), seed=71))
+    mel = tac.Melspectrogram(num_mels=128, sample_rate=44100, fft_length=4096, hop_length=1024).cuda()
+    before = launches(tac)
+    got = tac.realize(mel(x))
+    assert launched_since(tac, before) == {'tac_spectrogram_f32': 1, 'tac_apply_filterbank_sparse_f32': 1}
+    assert rel_err(host(got), g['mel']) < 1e-5
+    chain = torch.nn.Sequential(*mel, tac.AmplitudeToDb()).cuda()
+    before = launches(tac)
+    got_db = chain(x)
+    assert launched_since(tac, before) == {'tac_spectrogram_f32': 1, 'tac_apply_filterbank_sparse_db_f32': 1}
+    assert np.abs(host(got_db) - g['mel_db']).max() < DB_ABS
+    mel80 = tac.Melspectrogram(num_mels=80, sample_rate=48000, fft_length=4096, hop_length=1024, htk=True, min_freq=50.0).cuda()
+    assert rel_err(host(tac.realize(mel80(x))), g['mel80_htk']) < 1e-5
+    # a longer input: more frames than waves, rows of different phase
+    xl = signals.audio_like((3, 1, 250000), seed=72)
+    want = torch_ref.melspectrogram_db(torch.from_numpy(xl), num_mels=128, sample_rate=44100, n_fft=4096, hop=1024).numpy()
+    assert np.abs(host(chain(dev(xl))) - want).max() < DB_ABS
+
+
 def test_coded_waveforms_fused_into_the_frame_load(tac, golden):
     """int16 PCM and 8-bit mu-law codes (uint8 or the int64 mu_law_encoding returns) are converted in
     registers inside the fused kernel's frame load — ONE launch, the decoded waveform never exists — and agree with the

@@ -220,3 +220,15 @@ def test_g8_hpss(golden):
         for name, r in zip(('harm', 'perc', 'mask_harm', 'mask_perc'), res):
             want = g[tag + '_' + name]
             assert np.abs(r.numpy().astype(np.float32) - want.astype(np.float32)).max() <= 1e-6 * max(1.0, np.abs(want).max()), (tag, name)
+
+
+def test_g10_mel4096(golden):
+    """the oracle's Melspectrogram (-> dB) at fft_length 4096 against the reference's outputs (golden g10)."""
+    g = golden('g10_mel4096')
+    x = T(signals.audio_like((2, 2, 30000), seed=71))
+    mel = torch_ref.melspectrogram(x, num_mels=128, sample_rate=44100, n_fft=4096, hop=1024)
+    assert rel_err(mel.numpy(), g['mel']) < 1e-6
+    db = torch_ref.melspectrogram_db(x, num_mels=128, sample_rate=44100, n_fft=4096, hop=1024)
+    assert np.abs(db.numpy() - g['mel_db']).max() < 1e-4
+    mel80 = torch_ref.melspectrogram(x, num_mels=80, sample_rate=48000, min_freq=50.0, htk=True, n_fft=4096, hop=1024)
+    assert rel_err(mel80.numpy(), g['mel80_htk']) < 1e-6

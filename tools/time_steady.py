@@ -25,7 +25,9 @@ mel400 = torch.nn.Sequential(*tac.Melspectrogram(num_mels=80, sample_rate=16000,
 stft400, spec400 = tac.STFT(400, 160).cuda(), tac.Spectrogram(400, 160, power=2.).cuda()
 mel256 = torch.nn.Sequential(*tac.Melspectrogram(num_mels=40, sample_rate=8000, fft_length=256, hop_length=64),
                              tac.AmplitudeToDb()).cuda()                   # the three-phase band-sparse kernel
-fns = {'mel256': lambda: tac.realize(mel256(x5)), 'mel400': lambda: tac.realize(mel400(x5)), 'stft400': lambda: tac.realize(stft400(x5)), 'spec400': lambda: spec400(x5),
+mel4k = torch.nn.Sequential(*tac.Melspectrogram(num_mels=128, sample_rate=48000, fft_length=4096, hop_length=1024),
+                            tac.AmplitudeToDb()).cuda()
+fns = {'mel4096': lambda: tac.realize(mel4k(x4)), 'mel256': lambda: tac.realize(mel256(x5)), 'mel400': lambda: tac.realize(mel400(x5)), 'stft400': lambda: tac.realize(stft400(x5)), 'spec400': lambda: spec400(x5),
        'stft': lambda: tac.realize(stft(x)), 'spec': lambda: spec(x), 'mel': lambda: tac.realize(mel(x)),
        'stft4096': lambda: tac.realize(stft4(x4)), 'spec4096': lambda: spec4(x4),
        'stft512': lambda: tac.realize(stft512(x5)), 'spec512': lambda: spec512(x5),

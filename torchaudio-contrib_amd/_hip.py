@@ -269,11 +269,11 @@ def _melbank_pack(fb, n_fft):
     if n_fft in cache[1]:
         return cache[1][n_fft]
     n_freqs, n_mels = fb.shape
-    wpack = torch.empty(16384, dtype=torch.float32, device=fb.device)
+    wpack = torch.empty(24576, dtype=torch.float32, device=fb.device)
     desc = torch.empty(4096, dtype=torch.int32, device=fb.device)
     info = (ctypes.c_int32 * 8)()
     with _native.on_device(fb.device):
-        rc = _native.lib().tac_melbank_pack(_native.ptr(fb), n_freqs, n_mels, n_fft, _native.ptr(wpack), 16384,
+        rc = _native.lib().tac_melbank_pack(_native.ptr(fb), n_freqs, n_mels, n_fft, _native.ptr(wpack), 24576,
                                             _native.ptr(desc), 4096, ctypes.cast(info, ctypes.c_void_p),
                                             _native.stream_ptr(fb.device))
     if rc == _native.TAC_E_UNSUPPORTED:
@@ -343,11 +343,10 @@ def melspectrogram(wave, window, fb, n_fft, hop, win_length, center, pad_mode, n
             g.routes.clear()
         route = _fused_mel_route(g, fb, power)
         g.routes[rkey] = (weakref.ref(fb), route)
-    if route is None:
+    if route is None:       # (fft_length 4096, |X|^p with p outside {1, 2}, banks the fused kernels reject)
         spec = spectrogram(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided, power,
                            False, 1.0, 1e-7)
-        mel = apply_filterbank(spec, fb)
-        return amplitude_to_db(mel, ref, amin) if db else mel
+        return apply_filterbank(spec, fb, db=(ref, amin) if db else None)    # the dB epilogue rides on the filterbank kernel
     n_mels = fb.shape[1]
     src = _rows_of(wave, g)
     out = torch.empty(g.lead + (g.n_frames, n_mels), dtype=torch.float32, device=wave.device)
@@ -373,7 +372,9 @@ def melspectrogram(wave, window, fb, n_fft, hop, win_length, center, pad_mode, n
 
 
 # ----------------------------------------------------------------------------- filterbank
-def apply_filterbank(spec, fb, allow_sparse=True):
+def apply_filterbank(spec, fb, allow_sparse=True, db=None):
+    """``db = (ref, amin)``: followed by ``amplitude_to_db`` — in the same launch when the band-sparse streaming kernel
+    takes the call, as a second kernel behind the MFMA GEMM."""
     fb = fb if fb.is_contiguous() else fb.contiguous()
     n_freqs, n_frames = spec.shape[-2], spec.shape[-1]
     lead = tuple(spec.shape[:-2])
@@ -387,13 +388,21 @@ def apply_filterbank(spec, fb, allow_sparse=True):
         if pack is not None:
             wpack, desc, info = pack
             with _native.on_device(spec.device):
-                rc = _native.lib().tac_apply_filterbank_sparse_f32(
-                    _native.ptr(rows), rows.shape[0], n_freqs, n_frames, rows.stride(0) if rows.shape[0] > 1 else 0,
-                    rows.stride(2), _native.ptr(wpack), _native.ptr(desc), ctypes.cast(info, ctypes.c_void_p), n_mels,
-                    _native.ptr(out), _native.stream_ptr(spec.device))
+                if db is None:
+                    name = 'tac_apply_filterbank_sparse_f32'
+                    rc = _native.lib().tac_apply_filterbank_sparse_f32(
+                        _native.ptr(rows), rows.shape[0], n_freqs, n_frames, rows.stride(0) if rows.shape[0] > 1 else 0,
+                        rows.stride(2), _native.ptr(wpack), _native.ptr(desc), ctypes.cast(info, ctypes.c_void_p), n_mels,
+                        _native.ptr(out), _native.stream_ptr(spec.device))
+                else:
+                    name = 'tac_apply_filterbank_sparse_db_f32'
+                    rc = _native.lib().tac_apply_filterbank_sparse_db_f32(
+                        _native.ptr(rows), rows.shape[0], n_freqs, n_frames, rows.stride(0) if rows.shape[0] > 1 else 0,
+                        rows.stride(2), _native.ptr(wpack), _native.ptr(desc), ctypes.cast(info, ctypes.c_void_p), n_mels,
+                        1, float(db[0]), float(db[1]), _native.ptr(out), _native.stream_ptr(spec.device))
             if rc != _native.TAC_E_UNSUPPORTED:
-                _native.check(rc, 'tac_apply_filterbank_sparse_f32')
-                _count('tac_apply_filterbank_sparse_f32')
+                _native.check(rc, name)
+                _count(name)
                 return out.transpose(-2, -1)
         plan, _ = _filterbank_plan(fb)
         with _native.on_device(spec.device):
@@ -403,7 +412,8 @@ def apply_filterbank(spec, fb, allow_sparse=True):
                 _native.stream_ptr(spec.device))
         _native.check(rc, 'tac_apply_filterbank_f32')
         _count('tac_apply_filterbank_f32')
-    return out.transpose(-2, -1)
+    out = out.transpose(-2, -1)
+    return out if db is None else amplitude_to_db(out, db[0], db[1])
 
 
 # ----------------------------------------------------------------------------- complex pairs

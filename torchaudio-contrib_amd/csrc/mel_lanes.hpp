@@ -29,7 +29,8 @@ struct LaneMel {
     float* out;                 // [rows][T][n_mels]
 };
 
-constexpr int LM_MAX_MELS = 128, LM_MIN_MELS = 8, LM_MAX_STEPS = 12, LM_MAX_STEPS_WAVE = 16;   // (LANES = 64: one frame per wave, two slots)
+constexpr int LM_MAX_MELS = 128, LM_MIN_MELS = 8, LM_MAX_STEPS = 12;
+constexpr int LM_MAX_STEPS_WAVE = 36;   // LANES = 64 (one frame per wave, two slots): bands up to 144 bins — 128 mel bands over 2049 bins
 constexpr int LM_MARK = 1000;                                              // info_host[2] = LM_MARK + lanes per frame
 typedef float lm_f4 __attribute__((ext_vector_type(4)));
 
@@ -63,6 +64,40 @@ __device__ __forceinline__ void lane_mel_contract(float* srow, int bins, const i
     const float ten_log10_ref = 10.0f * mel.log10_ref;
     if (l < 3) srow[bins + l] = 0.0f;                                      // slack taps carry zero weights: keep them finite
     wave_lds_fence();
+    if constexpr (S > FLY) {
+        // a slot longer than FLY steps (standalone apply_filterbank on 2049-bin rows: up to 36): FLY of its steps in flight
+        // at a time, one slot after the other
+        int lo_c = mlo[l];
+#pragma unroll 1
+        for (int i0 = 0; i0 < mel.nslot; ++i0) {
+            cf acc0 = mkc(0.0f, 0.0f), acc1 = mkc(0.0f, 0.0f);
+            const lm_f4* wp = reinterpret_cast<const lm_f4*>(mwl) + i0 * (S * LANES) + l;
+            const lm_f4* pp = reinterpret_cast<const lm_f4*>(srow + lo_c);
+            lo_c = mlo[LANES * (i0 + 1) + l];                                // (table padded by one group)
+#pragma unroll
+            for (int c0 = 0; c0 < S; c0 += FLY) {
+                lm_f4 wv[FLY], pv[FLY];
+#pragma unroll
+                for (int j = 0; j < FLY; ++j)
+                    if (c0 + j < S) {
+                        wv[j] = wp[(c0 + j) * LANES];
+                        pv[j] = pp[c0 + j];
+                    }
+#pragma unroll
+                for (int j = 0; j < FLY; ++j)
+                    if (c0 + j < S) {
+                        acc0 = __builtin_elementwise_fma(mkc(wv[j].x, wv[j].y), mkc(pv[j].x, pv[j].y), acc0);
+                        acc1 = __builtin_elementwise_fma(mkc(wv[j].z, wv[j].w), mkc(pv[j].z, pv[j].w), acc1);
+                    }
+                asm volatile("" : "+v"(acc0), "+v"(acc1) : : "memory");      // the next chunk's reads stay behind these FMAs
+            }
+            float val = (acc0.x + acc0.y) + (acc1.x + acc1.y);
+            if (mel.db) val = fast_db ? amp_to_db_fast(val, mel.amin, ten_log10_ref) : amp_to_db(val, mel.amin, mel.log10_ref);
+            const int band = LANES * i0 + l;
+            if (band < mel.n_mels) mrow[band] = val;
+        }
+        return;
+    }
     int lo_g[GS];
 #pragma unroll
     for (int q = 0; q < GS; ++q) lo_g[q] = mlo[LANES * q + l];

@@ -411,11 +411,12 @@ static int launch_stream(FrameGeom g, const Tables& tb, const SparseArgs& sm, co
 // the frame's row in its own LDS buffer (16-byte chunks, the next frame's requested before this one is contracted),
 // contracts it and stores the band row — no workgroup barrier, no tile.  (fb_sparse_kernel above, round 1's 16-frame
 // tiles between barriers, stays the route for banks outside this layout and for other frame strides.)
-constexpr int FBL_WAVES = 8, FBL_FLY = 16, FBL_CHUNKS = 5;                  // up to 5 x 256 = 1280 bins per frame
+constexpr int FBL_WAVES = 8, FBL_FLY = 16;
+constexpr int FBL_CHUNKS = 5, FBL_CHUNKS_WIDE = 9;   // 16-byte chunks per lane and frame: up to 1280 / 2304 bins (fft_length 2048 / 4096)
 __host__ __device__ inline int fbl_pitch(int n_freqs) { return (n_freqs + 3 + 3) & ~3; }
 inline size_t fbl_base_lds(int n_freqs) { return (size_t)FBL_WAVES * (fbl_pitch(n_freqs) + LM_MAX_MELS + 4) * sizeof(float) + 16; }
 
-template <int S>
+template <int S, int CHUNKS>
 __global__ void __launch_bounds__(FBL_WAVES * 64, 2)
 fb_lanes_kernel(const float* __restrict__ spec, long long rows, int n_freqs, long long n_frames, long long stride_r,
                 long long stride_t, LaneMel mel) {
@@ -447,14 +448,14 @@ fb_lanes_kernel(const float* __restrict__ spec, long long rows, int n_freqs, lon
     // a frame's row as 16-byte chunks (global loads only need dword alignment); chunks past the row are clamped to its
     // last full one (the slack behind the bins is zeroed by the contraction)
     const int nch = (n_freqs + 3) >> 2, lastc = (n_freqs >> 2) - 1;         // chunk `nch - 1` may straddle the row's end
-    f4 nxt[FBL_CHUNKS];
+    f4 nxt[CHUNKS];
     float tail[3];
     auto request = [&](int i) {
         const long long gf = begin + i;
         const long long r = gf / n_frames;
         const float* src = spec + r * stride_r + (gf - r * n_frames) * stride_t;
 #pragma unroll
-        for (int u = 0; u < FBL_CHUNKS; ++u) {
+        for (int u = 0; u < CHUNKS; ++u) {
             const int c = lane + 64 * u;
             nxt[u] = *reinterpret_cast<const f4*>(src + 4 * (c < lastc ? c : lastc));
         }
@@ -463,7 +464,7 @@ fb_lanes_kernel(const float* __restrict__ spec, long long rows, int n_freqs, lon
     };
     auto deposit = [&]() {
 #pragma unroll
-        for (int u = 0; u < FBL_CHUNKS; ++u) {
+        for (int u = 0; u < CHUNKS; ++u) {
             const int c = lane + 64 * u;
             if (c <= lastc) *reinterpret_cast<f4*>(srow + 4 * c) = nxt[u];
         }
@@ -486,7 +487,7 @@ fb_lanes_kernel(const float* __restrict__ spec, long long rows, int n_freqs, lon
     }
 }
 
-template <int S>
+template <int S, int CHUNKS>
 static int launch_fb_lanes(const float* spec, long long rows, int n_freqs, long long n_frames, long long stride_r,
                            long long stride_t, const LaneMel& mel, hipStream_t stream) {
     const size_t bytes = fbl_base_lds(n_freqs) + lm_lds_bytes(64, mel.wtot);
@@ -495,7 +496,7 @@ static int launch_fb_lanes(const float* spec, long long rows, int n_freqs, long 
     if (total >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
     long long blocks = (total + FBL_WAVES - 1) / FBL_WAVES;
     if (blocks > device_cu_count()) blocks = device_cu_count();
-    auto kern = fb_lanes_kernel<S>;
+    auto kern = fb_lanes_kernel<S, CHUNKS>;
     if (bytes > 64 * 1024) TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(FBL_WAVES * 64), bytes, stream, spec, rows, n_freqs, n_frames, stride_r,
                        stride_t, mel);
@@ -629,7 +630,7 @@ int tac_melbank_pack(const float* fb, int32_t n_freqs, int32_t n_mels, int32_t n
     TAC_HIP(hipStreamSynchronize((hipStream_t)stream));
     if (n_fft == 2048)
         return pack_lanes(h, n_freqs, n_mels, wpack, wpack_cap, desc, desc_cap, info_host, (hipStream_t)stream);
-    if (n_fft == 0 && n_freqs >= 8 && (n_freqs + 3) / 4 <= FBL_CHUNKS * 64) {   // standalone: one frame per wave
+    if (n_fft == 0 && n_freqs >= 8 && (n_freqs + 3) / 4 <= FBL_CHUNKS_WIDE * 64) {   // standalone: one frame per wave
         const int rc = pack_lane_mel(h, n_freqs, n_mels, 64, fbl_pitch(n_freqs), 2, FBL_FLY, LM_MAX_STEPS_WAVE, fbl_base_lds(n_freqs),
                                      wpack, wpack_cap, desc, desc_cap, info_host, (hipStream_t)stream);
         if (rc != TAC_E_UNSUPPORTED) return rc;                             // else: the tile kernel's layout
@@ -766,18 +767,35 @@ int tac_melspec_sparse_coded_f32(const void* samples, int32_t sample_format, con
 int tac_apply_filterbank_sparse_f32(const float* spec, int64_t rows, int32_t n_freqs, int64_t n_frames,
                                     int64_t stride_r, int64_t stride_t, const float* wpack, const int32_t* desc,
                                     const int32_t* info_host, int32_t n_mels, float* out, void* stream) {
+    return tac_apply_filterbank_sparse_db_f32(spec, rows, n_freqs, n_frames, stride_r, stride_t, wpack, desc, info_host, n_mels, 0,
+                                              1.0f, 1e-7f, out, stream);
+}
+
+int tac_apply_filterbank_sparse_db_f32(const float* spec, int64_t rows, int32_t n_freqs, int64_t n_frames,
+                                       int64_t stride_r, int64_t stride_t, const float* wpack, const int32_t* desc,
+                                       const int32_t* info_host, int32_t n_mels, int db, float db_ref, float db_amin,
+                                       float* out, void* stream) {
     using namespace tac;
     if (rows == 0 || n_frames == 0) return TAC_OK;
     if (!spec || !wpack || !desc || !info_host || !out) return TAC_E_INVALID;
     if (rows < 0 || n_freqs <= 0 || n_frames < 0 || n_mels <= 0) return TAC_E_INVALID;
+    if (db && !(db_ref > 0.0f)) return TAC_E_INVALID;
+    const float log10_ref = db ? log10f(db_ref) : 0.0f;
     if (info_host[2] == LM_MARK + 64) {                                            // lane layout: the wave-autonomous kernel
         if (!lane_mel_info_ok(info_host, 64, FBL_FLY, LM_MAX_STEPS_WAVE)) return TAC_E_INVALID;
-        if (n_mels < LM_MIN_MELS || n_mels > LM_MAX_MELS || (n_freqs + 3) / 4 > FBL_CHUNKS * 64) return TAC_E_UNSUPPORTED;
-        const LaneMel lm{wpack, desc, info_host[1], info_host[0], n_mels, 0, 0.0f, 0.0f, out};
+        const int chunks = (n_freqs + 3) / 4;
+        if (n_mels < LM_MIN_MELS || n_mels > LM_MAX_MELS || chunks > FBL_CHUNKS_WIDE * 64) return TAC_E_UNSUPPORTED;
+        const LaneMel lm{wpack, desc, info_host[1], info_host[0], n_mels, db ? 1 : 0, db_amin, log10_ref, out};
         const long long sr = rows > 1 ? stride_r : 0;
+        const bool wide = chunks > FBL_CHUNKS * 64;
         switch (info_host[4]) {
-#define TAC_FBL_CASE(SS) case SS: return launch_fb_lanes<SS>(spec, rows, n_freqs, n_frames, sr, stride_t, lm, (hipStream_t)stream);
-            TAC_FBL_CASE(2) TAC_FBL_CASE(4) TAC_FBL_CASE(6) TAC_FBL_CASE(8) TAC_FBL_CASE(10) TAC_FBL_CASE(12) TAC_FBL_CASE(14) TAC_FBL_CASE(16)
+#define TAC_FBL_CASE(SS)                                                                                                    \
+    case SS:                                                                                                               \
+        return wide ? launch_fb_lanes<SS, FBL_CHUNKS_WIDE>(spec, rows, n_freqs, n_frames, sr, stride_t, lm, (hipStream_t)stream) \
+                    : launch_fb_lanes<SS, FBL_CHUNKS>(spec, rows, n_freqs, n_frames, sr, stride_t, lm, (hipStream_t)stream);
+            TAC_FBL_CASE(2) TAC_FBL_CASE(4) TAC_FBL_CASE(6) TAC_FBL_CASE(8) TAC_FBL_CASE(10) TAC_FBL_CASE(12) TAC_FBL_CASE(14)
+            TAC_FBL_CASE(16) TAC_FBL_CASE(18) TAC_FBL_CASE(20) TAC_FBL_CASE(22) TAC_FBL_CASE(24) TAC_FBL_CASE(26) TAC_FBL_CASE(28)
+            TAC_FBL_CASE(30) TAC_FBL_CASE(32) TAC_FBL_CASE(34) TAC_FBL_CASE(36)
 #undef TAC_FBL_CASE
             default: return TAC_E_INVALID;
         }
@@ -787,7 +805,7 @@ int tac_apply_filterbank_sparse_f32(const float* spec, int64_t rows, int32_t n_f
     int prow = n_freqs + 7;
     prow += (34 - (prow & 31)) & 31;                                               // == 2 (mod 32): conflict-free, 8-byte rows
     const int out_vec4 = ((n_mels & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0);
-    SparseArgs m{wpack, desc, info_host[0], info_host[1], n_mels, 0, 0.0f, 0.0f, out, out_vec4};
+    SparseArgs m{wpack, desc, info_host[0], info_host[1], n_mels, db ? 1 : 0, db_amin, log10_ref, out, out_vec4};
     const int ostr = sparse_ostr(n_mels, out_vec4);
     const size_t lds_bytes = (size_t)FBS_TILE * prow * 4 + (size_t)m.wtot * 4 + (size_t)((FBS_TILE * ostr + 3) & ~3) * 4 +
                              (size_t)FBS_WAVES * 4 * m.dstride * 4;
