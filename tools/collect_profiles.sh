@@ -2,7 +2,7 @@
 # Run ON THE GPU BOX (via gpurun): rocprofv3 kernel trace of the bench command + separate PMC passes for the
 # dominant kernels.  Writes under gpurun_out/$1/; tools/summarize_profiles.py turns it into profiles/$1/.
 set -u
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/$tag
 export TMPDIR=/tmp
 mkdir -p $out
@@ -19,6 +19,17 @@ done
 # the filterbank stage on the matrix cores (dense bank): MFMA instruction / busy counters of gemm_fb_kernel
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_fb_mfma -o p -- python tools/prof_driver.py fb 3 > /dev/null 2>&1
 # backward of the fused chain: which kernels, how long
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_grad -o grad -- python tools/prof_driver.py grad 5 > $out/kt_grad.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_gradf -o gradf -- python tools/prof_driver.py gradf 5 > $out/kt_gradf.log 2>&1
+# (120 back-to-back training steps each: steady-state clocks, not the five cold launches of round 2)
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_grad -o grad -- python tools/prof_driver.py grad 120 > $out/kt_grad.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_gradf -o gradf -- python tools/prof_driver.py gradf 120 > $out/kt_gradf.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_grad400 -o grad400 -- python tools/prof_driver.py grad400h160 60 > $out/kt_grad400.log 2>&1
+# counters of the backward kernels (separate passes, like the forward kernels')
+k=grad
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_${k}_fetch -o p -- python tools/prof_driver.py $k 3 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_${k}_write -o p -- python tools/prof_driver.py $k 3 > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $out/pmc_${k}_sq -o p -- python tools/prof_driver.py $k 3 > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $out/pmc_${k}_stall -o p -- python tools/prof_driver.py $k 3 > /dev/null 2>&1
+# steady-state timings of everything else
+python tools/time_steady.py stft spec mel stft4096 spec4096 mel4096 stft512 spec512 stft1024 spec1024 mel512 mel1024 mel400 stft400 spec400 mel256 > $out/time_steady.txt 2>&1
+python tools/time_others.py > $out/time_others.txt 2>&1
 ls $out

@@ -52,11 +52,12 @@ elif what == 'gradf':
         y = m(xg)
         y.backward(torch.ones_like(y))
         return y
-elif what.startswith('grad') and what[4:].split('x')[0].isdigit():
+elif what.startswith('grad') and what[4:].split('x')[0].split('h')[0].isdigit():
     # grad1024 / grad512: training step of the 80-band chain at that fft_length, hop = n / 4 (overlap-add in LDS);
     # grad1024x: hop = n / 4 - 6, which is not a multiple of n / 16: frame gradients through memory + gather overlap-add
-    n = int(what[4:].split('x')[0])
-    hop = n // 4 - (6 if what.endswith('x') else 0)
+    # grad400h160: explicit hop
+    n = int(what[4:].split('x')[0].split('h')[0])
+    hop = int(what.split('h')[1]) if 'h' in what[4:] else n // 4 - (6 if what.endswith('x') else 0)
     m = torch.nn.Sequential(*tac.Melspectrogram(num_mels=80, sample_rate=16000, fft_length=n, hop_length=hop),
                             tac.AmplitudeToDb()).cuda()
     xg = x.clone().requires_grad_(True)

@@ -6,7 +6,7 @@ import json
 import os
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 d = os.path.join('profiles', tag)
 bench = json.load(open(os.path.join(d, 'bench_N1.json')))
 stats = {}
@@ -59,6 +59,18 @@ for label, name, calls, ms, alg, traffic, c in rows:
                % (label, name, ms, calls, alg / 1e6, traffic / 1e6, gbs, 100 * gbs / 8000))
 out.append('')
 r = bench['roofline']
+sb = bench.get('single_buffer')
+if sb:
+    out.append('`bench.py` visits %s; on ONE re-read batch (it fits the 256 MiB Infinity Cache — what rounds 1 and 2 timed) the same '
+               'loop runs %.4f ms per step (%.0f M frames/s): the fused kernel barely notices, the stage kernels do (below).'
+               % (bench['config'].get('input_buffers', 'several input batches'), sb['ms_per_step'], sb['value'] / 1e6))
+    st = bench.get('stages', {})
+    if 'stft_complex' in st and 'single_buffer_kernel_ms_mean' in st['stft_complex']:
+        out.append('Stage kernels, rotating batches vs one re-read batch: complex STFT %.4f vs %.4f ms, power spectrogram %.4f vs '
+                   '%.4f ms — the complex STFT\'s 67 %% of round 2 was an Infinity-Cache-assisted figure; from HBM it is %.0f %%.'
+                   % (st['stft_complex']['kernel_ms_mean'], st['stft_complex']['single_buffer_kernel_ms_mean'],
+                      st['spectrogram_power']['kernel_ms_mean'], st['spectrogram_power']['single_buffer_kernel_ms_mean'],
+                      100 * st['stft_complex']['frac_of_hbm_peak']))
 out.append('`bench.py` on the same box, HIP events on the launch stream, un-profiled: fused kernel %.4f ms mean / %.4f ms '
            'median -> %.0f GB/s = %.1f %% of 8 TB/s; complex STFT %.4f ms (%.1f %%), power spectrogram %.4f ms (%.1f %%).'
            % (r['kernel_ms_mean'], r['kernel_ms_median'], r['achieved'], 100 * r['frac'],
@@ -114,15 +126,20 @@ out.append('All three kernels run 2 waves/SIMD (one 8-wave workgroup per CU whos
            'kernel is bound by its VALU + LDS instruction streams (stall table above), not by memory.  '
            'DESIGN.md §3.2/§3.3 hold the stage-stamp breakdowns, the ablations and the list of variants measured not to help.')
 for fname, what in (('kernel_stats_backward.csv',
-                     '`tools/prof_driver.py grad 5`: forward + backward of the reference idiom `Sequential(*Melspectrogram(...), '
+                     '`tools/prof_driver.py grad 120`: forward + backward of the reference idiom `Sequential(*Melspectrogram(...), '
                      'AmplitudeToDb())` at cfg-2 with `requires_grad` on the waveform: the chain is deferred as usual (one fused '
                      'forward kernel for the linear mel values + the dB op, which keeps them for its gradient) and differentiates through '
                      'the `tac_amd::melspectrogram` op — filterbank adjoint, ONE backward kernel that re-transforms the frames, '
                      'forms the gradient spectrum, inverse-transforms and overlap-adds in LDS, and the unpadding / border fold'),
                     ('kernel_stats_backward_fused_op.csv',
-                     '`tools/prof_driver.py gradf 5`: the same through the factory container (`Melspectrogram(...)` called as '
+                     '`tools/prof_driver.py gradf 120`: the same through the factory container (`Melspectrogram(...)` called as '
                      'ONE `tac_amd::melspectrogram` op) followed by `AmplitudeToDb`: fused forward kernel; backward = filterbank '
-                     'adjoint, the backward kernel (frames re-transformed, overlap-add in LDS), unpadding / border fold')):
+                     'adjoint, the backward kernel (frames re-transformed, overlap-add in LDS), unpadding / border fold'),
+                    ('kernel_stats_backward_n400.csv',
+                     '`tools/prof_driver.py grad400h160 60`: the 80-band speech front end (fft_length 400, hop 160) trained through '
+                     'the reference idiom: fused forward kernel, complex stft recomputed by the mixed-radix kernel, the inverse '
+                     'form of that kernel with the norm\'s adjoint folded into its load (`stft_n400_backward_kernel`), gather '
+                     'overlap-add')):
     pb = os.path.join(d, fname)
     if not os.path.exists(pb):
         continue
@@ -132,16 +149,37 @@ for fname, what in (('kernel_stats_backward.csv',
     out.append('| kernel | calls | average |')
     out.append('|---|---|---|')
     tot = 0.0
-    for r in csv.DictReader(open(pb)):
-        if 'tac::' in r['Name'] and int(r['Calls']) >= 5:
-            tot += float(r['TotalDurationNs']) / 5e6                  # five steps were profiled
+    recs = [r for r in csv.DictReader(open(pb)) if 'tac::' in r['Name']]
+    steps = max(int(r['Calls']) for r in recs)
+    for r in recs:
+        if int(r['Calls']) >= steps:
+            tot += float(r['TotalDurationNs']) / steps / 1e6
             out.append('| `%s` | %s | %.4f ms |' % (r['Name'].split('(')[0].replace('void ', ''), r['Calls'], float(r['AverageNs']) / 1e6))
-    out.append('| kernel time per step (total / 5 steps) | | %.3f ms |' % tot)
+    out.append('| kernel time per step (total / %d steps) | | %.3f ms |' % (steps, tot))
+pbk = os.path.join(d, 'pmc_backward.json')
+if os.path.exists(pbk):
+    for name, c in json.load(open(pbk)).items():
+        if 'spectrogram_backward_ola_kernel' in name and 'SQ_WAVE_CYCLES' in c:
+            wc = c['SQ_WAVE_CYCLES']
+            out.append('')
+            out.append('Counters of `spectrogram_backward_ola_kernel` (`pmc_backward.json`, per launch, separate `--pmc` passes around '
+                       '`tools/prof_driver.py grad 3`): %.0f VALU and %.0f LDS instructions per frame; a wave is parked %.0f %%, '
+                       'issue-stalled %.0f %% (LDS queue %.0f %%) and issuing %.0f %% of its cycles; LDS bank-conflict cycles %.0f %% of '
+                       'LDS cycles; HBM traffic %.0f MB per launch (%.0f MB read + %.0f MB written; the samples are 164 MB, the '
+                       'gradient of the power spectrogram 328 MB, the padded gradient + border sums 180 MB).'
+                       % (c['SQ_INSTS_VALU'] / FRAMES, c['SQ_INSTS_LDS'] / FRAMES, 100 * c['SQ_WAIT_ANY'] / wc,
+                          100 * c['SQ_WAIT_INST_ANY'] / wc, 100 * c['SQ_WAIT_INST_LDS'] / wc, 100 * c['SQ_ACTIVE_INST_ANY'] / wc,
+                          100 * c['SQ_LDS_BANK_CONFLICT'] / c['SQ_LDS_IDX_ACTIVE'], c['hbm_traffic_bytes_per_launch'] / 1e6,
+                          c['hbm_read_bytes_corrected'] / 1e6, c['hbm_write_bytes'] / 1e6))
+out.append('')
+out.append('`steady_state/time_steady.txt`, `steady_state/time_others.txt` — `tools/time_steady.py` / `tools/time_others.py` on the same '
+           'box (0.5 s spin-up per kernel, then 100 / 60 back-to-back launches with per-launch HIP events; medians): every other '
+           'kernel of the library, incl. the fft_length-4096 Melspectrogram chain and `hpss`.')
 out.append('')
 out.append('Micro-benchmarks behind the design decisions (sources in `tools/ubench/`, outputs quoted in DESIGN.md): '
            '`valu_rate` (scalar vs packed f32 issue rates), `lds_rate` (LDS access shapes at 8 waves/CU), `hbm_rate` '
            '(write / read / 1:4 mix ceilings of this box: 4.5-5.6 / 6.4 / 5.1-5.7 TB/s).')
 out.append('')
-out.append('`../r01/` holds the same measurements for round 1 (three-phase fused kernel, 0.174 ms) and `../r01_baseline_v0/` for the first correct version (0.61 ms).')
+out.append('`../r02/`, `../r01/` hold the same measurements for rounds 2 and 1 (streaming kernel 0.127 ms on one re-read batch; three-phase fused kernel, 0.174 ms) and `../r01_baseline_v0/` for the first correct version (0.61 ms).')
 open(os.path.join(d, 'README.md'), 'w').write('\n'.join(out) + '\n')
 print('\n'.join(out))

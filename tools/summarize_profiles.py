@@ -11,7 +11,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 src = os.path.join('gpurun_out', tag)
 dst = os.path.join('profiles', tag)
 os.makedirs(dst, exist_ok=True)
@@ -26,12 +26,17 @@ for f in glob.glob(src + '/kt/**/*kernel_stats.csv', recursive=True):
                 w.writerow([r[0][:100] + '...'] + r[1:])
 if os.path.exists(src + '/bench_N1.json'):
     shutil.copy(src + '/bench_N1.json', dst + '/bench_N1.json')
-for sub, name in (('kt_grad', 'kernel_stats_backward.csv'), ('kt_gradf', 'kernel_stats_backward_fused_op.csv')):
+for sub, name in (('kt_grad', 'kernel_stats_backward.csv'), ('kt_gradf', 'kernel_stats_backward_fused_op.csv'),
+                  ('kt_grad400', 'kernel_stats_backward_n400.csv')):
     for f in glob.glob(src + '/' + sub + '/**/*kernel_stats.csv', recursive=True):
         rows = [r for r in csv.reader(open(f)) if r and (r[0] == 'Name' or 'tac::' in r[0])]
         with open(os.path.join(dst, name), 'w') as o:
             csv.writer(o).writerows([[r[0][:140]] + r[1:] for r in rows])
-for k in ('mel', 'stft', 'spec', 'fb'):
+os.makedirs(os.path.join(dst, 'steady_state'), exist_ok=True)
+for f in ('time_steady.txt', 'time_others.txt'):
+    if os.path.exists(os.path.join(src, f)):
+        shutil.copy(os.path.join(src, f), os.path.join(dst, 'steady_state', f))
+for k in ('mel', 'stft', 'spec', 'fb', 'grad'):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(src + '/pmc_%s_*/**/*counter_collection.csv' % k, recursive=True):
         for r in csv.DictReader(open(f)):
@@ -48,6 +53,6 @@ for k in ('mel', 'stft', 'spec', 'fb'):
             d['hbm_traffic_bytes_per_launch'] = d['hbm_read_bytes_corrected'] + d['hbm_write_bytes']
         out[name] = d
     if out:
-        json.dump(out, open(os.path.join(dst, 'pmc_%s.json' % k), 'w'), indent=1, sort_keys=True)
+        json.dump(out, open(os.path.join(dst, 'pmc_%s.json' % ('backward' if k == 'grad' else k)), 'w'), indent=1, sort_keys=True)
         for name, d in out.items():
             print(k, name, 'traffic/launch: %.1f MB' % (d.get('hbm_traffic_bytes_per_launch', float('nan')) / 1e6))
