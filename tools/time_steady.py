@@ -6,6 +6,13 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torchaudio_contrib_amd as tac
 x = torch.rand(256, 1, 160000, device='cuda') * 2 - 1
+# TAC_ROTATE=n: the cfg-2 kernels (stft / spec / mel) visit n distinct input batches round-robin (n x 164 MB: beyond the 256 MiB
+# Infinity Cache from n = 2), like bench.py
+_xs = [x] + [torch.rand(256, 1, 160000, device='cuda') * 2 - 1 for _ in range(int(os.environ.get('TAC_ROTATE', '1')) - 1)]
+_rot = [0]
+def xr():
+    _rot[0] = (_rot[0] + 1) % len(_xs)
+    return _xs[_rot[0]]
 stft = tac.STFT(2048, 512).cuda()
 spec = tac.Spectrogram(2048, 512, power=2.).cuda()
 mel = torch.nn.Sequential(*tac.Melspectrogram(num_mels=128, sample_rate=16000, fft_length=2048, hop_length=512),
@@ -28,7 +35,7 @@ mel256 = torch.nn.Sequential(*tac.Melspectrogram(num_mels=40, sample_rate=8000, 
 mel4k = torch.nn.Sequential(*tac.Melspectrogram(num_mels=128, sample_rate=48000, fft_length=4096, hop_length=1024),
                             tac.AmplitudeToDb()).cuda()
 fns = {'mel4096': lambda: tac.realize(mel4k(x4)), 'mel256': lambda: tac.realize(mel256(x5)), 'mel400': lambda: tac.realize(mel400(x5)), 'stft400': lambda: tac.realize(stft400(x5)), 'spec400': lambda: spec400(x5),
-       'stft': lambda: tac.realize(stft(x)), 'spec': lambda: spec(x), 'mel': lambda: tac.realize(mel(x)),
+       'stft': lambda: tac.realize(stft(xr())), 'spec': lambda: spec(xr()), 'mel': lambda: tac.realize(mel(xr())),
        'stft4096': lambda: tac.realize(stft4(x4)), 'spec4096': lambda: spec4(x4),
        'stft512': lambda: tac.realize(stft512(x5)), 'spec512': lambda: spec512(x5),
        'stft1024': lambda: tac.realize(stft1k(x5)), 'spec1024': lambda: spec1k(x5),

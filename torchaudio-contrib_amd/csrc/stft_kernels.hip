@@ -270,6 +270,9 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 // (clamped duplicate lanes instead of predication) so the compiler can wait with an exact vmcnt(#stores) while
 // the stores drain behind the next frame's butterflies, and the window comes from LDS (lgkmcnt, not vmcnt).
 // (A three-waves-per-SIMD form with the twiddles in LDS measured equal, 0.163 vs 0.158 ms, and was dropped: tools/ablation/.)
+#ifndef TAC_PIPE_EARLY_REQ
+#define TAC_PIPE_EARLY_REQ 1    // 0: round 2's placement (request behind the FFT passes); 1 measured -3..7 % on the power spectrogram, rotating inputs
+#endif
 template <int NC, int E, int MODE, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64, 2)
 stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
@@ -344,9 +347,19 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
             load_frame<F, false>(v[0], g, nullptr, lds, urow, uframe, t);   // frames touching the padding
         }
         st.mark(8);
+#if TAC_PIPE_EARLY_REQ
+        // request the next frame as soon as this one's samples have left their registers: a whole frame of cover
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            pre = false;
+            if (nxt < end) pre = prefetch_frame_raw_x<F>(raw, g, nxt / T, nxt % T, t);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         F::template run<1, StftStamp, true>(v, ldsv, tw, t, st, t);         // lower-half spectrum stays in registers
         st.mark(9);
 
+#if !TAC_PIPE_EARLY_REQ
         // request the next frame now: it lands while this frame is split, staged and stored
         __builtin_amdgcn_sched_barrier(0);
         {
@@ -354,6 +367,7 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
             if (nxt < end) pre = prefetch_frame_raw_x<F>(raw, g, nxt / T, nxt % T, t);
         }
         __builtin_amdgcn_sched_barrier(0);
+#endif
         st.mark(1);                                         // next frame's loads issued
 
         const long long g0 = ((long long)urow * T + uframe) * LENF;
