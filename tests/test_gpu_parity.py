@@ -1266,6 +1266,33 @@ def test_g10_melspectrogram_fft_length_4096(tac, golden):
     assert np.abs(host(chain(dev(xl))) - want).max() < DB_ABS
 
 
+def test_tables_follow_the_filterbank_and_window(tac):
+    """The packed weights / plans / transposes derived from a filterbank or window are cached on the tensor, stamped with
+    its version counter and data pointer: every in-place torch op is seen.  A write PyTorch itself does not record —
+    ``fb.data.mul_(2)`` (``.data`` has a version counter of its own) — needs ``tac.invalidate(fb)``; after it the kernels
+    use the new values (without it they would keep the stale tables: the documented limit of the cheap stamps)."""
+    x = dev(signals.audio_like((2, 1, 20000), seed=341))
+    mel = tac.Melspectrogram(num_mels=64, sample_rate=16000, fft_length=2048, hop_length=512).cuda()
+    fb = mel[2].filterbank
+    y0 = host(tac.realize(mel(x)))
+    fb.mul_(2.0)                                                      # recorded by the version counter
+    assert rel_err(host(tac.realize(mel(x))), 2.0 * y0) < 1e-6
+    fb.data.mul_(0.5)                                                 # NOT recorded
+    assert fb._version == mel[2].filterbank._version
+    tac.invalidate(fb)
+    assert rel_err(host(tac.realize(mel(x))), y0) < 1e-6
+    win = mel[0].window
+    win.data.mul_(3.0)
+    tac.invalidate()                                                  # everything
+    assert rel_err(host(tac.realize(mel(x))), 9.0 * y0) < 1e-6
+    spec = tac.Spectrogram(2048, 512, power=2.).cuda()(x)
+    fb2 = tac.create_mel_filter(1025, 40, 0.0, 8000.0, False).cuda()
+    a = host(tac.apply_filterbank(spec, fb2))
+    fb2.data.mul_(4.0)
+    tac.invalidate(fb2)
+    assert rel_err(host(tac.apply_filterbank(spec, fb2)), 4.0 * a) < 1e-6
+
+
 def test_coded_waveforms_fused_into_the_frame_load(tac, golden):
     """int16 PCM and 8-bit mu-law codes (uint8 or the int64 mu_law_encoding returns) are converted in
     registers inside the fused kernel's frame load — ONE launch, the decoded waveform never exists — and agree with the
