@@ -4,6 +4,12 @@ and vs the live CPU oracle on the same seeded inputs.
 Tolerances (north_star): <= 1e-4 relative fp32 for floating outputs — measured as max|a-b|/max|b|
 per tensor for linear quantities and as absolute dB for dB quantities (the reference's own bar is
 1e-2 dB, tests/test_layers.py:83) — and bit-exact for mu-law integer codes.
+
+dB in the parameter sweeps: a dB value is compared only where the LINEAR reference value exceeds 1e-6 of its tensor's
+maximum (the ``big`` masks below).  Every bin, masked or not, is first checked on the linear output (<= 2e-5 of the tensor's
+maximum); below 1e-6 of the maximum that bound is wider than the value itself — the float32 FFT's own rounding (1e-7 of the
+frame's largest bin) decides those digits, for the reference's CPU FFT as much as for these kernels — so their logarithm
+is not comparable to 1e-3 dB.  The golden vectors g1 / g2 / g4 / g9 / g10 pin dB outputs UNMASKED on audio-like inputs.
 """
 import numpy as np
 import pytest
