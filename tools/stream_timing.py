@@ -9,8 +9,9 @@ import torchaudio_contrib_amd as tac
 x = torch.rand(256, 1, 160000, device='cuda') * 2 - 1
 m = torch.nn.Sequential(*tac.Melspectrogram(num_mels=128, sample_rate=16000, fft_length=2048, hop_length=512),
                         tac.AmplitudeToDb()).cuda()
-for _ in range(3):
-    y = m(x)
+xs = [x] + [torch.rand(256, 1, 160000, device='cuda') * 2 - 1 for _ in range(int(os.environ.get('TAC_ROTATE', '1')) - 1)]
+for i in range(3 * len(xs) + 1):            # (TAC_ROTATE=4: the stamped launch reads a batch that left the Infinity Cache)
+    y = m(xs[i % len(xs)])
 torch.cuda.synchronize()
 phys = y.transpose(-2, -1).contiguous().view(-1)
 t = phys[:256 * 8 * 8].view(256, 8, 8).cpu()
