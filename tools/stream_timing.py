@@ -14,13 +14,16 @@ for i in range(3 * len(xs) + 1):            # (TAC_ROTATE=4: the stamped launch 
     y = m(xs[i % len(xs)])
 torch.cuda.synchronize()
 phys = y.transpose(-2, -1).contiguous().view(-1)
-t = phys[:256 * 8 * 8].view(256, 8, 8).cpu()
-frames = 256 * 313 / (256 * 8)
+W = int(os.environ.get('TAC_ST_WAVES', '8'))
+NS = 12
+t = phys[:256 * 8 * NS].view(256, 8, NS).cpu()[:, :W]
+frames = 256 * 313 / (256 * W)
 tot = t[..., 0].mean()
 print('per wave: %.0f cycles total, %.1f frames -> %.0f cycles per frame (two frames in flight)' % (tot, frames, tot / frames))
 print('total by wave: ' + ' '.join('%7.0f' % v for v in t[..., 0].mean(0)))
-for k, name in ((3, 'wait for the samples (vmcnt)'), (1, 's0 window + pass 0 + exchange'), (2, 's12 pass 1, in-register exchange, pass 2'), (4, 's3 r2c + row + request'),
+for k, name in ((8, '  s0 fine: previous drain + butterflies'), (9, '  s0 fine: exchange write issue'),
+                (10, '  s0 fine: write drain + read issue'), (3, 'wait for the samples (vmcnt)'), (1, 's0 window + pass 0 + exchange'), (2, 's12 pass 1, in-register exchange, pass 2'), (4, 's3 r2c + row + request'),
                 (5, 's4 contraction + dB + store')):
     col = t[..., k]
-    print('%-32s %7.0f cycles/frame (%4.1f%%)  by wave: %s' % (name, col.mean() / frames, 100 * col.mean() / tot,
+    print('%-40s %7.0f cycles/frame (%4.1f%%)  by wave: %s' % (name, col.mean() / frames, 100 * col.mean() / tot,
                                                               ' '.join('%5.0f' % (v / frames) for v in col.mean(0))))

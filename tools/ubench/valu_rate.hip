@@ -42,6 +42,18 @@ __global__ void __launch_bounds__(256) rate_kernel(float* out, float seed) {
             } else if constexpr (KIND == 8) {   // 2 x v_fma_f32 acc = acc*b + c (accumulator as multiplicand)
                 asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(acc[i].x) : "v"(b.x), "v"(c.x));
                 asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(acc[i].y) : "v"(b.y), "v"(c.y));
+            } else if constexpr (KIND == 9) {   // DEPENDENT chain of v_pk_add_f32 on one accumulator (latency, not rate)
+                asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc[0]) : "v"(b));
+            } else if constexpr (KIND == 10) {  // DEPENDENT chain of v_pk_fma_f32
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[0]) : "v"(b), "v"(c));
+            } else if constexpr (KIND == 11) {  // two interleaved dependent chains of v_pk_fma_f32
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[i & 1]) : "v"(b), "v"(c));
+            } else if constexpr (KIND == 12) {  // four interleaved dependent chains
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[i & 3]) : "v"(b), "v"(c));
+            } else if constexpr (KIND == 13) {  // v_pk_add_f32 with op_sel / neg modifiers (the rotate-add of the butterflies)
+                asm volatile("v_pk_add_f32 %0, %1, %0 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "+v"(acc[i]) : "v"(b));
+            } else if constexpr (KIND == 14) {  // v_pk_fma_f32 with an SGPR-pair multiplicand (constant twiddles)
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(b), "s"(c));
             } else if constexpr (KIND == 5) {   // 2 x v_mul_f32
                 asm volatile("v_mul_f32 %0, %1, %0" : "+v"(acc[i].x) : "v"(b.x));
                 asm volatile("v_mul_f32 %0, %1, %0" : "+v"(acc[i].y) : "v"(b.y));
@@ -80,7 +92,15 @@ void run(const char* name, int insts_per_iter, int waves_per_simd, float* d) {
 int main() {
     float* d;
     CHECK(hipMalloc(&d, 4096));
-    for (int w = 2; w <= 8; w *= 2) {
+    for (int w = 1; w <= 2; ++w) {
+        run<9>("dependent v_pk_add_f32 chain", 16, w, d);
+        run<10>("dependent v_pk_fma_f32 chain", 16, w, d);
+        run<11>("2 interleaved pk_fma chains", 16, w, d);
+        run<12>("4 interleaved pk_fma chains", 16, w, d);
+        run<13>("1x v_pk_add_f32 op_sel/neg", 16, w, d);
+        run<14>("1x v_pk_fma_f32 sgpr operand", 16, w, d);
+    }
+    for (int w = 1; w <= 8; w *= 2) {
         run<0>("2x v_fma_f32", 32, w, d);
         run<1>("1x v_pk_fma_f32", 16, w, d);
         run<6>("2x v_fmac_f32", 32, w, d);

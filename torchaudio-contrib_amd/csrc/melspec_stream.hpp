@@ -32,7 +32,10 @@
 
 namespace tac {
 
-constexpr int ST_WAVES = 8;
+#ifndef TAC_ST_WAVES
+#define TAC_ST_WAVES 8
+#endif
+constexpr int ST_WAVES = TAC_ST_WAVES;
 constexpr int ST_MAX_SLOTS = 4;              // bands per lane (n_mels <= 256)
 constexpr int ST_TW_STRIDE = 36;              // floats between the 16 pass-1 twiddle sets in LDS (144 B: conflict-free b128)
 constexpr int ST_TW_BYTES = 16 * ST_TW_STRIDE * 4;
@@ -157,7 +160,7 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     __syncthreads();                                                   // the only barrier of the kernel (tables in place)
 
 #if TAC_ST_TIMING
-    float tstamp[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float tstamp[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const long long tstart = clock64();
     long long tlast = tstart;
 #define ST_MARK(k) do { const long long now_ = clock64(); tstamp[k] += (float)(now_ - tlast); tlast = now_; } while (0)
@@ -272,11 +275,21 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     auto s0b = [&](cf (&v)[E], int mode, auto&& before_writes) {
         if (mode == 1) Dft<16>::run_windowed(v, win);
         else F::template pass_butterflies<0>(v);
+#if TAC_ST_TIMING > 1
+        asm volatile("" : "+v"(v[0]), "+v"(v[5]), "+v"(v[10]), "+v"(v[15]));
+        ST_MARK(8);                                                    // (fine stamps: previous drain + butterflies)
+#endif
         wave_lds_fence();
         before_writes();
         F::template pass_write<0, true>(v, xa, t, t);
+#if TAC_ST_TIMING > 1
+        ST_MARK(9);                                                    // exchange write issue
+#endif
         wave_lds_fence();
         F::template pass_readback<1>(v, xa, t);
+#if TAC_ST_TIMING > 1
+        ST_MARK(10);                                                   // write drain + read issue
+#endif
     };
     // FAST2: pass 1's twiddles are requested at the end of the stage that precedes the s12 they are for (one set of
     // registers serves both threads)
@@ -557,7 +570,7 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
 #if TAC_ST_TIMING
     tstamp[0] = (float)(clock64() - tstart);
     if (lane == 0)
-        for (int i = 0; i < 8; ++i) m.out[((long long)blockIdx.x * 8 + w) * 8 + i] = tstamp[i];
+        for (int i = 0; i < 12; ++i) m.out[((long long)blockIdx.x * 8 + w) * 12 + i] = tstamp[i];
 #endif
 }
 
