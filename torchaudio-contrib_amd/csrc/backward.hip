@@ -257,7 +257,24 @@ struct OlaPlan {
     int segs_per_row;
     long long pad_len;    // floats per row of gpad (= length + 2·center_pad)
     int n_fft;
+    int direct;           // the fft_length-2048 kernel stores the clean interior straight into the waveform gradient
+    float* gwave;         // ... here (row r at gwave + r * gstride)
+    long long gstride;
 };
+
+// Frame f's `hop` complete positions need nothing but themselves: they lie outside the border zone of their segment
+// (whose first N - hop positions still lack the previous segment's edge sums) and no sample among them has a reflect /
+// replicate / circular image or falls into the padding.  Such runs go straight into the waveform gradient; the fold
+// kernel only handles the rest (round 3: it used to copy the whole padded gradient, 0.064 ms at cfg-2).
+__device__ __forceinline__ bool ola_direct(const FrameGeom& g, const OlaPlan& plan, int f) {
+    if (!plan.direct) return false;
+    const int S = plan.seg_frames, hop = g.hop, pad = g.center_pad, L = (int)g.length;
+    const int sg = f / S;
+    if (sg > 0 && (f - sg * S) * hop < plan.n_fft - hop) return false;
+    const int jlo = f * hop - pad, jhi = jlo + hop - 1;
+    if (pad == 0 || g.pad_mode == PAD_CONSTANT) return jlo >= 0 && jhi < L;
+    return jlo > pad && jhi < L - 1 - pad;
+}
 
 template <bool POW2>
 __global__ void __launch_bounds__(OLA_WAVES * 64, 2)
@@ -378,7 +395,15 @@ spectrogram_backward_ola_kernel(FrameGeom g, Tables tb, const float* __restrict_
 
         // ---- windowed frame gradient into the ring; complete positions out
         const int rot = (int)(((long long)f * H) & 15);
+        // (wave-uniform; ola_direct() with the segment already known: no division)
+        bool direct = false;
+        if (plan.direct && (sidx == 0 || (f - f0) * hop >= N - hop)) {
+            const int jlo = f * hop - g.center_pad, jhi = jlo + hop - 1, L = (int)g.length;
+            direct = (g.center_pad == 0 || g.pad_mode == PAD_CONSTANT) ? (jlo >= 0 && jhi < L)
+                                                                      : (jlo > g.center_pad && jhi < L - 1 - g.center_pad);
+        }
         float* const prow = gpad + (long long)row * plan.pad_len + (long long)f * hop;           // position f·hop
+        float* const drow = direct ? plan.gwave + (long long)row * plan.gstride + ((long long)f * hop - g.center_pad) : prow;
         const bool row_end = (f1 == T);
         float* const tail = row_end ? prow : edge + ((long long)row * (spr - 1) + sidx) * (N - hop) - hop;   // + n
 #pragma unroll
@@ -392,7 +417,7 @@ spectrogram_backward_ola_kernel(FrameGeom g, Tables tb, const float* __restrict_
                 const cf old = *slot;
                 acc = cadd(acc, old);
             }
-            if (j < H) *reinterpret_cast<cf*>(prow + 2 * m) = acc;          // complete
+            if (j < H) *reinterpret_cast<cf*>(drow + 2 * m) = acc;          // complete (clean interior: the waveform gradient itself)
             else if (last) *reinterpret_cast<cf*>(tail + 2 * m) = acc;      // the segment's open positions
             else *slot = acc;
         }
@@ -566,6 +591,10 @@ ola_fold_kernel(FrameGeom g, const float* __restrict__ gpad, const float* __rest
         float* orow = gwave + row * gwave_row_stride;
         for (int j = 4 * (int)(blockIdx.x * blockDim.x + threadIdx.x); j < L; j += 4 * (int)(gridDim.x * blockDim.x)) {
             const int p = j + pad;
+            if (plan.direct) {                               // already stored by the backward kernel (hop and pad are multiples of 4)
+                const int fc = p / hop;
+                if (fc < T && ola_direct(g, plan, fc)) continue;
+            }
             const int s = (int)((unsigned)p / (unsigned)seg_span), o = p - s * seg_span;
             const bool images = pad > 0 && (j <= pad || j + 3 >= L - 1 - pad);      // some sample has a padding image
             const bool in_zone = s >= 1 && s < spr && o + 3 < open, out_zone = s < 1 || s >= spr || (o >= open && o + 3 < seg_span);
@@ -808,6 +837,9 @@ static int ola_plan(const tac_stft_desc* d, const FrameGeom& g, OlaPlan* plan) {
     plan->segs_per_row = (T + S - 1) / S;
     plan->pad_len = g.length + 2LL * g.center_pad;
     plan->n_fft = n;
+    plan->direct = 0;
+    plan->gwave = nullptr;
+    plan->gstride = 0;
     return TAC_OK;
 }
 
@@ -908,6 +940,9 @@ int tac_spectrogram_backward_ola_f32(const float* wave, const float* window, con
     if (rc != TAC_OK) return rc;
     float* gpad = static_cast<float*>(workspace);
     float* edge = gpad + g.rows * plan.pad_len;
+    plan.gwave = grad_wave;
+    plan.gstride = grad_row_stride;
+    plan.direct = (d->n_fft == 2048 && (d->hop & 3) == 0 && (g.center_pad & 3) == 0) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     const bool pow2 = (power == 2.0f);
     auto launch = [&](auto kern, size_t lds_bytes, int streams_per_wave) -> int {
