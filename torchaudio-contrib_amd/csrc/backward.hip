@@ -613,39 +613,61 @@ ola_fold_kernel(FrameGeom g, const float* __restrict__ gpad, const float* __rest
 // frames[row][t][i + pad - t*hop]   (source(): torch.nn.functional.pad semantics, fft_core.hpp padded_index).
 __global__ void __launch_bounds__(256)
 overlap_add_kernel(FrameGeom g, int n_fft, const float* __restrict__ frames, float* __restrict__ gwave,
-                   long long gwave_row_stride) {
+                   long long gwave_row_stride, int vec4) {
     // positions inside a row are 32-bit (L < 2^31 - 2 n_fft, host-checked): only the final addresses are 64-bit — the
-    // 64-bit divisions of the first version were most of this kernel's time
+    // 64-bit divisions of the first version were most of this kernel's time.  A thread owns FOUR consecutive samples:
+    // where hop, pad and n_fft are multiples of four (vec4, host-checked together with the alignment of `frames`) and none
+    // of the four has a padding image, every frame that covers one of them covers all four at a 16-byte aligned offset,
+    // so the gather is one 16-byte load per covering frame instead of four 4-byte ones (round 3: 0.193 -> ~0.1 ms for
+    // fft_length 400 / hop 160 at 256 x 160 000 samples).
     const int L = (int)g.length, T = (int)g.n_frames;
     const int pad = g.center_pad, hop = g.hop;
-    const long long total = g.rows * (long long)L;
+    const int groups = (L + 3) >> 2;
+    const long long total = g.rows * (long long)groups;
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    typedef float f4a __attribute__((ext_vector_type(4)));
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
-        const int row = (int)(idx / L);
-        const int j = (int)(idx - (long long)row * L);
+        const int row = (int)(idx / groups);
+        const int j0 = 4 * (int)(idx - (long long)row * groups);
         const float* fr = frames + (long long)row * T * n_fft;
-        float acc = 0.0f;
-        auto add_position = [&](int i) {                                // i: position in the padded signal minus pad
-            const int p = i + pad;                                      // 0 <= p < L + 2 pad
-            int t1 = p / hop;
-            if (t1 > T - 1) t1 = T - 1;
-            int t0 = p - n_fft + 1 <= 0 ? 0 : (p - n_fft + hop) / hop;  // ceil((p - n_fft + 1) / hop)
-            for (int tt = t0; tt <= t1; ++tt) acc += fr[(long long)tt * n_fft + (p - tt * hop)];
-        };
-        add_position(j);
-        if (pad > 0) {
-            if (g.pad_mode == PAD_REFLECT) {
-                if (j >= 1 && j <= pad) add_position(-j);
-                if (j <= L - 2 && j >= L - 1 - pad) add_position(2 * (L - 1) - j);
-            } else if (g.pad_mode == PAD_REPLICATE) {
-                if (j == 0) for (int i = -pad; i < 0; ++i) add_position(i);
-                if (j == L - 1) for (int i = L; i < L + pad; ++i) add_position(i);
-            } else if (g.pad_mode == PAD_CIRCULAR) {
-                if (j >= L - pad) add_position(j - L);
-                if (j < pad) add_position(j + L);
+        float* orow = gwave + row * gwave_row_stride;
+        auto one = [&](int j) -> float {
+            float acc = 0.0f;
+            auto add_position = [&](int i) {                            // i: position in the padded signal minus pad
+                const int p = i + pad;                                  // 0 <= p < L + 2 pad
+                int t1 = p / hop;
+                if (t1 > T - 1) t1 = T - 1;
+                int t0 = p - n_fft + 1 <= 0 ? 0 : (p - n_fft + hop) / hop;  // ceil((p - n_fft + 1) / hop)
+                for (int tt = t0; tt <= t1; ++tt) acc += fr[(long long)tt * n_fft + (p - tt * hop)];
+            };
+            add_position(j);
+            if (pad > 0) {
+                if (g.pad_mode == PAD_REFLECT) {
+                    if (j >= 1 && j <= pad) add_position(-j);
+                    if (j <= L - 2 && j >= L - 1 - pad) add_position(2 * (L - 1) - j);
+                } else if (g.pad_mode == PAD_REPLICATE) {
+                    if (j == 0) for (int i = -pad; i < 0; ++i) add_position(i);
+                    if (j == L - 1) for (int i = L; i < L + pad; ++i) add_position(i);
+                } else if (g.pad_mode == PAD_CIRCULAR) {
+                    if (j >= L - pad) add_position(j - L);
+                    if (j < pad) add_position(j + L);
+                }
             }
+            return acc;
+        };
+        const bool images = pad > 0 && g.pad_mode != PAD_CONSTANT && (j0 <= pad || j0 + 3 >= L - 1 - pad);
+        if (vec4 && j0 + 3 < L && !images) {
+            const int p = j0 + pad;                                     // multiple of 4
+            int t1 = p / hop;                                           // the same frames cover p .. p + 3
+            if (t1 > T - 1) t1 = T - 1;
+            const int t0 = p + 3 - n_fft + 1 <= 0 ? 0 : (p + 3 - n_fft + hop) / hop;
+            f4a acc = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int tt = t0; tt <= t1; ++tt) acc += *reinterpret_cast<const f4a*>(fr + (long long)tt * n_fft + (p - tt * hop));
+            *reinterpret_cast<f4u*>(orow + j0) = acc;
+        } else {
+            for (int u = 0; u < 4 && j0 + u < L; ++u) orow[j0 + u] = one(j0 + u);
         }
-        gwave[row * gwave_row_stride + j] = acc;
     }
 }
 
@@ -1009,8 +1031,10 @@ int tac_overlap_add_f32(const float* grad_frames, const tac_stft_desc* d, float*
     float dummy_window = 0.0f;
     int rc = make_geometry(grad_frames, &dummy_window, d, &g, &T, true);     // framing only: any fft_length
     if (rc != TAC_OK) return rc;
-    hipLaunchKernelGGL(overlap_add_kernel, dim3(bw_blocks(g.rows * g.length)), dim3(256), 0, (hipStream_t)stream, g,
-                       (int)d->n_fft, grad_frames, grad_wave, (long long)grad_row_stride);
+    const int vec4 = ((d->hop & 3) == 0 && (d->n_fft & 3) == 0 && (g.center_pad & 3) == 0 &&
+                      (reinterpret_cast<uintptr_t>(grad_frames) & 15u) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(overlap_add_kernel, dim3(bw_blocks(g.rows * ((g.length + 3) / 4))), dim3(256), 0, (hipStream_t)stream, g,
+                       (int)d->n_fft, grad_frames, grad_wave, (long long)grad_row_stride, vec4);
     TAC_HIP(hipGetLastError());
     return TAC_OK;
 }
