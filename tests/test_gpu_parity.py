@@ -945,8 +945,9 @@ def test_general_gradient_routes_under_strict(tac, n_fft, hop, win_length, onesi
 def test_fft_length_400_trains_on_the_mixed_radix_kernels(tac):
     """The 25 ms speech front end (fft_length 400, hop 160) under strict mode: Spectrogram, the 80-band Melspectrogram
     and the complex stft differentiate w.r.t. the waveform through the inverse form of the mixed-radix kernel
-    (stft_n400_backward_kernel: the 8 x 25 transform on conjugated data) + the gather overlap-add — launch counters
-    asserted — and agree with torch.autograd through the CPU oracle."""
+    (stft_n400_backward_kernel: the 8 x 25 transform on conjugated data; for |z|^p the frames are re-transformed inside
+    it, no spectrum exists in memory) + the gather overlap-add — launch counters asserted — and agree with torch.autograd
+    through the CPU oracle.  Short rows (every unit touches the padding), odd frame counts and power 1 included."""
     assert tac._ops.strict()
     x = signals.audio_like((3, 1, 16000), seed=331)
     xc = torch.from_numpy(x).double().requires_grad_(True)
@@ -960,8 +961,17 @@ def test_fft_length_400_trains_on_the_mixed_radix_kernels(tac):
         before = launches(tac)
         (got,) = torch.autograd.grad((y * dev(wgt)).sum(), xg)
         ran = launched_since(tac, before)
-        assert ran == {'tac_stft_f32': 1, 'tac_stft_norm_backward_f32': 1, 'tac_overlap_add_f32': 1}, ran
+        assert ran == {'tac_spectrogram_backward_f32': 1, 'tac_overlap_add_f32': 1}, ran     # frames re-transformed in the kernel
         assert rel_err(host(got), want.numpy()) < 1e-4, power
+    xe = signals.audio_like((5, 2, 1234), seed=336)                   # 8 frames per row: every unit gathers its samples
+    xec, xeg = torch.from_numpy(xe).double().requires_grad_(True), dev(xe).requires_grad_(True)
+    for pad_mode, hop in (('reflect', 160), ('constant', 90), ('circular', 200)):
+        wy = torch_ref.complex_norm(torch_ref.stft(xec, 400, hop, pad_mode=pad_mode), 2.0)
+        wg = signals.uniform(tuple(wy.shape), seed=337)
+        (want,) = torch.autograd.grad((wy * torch.from_numpy(wg).double()).sum(), xec)
+        y = tac.Spectrogram(400, hop, pad_mode=pad_mode, power=2.).cuda()(xeg)
+        (got,) = torch.autograd.grad((y * dev(wg)).sum(), xeg)
+        assert rel_err(host(got), want.numpy()) < 1e-4, (pad_mode, hop)
     # the fused 80-band chain with its dB epilogue (the reference idiom)
     chain = torch.nn.Sequential(*tac.Melspectrogram(num_mels=80, sample_rate=16000, fft_length=400, hop_length=160),
                                 tac.AmplitudeToDb(amin=1e-5)).cuda()
@@ -973,7 +983,8 @@ def test_fft_length_400_trains_on_the_mixed_radix_kernels(tac):
     before = launches(tac)
     (got,) = torch.autograd.grad((y * dev(wgt)).sum(), xg)
     ran = launched_since(tac, before)
-    assert ran.get('tac_stft_norm_backward_f32') == 1 and ran.get('tac_overlap_add_f32') == 1 and 'tac_apply_filterbank_f32' not in ran, ran
+    assert ran.get('tac_spectrogram_backward_f32') == 1 and ran.get('tac_overlap_add_f32') == 1 and 'tac_apply_filterbank_f32' not in ran, ran
+    assert 'tac_stft_f32' not in ran
     assert rel_err(host(got), want.numpy()) < 1e-3
     # complex stft, an odd number of frames per unit, short window, not centred
     xs = signals.audio_like((2, 2, 2011), seed=334)

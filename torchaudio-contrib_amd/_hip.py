@@ -883,9 +883,10 @@ def stft_backward_supported(n_fft, onesided):
 
 
 def backward_recomputes_spectrum(n_fft):
-    """Sizes whose spectrogram backward kernel transforms the frames again itself (16 elements per lane; at 4096 the
-    second transform does not fit the registers and the spectrum is recomputed into memory by the stft kernel)."""
-    return fft_kernel_size(n_fft) and n_fft <= 2048
+    """Sizes whose spectrogram backward kernel transforms the frames again itself (16 elements per lane, and the
+    mixed-radix fft_length 400; at 4096 the second transform does not fit the registers and the spectrum is recomputed
+    into memory by the stft kernel)."""
+    return (fft_kernel_size(n_fft) and n_fft <= 2048) or mixed_radix_size(n_fft)
 
 
 def complex_norm_backward(z, grad_out, power):

@@ -24,7 +24,7 @@
 namespace tac {
 
 int launch_n400_backward(const FrameGeom& g, const float* gspec, const float* gnorm, float power, float* frames,
-                         hipStream_t stream);                     // stft_n400.hip
+                         hipStream_t stream, bool from_wave);     // stft_n400.hip
 
 constexpr int BW_WAVES = 4;
 
@@ -754,8 +754,8 @@ static int stft_backward_entry(const float* spec, const float* gnorm, float powe
     int rc = make_geometry(spec, window, d, &g, &T);
     if (rc != TAC_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    if (d->n_fft == 400)                                   // the mixed-radix form (stft_n400.hip); no in-kernel recomputation
-        return from_wave ? TAC_E_UNSUPPORTED : launch_n400_backward(g, spec, gnorm, power, grad_frames, s);
+    if (d->n_fft == 400)                                   // the mixed-radix form (stft_n400.hip)
+        return launch_n400_backward(g, spec, gnorm, power, grad_frames, s, from_wave);
     Tables tb;
     rc = get_tables(d->n_fft, &tb);
     if (rc != TAC_OK) return rc;

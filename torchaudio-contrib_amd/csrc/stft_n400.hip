@@ -456,7 +456,9 @@ stft_n400_backward_kernel(FrameGeom g, Q4Tables tb, const float* __restrict__ gs
     cf* const winl = tabs;                                                 // [8][Q4_ROW] window pairs of samples 2 (25 k1 + k2), + 1
     cf* const w200l = tabs + 8 * Q4_ROW;
     cf* const w400l = tabs + 16 * Q4_ROW;                                  // input layout: W_400^{e + 8 m}
-    unsigned* const next_unit = reinterpret_cast<unsigned*>(tabs + 24 * Q4_ROW);
+    cf* const winf = tabs + 24 * Q4_ROW;                                   // SRC_WAVE: the forward transform's window pairs (input layout)
+    cf* const w400o = tabs + 32 * Q4_ROW;                                  // SRC_WAVE: its R2C twiddles (output layout)
+    unsigned* const next_unit = reinterpret_cast<unsigned*>(tabs + 40 * Q4_ROW);
     const float wscale = 0.5f * g.scale;
     for (int i = threadIdx.x; i < 8 * Q4_ROW; i += Q4_WAVES * 64) {
         const int ll = i / Q4_ROW, m = i - ll * Q4_ROW;
@@ -464,6 +466,10 @@ stft_n400_backward_kernel(FrameGeom g, Q4Tables tb, const float* __restrict__ gs
         winl[i] = mkc(wn.x * wscale, -wn.y * wscale);                      // (y[2m + 1] = -Im R[m])
         w200l[i] = tb.w200[i];
         w400l[i] = tb.w400b[i];
+        if constexpr (SRC == SRC_WAVE) {
+            winf[i] = m < Q4_M ? window_pair(g, q4_e_of(ll) + 8 * m) : mkc(0.0f, 0.0f);
+            w400o[i] = tb.w400[i];
+        }
     }
     const float s1 = e >= 4 ? -1.0f : 1.0f, s2 = (e & 2) ? -1.0f : 1.0f, s3 = (e & 1) ? -1.0f : 1.0f;
     const float R = 0.70710678118654752f;
@@ -472,6 +478,14 @@ stft_n400_backward_kernel(FrameGeom g, Q4Tables tb, const float* __restrict__ gs
     if (e == 6) c1 = mkc(0.0f, -1.0f);
     if (e == 7) c1 = mkc(-R, -R);
     if ((e & 3) == 3) c2 = mkc(0.0f, -1.0f);
+    int p0lane = l;                                        // (SRC_WAVE) source lane of the k2 = 0 partner, as in stft_n400_kernel
+    if (l == 2) p0lane = 3;
+    if (l == 3) p0lane = 2;
+    if (l == 4) p0lane = 7;
+    if (l == 7) p0lane = 4;
+    if (l == 5) p0lane = 6;
+    if (l == 6) p0lane = 5;
+    const int p0addr = ((lane & ~7) | p0lane) << 2;
 
     const int T = (int)g.n_frames;
     const int upr = (T + Q4_G - 1) / Q4_G;
@@ -495,7 +509,84 @@ stft_n400_backward_kernel(FrameGeom g, Q4Tables tb, const float* __restrict__ gs
         const int nlive = (T - uframe0) < Q4_G ? (T - uframe0) : Q4_G;
         const long long f0 = (long long)urow * T + uframe0;                // first frame of the unit (global frame index)
         // (1) the unit's gradient rows -> staging area (rows past the end of the waveform's frames: zeros)
-        {
+        if constexpr (SRC == SRC_WAVE) {
+            // no spectrum in memory: the unit's frames are fetched from the WAVEFORM and transformed by the forward
+            // recipe of stft_n400_kernel; the R2C split leaves X[25 k1 + k2] in lane k1, where the gradient of |X|^p
+            // (25 contiguous floats per lane) turns it into the gradient spectrum that is parked for step (2)
+            const int frame = uframe0 + slot;
+            const bool live = frame < T;
+            const float* gn = gnorm + (f0 + (live ? slot : 0)) * ROWC + 25 * k1;
+            float gv[Q4_M], g200 = gn[200 - 25 * k1];
+#pragma unroll
+            for (int k = 0; k < Q4_M; ++k) gv[k] = gn[k];
+            const long long start = (long long)frame * g.hop - g.center_pad;
+            const bool ok = g.vec2_ok && live && start >= 0 && start + 400 <= g.length;
+            const bool all_ok = __builtin_amdgcn_ballot_w64(ok) == ~0ull;
+            cf v[Q4_M];
+            {
+                cf wn[Q4_M];
+                q4_read_row(winf + l * Q4_ROW, wn);
+                if (all_ok) {
+                    const cf* src = reinterpret_cast<const cf*>(g.wave + (long long)urow * g.row_stride + start) + e;
+#pragma unroll
+                    for (int m = 0; m < Q4_M; ++m) v[m] = cmul_elem(src[8 * m], wn[m]);
+                } else {
+                    const float* rp = g.wave + (long long)urow * g.row_stride;
+                    const int s0 = (int)start, L = (int)g.length;
+#pragma unroll 1
+                    for (int m = 0; m < Q4_M; ++m) {
+                        bool z0, z1;
+                        const int j0 = padded_index(s0 + 2 * (e + 8 * m), L, g.pad_mode, &z0);
+                        const int j1 = padded_index(s0 + 2 * (e + 8 * m) + 1, L, g.pad_mode, &z1);
+                        const float a0 = rp[j0], a1 = rp[j1];
+                        const cf wv = winf[l * Q4_ROW + m];
+                        wstage[lane * Q4_M + m] = mkc((live && !z0) ? a0 * wv.x : 0.0f, (live && !z1) ? a1 * wv.y : 0.0f);
+                    }
+                    wave_lds_fence();
+#pragma unroll
+                    for (int m = 0; m < Q4_M; ++m) v[m] = wstage[lane * Q4_M + m];
+                    wave_lds_fence();
+                }
+            }
+            q4_dft25(v);
+            {
+                cf tw[Q4_M];
+                q4_read_row(w200l + l * Q4_ROW, tw);
+#pragma unroll
+                for (int k = 1; k < Q4_M; ++k) v[k] = cmul(v[k], tw[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < Q4_M; ++k) {
+                cf p = q4_dpp<Q4_HALF_MIRROR>(v[k]);
+                v[k] = cmul(__builtin_elementwise_fma(v[k], mkc(s1, s1), p), c1);
+                p = q4_dpp<Q4_QUAD_XOR2>(v[k]);
+                v[k] = cmul(__builtin_elementwise_fma(v[k], mkc(s2, s2), p), c2);
+                p = q4_dpp<Q4_QUAD_XOR1>(v[k]);
+                v[k] = __builtin_elementwise_fma(v[k], mkc(s3, s3), p);
+            }
+            {
+                cf tw[Q4_M];
+                q4_read_row(w400o + l * Q4_ROW, tw);
+                const cf z0p = mkc(__int_as_float(__builtin_amdgcn_ds_bpermute(p0addr, __float_as_int(v[0].x))),
+                                   __int_as_float(__builtin_amdgcn_ds_bpermute(p0addr, __float_as_int(v[0].y))));
+                const float hscale = 0.5f * g.scale;
+                cf* row = wstage + slot * ROWC;
+#pragma unroll
+                for (int k = 0; k < Q4_M; ++k) {
+                    const cf zp = k == 0 ? z0p : q4_dpp<Q4_QUAD_XOR3>(q4_dpp<Q4_HALF_MIRROR>(v[Q4_M - k]));   // lane l ^ 4
+                    const cf ev = cadd_conj(v[k], zp), d = csub_conj(v[k], zp);
+                    const cf twd = cmul_rot(tw[k], d);
+                    cf gk = norm_pow_grad<POW2>(cscale(cadd(ev, twd), hscale), live ? gv[k] : 0.0f, power);
+                    const int bin = 25 * k1 + k;
+                    if (bin == 0) gk = mkc(2.0f * gk.x, 0.0f);                  // H[0] = 2 Re G[0]
+                    row[bin] = gk;
+                    if (k == 0 && l == 0) {
+                        const cf g2 = norm_pow_grad<POW2>(cscale(csub_then_conj(ev, twd), hscale), live ? g200 : 0.0f, power);
+                        row[200] = mkc(2.0f * g2.x, 0.0f);                      // H[200] = 2 Re G[200]
+                    }
+                }
+            }
+        } else {
             const cf* src = reinterpret_cast<const cf*>(gspec) + f0 * ROWC;
             const float* gn = (SRC == SRC_NORM) ? gnorm + f0 * ROWC : nullptr;
             const int live = nlive * ROWC;
@@ -575,19 +666,22 @@ stft_n400_backward_kernel(FrameGeom g, Q4Tables tb, const float* __restrict__ gs
 
 // tac_stft_backward_f32 / tac_stft_norm_backward_f32 for fft_length 400 (backward.hip's dispatcher calls this)
 int launch_n400_backward(const FrameGeom& g, const float* gspec, const float* gnorm, float power, float* frames,
-                         hipStream_t stream) {
+                         hipStream_t stream, bool from_wave) {
     Q4Tables tb;
     const int rc = q4_tables(&tb);
     if (rc != TAC_OK) return rc;
-    if ((reinterpret_cast<uintptr_t>(gspec) & 7u) || (reinterpret_cast<uintptr_t>(frames) & 15u)) return TAC_E_UNSUPPORTED;
+    if ((!from_wave && (reinterpret_cast<uintptr_t>(gspec) & 7u)) || (reinterpret_cast<uintptr_t>(frames) & 15u)) return TAC_E_UNSUPPORTED;
     const long long units = g.rows * ((g.n_frames + Q4_G - 1) / Q4_G);
     if (units >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
-    const size_t bytes = q4_lds_bytes(0);
+    const size_t bytes = q4_lds_bytes(0) + (size_t)16 * Q4_ROW * sizeof(cf);
     long long blocks = (units + Q4_WAVES - 1) / Q4_WAVES;
     const long long cap = (long long)device_cu_count();
     if (blocks > cap) blocks = cap;
     void (*kern)(FrameGeom, Q4Tables, const float*, const float*, float, float*);
-    if (!gnorm) kern = stft_n400_backward_kernel<SRC_GRAD, false>;
+    if (from_wave) {
+        if (!gnorm) return TAC_E_INVALID;
+        kern = power == 2.0f ? stft_n400_backward_kernel<SRC_WAVE, true> : stft_n400_backward_kernel<SRC_WAVE, false>;
+    } else if (!gnorm) kern = stft_n400_backward_kernel<SRC_GRAD, false>;
     else kern = power == 2.0f ? stft_n400_backward_kernel<SRC_NORM, true> : stft_n400_backward_kernel<SRC_NORM, false>;
     if (bytes > 64 * 1024) TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Q4_WAVES * 64), bytes, stream, g, tb, gspec, gnorm, power, frames);
