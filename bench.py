@@ -254,7 +254,7 @@ def run(a):
                    'parallelism': 'batch-sharded x%d, no data-path collective' % world,
                    'input_buffers': '%d distinct device-resident batches of %.1f MB visited round-robin (%.0f MB > the '
                                     '256 MiB Infinity Cache)' % (nbuf, x.numel() * 4 / 1e6, nbuf * x.numel() * 4 / 1e6)},
-        'roofline': {'kernel': 'melspec_stream_kernel<1024,16,pow2,fullM> (fused STFT + power + band-sparse mel + dB, one launch per step)', 'bound': 'hbm',
+        'roofline': {'kernel': 'melspec_stream3_kernel<1024,16,pow2,f32,14> (fused STFT + power + band-sparse mel + dB, one launch per step; 3 waves per SIMD)', 'bound': 'hbm',
                      'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                      'traffic': None, 'alg_bytes_per_launch': alg_bytes, 'kernel_ms_mean': mean_ms,
                      'kernel_ms_median': med_ms, 'kernel_ms_per_launch_events': per_launch_mean_ms,
@@ -279,7 +279,7 @@ def run(a):
         except Exception:
             continue
         for kname, d in pmc.items():
-            if ('melspec_stream_kernel<1024' in kname or 'melspec_sparse_kernel<1024' in kname) \
+            if ('melspec_stream3_kernel<1024' in kname or 'melspec_stream_kernel<1024' in kname or 'melspec_sparse_kernel<1024' in kname) \
                     and 'hbm_traffic_bytes_per_launch' in d:
                 result['roofline']['traffic'] = d['hbm_traffic_bytes_per_launch']
                 result['roofline']['traffic_source'] = ('profiles/%s/pmc_mel.json (rocprofv3 --pmc FETCH_SIZE / '

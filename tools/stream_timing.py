@@ -3,6 +3,7 @@
 stage (either thread of the wave): s0 window + pass 0, s1 pass 1, s2 pass 2, s3 R2C + |X|^2 row (+ next request),
 s4 contraction + dB + store."""
 import os, sys
+os.environ.setdefault('TAC_STREAM2', '1')      # the stamps live in round 2's two-frame rotation kernel
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torchaudio_contrib_amd as tac

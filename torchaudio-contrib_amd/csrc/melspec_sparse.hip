@@ -17,6 +17,7 @@
 #include "mel_lanes.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <functional>
 #include <atomic>
 #include <vector>
@@ -27,6 +28,7 @@
 
 #include "sparse_phase.hpp"
 #include "melspec_stream.hpp"
+#include "melspec_stream3.hpp"
 
 namespace tac {
 
@@ -367,7 +369,7 @@ static int launch_stream(FrameGeom g, const Tables& tb, const SparseArgs& sm, co
     if (total >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;                  // 32-bit global frame numbers in-kernel
     if (g.length < 2 * NC) return TAC_E_UNSUPPORTED;                       // (its clamped sample requests need a whole frame)
     const size_t lds_bytes = stream_lds_bytes<NC, E>(sm.wtot);
-    if (lds_bytes > 160 * 1024 || info_host[1] < 1 || info_host[1] > ST_MAX_SLOTS) return TAC_E_UNSUPPORTED;
+    if (info_host[1] < 1 || info_host[1] > ST_MAX_SLOTS) return TAC_E_UNSUPPORTED;
     if (FMT != FMT_F32) {                                                  // sample pairs fetched as one access of the format
         const uintptr_t pair = FMT == FMT_I16 ? 4 : (FMT == FMT_MULAW_U8 ? 2 : 8);
         g.vec2_ok = ((g.hop & 1) == 0) && ((g.center_pad & 1) == 0) && ((g.row_stride & 1) == 0) &&
@@ -387,6 +389,26 @@ static int launch_stream(FrameGeom g, const Tables& tb, const SparseArgs& sm, co
     const bool fast2 = fullm && info_host[1] == 2 && info_host[4] == ST_FAST_STEPS0 &&
                        (info_host[5] == ST_FAST_STEPS1 || info_host[5] == ST_FAST_STEPS1_SHORT);
     const bool fshort = info_host[5] == ST_FAST_STEPS1_SHORT;
+    // Round 3: the three-waves-per-SIMD form (melspec_stream3.hpp) is the route; TAC_STREAM2=1 selects round 2's two-frame
+    // rotation (kept for A/B runs and for tools/stream_timing.py)
+    static const bool two_waves = getenv("TAC_STREAM2") != nullptr;
+    const size_t lds3 = stream3_lds_bytes<NC, E>(sm.wtot);
+    if (!two_waves && lds3 <= 160 * 1024) {
+        void (*k3)(FrameGeom, Tables, StreamArgs);
+        if constexpr (FMT == FMT_F32) {
+            if (fast2 && fshort) k3 = pow2 ? melspec_stream3_kernel<NC, E, true, FMT, ST_FAST_STEPS1_SHORT> : melspec_stream3_kernel<NC, E, false, FMT, ST_FAST_STEPS1_SHORT>;
+            else if (fast2) k3 = pow2 ? melspec_stream3_kernel<NC, E, true, FMT, ST_FAST_STEPS1> : melspec_stream3_kernel<NC, E, false, FMT, ST_FAST_STEPS1>;
+            else k3 = pow2 ? melspec_stream3_kernel<NC, E, true, FMT, 0> : melspec_stream3_kernel<NC, E, false, FMT, 0>;
+        } else {
+            k3 = pow2 ? melspec_stream3_kernel<NC, E, true, FMT, 0> : melspec_stream3_kernel<NC, E, false, FMT, 0>;
+        }
+        long long b3 = (total + S3_WAVES - 1) / S3_WAVES;
+        if (b3 > device_cu_count()) b3 = device_cu_count();
+        TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(k3), 160 * 1024));
+        hipLaunchKernelGGL(k3, dim3((unsigned)b3), dim3(S3_WAVES * 64), lds3, stream, g, tb, m);
+        TAC_HIP(hipGetLastError());
+        return TAC_OK;
+    }
     void (*kern)(FrameGeom, Tables, StreamArgs);
     if constexpr (FMT == FMT_F32) {
         if (fast2 && fshort)
@@ -399,6 +421,7 @@ static int launch_stream(FrameGeom g, const Tables& tb, const SparseArgs& sm, co
     } else {
         kern = pow2 ? melspec_stream_kernel<NC, E, true, false, FMT, 0> : melspec_stream_kernel<NC, E, false, false, FMT, 0>;
     }
+    if (lds_bytes > 160 * 1024) return TAC_E_UNSUPPORTED;
     TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(ST_WAVES * 64), lds_bytes, stream, g, tb, m);
     TAC_HIP(hipGetLastError());
