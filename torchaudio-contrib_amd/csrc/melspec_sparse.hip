@@ -392,20 +392,32 @@ static int launch_stream(FrameGeom g, const Tables& tb, const SparseArgs& sm, co
     // Round 3: the three-waves-per-SIMD form (melspec_stream3.hpp) is the route; TAC_STREAM2=1 selects round 2's two-frame
     // rotation (kept for A/B runs and for tools/stream_timing.py)
     static const bool two_waves = getenv("TAC_STREAM2") != nullptr;
-    const size_t lds3 = stream3_lds_bytes<NC, E>(sm.wtot);
+    static const int waves_f32 = [] { const char* e = getenv("TAC_S3_WAVES"); return e ? atoi(e) : S3_WAVES_F32; }();
+    constexpr bool coded = FMT != FMT_F32;
+    const int waves3 = (!coded && waves_f32 == S3_WAVES_F32 && stream3_lds_bytes<NC, E>(sm.wtot, S3_WAVES_F32, false) <= 160 * 1024)
+                           ? S3_WAVES_F32 : S3_WAVES;
+    const size_t lds3 = stream3_lds_bytes<NC, E>(sm.wtot, waves3, coded);
     if (!two_waves && lds3 <= 160 * 1024) {
         void (*k3)(FrameGeom, Tables, StreamArgs);
         if constexpr (FMT == FMT_F32) {
-            if (fast2 && fshort) k3 = pow2 ? melspec_stream3_kernel<NC, E, true, FMT, ST_FAST_STEPS1_SHORT> : melspec_stream3_kernel<NC, E, false, FMT, ST_FAST_STEPS1_SHORT>;
-            else if (fast2) k3 = pow2 ? melspec_stream3_kernel<NC, E, true, FMT, ST_FAST_STEPS1> : melspec_stream3_kernel<NC, E, false, FMT, ST_FAST_STEPS1>;
-            else k3 = pow2 ? melspec_stream3_kernel<NC, E, true, FMT, 0> : melspec_stream3_kernel<NC, E, false, FMT, 0>;
+            if (waves3 == S3_WAVES_F32) {
+                constexpr int W = S3_WAVES_F32;
+                if (fast2 && fshort) k3 = pow2 ? melspec_stream3_kernel<NC, E, true, FMT, ST_FAST_STEPS1_SHORT, W> : melspec_stream3_kernel<NC, E, false, FMT, ST_FAST_STEPS1_SHORT, W>;
+                else if (fast2) k3 = pow2 ? melspec_stream3_kernel<NC, E, true, FMT, ST_FAST_STEPS1, W> : melspec_stream3_kernel<NC, E, false, FMT, ST_FAST_STEPS1, W>;
+                else k3 = pow2 ? melspec_stream3_kernel<NC, E, true, FMT, 0, W> : melspec_stream3_kernel<NC, E, false, FMT, 0, W>;
+            } else {
+                constexpr int W = S3_WAVES;
+                if (fast2 && fshort) k3 = pow2 ? melspec_stream3_kernel<NC, E, true, FMT, ST_FAST_STEPS1_SHORT, W> : melspec_stream3_kernel<NC, E, false, FMT, ST_FAST_STEPS1_SHORT, W>;
+                else if (fast2) k3 = pow2 ? melspec_stream3_kernel<NC, E, true, FMT, ST_FAST_STEPS1, W> : melspec_stream3_kernel<NC, E, false, FMT, ST_FAST_STEPS1, W>;
+                else k3 = pow2 ? melspec_stream3_kernel<NC, E, true, FMT, 0, W> : melspec_stream3_kernel<NC, E, false, FMT, 0, W>;
+            }
         } else {
-            k3 = pow2 ? melspec_stream3_kernel<NC, E, true, FMT, 0> : melspec_stream3_kernel<NC, E, false, FMT, 0>;
+            k3 = pow2 ? melspec_stream3_kernel<NC, E, true, FMT, 0, S3_WAVES> : melspec_stream3_kernel<NC, E, false, FMT, 0, S3_WAVES>;
         }
-        long long b3 = (total + S3_WAVES - 1) / S3_WAVES;
+        long long b3 = (total + waves3 - 1) / waves3;
         if (b3 > device_cu_count()) b3 = device_cu_count();
         TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(k3), 160 * 1024));
-        hipLaunchKernelGGL(k3, dim3((unsigned)b3), dim3(S3_WAVES * 64), lds3, stream, g, tb, m);
+        hipLaunchKernelGGL(k3, dim3((unsigned)b3), dim3(waves3 * 64), lds3, stream, g, tb, m);
         TAC_HIP(hipGetLastError());
         return TAC_OK;
     }

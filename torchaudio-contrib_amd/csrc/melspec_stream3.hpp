@@ -10,17 +10,22 @@
 
 namespace tac {
 
-constexpr int S3_WAVES = 12;
+constexpr int S3_WAVES = 12;          // default; the float32 fast path takes S3_WAVES_F32
+constexpr int S3_WAVES_F32 = 15;
 
+// exchange areas + bank weights + pass-1 twiddles + frame counter + R2C twiddle table + window table [+ mu-law table]
 template <int NC, int E>
-__host__ __device__ inline size_t stream3_lds_bytes(int wtot) {
+__host__ __device__ inline size_t stream3_lds_bytes(int wtot, int waves, bool coded) {
     using C = StreamCfg<NC, E>;
     size_t xa = ((size_t)C::F::PADDED * sizeof(cf) + 15) & ~(size_t)15;
-    return (size_t)S3_WAVES * xa + (((size_t)wtot * 4 + 15) & ~(size_t)15) + ST_TW_BYTES + 64 + 2 * 64 * 18 * sizeof(cf) + 1024;   // + R2C twiddle rows + window rows + mu-law table
+    return (size_t)waves * xa + (((size_t)wtot * 4 + 15) & ~(size_t)15) + ST_TW_BYTES + 64 + 64 * (C::F::NPAIR + E) * sizeof(cf) + (coded ? 1024 : 0);
 }
 
 #ifndef TAC_S3_PTW_REGS
 #define TAC_S3_PTW_REGS 0
+#endif
+#ifndef TAC_S3_CHUNK
+#define TAC_S3_CHUNK 5
 #endif
 #ifndef TAC_S3_WIN_REGS
 #define TAC_S3_WIN_REGS 0
@@ -28,8 +33,10 @@ __host__ __device__ inline size_t stream3_lds_bytes(int wtot) {
 // FAST1: 0 = any bank the lane layout takes; otherwise the number of steps of slot 1 in the (4, FAST1)-step two-slot layout of
 // a 128-band bank (what tac_melbank_pack produces for the standard mel banks): the contraction fully unrolled
 // FMT: sample format of the frame load (FMT_*): float32, int16 PCM, mu-law codes as uint8 / int64 (converted in registers)
-template <int NC, int E, bool POW2, int FMT, int FAST1>
-__global__ void __launch_bounds__(S3_WAVES * 64, 3)
+// WAVES: waves per workgroup (= per CU).  12 is three per SIMD; 15 (four on three of the SIMDs: what the LDS holds next to a
+// 128-band bank) caps the registers at 128, which costs a handful of loop-invariant reloads per frame
+template <int NC, int E, bool POW2, int FMT, int FAST1, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, (WAVES + 3) / 4)
 melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     using C = StreamCfg<NC, E>;
     using F = typename C::F;
@@ -42,9 +49,9 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     cf* const xa = reinterpret_cast<cf*>(smem_raw + (size_t)w * XA_BYTES);
     float* const prow = reinterpret_cast<float*>(xa);                               // the frame's |X|^2 row, in place
-    float* const wlds = reinterpret_cast<float*>(smem_raw + (size_t)S3_WAVES * XA_BYTES);
+    float* const wlds = reinterpret_cast<float*>(smem_raw + (size_t)WAVES * XA_BYTES);
     float* const twlds = wlds + ((m.wtot + 3) & ~3);
-    for (int i = tid; i < m.wtot; i += S3_WAVES * 64) wlds[i] = m.wl[i];
+    for (int i = tid; i < m.wtot; i += WAVES * 64) wlds[i] = m.wl[i];
     if (tid < 16 * 16) {
         const int js = tid >> 4, q = tid & 15;
         const cf wv = q ? tb.w_nc[js * q * (NC / 256)] : mkc(1.0f, 0.0f);
@@ -52,12 +59,13 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         twlds[js * ST_TW_STRIDE + 2 * (q ? q - 1 : 15) + 1] = wv.y;
     }
     unsigned* const next_frame = reinterpret_cast<unsigned*>(twlds + ST_TW_BYTES / 4);
-    if (tid == 0) *next_frame = S3_WAVES;
-    // the eight R2C twiddles of a lane as one 144-byte row (re-read every frame: 168 registers do not hold them)
+    if (tid == 0) *next_frame = WAVES;
+    // the eight R2C twiddles of a lane (re-read every frame: the register budget does not hold them), as [read u][lane] 16-byte
+    // pairs: every ds_read_b128 of the wave is one contiguous kilobyte
     cf* const ptwl = reinterpret_cast<cf*>(next_frame + 16);
-    for (int idx = tid; idx < 64 * F::NPAIR; idx += S3_WAVES * 64) {
+    for (int idx = tid; idx < 64 * F::NPAIR; idx += WAVES * 64) {
         const int tt = idx / F::NPAIR, p = idx - tt * F::NPAIR;
-        ptwl[tt * 18 + p] = tb.w_n[tt + p * F::LPF];
+        ptwl[((p >> 1) * 64 + tt) * 2 + (p & 1)] = tb.w_n[tt + p * F::LPF];
     }
 
     const long long chunk = (m.total + gridDim.x - 1) / gridDim.x;
@@ -79,15 +87,15 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
 #pragma unroll
     for (int p = 0; p < F::NPAIR; ++p) ptw_regs[p] = tb.w_n[t + p * F::LPF];
 #endif
-    // the window pairs of a lane's sixteen first-pass elements as one 144-byte row, scale folded in
+    // the window pairs of a lane's sixteen first-pass elements, same [read u][lane] layout, scale folded in
     // (2X -> scale * X once, in the window; int16 PCM samples enter as integers: their 2^-15 goes in as well)
     const float half = 0.5f * g.scale * (FMT == FMT_I16 ? (1.0f / 32768.0f) : 1.0f);
-    cf* const winl = ptwl + 64 * 18;
-    for (int idx = tid; idx < 64 * E; idx += S3_WAVES * 64) {
+    cf* const winl = ptwl + 64 * F::NPAIR;
+    for (int idx = tid; idx < 64 * E; idx += WAVES * 64) {
         const int tt = idx / E, q = idx - tt * E;
-        winl[tt * 18 + q] = cscale(window_pair(g, tt + q * F::LPF), half);
+        winl[((q >> 1) * 64 + tt) * 2 + (q & 1)] = cscale(window_pair(g, tt + q * F::LPF), half);
     }
-    float* const lutlds = reinterpret_cast<float*>(winl + 64 * 18);                 // mu-law decode table (coded inputs)
+    float* const lutlds = reinterpret_cast<float*>(winl + 64 * E);                 // mu-law decode table (coded inputs)
     if (FMT >= FMT_MULAW_U8 && tid < 256) lutlds[tid] = m.lut[tid];
 #if TAC_S3_WIN_REGS
     cf win_regs[E];
@@ -186,10 +194,10 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             Dft<16>::run_windowed(v, win_regs);
 #else
             cf win[E];
-            const f4* wl = reinterpret_cast<const f4*>(winl + t * 18);
+            const f4* wl = reinterpret_cast<const f4*>(winl) + t;
 #pragma unroll
             for (int u = 0; u < E / 2; ++u) {
-                const f4 x = wl[u];
+                const f4 x = wl[u * 64];
                 win[2 * u] = mkc(x.x, x.y);
                 win[2 * u + 1] = mkc(x.z, x.w);
             }
@@ -243,10 +251,10 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
 #else
         cf ptw[F::NPAIR];
         {
-            const f4* pl = reinterpret_cast<const f4*>(ptwl + t * 18);
+            const f4* pl = reinterpret_cast<const f4*>(ptwl) + t;
 #pragma unroll
             for (int u = 0; u < F::NPAIR / 2; ++u) {
-                const f4 x = pl[u];
+                const f4 x = pl[u * 64];
                 ptw[2 * u] = mkc(x.x, x.y);
                 ptw[2 * u + 1] = mkc(x.z, x.w);
             }
@@ -276,6 +284,34 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             const f4* wp = reinterpret_cast<const f4*>(wlds) + lane;
             const f4* p0 = reinterpret_cast<const f4*>(prow + lo_s[0]);
             const f4* p1 = reinterpret_cast<const f4*>(prow + lo_s[1]);
+            cf a0 = mkc(0.f, 0.f), a1 = mkc(0.f, 0.f), b0 = mkc(0.f, 0.f), b1 = mkc(0.f, 0.f);
+            if constexpr ((WAVES + 3) / 4 >= 4) {
+            // four waves per SIMD leave 128 registers: the taps arrive in chunks of TAC_S3_CHUNK steps, the other waves cover the waits
+            {
+                f4 w0[ST_FAST_STEPS0], q0[ST_FAST_STEPS0];
+#pragma unroll
+                for (int u = 0; u < ST_FAST_STEPS0; ++u) {
+                    w0[u] = wp[u * 64];
+                    q0[u] = p0[u];
+                }
+#pragma unroll
+                for (int u = 0; u < ST_FAST_STEPS0; ++u) fma4(w0[u], q0[u], a0, a1);
+            }
+#pragma unroll
+            for (int c = 0; c < FAST1; c += TAC_S3_CHUNK) {
+                constexpr int CH = TAC_S3_CHUNK;
+                f4 wc[CH], qc[CH];
+#pragma unroll
+                for (int u = 0; u < CH; ++u)
+                    if (c + u < FAST1) {
+                        wc[u] = wp[(ST_FAST_STEPS0 + c + u) * 64];
+                        qc[u] = p1[c + u];
+                    }
+#pragma unroll
+                for (int u = 0; u < CH; ++u)
+                    if (c + u < FAST1) fma4(wc[u], qc[u], b0, b1);
+            }
+            } else {
             constexpr int B1 = (FAST1 + 1) / 2, B2 = FAST1 - B1;              // slot 1 in two batches
             f4 w0[ST_FAST_STEPS0], q0[ST_FAST_STEPS0], wa[B1], qa[B1];
 #pragma unroll
@@ -288,7 +324,6 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
                 wa[u] = wp[(ST_FAST_STEPS0 + u) * 64];
                 qa[u] = p1[u];
             }
-            cf a0 = mkc(0.f, 0.f), a1 = mkc(0.f, 0.f), b0 = mkc(0.f, 0.f), b1 = mkc(0.f, 0.f);
 #pragma unroll
             for (int u = 0; u < ST_FAST_STEPS0; ++u) fma4(w0[u], q0[u], a0, a1);
             f4 wb[B2], qb[B2];
@@ -301,6 +336,7 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             for (int u = 0; u < B1; ++u) fma4(wa[u], qa[u], b0, b1);
 #pragma unroll
             for (int u = 0; u < B2; ++u) fma4(wb[u], qb[u], b0, b1);
+            }
             float v0 = (a0.x + a0.y) + (a1.x + a1.y), v1 = (b0.x + b0.y) + (b1.x + b1.y);
             if (m.db) {
                 v0 = fast_db ? amp_to_db_fast(v0, m.amin, ten_log10_ref) : amp_to_db(v0, m.amin, m.log10_ref);

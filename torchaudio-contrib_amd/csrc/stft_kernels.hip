@@ -7,6 +7,7 @@
 // Reflect / constant / replicate / circular padding is done by index arithmetic on the unpadded
 // waveform — no padded copy, no framed copy, no separate window multiply.
 #include "host_common.hpp"
+#include "stft_stream3.hpp"
 
 
 #ifndef TAC_STFT_TIMING
@@ -478,6 +479,27 @@ static int launch_pipe(const FrameGeom& g, const Tables& tb, const StftEpilogue&
     return TAC_OK;
 }
 
+// three waves per SIMD (stft_stream3.hpp); TAC_STFT_PIPE2=1 keeps the two-wave pipelined kernel above
+template <int NC, int E, int PMODE>
+static int launch_pipe3(const FrameGeom& g, const Tables& tb, const StftEpilogue& ep, long long groups, hipStream_t stream) {
+    static const bool two_wave = [] { const char* e = getenv("TAC_STFT_PIPE2"); return e && e[0] == '1'; }();
+    if (two_wave) return launch_pipe<NC, E, PMODE>(g, tb, ep, groups, stream);
+    // real rows: four waves per SIMD (0.134 -> 0.115 ms at cfg-2, inputs in the Infinity Cache); complex rows are bound by their
+    // 658 MB of stores either way and measure best with three (profiles/r03/ab_stream3.txt)
+    static const int waves_env = [] { const char* e = getenv("TAC_STFT_S3_WAVES"); return e ? atoi(e) : 0; }();
+    const int waves = waves_env ? waves_env : (PMODE == 0 ? 12 : 16);
+    auto go = [&](auto kern, int W, size_t bytes) {
+        long long blocks = (groups + W - 1) / W;
+        if (blocks > device_cu_count()) blocks = device_cu_count();
+        TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes));
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W * 64), bytes, stream, g, tb, ep);
+        TAC_HIP(hipGetLastError());
+        return (int)TAC_OK;
+    };
+    if (waves == 12) return go(stft_stream3_kernel<NC, E, PMODE, 12>, 12, stft_stream3_lds_bytes<NC, E, 12>());
+    return go(stft_stream3_kernel<NC, E, PMODE, 16>, 16, stft_stream3_lds_bytes<NC, E, 16>());
+}
+
 template <int NC, int E, int MODE>
 static int launch_stft(const FrameGeom& g, const Tables& tb, const StftEpilogue& ep, hipStream_t stream) {
     using F = WaveFft<NC, E>;
@@ -496,11 +518,11 @@ static int launch_stft(const FrameGeom& g, const Tables& tb, const StftEpilogue&
             else if (ep.power == 1.0f) pmode = ep.db ? 4 : 2;
         }
         switch (pmode) {
-            case 0: return launch_pipe<NC, E, 0>(g, tb, ep, groups, stream);
-            case 1: return launch_pipe<NC, E, 1>(g, tb, ep, groups, stream);
-            case 2: return launch_pipe<NC, E, 2>(g, tb, ep, groups, stream);
-            case 3: return launch_pipe<NC, E, 3>(g, tb, ep, groups, stream);
-            case 4: return launch_pipe<NC, E, 4>(g, tb, ep, groups, stream);
+            case 0: return launch_pipe3<NC, E, 0>(g, tb, ep, groups, stream);
+            case 1: return launch_pipe3<NC, E, 1>(g, tb, ep, groups, stream);
+            case 2: return launch_pipe3<NC, E, 2>(g, tb, ep, groups, stream);
+            case 3: return launch_pipe3<NC, E, 3>(g, tb, ep, groups, stream);
+            case 4: return launch_pipe3<NC, E, 4>(g, tb, ep, groups, stream);
             default: break;
         }
     }
