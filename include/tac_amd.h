@@ -232,6 +232,12 @@ int tac_mulaw_decode_f32_f32(const float* codes, int64_t n, int32_t n_quantize, 
  *       exist in memory.  `workspace`
  *       (device) must hold tac_spectrogram_backward_ola_workspace(d) bytes (that call returns a negative TAC_E_* code
  *       for geometries the form does not cover); grad_wave[r][j] at grad_wave + r * grad_row_stride + j.
+ *     tac_melspectrogram_backward_ola_f32: the same for the mel chain (layers.py:333-339, functional.py:183-184): `grad_mel`
+ *       is the gradient of the (linear) mel values, (rows, n_frames, n_mels) frame-major, and the filterbank stage's adjoint
+ *       — two multiply-adds per bin through the table of tac_filterbank_adjoint_pack — is formed inside the kernel, per
+ *       frame: the gradient of the power spectrogram never exists in memory.  fft_length 2048, n_mels <= 256, banks with at
+ *       most two non-zero weights per bin; TAC_E_UNSUPPORTED otherwise (callers then run tac_apply_filterbank_adjoint_f32 +
+ *       tac_spectrogram_backward_ola_f32).  Same workspace as tac_spectrogram_backward_ola_f32.
  *     tac_overlap_add_f32: adjoint of framing + padding: grad_wave[r][j] = sum of grad_frames over every (frame, tap)
  *       that read sample j, reflect / replicate / circular images included (a gather: deterministic, no atomics).
  *     tac_complex_norm_backward_f32: grad_z[i] = grad_out[i] * power * |z_i|^(power-2) * z_i (0 where z_i == 0),
@@ -253,6 +259,10 @@ int64_t tac_spectrogram_backward_ola_workspace(const tac_stft_desc* d);
 int tac_spectrogram_backward_ola_f32(const float* wave, const float* window, const tac_stft_desc* d,
                                      const float* grad_norm, float power, void* workspace, int64_t workspace_bytes,
                                      float* grad_wave, int64_t grad_row_stride, void* stream);
+int tac_melspectrogram_backward_ola_f32(const float* wave, const float* window, const tac_stft_desc* d,
+                                        const float* grad_mel, int32_t n_mels, const void* adjoint_table,
+                                        int32_t n_freqs, float power, void* workspace, int64_t workspace_bytes,
+                                        float* grad_wave, int64_t grad_row_stride, void* stream);
 int tac_filterbank_adjoint_pack(const float* fb, int32_t n_freqs, int32_t n_mels, void* table,
                                 int32_t* max_nonzeros_host, void* stream);
 int tac_apply_filterbank_adjoint_f32(const float* grad_mel, int64_t rows_times_frames, int32_t n_mels,

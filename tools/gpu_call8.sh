@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/ab
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
-for rep in 1 2; do
+timeout 600 python -m pytest tests -m gpu -x -q -k "mel or golden or g0" 2>&1 | tail -3
+for rep in 1 2 3; do
 for rot in 1 4; do
   export TAC_ROTATE=$rot
   echo "== rotate $rot"

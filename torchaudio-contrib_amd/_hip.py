@@ -670,6 +670,42 @@ def apply_filterbank_backward(grad_out, fb):
     return apply_filterbank(grad_out, transposed_bank(fb), allow_sparse=False)
 
 
+def melspectrogram_backward_fused(grad_mel, wave, window, fb, n_fft, hop, win_length, center, pad_mode, normalized, power):
+    """Gradient of the waveform from the gradient of the (linear) mel values ``(*, M, T)`` in ONE kernel: the filterbank
+    adjoint is formed per frame inside the backward kernel (tac_melspectrogram_backward_ola_f32), so the gradient of the
+    power spectrogram — 4·F bytes per frame written by the adjoint kernel and read back by the backward kernel — never
+    exists.  None when the form does not cover the case (fft_length other than 2048, more than 256 bands, a bank with
+    more than two non-zero weights per bin): the caller then runs the two kernels."""
+    if n_fft != 2048 or fb.dim() != 2 or fb.shape[1] > 256 or MEL_PATH == 'mfma':
+        return None
+    table = _adjoint_table(fb)
+    if table is None:
+        return None
+    g = geometry(wave, n_fft, hop, win_length, center, pad_mode, normalized, True)
+    if g.desc is None:
+        return None
+    need = _native.lib().tac_spectrogram_backward_ola_workspace(g.desc)
+    if need < 0:
+        return None
+    n_freqs, n_mels = fb.shape
+    gm = grad_mel.transpose(-2, -1)                                   # physical frame-major (*, T, M)
+    gm = gm if gm.is_contiguous() else gm.contiguous()
+    if gm.dtype != torch.float32:
+        gm = gm.float()
+    out = torch.empty(tuple(wave.shape), dtype=torch.float32, device=wave.device)
+    work = torch.empty(max(int(need), 4) // 4, dtype=torch.float32, device=wave.device)
+    with _native.on_device(wave.device):
+        rc = _native.lib().tac_melspectrogram_backward_ola_f32(
+            _native.ptr(_rows_of(wave, g)), _native.ptr(window), g.desc, _native.ptr(gm), n_mels, _native.ptr(table),
+            n_freqs, float(power), _native.ptr(work), int(need), _native.ptr(out), g.length,
+            _native.stream_ptr(wave.device))
+    if rc == _native.TAC_E_UNSUPPORTED:
+        return None
+    _native.check(rc, 'tac_melspectrogram_backward_ola_f32')
+    _count('tac_melspectrogram_backward_ola_f32')
+    return out
+
+
 def stft_backward(grad_spec, wave, window, n_fft, hop, win_length, center, pad_mode, normalized, grad_norm=None,
                   power=2.0):
     """grad of the one-sided stft output ``(*, F, T, 2)`` w.r.t. the waveform: one inverse real FFT per frame

@@ -229,6 +229,11 @@ def _melspectrogram_hip_backward(saved, rest, needs, grads):
                                                     onesided, power, False, 1.0, 1e-7), g)
     if not (needs[0] or needs[1]):
         return [None, None, grad_bank]
+    if _fast_backward(needs[:2], n_fft, onesided):
+        # fft_length 2048: filterbank adjoint, frame re-transform, norm adjoint, inverse FFT and overlap-add in one kernel
+        gw = H.melspectrogram_backward_fused(g, wave, window, bank, n_fft, hop, win_length, center, pad_mode, normalized, power)
+        if gw is not None:
+            return [gw, None, grad_bank]
     gp = H.apply_filterbank_backward(g, bank)
     if not _fast_backward(needs[:2], n_fft, onesided):
         gw, gwin = _spectrogram_general_backward(wave, window, rest[:7], power, gp, bool(needs[0]), bool(needs[1]))

@@ -20,6 +20,7 @@
 #include "host_common.hpp"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace tac {
 
@@ -276,10 +277,25 @@ __device__ __forceinline__ bool ola_direct(const FrameGeom& g, const OlaPlan& pl
     return jlo > pad && jhi < L - 1 - pad;
 }
 
-template <bool POW2>
-__global__ void __launch_bounds__(OLA_WAVES * 64, 2)
+// per-bin entry of the band-sparse filterbank adjoint (built by fb_adjoint_pack_kernel below)
+struct AdjEntry { float w0, w1; int b0, b1; };
+
+// FUSE: `gnorm` is the gradient of the MEL values, (rows, T, n_mels) frame-major, and the filterbank adjoint
+// (grad_mel . fb^T, two multiply-adds per bin through `adj`) happens here, per frame, out of a 16 KB LDS table: the
+// 4 F bytes per frame of gradient spectrogram that fb_adjoint_kernel writes and this kernel reads back never exist.
+// What makes room for the table is the ring: of a frame's 16 chunks of 128 samples the first H = hop / 128 complete at once,
+// so 16 - H slots are ever live (plan.ring_slots; 16 in the unfused form, whose two 4-wave workgroups per CU do not share tables).
+struct OlaFuse {
+    const AdjEntry* adj;   // [n_freqs]
+    int n_mels;            // <= 256
+    int mel_stride;        // floats per wave of mel-gradient row in LDS (n_mels rounded up to 64)
+    int ring_slots;        // R
+};
+
+template <bool POW2, bool FUSE, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, 2)
 spectrogram_backward_ola_kernel(FrameGeom g, Tables tb, const float* __restrict__ gnorm, float power,
-                                float* __restrict__ gpad, float* __restrict__ edge, OlaPlan plan) {
+                                float* __restrict__ gpad, float* __restrict__ edge, OlaPlan plan, OlaFuse fz) {
     using F = WaveFft<OLA_NC, OLA_E>;
     constexpr int NC = OLA_NC, E = OLA_E, N = OLA_N, NBINS = NC + 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -287,36 +303,52 @@ spectrogram_backward_ola_kernel(FrameGeom g, Tables tb, const float* __restrict_
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int WAVE_SLOTS = ((F::PADDED + 1) / 2) * 2;
     cf* const lds = reinterpret_cast<cf*>(smem_raw) + w * WAVE_SLOTS;
-    cf* const ring = reinterpret_cast<cf*>(smem_raw) + OLA_WAVES * WAVE_SLOTS + w * NC;      // N floats per wave
-    cf* const win_lds = reinterpret_cast<cf*>(smem_raw) + OLA_WAVES * (WAVE_SLOTS + NC);
+    const int R = fz.ring_slots;
+    cf* const ring = reinterpret_cast<cf*>(smem_raw) + WAVES * WAVE_SLOTS + w * (R << 6);   // R slots of 64 sample pairs per wave
+    cf* const win_lds = reinterpret_cast<cf*>(smem_raw) + WAVES * (WAVE_SLOTS + (R << 6));
     cf* const wk_lds = win_lds + NC;
-    for (int m = threadIdx.x; m < NC; m += OLA_WAVES * 64) win_lds[m] = window_pair(g, m);
-    for (int k = threadIdx.x; k <= NC / 2; k += OLA_WAVES * 64) wk_lds[k] = tb.w_n[k];
+    // FUSE: the per-bin adjoint table (16-byte entries) and one mel-gradient row per wave behind the twiddles
+    const AdjEntry* const adj_lds = reinterpret_cast<const AdjEntry*>(wk_lds + NC / 2 + 2);
+    float* const grow = reinterpret_cast<float*>(const_cast<AdjEntry*>(adj_lds) + NBINS) + w * fz.mel_stride;
+    if constexpr (FUSE)
+        for (int k = threadIdx.x; k < NBINS; k += WAVES * 64) const_cast<AdjEntry*>(adj_lds)[k] = fz.adj[k];
+    for (int m = threadIdx.x; m < NC; m += WAVES * 64) win_lds[m] = window_pair(g, m);
+    for (int k = threadIdx.x; k <= NC / 2; k += WAVES * 64) wk_lds[k] = tb.w_n[k];
     __syncthreads();
 
     const int T = (int)g.n_frames, hop = g.hop, H = hop >> 7, S = plan.seg_frames, spr = plan.segs_per_row;
     const long long nseg_total = g.rows * (long long)spr;
-    const long long stride = (long long)gridDim.x * OLA_WAVES;
+    const long long stride = (long long)gridDim.x * WAVES;
     const float wscale = 0.5f * g.scale, xscale = 0.5f * g.scale;
     cf tw[F::NTW];
     F::load_twiddles(tw, tb.w_nc, t);
 
-    long long seg = (long long)blockIdx.x * OLA_WAVES + w;
+    long long seg = (long long)blockIdx.x * WAVES + w;
     if (seg >= nseg_total) return;
     int row = (int)(seg / spr), sidx = (int)(seg - (long long)row * spr);
     int f0 = sidx * S, f1 = f0 + S < T ? f0 + S : T, f = f0;
 
     cf raw[E];
     float gk[E], gm[E];
+    float gq[4];                                            // FUSE: the frame's mel-gradient row, 64 bands per register
     bool pre = false;
     const bool can_prefetch = g.vec2_ok && g.length >= N;
     auto request = [&](int r, int fr) {                     // samples + gradient row of (row r, frame fr), unconditionally
-        const float* gn = gnorm + ((long long)r * T + fr) * NBINS;
+        if constexpr (FUSE) {
+            const float* gn = gnorm + ((long long)r * T + fr) * fz.n_mels;
 #pragma unroll
-        for (int q = 0; q < E; ++q) {
-            const int k = t + q * (NC / E);
-            gk[q] = gn[k];
-            gm[q] = gn[NC - k];
+            for (int i = 0; i < 4; ++i) {
+                const int b = t + 64 * i;
+                gq[i] = gn[b < fz.n_mels ? b : fz.n_mels - 1];
+            }
+        } else {
+            const float* gn = gnorm + ((long long)r * T + fr) * NBINS;
+#pragma unroll
+            for (int q = 0; q < E; ++q) {
+                const int k = t + q * (NC / E);
+                gk[q] = gn[k];
+                gm[q] = gn[NC - k];
+            }
         }
         const long long start = (long long)fr * hop - g.center_pad;
         const bool ok = can_prefetch && start >= 0 && start + N <= g.length;
@@ -331,6 +363,7 @@ spectrogram_backward_ola_kernel(FrameGeom g, Tables tb, const float* __restrict_
         pre = ok;
     };
     request(row, f);
+    int rot = 0;
     while (true) {
         // the item after this one: next frame of the segment, or the first frame of this wave's next segment
         long long nseg = seg;
@@ -367,6 +400,12 @@ spectrogram_backward_ola_kernel(FrameGeom g, Tables tb, const float* __restrict_
         // ---- gradient spectrum -> operands of the inverse transform (see stft_backward_kernel)
         int tg = t;
         asm volatile("" : "+v"(tg));
+        if constexpr (FUSE) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (tg + 64 * i < fz.n_mels) grow[tg + 64 * i] = gq[i];
+            wave_lds_fence();
+        }
 #pragma unroll
         for (int q = 0; q < E; ++q) {
             const int k = tg + q * (NC / E);
@@ -375,8 +414,17 @@ spectrogram_backward_ola_kernel(FrameGeom g, Tables tb, const float* __restrict_
             const cf wkk = k <= NC / 2 ? wk : mkc(-wk.x, wk.y);
             cf hk, hm;
             F::r2c_pair(lds, k, wkk, hk, hm);
-            hk = norm_pow_grad<POW2>(cscale(hk, xscale), gk[q], power);
-            hm = norm_pow_grad<POW2>(cscale(hm, xscale), gm[q], power);
+            float gkq, gmq;
+            if constexpr (FUSE) {                                           // (grad_mel . fb^T)[k], [NC - k]
+                const AdjEntry ek = adj_lds[k], em = adj_lds[NC - k];
+                gkq = __builtin_fmaf(ek.w0, grow[ek.b0], ek.w1 * grow[ek.b1]);
+                gmq = __builtin_fmaf(em.w0, grow[em.b0], em.w1 * grow[em.b1]);
+            } else {
+                gkq = gk[q];
+                gmq = gm[q];
+            }
+            hk = norm_pow_grad<POW2>(cscale(hk, xscale), gkq, power);
+            hm = norm_pow_grad<POW2>(cscale(hm, xscale), gmq, power);
             if (q == 0) {
                 if (k == 0) {
                     hk = mkc(2.0f * hk.x, 0.0f);
@@ -394,7 +442,7 @@ spectrogram_backward_ola_kernel(FrameGeom g, Tables tb, const float* __restrict_
         F::template run<1>(v, ldsv, tw, t);                 // R[] in natural order at lds[lds_pad(i)]
 
         // ---- windowed frame gradient into the ring; complete positions out
-        const int rot = (int)(((long long)f * H) & 15);
+        // slot of chunk j = (j + rot) mod R; rot advances by H per frame of the segment (only differences within a segment matter)
         // (wave-uniform; ola_direct() with the segment already known: no division)
         bool direct = false;
         if (plan.direct && (sidx == 0 || (f - f0) * hop >= N - hop)) {
@@ -406,13 +454,15 @@ spectrogram_backward_ola_kernel(FrameGeom g, Tables tb, const float* __restrict_
         float* const drow = direct ? plan.gwave + (long long)row * plan.gstride + ((long long)f * hop - g.center_pad) : prow;
         const bool row_end = (f1 == T);
         float* const tail = row_end ? prow : edge + ((long long)row * (spr - 1) + sidx) * (N - hop) - hop;   // + n
+        int sl = rot;
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             const int m = t + j * 64;                                       // samples n = 2m, 2m + 1 of the frame
             const cf r = lds[lds_pad(m)];
             const cf wn = win_lds[m];
             cf acc = cmul_elem(cmul_elem(r, wn), mkc(wscale, -wscale));     // (Re, -Im) R[m] · window / 2
-            cf* const slot = ring + (((j + rot) & 15) << 6) + t;
+            cf* const slot = ring + (sl << 6) + t;
+            sl = sl + 1 == R ? 0 : sl + 1;
             if (!(first || j >= 16 - H)) {
                 const cf old = *slot;
                 acc = cadd(acc, old);
@@ -423,9 +473,15 @@ spectrogram_backward_ola_kernel(FrameGeom g, Tables tb, const float* __restrict_
         }
         wave_lds_fence();
         if (!more) break;
+        rot = (nf == nf0) ? 0 : rot + H;
+        while (rot >= R) rot -= R;
         seg = nseg; row = nrow; sidx = nsidx; f0 = nf0; f1 = nf1; f = nf;
     }
 }
+
+}  // namespace tac
+#include "backward_ring3.hpp"
+namespace tac {
 
 // The same for fft_length 256 / 512 / 1024, where a wave carries G = 64 / LPF frames side by side: its G lane groups walk G
 // different SEGMENTS (each with its own ring), so nothing in the ring update crosses lane groups; hop is a multiple of
@@ -778,7 +834,6 @@ static int stft_backward_entry(const float* spec, const float* gnorm, float powe
 // of a GEMM row: fb_adjoint_pack_kernel builds {w0, w1, band0, band1} per bin on the device (and counts the non-zeros of
 // the fullest bin: banks with more than two keep the GEMM), fb_adjoint_kernel streams frames through it — a wave per
 // frame, the frame's mel-gradient row in LDS, 4·F bytes out per frame: write-bound.
-struct AdjEntry { float w0, w1; int b0, b1; };
 
 __global__ void __launch_bounds__(256)
 fb_adjoint_pack_kernel(const float* __restrict__ fb, int n_freqs, int n_mels, AdjEntry* __restrict__ table,
@@ -842,7 +897,7 @@ fb_adjoint_kernel(const float* __restrict__ gmel, long long n_rows_frames, int n
 }
 
 // segmentation of the LDS overlap-add form; TAC_E_UNSUPPORTED for geometries it does not cover
-static int ola_plan(const tac_stft_desc* d, const FrameGeom& g, OlaPlan* plan) {
+static int ola_plan(const tac_stft_desc* d, const FrameGeom& g, OlaPlan* plan, int waves_per_cu = 2 * OLA_WAVES) {
     const int n = d->n_fft;
     if (n != 2048 && n != 1024 && n != 512 && n != 256) return TAC_E_UNSUPPORTED;
     if (!d->onesided || d->hop <= 0 || (d->hop % (n / 16)) || d->hop > n) return TAC_E_UNSUPPORTED;
@@ -850,7 +905,7 @@ static int ola_plan(const tac_stft_desc* d, const FrameGeom& g, OlaPlan* plan) {
     const int T = (int)g.n_frames;
     const int s_min = std::max(1, (n - d->hop + d->hop - 1) / d->hop);
     // one segment per resident frame stream (a wave carries 2048 / n_fft of them)
-    const long long target = (long long)device_cu_count() * 2 * OLA_WAVES * (OLA_N / n);
+    const long long target = (long long)device_cu_count() * waves_per_cu * (OLA_N / n);
     long long spr = (target + g.rows - 1) / g.rows;
     spr = std::max(1LL, std::min(spr, (long long)std::max(1, T / s_min)));
     int S = (int)((T + spr - 1) / spr);
@@ -941,14 +996,23 @@ int64_t tac_spectrogram_backward_ola_workspace(const tac_stft_desc* d) {
     OlaPlan plan;
     rc = ola_plan(d, g, &plan);
     if (rc != TAC_OK) return rc;
-    return (int64_t)ola_workspace_floats(g, plan, d->hop) * (int64_t)sizeof(float);
+    long long floats = ola_workspace_floats(g, plan, d->hop);
+    if (d->n_fft == 2048) {      // the twelve-wave form of the mel chain cuts more segments per row: room for either
+        OlaPlan p12;
+        if (ola_plan(d, g, &p12, BR_WAVES) == TAC_OK) floats = std::max(floats, ola_workspace_floats(g, p12, d->hop));
+    }
+    return (int64_t)floats * (int64_t)sizeof(float);
 }
 
-int tac_spectrogram_backward_ola_f32(const float* wave, const float* window, const tac_stft_desc* d, const float* grad_norm,
-                                     float power, void* workspace, int64_t workspace_bytes, float* grad_wave,
-                                     int64_t grad_row_stride, void* stream) {
-    using namespace tac;
-    if (!wave || !window || !d || !grad_norm || !workspace || !grad_wave) return TAC_E_INVALID;
+}  // extern "C"
+
+namespace tac {
+// shared body of tac_spectrogram_backward_ola_f32 and tac_melspectrogram_backward_ola_f32 (adj != nullptr: `grad` is the
+// gradient of the mel values and the filterbank adjoint is folded into the kernel; fft_length 2048 only)
+static int ola_backward_entry(const float* wave, const float* window, const tac_stft_desc* d, const float* grad, float power,
+                              const AdjEntry* adj, int n_mels, void* workspace, int64_t workspace_bytes, float* grad_wave,
+                              int64_t grad_row_stride, void* stream) {
+    if (!wave || !window || !d || !grad || !workspace || !grad_wave) return TAC_E_INVALID;
     FrameGeom g;
     int64_t T = 0;
     int rc = make_geometry(wave, window, d, &g, &T);
@@ -967,13 +1031,25 @@ int tac_spectrogram_backward_ola_f32(const float* wave, const float* window, con
     plan.direct = (d->n_fft == 2048 && (d->hop & 3) == 0 && (g.center_pad & 3) == 0) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     const bool pow2 = (power == 2.0f);
-    auto launch = [&](auto kern, size_t lds_bytes, int streams_per_wave) -> int {
+    OlaFuse fz{nullptr, 0, 0, 16};
+    auto launch = [&](auto kern, size_t lds_bytes, int streams_per_wave, int waves = OLA_WAVES) -> int {
+        const long long nwork = (g.rows * (long long)plan.segs_per_row + streams_per_wave - 1) / streams_per_wave;
+        long long blocks = (nwork + waves - 1) / waves;
+        const long long cap = (long long)device_cu_count() * 2 * OLA_WAVES / waves;
+        if (blocks > cap) blocks = cap;
+        TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds_bytes));
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(waves * 64), lds_bytes, s, g, tb, grad, power, gpad,
+                           edge, plan, fz);
+        TAC_HIP(hipGetLastError());
+        return TAC_OK;
+    };
+    auto launch_multi = [&](auto kern, size_t lds_bytes, int streams_per_wave) -> int {
         const long long nwork = (g.rows * (long long)plan.segs_per_row + streams_per_wave - 1) / streams_per_wave;
         long long blocks = (nwork + OLA_WAVES - 1) / OLA_WAVES;
         const long long cap = (long long)device_cu_count() * 2;
         if (blocks > cap) blocks = cap;
         TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds_bytes));
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(OLA_WAVES * 64), lds_bytes, s, g, tb, grad_norm, power, gpad,
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(OLA_WAVES * 64), lds_bytes, s, g, tb, grad, power, gpad,
                            edge, plan);
         TAC_HIP(hipGetLastError());
         return TAC_OK;
@@ -984,29 +1060,79 @@ int tac_spectrogram_backward_ola_f32(const float* wave, const float* window, con
         return (size_t)OLA_WAVES * ((size_t)(((gframes * padded + 1) / 2) * 2) + (size_t)gframes * nc) * sizeof(cf) +
                (size_t)(nc + nc / 2 + 2) * sizeof(cf);
     };
+    static const bool lds_ring = [] { const char* e = getenv("TAC_BWD_LDS_RING"); return e && e[0] == '1'; }();
+    if (adj && d->n_fft == 2048 && n_mels >= 1 && n_mels <= 256 && !lds_ring && g.length >= OLA_N &&
+        (d->hop == 256 || d->hop == 512 || d->hop == 1024)) {
+        // twelve waves per CU, the ring in registers (backward_ring3.hpp): its own segmentation, one segment per wave
+        OlaPlan p12;
+        rc = ola_plan(d, g, &p12, BR_WAVES);
+        if (rc != TAC_OK) return rc;
+        if (workspace_bytes < (int64_t)(ola_workspace_floats(g, p12, d->hop) * (long long)sizeof(float))) return TAC_E_INVALID;
+        p12.gwave = plan.gwave;
+        p12.gstride = plan.gstride;
+        p12.direct = plan.direct;
+        plan = p12;
+        edge = gpad + g.rows * plan.pad_len;
+        fz.adj = adj;
+        fz.n_mels = n_mels;
+        fz.mel_stride = (n_mels + 63) & ~63;
+        fz.ring_slots = 16 - (d->hop >> 7);
+        const size_t lds = ring3_lds_bytes<OLA_NC, OLA_E>(fz.mel_stride);
+        const long long nseg = g.rows * (long long)plan.segs_per_row;
+        long long blocks = (nseg + BR_WAVES - 1) / BR_WAVES;
+        if (blocks > device_cu_count()) blocks = device_cu_count();
+        auto go = [&](auto kern) -> int {
+            TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds));
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BR_WAVES * 64), lds, s, g, tb, grad, power, gpad, edge, plan, fz);
+            TAC_HIP(hipGetLastError());
+            return TAC_OK;
+        };
+        switch (d->hop) {
+            case 256: rc = pow2 ? go(melspec_backward_ring3_kernel<true, 2>) : go(melspec_backward_ring3_kernel<false, 2>); break;
+            case 512: rc = pow2 ? go(melspec_backward_ring3_kernel<true, 4>) : go(melspec_backward_ring3_kernel<false, 4>); break;
+            default: rc = pow2 ? go(melspec_backward_ring3_kernel<true, 8>) : go(melspec_backward_ring3_kernel<false, 8>); break;
+        }
+    } else if (adj) {
+        // one 8-wave workgroup per CU around one copy of the tables; the ring shrinks to its 16 - H live slots
+        using F = WaveFft<OLA_NC, OLA_E>;
+        constexpr int FW = 2 * OLA_WAVES;
+        if (d->n_fft != 2048 || n_mels < 1 || n_mels > 256) return TAC_E_UNSUPPORTED;
+        const int H = d->hop >> 7;
+        fz.adj = adj;
+        fz.n_mels = n_mels;
+        fz.mel_stride = (n_mels + 63) & ~63;
+        fz.ring_slots = H >= 16 ? 1 : 16 - H;
+        const size_t lds = (size_t)FW * ((size_t)(((F::PADDED + 1) / 2) * 2) + (size_t)fz.ring_slots * 64) * sizeof(cf) +
+                           (size_t)(OLA_NC + OLA_NC / 2 + 2) * sizeof(cf) + (size_t)(OLA_NC + 1) * sizeof(AdjEntry) +
+                           (size_t)FW * fz.mel_stride * sizeof(float);
+        if (lds > 160 * 1024) return TAC_E_UNSUPPORTED;
+        rc = pow2 ? launch(spectrogram_backward_ola_kernel<true, true, FW>, lds, 1, FW)
+                  : launch(spectrogram_backward_ola_kernel<false, true, FW>, lds, 1, FW);
+    } else
     switch (d->n_fft) {
         case 2048: {
             using F = WaveFft<OLA_NC, OLA_E>;
-            rc = pow2 ? launch(spectrogram_backward_ola_kernel<true>, lds_for(OLA_NC, F::PADDED, 1), 1)
-                      : launch(spectrogram_backward_ola_kernel<false>, lds_for(OLA_NC, F::PADDED, 1), 1);
+            fz.ring_slots = 16;
+            rc = pow2 ? launch(spectrogram_backward_ola_kernel<true, false, OLA_WAVES>, lds_for(OLA_NC, F::PADDED, 1), 1)
+                      : launch(spectrogram_backward_ola_kernel<false, false, OLA_WAVES>, lds_for(OLA_NC, F::PADDED, 1), 1);
             break;
         }
         case 1024: {
             using F = WaveFft<512, OLA_E>;
-            rc = pow2 ? launch(spectrogram_backward_ola_multi_kernel<512, true>, lds_for(512, F::PADDED, F::G), F::G)
-                      : launch(spectrogram_backward_ola_multi_kernel<512, false>, lds_for(512, F::PADDED, F::G), F::G);
+            rc = pow2 ? launch_multi(spectrogram_backward_ola_multi_kernel<512, true>, lds_for(512, F::PADDED, F::G), F::G)
+                      : launch_multi(spectrogram_backward_ola_multi_kernel<512, false>, lds_for(512, F::PADDED, F::G), F::G);
             break;
         }
         case 512: {
             using F = WaveFft<256, OLA_E>;
-            rc = pow2 ? launch(spectrogram_backward_ola_multi_kernel<256, true>, lds_for(256, F::PADDED, F::G), F::G)
-                      : launch(spectrogram_backward_ola_multi_kernel<256, false>, lds_for(256, F::PADDED, F::G), F::G);
+            rc = pow2 ? launch_multi(spectrogram_backward_ola_multi_kernel<256, true>, lds_for(256, F::PADDED, F::G), F::G)
+                      : launch_multi(spectrogram_backward_ola_multi_kernel<256, false>, lds_for(256, F::PADDED, F::G), F::G);
             break;
         }
         case 256: {
             using F = WaveFft<128, OLA_E>;
-            rc = pow2 ? launch(spectrogram_backward_ola_multi_kernel<128, true>, lds_for(128, F::PADDED, F::G), F::G)
-                      : launch(spectrogram_backward_ola_multi_kernel<128, false>, lds_for(128, F::PADDED, F::G), F::G);
+            rc = pow2 ? launch_multi(spectrogram_backward_ola_multi_kernel<128, true>, lds_for(128, F::PADDED, F::G), F::G)
+                      : launch_multi(spectrogram_backward_ola_multi_kernel<128, false>, lds_for(128, F::PADDED, F::G), F::G);
             break;
         }
         default: return TAC_E_UNSUPPORTED;
@@ -1020,6 +1146,26 @@ int tac_spectrogram_backward_ola_f32(const float* wave, const float* window, con
                        (long long)grad_row_stride);
     TAC_HIP(hipGetLastError());
     return TAC_OK;
+}
+}  // namespace tac
+
+extern "C" {
+
+int tac_spectrogram_backward_ola_f32(const float* wave, const float* window, const tac_stft_desc* d, const float* grad_norm,
+                                     float power, void* workspace, int64_t workspace_bytes, float* grad_wave,
+                                     int64_t grad_row_stride, void* stream) {
+    return tac::ola_backward_entry(wave, window, d, grad_norm, power, nullptr, 0, workspace, workspace_bytes, grad_wave,
+                                   grad_row_stride, stream);
+}
+
+int tac_melspectrogram_backward_ola_f32(const float* wave, const float* window, const tac_stft_desc* d, const float* grad_mel,
+                                        int32_t n_mels, const void* adjoint_table, int32_t n_freqs, float power,
+                                        void* workspace, int64_t workspace_bytes, float* grad_wave, int64_t grad_row_stride,
+                                        void* stream) {
+    if (!adjoint_table || !d) return TAC_E_INVALID;
+    if (n_freqs != d->n_fft / 2 + 1) return TAC_E_INVALID;
+    return tac::ola_backward_entry(wave, window, d, grad_mel, power, static_cast<const tac::AdjEntry*>(adjoint_table), n_mels,
+                                   workspace, workspace_bytes, grad_wave, grad_row_stride, stream);
 }
 
 int tac_overlap_add_f32(const float* grad_frames, const tac_stft_desc* d, float* grad_wave, int64_t grad_row_stride,

@@ -392,7 +392,10 @@ static int launch_stream(FrameGeom g, const Tables& tb, const SparseArgs& sm, co
     // Round 3: the three-waves-per-SIMD form (melspec_stream3.hpp) is the route; TAC_STREAM2=1 selects round 2's two-frame
     // rotation (kept for A/B runs and for tools/stream_timing.py)
     static const bool two_waves = getenv("TAC_STREAM2") != nullptr;
-    static const int waves_f32 = [] { const char* e = getenv("TAC_S3_WAVES"); return e ? atoi(e) : S3_WAVES_F32; }();
+    // 12 waves per CU ship; TAC_S3_WAVES=15 selects the 128-register form (four waves on three of the SIMDs), measured
+    // 11 % SLOWER at cfg-2 (0.125 vs 0.113 ms: its 48 bytes of scratch and the chunked contraction cost more than the extra
+    // waves hide — profiles/r03/ab_stream3.txt)
+    static const int waves_f32 = [] { const char* e = getenv("TAC_S3_WAVES"); return e ? atoi(e) : S3_WAVES; }();
     constexpr bool coded = FMT != FMT_F32;
     const int waves3 = (!coded && waves_f32 == S3_WAVES_F32 && stream3_lds_bytes<NC, E>(sm.wtot, S3_WAVES_F32, false) <= 160 * 1024)
                            ? S3_WAVES_F32 : S3_WAVES;

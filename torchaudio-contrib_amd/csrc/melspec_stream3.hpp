@@ -10,15 +10,15 @@
 
 namespace tac {
 
-constexpr int S3_WAVES = 12;          // default; the float32 fast path takes S3_WAVES_F32
-constexpr int S3_WAVES_F32 = 15;
+constexpr int S3_WAVES = 12;          // what ships
+constexpr int S3_WAVES_F32 = 15;      // A/B form (TAC_S3_WAVES=15): as many 128-register waves as the LDS holds next to a 128-band bank
 
 // exchange areas + bank weights + pass-1 twiddles + frame counter + R2C twiddle table + window table [+ mu-law table]
 template <int NC, int E>
 __host__ __device__ inline size_t stream3_lds_bytes(int wtot, int waves, bool coded) {
     using C = StreamCfg<NC, E>;
     size_t xa = ((size_t)C::F::PADDED * sizeof(cf) + 15) & ~(size_t)15;
-    return (size_t)waves * xa + (((size_t)wtot * 4 + 15) & ~(size_t)15) + ST_TW_BYTES + 64 + 64 * (C::F::NPAIR + E) * sizeof(cf) + (coded ? 1024 : 0);
+    return (size_t)waves * xa + (((size_t)wtot * 4 + 15) & ~(size_t)15) + ST_TW_BYTES + 16 + 64 * (C::F::NPAIR + E) * sizeof(cf) + (coded ? 1024 : 0);
 }
 
 #ifndef TAC_S3_PTW_REGS
@@ -62,7 +62,7 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     if (tid == 0) *next_frame = WAVES;
     // the eight R2C twiddles of a lane (re-read every frame: the register budget does not hold them), as [read u][lane] 16-byte
     // pairs: every ds_read_b128 of the wave is one contiguous kilobyte
-    cf* const ptwl = reinterpret_cast<cf*>(next_frame + 16);
+    cf* const ptwl = reinterpret_cast<cf*>(next_frame + 4);
     for (int idx = tid; idx < 64 * F::NPAIR; idx += WAVES * 64) {
         const int tt = idx / F::NPAIR, p = idx - tt * F::NPAIR;
         ptwl[((p >> 1) * 64 + tt) * 2 + (p & 1)] = tb.w_n[tt + p * F::LPF];
