@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Tiny driver for rocprofv3: launch one kernel family a few times at cfg-2 size.
-    python tools/prof_driver.py mel|stft|spec|fb|grad|gradf|mulaw [iters]"""
+    python tools/prof_driver.py mel|stft|spec|fb|grad|gradf|gradspec|mulaw [iters]"""
 import os
 import sys
 
@@ -37,6 +37,14 @@ elif what == 'grad':
     # fused forward kernel), differentiated through the tac_amd::melspectrogram op's HIP gradient kernels
     m = torch.nn.Sequential(*tac.Melspectrogram(num_mels=128, sample_rate=16000, fft_length=2048, hop_length=512),
                             tac.AmplitudeToDb()).cuda()
+    xg = x.clone().requires_grad_(True)
+    def fn():
+        y = m(xg)
+        y.backward(torch.ones_like(y))
+        return y
+elif what == 'gradspec':
+    # training step through the Spectrogram layer (power 2): fused forward kernel, one backward kernel + border fold
+    m = tac.Spectrogram(2048, 512, power=2.).cuda()
     xg = x.clone().requires_grad_(True)
     def fn():
         y = m(xg)

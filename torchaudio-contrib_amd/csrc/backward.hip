@@ -1061,7 +1061,7 @@ static int ola_backward_entry(const float* wave, const float* window, const tac_
                (size_t)(nc + nc / 2 + 2) * sizeof(cf);
     };
     static const bool lds_ring = [] { const char* e = getenv("TAC_BWD_LDS_RING"); return e && e[0] == '1'; }();
-    if (adj && d->n_fft == 2048 && n_mels >= 1 && n_mels <= 256 && !lds_ring && g.length >= OLA_N &&
+    if (d->n_fft == 2048 && (!adj || (n_mels >= 1 && n_mels <= 256)) && !lds_ring && g.length >= OLA_N &&
         (d->hop == 256 || d->hop == 512 || d->hop == 1024)) {
         // twelve waves per CU, the ring in registers (backward_ring3.hpp): its own segmentation, one segment per wave
         OlaPlan p12;
@@ -1074,8 +1074,8 @@ static int ola_backward_entry(const float* wave, const float* window, const tac_
         plan = p12;
         edge = gpad + g.rows * plan.pad_len;
         fz.adj = adj;
-        fz.n_mels = n_mels;
-        fz.mel_stride = (n_mels + 63) & ~63;
+        fz.n_mels = adj ? n_mels : 0;
+        fz.mel_stride = adj ? (n_mels + 63) & ~63 : 0;
         fz.ring_slots = 16 - (d->hop >> 7);
         const size_t lds = ring3_lds_bytes<OLA_NC, OLA_E>(fz.mel_stride);
         const long long nseg = g.rows * (long long)plan.segs_per_row;
@@ -1087,10 +1087,15 @@ static int ola_backward_entry(const float* wave, const float* window, const tac_
             TAC_HIP(hipGetLastError());
             return TAC_OK;
         };
+        auto pick = [&](auto h_tag) -> int {
+            constexpr int HH = decltype(h_tag)::value;
+            if (adj) return pow2 ? go(melspec_backward_ring3_kernel<true, HH, true>) : go(melspec_backward_ring3_kernel<false, HH, true>);
+            return pow2 ? go(melspec_backward_ring3_kernel<true, HH, false>) : go(melspec_backward_ring3_kernel<false, HH, false>);
+        };
         switch (d->hop) {
-            case 256: rc = pow2 ? go(melspec_backward_ring3_kernel<true, 2>) : go(melspec_backward_ring3_kernel<false, 2>); break;
-            case 512: rc = pow2 ? go(melspec_backward_ring3_kernel<true, 4>) : go(melspec_backward_ring3_kernel<false, 4>); break;
-            default: rc = pow2 ? go(melspec_backward_ring3_kernel<true, 8>) : go(melspec_backward_ring3_kernel<false, 8>); break;
+            case 256: rc = pick(std::integral_constant<int, 2>{}); break;
+            case 512: rc = pick(std::integral_constant<int, 4>{}); break;
+            default: rc = pick(std::integral_constant<int, 8>{}); break;
         }
     } else if (adj) {
         // one 8-wave workgroup per CU around one copy of the tables; the ring shrinks to its 16 - H live slots

@@ -27,7 +27,9 @@ __host__ __device__ inline size_t ring3_lds_bytes(int mel_stride) {
            (size_t)BR_WAVES * mel_stride * sizeof(float);
 }
 
-template <bool POW2, int H>
+// FUSE: `gmel` is the gradient of the mel values and the filterbank adjoint happens here (fz); otherwise it is the gradient of
+// |z|^power itself, (rows, T, NC + 1) frame-major (tac_spectrogram_backward_ola_f32), fetched per pair at the top of the frame
+template <bool POW2, int H, bool FUSE>
 __global__ void __launch_bounds__(BR_WAVES * 64, 3)
 melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ gmel, float power, float* __restrict__ gpad,
                               float* __restrict__ edge, OlaPlan plan, OlaFuse fz) {
@@ -60,7 +62,8 @@ melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ 
         winl[((q >> 1) * 64 + tt) * 2 + (q & 1)] = cscale(window_pair(g, tt + q * F::LPF), half);
     }
     AdjEntry* const adj_lds = reinterpret_cast<AdjEntry*>(winl + 64 * E);
-    for (int k = tid; k < NBINS; k += WAVES * 64) adj_lds[k] = fz.adj[k];
+    if constexpr (FUSE)
+        for (int k = tid; k < NBINS; k += WAVES * 64) adj_lds[k] = fz.adj[k];
     float* const grow = reinterpret_cast<float*>(adj_lds + NBINS) + w * fz.mel_stride;
     __syncthreads();
 
@@ -84,11 +87,13 @@ melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ 
     float gq[4];
     int mode = 0;
     auto request = [&](int r, int fr) {                     // samples + mel-gradient row of (row r, frame fr), unconditionally
-        const float* gn = gmel + ((long long)r * T + fr) * fz.n_mels;
+        if constexpr (FUSE) {
+            const float* gn = gmel + ((long long)r * T + fr) * fz.n_mels;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int b = t + 64 * i;
-            gq[i] = gn[b < fz.n_mels ? b : fz.n_mels - 1];
+            for (int i = 0; i < 4; ++i) {
+                const int b = t + 64 * i;
+                gq[i] = gn[b < fz.n_mels ? b : fz.n_mels - 1];
+            }
         }
         const long long start = (long long)fr * hop - g.center_pad;
         const bool ok = g.vec2_ok && start >= 0 && start + N <= g.length;
@@ -151,6 +156,17 @@ melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ 
         }
         const bool last = (f + 1 == f1);
 
+        // (unfused: the gradient values of this lane's eight pairs and of bin NC / 2 travel behind the forward transform)
+        float gk[F::NPAIR], gm[F::NPAIR], gmid_reg = 0.0f;
+        if constexpr (!FUSE) {
+            const float* gn = gmel + ((long long)row * T + f) * NBINS;
+#pragma unroll
+            for (int p = 0; p < F::NPAIR; ++p) {
+                gk[p] = gn[t + p * F::LPF];
+                gm[p] = gn[NC - (t + p * F::LPF)];
+            }
+            gmid_reg = gn[NC / 2];
+        }
         // ---- forward transform of the frame
         if (mode == 1) {
             cf win[E];
@@ -182,9 +198,11 @@ melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ 
             zmid = xa[lds_pad(NC / 2)];
         }
         // the frame's mel-gradient row, for the per-bin gathers
+        if constexpr (FUSE) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (t + 64 * i < fz.n_mels) grow[t + 64 * i] = gq[i];
+            for (int i = 0; i < 4; ++i)
+                if (t + 64 * i < fz.n_mels) grow[t + 64 * i] = gq[i];
+        }
         wave_lds_fence();                                   // partners in registers: the exchange area is free again
 
         // ---- gradient spectrum, pair by pair -> operands of the inverse transform
@@ -208,8 +226,16 @@ melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ 
             const int k = t + p * F::LPF;
             cf xk, xm;                                      // X[k], X[NC - k] (scale folded into the window)
             F::r2c_split_x2(v[F::reg_of_spectrum(p)], zm[p], ptw[p], xk, xm);
-            cf hk = norm_pow_grad<POW2>(xk, bin_grad(k), power);
-            cf hm = norm_pow_grad<POW2>(xm, bin_grad(NC - k), power);
+            float gkp, gmp;
+            if constexpr (FUSE) {
+                gkp = bin_grad(k);
+                gmp = bin_grad(NC - k);
+            } else {
+                gkp = gk[p];
+                gmp = gm[p];
+            }
+            cf hk = norm_pow_grad<POW2>(xk, gkp, power);
+            cf hm = norm_pow_grad<POW2>(xm, gmp, power);
             if (p == 0) {                                   // DC and Nyquist: H = 2 Re G
                 const bool dc = (t == 0);
                 hk = mkc(dc ? 2.0f * hk.x : hk.x, dc ? 0.0f : hk.y);
@@ -223,7 +249,9 @@ melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ 
             cf xk, xm;
             const cf wq = mkc(0.0f, -1.0f);
             F::r2c_split_x2(zmid, zmid, wq, xk, xm);
-            const float gmid = bin_grad(NC / 2);
+            float gmid;
+            if constexpr (FUSE) gmid = bin_grad(NC / 2);
+            else gmid = gmid_reg;
             xa[lds_pad(NC / 2)] = c2r_operand(norm_pow_grad<POW2>(xk, gmid, power), norm_pow_grad<POW2>(xm, gmid, power), wq);
         }
         wave_lds_fence();
