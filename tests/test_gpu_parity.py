@@ -246,7 +246,9 @@ def test_tiny_inputs_every_kernel_family(tac):
                 assert rel_err(got[..., 0] + 1j * got[..., 1], ref) < 5e-6, (n, length, center, rows)
                 spec = host(torch.nn.Sequential(*tac.Spectrogram(n, hop, center=center, power=2.), tac.AmplitudeToDb()).cuda()(dev(x)))
                 want = 10.0 * np.log10(np.maximum((np.abs(ref) ** 2) ** 2, 1e-7))
-                big = np.abs(ref) ** 2 > 1e-6 * (np.abs(ref) ** 2).max()
+                # (amplitude_to_db squares the power: a bin 50 dB under the frame's peak carries ~3e-5 of relative fp32 FFT
+                #  noise in |X|, 1.2e-4 in |X|^4, 5e-4 dB — bins further down are beyond DB_ABS for ANY float32 transform)
+                big = np.abs(ref) ** 2 > 1e-5 * (np.abs(ref) ** 2).max()
                 assert np.abs(spec - want)[big].max() < DB_ABS, (n, length, center, rows)
                 if n >= 256:
                     mel = tac.Melspectrogram(num_mels=40, sample_rate=16000, fft_length=n, hop_length=hop, center=center).cuda()

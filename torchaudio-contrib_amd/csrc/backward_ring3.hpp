@@ -168,7 +168,12 @@ melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ 
             gmid_reg = gn[NC / 2];
         }
         // ---- forward transform of the frame
-        if (mode == 1) {
+        if (mode != 1) {                                    // frames touching the padding gather their samples first
+            int tz;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(tz) : "v"(t));
+            load_frame<F, false, true, true>(v, g, nullptr, xa, row, f, tz, FetchF32{g.wave});
+        }
+        {
             cf win[E];
             const f4* wl = reinterpret_cast<const f4*>(winl) + t;
 #pragma unroll
@@ -178,13 +183,6 @@ melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ 
                 win[2 * u + 1] = mkc(x.z, x.w);
             }
             Dft<16>::run_windowed(v, win);
-        } else {
-            int tz;
-            asm volatile("v_mov_b32 %0, %1" : "=v"(tz) : "v"(t));
-            load_frame<F, false, true>(v, g, nullptr, xa, row, f, tz, FetchF32{g.wave});
-#pragma unroll
-            for (int e = 0; e < E; ++e) v[e] = cscale(v[e], half);
-            F::template pass_butterflies<0>(v);
         }
         passes_after_first(std::true_type{});
         cf zm[F::NPAIR], zmid;

@@ -639,7 +639,9 @@ __device__ __forceinline__ void load_frame(cf* v, const FrameGeom& g, const cf* 
 }
 
 // GATHER_ONLY: never take the vectorised interior path (which reads g.wave as float pairs)
-template <class F, bool HOIST_WIN, bool GATHER_ONLY, class Fetch>
+// RAW: deliver the (padded) samples UNwindowed — the caller multiplies by the window exactly as it does for interior frames,
+// so that a frame's values do not depend on which path fetched it
+template <class F, bool HOIST_WIN, bool GATHER_ONLY, bool RAW = false, class Fetch>
 __device__ __forceinline__ void load_frame(cf* v, const FrameGeom& g, const cf* win, cf* lds, long long row,
                                            long long frame, int t, Fetch fetch) {
     constexpr int R0 = radix_at(F::NC, 0);
@@ -684,7 +686,7 @@ __device__ __forceinline__ void load_frame(cf* v, const FrameGeom& g, const cf* 
             for (int u = 0; u < 8; ++u) a[u] = fetch(row_offset, j[u]);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const cf w = window_pair(g, mm[u]);
+                const cf w = RAW ? mkc(1.0f, 1.0f) : window_pair(g, mm[u]);
                 lds[lds_pad(mm[u])] = mkc(z[2 * u] ? 0.0f : a[2 * u] * w.x, z[2 * u + 1] ? 0.0f : a[2 * u + 1] * w.y);
             }
         }

@@ -190,6 +190,12 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         // ---- s0: window, pass 0, exchange
         if (mode == 1) {
             decode();
+        } else {                                            // frames touching the padding gather their (decoded) samples first
+            int tz;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(tz) : "v"(t));
+            load_frame<F, false, true, true>(v, g, nullptr, xa, row, fr, tz, Fetch{m.samples, lutlds});
+        }
+        {
 #if TAC_S3_WIN_REGS
             Dft<16>::run_windowed(v, win_regs);
 #else
@@ -203,13 +209,6 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             }
             Dft<16>::run_windowed(v, win);
 #endif
-        } else {
-            int tz;
-            asm volatile("v_mov_b32 %0, %1" : "=v"(tz) : "v"(t));
-            load_frame<F, false, true>(v, g, nullptr, xa, row, fr, tz, Fetch{m.samples, lutlds});
-#pragma unroll
-            for (int e = 0; e < E; ++e) v[e] = cscale(v[e], half);
-            F::template pass_butterflies<0>(v);
         }
         wave_lds_fence();
         cf tw1[16];

@@ -20,6 +20,9 @@ typedef float sm_f4 __attribute__((ext_vector_type(4)));
 // mel rows are staged behind them and stored instead of the spectrogram rows.
 __host__ __device__ constexpr int sm_mel_pitch(int nc) { return (nc + 1 + 3 + 3) & ~3; }
 constexpr int SM_FLY = 6;       // contraction steps in flight: this kernel keeps its twiddles in registers, 48 more is what fits
+}  // namespace tac
+#include "stft_small3.hpp"
+namespace tac {
 
 template <int NC, int MODE, bool MEL, int S>
 __global__ void __launch_bounds__(SM_WAVES * 64, 2)
@@ -197,6 +200,17 @@ stft_small_kernel(FrameGeom g, Tables tb, StftEpilogue ep, LaneMel mel) {
     }
 }
 
+// waves per CU of the stft_small3 form: 0 = the two-wave kernel (TAC_SMALL2=1), else TAC_SM3_WAVES or 16
+static int small3_waves() {
+    static const int wv = [] {
+        const char* two = getenv("TAC_SMALL2");
+        if (two && two[0] == '1') return 0;
+        const char* e = getenv("TAC_SM3_WAVES");
+        return e ? atoi(e) : 16;
+    }();
+    return wv;
+}
+
 template <int NC, int MODE>
 static int launch_small(const FrameGeom& g, const Tables& tb, const StftEpilogue& ep, hipStream_t stream) {
     using F = WaveFft<NC, 16>;
@@ -207,6 +221,23 @@ static int launch_small(const FrameGeom& g, const Tables& tb, const StftEpilogue
     long long blocks = (units + SM_WAVES - 1) / SM_WAVES;
     const long long cap = (long long)device_cu_count();
     if (blocks > cap) blocks = cap;
+    if (small3_waves() && g.length >= 2 * NC) {
+        // three / four waves per SIMD (stft_small3.hpp); TAC_SMALL2=1 keeps the two-wave kernel below
+        auto go = [&](auto k3, int W) -> int {
+            const size_t b3 = small3_lds_bytes<NC>(W);
+            long long bl = (units + W - 1) / W;
+            if (bl > cap) bl = cap;
+            TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(k3), (int)b3));
+            hipLaunchKernelGGL(k3, dim3((unsigned)bl), dim3(W * 64), b3, stream, g, tb, ep, LaneMel{});
+            TAC_HIP(hipGetLastError());
+            return TAC_OK;
+        };
+        // complex rows are bound by their stores (12 waves measure like the two-wave kernel, 16 slower); real rows gain 8-10 %
+        // from the fourth wave per SIMD (profiles/r03/ab_stream3.txt)
+        const int wv = getenv("TAC_SM3_WAVES") ? small3_waves() : (MODE == 0 ? 12 : 16);
+        if (wv == 12) return go(stft_small3_kernel<NC, MODE, false, 1, 12>, 12);
+        return go(stft_small3_kernel<NC, MODE, false, 1, 16>, 16);
+    }
     auto kern = stft_small_kernel<NC, MODE, false, 1>;
     if (bytes > 64 * 1024) TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SM_WAVES * 64), bytes, stream, g, tb, ep, LaneMel{});
@@ -231,6 +262,19 @@ static int launch_small_mel(const FrameGeom& g, const Tables& tb, const LaneMel&
     long long blocks = (units + SM_WAVES - 1) / SM_WAVES;
     const long long cap = (long long)device_cu_count();
     if (blocks > cap) blocks = cap;
+    if (small3_waves() && g.length >= 2 * NC) {
+        const size_t b3 = small3_lds_bytes<NC>(12) + lm_lds_bytes(F::LPF, mel.wtot);
+        if (b3 <= 160 * 1024) {
+            auto k3 = stft_small3_kernel<NC, MODE, true, S, 12>;
+            long long bl = (units + 12 - 1) / 12;
+            if (bl > cap) bl = cap;
+            TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(k3), (int)b3));
+            hipLaunchKernelGGL(k3, dim3((unsigned)bl), dim3(12 * 64), b3, stream, g, tb,
+                               StftEpilogue{nullptr, 1, 1, MODE == 1 ? 2.0f : 1.0f, 0, 0.0f, 0.0f}, mel);
+            TAC_HIP(hipGetLastError());
+            return TAC_OK;
+        }
+    }
     auto kern = stft_small_kernel<NC, MODE, true, S>;
     if (bytes > 64 * 1024) TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SM_WAVES * 64), bytes, stream, g, tb,

@@ -98,7 +98,12 @@ stft_stream3_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
         if (t == 0) ask = __hip_atomic_fetch_add(next_frame, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const long long g0 = ((long long)row * T + fr) * LENF;      // this frame's row in the frame-major output
         // ---- s0: window, pass 0, exchange
-        if (mode == 1) {
+        if (mode != 1) {                                    // frames touching the padding gather their samples first
+            int tz;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(tz) : "v"(t));
+            load_frame<F, false, true, true>(v, g, nullptr, xa, row, fr, tz, FetchF32{g.wave});
+        }
+        {
             cf win[E];
             const f4* wl = reinterpret_cast<const f4*>(winl + t * 18);
 #pragma unroll
@@ -108,13 +113,6 @@ stft_stream3_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
                 win[2 * u + 1] = mkc(x.z, x.w);
             }
             Dft<16>::run_windowed(v, win);
-        } else {
-            int tz;
-            asm volatile("v_mov_b32 %0, %1" : "=v"(tz) : "v"(t));
-            load_frame<F, false, true>(v, g, nullptr, xa, row, fr, tz, FetchF32{g.wave});
-#pragma unroll
-            for (int e = 0; e < E; ++e) v[e] = cscale(v[e], half);
-            F::template pass_butterflies<0>(v);
         }
         wave_lds_fence();
         cf tw1[16];
