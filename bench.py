@@ -254,7 +254,7 @@ def run(a):
                    'parallelism': 'batch-sharded x%d, no data-path collective' % world,
                    'input_buffers': '%d distinct device-resident batches of %.1f MB visited round-robin (%.0f MB > the '
                                     '256 MiB Infinity Cache)' % (nbuf, x.numel() * 4 / 1e6, nbuf * x.numel() * 4 / 1e6)},
-        'roofline': {'kernel': 'melspec_stream3_kernel<1024,16,pow2,f32,14> (fused STFT + power + band-sparse mel + dB, one launch per step; 3 waves per SIMD)', 'bound': 'hbm',
+        'roofline': {'kernel': 'melspec_stream3_kernel<1024, 16, true, 0, 14, 12> (fused STFT + power + band-sparse mel + dB, one launch per step; 12 waves per CU)', 'bound': 'hbm',
                      'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                      'traffic': None, 'alg_bytes_per_launch': alg_bytes, 'kernel_ms_mean': mean_ms,
                      'kernel_ms_median': med_ms, 'kernel_ms_per_launch_events': per_launch_mean_ms,
@@ -315,6 +315,26 @@ def run(a):
                                            'achieved_TFLOPs': flops / (ms * 1e-3) / 1e12,
                                            'frac_of_f32_mfma_peak': flops / (ms * 1e-3) / 1e12 / 157.3}
         del p_spec
+        # training step of the same chain (waveform requires grad): fused forward + dB op, then the HIP gradient kernels
+        # (dB adjoint, ONE backward kernel: filterbank adjoint + frame re-transform + norm adjoint + inverse FFT + overlap-add,
+        # border fold); wall time per step between two events, gradient buffer released each step
+        try:
+            xg = x.clone().requires_grad_(True)
+            ones = torch.ones((BATCH, CHANNELS, N_MELS, frames), device=dev)
+
+            def train():
+                xg.grad = None
+                y = model(xg)
+                y.backward(ones)
+                return y
+            spin(train, 0.3)
+            ms, med = event_ms(train, 30)
+            stages['train_step_fwd_bwd'] = {'ms_mean': ms, 'ms_median': med,
+                                            'note': 'forward + backward of Sequential(*Melspectrogram, AmplitudeToDb) at cfg-2, '
+                                                    'event pair around each step (kernels + launch gaps of the autograd graph)'}
+            del xg, ones
+        except Exception as exc:            # noqa: BLE001 — a secondary figure
+            stages['train_step_fwd_bwd'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
         result['stages'] = stages
 
     def gather_leg(mdl, inputs, rows_total, frames_step, steps):

@@ -31,9 +31,9 @@ def pmc(k):
 
 
 rows = []
-for label, sub, key, per_frame in (('fused STFT + power + band-sparse mel + dB', 'melspec_stream_kernel<1024', 'mel', 2560),
-                                   ('complex STFT', 'stft_pipe_kernel<1024, 16, 0', 'stft', 10248),
-                                   ('power spectrogram', 'stft_pipe_kernel<1024, 16, 1', 'spec', 6148)):
+for label, sub, key, per_frame in (('fused STFT + power + band-sparse mel + dB', 'melspec_stream3_kernel<1024', 'mel', 2560),
+                                   ('complex STFT', 'stft_stream3_kernel<1024, 16, 0', 'stft', 10248),
+                                   ('power spectrogram', 'stft_stream3_kernel<1024, 16, 1', 'spec', 6148)):
     name, calls, ms = kern(sub)
     c = pmc(key)
     alg = FRAMES * per_frame
@@ -121,20 +121,26 @@ if all('SQ_WAIT_INST_ANY' in c for _, _, _, _, _, _, c in rows if c):
                       100 * c['SQ_ACTIVE_INST_ANY'] / wc, 100 * c['SQ_ACTIVE_INST_VALU'] / wc,
                       100 * c['SQ_ACTIVE_INST_LDS'] / wc, 100 * c['SQ_ACTIVE_INST_SCA'] / wc))
     out.append('')
-out.append('All three kernels run 2 waves/SIMD (one 8-wave workgroup per CU whose waves draw frames from a workgroup '
-           'counter), no scratch.  HBM traffic equals the algorithmic bytes to within 0.5 %: nothing is re-read, the fused '
-           'kernel is bound by its VALU + LDS instruction streams (stall table above), not by memory.  '
-           'DESIGN.md §3.2/§3.3 hold the stage-stamp breakdowns, the ablations and the list of variants measured not to help.')
+out.append('The fused kernel and the complex STFT run 3 waves/SIMD, the power spectrogram 4 (one 12- / 16-wave workgroup per CU whose '
+           'waves draw frames from a workgroup counter), no scratch.  HBM traffic equals the algorithmic bytes to within 0.5 %: '
+           'nothing is re-read; the fused kernel is bound by its VALU + LDS instruction streams — with three waves per SIMD the '
+           'SIMD issues VALU work 3 x the per-wave VALU share above of its cycles and the LDS is busy as tabulated — not by memory.  '
+           '`ab_stream3.txt` holds the A/B runs of the wave counts (2 / 3 / 4 per SIMD) for every kernel re-cut this round; '
+           'DESIGN.md §3.3 the reasoning.')
 for fname, what in (('kernel_stats_backward.csv',
                      '`tools/prof_driver.py grad 120`: forward + backward of the reference idiom `Sequential(*Melspectrogram(...), '
                      'AmplitudeToDb())` at cfg-2 with `requires_grad` on the waveform: the chain is deferred as usual (one fused '
                      'forward kernel for the linear mel values + the dB op, which keeps them for its gradient) and differentiates through '
-                     'the `tac_amd::melspectrogram` op — filterbank adjoint, ONE backward kernel that re-transforms the frames, '
-                     'forms the gradient spectrum, inverse-transforms and overlap-adds in LDS, and the unpadding / border fold'),
+                     'the `tac_amd::melspectrogram` op — ONE backward kernel (`melspec_backward_ring3_kernel`: filterbank adjoint per '
+                     'bin pair, frames re-transformed, adjoint of the norm, inverse transform, overlap-add in a register ring; twelve '
+                     'waves per CU) and the unpadding / border fold'),
                     ('kernel_stats_backward_fused_op.csv',
                      '`tools/prof_driver.py gradf 120`: the same through the factory container (`Melspectrogram(...)` called as '
-                     'ONE `tac_amd::melspectrogram` op) followed by `AmplitudeToDb`: fused forward kernel; backward = filterbank '
-                     'adjoint, the backward kernel (frames re-transformed, overlap-add in LDS), unpadding / border fold'),
+                     'ONE `tac_amd::melspectrogram` op) followed by `AmplitudeToDb`: fused forward kernel; backward = the linear mel '
+                     'values recomputed by the forward kernel for the dB adjoint, the backward kernel, unpadding / border fold'),
+                    ('kernel_stats_backward_spectrogram.csv',
+                     '`tools/prof_driver.py gradspec 60`: training step through `Spectrogram(2048, 512, power=2)`: forward kernel, the same '
+                     'backward kernel fed with the gradient of the power spectrogram (no filterbank stage), border fold'),
                     ('kernel_stats_backward_n400.csv',
                      '`tools/prof_driver.py grad400h160 60`: the 80-band speech front end (fft_length 400, hop 160) trained through '
                      'the reference idiom: fused forward kernel, complex stft recomputed by the mixed-radix kernel, the inverse '
@@ -159,15 +165,16 @@ for fname, what in (('kernel_stats_backward.csv',
 pbk = os.path.join(d, 'pmc_backward.json')
 if os.path.exists(pbk):
     for name, c in json.load(open(pbk)).items():
-        if 'spectrogram_backward_ola_kernel' in name and 'SQ_WAVE_CYCLES' in c:
+        if ('melspec_backward_ring3_kernel' in name or 'spectrogram_backward_ola_kernel' in name) and 'SQ_WAVE_CYCLES' in c:
             wc = c['SQ_WAVE_CYCLES']
             out.append('')
-            out.append('Counters of `spectrogram_backward_ola_kernel` (`pmc_backward.json`, per launch, separate `--pmc` passes around '
+            out.append('Counters of `%s` (`pmc_backward.json`, per launch, separate `--pmc` passes around '
                        '`tools/prof_driver.py grad 3`): %.0f VALU and %.0f LDS instructions per frame; a wave is parked %.0f %%, '
                        'issue-stalled %.0f %% (LDS queue %.0f %%) and issuing %.0f %% of its cycles; LDS bank-conflict cycles %.0f %% of '
                        'LDS cycles; HBM traffic %.0f MB per launch (%.0f MB read + %.0f MB written; the samples are 164 MB, the '
-                       'gradient of the power spectrogram 328 MB, the padded gradient + border sums 180 MB).'
-                       % (c['SQ_INSTS_VALU'] / FRAMES, c['SQ_INSTS_LDS'] / FRAMES, 100 * c['SQ_WAIT_ANY'] / wc,
+                       'gradient of the mel values 41 MB; written: the waveform gradient\'s clean interior + the padded border runs and '
+                       'segment-border sums the fold kernel finishes).'
+                       % (name.split('<')[0].replace('void tac::', ''), c['SQ_INSTS_VALU'] / FRAMES, c['SQ_INSTS_LDS'] / FRAMES, 100 * c['SQ_WAIT_ANY'] / wc,
                           100 * c['SQ_WAIT_INST_ANY'] / wc, 100 * c['SQ_WAIT_INST_LDS'] / wc, 100 * c['SQ_ACTIVE_INST_ANY'] / wc,
                           100 * c['SQ_LDS_BANK_CONFLICT'] / c['SQ_LDS_IDX_ACTIVE'], c['hbm_traffic_bytes_per_launch'] / 1e6,
                           c['hbm_read_bytes_corrected'] / 1e6, c['hbm_write_bytes'] / 1e6))
@@ -180,6 +187,6 @@ out.append('Micro-benchmarks behind the design decisions (sources in `tools/uben
            '`valu_rate` (scalar vs packed f32 issue rates), `lds_rate` (LDS access shapes at 8 waves/CU), `hbm_rate` '
            '(write / read / 1:4 mix ceilings of this box: 4.5-5.6 / 6.4 / 5.1-5.7 TB/s).')
 out.append('')
-out.append('`../r02/`, `../r01/` hold the same measurements for rounds 2 and 1 (streaming kernel 0.127 ms on one re-read batch; three-phase fused kernel, 0.174 ms) and `../r01_baseline_v0/` for the first correct version (0.61 ms).')
+out.append('`../r02/`, `../r01/` hold the same measurements for rounds 2 and 1 (two-waves-per-SIMD streaming kernel 0.127 ms on one re-read batch; three-phase fused kernel, 0.174 ms) and `../r01_baseline_v0/` for the first correct version (0.61 ms).')
 open(os.path.join(d, 'README.md'), 'w').write('\n'.join(out) + '\n')
 print('\n'.join(out))
