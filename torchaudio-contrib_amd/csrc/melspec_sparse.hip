@@ -449,13 +449,19 @@ static int launch_stream(FrameGeom g, const Tables& tb, const SparseArgs& sm, co
 // the frame's row in its own LDS buffer (16-byte chunks, the next frame's requested before this one is contracted),
 // contracts it and stores the band row — no workgroup barrier, no tile.  (fb_sparse_kernel above, round 1's 16-frame
 // tiles between barriers, stays the route for banks outside this layout and for other frame strides.)
-constexpr int FBL_WAVES = 8, FBL_FLY = 16;
+// Rows up to 1280 bins (fft_length <= 2560): SIXTEEN 128-register waves per CU with 12 contraction steps in flight (round 3:
+// 0.092 -> 0.080 ms on cfg-2's 1025 x 128, 4.0 -> 4.6 TB/s; twelve waves 0.081); wider rows (fft_length 4096): eight waves, 16 steps
+// in flight — sixteen row buffers of 8 KB do not fit next to 41 KB of weights.  The packed layout depends on the steps in flight
+// (lm_group), so the pack and the launch use the same rule.
 constexpr int FBL_CHUNKS = 5, FBL_CHUNKS_WIDE = 9;   // 16-byte chunks per lane and frame: up to 1280 / 2304 bins (fft_length 2048 / 4096)
+__host__ __device__ inline bool fbl_is_wide(int n_freqs) { return (n_freqs + 3) / 4 > FBL_CHUNKS * 64; }
+__host__ __device__ inline int fbl_waves(int n_freqs) { return fbl_is_wide(n_freqs) ? 8 : 16; }
+__host__ __device__ inline int fbl_fly(int n_freqs) { return fbl_is_wide(n_freqs) ? 16 : 12; }
 __host__ __device__ inline int fbl_pitch(int n_freqs) { return (n_freqs + 3 + 3) & ~3; }
-inline size_t fbl_base_lds(int n_freqs) { return (size_t)FBL_WAVES * (fbl_pitch(n_freqs) + LM_MAX_MELS + 4) * sizeof(float) + 16; }
+inline size_t fbl_base_lds(int n_freqs) { return (size_t)fbl_waves(n_freqs) * (fbl_pitch(n_freqs) + LM_MAX_MELS + 4) * sizeof(float) + 16; }
 
-template <int S, int CHUNKS>
-__global__ void __launch_bounds__(FBL_WAVES * 64, 2)
+template <int S, int CHUNKS, int FBL_WAVES, int FBL_FLY>
+__global__ void __launch_bounds__(FBL_WAVES * 64, FBL_WAVES / 4)
 fb_lanes_kernel(const float* __restrict__ spec, long long rows, int n_freqs, long long n_frames, long long stride_r,
                 long long stride_t, LaneMel mel) {
     typedef float f4 __attribute__((ext_vector_type(4)));
@@ -528,13 +534,14 @@ fb_lanes_kernel(const float* __restrict__ spec, long long rows, int n_freqs, lon
 template <int S, int CHUNKS>
 static int launch_fb_lanes(const float* spec, long long rows, int n_freqs, long long n_frames, long long stride_r,
                            long long stride_t, const LaneMel& mel, hipStream_t stream) {
+    constexpr int FBL_WAVES = CHUNKS == FBL_CHUNKS_WIDE ? 8 : 16, FBL_FLY = CHUNKS == FBL_CHUNKS_WIDE ? 16 : 12;
     const size_t bytes = fbl_base_lds(n_freqs) + lm_lds_bytes(64, mel.wtot);
     if (bytes > 160 * 1024) return TAC_E_UNSUPPORTED;
     const long long total = rows * n_frames;
     if (total >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
     long long blocks = (total + FBL_WAVES - 1) / FBL_WAVES;
     if (blocks > device_cu_count()) blocks = device_cu_count();
-    auto kern = fb_lanes_kernel<S, CHUNKS>;
+    auto kern = fb_lanes_kernel<S, CHUNKS, FBL_WAVES, FBL_FLY>;
     if (bytes > 64 * 1024) TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(FBL_WAVES * 64), bytes, stream, spec, rows, n_freqs, n_frames, stride_r,
                        stride_t, mel);
@@ -669,7 +676,7 @@ int tac_melbank_pack(const float* fb, int32_t n_freqs, int32_t n_mels, int32_t n
     if (n_fft == 2048)
         return pack_lanes(h, n_freqs, n_mels, wpack, wpack_cap, desc, desc_cap, info_host, (hipStream_t)stream);
     if (n_fft == 0 && n_freqs >= 8 && (n_freqs + 3) / 4 <= FBL_CHUNKS_WIDE * 64) {   // standalone: one frame per wave
-        const int rc = pack_lane_mel(h, n_freqs, n_mels, 64, fbl_pitch(n_freqs), 2, FBL_FLY, LM_MAX_STEPS_WAVE, fbl_base_lds(n_freqs),
+        const int rc = pack_lane_mel(h, n_freqs, n_mels, 64, fbl_pitch(n_freqs), 2, fbl_fly(n_freqs), LM_MAX_STEPS_WAVE, fbl_base_lds(n_freqs),
                                      wpack, wpack_cap, desc, desc_cap, info_host, (hipStream_t)stream);
         if (rc != TAC_E_UNSUPPORTED) return rc;                             // else: the tile kernel's layout
     }
@@ -820,7 +827,7 @@ int tac_apply_filterbank_sparse_db_f32(const float* spec, int64_t rows, int32_t 
     if (db && !(db_ref > 0.0f)) return TAC_E_INVALID;
     const float log10_ref = db ? log10f(db_ref) : 0.0f;
     if (info_host[2] == LM_MARK + 64) {                                            // lane layout: the wave-autonomous kernel
-        if (!lane_mel_info_ok(info_host, 64, FBL_FLY, LM_MAX_STEPS_WAVE)) return TAC_E_INVALID;
+        if (!lane_mel_info_ok(info_host, 64, fbl_fly(n_freqs), LM_MAX_STEPS_WAVE)) return TAC_E_INVALID;
         const int chunks = (n_freqs + 3) / 4;
         if (n_mels < LM_MIN_MELS || n_mels > LM_MAX_MELS || chunks > FBL_CHUNKS_WIDE * 64) return TAC_E_UNSUPPORTED;
         const LaneMel lm{wpack, desc, info_host[1], info_host[0], n_mels, db ? 1 : 0, db_amin, log10_ref, out};
