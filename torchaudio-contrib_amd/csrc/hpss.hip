@@ -55,8 +55,11 @@ __device__ __forceinline__ void hpss_masks(float harm, float perc, float power, 
 }
 
 // A = the slow memory axis (stride sa), B = the fast one (stride sb); b_is_time says which of them is time.
+#ifndef TAC_HPSS_OCC
+#define TAC_HPSS_OCC 3   // k = 31: 176 -> 168 registers (36 bytes of scratch) buys a third wave per SIMD: 1.05 -> 0.91 ms; 4 (128 registers, 252 B) 1.26 ms
+#endif
 template <int K>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, TAC_HPSS_OCC)
 hpss_tile_kernel(const float* __restrict__ x, int NA, int NB, long long sr, long long sa, long long sb, int tiles_a,
                  int tiles_b, int b_is_time, float power, int hard, float* __restrict__ harm_o, float* __restrict__ perc_o,
                  float* __restrict__ mh_o, float* __restrict__ mp_o) {
