@@ -49,6 +49,56 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     cf* const xa = reinterpret_cast<cf*>(smem_raw + (size_t)w * XA_BYTES);
     float* const prow = reinterpret_cast<float*>(xa);                               // the frame's |X|^2 row, in place
+    const long long chunk = (m.total + gridDim.x - 1) / gridDim.x;
+    const long long begin = (long long)blockIdx.x * chunk;
+    const long long endl = begin + chunk < m.total ? begin + chunk : m.total;
+    const int nloc = endl > begin ? (int)(endl - begin) : 0;
+    const unsigned T = (unsigned)g.n_frames;
+    const int t = lane;
+
+    cf v[E];
+    int mode = 0, row = 0;
+    long long fr = 0;
+    auto request = [&](int i) {
+        i = i < nloc ? i : nloc - 1;
+        const unsigned gf = (unsigned)(begin + i);
+        const unsigned r = gf / T;
+        row = (int)r;
+        fr = (long long)(gf - r * T);
+        const long long start = fr * (long long)g.hop - g.center_pad;
+        const bool ok = g.vec2_ok && start >= 0 && start + F::N <= g.length;
+        mode = ok ? 1 : 2;
+        long long cs = start < 0 ? 0 : start;
+        cs = cs + F::N <= g.length ? cs : g.length - F::N;
+        const long long off = (long long)row * g.row_stride + cs;                  // in samples
+        if constexpr (FMT == FMT_F32) {
+            const cf* src = reinterpret_cast<const cf*>(static_cast<const float*>(m.samples) + off);
+#pragma unroll
+            for (int q = 0; q < E; ++q) v[q] = src[t + q * F::LPF];
+        } else if constexpr (FMT == FMT_I16) {                              // a pair of samples = one dword
+            const unsigned* src = reinterpret_cast<const unsigned*>(static_cast<const short*>(m.samples) + off);
+#pragma unroll
+            for (int q = 0; q < E; ++q) v[q].x = __uint_as_float(src[t + q * F::LPF]);
+        } else if constexpr (FMT == FMT_MULAW_U8) {                         // a pair of codes = one 16-bit load
+            const unsigned short* src = reinterpret_cast<const unsigned short*>(static_cast<const unsigned char*>(m.samples) + off);
+#pragma unroll
+            for (int q = 0; q < E; ++q) v[q].x = __uint_as_float((unsigned)src[t + q * F::LPF]);
+        } else {                                                            // int64 codes: the low dword of each
+            const int* src = reinterpret_cast<const int*>(static_cast<const long long*>(m.samples) + off);
+#pragma unroll
+            for (int q = 0; q < E; ++q) {
+                v[q].x = __int_as_float(src[4 * (t + q * F::LPF)]);
+                v[q].y = __int_as_float(src[4 * (t + q * F::LPF) + 2]);
+            }
+        }
+    };
+#ifndef TAC_S3_EARLY_FIRST
+#define TAC_S3_EARLY_FIRST 1
+#endif
+#if TAC_S3_EARLY_FIRST
+    // the wave's first frame is requested before the tables are built: its HBM latency runs behind the workgroup's set-up
+    if (nloc > 0) request(w);
+#endif
     float* const wlds = reinterpret_cast<float*>(smem_raw + (size_t)WAVES * XA_BYTES);
     float* const twlds = wlds + ((m.wtot + 3) & ~3);
     for (int i = tid; i < m.wtot; i += WAVES * 64) wlds[i] = m.wl[i];
@@ -67,13 +117,6 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         const int tt = idx / F::NPAIR, p = idx - tt * F::NPAIR;
         ptwl[((p >> 1) * 64 + tt) * 2 + (p & 1)] = tb.w_n[tt + p * F::LPF];
     }
-
-    const long long chunk = (m.total + gridDim.x - 1) / gridDim.x;
-    const long long begin = (long long)blockIdx.x * chunk;
-    const long long endl = begin + chunk < m.total ? begin + chunk : m.total;
-    const int nloc = endl > begin ? (int)(endl - begin) : 0;
-    const unsigned T = (unsigned)g.n_frames;
-    const int t = lane;
 
     cf tw2[3];
     {
@@ -112,42 +155,6 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     const bool fast_db = m.amin >= 1.1754944e-38f;
     const float ten_log10_ref = 10.0f * m.log10_ref;
-    cf v[E];
-    int mode = 0, row = 0;
-    long long fr = 0;
-    auto request = [&](int i) {
-        i = i < nloc ? i : nloc - 1;
-        const unsigned gf = (unsigned)(begin + i);
-        const unsigned r = gf / T;
-        row = (int)r;
-        fr = (long long)(gf - r * T);
-        const long long start = fr * (long long)g.hop - g.center_pad;
-        const bool ok = g.vec2_ok && start >= 0 && start + F::N <= g.length;
-        mode = ok ? 1 : 2;
-        long long cs = start < 0 ? 0 : start;
-        cs = cs + F::N <= g.length ? cs : g.length - F::N;
-        const long long off = (long long)row * g.row_stride + cs;                  // in samples
-        if constexpr (FMT == FMT_F32) {
-            const cf* src = reinterpret_cast<const cf*>(static_cast<const float*>(m.samples) + off);
-#pragma unroll
-            for (int q = 0; q < E; ++q) v[q] = src[t + q * F::LPF];
-        } else if constexpr (FMT == FMT_I16) {                              // a pair of samples = one dword
-            const unsigned* src = reinterpret_cast<const unsigned*>(static_cast<const short*>(m.samples) + off);
-#pragma unroll
-            for (int q = 0; q < E; ++q) v[q].x = __uint_as_float(src[t + q * F::LPF]);
-        } else if constexpr (FMT == FMT_MULAW_U8) {                         // a pair of codes = one 16-bit load
-            const unsigned short* src = reinterpret_cast<const unsigned short*>(static_cast<const unsigned char*>(m.samples) + off);
-#pragma unroll
-            for (int q = 0; q < E; ++q) v[q].x = __uint_as_float((unsigned)src[t + q * F::LPF]);
-        } else {                                                            // int64 codes: the low dword of each
-            const int* src = reinterpret_cast<const int*>(static_cast<const long long*>(m.samples) + off);
-#pragma unroll
-            for (int q = 0; q < E; ++q) {
-                v[q].x = __int_as_float(src[4 * (t + q * F::LPF)]);
-                v[q].y = __int_as_float(src[4 * (t + q * F::LPF) + 2]);
-            }
-        }
-    };
     // the requested registers as float sample pairs (still unwindowed): PCM integers / decoded codes
     auto decode = [&]() {
         if constexpr (FMT == FMT_I16) {
@@ -182,7 +189,9 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         a1 = __builtin_elementwise_fma(mkc(wv.z, wv.w), mkc(pv.z, pv.w), a1);
     };
     int i = w;
+#if !TAC_S3_EARLY_FIRST
     request(i);
+#endif
     while (i < nloc) {
         // the next frame of this wave (the counter's answer travels with the stage's other LDS traffic)
         unsigned ask = 0;

@@ -12,6 +12,9 @@
 namespace tac {
 
 constexpr int PV_THREADS = 256;
+#ifndef TAC_PV_HW_SINCOS
+#define TAC_PV_HW_SINCOS 1     // 0: library sincosf on the float64-reduced angle (0.293 vs 0.274 ms at cfg-2)
+#endif
 
 // Precision.  The reference evaluates the recurrence in the dtype of its input, and in float32 that is
 // ill-conditioned: `angle_1 - angle_0 - phase_advance` is rounded at the magnitude of the phase advance (up to
@@ -24,11 +27,42 @@ template <class T>
 struct pv_math;
 template <>
 struct pv_math<float> {
-    static __device__ __forceinline__ float atan2(float y, float x) { return atan2f(y, x); }
+    // atan2f without the library's special-case ladder (~25 instructions instead of ~50; the kernel is bound by this
+    // arithmetic, not by memory): octant reduction to a = min / max in [0, 1], atan(a) = a P(a^2) with a degree-8 minimax P
+    // (max error 1.0e-7 rad in float32, fitted and checked over 2 M points by the script quoted in tools/ablation/README.md),
+    // signs restored.  atan2(0, 0) = 0 like the library; the errors telescope in the running sum (a step's second
+    // phase is the next step's first).
+    static __device__ __forceinline__ float atan2(float y, float x) {
+        const float ax = fabsf(x), ay = fabsf(y);
+        const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+        float a = mn * __builtin_amdgcn_rcpf(mx);
+        a = mx == 0.0f ? 0.0f : a;
+        const float s = a * a;
+        float p = 0.0024567253421992064f;
+        p = fmaf(p, s, -0.014401361346244812f);
+        p = fmaf(p, s, 0.03978123143315315f);
+        p = fmaf(p, s, -0.07234857976436615f);
+        p = fmaf(p, s, 0.10498946160078049f);
+        p = fmaf(p, s, -0.14161229133605957f);
+        p = fmaf(p, s, 0.19985906779766083f);
+        p = fmaf(p, s, -0.33332598209381104f);
+        p = fmaf(p, s, 0.9999998807907104f);
+        float r = p * a;
+        r = ay > ax ? 1.5707963267948966f - r : r;
+        r = x < 0.0f ? 3.141592653589793f - r : r;
+        return copysignf(r, y);
+    }
     static __device__ __forceinline__ float hypot(float x, float y) { return sqrtf(x * x + y * y); }
     static __device__ __forceinline__ void sincos(double a, float* s, float* c) {
+#if TAC_PV_HW_SINCOS
+        const double tr = a * 0.15915494309189535;                  // reduced to a fraction of a turn in float64,
+        const float fr = (float)(tr - rint(tr));                    // evaluated by the hardware's v_sin / v_cos (input in turns)
+        *s = __builtin_amdgcn_sinf(fr);
+        *c = __builtin_amdgcn_cosf(fr);
+#else
         const double turns = rint(a * 0.15915494309189535);
         sincosf((float)(a - turns * 6.283185307179586), s, c);      // reduced in float64, evaluated in float32
+#endif
     }
 };
 template <>
@@ -73,36 +107,60 @@ phase_vocoder_kernel(const T* __restrict__ spec, long long rows, int n_freqs, in
     // evaluated again (the grid is wave-uniform, so is the branch; the values are the ones that would be recomputed).
     int t_kept = -1;
     T ang_kept = (T)0, n_kept = (T)0;
-    for (int i = 0; i < n_out; ++i) {
-        const int t0 = idx0[i], t1 = idx1[i];
-        T ang0, n0;
-        if (t0 == t_kept) {
-            ang0 = ang_kept;
-            n0 = n_kept;
-        } else {
-            frame(t0, re0, im0);
-            ang0 = M::atan2(im0, re0);
-            n0 = M::hypot(re0, im0);
+    // The loop is a chain of dependent steps, and a step's only long latency is the load of its second frame: left in
+    // the step it made every one of the n_out steps one HBM round trip long (0.336 ms at cfg-2, whatever the occupancy).
+    // The second frames of the next PV_AHEAD steps are therefore always in flight (their indices come from the grid,
+    // not from the recurrence), in a rotating set of registers.
+    constexpr int AHEAD = 4;
+    T2 ahead[AHEAD];
+    auto fetch = [&](int i) -> T2 {             // second frame of step i (clamped to the last step; zero past the input)
+        const int ic = i < n_out ? i : n_out - 1;
+        const int t = idx1[ic];
+        const int tc = t < n_frames ? t : n_frames - 1;
+        T2 v = *reinterpret_cast<const T2*>(base + (long long)tc * stride_t);
+        if (t >= n_frames) v.x = v.y = (T)0;
+        return v;
+    };
+#pragma unroll
+    for (int k = 0; k < AHEAD; ++k) ahead[k] = fetch(k);
+    for (int i0 = 0; i0 < n_out; i0 += AHEAD) {
+#pragma unroll
+        for (int k = 0; k < AHEAD; ++k) {
+            const int i = i0 + k;
+            if (i >= n_out) break;
+            const int t0 = idx0[i], t1 = idx1[i];
+            const T2 cur = ahead[k];
+            ahead[k] = fetch(i + AHEAD);
+            T ang0, n0;
+            if (t0 == t_kept) {
+                ang0 = ang_kept;
+                n0 = n_kept;
+            } else {
+                frame(t0, re0, im0);
+                ang0 = M::atan2(im0, re0);
+                n0 = M::hypot(re0, im0);
+            }
+            re1 = cur.x;
+            im1 = cur.y;
+            const T ang1 = M::atan2(im1, re1), n1 = M::hypot(re1, im1);
+            t_kept = t1;
+            ang_kept = ang1;
+            n_kept = n1;
+            const T w = alpha[i];
+            const T mag = w * n1 + ((T)1 - w) * n0;
+            T sn, cs;
+            M::sincos(acc, &sn, &cs);
+            T2 res;
+            res.x = mag * cs;
+            res.y = mag * sn;
+            *reinterpret_cast<T2*>(o) = res;
+            o += 2 * (long long)n_freqs;
+            double ph = (double)ang1 - (double)ang0 - pa;
+            // (a reciprocal instead of the reference's division: where the two round differently the wrapped phase moves by
+            // exactly one turn, which the sine and cosine of the running sum do not see)
+            ph = ph - two_pi * rint(ph * 0.15915494309189535);
+            acc += ph + pa;
         }
-        frame(t1, re1, im1);
-        const T ang1 = M::atan2(im1, re1), n1 = M::hypot(re1, im1);
-        t_kept = t1;
-        ang_kept = ang1;
-        n_kept = n1;
-        const T w = alpha[i];
-        const T mag = w * n1 + ((T)1 - w) * n0;
-        T sn, cs;
-        M::sincos(acc, &sn, &cs);
-        T2 res;
-        res.x = mag * cs;
-        res.y = mag * sn;
-        *reinterpret_cast<T2*>(o) = res;
-        o += 2 * (long long)n_freqs;
-        double ph = (double)ang1 - (double)ang0 - pa;
-        // (a reciprocal instead of the reference's division: where the two round differently the wrapped phase moves by
-        // exactly one turn, which the sine and cosine of the running sum do not see)
-        ph = ph - two_pi * rint(ph * 0.15915494309189535);
-        acc += ph + pa;
     }
 }
 
