@@ -31,6 +31,6 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_${k}_write -o p -- py
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $out/pmc_${k}_sq -o p -- python tools/prof_driver.py $k 3 > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $out/pmc_${k}_stall -o p -- python tools/prof_driver.py $k 3 > /dev/null 2>&1
 # steady-state timings of everything else
-python tools/time_steady.py stft spec mel stft4096 spec4096 mel4096 stft512 spec512 stft1024 spec1024 mel512 mel1024 mel400 stft400 spec400 mel256 > $out/time_steady.txt 2>&1
+python tools/time_steady.py stft spec mel stft4096 spec4096 mel4096 stft512 spec512 stft1024 spec1024 mel512 mel1024 mel400 stft400 spec400 mel256 stft256 spec256 > $out/time_steady.txt 2>&1
 python tools/time_others.py > $out/time_others.txt 2>&1
 ls $out

@@ -1,10 +1,8 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/ab
-timeout 600 python -m pytest tests -m gpu -x -q -k "mel or golden or g9 or coded" 2>&1 | tail -2
-for rep in 1 2 3; do
-for v in default late; do
+for rep in 1 2; do
+for v in default fly8 fly10 fly12 fly16; do
   if [ "$v" = default ]; then unset TAC_AMD_LIB; else export TAC_AMD_LIB=$PWD/gpurun_variants/libtac_$v.so; fi
-  TAC_ROTATE=1 python tools/time_steady.py mel 2>&1 | grep median | sed "s/^/$v rot1 /"
-  TAC_ROTATE=4 python tools/time_steady.py mel 2>&1 | grep median | sed "s/^/$v rot4 /"
+  python tools/time_steady.py mel512 mel1024 2>&1 | grep median | sed "s/^/$v /"
 done
-done | tee gpurun_out/ab/early_first.txt
+done | tee gpurun_out/ab/sm_fly.txt

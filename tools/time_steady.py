@@ -34,7 +34,8 @@ mel256 = torch.nn.Sequential(*tac.Melspectrogram(num_mels=40, sample_rate=8000, 
                              tac.AmplitudeToDb()).cuda()                   # the three-phase band-sparse kernel
 mel4k = torch.nn.Sequential(*tac.Melspectrogram(num_mels=128, sample_rate=48000, fft_length=4096, hop_length=1024),
                             tac.AmplitudeToDb()).cuda()
-fns = {'mel4096': lambda: tac.realize(mel4k(x4)), 'mel256': lambda: tac.realize(mel256(x5)), 'mel400': lambda: tac.realize(mel400(x5)), 'stft400': lambda: tac.realize(stft400(x5)), 'spec400': lambda: spec400(x5),
+stft256, spec256 = tac.STFT(256, 64).cuda(), tac.Spectrogram(256, 64, power=2.).cuda()
+fns = {'stft256': lambda: tac.realize(stft256(x5)), 'spec256': lambda: spec256(x5), 'mel4096': lambda: tac.realize(mel4k(x4)), 'mel256': lambda: tac.realize(mel256(x5)), 'mel400': lambda: tac.realize(mel400(x5)), 'stft400': lambda: tac.realize(stft400(x5)), 'spec400': lambda: spec400(x5),
        'stft': lambda: tac.realize(stft(xr())), 'spec': lambda: spec(xr()), 'mel': lambda: tac.realize(mel(xr())),
        'stft4096': lambda: tac.realize(stft4(x4)), 'spec4096': lambda: spec4(x4),
        'stft512': lambda: tac.realize(stft512(x5)), 'spec512': lambda: spec512(x5),

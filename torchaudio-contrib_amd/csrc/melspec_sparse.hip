@@ -681,7 +681,7 @@ int tac_melbank_pack(const float* fb, int32_t n_freqs, int32_t n_mels, int32_t n
         if (rc != TAC_E_UNSUPPORTED) return rc;                             // else: the tile kernel's layout
     }
     if (n_fft == 400) return pack_n400(h, n_freqs, n_mels, wpack, wpack_cap, desc, desc_cap, info_host, (hipStream_t)stream);
-    if (n_fft == 512 || n_fft == 1024) {
+    if (n_fft == 256 || n_fft == 512 || n_fft == 1024) {
         const int rc = pack_small(n_fft, h, n_freqs, n_mels, wpack, wpack_cap, desc, desc_cap, info_host, (hipStream_t)stream);
         if (rc != TAC_E_UNSUPPORTED) return rc;                             // else: the three-phase kernel's layout
     }
@@ -752,7 +752,7 @@ int tac_melspec_sparse_f32(const float* wave, const float* window, const tac_stf
     int64_t T = 0;
     int rc = make_geometry(wave, window, d, &g, &T);
     if (rc != TAC_OK) return rc;
-    if (lanes_pack && (d->n_fft == 512 || d->n_fft == 1024)) {
+    if (lanes_pack && (d->n_fft == 256 || d->n_fft == 512 || d->n_fft == 1024)) {
         Tables tbs;
         rc = get_tables(d->n_fft, &tbs);
         if (rc != TAC_OK) return rc;

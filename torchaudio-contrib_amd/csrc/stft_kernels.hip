@@ -562,7 +562,11 @@ static int dispatch_stft(int n_fft, const FrameGeom& g, const Tables& tb, const 
         case 32: return launch_stft<16, 16, MODE>(g, tb, ep, s);
         case 64: return launch_stft<32, 16, MODE>(g, tb, ep, s);
         case 128: return launch_stft<64, 16, MODE>(g, tb, ep, s);
-        case 256: return launch_stft<128, 16, MODE>(g, tb, ep, s);
+        case 256: {
+            const int rc = try_launch_small(n_fft, g, tb, ep, MODE, s);     // stft_small3.hpp: plain epilogues, rows >= one frame
+            if (rc != TAC_E_UNSUPPORTED) return rc;
+            return launch_stft<128, 16, MODE>(g, tb, ep, s);
+        }
         case 512:
         case 1024: {
             const int rc = try_launch_small(n_fft, g, tb, ep, MODE, s);     // stft_small.hip: plain epilogues

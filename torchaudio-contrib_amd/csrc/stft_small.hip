@@ -19,7 +19,10 @@ typedef float sm_f4 __attribute__((ext_vector_type(4)));
 // are contracted with a band-sparse filterbank there by the frame's LPF lanes (mel_lanes.hpp, S steps per band); the
 // mel rows are staged behind them and stored instead of the spectrogram rows.
 __host__ __device__ constexpr int sm_mel_pitch(int nc) { return (nc + 1 + 3 + 3) & ~3; }
-constexpr int SM_FLY = 6;       // contraction steps in flight: this kernel keeps its twiddles in registers, 48 more is what fits
+#ifndef TAC_SM_FLY
+#define TAC_SM_FLY 6
+#endif
+constexpr int SM_FLY = TAC_SM_FLY;       // contraction steps in flight (the packed layout depends on it: groups of slots)
 }  // namespace tac
 #include "stft_small3.hpp"
 namespace tac {
@@ -238,11 +241,15 @@ static int launch_small(const FrameGeom& g, const Tables& tb, const StftEpilogue
         if (wv == 12) return go(stft_small3_kernel<NC, MODE, false, 1, 12>, 12);
         return go(stft_small3_kernel<NC, MODE, false, 1, 16>, 16);
     }
-    auto kern = stft_small_kernel<NC, MODE, false, 1>;
-    if (bytes > 64 * 1024) TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes));
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SM_WAVES * 64), bytes, stream, g, tb, ep, LaneMel{});
-    TAC_HIP(hipGetLastError());
-    return TAC_OK;
+    if constexpr (NC < 256) {
+        return TAC_E_UNSUPPORTED;                            // fft_length 256 has no two-wave form: the generic kernel
+    } else {
+        auto kern = stft_small_kernel<NC, MODE, false, 1>;
+        if (bytes > 64 * 1024) TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes));
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SM_WAVES * 64), bytes, stream, g, tb, ep, LaneMel{});
+        TAC_HIP(hipGetLastError());
+        return TAC_OK;
+    }
 }
 
 template <int NC>
@@ -275,12 +282,16 @@ static int launch_small_mel(const FrameGeom& g, const Tables& tb, const LaneMel&
             return TAC_OK;
         }
     }
-    auto kern = stft_small_kernel<NC, MODE, true, S>;
-    if (bytes > 64 * 1024) TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes));
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SM_WAVES * 64), bytes, stream, g, tb,
-                       StftEpilogue{nullptr, 1, 1, MODE == 1 ? 2.0f : 1.0f, 0, 0.0f, 0.0f}, mel);
-    TAC_HIP(hipGetLastError());
-    return TAC_OK;
+    if constexpr (NC < 256) {
+        return TAC_E_UNSUPPORTED;
+    } else {
+        auto kern = stft_small_kernel<NC, MODE, true, S>;
+        if (bytes > 64 * 1024) TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes));
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SM_WAVES * 64), bytes, stream, g, tb,
+                           StftEpilogue{nullptr, 1, 1, MODE == 1 ? 2.0f : 1.0f, 0, 0.0f, 0.0f}, mel);
+        TAC_HIP(hipGetLastError());
+        return TAC_OK;
+    }
 }
 
 template <int NC>
@@ -298,19 +309,20 @@ static int launch_small_mel_nc(const FrameGeom& g, const Tables& tb, float power
 int launch_small_mel_entry(int n_fft, const FrameGeom& g, const Tables& tb, float power, const float* wpack, const int* desc,
                            const int32_t* info_host, int n_mels, int db, float amin, float log10_ref, float* out,
                            hipStream_t stream) {
-    const int lanes = n_fft == 512 ? 16 : 32;
-    if ((n_fft != 512 && n_fft != 1024) || !lane_mel_info_ok(info_host, lanes, SM_FLY)) return TAC_E_INVALID;
+    const int lanes = n_fft / 32;
+    if ((n_fft != 256 && n_fft != 512 && n_fft != 1024) || !lane_mel_info_ok(info_host, lanes, SM_FLY)) return TAC_E_INVALID;
     if (n_mels < LM_MIN_MELS || n_mels > LM_MAX_MELS) return TAC_E_UNSUPPORTED;
     const LaneMel mel{wpack, desc, info_host[1], info_host[0], n_mels, db, amin, log10_ref, out};
+    if (n_fft == 256) return launch_small_mel_nc<128>(g, tb, power, mel, info_host[4], stream);
     return n_fft == 512 ? launch_small_mel_nc<256>(g, tb, power, mel, info_host[4], stream)
                         : launch_small_mel_nc<512>(g, tb, power, mel, info_host[4], stream);
 }
 
 int pack_small(int n_fft, const std::vector<float>& h, int n_freqs, int n_mels, float* wpack, int wpack_cap, int32_t* desc,
                int desc_cap, int32_t* info_host, hipStream_t stream) {
-    if ((n_fft != 512 && n_fft != 1024) || n_freqs != n_fft / 2 + 1) return TAC_E_UNSUPPORTED;
-    const int lanes = n_fft == 512 ? 16 : 32;
-    const size_t base = n_fft == 512 ? small_lds_bytes<256>() : small_lds_bytes<512>();
+    if ((n_fft != 256 && n_fft != 512 && n_fft != 1024) || n_freqs != n_fft / 2 + 1) return TAC_E_UNSUPPORTED;
+    const int lanes = n_fft / 32;
+    const size_t base = n_fft == 256 ? small3_lds_bytes<128>(12) : (n_fft == 512 ? small_lds_bytes<256>() : small_lds_bytes<512>());
     return pack_lane_mel(h, n_freqs, n_mels, lanes, sm_mel_pitch(n_fft / 2), 2, SM_FLY, LM_MAX_STEPS, base, wpack, wpack_cap, desc, desc_cap,
                          info_host, stream);
 }
@@ -338,6 +350,7 @@ int try_launch_small(int n_fft, const FrameGeom& g, const Tables& tb, const Stft
     if (pmode < 0) return TAC_E_UNSUPPORTED;
     if (n_fft == 1024) return launch_small_mode<512>(pmode, g, tb, ep, stream);
     if (n_fft == 512) return launch_small_mode<256>(pmode, g, tb, ep, stream);
+    if (n_fft == 256) return launch_small_mode<128>(pmode, g, tb, ep, stream);
     return TAC_E_UNSUPPORTED;
 }
 

@@ -27,8 +27,12 @@ stft_small3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, LaneMel mel) {
     constexpr int E = 16;
     using F = WaveFft<NC, E>;
     constexpr int LPF = F::LPF, G = F::G, NPASS = F::NPASS;
-    static_assert(G >= 2 && radix_at(NC, 0) == E && (NPASS == 2 || NPASS == 3), "fft_length 512 / 1024");
-    static_assert(radix_at(NC, 1) == 16 && LPF % 16 == 0, "pass 1 shares one twiddle set per lane, indexed by t & 15");
+    static_assert(G >= 2 && radix_at(NC, 0) == E && (NPASS == 2 || NPASS == 3), "fft_length 256 / 512 / 1024");
+    // pass 1 uses ONE set of R1 - 1 twiddles per lane: a middle pass whose stride 16 divides LPF (row t & 15), or the last pass
+    // (row t; its W_E^{bq} factors are compile-time constants inside pass_twiddle)
+    constexpr int R1 = radix_at(NC, 1);
+    static_assert(pass_shares_twiddles(NC, E, 1) && (LPF % 16 == 0 || pass_is_last(NC, 1)) && R1 <= 16, "one pass-1 twiddle set per lane");
+    constexpr int TW1_ROWS = LPF < 16 ? LPF : 16;
     typedef float f4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf* smem = reinterpret_cast<cf*>(smem_raw);
@@ -47,9 +51,11 @@ stft_small3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, LaneMel mel) {
     float* const twlds = reinterpret_cast<float*>(wlds + LPF * WROW);
     if (threadIdx.x < 16 * 16) {
         const int js = threadIdx.x >> 4, q = threadIdx.x & 15;
-        const cf wv = q ? tb.w_nc[js * q * (NC / 256)] : mkc(1.0f, 0.0f);
-        twlds[js * SM3_TW_STRIDE + 2 * (q ? q - 1 : 15)] = wv.x;
-        twlds[js * SM3_TW_STRIDE + 2 * (q ? q - 1 : 15) + 1] = wv.y;
+        if (js < TW1_ROWS && q < R1) {
+            const cf wv = q ? tb.w_nc[js * q * (NC / (16 * R1))] : mkc(1.0f, 0.0f);
+            twlds[js * SM3_TW_STRIDE + 2 * (q ? q - 1 : 15)] = wv.x;
+            twlds[js * SM3_TW_STRIDE + 2 * (q ? q - 1 : 15) + 1] = wv.y;
+        }
     }
     // the eight R2C twiddles of a column as [read u][column] 16-byte pairs
     cf* const ptwl = reinterpret_cast<cf*>(twlds + SM3_TW_BYTES / 4);
@@ -133,9 +139,9 @@ stft_small3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, LaneMel mel) {
         // ---- pass 1 (its fifteen twiddles from LDS) [and pass 2]; the last pass keeps the lower half of the spectrum in registers
         {
             cf tw1[16];
-            const f4* tl = reinterpret_cast<const f4*>(twlds + (t & 15) * SM3_TW_STRIDE);
+            const f4* tl = reinterpret_cast<const f4*>(twlds + (t & (TW1_ROWS - 1)) * SM3_TW_STRIDE);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < R1 / 2; ++u) {
                 const f4 x = tl[u];
                 tw1[2 * u] = mkc(x.x, x.y);
                 tw1[2 * u + 1] = mkc(x.z, x.w);
