@@ -42,7 +42,8 @@ __host__ __device__ constexpr int lm_weight_slots(int nslot, int S, int FLY) {
     return ((nslot + lm_group(S, FLY) - 1) / lm_group(S, FLY)) * lm_group(S, FLY);
 }
 __host__ __device__ constexpr int lm_padded_slots(int nslot, int S, int FLY) { return lm_weight_slots(nslot, S, FLY) + lm_group(S, FLY); }
-__host__ __device__ constexpr int lm_desc_ints(int lanes) { return lanes * (LM_MAX_MELS / lanes + 8); }
+// first bins [padded slot][lane] followed by the padded slots' own step counts (round 3: a slot stops at ITS longest band)
+__host__ __device__ constexpr int lm_desc_ints(int lanes) { return lanes * (LM_MAX_MELS / lanes + 8) + 32; }
 // LDS of the fused form behind a kernel's own: first bins + packed weights
 inline size_t lm_lds_bytes(int lanes, int wtot) {
     return (size_t)lm_desc_ints(lanes) * sizeof(int) + (((size_t)wtot + 3) & ~(size_t)3) * sizeof(float);
@@ -51,8 +52,40 @@ inline size_t lm_lds_bytes(int lanes, int wtot) {
 // tables into LDS (all threads of the workgroup; the caller's barrier follows)
 template <int S, int LANES, int FLY>
 __device__ __forceinline__ void lane_mel_load_tables(int* mlo, float* mwl, const LaneMel& mel, int tid, int nthreads) {
-    for (int i = tid; i < LANES * lm_padded_slots(mel.nslot, S, FLY); i += nthreads) mlo[i] = mel.desc[i];
+    for (int i = tid; i < (LANES + 1) * lm_padded_slots(mel.nslot, S, FLY); i += nthreads) mlo[i] = mel.desc[i];
     for (int i = tid; i < mel.wtot; i += nthreads) mwl[i] = mel.wpack[i];
+}
+
+// N steps of one slot (N <= S), FLY in flight at a time
+template <int N, int LANES, int FLY>
+__device__ __forceinline__ void lm_slot_steps(const lm_f4* wp, const lm_f4* pp, cf& acc0, cf& acc1) {
+#pragma unroll
+    for (int c0 = 0; c0 < N; c0 += FLY) {
+        lm_f4 wv[FLY], pv[FLY];
+#pragma unroll
+        for (int j = 0; j < FLY; ++j)
+            if (c0 + j < N) {
+                wv[j] = wp[(c0 + j) * LANES];
+                pv[j] = pp[c0 + j];
+            }
+#pragma unroll
+        for (int j = 0; j < FLY; ++j)
+            if (c0 + j < N) {
+                acc0 = __builtin_elementwise_fma(mkc(wv[j].x, wv[j].y), mkc(pv[j].x, pv[j].y), acc0);
+                acc1 = __builtin_elementwise_fma(mkc(wv[j].z, wv[j].w), mkc(pv[j].z, pv[j].w), acc1);
+            }
+        asm volatile("" : "+v"(acc0), "+v"(acc1) : : "memory");              // the next chunk's reads stay behind these FMAs
+    }
+}
+// wave-uniform `pairs` (1 .. P) -> the body unrolled for min(2 pairs, S) steps
+template <int P, int S, int LANES, int FLY>
+__device__ __forceinline__ void lm_slot_dispatch(int pairs, const lm_f4* wp, const lm_f4* pp, cf& acc0, cf& acc1) {
+    if constexpr (P <= 1) {
+        lm_slot_steps<(2 < S ? 2 : S), LANES, FLY>(wp, pp, acc0, acc1);
+    } else {
+        if (pairs >= P) lm_slot_steps<(2 * P < S ? 2 * P : S), LANES, FLY>(wp, pp, acc0, acc1);
+        else lm_slot_dispatch<P - 1, S, LANES, FLY>(pairs, wp, pp, acc0, acc1);
+    }
 }
 
 // One frame's row (srow: 16-byte aligned, `bins` values, at least three floats of slack behind them) -> its mel (dB) row
@@ -64,9 +97,12 @@ __device__ __forceinline__ void lane_mel_contract(float* srow, int bins, const i
     const float ten_log10_ref = 10.0f * mel.log10_ref;
     if (l < 3) srow[bins + l] = 0.0f;                                      // slack taps carry zero weights: keep them finite
     wave_lds_fence();
-    if constexpr (S > FLY) {
-        // a slot longer than FLY steps (standalone apply_filterbank on 2049-bin rows: up to 36): FLY of its steps in flight
-        // at a time, one slot after the other
+    if constexpr (S > FLY || GS == 1) {
+        // One slot after the other, FLY of its steps in flight at a time.  A slot runs ITS OWN number of steps (the longest band
+        // among its lanes, in pairs; wave-uniform, from the table behind the first bins) through a switch over fully unrolled
+        // bodies: the zero-padded tail of the uniform-S layout — 40 % of the steps of an 80-band bank at fft_length 512 — is
+        // neither read nor multiplied.
+        const int* const msteps = mlo + LANES * lm_padded_slots(mel.nslot, S, FLY);
         int lo_c = mlo[l];
 #pragma unroll 1
         for (int i0 = 0; i0 < mel.nslot; ++i0) {
@@ -74,23 +110,8 @@ __device__ __forceinline__ void lane_mel_contract(float* srow, int bins, const i
             const lm_f4* wp = reinterpret_cast<const lm_f4*>(mwl) + i0 * (S * LANES) + l;
             const lm_f4* pp = reinterpret_cast<const lm_f4*>(srow + lo_c);
             lo_c = mlo[LANES * (i0 + 1) + l];                                // (table padded by one group)
-#pragma unroll
-            for (int c0 = 0; c0 < S; c0 += FLY) {
-                lm_f4 wv[FLY], pv[FLY];
-#pragma unroll
-                for (int j = 0; j < FLY; ++j)
-                    if (c0 + j < S) {
-                        wv[j] = wp[(c0 + j) * LANES];
-                        pv[j] = pp[c0 + j];
-                    }
-#pragma unroll
-                for (int j = 0; j < FLY; ++j)
-                    if (c0 + j < S) {
-                        acc0 = __builtin_elementwise_fma(mkc(wv[j].x, wv[j].y), mkc(pv[j].x, pv[j].y), acc0);
-                        acc1 = __builtin_elementwise_fma(mkc(wv[j].z, wv[j].w), mkc(pv[j].z, pv[j].w), acc1);
-                    }
-                asm volatile("" : "+v"(acc0), "+v"(acc1) : : "memory");      // the next chunk's reads stay behind these FMAs
-            }
+            const int pairs = __builtin_amdgcn_readfirstlane(msteps[i0]);    // steps of this slot / 2, 1 .. (S + 1) / 2
+            lm_slot_dispatch<(S + 1) / 2, S, LANES, FLY>(pairs, wp, pp, acc0, acc1);
             float val = (acc0.x + acc0.y) + (acc1.x + acc1.y);
             if (mel.db) val = fast_db ? amp_to_db_fast(val, mel.amin, ten_log10_ref) : amp_to_db(val, mel.amin, mel.log10_ref);
             const int band = LANES * i0 + l;
@@ -183,11 +204,12 @@ inline int pack_lane_mel(const std::vector<float>& h, int n_freqs, int n_mels, i
     S = ((S + step_quantum - 1) / step_quantum) * step_quantum;            // (the kernels are instantiated for these values of S only)
     if (S > max_steps || 4 * S > pitch) return TAC_E_UNSUPPORTED;          // bands too wide: the unfused chain
     const int pslot = lm_padded_slots(nslot, S, fly);
-    if (lanes * pslot > desc_cap || lanes * pslot > lm_desc_ints(lanes)) return TAC_E_UNSUPPORTED;
+    if ((lanes + 1) * pslot > desc_cap || (lanes + 1) * pslot > lm_desc_ints(lanes)) return TAC_E_UNSUPPORTED;
     const long long wtot = 4LL * lanes * S * lm_weight_slots(nslot, S, fly);
     if (wtot > wpack_cap || base_lds + lm_lds_bytes(lanes, (int)wtot) > 160 * 1024) return TAC_E_UNSUPPORTED;
     std::vector<float> wp((size_t)wtot, 0.0f);
-    std::vector<int32_t> dd((size_t)lanes * pslot, 0);
+    std::vector<int32_t> dd((size_t)(lanes + 1) * pslot, 0);               // first bins, then the slots' step counts in pairs
+    for (int i = 0; i < pslot; ++i) dd[(size_t)lanes * pslot + i] = 1;
     for (int i = 0; i < nslot; ++i)
         for (int l = 0; l < lanes; ++l) {
             const int m = lanes * i + l;
@@ -200,6 +222,11 @@ inline int pack_lane_mel(const std::vector<float>& h, int n_freqs, int n_mels, i
                     wp[(((size_t)i * S + j) * lanes + l) * 4 + u] = live ? h[(size_t)bin * n_mels + m] : 0.0f;
                 }
             dd[lanes * i + l] = first;
+            if (m < n_mels && hi[m] > lo[m]) {
+                const int need = (hi[m] - first + 3) / 4;                  // steps this band takes from its (possibly shifted) first bin
+                int32_t& pr = dd[(size_t)lanes * pslot + i];
+                pr = std::max<int32_t>(pr, std::min((need + 1) / 2, (S + 1) / 2));
+            }
         }
     TAC_HIP(hipMemcpyAsync(wpack, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice, stream));
     TAC_HIP(hipMemcpyAsync(desc, dd.data(), dd.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));

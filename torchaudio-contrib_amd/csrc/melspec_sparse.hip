@@ -449,14 +449,14 @@ static int launch_stream(FrameGeom g, const Tables& tb, const SparseArgs& sm, co
 // the frame's row in its own LDS buffer (16-byte chunks, the next frame's requested before this one is contracted),
 // contracts it and stores the band row — no workgroup barrier, no tile.  (fb_sparse_kernel above, round 1's 16-frame
 // tiles between barriers, stays the route for banks outside this layout and for other frame strides.)
-// Rows up to 1280 bins (fft_length <= 2560): SIXTEEN 128-register waves per CU with 12 contraction steps in flight (round 3:
+// Rows up to 1280 bins (fft_length <= 2560): SIXTEEN 128-register waves per CU with 8 contraction steps in flight (round 3:
 // 0.092 -> 0.080 ms on cfg-2's 1025 x 128, 4.0 -> 4.6 TB/s; twelve waves 0.081); wider rows (fft_length 4096): eight waves, 16 steps
 // in flight — sixteen row buffers of 8 KB do not fit next to 41 KB of weights.  The packed layout depends on the steps in flight
 // (lm_group), so the pack and the launch use the same rule.
 constexpr int FBL_CHUNKS = 5, FBL_CHUNKS_WIDE = 9;   // 16-byte chunks per lane and frame: up to 1280 / 2304 bins (fft_length 2048 / 4096)
 __host__ __device__ inline bool fbl_is_wide(int n_freqs) { return (n_freqs + 3) / 4 > FBL_CHUNKS * 64; }
 __host__ __device__ inline int fbl_waves(int n_freqs) { return fbl_is_wide(n_freqs) ? 8 : 16; }
-__host__ __device__ inline int fbl_fly(int n_freqs) { return fbl_is_wide(n_freqs) ? 16 : 12; }
+__host__ __device__ inline int fbl_fly(int n_freqs) { return fbl_is_wide(n_freqs) ? 16 : 8; }
 __host__ __device__ inline int fbl_pitch(int n_freqs) { return (n_freqs + 3 + 3) & ~3; }
 inline size_t fbl_base_lds(int n_freqs) { return (size_t)fbl_waves(n_freqs) * (fbl_pitch(n_freqs) + LM_MAX_MELS + 4) * sizeof(float) + 16; }
 
@@ -534,7 +534,7 @@ fb_lanes_kernel(const float* __restrict__ spec, long long rows, int n_freqs, lon
 template <int S, int CHUNKS>
 static int launch_fb_lanes(const float* spec, long long rows, int n_freqs, long long n_frames, long long stride_r,
                            long long stride_t, const LaneMel& mel, hipStream_t stream) {
-    constexpr int FBL_WAVES = CHUNKS == FBL_CHUNKS_WIDE ? 8 : 16, FBL_FLY = CHUNKS == FBL_CHUNKS_WIDE ? 16 : 12;
+    constexpr int FBL_WAVES = CHUNKS == FBL_CHUNKS_WIDE ? 8 : 16, FBL_FLY = CHUNKS == FBL_CHUNKS_WIDE ? 16 : 8;
     const size_t bytes = fbl_base_lds(n_freqs) + lm_lds_bytes(64, mel.wtot);
     if (bytes > 160 * 1024) return TAC_E_UNSUPPORTED;
     const long long total = rows * n_frames;
