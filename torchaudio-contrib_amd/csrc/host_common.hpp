@@ -32,6 +32,9 @@ __device__ __forceinline__ float spectral_row_value(float norm2, const StftEpilo
 #endif
 
 
+// sample formats of the fused kernels' frame loads (= TAC_SAMPLES_*): float32, int16 PCM, mu-law codes as uint8 / int64
+enum { FMT_F32 = 0, FMT_I16 = 1, FMT_MULAW_U8 = 2, FMT_MULAW_I64 = 3 };
+
 extern thread_local int g_last_hip_error;
 
 inline int hip_fail(hipError_t e) {

@@ -65,7 +65,7 @@ struct StreamArgs {
 };
 
 // sample formats of the frame load (tac_amd.h TAC_SAMPLES_*)
-enum { FMT_F32 = 0, FMT_I16 = 1, FMT_MULAW_U8 = 2, FMT_MULAW_I64 = 3 };
+// (FMT_*: host_common.hpp)
 
 template <int NC, int E>
 struct StreamCfg {

@@ -231,7 +231,8 @@ static int launch_small(const FrameGeom& g, const Tables& tb, const StftEpilogue
             long long bl = (units + W - 1) / W;
             if (bl > cap) bl = cap;
             TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(k3), (int)b3));
-            hipLaunchKernelGGL(k3, dim3((unsigned)bl), dim3(W * 64), b3, stream, g, tb, ep, LaneMel{});
+            hipLaunchKernelGGL(k3, dim3((unsigned)bl), dim3(W * 64), b3, stream, g, tb, ep, LaneMel{}, (const void*)nullptr,
+                               (const float*)nullptr);
             TAC_HIP(hipGetLastError());
             return TAC_OK;
         };
@@ -277,7 +278,8 @@ static int launch_small_mel(const FrameGeom& g, const Tables& tb, const LaneMel&
             if (bl > cap) bl = cap;
             TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(k3), (int)b3));
             hipLaunchKernelGGL(k3, dim3((unsigned)bl), dim3(12 * 64), b3, stream, g, tb,
-                               StftEpilogue{nullptr, 1, 1, MODE == 1 ? 2.0f : 1.0f, 0, 0.0f, 0.0f}, mel);
+                               StftEpilogue{nullptr, 1, 1, MODE == 1 ? 2.0f : 1.0f, 0, 0.0f, 0.0f}, mel, (const void*)nullptr,
+                               (const float*)nullptr);
             TAC_HIP(hipGetLastError());
             return TAC_OK;
         }
@@ -294,6 +296,49 @@ static int launch_small_mel(const FrameGeom& g, const Tables& tb, const LaneMel&
     }
 }
 
+// int16 PCM / mu-law codes read by the fused kernel itself (power 2 only: one instantiation per format and band length)
+template <int NC, int S, int FMT>
+static int launch_small_mel_coded(FrameGeom g, const Tables& tb, const LaneMel& mel, hipStream_t stream, const void* samples,
+                                  const float* lut) {
+    using F = WaveFft<NC, 16>;
+    const long long units = g.rows * ((g.n_frames + F::G - 1) / F::G);
+    if (units >= 0x7fffffffLL || !small3_waves() || g.length < 2 * NC) return TAC_E_UNSUPPORTED;
+    const size_t b3 = small3_lds_bytes<NC>(12) + lm_lds_bytes(F::LPF, mel.wtot) + 1024;
+    if (b3 > 160 * 1024) return TAC_E_UNSUPPORTED;
+    {                                                                      // sample pairs fetched as one access of the format
+        const uintptr_t pair = FMT == FMT_I16 ? 4 : (FMT == FMT_MULAW_U8 ? 2 : 8);
+        g.vec2_ok = ((g.hop & 1) == 0) && ((g.center_pad & 1) == 0) && ((g.row_stride & 1) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(samples) & (pair - 1)) == 0);
+    }
+    auto k3 = stft_small3_kernel<NC, 1, true, S, 12, FMT>;
+    long long bl = (units + 12 - 1) / 12;
+    if (bl > device_cu_count()) bl = device_cu_count();
+    TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(k3), (int)b3));
+    hipLaunchKernelGGL(k3, dim3((unsigned)bl), dim3(12 * 64), b3, stream, g, tb, StftEpilogue{nullptr, 1, 1, 2.0f, 0, 0.0f, 0.0f}, mel,
+                       samples, lut);
+    TAC_HIP(hipGetLastError());
+    return TAC_OK;
+}
+
+template <int NC, int FMT>
+static int launch_small_mel_coded_nc(const FrameGeom& g, const Tables& tb, const LaneMel& mel, int S, hipStream_t stream,
+                                     const void* samples, const float* lut) {
+    switch (S) {
+#define TAC_SM_CASE(SS) case SS: return launch_small_mel_coded<NC, SS, FMT>(g, tb, mel, stream, samples, lut);
+        TAC_SM_CASE(2) TAC_SM_CASE(4) TAC_SM_CASE(6) TAC_SM_CASE(8) TAC_SM_CASE(10) TAC_SM_CASE(12)
+#undef TAC_SM_CASE
+        default: return TAC_E_INVALID;
+    }
+}
+
+template <int FMT>
+static int launch_small_mel_coded_fmt(int n_fft, const FrameGeom& g, const Tables& tb, const LaneMel& mel, int S, hipStream_t stream,
+                                      const void* samples, const float* lut) {
+    if (n_fft == 256) return launch_small_mel_coded_nc<128, FMT>(g, tb, mel, S, stream, samples, lut);
+    if (n_fft == 512) return launch_small_mel_coded_nc<256, FMT>(g, tb, mel, S, stream, samples, lut);
+    return launch_small_mel_coded_nc<512, FMT>(g, tb, mel, S, stream, samples, lut);
+}
+
 template <int NC>
 static int launch_small_mel_nc(const FrameGeom& g, const Tables& tb, float power, const LaneMel& mel, int S, hipStream_t stream) {
     const bool p2 = power == 2.0f;
@@ -308,11 +353,19 @@ static int launch_small_mel_nc(const FrameGeom& g, const Tables& tb, float power
 // The fused Melspectrogram (+dB) chain for fft_length 512 / 1024 (melspec_sparse.hip's entry points call these).
 int launch_small_mel_entry(int n_fft, const FrameGeom& g, const Tables& tb, float power, const float* wpack, const int* desc,
                            const int32_t* info_host, int n_mels, int db, float amin, float log10_ref, float* out,
-                           hipStream_t stream) {
+                           hipStream_t stream, int fmt, const void* samples, const float* lut) {
     const int lanes = n_fft / 32;
     if ((n_fft != 256 && n_fft != 512 && n_fft != 1024) || !lane_mel_info_ok(info_host, lanes, SM_FLY)) return TAC_E_INVALID;
     if (n_mels < LM_MIN_MELS || n_mels > LM_MAX_MELS) return TAC_E_UNSUPPORTED;
     const LaneMel mel{wpack, desc, info_host[1], info_host[0], n_mels, db, amin, log10_ref, out};
+    if (fmt != FMT_F32) {
+        if (power != 2.0f) return TAC_E_UNSUPPORTED;
+        switch (fmt) {
+            case FMT_I16: return launch_small_mel_coded_fmt<FMT_I16>(n_fft, g, tb, mel, info_host[4], stream, samples, lut);
+            case FMT_MULAW_U8: return launch_small_mel_coded_fmt<FMT_MULAW_U8>(n_fft, g, tb, mel, info_host[4], stream, samples, lut);
+            default: return launch_small_mel_coded_fmt<FMT_MULAW_I64>(n_fft, g, tb, mel, info_host[4], stream, samples, lut);
+        }
+    }
     if (n_fft == 256) return launch_small_mel_nc<128>(g, tb, power, mel, info_host[4], stream);
     return n_fft == 512 ? launch_small_mel_nc<256>(g, tb, power, mel, info_host[4], stream)
                         : launch_small_mel_nc<512>(g, tb, power, mel, info_host[4], stream);

@@ -21,9 +21,13 @@ inline size_t small3_lds_bytes(int waves) {
            (size_t)4 * F::LPF * 16 + 16;
 }
 
-template <int NC, int MODE, bool MEL, int S, int WAVES>
+// FMT (fused mel form only): sample format of the frame load — int16 PCM (value = sample 2^-15, folded into the window) and mu-law
+// codes (uint8 / int64; 256-entry decode table in LDS) are converted in registers, like melspec_stream3_kernel does at 2048
+template <int NC, int MODE, bool MEL, int S, int WAVES, int FMT = FMT_F32>
 __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
-stft_small3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, LaneMel mel) {
+stft_small3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, LaneMel mel, const void* __restrict__ samples = nullptr,
+                   const float* __restrict__ lut = nullptr) {
+    static_assert(FMT == FMT_F32 || MEL, "coded inputs: the fused Melspectrogram form");
     constexpr int E = 16;
     using F = WaveFft<NC, E>;
     constexpr int LPF = F::LPF, G = F::G, NPASS = F::NPASS;
@@ -45,7 +49,7 @@ stft_small3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, LaneMel mel) {
     // window pairs, one 144-byte row per first-pass column (8 conflict-free ds_read_b128 per lane); the 1/2 of the R2C split
     // and the normalisation are folded in
     constexpr int WROW = E + 2;
-    const float half = 0.5f * g.scale;
+    const float half = 0.5f * g.scale * (FMT == FMT_I16 ? (1.0f / 32768.0f) : 1.0f);
     cf* const wlds = smem + WAVES * WAVE_SLOTS;
     for (int m = threadIdx.x; m < NC; m += WAVES * 64) wlds[(m % LPF) * WROW + (m / LPF)] = cscale(window_pair(g, m), half);
     float* const twlds = reinterpret_cast<float*>(wlds + LPF * WROW);
@@ -87,6 +91,10 @@ stft_small3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, LaneMel mel) {
     int* const mlo = reinterpret_cast<int*>(next_unit + 4);                // MEL: first bins [slot][lane]; the weights
     float* const mwl = reinterpret_cast<float*>(mlo + lm_desc_ints(LPF));
     if constexpr (MEL) lane_mel_load_tables<S, LPF, SM_FLY>(mlo, mwl, mel, threadIdx.x, WAVES * 64);
+    float* const lutlds = mwl + ((mel.wtot + 3) & ~3);                     // mu-law decode table behind the weights
+    if constexpr (FMT >= FMT_MULAW_U8) {
+        if (threadIdx.x < 256) lutlds[threadIdx.x] = lut[threadIdx.x];
+    }
     auto grab = [&]() -> int {
         unsigned v = 0;
         if (lane == 0) v = __hip_atomic_fetch_add(next_unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -105,9 +113,57 @@ stft_small3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, LaneMel mel) {
         fast = __builtin_amdgcn_ballot_w64(ok) == ~0ull;
         long long cs = start < 0 ? 0 : start;
         cs = cs + F::N <= g.length ? cs : g.length - F::N;
-        const cf* src = reinterpret_cast<const cf*>(g.wave + (long long)urow * g.row_stride + cs);
+        const long long off = (long long)urow * g.row_stride + cs;           // in samples
+        if constexpr (FMT == FMT_F32) {
+            const cf* src = reinterpret_cast<const cf*>(g.wave + off);
 #pragma unroll
-        for (int q = 0; q < E; ++q) v[0][q] = src[t + q * LPF];
+            for (int q = 0; q < E; ++q) v[0][q] = src[t + q * LPF];
+        } else if constexpr (FMT == FMT_I16) {                              // a pair of samples = one dword
+            const unsigned* src = reinterpret_cast<const unsigned*>(static_cast<const short*>(samples) + off);
+#pragma unroll
+            for (int q = 0; q < E; ++q) v[0][q].x = __uint_as_float(src[t + q * LPF]);
+        } else if constexpr (FMT == FMT_MULAW_U8) {                         // a pair of codes = one 16-bit load
+            const unsigned short* src = reinterpret_cast<const unsigned short*>(static_cast<const unsigned char*>(samples) + off);
+#pragma unroll
+            for (int q = 0; q < E; ++q) v[0][q].x = __uint_as_float((unsigned)src[t + q * LPF]);
+        } else {                                                            // int64 codes: the low dword of each
+            const int* src = reinterpret_cast<const int*>(static_cast<const long long*>(samples) + off);
+#pragma unroll
+            for (int q = 0; q < E; ++q) {
+                v[0][q].x = __int_as_float(src[4 * (t + q * LPF)]);
+                v[0][q].y = __int_as_float(src[4 * (t + q * LPF) + 2]);
+            }
+        }
+    };
+    // the requested registers as float sample pairs (still unwindowed): PCM integers / decoded codes
+    auto decode = [&]() {
+        if constexpr (FMT == FMT_I16) {
+#pragma unroll
+            for (int q = 0; q < E; ++q) {
+                const int bits = __float_as_int(v[0][q].x);
+                v[0][q] = mkc((float)(short)(bits & 0xffff), (float)(bits >> 16));
+            }
+        } else if constexpr (FMT == FMT_MULAW_U8) {
+#pragma unroll
+            for (int q = 0; q < E; ++q) {
+                const unsigned bits = __float_as_uint(v[0][q].x);
+                v[0][q] = mkc(lutlds[bits & 0xffu], lutlds[(bits >> 8) & 0xffu]);
+            }
+        } else if constexpr (FMT == FMT_MULAW_I64) {
+#pragma unroll
+            for (int q = 0; q < E; ++q)
+                v[0][q] = mkc(lutlds[__float_as_uint(v[0][q].x) & 0xffu], lutlds[__float_as_uint(v[0][q].y) & 0xffu]);
+        }
+    };
+    struct Fetch {                                        // sample access of the gather path, in the same units as `decode`
+        const void* base;
+        const float* lut;
+        __device__ __forceinline__ float operator()(long long row_offset, int j) const {
+            if constexpr (FMT == FMT_F32) return static_cast<const float*>(base)[row_offset + j];
+            else if constexpr (FMT == FMT_I16) return (float)static_cast<const short*>(base)[row_offset + j];
+            else if constexpr (FMT == FMT_MULAW_U8) return lut[static_cast<const unsigned char*>(base)[row_offset + j]];
+            else return lut[(unsigned)static_cast<const long long*>(base)[row_offset + j] & 0xffu];
+        }
     };
     int unit = begin + w;
     __syncthreads();
@@ -122,7 +178,10 @@ stft_small3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, LaneMel mel) {
         if (!fast) {
             int tz;
             asm volatile("v_mov_b32 %0, %1" : "=v"(tz) : "v"(t));
-            load_frame<F, false, true, true>(v[0], g, nullptr, lds, urow, uframe0 + sub, tz, FetchF32{g.wave});
+            load_frame<F, false, true, true>(v[0], g, nullptr, lds, urow, uframe0 + sub, tz,
+                                             Fetch{FMT == FMT_F32 ? static_cast<const void*>(g.wave) : samples, lutlds});
+        } else {
+            decode();
         }
         {
             const f4* wp = reinterpret_cast<const f4*>(wlds + t * WROW);
