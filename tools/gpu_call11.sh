@@ -1,11 +1,10 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/ab
-TAC_STFT_S3_WAVES=12 TAC_STFT_S3_EARLY=1 timeout 600 python -m pytest tests -m gpu -x -q -k "stft or spectrogram or tiny or layout" 2>&1 | tail -2
-for rep in 1 2; do
-for rot in 1 4; do
-  export TAC_ROTATE=$rot
-  python tools/time_steady.py stft spec 2>&1 | grep median | sed "s/^/default(12c,16r) rot$rot /"
-  TAC_STFT_S3_WAVES=12 python tools/time_steady.py stft spec 2>&1 | grep median | sed "s/^/12 late rot$rot /"
-  TAC_STFT_S3_WAVES=12 TAC_STFT_S3_EARLY=1 python tools/time_steady.py stft spec 2>&1 | grep median | sed "s/^/12 early rot$rot /"
+export TMPDIR=/tmp
+for v in one two; do
+  if [ $v = two ]; then export TAC_N4096_TWO_AREAS=1; else unset TAC_N4096_TWO_AREAS; fi
+  out=gpurun_out/pmc_4096_$v
+  mkdir -p $out
+  rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $out/sq -o p -- python tools/prof_driver.py spec4096 3 > /dev/null 2>&1
+  rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $out/stall -o p -- python tools/prof_driver.py spec4096 3 > /dev/null 2>&1
+  echo "== $v"; python tools/pmc_summary.py $out
 done
-done | tee gpurun_out/ab/stft_early.txt

@@ -42,6 +42,11 @@ elif what == 'grad':
         y = m(xg)
         y.backward(torch.ones_like(y))
         return y
+elif what == 'spec4096':
+    # cfg-4 slice: 64 rows x 480 000 samples, fft_length 4096 / hop 1024, magnitude rows
+    x4 = torch.rand(8, 8, 480000, device='cuda') * 2 - 1
+    m = tac.Spectrogram(4096, 1024).cuda()
+    fn = lambda: m(x4)
 elif what == 'gradspec':
     # training step through the Spectrogram layer (power 2): fused forward kernel, one backward kernel + border fold
     m = tac.Spectrogram(2048, 512, power=2.).cuda()
