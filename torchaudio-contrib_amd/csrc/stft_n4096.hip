@@ -143,8 +143,10 @@ stft_n4096_kernel(FrameGeom g, Tables tb1k, Tables tb4k, StftEpilogue ep) {
             }
             wave_lds_fence();
         }
-        F::template run<1>(va, la, tw, t, st, t);
-        F::template run<1>(vb, lb, tw, t, st, t);
+        // both transforms keep the lower half of their spectrum in registers (the HALF form of fft_core.hpp): a lane then owns the
+        // eight PAIRS (k, 1024 - k), k = t + 64 p, and needs only the partners A[1024 - k], B[1024 - k] from LDS
+        F::template run<1, NoStamp, true>(va, la, tw, t, st, t);
+        F::template run<1, NoStamp, true>(vb, lb, tw, t, st, t);
 
         // request the next frame now: it lands while this frame is combined, split, staged and stored
         __builtin_amdgcn_sched_barrier(0);
@@ -158,41 +160,79 @@ stft_n4096_kernel(FrameGeom g, Tables tb1k, Tables tb4k, StftEpilogue ep) {
         const int a = (int)(g0 & 3);
         float* const stage = reinterpret_cast<float*>(bufA) + a;     // LDS and global share their 16-byte phase
         {
-            cf xa[E], xb[E];
+            // round 3: each pair is combined ONCE into its four bins (it used to be formed twice, once from either end, at four
+            // LDS reads per bin pair):  P = W_2048^k B[k], Q = conj(W_2048^k) B[1024-k];
+            //   Z[k] = A[k] + P, Z[1024+k] = A[k] - P, Z[2048-k] = A[1024-k] + Q, Z[1024-k] = A[1024-k] - Q;
+            //   bins (k, 2048-k) from (Z[k], Z[2048-k]) with W_4096^k; bins (1024-k, 1024+k) from (Z[1024-k], Z[1024+k]) with
+            //   W_4096^(1024-k) = -i conj(W_4096^k).  k = 0 yields DC, Nyquist and bin 1024 by the same formulas; the self-paired
+            //   k = 512 is lane 0's extra.
+            cf am[8], bm[8];
+            {
+                const cf* const pa = bufA + lds_pad(NCH - t);
+                const cf* const pb = bufB + lds_pad(NCH - t);
 #pragma unroll
-            for (int i = 0; i < E; ++i) {
-                const int k = t + 64 * i;
-                const int m = (NCH - k) & (NCH - 1);
-                const cf ak = bufA[lds_pad(k)], bk = bufB[lds_pad(k)];
-                const cf am = bufA[lds_pad(m)], bm = bufB[lds_pad(m)];
-                const cf zk = cadd(ak, cmul(mul_w32(bk, i), w2k));                       // Z[k]
-                const cf zp = cadd(am, cmul_conj(mul_w32(bm, 32 - i), w2k));             // Z[2048-k]
-                const cf ev = cadd_conj(zk, zp), d = csub_conj(zk, zp);
-                const cf twd = cmul_rot(w4k, mul_w64(d, i));
-                if constexpr (MODE != 0) {                            // xa[i] = (|X[k]|^2, |X[2048-k]|^2), no spectra formed
-                    xa[i] = cscale(power_pair(ev, twd), hscale * hscale);
-                } else {
-                    xa[i] = cscale(cadd(ev, twd), hscale);
-                    xb[i] = cscale(csub_then_conj(ev, twd), hscale);
+                for (int p = 0; p < 8; ++p) {
+                    const cf za = pa[-lds_pad_c(p * 64)], zb = pb[-lds_pad_c(p * 64)];
+                    am[p] = (p == 0 && t == 0) ? va[0][F::reg_of_spectrum(0)] : za;
+                    bm[p] = (p == 0 && t == 0) ? vb[0][F::reg_of_spectrum(0)] : zb;
                 }
             }
-            const cf a0 = bufA[0], b0 = bufB[0];
-            const cf xm = mkc((a0.x - b0.x) * g.scale, -(a0.y - b0.y) * g.scale);         // X[1024] = conj(A[0] - B[0])
+            const cf amid = bufA[lds_pad(NCH / 2)], bmid = bufB[lds_pad(NCH / 2)];
+            cf x0[8], x1[8], y0[8], y1[8];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const cf ak = va[0][F::reg_of_spectrum(p)], bk = vb[0][F::reg_of_spectrum(p)];
+                const cf pp = cmul(mul_w32(bk, p), w2k);
+                const cf qq = cmul_conj(mul_w32(bm[p], 32 - p), w2k);
+                const cf zk = cadd(ak, pp), zk2 = csub(ak, pp);         // Z[k], Z[1024 + k]
+                const cf zp = cadd(am[p], qq), zm = csub(am[p], qq);    // Z[2048 - k], Z[1024 - k]
+                const cf wq = mul_w64(w4k, p);                          // W_4096^k = W_4096^t W_64^p
+                const cf wr = mkc(-wq.y, -wq.x);                        // W_4096^(1024 - k)
+                if constexpr (MODE != 0) {
+                    x0[p] = cscale(F::r2c_power_x2(zk, zp, wq), hscale * hscale);     // (|X[k]|^2, |X[2048 - k]|^2)
+                    x1[p] = cscale(F::r2c_power_x2(zm, zk2, wr), hscale * hscale);    // (|X[1024 - k]|^2, |X[1024 + k]|^2)
+                } else {
+                    F::r2c_split_x2(zk, zp, wq, x0[p], y0[p]);
+                    F::r2c_split_x2(zm, zk2, wr, x1[p], y1[p]);
+                    x0[p] = cscale(x0[p], hscale); y0[p] = cscale(y0[p], hscale);
+                    x1[p] = cscale(x1[p], hscale); y1[p] = cscale(y1[p], hscale);
+                }
+            }
+            cf x5 = mkc(0.0f, 0.0f), y5 = mkc(0.0f, 0.0f);              // k = 512: bins 512 and 1536
+            {
+                const cf wi = mkc(0.0f, -1.0f);                         // W_2048^512
+                const cf pm = cmul(bmid, wi);
+                const cf z5 = cadd(amid, pm), z15 = csub(amid, pm);
+                const cf w5 = mkc(0.70710678118654752f, -0.70710678118654752f);     // W_4096^512
+                if constexpr (MODE != 0) x5 = cscale(F::r2c_power_x2(z5, z15, w5), hscale * hscale);
+                else {
+                    F::r2c_split_x2(z5, z15, w5, x5, y5);
+                    x5 = cscale(x5, hscale); y5 = cscale(y5, hscale);
+                }
+            }
             wave_lds_fence();                                         // every A, B of this frame is in registers
 #pragma unroll
-            for (int i = 0; i < E; ++i) {
-                const int k = t + 64 * i;
+            for (int p = 0; p < 8; ++p) {
+                const int k = t + 64 * p;
                 if constexpr (MODE == 0) {
-                    reinterpret_cast<cf*>(stage)[k] = xa[i];
-                    reinterpret_cast<cf*>(stage)[2048 - k] = xb[i];
+                    cf* const sc = reinterpret_cast<cf*>(stage);
+                    sc[k] = x0[p]; sc[2048 - k] = y0[p];
+                    sc[1024 - k] = x1[p]; sc[1024 + k] = y1[p];
                 } else {
-                    stage[k] = spectral_row_value<MODE>(xa[i].x, ep);
-                    stage[2048 - k] = spectral_row_value<MODE>(xa[i].y, ep);
+                    stage[k] = spectral_row_value<MODE>(x0[p].x, ep);
+                    stage[2048 - k] = spectral_row_value<MODE>(x0[p].y, ep);
+                    stage[1024 - k] = spectral_row_value<MODE>(x1[p].x, ep);
+                    stage[1024 + k] = spectral_row_value<MODE>(x1[p].y, ep);
                 }
             }
             if (t == 0) {
-                if constexpr (MODE == 0) reinterpret_cast<cf*>(stage)[1024] = xm;
-                else stage[1024] = spectral_row_value<MODE>(cnorm2(xm), ep);
+                if constexpr (MODE == 0) {
+                    reinterpret_cast<cf*>(stage)[512] = x5;
+                    reinterpret_cast<cf*>(stage)[1536] = y5;
+                } else {
+                    stage[512] = spectral_row_value<MODE>(x5.x, ep);
+                    stage[1536] = spectral_row_value<MODE>(x5.y, ep);
+                }
             }
             wave_lds_fence();
         }
