@@ -1,3 +1,5 @@
+cd $GRAFT_REPO_ROOT
+timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
 cd /tmp && export TMPDIR=/tmp
 for k in grad1024 grad512; do
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$k -o $k -- python $GRAFT_REPO_ROOT/tools/prof_driver.py $k 60 > /tmp/kt.log 2>&1

@@ -674,9 +674,10 @@ def melspectrogram_backward_fused(grad_mel, wave, window, fb, n_fft, hop, win_le
     """Gradient of the waveform from the gradient of the (linear) mel values ``(*, M, T)`` in ONE kernel: the filterbank
     adjoint is formed per frame inside the backward kernel (tac_melspectrogram_backward_ola_f32), so the gradient of the
     power spectrogram — 4·F bytes per frame written by the adjoint kernel and read back by the backward kernel — never
-    exists.  None when the form does not cover the case (fft_length other than 2048, more than 256 bands, a bank with
+    exists.  None when the form does not cover the case (fft_length other than 512 / 1024 / 2048, too many bands, a hop the
+    register-ring kernels are not instantiated for at 512 / 1024, a bank with
     more than two non-zero weights per bin): the caller then runs the two kernels."""
-    if n_fft != 2048 or fb.dim() != 2 or fb.shape[1] > 256 or MEL_PATH == 'mfma':
+    if n_fft not in (512, 1024, 2048) or fb.dim() != 2 or fb.shape[1] > (256 if n_fft == 2048 else 128) or MEL_PATH == 'mfma':
         return None
     table = _adjoint_table(fb)
     if table is None:

@@ -480,7 +480,7 @@ spectrogram_backward_ola_kernel(FrameGeom g, Tables tb, const float* __restrict_
 }
 
 }  // namespace tac
-#include "backward_ring3.hpp"
+#include "backward_ring3_multi.hpp"
 namespace tac {
 
 // The same for fft_length 256 / 512 / 1024, where a wave carries G = 64 / LPF frames side by side: its G lane groups walk G
@@ -997,7 +997,7 @@ int64_t tac_spectrogram_backward_ola_workspace(const tac_stft_desc* d) {
     rc = ola_plan(d, g, &plan);
     if (rc != TAC_OK) return rc;
     long long floats = ola_workspace_floats(g, plan, d->hop);
-    if (d->n_fft == 2048) {      // the twelve-wave form of the mel chain cuts more segments per row: room for either
+    if (d->n_fft == 2048 || d->n_fft == 1024 || d->n_fft == 512) {      // the twelve-wave forms cut more segments per row: room for either
         OlaPlan p12;
         if (ola_plan(d, g, &p12, BR_WAVES) == TAC_OK) floats = std::max(floats, ola_workspace_floats(g, p12, d->hop));
     }
@@ -1096,6 +1096,47 @@ static int ola_backward_entry(const float* wave, const float* window, const tac_
             case 256: rc = pick(std::integral_constant<int, 2>{}); break;
             case 512: rc = pick(std::integral_constant<int, 4>{}); break;
             default: rc = pick(std::integral_constant<int, 8>{}); break;
+        }
+    } else if ((d->n_fft == 1024 || d->n_fft == 512) && (!adj || (n_mels >= 1 && n_mels <= 128)) && !lds_ring &&
+               g.length >= d->n_fft && (d->hop == d->n_fft / 8 || d->hop == d->n_fft / 4 || d->hop == d->n_fft / 2)) {
+        // fft_length 512 / 1024: the same on 4 / 2 lane groups per wave (backward_ring3_multi.hpp)
+        OlaPlan p12;
+        rc = ola_plan(d, g, &p12, BR_WAVES);
+        if (rc != TAC_OK) return rc;
+        if (workspace_bytes < (int64_t)(ola_workspace_floats(g, p12, d->hop) * (long long)sizeof(float))) return TAC_E_INVALID;
+        p12.gwave = plan.gwave;
+        p12.gstride = plan.gstride;
+        p12.direct = ((d->hop & 3) == 0 && (g.center_pad & 3) == 0) ? 1 : 0;
+        plan = p12;
+        edge = gpad + g.rows * plan.pad_len;
+        fz.adj = adj;
+        fz.n_mels = adj ? n_mels : 0;
+        fz.mel_stride = adj ? (n_mels + 63) & ~63 : 0;
+        fz.ring_slots = 0;
+        const int G = 2048 / d->n_fft;
+        const size_t lds = d->n_fft == 1024 ? ring3_multi_lds_bytes<512>(fz.mel_stride) : ring3_multi_lds_bytes<256>(fz.mel_stride);
+        if (lds > 160 * 1024) return TAC_E_UNSUPPORTED;
+        const long long ngroups = (g.rows * (long long)plan.segs_per_row + G - 1) / G;
+        long long blocks = (ngroups + BR_WAVES - 1) / BR_WAVES;
+        if (blocks > device_cu_count()) blocks = device_cu_count();
+        auto go = [&](auto kern) -> int {
+            TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds));
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BR_WAVES * 64), lds, s, g, tb, grad, power, gpad, edge, plan, fz);
+            TAC_HIP(hipGetLastError());
+            return TAC_OK;
+        };
+        auto pick = [&](auto nc_tag, auto h_tag) -> int {
+            constexpr int NCC = decltype(nc_tag)::value, HH = decltype(h_tag)::value;
+            if (adj) return pow2 ? go(melspec_backward_ring3_multi_kernel<NCC, true, HH, true>) : go(melspec_backward_ring3_multi_kernel<NCC, false, HH, true>);
+            return pow2 ? go(melspec_backward_ring3_multi_kernel<NCC, true, HH, false>) : go(melspec_backward_ring3_multi_kernel<NCC, false, HH, false>);
+        };
+        const int Hh = d->hop / (d->n_fft / 16);
+        if (d->n_fft == 1024) {
+            using NCT = std::integral_constant<int, 512>;
+            rc = Hh == 2 ? pick(NCT{}, std::integral_constant<int, 2>{}) : (Hh == 4 ? pick(NCT{}, std::integral_constant<int, 4>{}) : pick(NCT{}, std::integral_constant<int, 8>{}));
+        } else {
+            using NCT = std::integral_constant<int, 256>;
+            rc = Hh == 2 ? pick(NCT{}, std::integral_constant<int, 2>{}) : (Hh == 4 ? pick(NCT{}, std::integral_constant<int, 4>{}) : pick(NCT{}, std::integral_constant<int, 8>{}));
         }
     } else if (adj) {
         // one 8-wave workgroup per CU around one copy of the tables; the ring shrinks to its 16 - H live slots
