@@ -24,6 +24,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_grad -o grad -- 
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_gradf -o gradf -- python tools/prof_driver.py gradf 120 > $out/kt_gradf.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_grad400 -o grad400 -- python tools/prof_driver.py grad400h160 60 > $out/kt_grad400.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_gradspec -o gradspec -- python tools/prof_driver.py gradspec 60 > $out/kt_gradspec.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_grad1024 -o grad1024 -- python tools/prof_driver.py grad1024 60 > $out/kt_grad1024.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_grad512 -o grad512 -- python tools/prof_driver.py grad512 60 > $out/kt_grad512.log 2>&1
 # counters of the backward kernels (separate passes, like the forward kernels')
 k=grad
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_${k}_fetch -o p -- python tools/prof_driver.py $k 3 > /dev/null 2>&1

@@ -141,6 +141,12 @@ for fname, what in (('kernel_stats_backward.csv',
                     ('kernel_stats_backward_spectrogram.csv',
                      '`tools/prof_driver.py gradspec 60`: training step through `Spectrogram(2048, 512, power=2)`: forward kernel, the same '
                      'backward kernel fed with the gradient of the power spectrogram (no filterbank stage), border fold'),
+                    ('kernel_stats_backward_n1024.csv',
+                     '`tools/prof_driver.py grad1024 60`: the 80-band chain at fft_length 1024 / hop 256 trained through the reference '
+                     'idiom: fused forward kernel (two frames per wave), `melspec_backward_ring3_multi_kernel` (two lane groups per wave, '
+                     'each with its own register ring; filterbank adjoint inside), border fold'),
+                    ('kernel_stats_backward_n512.csv',
+                     '`tools/prof_driver.py grad512 60`: the same at fft_length 512 / hop 128 (four frames / lane groups per wave)'),
                     ('kernel_stats_backward_n400.csv',
                      '`tools/prof_driver.py grad400h160 60`: the 80-band speech front end (fft_length 400, hop 160) trained through '
                      'the reference idiom: fused forward kernel, complex stft recomputed by the mixed-radix kernel, the inverse '

@@ -27,7 +27,8 @@ for f in glob.glob(src + '/kt/**/*kernel_stats.csv', recursive=True):
 if os.path.exists(src + '/bench_N1.json'):
     shutil.copy(src + '/bench_N1.json', dst + '/bench_N1.json')
 for sub, name in (('kt_grad', 'kernel_stats_backward.csv'), ('kt_gradf', 'kernel_stats_backward_fused_op.csv'),
-                  ('kt_grad400', 'kernel_stats_backward_n400.csv'), ('kt_gradspec', 'kernel_stats_backward_spectrogram.csv')):
+                  ('kt_grad400', 'kernel_stats_backward_n400.csv'), ('kt_gradspec', 'kernel_stats_backward_spectrogram.csv'),
+                  ('kt_grad1024', 'kernel_stats_backward_n1024.csv'), ('kt_grad512', 'kernel_stats_backward_n512.csv')):
     for f in glob.glob(src + '/' + sub + '/**/*kernel_stats.csv', recursive=True):
         rows = [r for r in csv.reader(open(f)) if r and (r[0] == 'Name' or 'tac::' in r[0])]
         with open(os.path.join(dst, name), 'w') as o:
