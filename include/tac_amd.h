@@ -264,6 +264,12 @@ int tac_melspectrogram_backward_ola_f32(const float* wave, const float* window, 
                                         const float* grad_mel, int32_t n_mels, const void* adjoint_table,
                                         int32_t n_freqs, float power, void* workspace, int64_t workspace_bytes,
                                         float* grad_wave, int64_t grad_row_stride, void* stream);
+/* fft_length 400 (frame gradients through memory, then tac_overlap_add_f32): tac_spectrogram_backward_f32 with the filterbank
+ * adjoint of the mel chain formed inside the kernel from grad_mel (rows, n_frames, n_mels <= 128) and the
+ * tac_filterbank_adjoint_pack table; TAC_E_UNSUPPORTED for other sizes. */
+int tac_melspectrogram_backward_f32(const float* wave, const float* window, const tac_stft_desc* d,
+                                    const float* grad_mel, int32_t n_mels, const void* adjoint_table, int32_t n_freqs,
+                                    float power, float* grad_frames, void* stream);
 int tac_filterbank_adjoint_pack(const float* fb, int32_t n_freqs, int32_t n_mels, void* table,
                                 int32_t* max_nonzeros_host, void* stream);
 int tac_apply_filterbank_adjoint_f32(const float* grad_mel, int64_t rows_times_frames, int32_t n_mels,

@@ -677,8 +677,10 @@ def melspectrogram_backward_fused(grad_mel, wave, window, fb, n_fft, hop, win_le
     exists.  None when the form does not cover the case (fft_length other than 512 / 1024 / 2048, too many bands, a hop the
     register-ring kernels are not instantiated for at 512 / 1024, a bank with
     more than two non-zero weights per bin): the caller then runs the two kernels."""
-    if n_fft not in (512, 1024, 2048) or fb.dim() != 2 or fb.shape[1] > (256 if n_fft == 2048 else 128) or MEL_PATH == 'mfma':
+    if n_fft not in (400, 512, 1024, 2048) or fb.dim() != 2 or fb.shape[1] > (256 if n_fft == 2048 else 128) or MEL_PATH == 'mfma':
         return None
+    if n_fft == 400:
+        return _melspectrogram_backward_fused_n400(grad_mel, wave, window, fb, hop, win_length, center, pad_mode, normalized, power)
     table = _adjoint_table(fb)
     if table is None:
         return None
@@ -704,6 +706,40 @@ def melspectrogram_backward_fused(grad_mel, wave, window, fb, n_fft, hop, win_le
         return None
     _native.check(rc, 'tac_melspectrogram_backward_ola_f32')
     _count('tac_melspectrogram_backward_ola_f32')
+    return out
+
+
+def _melspectrogram_backward_fused_n400(grad_mel, wave, window, fb, hop, win_length, center, pad_mode, normalized, power):
+    """fft_length 400: the mixed-radix backward kernel forms the filterbank adjoint itself (tac_melspectrogram_backward_f32),
+    frame gradients cross memory once, gather overlap-add follows (tac_overlap_add_f32)."""
+    table = _adjoint_table(fb)
+    if table is None:
+        return None
+    g = geometry(wave, 400, hop, win_length, center, pad_mode, normalized, True)
+    if g.desc is None:
+        return None
+    n_freqs, n_mels = fb.shape
+    gm = grad_mel.transpose(-2, -1)                                   # physical frame-major (*, T, M)
+    gm = gm if gm.is_contiguous() else gm.contiguous()
+    if gm.dtype != torch.float32:
+        gm = gm.float()
+    frames = torch.empty((g.rows, g.n_frames, 400), dtype=torch.float32, device=wave.device)
+    out = torch.empty(tuple(wave.shape), dtype=torch.float32, device=wave.device)
+    desc = _native.StftDesc(rows=g.rows, length=g.length, row_stride=g.length, n_fft=400, hop=hop, win_length=win_length,
+                            center=1 if center else 0, pad_mode=_native.PAD_MODES[pad_mode],
+                            normalized=1 if normalized else 0, onesided=1, reserved=0)
+    with _native.on_device(wave.device):
+        rc = _native.lib().tac_melspectrogram_backward_f32(
+            _native.ptr(_rows_of(wave, g)), _native.ptr(window), g.desc, _native.ptr(gm), n_mels, _native.ptr(table), n_freqs,
+            float(power), _native.ptr(frames), _native.stream_ptr(wave.device))
+        if rc == _native.TAC_E_UNSUPPORTED:
+            return None
+        _native.check(rc, 'tac_melspectrogram_backward_f32')
+        _count('tac_melspectrogram_backward_f32')
+        rc = _native.lib().tac_overlap_add_f32(_native.ptr(frames), desc, _native.ptr(out), g.length,
+                                               _native.stream_ptr(wave.device))
+        _native.check(rc, 'tac_overlap_add_f32')
+        _count('tac_overlap_add_f32')
     return out
 
 

@@ -25,7 +25,7 @@
 namespace tac {
 
 int launch_n400_backward(const FrameGeom& g, const float* gspec, const float* gnorm, float power, float* frames,
-                         hipStream_t stream, bool from_wave);     // stft_n400.hip
+                         hipStream_t stream, bool from_wave, const AdjEntry* adj = nullptr, int n_mels = 0);     // stft_n400.hip
 
 constexpr int BW_WAVES = 4;
 
@@ -277,8 +277,6 @@ __device__ __forceinline__ bool ola_direct(const FrameGeom& g, const OlaPlan& pl
     return jlo > pad && jhi < L - 1 - pad;
 }
 
-// per-bin entry of the band-sparse filterbank adjoint (built by fb_adjoint_pack_kernel below)
-struct AdjEntry { float w0, w1; int b0, b1; };
 
 // FUSE: `gnorm` is the gradient of the MEL values, (rows, T, n_mels) frame-major, and the filterbank adjoint
 // (grad_mel . fb^T, two multiply-adds per bin through `adj`) happens here, per frame, out of a 16 KB LDS table: the
@@ -800,7 +798,8 @@ static int launch_stft_backward(const FrameGeom& g, const Tables& tb, const floa
 }
 
 static int stft_backward_entry(const float* spec, const float* gnorm, float power, const float* window, const tac_stft_desc* d,
-                               float* grad_frames, void* stream, bool from_wave = false) {
+                               float* grad_frames, void* stream, bool from_wave = false, const AdjEntry* adj = nullptr,
+                               int n_mels = 0) {
     if (!spec || !grad_frames || !d) return TAC_E_INVALID;
     if (!d->onesided) return TAC_E_UNSUPPORTED;
     FrameGeom g;
@@ -811,7 +810,8 @@ static int stft_backward_entry(const float* spec, const float* gnorm, float powe
     if (rc != TAC_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     if (d->n_fft == 400)                                   // the mixed-radix form (stft_n400.hip)
-        return launch_n400_backward(g, spec, gnorm, power, grad_frames, s, from_wave);
+        return launch_n400_backward(g, spec, gnorm, power, grad_frames, s, from_wave, adj, n_mels);
+    if (adj) return TAC_E_UNSUPPORTED;                     // (the filterbank adjoint inside the frame-gradient kernel: fft_length 400 only)
     Tables tb;
     rc = get_tables(d->n_fft, &tb);
     if (rc != TAC_OK) return rc;
@@ -949,6 +949,16 @@ int tac_spectrogram_backward_f32(const float* wave, const float* window, const t
                                  float power, float* grad_frames, void* stream) {
     if (!grad_norm) return TAC_E_INVALID;
     return tac::stft_backward_entry(wave, grad_norm, power, window, d, grad_frames, stream, true);
+}
+
+int tac_melspectrogram_backward_f32(const float* wave, const float* window, const tac_stft_desc* d, const float* grad_mel,
+                                    int32_t n_mels, const void* adjoint_table, int32_t n_freqs, float power, float* grad_frames,
+                                    void* stream) {
+    if (!grad_mel || !adjoint_table || !d) return TAC_E_INVALID;
+    if (n_freqs != d->n_fft / 2 + 1 || n_mels < 1) return TAC_E_INVALID;
+    if (d->n_fft != 400 || n_mels > 128) return TAC_E_UNSUPPORTED;
+    return tac::stft_backward_entry(wave, grad_mel, power, window, d, grad_frames, stream, true,
+                                    static_cast<const tac::AdjEntry*>(adjoint_table), n_mels);
 }
 
 int tac_filterbank_adjoint_pack(const float* fb, int32_t n_freqs, int32_t n_mels, void* table, int32_t* max_nonzeros_host,

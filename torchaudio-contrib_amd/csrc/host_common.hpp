@@ -32,6 +32,10 @@ __device__ __forceinline__ float spectral_row_value(float norm2, const StftEpilo
 #endif
 
 
+// per-bin entry of the band-sparse filterbank adjoint (built by fb_adjoint_pack_kernel, backward.hip): grad_spec[bin] =
+// w0 grad_mel[b0] + w1 grad_mel[b1]
+struct AdjEntry { float w0, w1; int b0, b1; };
+
 // sample formats of the fused kernels' frame loads (= TAC_SAMPLES_*): float32, int16 PCM, mu-law codes as uint8 / int64
 enum { FMT_F32 = 0, FMT_I16 = 1, FMT_MULAW_U8 = 2, FMT_MULAW_I64 = 3 };
 

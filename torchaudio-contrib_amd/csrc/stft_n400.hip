@@ -438,10 +438,14 @@ int pack_n400(const std::vector<float>& h, int n_freqs, int n_mels, float* wpack
 // A unit is eight consecutive frames of one row: their gradient rows (SRC_NORM: spectrum rows + rows of the gradient of
 // |z|^power, the norm's adjoint formed on the way in) are adjacent in memory and are parked in the wave's staging area,
 // which then takes the unit's eight frame gradients and leaves as 16-byte stores.
-template <int SRC, bool POW2>
+// MELADJ (SRC_WAVE only): `gnorm` is the gradient of the MEL values, (rows, T, n_mels) frame-major, and the filterbank adjoint
+// (two multiply-adds per bin through the 201-entry table `adj`, functional.py:183-184 transposed) is formed where the
+// gradient of |X|^p is needed: the 4 F bytes per frame that fb_adjoint_kernel writes and this kernel reads never exist.
+template <int SRC, bool POW2, bool MELADJ = false>
 __global__ void __launch_bounds__(Q4_WAVES * 64, 2)
 stft_n400_backward_kernel(FrameGeom g, Q4Tables tb, const float* __restrict__ gspec, const float* __restrict__ gnorm,
-                          float power, float* __restrict__ frames) {
+                          float power, float* __restrict__ frames, const AdjEntry* __restrict__ adj = nullptr, int n_mels = 0) {
+    static_assert(!MELADJ || SRC == SRC_WAVE, "the fused adjoint re-transforms the frames");
     constexpr int STAGE = Q4_STAGE;
     constexpr int ROWC = Q4_BINS;                                          // complex per staged gradient row
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -459,6 +463,10 @@ stft_n400_backward_kernel(FrameGeom g, Q4Tables tb, const float* __restrict__ gs
     cf* const winf = tabs + 24 * Q4_ROW;                                   // SRC_WAVE: the forward transform's window pairs (input layout)
     cf* const w400o = tabs + 32 * Q4_ROW;                                  // SRC_WAVE: its R2C twiddles (output layout)
     unsigned* const next_unit = reinterpret_cast<unsigned*>(tabs + 40 * Q4_ROW);
+    AdjEntry* const adj_lds = reinterpret_cast<AdjEntry*>(next_unit + 4);   // MELADJ: the per-bin table, then 8 mel-gradient rows per wave
+    float* const grow = reinterpret_cast<float*>(adj_lds + Q4_BINS) + (w * Q4_G + slot) * 128;
+    if constexpr (MELADJ)
+        for (int i = threadIdx.x; i < Q4_BINS; i += Q4_WAVES * 64) adj_lds[i] = adj[i];
     const float wscale = 0.5f * g.scale;
     for (int i = threadIdx.x; i < 8 * Q4_ROW; i += Q4_WAVES * 64) {
         const int ll = i / Q4_ROW, m = i - ll * Q4_ROW;
@@ -515,10 +523,20 @@ stft_n400_backward_kernel(FrameGeom g, Q4Tables tb, const float* __restrict__ gs
             // (25 contiguous floats per lane) turns it into the gradient spectrum that is parked for step (2)
             const int frame = uframe0 + slot;
             const bool live = frame < T;
-            const float* gn = gnorm + (f0 + (live ? slot : 0)) * ROWC + 25 * k1;
-            float gv[Q4_M], g200 = gn[200 - 25 * k1];
+            float gv[MELADJ ? 16 : Q4_M], g200 = 0.0f;
+            if constexpr (MELADJ) {                                         // the frame's mel-gradient row: 16 values per lane of its eight
+                const float* gn = gnorm + (f0 + (live ? slot : 0)) * n_mels;
 #pragma unroll
-            for (int k = 0; k < Q4_M; ++k) gv[k] = gn[k];
+                for (int q = 0; q < 16; ++q) {
+                    const int b = l + 8 * q;
+                    gv[q] = gn[b < n_mels ? b : n_mels - 1];
+                }
+            } else {
+                const float* gn = gnorm + (f0 + (live ? slot : 0)) * ROWC + 25 * k1;
+                g200 = gn[200 - 25 * k1];
+#pragma unroll
+                for (int k = 0; k < Q4_M; ++k) gv[k] = gn[k];
+            }
             const long long start = (long long)frame * g.hop - g.center_pad;
             const bool ok = g.vec2_ok && live && start >= 0 && start + 400 <= g.length;
             const bool all_ok = __builtin_amdgcn_ballot_w64(ok) == ~0ull;
@@ -571,17 +589,33 @@ stft_n400_backward_kernel(FrameGeom g, Q4Tables tb, const float* __restrict__ gs
                                    __int_as_float(__builtin_amdgcn_ds_bpermute(p0addr, __float_as_int(v[0].y))));
                 const float hscale = 0.5f * g.scale;
                 cf* row = wstage + slot * ROWC;
+                if constexpr (MELADJ) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        if (l + 8 * q < n_mels) grow[l + 8 * q] = live ? gv[q] : 0.0f;
+                    wave_lds_fence();
+                }
+                auto bin_grad = [&](int bin) {                              // (grad_mel . fb^T)[bin]
+                    const AdjEntry en = adj_lds[bin];
+                    return __builtin_fmaf(en.w0, grow[en.b0], en.w1 * grow[en.b1]);
+                };
 #pragma unroll
                 for (int k = 0; k < Q4_M; ++k) {
                     const cf zp = k == 0 ? z0p : q4_dpp<Q4_QUAD_XOR3>(q4_dpp<Q4_HALF_MIRROR>(v[Q4_M - k]));   // lane l ^ 4
                     const cf ev = cadd_conj(v[k], zp), d = csub_conj(v[k], zp);
                     const cf twd = cmul_rot(tw[k], d);
-                    cf gk = norm_pow_grad<POW2>(cscale(cadd(ev, twd), hscale), live ? gv[k] : 0.0f, power);
+                    float gvk;
+                    if constexpr (MELADJ) gvk = bin_grad(25 * k1 + k);
+                    else gvk = live ? gv[k] : 0.0f;
+                    cf gk = norm_pow_grad<POW2>(cscale(cadd(ev, twd), hscale), gvk, power);
                     const int bin = 25 * k1 + k;
                     if (bin == 0) gk = mkc(2.0f * gk.x, 0.0f);                  // H[0] = 2 Re G[0]
                     row[bin] = gk;
                     if (k == 0 && l == 0) {
-                        const cf g2 = norm_pow_grad<POW2>(cscale(csub_then_conj(ev, twd), hscale), live ? g200 : 0.0f, power);
+                        float g2v;
+                        if constexpr (MELADJ) g2v = bin_grad(200);
+                        else g2v = live ? g200 : 0.0f;
+                        const cf g2 = norm_pow_grad<POW2>(cscale(csub_then_conj(ev, twd), hscale), g2v, power);
                         row[200] = mkc(2.0f * g2.x, 0.0f);                      // H[200] = 2 Re G[200]
                     }
                 }
@@ -666,25 +700,29 @@ stft_n400_backward_kernel(FrameGeom g, Q4Tables tb, const float* __restrict__ gs
 
 // tac_stft_backward_f32 / tac_stft_norm_backward_f32 for fft_length 400 (backward.hip's dispatcher calls this)
 int launch_n400_backward(const FrameGeom& g, const float* gspec, const float* gnorm, float power, float* frames,
-                         hipStream_t stream, bool from_wave) {
+                         hipStream_t stream, bool from_wave, const AdjEntry* adj, int n_mels) {
     Q4Tables tb;
     const int rc = q4_tables(&tb);
     if (rc != TAC_OK) return rc;
     if ((!from_wave && (reinterpret_cast<uintptr_t>(gspec) & 7u)) || (reinterpret_cast<uintptr_t>(frames) & 15u)) return TAC_E_UNSUPPORTED;
     const long long units = g.rows * ((g.n_frames + Q4_G - 1) / Q4_G);
     if (units >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
-    const size_t bytes = q4_lds_bytes(0) + (size_t)16 * Q4_ROW * sizeof(cf);
+    if (adj && (!from_wave || n_mels < 1 || n_mels > 128)) return TAC_E_UNSUPPORTED;
+    const size_t bytes = q4_lds_bytes(0) + (size_t)16 * Q4_ROW * sizeof(cf) +
+                         (adj ? (size_t)Q4_BINS * sizeof(AdjEntry) + (size_t)Q4_WAVES * Q4_G * 128 * sizeof(float) : 0);
     long long blocks = (units + Q4_WAVES - 1) / Q4_WAVES;
     const long long cap = (long long)device_cu_count();
     if (blocks > cap) blocks = cap;
-    void (*kern)(FrameGeom, Q4Tables, const float*, const float*, float, float*);
+    void (*kern)(FrameGeom, Q4Tables, const float*, const float*, float, float*, const AdjEntry*, int);
     if (from_wave) {
         if (!gnorm) return TAC_E_INVALID;
-        kern = power == 2.0f ? stft_n400_backward_kernel<SRC_WAVE, true> : stft_n400_backward_kernel<SRC_WAVE, false>;
+        if (adj) kern = power == 2.0f ? stft_n400_backward_kernel<SRC_WAVE, true, true> : stft_n400_backward_kernel<SRC_WAVE, false, true>;
+        else kern = power == 2.0f ? stft_n400_backward_kernel<SRC_WAVE, true> : stft_n400_backward_kernel<SRC_WAVE, false>;
     } else if (!gnorm) kern = stft_n400_backward_kernel<SRC_GRAD, false>;
     else kern = power == 2.0f ? stft_n400_backward_kernel<SRC_NORM, true> : stft_n400_backward_kernel<SRC_NORM, false>;
     if (bytes > 64 * 1024) TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes));
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Q4_WAVES * 64), bytes, stream, g, tb, gspec, gnorm, power, frames);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Q4_WAVES * 64), bytes, stream, g, tb, gspec, gnorm, power, frames, adj,
+                       n_mels);
     TAC_HIP(hipGetLastError());
     return TAC_OK;
 }
