@@ -288,53 +288,56 @@ def run(a):
             break
 
     if rank == 0 and not a.no_stages and a.config == 'cfg2':
-        # secondary stages named by north_star, each one kernel: complex STFT and power spectrogram — on the rotating
-        # batches, and on one re-read batch beside it
-        spec = tac.Spectrogram(N_FFT, HOP, power=2.).to(dev)
-        f_bins = N_FFT // 2 + 1
         stages = {}
-        for name, make, per_frame in (('stft_complex', lambda t: tac.stft(t, N_FFT, HOP), 4 * HOP + 8 * f_bins),
-                                      ('spectrogram_power', spec, 4 * HOP + 4 * f_bins)):
-            fn = rotating(make, xs)
-            spin(fn, 0.3)                                    # same spin-up as the headline loop (clocks, TLB, allocator)
+        try:            # secondary figures: a failure here must not cost the headline line
+            # secondary stages named by north_star, each one kernel: complex STFT and power spectrogram — on the rotating
+            # batches, and on one re-read batch beside it
+            spec = tac.Spectrogram(N_FFT, HOP, power=2.).to(dev)
+            f_bins = N_FFT // 2 + 1
+            for name, make, per_frame in (('stft_complex', lambda t: tac.stft(t, N_FFT, HOP), 4 * HOP + 8 * f_bins),
+                                          ('spectrogram_power', spec, 4 * HOP + 4 * f_bins)):
+                fn = rotating(make, xs)
+                spin(fn, 0.3)                                    # same spin-up as the headline loop (clocks, TLB, allocator)
+                ms, med = event_ms(fn, 50)
+                ms1, _ = event_ms(lambda: make(x), 50)
+                gbs = BATCH * CHANNELS * frames * per_frame / (ms * 1e-3) / 1e9
+                stages[name] = {'kernel_ms_mean': ms, 'kernel_ms_median': med, 'alg_bytes_per_frame': per_frame,
+                                'achieved_GBs': gbs, 'frac_of_hbm_peak': gbs / HBM_PEAK_GBS,
+                                'single_buffer_kernel_ms_mean': ms1}
+            # the filterbank stage as a dense fp32 MFMA GEMM (a random 1025 x 128 bank is not band-sparse, so
+            # apply_filterbank takes the GEMM kernel): executed flops = 2*F*M per frame against the 157.3 TFLOP/s f32 MFMA peak
+            fb_dense = torch.rand(f_bins, N_MELS, device=dev, generator=gen)
+            p_spec = spec(x)
+            fn = lambda: tac.apply_filterbank(p_spec, fb_dense)
+            spin(fn, 0.3)
             ms, med = event_ms(fn, 50)
-            ms1, _ = event_ms(lambda: make(x), 50)
-            gbs = BATCH * CHANNELS * frames * per_frame / (ms * 1e-3) / 1e9
-            stages[name] = {'kernel_ms_mean': ms, 'kernel_ms_median': med, 'alg_bytes_per_frame': per_frame,
-                            'achieved_GBs': gbs, 'frac_of_hbm_peak': gbs / HBM_PEAK_GBS,
-                            'single_buffer_kernel_ms_mean': ms1}
-        # the filterbank stage as a dense fp32 MFMA GEMM (a random 1025 x 128 bank is not band-sparse, so
-        # apply_filterbank takes the GEMM kernel): executed flops = 2*F*M per frame against the 157.3 TFLOP/s f32 MFMA peak
-        fb_dense = torch.rand(f_bins, N_MELS, device=dev, generator=gen)
-        p_spec = spec(x)
-        fn = lambda: tac.apply_filterbank(p_spec, fb_dense)
-        spin(fn, 0.3)
-        ms, med = event_ms(fn, 50)
-        flops = 2.0 * f_bins * N_MELS * BATCH * CHANNELS * frames
-        stages['filterbank_mfma_dense'] = {'kernel_ms_mean': ms, 'kernel_ms_median': med, 'flops': flops,
-                                           'achieved_TFLOPs': flops / (ms * 1e-3) / 1e12,
-                                           'frac_of_f32_mfma_peak': flops / (ms * 1e-3) / 1e12 / 157.3}
-        del p_spec
-        # training step of the same chain (waveform requires grad): fused forward + dB op, then the HIP gradient kernels
-        # (dB adjoint, ONE backward kernel: filterbank adjoint + frame re-transform + norm adjoint + inverse FFT + overlap-add,
-        # border fold); wall time per step between two events, gradient buffer released each step
-        try:
-            xg = x.clone().requires_grad_(True)
-            ones = torch.ones((BATCH, CHANNELS, N_MELS, frames), device=dev)
+            flops = 2.0 * f_bins * N_MELS * BATCH * CHANNELS * frames
+            stages['filterbank_mfma_dense'] = {'kernel_ms_mean': ms, 'kernel_ms_median': med, 'flops': flops,
+                                               'achieved_TFLOPs': flops / (ms * 1e-3) / 1e12,
+                                               'frac_of_f32_mfma_peak': flops / (ms * 1e-3) / 1e12 / 157.3}
+            del p_spec
+            # training step of the same chain (waveform requires grad): fused forward + dB op, then the HIP gradient kernels
+            # (dB adjoint, ONE backward kernel: filterbank adjoint + frame re-transform + norm adjoint + inverse FFT + overlap-add,
+            # border fold); wall time per step between two events, gradient buffer released each step
+            try:
+                xg = x.clone().requires_grad_(True)
+                ones = torch.ones((BATCH, CHANNELS, N_MELS, frames), device=dev)
 
-            def train():
-                xg.grad = None
-                y = model(xg)
-                y.backward(ones)
-                return y
-            spin(train, 0.3)
-            ms, med = event_ms(train, 30)
-            stages['train_step_fwd_bwd'] = {'ms_mean': ms, 'ms_median': med,
-                                            'note': 'forward + backward of Sequential(*Melspectrogram, AmplitudeToDb) at cfg-2, '
-                                                    'event pair around each step (kernels + launch gaps of the autograd graph)'}
-            del xg, ones
-        except Exception as exc:            # noqa: BLE001 — a secondary figure
-            stages['train_step_fwd_bwd'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
+                def train():
+                    xg.grad = None
+                    y = model(xg)
+                    y.backward(ones)
+                    return y
+                spin(train, 0.3)
+                ms, med = event_ms(train, 30)
+                stages['train_step_fwd_bwd'] = {'ms_mean': ms, 'ms_median': med,
+                                                'note': 'forward + backward of Sequential(*Melspectrogram, AmplitudeToDb) at cfg-2, '
+                                                        'event pair around each step (kernels + launch gaps of the autograd graph)'}
+                del xg, ones
+            except Exception as exc:            # noqa: BLE001 — a secondary figure
+                stages['train_step_fwd_bwd'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
+        except Exception as exc:            # noqa: BLE001 — reported in the line, not swallowed
+            stages['error'] = '%s: %s' % (type(exc).__name__, exc)
         result['stages'] = stages
 
     def gather_leg(mdl, inputs, rows_total, frames_step, steps):
