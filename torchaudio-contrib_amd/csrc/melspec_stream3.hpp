@@ -44,6 +44,12 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     constexpr int XA_BYTES = (F::PADDED * sizeof(cf) + 15) & ~15;
     static_assert((int)(F::PADDED * sizeof(cf)) >= (int)(C::PROW * 4), "the power row fits the exchange area");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+#ifndef TAC_S3_CYCLES
+#define TAC_S3_CYCLES 0
+#endif
+#if TAC_S3_CYCLES
+    const unsigned long long wall_entry = wall_clock64();
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -95,29 +101,38 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
 #ifndef TAC_S3_EARLY_FIRST
 #define TAC_S3_EARLY_FIRST 1
 #endif
-#if TAC_S3_EARLY_FIRST
-    // the wave's first frame is requested before the tables are built: its HBM latency runs behind the workgroup's set-up
-    if (nloc > 0) request(w);
-#endif
+    // ---- tables into LDS.  Every global load of the set-up is issued before the first LDS store (loads of one loop iteration
+    //      used to wait for the previous iteration's: a dozen serialized L2 round trips, 4.3 us of a 110 us kernel; now ~one)
+    typedef float pf4 __attribute__((ext_vector_type(4)));
     float* const wlds = reinterpret_cast<float*>(smem_raw + (size_t)WAVES * XA_BYTES);
     float* const twlds = wlds + ((m.wtot + 3) & ~3);
-    for (int i = tid; i < m.wtot; i += WAVES * 64) wlds[i] = m.wl[i];
-    if (tid < 16 * 16) {
-        const int js = tid >> 4, q = tid & 15;
-        const cf wv = q ? tb.w_nc[js * q * (NC / 256)] : mkc(1.0f, 0.0f);
-        twlds[js * ST_TW_STRIDE + 2 * (q ? q - 1 : 15)] = wv.x;
-        twlds[js * ST_TW_STRIDE + 2 * (q ? q - 1 : 15) + 1] = wv.y;
-    }
     unsigned* const next_frame = reinterpret_cast<unsigned*>(twlds + ST_TW_BYTES / 4);
-    if (tid == 0) *next_frame = WAVES;
-    // the eight R2C twiddles of a lane (re-read every frame: the register budget does not hold them), as [read u][lane] 16-byte
-    // pairs: every ds_read_b128 of the wave is one contiguous kilobyte
     cf* const ptwl = reinterpret_cast<cf*>(next_frame + 4);
-    for (int idx = tid; idx < 64 * F::NPAIR; idx += WAVES * 64) {
-        const int tt = idx / F::NPAIR, p = idx - tt * F::NPAIR;
-        ptwl[((p >> 1) * 64 + tt) * 2 + (p & 1)] = tb.w_n[tt + p * F::LPF];
+    cf* const winl = ptwl + 64 * F::NPAIR;
+    // (2X -> scale * X once, in the window; int16 PCM samples enter as integers: their 2^-15 goes in as well)
+    const float half = 0.5f * g.scale * (FMT == FMT_I16 ? (1.0f / 32768.0f) : 1.0f);
+    constexpr int WCH = 4;                                 // 16-byte weight chunks per thread and round
+    const int n4 = (m.wtot + 3) >> 2;                      // (the pack is zero-padded to whole 16-byte chunks)
+    pf4 wreg[WCH];
+#pragma unroll
+    for (int u = 0; u < WCH; ++u) {
+        const int c = tid + u * WAVES * 64;
+        wreg[u] = reinterpret_cast<const pf4*>(m.wl)[c < n4 ? c : n4 - 1];
     }
-
+    const int js1 = (tid >> 4) & 15, q1 = tid & 15;
+    const cf tw1v = tb.w_nc[js1 * q1 * (NC / 256)];
+    constexpr int NPT = (64 * F::NPAIR + WAVES * 64 - 1) / (WAVES * 64), NWT = (64 * E + WAVES * 64 - 1) / (WAVES * 64);
+    cf ptv[NPT], wnv[NWT];
+#pragma unroll
+    for (int u = 0; u < NPT; ++u) {
+        const int idx = tid + u * WAVES * 64, ic = idx < 64 * F::NPAIR ? idx : 0;
+        ptv[u] = tb.w_n[ic / F::NPAIR + (ic % F::NPAIR) * F::LPF];
+    }
+#pragma unroll
+    for (int u = 0; u < NWT; ++u) {
+        const int idx = tid + u * WAVES * 64, ic = idx < 64 * E ? idx : 0;
+        wnv[u] = window_pair(g, ic / E + (ic % E) * F::LPF);
+    }
     cf tw2[3];
     {
         cf all[F::NTW];
@@ -125,30 +140,68 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) tw2[q] = all[twiddles_before(NC, E, 2) + q];
     }
+    int lo_s[ST_MAX_SLOTS];
+#pragma unroll
+    for (int s = 0; s < ST_MAX_SLOTS; ++s) lo_s[s] = s < m.nslot ? m.lo[s * 64 + lane] : 0;
+    float lutv = 0.0f;
+    if (FMT >= FMT_MULAW_U8) lutv = m.lut[tid & 255];
+    __builtin_amdgcn_sched_barrier(0);
+#if TAC_S3_CYCLES
+    const unsigned long long wall_a = wall_clock64();                  // loads issued
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                // (debug) vmcnt(0)
+    const unsigned long long wall_b = wall_clock64();                  // loads landed
+#endif
+#if TAC_S3_EARLY_FIRST
+    // the wave's first frame is requested BEHIND the table loads (one in-order vmcnt: the tables' wait then leaves these sixteen
+    // loads outstanding) and ahead of the LDS stores and the barrier: its HBM latency runs behind the rest of the set-up
+    if (nloc > 0) request(w);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    // ---- stores
+#pragma unroll
+    for (int u = 0; u < WCH; ++u) {
+        const int c = tid + u * WAVES * 64;
+        if (c < n4) reinterpret_cast<pf4*>(wlds)[c] = wreg[u];
+    }
+    for (int c = tid + WCH * WAVES * 64; c < n4; c += WAVES * 64)          // banks with more than 48 KB of weights: the rest, plainly
+        reinterpret_cast<pf4*>(wlds)[c] = reinterpret_cast<const pf4*>(m.wl)[c];
+    if (tid < 16 * 16) {
+        const cf wv = q1 ? tw1v : mkc(1.0f, 0.0f);
+        twlds[js1 * ST_TW_STRIDE + 2 * (q1 ? q1 - 1 : 15)] = wv.x;
+        twlds[js1 * ST_TW_STRIDE + 2 * (q1 ? q1 - 1 : 15) + 1] = wv.y;
+    }
+    if (tid == 0) *next_frame = WAVES;
+    // the eight R2C twiddles of a lane (re-read every frame: the register budget does not hold them) and the window pairs of its
+    // sixteen first-pass elements (scale folded in), as [read u][lane] 16-byte pairs: every ds_read_b128 of the wave is one
+    // contiguous kilobyte
+#pragma unroll
+    for (int u = 0; u < NPT; ++u) {
+        const int idx = tid + u * WAVES * 64;
+        const int tt = idx / F::NPAIR, p = idx - tt * F::NPAIR;
+        if (idx < 64 * F::NPAIR) ptwl[((p >> 1) * 64 + tt) * 2 + (p & 1)] = ptv[u];
+    }
+#pragma unroll
+    for (int u = 0; u < NWT; ++u) {
+        const int idx = tid + u * WAVES * 64;
+        const int tt = idx / E, q = idx - tt * E;
+        if (idx < 64 * E) winl[((q >> 1) * 64 + tt) * 2 + (q & 1)] = cscale(wnv[u], half);
+    }
 #if TAC_S3_PTW_REGS
     cf ptw_regs[F::NPAIR];
 #pragma unroll
     for (int p = 0; p < F::NPAIR; ++p) ptw_regs[p] = tb.w_n[t + p * F::LPF];
 #endif
-    // the window pairs of a lane's sixteen first-pass elements, same [read u][lane] layout, scale folded in
-    // (2X -> scale * X once, in the window; int16 PCM samples enter as integers: their 2^-15 goes in as well)
-    const float half = 0.5f * g.scale * (FMT == FMT_I16 ? (1.0f / 32768.0f) : 1.0f);
-    cf* const winl = ptwl + 64 * F::NPAIR;
-    for (int idx = tid; idx < 64 * E; idx += WAVES * 64) {
-        const int tt = idx / E, q = idx - tt * E;
-        winl[((q >> 1) * 64 + tt) * 2 + (q & 1)] = cscale(window_pair(g, tt + q * F::LPF), half);
-    }
     float* const lutlds = reinterpret_cast<float*>(winl + 64 * E);                 // mu-law decode table (coded inputs)
-    if (FMT >= FMT_MULAW_U8 && tid < 256) lutlds[tid] = m.lut[tid];
+    if (FMT >= FMT_MULAW_U8 && tid < 256) lutlds[tid] = lutv;
 #if TAC_S3_WIN_REGS
     cf win_regs[E];
     load_window_regs<F>(win_regs, g, t);
 #pragma unroll
     for (int e = 0; e < E; ++e) win_regs[e] = cscale(win_regs[e], half);
 #endif
-    int lo_s[ST_MAX_SLOTS];
-#pragma unroll
-    for (int s = 0; s < ST_MAX_SLOTS; ++s) lo_s[s] = s < m.nslot ? m.lo[s * 64 + lane] : 0;
+#if TAC_S3_CYCLES
+    const unsigned long long wall_c = wall_clock64();                  // stores issued
+#endif
     __syncthreads();
     if (nloc <= 0) return;
 
@@ -191,6 +244,12 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     int i = w;
 #if !TAC_S3_EARLY_FIRST
     request(i);
+#endif
+#ifndef TAC_S3_CYCLES
+#define TAC_S3_CYCLES 0
+#endif
+#if TAC_S3_CYCLES
+    const unsigned long long cyc0 = __builtin_readcyclecounter(), wall0 = wall_clock64();
 #endif
     while (i < nloc) {
         // the next frame of this wave (the counter's answer travels with the stage's other LDS traffic)
@@ -397,6 +456,21 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         }
         wave_lds_fence();                                                   // the row is consumed: the area takes the next frame
     }
+#if TAC_S3_CYCLES
+    // debug build (tools/stream3_cycles.py): shader cycles and 100 MHz ticks of every wave's frame loop, over the first outputs
+    __syncthreads();
+    if (lane == 0) {
+        m.out[((long long)blockIdx.x * WAVES + w) * 2] = (float)(__builtin_readcyclecounter() - cyc0);
+        m.out[((long long)blockIdx.x * WAVES + w) * 2 + 1] = (float)(wall_clock64() - wall0);
+        if (w == 0) m.out[(long long)gridDim.x * WAVES * 2 + blockIdx.x] = (float)(wall0 - wall_entry);   // set-up: entry -> loop
+        if (w == 0 && blockIdx.x == 7) {
+            m.out[(long long)gridDim.x * WAVES * 2 + gridDim.x + 0] = (float)(wall_a - wall_entry);
+            m.out[(long long)gridDim.x * WAVES * 2 + gridDim.x + 1] = (float)(wall_b - wall_a);
+            m.out[(long long)gridDim.x * WAVES * 2 + gridDim.x + 2] = (float)(wall_c - wall_b);
+            m.out[(long long)gridDim.x * WAVES * 2 + gridDim.x + 3] = (float)(wall0 - wall_c);
+        }
+    }
+#endif
 }
 
 }  // namespace tac
