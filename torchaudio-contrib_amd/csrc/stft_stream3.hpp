@@ -217,7 +217,14 @@ stft_stream3_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
             }
             __builtin_amdgcn_sched_barrier(0);            // all LDS reads in flight before the first store issues
 #pragma unroll
+#ifndef TAC_S3_NT
+#define TAC_S3_NT 1
+#endif
+#if TAC_S3_NT
             for (int u = 0; u < NST; ++u) __builtin_nontemporal_store(b[u], &g4[c[u]]);
+#else
+            for (int u = 0; u < NST; ++u) g4[c[u]] = b[u];
+#endif
         }
         {
             const int r = LENF - npre - 4 * nchunks;
