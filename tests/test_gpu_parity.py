@@ -231,6 +231,29 @@ def test_non_power_of_two_and_large_n_fft(tac, golden):
         tac.set_strict(True)
 
 
+def test_rows_shorter_than_a_frame(tac):
+    """Signals shorter than fft_length (centred: every frame touches the padding, the clamped whole-frame requests of the
+    persistent kernels have nothing to read): complex stft, power dB and fused mel dB of every kernel family against the CPU
+    route of the same modules (torch's CPU operators in the reference's operator order)."""
+    torch.manual_seed(0)
+    for n in (64, 256, 400, 512, 1024, 2048, 4096):
+        for length in (n // 2 + 3, n - 1, n - 7):
+            for rows in ((1, 1), (3, 2)):
+                x = torch.rand(*rows, length) * 2 - 1
+                z_want = tac.STFT(n, n // 4)(x)
+                z = tac.realize(tac.STFT(n, n // 4).cuda()(x.cuda())).cpu()
+                assert float((z - z_want).abs().max()) < 2e-6 * max(1.0, float(z_want.abs().max())) * 50, (n, length, rows)
+                chains = [torch.nn.Sequential(*tac.Spectrogram(n, n // 4, power=2.), tac.AmplitudeToDb())]
+                if n >= 256:
+                    chains.append(torch.nn.Sequential(*tac.Melspectrogram(num_mels=40, sample_rate=16000, fft_length=n, hop_length=n // 4),
+                                                      tac.AmplitudeToDb()))
+                for m in chains:
+                    want = tac.realize(m(x))
+                    got = tac.realize(m.cuda()(x.cuda())).cpu()
+                    big = want > want.max() - 50.0                       # dB values within 50 dB of the peak (see the note in the test below)
+                    assert float((got - want)[big].abs().max()) < DB_ABS, (n, length, rows, len(m))
+
+
 def test_tiny_inputs_every_kernel_family(tac):
     """One frame, a handful of frames, fewer frames than waves, a single row: the persistent kernels' frame counters,
     clamped duplicate frames and sample-by-sample edge paths at their smallest sizes (every FFT size class; complex,

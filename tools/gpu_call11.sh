@@ -1,8 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for rep in 1 2; do
-for rot in 1 4; do
-  export TAC_ROTATE=$rot
-  unset TAC_AMD_LIB; python tools/time_steady.py stft spec 2>&1 | grep median | sed "s/^/nt  rot$rot /"
-  export TAC_AMD_LIB=$PWD/gpurun_variants/libtac_nont.so; python tools/time_steady.py stft spec 2>&1 | grep median | sed "s/^/plain rot$rot /"
-done
+for env in "TAC_STREAM2=1" "TAC_S3_WAVES=15" "TAC_STFT_PIPE2=1" "TAC_SMALL2=1" "TAC_BWD_LDS_RING=1" "TAC_STFT_S3_WAVES=12" "TAC_SM3_WAVES=12"; do
+  echo "== $env"
+  env $env timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -2
 done

@@ -357,6 +357,10 @@ def melspectrogram(wave, window, fb, n_fft, hop, win_length, center, pad_mode, n
                 _native.ptr(src), _native.ptr(window), g.desc, float(power), _native.ptr(wpack), _native.ptr(desc),
                 ctypes.cast(info, ctypes.c_void_p), n_mels, 1 if db else 0, float(ref), float(amin),
                 _native.ptr(out), _native.stream_ptr(wave.device))
+        if rc == _native.TAC_E_UNSUPPORTED:         # a geometry the fused kernel of this size declines: the two-kernel chain
+            spec = spectrogram(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided, power,
+                               False, 1.0, 1e-7)
+            return apply_filterbank(spec, fb, db=(ref, amin) if db else None)
         _native.check(rc, 'tac_melspec_sparse_f32')
         _count('tac_melspec_sparse_f32')
         return out.transpose(-2, -1)

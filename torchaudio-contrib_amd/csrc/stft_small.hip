@@ -224,7 +224,7 @@ static int launch_small(const FrameGeom& g, const Tables& tb, const StftEpilogue
     long long blocks = (units + SM_WAVES - 1) / SM_WAVES;
     const long long cap = (long long)device_cu_count();
     if (blocks > cap) blocks = cap;
-    if (small3_waves() && g.length >= 2 * NC) {
+    if (small3_waves()) {
         // three / four waves per SIMD (stft_small3.hpp); TAC_SMALL2=1 keeps the two-wave kernel below
         auto go = [&](auto k3, int W) -> int {
             const size_t b3 = small3_lds_bytes<NC>(W);
@@ -270,7 +270,7 @@ static int launch_small_mel(const FrameGeom& g, const Tables& tb, const LaneMel&
     long long blocks = (units + SM_WAVES - 1) / SM_WAVES;
     const long long cap = (long long)device_cu_count();
     if (blocks > cap) blocks = cap;
-    if (small3_waves() && g.length >= 2 * NC) {
+    if (small3_waves()) {
         const size_t b3 = small3_lds_bytes<NC>(12) + lm_lds_bytes(F::LPF, mel.wtot);
         if (b3 <= 160 * 1024) {
             auto k3 = stft_small3_kernel<NC, MODE, true, S, 12>;
@@ -302,7 +302,7 @@ static int launch_small_mel_coded(FrameGeom g, const Tables& tb, const LaneMel& 
                                   const float* lut) {
     using F = WaveFft<NC, 16>;
     const long long units = g.rows * ((g.n_frames + F::G - 1) / F::G);
-    if (units >= 0x7fffffffLL || !small3_waves() || g.length < 2 * NC) return TAC_E_UNSUPPORTED;
+    if (units >= 0x7fffffffLL || !small3_waves()) return TAC_E_UNSUPPORTED;
     const size_t b3 = small3_lds_bytes<NC>(12) + lm_lds_bytes(F::LPF, mel.wtot) + 1024;
     if (b3 > 160 * 1024) return TAC_E_UNSUPPORTED;
     {                                                                      // sample pairs fetched as one access of the format
@@ -374,6 +374,7 @@ int launch_small_mel_entry(int n_fft, const FrameGeom& g, const Tables& tb, floa
 int pack_small(int n_fft, const std::vector<float>& h, int n_freqs, int n_mels, float* wpack, int wpack_cap, int32_t* desc,
                int desc_cap, int32_t* info_host, hipStream_t stream) {
     if ((n_fft != 256 && n_fft != 512 && n_fft != 1024) || n_freqs != n_fft / 2 + 1) return TAC_E_UNSUPPORTED;
+    if (n_fft == 256 && !small3_waves()) return TAC_E_UNSUPPORTED;        // (TAC_SMALL2=1: the three-phase kernel's layout)
     const int lanes = n_fft / 32;
     const size_t base = n_fft == 256 ? small3_lds_bytes<128>(12) : (n_fft == 512 ? small_lds_bytes<256>() : small_lds_bytes<512>());
     return pack_lane_mel(h, n_freqs, n_mels, lanes, sm_mel_pitch(n_fft / 2), 2, SM_FLY, LM_MAX_STEPS, base, wpack, wpack_cap, desc, desc_cap,

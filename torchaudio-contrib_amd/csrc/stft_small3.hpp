@@ -111,6 +111,7 @@ stft_small3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, LaneMel mel, const v
         const long long start = (long long)frame * g.hop - g.center_pad;
         const bool ok = g.vec2_ok && frame < T && start >= 0 && start + F::N <= g.length;
         fast = __builtin_amdgcn_ballot_w64(ok) == ~0ull;
+        if (g.length < F::N) return;                                        // rows shorter than a frame: every unit gathers
         long long cs = start < 0 ? 0 : start;
         cs = cs + F::N <= g.length ? cs : g.length - F::N;
         const long long off = (long long)urow * g.row_stride + cs;           // in samples
