@@ -252,6 +252,19 @@ def test_rows_shorter_than_a_frame(tac):
                     got = tac.realize(m.cuda()(x.cuda())).cpu()
                     big = want > want.max() - 50.0                       # dB values within 50 dB of the peak (see the note in the test below)
                     assert float((got - want)[big].abs().max()) < DB_ABS, (n, length, rows, len(m))
+                if n < 256 or length != n - 7:
+                    continue
+                # ... and their gradients (the backward kernels re-read the frames with the same clamped requests)
+                for mk in (lambda: tac.Spectrogram(n, n // 4, power=2.),
+                           lambda: tac.Melspectrogram(num_mels=40, sample_rate=16000, fft_length=n, hop_length=n // 4)):
+                    m = mk()
+                    xc = x.clone().requires_grad_(True)
+                    y = tac.realize(m(xc))
+                    wgt = torch.rand_like(y)
+                    (gw,) = torch.autograd.grad((y * wgt).sum(), xc)
+                    xg = x.cuda().requires_grad_(True)
+                    (gg,) = torch.autograd.grad((tac.realize(m.cuda()(xg)) * wgt.cuda()).sum(), xg)
+                    assert float((gg.cpu() - gw).abs().max() / gw.abs().max()) < 1e-3, (n, length, rows)
 
 
 def test_tiny_inputs_every_kernel_family(tac):

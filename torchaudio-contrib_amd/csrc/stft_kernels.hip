@@ -483,7 +483,8 @@ static int launch_pipe(const FrameGeom& g, const Tables& tb, const StftEpilogue&
 template <int NC, int E, int PMODE>
 static int launch_pipe3(const FrameGeom& g, const Tables& tb, const StftEpilogue& ep, long long groups, hipStream_t stream) {
     static const bool two_wave = [] { const char* e = getenv("TAC_STFT_PIPE2"); return e && e[0] == '1'; }();
-    if (two_wave) return launch_pipe<NC, E, PMODE>(g, tb, ep, groups, stream);
+    // (rows shorter than a frame: the kernel's clamped whole-frame requests would have nothing to read)
+    if (two_wave || g.length < 2 * NC) return launch_pipe<NC, E, PMODE>(g, tb, ep, groups, stream);
     // real rows: four waves per SIMD (0.134 -> 0.115 ms at cfg-2, inputs in the Infinity Cache); complex rows are bound by their
     // 658 MB of stores either way and measure best with three (profiles/r03/ab_stream3.txt)
     static const int waves_env = [] { const char* e = getenv("TAC_STFT_S3_WAVES"); return e ? atoi(e) : 0; }();
