@@ -1,5 +1,6 @@
 cd $GRAFT_REPO_ROOT
-for env in "TAC_STREAM2=1" "TAC_S3_WAVES=15" "TAC_STFT_PIPE2=1" "TAC_SMALL2=1" "TAC_BWD_LDS_RING=1" "TAC_STFT_S3_WAVES=12" "TAC_SM3_WAVES=12"; do
-  echo "== $env"
-  env $env timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -2
+timeout 900 python -m pytest tests -m gpu -x -q -k "mel or golden or coded or g9 or fuzz or cfg2 or cfg3" 2>&1 | tail -2
+for rep in 1 2 3; do
+  unset TAC_AMD_LIB; python tools/time_steady.py mel 2>&1 | grep median | sed "s/^/rotated /"
+  export TAC_AMD_LIB=$PWD/gpurun_variants/libtac_norot.so; python tools/time_steady.py mel 2>&1 | grep median | sed "s/^/in-order /"
 done

@@ -62,12 +62,19 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     const unsigned T = (unsigned)g.n_frames;
     const int t = lane;
 
+#ifndef TAC_S3_ROTATE_DEAL
+#define TAC_S3_ROTATE_DEAL 1
+#endif
+    // the i-th frame dealt is frame (i + nloc / 2) mod nloc of the chunk: a chunk is often a whole row, whose first and last frames
+    // touch the padding and take the slower gather path — they are dealt in the middle of the run, not as its tail
+    const int deal_shift = TAC_S3_ROTATE_DEAL ? (nloc >> 1) : 0;
+    auto place = [&](int i) { const int j = i + deal_shift; return j < nloc ? j : j - nloc; };
     cf v[E];
     int mode = 0, row = 0;
     long long fr = 0;
     auto request = [&](int i) {
         i = i < nloc ? i : nloc - 1;
-        const unsigned gf = (unsigned)(begin + i);
+        const unsigned gf = (unsigned)(begin + place(i));
         const unsigned r = gf / T;
         row = (int)r;
         fr = (long long)(gf - r * T);
@@ -409,13 +416,13 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
                 v0 = fast_db ? amp_to_db_fast(v0, m.amin, ten_log10_ref) : amp_to_db(v0, m.amin, m.log10_ref);
                 v1 = fast_db ? amp_to_db_fast(v1, m.amin, ten_log10_ref) : amp_to_db(v1, m.amin, m.log10_ref);
             }
-            float* orow = m.out + (begin + ci) * (long long)m.n_mels + lane;
+            float* orow = m.out + (begin + place(ci)) * (long long)m.n_mels + lane;
             orow[0] = v0;
             orow[64] = v1;
         } else {
             const int ci = cur < nloc ? cur : nloc - 1;
             const f4* wp = reinterpret_cast<const f4*>(wlds) + lane;
-            float* orow = m.out + (begin + ci) * (long long)m.n_mels + lane;
+            float* orow = m.out + (begin + place(ci)) * (long long)m.n_mels + lane;
 #pragma unroll
             for (int s = 0; s < ST_MAX_SLOTS; ++s) {
                 if (s < m.nslot) {
