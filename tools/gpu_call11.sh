@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT
-export TAC_AMD_LIB=$PWD/gpurun_variants/libtac_gmask.so
-timeout 600 python -m pytest tests -m gpu -x -q -k "g2 or golden or cfg2" 2>&1 | tail -2
-for rep in 1 2 3; do
-  unset TAC_AMD_LIB; python tools/time_steady.py mel 2>&1 | grep median | sed "s/^/plain  /"
-  export TAC_AMD_LIB=$PWD/gpurun_variants/libtac_gmask.so; python tools/time_steady.py mel 2>&1 | grep median | sed "s/^/masked /"
+for rep in 1 2; do
+for v in default q4fly4 q4fly8; do
+  if [ "$v" = default ]; then unset TAC_AMD_LIB; else export TAC_AMD_LIB=$PWD/gpurun_variants/libtac_$v.so; fi
+  python tools/time_steady.py mel400 2>&1 | grep median | sed "s/^/$v /"
+done
 done
