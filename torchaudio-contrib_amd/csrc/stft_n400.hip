@@ -48,7 +48,10 @@ struct Q4Tables {
 // The fused Melspectrogram form (MEL): the unit's |X|^p rows stay in LDS (204-float pitch) and are contracted with a
 // band-sparse filterbank there by the frame's eight lanes (mel_lanes.hpp); the mel rows are staged behind them.
 constexpr int Q4_MEL_PITCH = 204;
-constexpr int Q4_FLY = 16;                                            // contraction steps in flight (128 registers)
+#ifndef TAC_Q4_FLY
+#define TAC_Q4_FLY 8
+#endif
+constexpr int Q4_FLY = TAC_Q4_FLY;       // contraction steps in flight (64 registers: the twelve-wave kernel has the next unit's 50 in flight too)
 constexpr int Q4_MEL_OFF = Q4_G * Q4_MEL_PITCH + 8;
 static_assert(Q4_MEL_OFF + 4 + Q4_G * LM_MAX_MELS <= Q4_STAGE, "mel rows fit the staging area");
 
@@ -332,6 +335,10 @@ stft_n400_kernel(FrameGeom g, Q4Tables tb, StftEpilogue ep, LaneMel mel) {
     }
 }
 
+}  // namespace tac
+#include "stft_n400_s3.hpp"
+namespace tac {
+
 // dynamic LDS of the kernel: staging areas, the three tables, the unit counter (the fused form adds lm_lds_bytes)
 static size_t q4_lds_bytes(int) {
     return (size_t)Q4_WAVES * Q4_STAGE * sizeof(float) + (size_t)24 * Q4_ROW * sizeof(cf) + 16;
@@ -369,6 +376,11 @@ static int q4_tables(Q4Tables* out) {
     return TAC_OK;
 }
 
+static bool q4_three_waves() {
+    static const bool on = [] { const char* e = getenv("TAC_N400_TWO"); return !(e && e[0] == '1'); }();
+    return on;
+}
+
 template <int MODE>
 static int launch_n400(const FrameGeom& g, const Q4Tables& tb, const StftEpilogue& ep, hipStream_t stream) {
     const long long units = g.rows * ((g.n_frames + Q4_G - 1) / Q4_G);
@@ -377,6 +389,7 @@ static int launch_n400(const FrameGeom& g, const Q4Tables& tb, const StftEpilogu
     long long blocks = (units + Q4_WAVES - 1) / Q4_WAVES;
     const long long cap = (long long)device_cu_count();
     if (blocks > cap) blocks = cap;
+    // (the twelve-wave form, stft_n400_s3.hpp, serves the fused mel chain only: on these store-bound rows it measured 0-4 % slower)
     auto kern = stft_n400_kernel<MODE, false, 1>;
     if (bytes > 64 * 1024) TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Q4_WAVES * 64), bytes, stream, g, tb, ep, LaneMel{});
@@ -393,6 +406,19 @@ static int launch_n400_mel_mode(const FrameGeom& g, const Q4Tables& tb, const La
     long long blocks = (units + Q4_WAVES - 1) / Q4_WAVES;
     const long long cap = (long long)device_cu_count();
     if (blocks > cap) blocks = cap;
+    if (q4_three_waves() && g.length >= 400) {
+        const size_t b3 = q4s3_lds_bytes(MODE, true) + lm_lds_bytes(8, mel.wtot);
+        if (b3 <= 160 * 1024) {
+            long long bl = (units + Q4S3_WAVES - 1) / Q4S3_WAVES;
+            if (bl > cap) bl = cap;
+            auto k3 = stft_n400_s3_kernel<MODE, true, S>;
+            TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(k3), (int)b3));
+            hipLaunchKernelGGL(k3, dim3((unsigned)bl), dim3(Q4S3_WAVES * 64), b3, stream, g, tb,
+                               StftEpilogue{nullptr, 1, 1, MODE == 1 ? 2.0f : 1.0f, 0, 0.0f, 0.0f}, mel);
+            TAC_HIP(hipGetLastError());
+            return TAC_OK;
+        }
+    }
     auto kern = stft_n400_kernel<MODE, true, S>;
     if (bytes > 64 * 1024) TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Q4_WAVES * 64), bytes, stream, g, tb,
