@@ -1,7 +1,9 @@
-// melspec_stream3.hpp — EXPERIMENT (round 3): the fused fft_length-2048 chain with THREE waves per SIMD.
+// melspec_stream3.hpp — the fused fft_length-2048 chain (STFT -> |X|^p -> band-sparse mel filterbank -> dB, one launch; the
+// benchmark kernel since round 3) with THREE waves per SIMD.  Replaces reference layers.py:307-381 / functional.py:36-38,
+// 58-72, 172-184, 291-296 for this size.
 //
-// melspec_stream_kernel runs two 239-register waves per SIMD, each rotating two frames; its counters say that both the
-// VALU (64 %) and the LDS (44 %) idle while the SIMD's two waves are stuck at the same time.  This form trades the
+// melspec_stream_kernel (round 2) runs two 239-register waves per SIMD, each rotating two frames; its counters say that both
+// the VALU (64 %) and the LDS (44 %) idle while the SIMD's two waves are stuck at the same time.  This form trades the
 // software rotation for a third hardware wave: twelve waves per workgroup (<= 168 VGPRs), ONE frame per wave, the
 // |X|^2 row written in place over the frame's exchange area (which is what lets twelve waves fit the LDS:
 // 12 x 8.7 KB + 20 KB of weights), no instruction of one frame interleaved with another's.

@@ -1,6 +1,6 @@
-// stft_stream3.hpp — the fft_length-2048 STFT / spectrogram rows with THREE waves per SIMD.
+// stft_stream3.hpp — the fft_length-2048 STFT / spectrogram rows with THREE (complex rows) or FOUR (real rows) waves per SIMD.
 //
-// Same front end as melspec_stream3_kernel (one frame per wave, twelve <=168-register waves per CU, window, pass-1 and
+// Same front end as melspec_stream3_kernel (one frame per wave, twelve <=168- or sixteen <=128-register waves per CU, window, pass-1 and
 // R2C twiddles from LDS); where that kernel contracts the |X|^2 row with the mel bank, this one streams the row out:
 // it is staged IN PLACE over the frame's exchange area at the 16-byte phase of its place in the output, and leaves as
 // unconditional 16-byte nontemporal stores (stft_pipe_kernel's epilogue).  Replaces
