@@ -26,6 +26,9 @@ __host__ __device__ inline size_t stream3_lds_bytes(int wtot, int waves, bool co
 #ifndef TAC_S3_PTW_REGS
 #define TAC_S3_PTW_REGS 0
 #endif
+#ifndef TAC_S3_LDS_EXCHANGE
+#define TAC_S3_LDS_EXCHANGE 0
+#endif
 #ifndef TAC_S3_CHUNK
 #define TAC_S3_CHUNK 5
 #endif
@@ -304,7 +307,14 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         // ---- s12
         F::template pass_twiddle<1, true>(v, tw1);
         F::template pass_butterflies<1>(v);
+#if TAC_S3_LDS_EXCHANGE
+        wave_lds_fence();                                   // (A/B) the pass 1 -> 2 exchange through the LDS area instead of permlane swaps
+        F::template pass_write<1, true>(v, xa, t, t);
+        wave_lds_fence();
+        F::template pass_readback<2>(v, xa, t);
+#else
         F::exchange_1_2_in_registers(v);
+#endif
         F::template pass_twiddle<2, true>(v, tw2);
         F::template pass_butterflies<2>(v);
         wave_lds_fence();
