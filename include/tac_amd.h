@@ -112,7 +112,7 @@ int tac_melspec_sparse_f32(const float* wave, const float* window, const tac_stf
  *      TAC_SAMPLES_I16 = int16 PCM, value = sample * 2^-15; TAC_SAMPLES_MULAW_U8 / _I64 = 8-bit mu-law codes stored as
  *      uint8 / int64 (what mu_law_encoding returns), value = decode_lut[code & 255] with decode_lut the DEVICE float[256]
  *      table of (8).  d->row_stride and d->length count samples.  Served by the fft_length 2048 streaming kernel and, for
- *      power 2, by the fft_length 256 / 512 / 1024 kernels; TAC_E_UNSUPPORTED otherwise (callers then convert with (8) /
+ *      power 2, by the fft_length 256 / 400 / 512 / 1024 kernels; TAC_E_UNSUPPORTED otherwise (callers then convert with (8) /
  *      tac_pcm16_to_f32 and use (3b)). */
 #define TAC_SAMPLES_F32 0
 #define TAC_SAMPLES_I16 1

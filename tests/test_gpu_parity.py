@@ -1369,8 +1369,8 @@ def test_tables_follow_the_filterbank_and_window(tac):
 def test_coded_waveforms_fused_into_the_frame_load(tac, golden):
     """int16 PCM and 8-bit mu-law codes (uint8 or the int64 mu_law_encoding returns) are converted in
     registers inside the fused kernel's frame load — ONE launch, the decoded waveform never exists — and agree with the
-    reference chain MuLawDecoding -> Melspectrogram -> AmplitudeToDb (golden g9), at fft_length 2048 and (round 3) 256 / 512 /
-    1024; other fft sizes convert first."""
+    reference chain MuLawDecoding -> Melspectrogram -> AmplitudeToDb (golden g9), at fft_length 2048 and (round 3) 256 / 400 /
+    512 / 1024; other fft sizes convert first."""
     g = golden('g9_mulaw_mel')
     for dtype in (torch.int64, torch.uint8):
         codes = torch.from_numpy(g['codes']).to(dtype).cuda()
@@ -1403,19 +1403,28 @@ def test_coded_waveforms_fused_into_the_frame_load(tac, golden):
     assert np.abs(host(got) - host(want)).max() < 1e-4
     odd = dev(pcm)[:, :, 1:]                                            # row base no longer 4-byte aligned
     assert np.abs(host(mel(odd)) - host(mel(dev(pcm.astype(np.float32)[:, :, 1:] / 32768.0)))).max() < 1e-4
-    # the same at the sizes of the 2 / 4 / 8-frames-per-wave kernels; a size without a coded frame load converts first
+    # the same at the sizes of the 2 / 4 / 8-frames-per-wave kernels and the mixed-radix 400 one
     for n_fft, hop, mels in ((1024, 256, 80), (512, 128, 80), (256, 64, 40), (400, 160, 80)):
         chain = torch.nn.Sequential(*tac.Melspectrogram(num_mels=mels, sample_rate=16000, fft_length=n_fft, hop_length=hop),
                                     tac.AmplitudeToDb()).cuda()
         before = launches(tac)
         got = chain(dev(pcm))
         ran = launched_since(tac, before)
-        if n_fft == 400:
-            assert 'tac_pcm16_to_f32' in ran and 'tac_melspec_sparse_coded_f32' not in ran, ran
-        else:
-            assert ran == {'tac_melspec_sparse_coded_f32': 1}, (n_fft, ran)
+        assert ran == {'tac_melspec_sparse_coded_f32': 1}, (n_fft, ran)
         assert np.abs(host(got) - host(chain(dev(pcm.astype(np.float32) / 32768.0)))).max() < 1e-4, n_fft
         assert np.abs(host(chain(odd)) - host(chain(dev(pcm.astype(np.float32)[:, :, 1:] / 32768.0)))).max() < 1e-4, n_fft
+    # mu-law codes at the speech configuration (400 / 160 / 40 mels), both storage types, against decode-then-float32
+    codes = torch.from_numpy(g['codes'])
+    for dtype in (torch.int64, torch.uint8):
+        chain = torch.nn.Sequential(tac.MuLawDecoding(256),
+                                    *tac.Melspectrogram(num_mels=40, sample_rate=16000, fft_length=400, hop_length=160),
+                                    tac.AmplitudeToDb()).cuda()
+        before = launches(tac)
+        got = chain(codes.to(dtype).cuda())
+        assert launched_since(tac, before) == {'tac_melspec_sparse_coded_f32': 1}
+        wave = tac.MuLawDecoding(256)(codes.cuda()) + 0.0
+        assert np.abs(host(got) - host(chain[1:](wave))).max() < 1e-4
+        assert np.abs(host(chain(codes.to(dtype).cuda()[..., 3:])) - host(chain[1:](wave[..., 3:].contiguous()))).max() < 1e-4
     z = tac.stft(dev(pcm), 512, 128)                                    # no coded frame load there: converted by a kernel first
     assert rel_err(host(z), host(tac.stft(dev(pcm.astype(np.float32) / 32768.0), 512, 128))) < 1e-6
 

@@ -1046,7 +1046,8 @@ def melspectrogram_coded(samples, window, fb, n_fft, hop, win_length, center, pa
     the frame load.  Returns None when the single-kernel route does not cover the configuration — the caller then
     converts first and takes the float32 path."""
     g = geometry(samples, n_fft, hop, win_length, center, pad_mode, normalized, onesided)
-    if not (g.fft_kernel and g.onesided and g.n_fft in (256, 512, 1024, 2048) and fb.dim() == 2 and fb.shape[0] == g.n_bins
+    if not ((g.fft_kernel or g.mixed_radix) and g.onesided and g.n_fft in (256, 400, 512, 1024, 2048) and fb.dim() == 2
+            and fb.shape[0] == g.n_bins
             and fb.is_contiguous() and power in (1.0, 2.0) and MEL_PATH != 'mfma'):
         return None
     pack = _melbank_pack(fb, g.n_fft)

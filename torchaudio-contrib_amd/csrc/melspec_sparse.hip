@@ -34,7 +34,8 @@ namespace tac {
 
 // stft_n400.hip: the fused chain for fft_length 400
 int launch_n400_mel(const FrameGeom& g, float power, const float* wpack, const int* desc, const int32_t* info_host,
-                    int n_mels, int db, float amin, float log10_ref, float* out, hipStream_t stream);
+                    int n_mels, int db, float amin, float log10_ref, float* out, hipStream_t stream, int fmt = FMT_F32,
+                    const void* samples = nullptr, const float* lut = nullptr);
 int pack_n400(const std::vector<float>& h, int n_freqs, int n_mels, float* wpack, int wpack_cap, int32_t* desc,
               int desc_cap, int32_t* info_host, hipStream_t stream);
 // stft_small.hip: the same form for fft_length 512 / 1024 (the three-phase kernel below stays the fallback)
@@ -789,7 +790,7 @@ int tac_melspec_sparse_coded_f32(const void* samples, int32_t sample_format, con
     if (!samples || !wpack || !desc || !info_host || !out || !d || n_mels <= 0) return TAC_E_INVALID;
     if (sample_format < TAC_SAMPLES_F32 || sample_format > TAC_SAMPLES_MULAW_I64) return TAC_E_INVALID;
     if (sample_format >= TAC_SAMPLES_MULAW_U8 && !decode_lut) return TAC_E_INVALID;
-    const bool small = d->n_fft == 256 || d->n_fft == 512 || d->n_fft == 1024;      // stft_small3_kernel (lane-layout packs)
+    const bool small = d->n_fft == 256 || d->n_fft == 512 || d->n_fft == 1024 || d->n_fft == 400;   // lane-layout packs
     if (!d->onesided || (d->n_fft != 2048 && !small)) return TAC_E_UNSUPPORTED;
     if (power != 2.0f && power != 1.0f) return TAC_E_UNSUPPORTED;
     if (small ? info_host[2] < LM_MARK : info_host[2] != sparse_groups_for(d->n_fft)) return small ? TAC_E_UNSUPPORTED : TAC_E_INVALID;
@@ -802,6 +803,9 @@ int tac_melspec_sparse_coded_f32(const void* samples, int32_t sample_format, con
     if (rc != TAC_OK) return rc;
     if (small) {
         if (sample_format == TAC_SAMPLES_F32) return TAC_E_UNSUPPORTED;   // (float32 callers use tac_melspec_sparse_f32)
+        if (d->n_fft == 400)
+            return launch_n400_mel(g, power, wpack, desc, info_host, n_mels, db ? 1 : 0, db_amin, db ? log10f(db_ref) : 0.0f, out,
+                                   (hipStream_t)stream, sample_format, samples, decode_lut);
         return launch_small_mel_entry(d->n_fft, g, tb, power, wpack, desc, info_host, n_mels, db ? 1 : 0, db_amin,
                                       db ? log10f(db_ref) : 0.0f, out, (hipStream_t)stream, sample_format, samples, decode_lut);
     }

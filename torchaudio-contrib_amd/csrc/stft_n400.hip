@@ -414,7 +414,8 @@ static int launch_n400_mel_mode(const FrameGeom& g, const Q4Tables& tb, const La
             auto k3 = stft_n400_s3_kernel<MODE, true, S>;
             TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(k3), (int)b3));
             hipLaunchKernelGGL(k3, dim3((unsigned)bl), dim3(Q4S3_WAVES * 64), b3, stream, g, tb,
-                               StftEpilogue{nullptr, 1, 1, MODE == 1 ? 2.0f : 1.0f, 0, 0.0f, 0.0f}, mel);
+                               StftEpilogue{nullptr, 1, 1, MODE == 1 ? 2.0f : 1.0f, 0, 0.0f, 0.0f}, mel, (const void*)nullptr,
+                               (const float*)nullptr);
             TAC_HIP(hipGetLastError());
             return TAC_OK;
         }
@@ -427,15 +428,59 @@ static int launch_n400_mel_mode(const FrameGeom& g, const Q4Tables& tb, const La
     return TAC_OK;
 }
 
+// int16 PCM / mu-law codes read by the fused kernel itself (power 2, twelve-wave kernel only)
+template <int S, int FMT>
+static int launch_n400_mel_coded(FrameGeom g, const Q4Tables& tb, const LaneMel& mel, hipStream_t stream, const void* samples,
+                                 const float* lut) {
+    const long long units = g.rows * ((g.n_frames + Q4_G - 1) / Q4_G);
+    if (units >= 0x7fffffffLL || !q4_three_waves() || g.length < 400) return TAC_E_UNSUPPORTED;
+    const size_t b3 = q4s3_lds_bytes(1, true) + lm_lds_bytes(8, mel.wtot) + 1024;
+    if (b3 > 160 * 1024) return TAC_E_UNSUPPORTED;
+    {                                                                      // sample pairs fetched as one access of the format
+        const uintptr_t pair = FMT == FMT_I16 ? 4 : (FMT == FMT_MULAW_U8 ? 2 : 8);
+        g.vec2_ok = ((g.hop & 1) == 0) && ((g.center_pad & 1) == 0) && ((g.row_stride & 1) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(samples) & (pair - 1)) == 0);
+    }
+    long long bl = (units + Q4S3_WAVES - 1) / Q4S3_WAVES;
+    if (bl > device_cu_count()) bl = device_cu_count();
+    auto k3 = stft_n400_s3_kernel<1, true, S, FMT>;
+    TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(k3), (int)b3));
+    hipLaunchKernelGGL(k3, dim3((unsigned)bl), dim3(Q4S3_WAVES * 64), b3, stream, g, tb, StftEpilogue{nullptr, 1, 1, 2.0f, 0, 0.0f, 0.0f},
+                       mel, samples, lut);
+    TAC_HIP(hipGetLastError());
+    return TAC_OK;
+}
+
+template <int FMT>
+static int launch_n400_mel_coded_s(const FrameGeom& g, const Q4Tables& tb, const LaneMel& mel, int S, hipStream_t stream,
+                                   const void* samples, const float* lut) {
+    switch (S) {
+#define TAC_Q4_CASE(SS) case SS: return launch_n400_mel_coded<SS, FMT>(g, tb, mel, stream, samples, lut);
+        TAC_Q4_CASE(1) TAC_Q4_CASE(2) TAC_Q4_CASE(3) TAC_Q4_CASE(4) TAC_Q4_CASE(5) TAC_Q4_CASE(6) TAC_Q4_CASE(7) TAC_Q4_CASE(8)
+        TAC_Q4_CASE(9) TAC_Q4_CASE(10) TAC_Q4_CASE(11) TAC_Q4_CASE(12)
+#undef TAC_Q4_CASE
+        default: return TAC_E_INVALID;
+    }
+}
+
 // The fused Melspectrogram (+dB) chain for fft_length 400 (melspec_sparse.hip's entry points call these).
 int launch_n400_mel(const FrameGeom& g, float power, const float* wpack, const int* desc, const int32_t* info_host,
-                    int n_mels, int db, float amin, float log10_ref, float* out, hipStream_t stream) {
+                    int n_mels, int db, float amin, float log10_ref, float* out, hipStream_t stream, int fmt,
+                    const void* samples, const float* lut) {
     if (!lane_mel_info_ok(info_host, 8, Q4_FLY)) return TAC_E_INVALID;
     if (n_mels < LM_MIN_MELS || n_mels > LM_MAX_MELS) return TAC_E_UNSUPPORTED;
     Q4Tables tb;
     const int rc = q4_tables(&tb);
     if (rc != TAC_OK) return rc;
     const LaneMel mel{wpack, desc, info_host[1], info_host[0], n_mels, db, amin, log10_ref, out};
+    if (fmt != FMT_F32) {
+        if (power != 2.0f) return TAC_E_UNSUPPORTED;
+        switch (fmt) {
+            case FMT_I16: return launch_n400_mel_coded_s<FMT_I16>(g, tb, mel, info_host[4], stream, samples, lut);
+            case FMT_MULAW_U8: return launch_n400_mel_coded_s<FMT_MULAW_U8>(g, tb, mel, info_host[4], stream, samples, lut);
+            default: return launch_n400_mel_coded_s<FMT_MULAW_I64>(g, tb, mel, info_host[4], stream, samples, lut);
+        }
+    }
     const bool p2 = power == 2.0f;
     switch (info_host[4]) {                                                // steps per band
 #define TAC_Q4_CASE(SS) case SS: return p2 ? launch_n400_mel_mode<1, SS>(g, tb, mel, stream) : launch_n400_mel_mode<2, SS>(g, tb, mel, stream);

@@ -19,9 +19,13 @@ inline size_t q4s3_lds_bytes(int mode, bool mel) {
     return (size_t)Q4S3_WAVES * q4s3_stage(mode, mel) * sizeof(float) + (size_t)24 * Q4_ROW * sizeof(cf) + 16;
 }
 
-template <int MODE, bool MEL, int S>
+// FMT (fused mel form): sample format of the frame load — int16 PCM (value = sample 2^-15, folded into the window table) and
+// mu-law codes (uint8 / int64, 256-entry decode table in LDS) are converted in registers, like the other fused kernels do
+template <int MODE, bool MEL, int S, int FMT = FMT_F32>
 __global__ void __launch_bounds__(Q4S3_WAVES * 64, 3)
-stft_n400_s3_kernel(FrameGeom g, Q4Tables tb, StftEpilogue ep, LaneMel mel) {
+stft_n400_s3_kernel(FrameGeom g, Q4Tables tb, StftEpilogue ep, LaneMel mel, const void* __restrict__ samples = nullptr,
+                    const float* __restrict__ lut = nullptr) {
+    static_assert(FMT == FMT_F32 || MEL, "coded inputs: the fused Melspectrogram form");
     constexpr int LENF = (MODE == 0 ? 2 : 1) * Q4_BINS;
     constexpr int STAGE = q4s3_stage(MODE, MEL);                           // floats per wave
     constexpr int NST = (((Q4_G * LENF) >> 2) + 63) / 64;                  // 16-byte wave-stores per unit
@@ -41,10 +45,15 @@ stft_n400_s3_kernel(FrameGeom g, Q4Tables tb, StftEpilogue ep, LaneMel mel) {
     int* const mlo = reinterpret_cast<int*>(next_unit + 4);                // MEL: first bins [slot][lane]; the weights
     float* const mwl = reinterpret_cast<float*>(mlo + lm_desc_ints(8));
     if constexpr (MEL) lane_mel_load_tables<S, 8, Q4_FLY>(mlo, mwl, mel, threadIdx.x, Q4S3_WAVES * 64);
+    float* const lutlds = mwl + ((mel.wtot + 3) & ~3);                     // mu-law decode table behind the weights
+    if constexpr (FMT >= FMT_MULAW_U8) {
+        if (threadIdx.x < 256) lutlds[threadIdx.x] = lut[threadIdx.x];
+    }
+    const float pcm = FMT == FMT_I16 ? (1.0f / 32768.0f) : 1.0f;
     for (int i = threadIdx.x; i < 8 * Q4_ROW; i += Q4S3_WAVES * 64) {
         const int ll = i / Q4_ROW, m = i - ll * Q4_ROW;
         const int ee = ll < 4 ? ll : 11 - ll;
-        winl[i] = m < Q4_M ? window_pair(g, ee + 8 * m) : mkc(0.0f, 0.0f);
+        winl[i] = m < Q4_M ? cscale(window_pair(g, ee + 8 * m), pcm) : mkc(0.0f, 0.0f);
         w200l[i] = tb.w200[i];
         w400l[i] = tb.w400[i];
     }
@@ -95,9 +104,52 @@ stft_n400_s3_kernel(FrameGeom g, Q4Tables tb, StftEpilogue ep, LaneMel mel) {
         fast = __builtin_amdgcn_ballot_w64(ok) == ~0ull;
         long long cs = start < 0 ? 0 : start;
         cs = cs + 400 <= g.length ? cs : g.length - 400;
-        const cf* src = reinterpret_cast<const cf*>(g.wave + (long long)urow * g.row_stride + cs) + e;
+        const long long off = (long long)urow * g.row_stride + cs;           // in samples
+        if constexpr (FMT == FMT_F32) {
+            const cf* src = reinterpret_cast<const cf*>(g.wave + off) + e;
 #pragma unroll
-        for (int m = 0; m < Q4_M; ++m) v[m] = src[8 * m];
+            for (int m = 0; m < Q4_M; ++m) v[m] = src[8 * m];
+        } else if constexpr (FMT == FMT_I16) {                              // a pair of samples = one dword
+            const unsigned* src = reinterpret_cast<const unsigned*>(static_cast<const short*>(samples) + off) + e;
+#pragma unroll
+            for (int m = 0; m < Q4_M; ++m) v[m].x = __uint_as_float(src[8 * m]);
+        } else if constexpr (FMT == FMT_MULAW_U8) {                         // a pair of codes = one 16-bit load
+            const unsigned short* src = reinterpret_cast<const unsigned short*>(static_cast<const unsigned char*>(samples) + off) + e;
+#pragma unroll
+            for (int m = 0; m < Q4_M; ++m) v[m].x = __uint_as_float((unsigned)src[8 * m]);
+        } else {                                                            // int64 codes: the low dword of each
+            const int* src = reinterpret_cast<const int*>(static_cast<const long long*>(samples) + off) + 4 * e;
+#pragma unroll
+            for (int m = 0; m < Q4_M; ++m) {
+                v[m].x = __int_as_float(src[32 * m]);
+                v[m].y = __int_as_float(src[32 * m + 2]);
+            }
+        }
+    };
+    // the requested registers as float sample pairs (still unwindowed): PCM integers / decoded codes
+    auto decode = [&]() {
+        if constexpr (FMT == FMT_I16) {
+#pragma unroll
+            for (int m = 0; m < Q4_M; ++m) {
+                const int bits = __float_as_int(v[m].x);
+                v[m] = mkc((float)(short)(bits & 0xffff), (float)(bits >> 16));
+            }
+        } else if constexpr (FMT == FMT_MULAW_U8) {
+#pragma unroll
+            for (int m = 0; m < Q4_M; ++m) {
+                const unsigned bits = __float_as_uint(v[m].x);
+                v[m] = mkc(lutlds[bits & 0xffu], lutlds[(bits >> 8) & 0xffu]);
+            }
+        } else if constexpr (FMT == FMT_MULAW_I64) {
+#pragma unroll
+            for (int m = 0; m < Q4_M; ++m) v[m] = mkc(lutlds[__float_as_uint(v[m].x) & 0xffu], lutlds[__float_as_uint(v[m].y) & 0xffu]);
+        }
+    };
+    auto sample_at = [&](long long row_offset, int j) -> float {            // the gather path's access, in the same units as `decode`
+        if constexpr (FMT == FMT_F32) return g.wave[row_offset + j];
+        else if constexpr (FMT == FMT_I16) return (float)static_cast<const short*>(samples)[row_offset + j];
+        else if constexpr (FMT == FMT_MULAW_U8) return lutlds[static_cast<const unsigned char*>(samples)[row_offset + j]];
+        else return lutlds[(unsigned)static_cast<const long long*>(samples)[row_offset + j] & 0xffu];
     };
     int unit = begin + w;
     __syncthreads();
@@ -109,6 +161,7 @@ stft_n400_s3_kernel(FrameGeom g, Q4Tables tb, StftEpilogue ep, LaneMel mel) {
         const int urow = unit / upr;
         const int uframe0 = (unit - urow * upr) * Q4_G;
         if (fast) {
+            decode();
             cf wn[Q4_M];
             q4_read_row(winl + l * Q4_ROW, wn);
 #pragma unroll
@@ -117,7 +170,7 @@ stft_n400_s3_kernel(FrameGeom g, Q4Tables tb, StftEpilogue ep, LaneMel mel) {
             // frames touching the padding / past the end of the row: sample by sample (rolled loops), in two halves through
             // the (smaller) staging area — registers are indexed at compile time only
             const int frame = uframe0 + slot;
-            const float* rp = g.wave + (long long)urow * g.row_stride;
+            const long long rbase = (long long)urow * g.row_stride;
             const int s0 = (int)((long long)frame * g.hop - g.center_pad);
             const int L = (int)g.length;
             const bool live = frame < T;
@@ -130,7 +183,7 @@ stft_n400_s3_kernel(FrameGeom g, Q4Tables tb, StftEpilogue ep, LaneMel mel) {
                     bool z0, z1;
                     const int j0 = padded_index(s0 + 2 * (e + 8 * m), L, g.pad_mode, &z0);
                     const int j1 = padded_index(s0 + 2 * (e + 8 * m) + 1, L, g.pad_mode, &z1);
-                    const float a0 = rp[j0], a1 = rp[j1];
+                    const float a0 = sample_at(rbase, j0), a1 = sample_at(rbase, j1);
                     const cf wv = winl[l * Q4_ROW + m];
                     reinterpret_cast<cf*>(wstage)[lane * HALF0 + (m - m0)] =
                         mkc((live && !z0) ? a0 * wv.x : 0.0f, (live && !z1) ? a1 * wv.y : 0.0f);
