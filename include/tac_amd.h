@@ -185,6 +185,21 @@ int tac_phase_vocoder_f64(const double* spec, int64_t rows, int32_t n_freqs, int
                           const double* phase_advance, const int32_t* idx0, const int32_t* idx1,
                           const double* alpha, int64_t n_out, double* out, void* stream);
 
+/* (1d)-(6d) The path in float64 (the reference keeps f64 -> f64: functional.py:48-113, :116-128, :172-184, :187-201,
+ *      :277-314).  Same argument meaning as the _f32 entry points with double data; d->n_fft: a power of two in
+ *      [8, 8192] (N/2-point complex Stockham transform per workgroup in LDS) or any length <= 4096 (direct transform);
+ *      tac_apply_filterbank_f64 takes the dense bank (no plan) and optionally applies amplitude_to_db to its result;
+ *      tac_magphase_f64: mag and / or phase may be NULL (complex_norm / angle alone). */
+int tac_stft_f64(const double* wave, const double* window, const tac_stft_desc* d, double* out, void* stream);
+int tac_spectrogram_f64(const double* wave, const double* window, const tac_stft_desc* d, double power, int db,
+                        double db_ref, double db_amin, double* out, void* stream);
+int tac_apply_filterbank_f64(const double* spec, int64_t rows, int32_t n_freqs, int64_t n_frames, int64_t stride_r,
+                             int64_t stride_f, int64_t stride_t, const double* fb, int32_t n_mels, int db,
+                             double db_ref, double db_amin, double* out, void* stream);
+int tac_magphase_f64(const double* z, int64_t n, double power, double* mag, double* phase, void* stream);
+int tac_amplitude_to_db_f64(const double* x, int64_t n, double ref, double amin, double* out, void* stream);
+int tac_db_to_amplitude_f64(const double* x, int64_t n, double ref, double* out, void* stream);
+
 /* (6) functional.amplitude_to_db, functional.py:277-296: 10*(log10(max(x^2, amin)) - log10(ref)). */
 int tac_amplitude_to_db_f32(const float* x, int64_t n, float ref, float amin, float* out,
                             void* stream);

@@ -353,3 +353,11 @@ def test_median_run_matches_nth_element(tmp_path):
     subprocess.run(['g++', '-O1', '-I', os.path.join(ROOT, 'torchaudio-contrib_amd', 'csrc'), '-o', exe, str(src)], check=True)
     out = subprocess.run([exe], stdout=subprocess.PIPE, text=True)
     assert out.returncode == 0 and out.stdout.strip() == 'bad=0', out.stdout
+
+
+def test_float64_size_coverage_matches_the_kernel_plan(tac):
+    """``_hip64.covers`` restates ``plan_f64`` / ``geometry_f64`` of csrc/chain_f64.hip: every length <= 4096 (direct
+    transform when the half is not 5-smooth or the length is odd), above that only even lengths <= 8192 with a 5-smooth half."""
+    h64 = tac._ops.H64
+    assert all(h64.covers(n) for n in (1, 4, 77, 134, 400, 2048, 4096, 6000, 8192, 5000))
+    assert not any(h64.covers(n) for n in (4097, 8190, 8194, 16384, 4099 * 2))

@@ -10,8 +10,9 @@ see them by name.
     tac_amd::mu_law_encoding, mu_law_decoding                           likewise
 
 Routing on a HIP device: float32 (and float16/bfloat16, widened as ``torch.stft`` widens half input) always runs
-the hand-written kernels and raises if ``libtac_amd.so`` is missing.  float64 — which the gfx950 kernels do not
-compute — and fft sizes outside the kernels' range are evaluated by torch's own GPU operators
+the hand-written kernels and raises if ``libtac_amd.so`` is missing.  float64 runs the float64 kernels of the STFT chain
+(``_hip64.py`` -> csrc/chain_f64.hip) and of the phase vocoder.  What those do not cover (float64 mu-law / HPSS) and fft
+sizes outside the kernels' range are evaluated by torch's own GPU operators
 (``_composite.py``) with a one-time ``CompositeRouteWarning``; ``set_strict(True)`` turns that route into an error
 (the GPU parity tests run strict, so nothing they check can have come from anywhere but the HIP kernels).
 
@@ -28,6 +29,7 @@ from torch.library import Library
 
 from . import _composite as C
 from . import _hip as H
+from . import _hip64 as H64
 
 NS = 'tac_amd'
 _lib = Library(NS, 'DEF')
@@ -324,6 +326,8 @@ def _stft_route(op, wave, n_fft, *others):
 
 def _stft_cuda(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided):
     _same_device('stft', wave, window)
+    if H64.all_f64(wave, window) and H64.covers(n_fft):
+        return H64.stft(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided)
     if _stft_route('stft', wave, n_fft, window) is not None:
         return C.stft(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided)
     return H.stft(_pcm(wave), _f32(window).contiguous(), n_fft, hop, win_length, center, pad_mode, normalized,
@@ -343,6 +347,9 @@ _register('stft', '(Tensor wave, Tensor window, %s) -> Tensor' % _STFT_ARGS, _st
 def _spectrogram_cuda(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided, power, db, ref,
                       amin):
     _same_device('spectrogram', wave, window)
+    if H64.all_f64(wave, window) and H64.covers(n_fft):
+        return H64.spectrogram(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided, power, db, ref,
+                               amin)
     if _stft_route('spectrogram', wave, n_fft, window) is not None:
         return C.spectrogram(wave, window, n_fft, hop, win_length, center, pad_mode, normalized, onesided, power, db,
                              ref, amin)
@@ -365,6 +372,10 @@ _register('spectrogram', '(Tensor wave, Tensor window, %s, float power, bool db,
 def _melspectrogram_cuda(wave, window, bank, n_fft, hop, win_length, center, pad_mode, normalized, onesided, power,
                          db, ref, amin):
     _same_device('melspectrogram', wave, window, bank)
+    if H64.all_f64(wave, window, bank) and H64.covers(n_fft) and bank.dim() == 2 and bank.shape[0] == (
+            n_fft // 2 + 1 if onesided else n_fft):
+        return H64.melspectrogram(wave, window, bank, n_fft, hop, win_length, center, pad_mode, normalized, onesided, power,
+                                  db, ref, amin)
     if _stft_route('melspectrogram', wave, n_fft, window, bank) is not None:
         return C.melspectrogram(wave, window, bank, n_fft, hop, win_length, center, pad_mode, normalized, onesided,
                                 power, db, ref, amin)
@@ -429,6 +440,8 @@ _register('melspectrogram_mulaw', '(Tensor codes, Tensor window, Tensor filterba
 # ============================================================================= apply_filterbank
 def _apply_filterbank_cuda(spec, bank):
     _same_device('apply_filterbank', spec, bank)
+    if H64.all_f64(spec, bank) and spec.dim() >= 2 and bank.dim() == 2 and spec.shape[-2] == bank.shape[0]:
+        return H64.apply_filterbank(spec, bank)
     if _hip_dtype(spec, bank) is not None:
         _composite_route('apply_filterbank', _hip_dtype(spec, bank))
         return C.apply_filterbank(spec, bank)
@@ -447,6 +460,8 @@ _register('apply_filterbank', '(Tensor spec, Tensor filterbank) -> Tensor', _app
 # ============================================================================= complex pairs
 def _pairwise_cuda(op, hip_fn, composite_fn):
     def run(z, *args):
+        if z.dtype == torch.float64 and z.dim() >= 1 and z.shape[-1] == 2:
+            return getattr(H64, op)(z, *args)
         reason = _hip_dtype(z)
         if reason is not None:
             _composite_route(op, reason)
@@ -511,6 +526,8 @@ _register('phase_vocoder', '(Tensor spec, Tensor phase_advance, float rate) -> T
 # ============================================================================= dB
 def _unary_cuda(op, hip_fn, composite_fn):
     def run(x, *args):
+        if x.dtype == torch.float64:
+            return getattr(H64, op)(x, *args)
         reason = _hip_dtype(x)
         if reason is not None:
             _composite_route(op, reason)

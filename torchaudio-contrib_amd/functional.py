@@ -7,7 +7,8 @@ Where the work runs (decided by the dispatcher, like for any torch op):
   * HIP device, float32 (float16 / bfloat16 widened)  → the gfx950 kernels; a missing ``libtac_amd.so`` raises.
   * CPU tensors (the reference's own test-suite, BASELINE configs[0]) → torch's CPU operators in the reference's
     operator order (``_composite.py``), so reference call sites written for the CPU keep working unchanged.
-  * float64 → torch's operators on the tensor's device (the reference keeps f64 → f64).
+  * HIP device, float64 (the reference keeps f64 → f64) → the float64 kernels of the STFT chain and the phase vocoder
+    (``_hip64.py``); float64 mu-law and HPSS → torch's operators on the device, announced.
 
 Outputs are fresh tensors; the STFT-family results are returned as the same strided views the reference
 produces (physically frame-major, logically ``(*, channel, freq, time[, 2])``).
