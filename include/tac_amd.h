@@ -243,16 +243,16 @@ int tac_mulaw_decode_f32_f32(const float* codes, int64_t n, int32_t n_quantize, 
  *       (wave / d exactly as given to (2)), transformed again in the kernel, and the spectrum values the norm's adjoint
  *       needs are formed from the FFT's exchange area while the inverse's operands are gathered.
  *     tac_spectrogram_backward_ola_f32: the whole adjoint of (2) — tac_spectrogram_backward_f32 + tac_overlap_add_f32 —
- *       for fft_length 256 / 512 / 1024 / 2048 with a hop that is a multiple of fft_length / 16 (TAC_E_UNSUPPORTED
- *       otherwise): every wave walks runs of consecutive frames and keeps their overlap-add in LDS, so no frame gradients
+ *       for fft_length 256 / 512 / 1024 / 2048 with a hop that is a multiple of fft_length / 16, and fft_length 400 with
+ *       50 <= hop <= 400 and hop, centre padding multiples of 4 (TAC_E_UNSUPPORTED otherwise): every wave walks runs of consecutive frames and keeps their overlap-add in LDS, so no frame gradients
  *       exist in memory.  `workspace`
  *       (device) must hold tac_spectrogram_backward_ola_workspace(d) bytes (that call returns a negative TAC_E_* code
  *       for geometries the form does not cover); grad_wave[r][j] at grad_wave + r * grad_row_stride + j.
  *     tac_melspectrogram_backward_ola_f32: the same for the mel chain (layers.py:333-339, functional.py:183-184): `grad_mel`
  *       is the gradient of the (linear) mel values, (rows, n_frames, n_mels) frame-major, and the filterbank stage's adjoint
  *       — two multiply-adds per bin through the table of tac_filterbank_adjoint_pack — is formed inside the kernel, per
- *       frame: the gradient of the power spectrogram never exists in memory.  fft_length 2048, n_mels <= 256, banks with at
- *       most two non-zero weights per bin; TAC_E_UNSUPPORTED otherwise (callers then run tac_apply_filterbank_adjoint_f32 +
+ *       frame: the gradient of the power spectrogram never exists in memory.  fft_length 2048 (n_mels <= 256), 512 / 1024 (hop = N/8, N/4, N/2) and 400
+ *       (n_mels <= 128), banks with at most two non-zero weights per bin; TAC_E_UNSUPPORTED otherwise (callers then run tac_apply_filterbank_adjoint_f32 +
  *       tac_spectrogram_backward_ola_f32).  Same workspace as tac_spectrogram_backward_ola_f32.
  *     tac_overlap_add_f32: adjoint of framing + padding: grad_wave[r][j] = sum of grad_frames over every (frame, tap)
  *       that read sample j, reflect / replicate / circular images included (a gather: deterministic, no atomics).

@@ -205,14 +205,18 @@ def test_fuzz_gradients(tac):
 
 
 def test_fuzz_gradients_overlap_add_in_lds(tac):
-    """The hop = (fft_length / 16)·H backward form for fft_length 256 / 512 / 1024 / 2048 (csrc/backward.hip: overlap-add in
+    """The hop = (fft_length / 16)·H backward form for fft_length 256 / 512 / 1024 / 2048 and the hop = 4·k form of fft_length 400
+    (csrc/backward.hip, stft_n400.hip: overlap-add in
     an LDS ring over segments of consecutive frames, partial sums at segment borders folded afterwards) over every H, pad
     mode, centring, short windows and signal lengths from one frame to hundreds (one to many segments per row, ragged
     segment lengths inside a wave for the sizes that carry several frames per wave)."""
     rng = np.random.default_rng(6000 + SEED)
     for case in range(max(16, CASES // 2)):
-        n = int(rng.choice([2048, 1024, 512, 256]))
-        hop = (n // 16) * int(rng.integers(1, 17)) if case % 3 else n // 4
+        n = int(rng.choice([2048, 1024, 512, 256, 400]))
+        if n == 400:                       # the mixed-radix kernel: any hop that is a multiple of four from 52 up
+            hop = 4 * int(rng.integers(13, 101)) if case % 3 else 160
+        else:
+            hop = (n // 16) * int(rng.integers(1, 17)) if case % 3 else n // 4
         win_length = n if rng.random() < 0.6 else int(rng.integers(n // 4, n + 1))
         center = bool(rng.random() < 0.75)
         pad_mode = str(rng.choice(['reflect', 'constant', 'replicate', 'circular']))
@@ -248,7 +252,7 @@ def test_fuzz_gradients_overlap_add_in_lds(tac):
         (got,) = torch.autograd.grad((y * dev(w.astype(np.float32))).sum(), xg)
         ran = {k: v - before.get(k, 0) for k, v in tac._hip.launches.items() if v != before.get(k, 0)}
         # the mel chain at fft_length 2048 folds the filterbank adjoint into the backward kernel as well
-        fused = kind.startswith('mel') and (n == 2048 or (n in (512, 1024) and hop in (n // 8, n // 4, n // 2)))
+        fused = kind.startswith('mel') and (n in (2048, 400) or (n in (512, 1024) and hop in (n // 8, n // 4, n // 2)))
         entry = 'tac_melspectrogram_backward_ola_f32' if fused else 'tac_spectrogram_backward_ola_f32'
         assert ran.get(entry) == 1 and 'tac_overlap_add_f32' not in ran, (tag, ran)
         assert entry == 'tac_spectrogram_backward_ola_f32' or 'tac_apply_filterbank_adjoint_f32' not in ran, (tag, ran)

@@ -1076,8 +1076,10 @@ def test_fft_length_400_trains_on_the_mixed_radix_kernels(tac):
     """The 25 ms speech front end (fft_length 400, hop 160) under strict mode: Spectrogram, the 80-band Melspectrogram
     and the complex stft differentiate w.r.t. the waveform through the inverse form of the mixed-radix kernel
     (stft_n400_backward_kernel: the 8 x 25 transform on conjugated data; for |z|^p the frames are re-transformed inside
-    it, no spectrum exists in memory) + the gather overlap-add — launch counters asserted — and agree with torch.autograd
-    through the CPU oracle.  Short rows (every unit touches the padding), odd frame counts and power 1 included."""
+    it, no spectrum exists in memory) with the overlap-add of a unit's eight frames inside the kernel when hop and padding
+    are multiples of four (else frame gradients + the gather overlap-add) — launch counters asserted — and agree with
+    torch.autograd through the CPU oracle.  Short rows (every unit touches the padding), odd frame counts, every pad mode,
+    hops from 52 to 400 and power 1 included."""
     assert tac._ops.strict()
     x = signals.audio_like((3, 1, 16000), seed=331)
     xc = torch.from_numpy(x).double().requires_grad_(True)
@@ -1091,17 +1093,30 @@ def test_fft_length_400_trains_on_the_mixed_radix_kernels(tac):
         before = launches(tac)
         (got,) = torch.autograd.grad((y * dev(wgt)).sum(), xg)
         ran = launched_since(tac, before)
-        assert ran == {'tac_spectrogram_backward_f32': 1, 'tac_overlap_add_f32': 1}, ran     # frames re-transformed in the kernel
+        assert ran == {'tac_spectrogram_backward_ola_f32': 1}, ran       # frames re-transformed AND overlap-added in the kernel
         assert rel_err(host(got), want.numpy()) < 1e-4, power
     xe = signals.audio_like((5, 2, 1234), seed=336)                   # 8 frames per row: every unit gathers its samples
     xec, xeg = torch.from_numpy(xe).double().requires_grad_(True), dev(xe).requires_grad_(True)
-    for pad_mode, hop in (('reflect', 160), ('constant', 90), ('circular', 200)):
-        wy = torch_ref.complex_norm(torch_ref.stft(xec, 400, hop, pad_mode=pad_mode), 2.0)
+    for pad_mode, hop, center in (('reflect', 160, True), ('constant', 90, True), ('circular', 200, True), ('replicate', 52, True),
+                                  ('reflect', 400, True), ('reflect', 160, False), ('constant', 120, True), ('reflect', 48, True)):
+        wy = torch_ref.complex_norm(torch_ref.stft(xec, 400, hop, pad_mode=pad_mode, center=center), 2.0)
         wg = signals.uniform(tuple(wy.shape), seed=337)
         (want,) = torch.autograd.grad((wy * torch.from_numpy(wg).double()).sum(), xec)
-        y = tac.Spectrogram(400, hop, pad_mode=pad_mode, power=2.).cuda()(xeg)
+        y = tac.Spectrogram(400, hop, pad_mode=pad_mode, center=center, power=2.).cuda()(xeg)
+        before = launches(tac)
         (got,) = torch.autograd.grad((y * dev(wg)).sum(), xeg)
-        assert rel_err(host(got), want.numpy()) < 1e-4, (pad_mode, hop)
+        fused = hop % 4 == 0 and hop >= 50
+        assert launched_since(tac, before) == ({'tac_spectrogram_backward_ola_f32': 1} if fused else
+                                               {'tac_spectrogram_backward_f32': 1, 'tac_overlap_add_f32': 1}), (pad_mode, hop)
+        assert rel_err(host(got), want.numpy()) < 1e-4, (pad_mode, hop, center)
+    # long rows without centring: the frames stop short of the row's end (positions past the last frame get no gradient)
+    xl = signals.audio_like((2, 1, 9000), seed=339)
+    xlc, xlg = torch.from_numpy(xl).double().requires_grad_(True), dev(xl).requires_grad_(True)
+    wy = torch_ref.complex_norm(torch_ref.stft(xlc, 400, 160, center=False), 2.0)
+    wg = signals.uniform(tuple(wy.shape), seed=340)
+    (want,) = torch.autograd.grad((wy * torch.from_numpy(wg).double()).sum(), xlc)
+    (got,) = torch.autograd.grad((tac.Spectrogram(400, 160, center=False, power=2.).cuda()(xlg) * dev(wg)).sum(), xlg)
+    assert rel_err(host(got), want.numpy()) < 1e-4 and np.all(host(got)[..., 8880:] == 0.0)
     # the fused 80-band chain with its dB epilogue (the reference idiom)
     chain = torch.nn.Sequential(*tac.Melspectrogram(num_mels=80, sample_rate=16000, fft_length=400, hop_length=160),
                                 tac.AmplitudeToDb(amin=1e-5)).cuda()
@@ -1114,7 +1129,7 @@ def test_fft_length_400_trains_on_the_mixed_radix_kernels(tac):
     (got,) = torch.autograd.grad((y * dev(wgt)).sum(), xg)
     ran = launched_since(tac, before)
     # (round 3: the filterbank adjoint is formed inside the backward kernel — no gradient spectrogram in memory)
-    assert ran.get('tac_melspectrogram_backward_f32') == 1 and ran.get('tac_overlap_add_f32') == 1, ran
+    assert ran.get('tac_melspectrogram_backward_ola_f32') == 1 and 'tac_overlap_add_f32' not in ran, ran
     assert rel_err(host(got), want.numpy()) < 1e-3
     assert 'tac_apply_filterbank_adjoint_f32' not in ran and 'tac_apply_filterbank_f32' not in ran and 'tac_stft_f32' not in ran, ran
     # ... also for short rows whose every unit gathers its samples, power 1 and a bank with few bands
@@ -1128,7 +1143,8 @@ def test_fft_length_400_trains_on_the_mixed_radix_kernels(tac):
         (want,) = torch.autograd.grad((want_m * torch.from_numpy(wg)).sum(), xe32)
         before = launches(tac)
         (got,) = torch.autograd.grad((mel_c.cuda()(xeg) * dev(wg)).sum(), xeg)
-        assert launched_since(tac, before).get('tac_melspectrogram_backward_f32') == 1, (pad_mode, hop)
+        assert launched_since(tac, before).get('tac_melspectrogram_backward_ola_f32' if hop % 4 == 0 else
+                                               'tac_melspectrogram_backward_f32') == 1, (pad_mode, hop)
         assert rel_err(host(got), want.numpy()) < 1e-3, (pad_mode, hop, mels, pw)
     # complex stft, an odd number of frames per unit, short window, not centred
     xs = signals.audio_like((2, 2, 2011), seed=334)

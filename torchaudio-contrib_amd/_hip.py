@@ -683,8 +683,15 @@ def melspectrogram_backward_fused(grad_mel, wave, window, fb, n_fft, hop, win_le
     more than two non-zero weights per bin): the caller then runs the two kernels."""
     if n_fft not in (400, 512, 1024, 2048) or fb.dim() != 2 or fb.shape[1] > (256 if n_fft == 2048 else 128) or MEL_PATH == 'mfma':
         return None
-    if n_fft == 400:
+    if n_fft == 400:        # overlap-add inside the kernel when the hop allows it, else frame gradients + the gather kernel
+        out = _melspectrogram_backward_ola(grad_mel, wave, window, fb, n_fft, hop, win_length, center, pad_mode, normalized, power)
+        if out is not None:
+            return out
         return _melspectrogram_backward_fused_n400(grad_mel, wave, window, fb, hop, win_length, center, pad_mode, normalized, power)
+    return _melspectrogram_backward_ola(grad_mel, wave, window, fb, n_fft, hop, win_length, center, pad_mode, normalized, power)
+
+
+def _melspectrogram_backward_ola(grad_mel, wave, window, fb, n_fft, hop, win_length, center, pad_mode, normalized, power):
     table = _adjoint_table(fb)
     if table is None:
         return None
@@ -768,7 +775,8 @@ def stft_backward(grad_spec, wave, window, n_fft, hop, win_length, center, pad_m
             gn = gn.float()
     out = torch.empty(tuple(wave.shape), dtype=torch.float32, device=wave.device)
     if gs is None and g.desc is not None:
-        # fft_length 2048, hop a multiple of 128: overlap-add inside the kernel (LDS), no frame gradients in memory
+        # fft_length 256 … 2048 with hop a multiple of fft_length / 16, fft_length 400 with hop a multiple of 4: overlap-add
+        # inside the kernel, no frame gradients in memory
         need = _native.lib().tac_spectrogram_backward_ola_workspace(g.desc)
         if need >= 0:
             work = torch.empty(max(int(need), 4) // 4, dtype=torch.float32, device=wave.device)
@@ -776,9 +784,10 @@ def stft_backward(grad_spec, wave, window, n_fft, hop, win_length, center, pad_m
                 rc = _native.lib().tac_spectrogram_backward_ola_f32(
                     _native.ptr(_rows_of(wave, g)), _native.ptr(window), g.desc, _native.ptr(gn), float(power),
                     _native.ptr(work), int(need), _native.ptr(out), g.length, _native.stream_ptr(wave.device))
-            _native.check(rc, 'tac_spectrogram_backward_ola_f32')
-            _count('tac_spectrogram_backward_ola_f32')
-            return out
+            if rc != _native.TAC_E_UNSUPPORTED:
+                _native.check(rc, 'tac_spectrogram_backward_ola_f32')
+                _count('tac_spectrogram_backward_ola_f32')
+                return out
     frames = torch.empty((g.rows, g.n_frames, n_fft), dtype=torch.float32, device=wave.device)
     desc = _native.StftDesc(rows=g.rows, length=g.length, row_stride=g.length, n_fft=n_fft, hop=hop,
                             win_length=win_length, center=1 if center else 0, pad_mode=_native.PAD_MODES[pad_mode],

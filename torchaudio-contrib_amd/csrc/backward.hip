@@ -18,6 +18,7 @@
 //   tac_apply_filterbank_adjoint_f32   the filterbank stage's adjoint for banks with <= 2 non-zero weights per bin (mel
 //                                banks); other banks: the forward GEMM with the transposed matrix (tac_apply_filterbank_f32).
 #include "host_common.hpp"
+#include "ola_plan.hpp"
 
 #include <algorithm>
 #include <type_traits>
@@ -25,7 +26,8 @@
 namespace tac {
 
 int launch_n400_backward(const FrameGeom& g, const float* gspec, const float* gnorm, float power, float* frames,
-                         hipStream_t stream, bool from_wave, const AdjEntry* adj = nullptr, int n_mels = 0);     // stft_n400.hip
+                         hipStream_t stream, bool from_wave, const AdjEntry* adj = nullptr, int n_mels = 0, float* gpad = nullptr,
+                         float* edge = nullptr, const OlaPlan* plan = nullptr);     // stft_n400.hip
 
 constexpr int BW_WAVES = 4;
 
@@ -252,31 +254,6 @@ stft_backward_kernel(FrameGeom g, Tables tb, const float* __restrict__ gspec, co
 // every value has exactly one writer, no atomics, deterministic.
 constexpr int OLA_WAVES = 4;
 constexpr int OLA_NC = 1024, OLA_E = 16, OLA_N = 2048;
-
-struct OlaPlan {
-    int seg_frames;       // S: frames per segment (>= (N - hop) / hop, so that a tail never reaches past the next segment)
-    int segs_per_row;
-    long long pad_len;    // floats per row of gpad (= length + 2·center_pad)
-    int n_fft;
-    int direct;           // the fft_length-2048 kernel stores the clean interior straight into the waveform gradient
-    float* gwave;         // ... here (row r at gwave + r * gstride)
-    long long gstride;
-};
-
-// Frame f's `hop` complete positions need nothing but themselves: they lie outside the border zone of their segment
-// (whose first N - hop positions still lack the previous segment's edge sums) and no sample among them has a reflect /
-// replicate / circular image or falls into the padding.  Such runs go straight into the waveform gradient; the fold
-// kernel only handles the rest (round 3: it used to copy the whole padded gradient, 0.064 ms at cfg-2).
-__device__ __forceinline__ bool ola_direct(const FrameGeom& g, const OlaPlan& plan, int f) {
-    if (!plan.direct) return false;
-    const int S = plan.seg_frames, hop = g.hop, pad = g.center_pad, L = (int)g.length;
-    const int sg = f / S;
-    if (sg > 0 && (f - sg * S) * hop < plan.n_fft - hop) return false;
-    const int jlo = f * hop - pad, jhi = jlo + hop - 1;
-    if (pad == 0 || g.pad_mode == PAD_CONSTANT) return jlo >= 0 && jhi < L;
-    return jlo > pad && jhi < L - 1 - pad;
-}
-
 
 // FUSE: `gnorm` is the gradient of the MEL values, (rows, T, n_mels) frame-major, and the filterbank adjoint
 // (grad_mel . fb^T, two multiply-adds per bin through `adj`) happens here, per frame, out of a 16 KB LDS table: the
@@ -899,10 +876,21 @@ fb_adjoint_kernel(const float* __restrict__ gmel, long long n_rows_frames, int n
 // segmentation of the LDS overlap-add form; TAC_E_UNSUPPORTED for geometries it does not cover
 static int ola_plan(const tac_stft_desc* d, const FrameGeom& g, OlaPlan* plan, int waves_per_cu = 2 * OLA_WAVES) {
     const int n = d->n_fft;
-    if (n != 2048 && n != 1024 && n != 512 && n != 256) return TAC_E_UNSUPPORTED;
-    if (!d->onesided || d->hop <= 0 || (d->hop % (n / 16)) || d->hop > n) return TAC_E_UNSUPPORTED;
+    if (n != 2048 && n != 1024 && n != 512 && n != 256 && n != 400) return TAC_E_UNSUPPORTED;
+    if (!d->onesided || d->hop <= 0 || d->hop > n) return TAC_E_UNSUPPORTED;
+    if (n == 400 ? ((d->hop & 3) || (g.center_pad & 3) || d->hop < 50) : (d->hop % (n / 16)) != 0) return TAC_E_UNSUPPORTED;
     if (g.length >= 0x7fffffffLL - 2 * n || g.n_frames < 1 || g.n_frames >= 0x7fffffffLL / n) return TAC_E_UNSUPPORTED;
     const int T = (int)g.n_frames;
+    if (n == 400) {                         // stft_n400_backward_kernel<.., OLA>: a segment is one unit of eight frames
+        plan->seg_frames = 8;
+        plan->segs_per_row = (T + 7) / 8;
+        plan->pad_len = g.length + 2LL * g.center_pad;
+        plan->n_fft = n;
+        plan->direct = 0;
+        plan->gwave = nullptr;
+        plan->gstride = 0;
+        return TAC_OK;
+    }
     const int s_min = std::max(1, (n - d->hop + d->hop - 1) / d->hop);
     // one segment per resident frame stream (a wave carries 2048 / n_fft of them)
     const long long target = (long long)device_cu_count() * waves_per_cu * (OLA_N / n);
@@ -1038,9 +1026,14 @@ static int ola_backward_entry(const float* wave, const float* window, const tac_
     float* edge = gpad + g.rows * plan.pad_len;
     plan.gwave = grad_wave;
     plan.gstride = grad_row_stride;
-    plan.direct = (d->n_fft == 2048 && (d->hop & 3) == 0 && (g.center_pad & 3) == 0) ? 1 : 0;
+    plan.direct = ((d->n_fft == 2048 || d->n_fft == 400) && (d->hop & 3) == 0 && (g.center_pad & 3) == 0) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     const bool pow2 = (power == 2.0f);
+    if (d->n_fft == 400) {
+        rc = launch_n400_backward(g, nullptr, grad, power, nullptr, s, true, adj, n_mels, gpad, edge, &plan);
+        if (rc != TAC_OK) return rc;
+    } else {
+    rc = TAC_OK;
     OlaFuse fz{nullptr, 0, 0, 16};
     auto launch = [&](auto kern, size_t lds_bytes, int streams_per_wave, int waves = OLA_WAVES) -> int {
         const long long nwork = (g.rows * (long long)plan.segs_per_row + streams_per_wave - 1) / streams_per_wave;
@@ -1192,6 +1185,7 @@ static int ola_backward_entry(const float* wave, const float* window, const tac_
             break;
         }
         default: return TAC_E_UNSUPPORTED;
+    }
     }
     if (rc != TAC_OK) return rc;
     // ~16 workgroups per CU in flight, each thread walking its row with a stride: rows on y, a row's samples on x

@@ -19,6 +19,7 @@
 // Reference: torchaudio_contrib/functional.py:48-113 (stft), :116-128 (complex_norm), :277-296 (amplitude_to_db).
 #include "host_common.hpp"
 #include "mel_lanes.hpp"
+#include "ola_plan.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -512,11 +513,17 @@ int pack_n400(const std::vector<float>& h, int n_freqs, int n_mels, float* wpack
 // MELADJ (SRC_WAVE only): `gnorm` is the gradient of the MEL values, (rows, T, n_mels) frame-major, and the filterbank adjoint
 // (two multiply-adds per bin through the 201-entry table `adj`, functional.py:183-184 transposed) is formed where the
 // gradient of |X|^p is needed: the 4 F bytes per frame that fb_adjoint_kernel writes and this kernel reads never exist.
-template <int SRC, bool POW2, bool MELADJ = false>
+// OLA (SRC_WAVE only; hop and centre padding multiples of 4, hop >= 50): the unit IS a segment of ola_plan.hpp — its eight
+// frame gradients are overlap-added out of the staging area: complete positions of clean frames go straight into the
+// waveform gradient, the segment's border zone to gpad, its tail to edge[row][segment] (ola_fold_kernel finishes those and
+// the padding images) — so neither the 1600 bytes of frame gradient per frame nor the gather kernel's pass over them exist.
+template <int SRC, bool POW2, bool MELADJ = false, bool OLA = false>
 __global__ void __launch_bounds__(Q4_WAVES * 64, 2)
 stft_n400_backward_kernel(FrameGeom g, Q4Tables tb, const float* __restrict__ gspec, const float* __restrict__ gnorm,
-                          float power, float* __restrict__ frames, const AdjEntry* __restrict__ adj = nullptr, int n_mels = 0) {
+                          float power, float* __restrict__ frames, const AdjEntry* __restrict__ adj, int n_mels,
+                          float* __restrict__ gpad, float* __restrict__ edge, OlaPlan plan) {
     static_assert(!MELADJ || SRC == SRC_WAVE, "the fused adjoint re-transforms the frames");
+    static_assert(!OLA || SRC == SRC_WAVE, "the in-kernel overlap-add serves the Spectrogram / Melspectrogram adjoints");
     constexpr int STAGE = Q4_STAGE;
     constexpr int ROWC = Q4_BINS;                                          // complex per staged gradient row
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -753,6 +760,40 @@ stft_n400_backward_kernel(FrameGeom g, Q4Tables tb, const float* __restrict__ gs
             for (int k = 0; k < Q4_M; ++k) fr[k] = cmul_elem(v[k], wn[k]);
         }
         wave_lds_fence();
+        if constexpr (OLA) {
+            // (4') overlap-add of the unit's frames: a lane owns four consecutive positions o .. o + 3 of the unit's span
+            // (hop, 400 and the padding are multiples of four: every frame covers all four or none, at a 16-byte offset)
+            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+            const q4_f4* s4 = reinterpret_cast<const q4_f4*>(wstage);
+            const int hop = g.hop, seg = unit - urow * upr, seg_span = Q4_G * hop, open = 400 - hop;
+            const int span = (nlive - 1) * hop + 400;
+            const int p0 = seg * seg_span;                                  // padded position of the unit's first sample
+            float* const prow = gpad + (long long)urow * plan.pad_len;
+            float* const erow = edge + ((long long)urow * (plan.segs_per_row - 1) + seg) * open;
+            float* const orow = plan.gwave + (long long)urow * plan.gstride;
+            const float inv_hop = 1.0f / (float)hop;
+            for (int o = 4 * lane; o < span; o += 256) {
+                q4_f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int q = 0; q < Q4_G; ++q) {
+                    const int n = o - q * hop;
+                    if (q < nlive && n >= 0 && n < 400) acc += s4[q * 100 + (n >> 2)];
+                }
+                f4u out4;
+                out4.x = acc.x; out4.y = acc.y; out4.z = acc.z; out4.w = acc.w;
+                if (o < seg_span) {
+                    const int qf = (int)(((float)o + 0.5f) * inv_hop);      // o / hop (exact: o < 2^13)
+                    const int p = p0 + o;
+                    const int fc = seg * Q4_G + qf;                         // (the fold kernel skips exactly these runs)
+                    if (fc < T && ola_direct(g, plan, fc)) *reinterpret_cast<f4u*>(orow + (p - g.center_pad)) = out4;
+                    else *reinterpret_cast<f4u*>(prow + p) = out4;
+                } else if (seg < plan.segs_per_row - 1) {
+                    *reinterpret_cast<f4u*>(erow + (o - seg_span)) = out4;
+                } else {
+                    *reinterpret_cast<f4u*>(prow + p0 + o) = out4;
+                }
+            }
+        } else {
         // (4) the live frames leave as 16-byte stores (a frame is 1600 bytes: the unit's run is 16-byte aligned)
         {
             const q4_f4* s4 = reinterpret_cast<const q4_f4*>(wstage);
@@ -764,6 +805,7 @@ stft_n400_backward_kernel(FrameGeom g, Q4Tables tb, const float* __restrict__ gs
                 if (c < nch) g4[c] = s4[c];
             }
         }
+        }
         wave_lds_fence();
         unit = nxt;
     }
@@ -771,11 +813,15 @@ stft_n400_backward_kernel(FrameGeom g, Q4Tables tb, const float* __restrict__ gs
 
 // tac_stft_backward_f32 / tac_stft_norm_backward_f32 for fft_length 400 (backward.hip's dispatcher calls this)
 int launch_n400_backward(const FrameGeom& g, const float* gspec, const float* gnorm, float power, float* frames,
-                         hipStream_t stream, bool from_wave, const AdjEntry* adj, int n_mels) {
+                         hipStream_t stream, bool from_wave, const AdjEntry* adj, int n_mels, float* gpad, float* edge,
+                         const OlaPlan* plan) {
     Q4Tables tb;
     const int rc = q4_tables(&tb);
     if (rc != TAC_OK) return rc;
-    if ((!from_wave && (reinterpret_cast<uintptr_t>(gspec) & 7u)) || (reinterpret_cast<uintptr_t>(frames) & 15u)) return TAC_E_UNSUPPORTED;
+    if ((!from_wave && (reinterpret_cast<uintptr_t>(gspec) & 7u)) || (!plan && (reinterpret_cast<uintptr_t>(frames) & 15u))) return TAC_E_UNSUPPORTED;
+    if (plan && (!from_wave || !gpad || !edge || plan->seg_frames != Q4_G || (g.hop & 3) || (g.center_pad & 3) || g.hop < 50 ||
+                 g.hop > 400 || !plan->gwave))
+        return TAC_E_UNSUPPORTED;
     const long long units = g.rows * ((g.n_frames + Q4_G - 1) / Q4_G);
     if (units >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
     if (adj && (!from_wave || n_mels < 1 || n_mels > 128)) return TAC_E_UNSUPPORTED;
@@ -784,8 +830,12 @@ int launch_n400_backward(const FrameGeom& g, const float* gspec, const float* gn
     long long blocks = (units + Q4_WAVES - 1) / Q4_WAVES;
     const long long cap = (long long)device_cu_count();
     if (blocks > cap) blocks = cap;
-    void (*kern)(FrameGeom, Q4Tables, const float*, const float*, float, float*, const AdjEntry*, int);
-    if (from_wave) {
+    void (*kern)(FrameGeom, Q4Tables, const float*, const float*, float, float*, const AdjEntry*, int, float*, float*, OlaPlan);
+    if (from_wave && plan) {
+        if (!gnorm) return TAC_E_INVALID;
+        if (adj) kern = power == 2.0f ? stft_n400_backward_kernel<SRC_WAVE, true, true, true> : stft_n400_backward_kernel<SRC_WAVE, false, true, true>;
+        else kern = power == 2.0f ? stft_n400_backward_kernel<SRC_WAVE, true, false, true> : stft_n400_backward_kernel<SRC_WAVE, false, false, true>;
+    } else if (from_wave) {
         if (!gnorm) return TAC_E_INVALID;
         if (adj) kern = power == 2.0f ? stft_n400_backward_kernel<SRC_WAVE, true, true> : stft_n400_backward_kernel<SRC_WAVE, false, true>;
         else kern = power == 2.0f ? stft_n400_backward_kernel<SRC_WAVE, true> : stft_n400_backward_kernel<SRC_WAVE, false>;
@@ -793,7 +843,7 @@ int launch_n400_backward(const FrameGeom& g, const float* gspec, const float* gn
     else kern = power == 2.0f ? stft_n400_backward_kernel<SRC_NORM, true> : stft_n400_backward_kernel<SRC_NORM, false>;
     if (bytes > 64 * 1024) TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Q4_WAVES * 64), bytes, stream, g, tb, gspec, gnorm, power, frames, adj,
-                       n_mels);
+                       n_mels, gpad, edge, plan ? *plan : OlaPlan{});
     TAC_HIP(hipGetLastError());
     return TAC_OK;
 }
