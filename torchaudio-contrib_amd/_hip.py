@@ -250,6 +250,9 @@ def spectrogram(wave, window, n_fft, hop, win_length, center, pad_mode, normaliz
     return out.transpose(-2, -1)
 
 
+#: test hook: gradient outputs start as NaN, so that a position no kernel writes cannot pass a comparison by luck
+POISON_OUTPUTS = False
+
 # A/B knob for the two fused Melspectrogram kernels: 'auto' (band-sparse when the bank allows it, else MFMA),
 # 'sparse', 'mfma'
 MEL_PATH = os.environ.get('TAC_MEL_PATH', 'auto')
@@ -707,6 +710,8 @@ def _melspectrogram_backward_ola(grad_mel, wave, window, fb, n_fft, hop, win_len
     if gm.dtype != torch.float32:
         gm = gm.float()
     out = torch.empty(tuple(wave.shape), dtype=torch.float32, device=wave.device)
+    if POISON_OUTPUTS:
+        out.fill_(float('nan'))
     work = torch.empty(max(int(need), 4) // 4, dtype=torch.float32, device=wave.device)
     with _native.on_device(wave.device):
         rc = _native.lib().tac_melspectrogram_backward_ola_f32(
@@ -774,6 +779,8 @@ def stft_backward(grad_spec, wave, window, n_fft, hop, win_length, center, pad_m
         if gn.dtype != torch.float32:
             gn = gn.float()
     out = torch.empty(tuple(wave.shape), dtype=torch.float32, device=wave.device)
+    if POISON_OUTPUTS:
+        out.fill_(float('nan'))
     if gs is None and g.desc is not None:
         # fft_length 256 … 2048 with hop a multiple of fft_length / 16, fft_length 400 with hop a multiple of 4: overlap-add
         # inside the kernel, no frame gradients in memory

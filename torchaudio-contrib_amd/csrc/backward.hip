@@ -580,18 +580,17 @@ spectrogram_backward_ola_multi_kernel(FrameGeom g, Tables tb, const float* __res
 
 // g_wave[row][j] = sum over the padded positions i with source(i) == j of P[row][i + pad], where
 // P = gpad + (inside a segment's first N - hop positions) the previous segment's edge sums; positions no frame covers are 0.
-__global__ void __launch_bounds__(256)
-ola_fold_kernel(FrameGeom g, const float* __restrict__ gpad, const float* __restrict__ edge, OlaPlan plan,
-                float* __restrict__ gwave, long long gwave_row_stride) {
+// Four consecutive samples j .. j + 3 of one row: where none of them has a padding image or straddles a segment-border zone
+// they move as one 16-byte access (global accesses need dword alignment only).
+// (s, o): segment and offset inside it of padded position j + pad — wave-uniform work for the caller that walks runs.
+__device__ __forceinline__ void ola_fold_quad(const FrameGeom& g, const OlaPlan& plan, const float* __restrict__ prow,
+                                              const float* __restrict__ erow, float* __restrict__ orow, int j, int s, int o) {
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
     const int L = (int)g.length, T = (int)g.n_frames;
     const int pad = g.center_pad, hop = g.hop;
     const int covered = (T - 1) * hop + plan.n_fft;        // positions [0, covered) are touched by some frame
     const int seg_span = plan.seg_frames * hop, open = plan.n_fft - hop, spr = plan.segs_per_row;
-    // grid: x over the samples of a row, y over rows — no division by L per sample, 32-bit positions.  A thread owns four
-    // consecutive samples; where none of them has a padding image or straddles a segment-border zone they move as one
-    // 16-byte access (global accesses need dword alignment only).
-    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-    auto one = [&](const float* prow, const float* erow, int j) -> float {
+    auto one = [&](int jj) -> float {
         float acc = 0.0f;
         auto add_position = [&](int i) {
             const int p = i + pad;
@@ -601,40 +600,163 @@ ola_fold_kernel(FrameGeom g, const float* __restrict__ gpad, const float* __rest
             if (s >= 1 && s < spr && o < open) v += erow[(long long)(s - 1) * open + o];
             acc += v;
         };
-        add_position(j);
+        add_position(jj);
         if (pad > 0) {
             if (g.pad_mode == PAD_REFLECT) {
-                if (j >= 1 && j <= pad) add_position(-j);
-                if (j <= L - 2 && j >= L - 1 - pad) add_position(2 * (L - 1) - j);
+                if (jj >= 1 && jj <= pad) add_position(-jj);
+                if (jj <= L - 2 && jj >= L - 1 - pad) add_position(2 * (L - 1) - jj);
             } else if (g.pad_mode == PAD_REPLICATE) {
-                if (j == 0) for (int i = -pad; i < 0; ++i) add_position(i);
-                if (j == L - 1) for (int i = L; i < L + pad; ++i) add_position(i);
+                if (jj == 0) for (int i = -pad; i < 0; ++i) add_position(i);
+                if (jj == L - 1) for (int i = L; i < L + pad; ++i) add_position(i);
             } else if (g.pad_mode == PAD_CIRCULAR) {
-                if (j >= L - pad) add_position(j - L);
-                if (j < pad) add_position(j + L);
+                if (jj >= L - pad) add_position(jj - L);
+                if (jj < pad) add_position(jj + L);
             }
         }
         return acc;
     };
+    const int p = j + pad;
+    const bool images = pad > 0 && (j <= pad || j + 3 >= L - 1 - pad);      // some sample has a padding image
+    const bool in_zone = s >= 1 && s < spr && o + 3 < open, out_zone = s < 1 || s >= spr || (o >= open && o + 3 < seg_span);
+    if (j + 3 < L && p + 3 < covered && !images && (in_zone || out_zone)) {
+        f4u v = *reinterpret_cast<const f4u*>(prow + p);
+        if (in_zone) v += *reinterpret_cast<const f4u*>(erow + (long long)(s - 1) * open + o);
+        *reinterpret_cast<f4u*>(orow + j) = v;
+    } else {
+        // up to three padded positions per sample (itself and its reflect / circular images): every address first, then all
+        // loads back to back — taken one sample at a time these were a chain of ~16 dependent memory round trips per thread,
+        // most of this kernel's time.  (replicate: the two end samples own `pad` images each and take the loop above)
+        int pos[4][3];
+        bool use[4][3], zone[4][3];
+        float val[4][3], edg[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int jj = j + u;
+            int cand[3] = {jj, 0, 0};
+            bool ok[3] = {jj < L, false, false};
+            if (pad > 0 && g.pad_mode == PAD_REFLECT) {
+                cand[1] = -jj;
+                ok[1] = jj >= 1 && jj <= pad;
+                cand[2] = 2 * (L - 1) - jj;
+                ok[2] = jj <= L - 2 && jj >= L - 1 - pad;
+            } else if (pad > 0 && g.pad_mode == PAD_CIRCULAR) {
+                cand[1] = jj - L;
+                ok[1] = jj >= L - pad;
+                cand[2] = jj + L;
+                ok[2] = jj < pad;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int pc = cand[c] + pad;
+                use[u][c] = jj < L && ok[c] && pc >= 0 && pc < covered;
+                pos[u][c] = use[u][c] ? pc : 0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int pc = pos[u][c];
+                const int sc = (int)((unsigned)pc / (unsigned)seg_span), oc = pc - sc * seg_span;
+                zone[u][c] = use[u][c] && sc >= 1 && sc < spr && oc < open;
+                val[u][c] = prow[pc];
+                const float* ea = zone[u][c] ? erow + ((long long)(sc - 1) * open + oc) : prow;
+                edg[u][c] = *ea;
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int jj = j + u;
+            if (jj >= L) break;
+            if (pad > 0 && g.pad_mode == PAD_REPLICATE && (jj == 0 || jj == L - 1)) {
+                orow[jj] = one(jj);
+                continue;
+            }
+            float acc = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (use[u][c]) acc += val[u][c] + (zone[u][c] ? edg[u][c] : 0.0f);
+            }
+            orow[jj] = acc;
+        }
+    }
+}
+
+// every sample of every row (grid: x over the samples of a row, y over rows — no division by L per sample, 32-bit positions)
+__global__ void __launch_bounds__(256)
+ola_fold_kernel(FrameGeom g, const float* __restrict__ gpad, const float* __restrict__ edge, OlaPlan plan,
+                float* __restrict__ gwave, long long gwave_row_stride) {
+    const int L = (int)g.length, T = (int)g.n_frames;
+    const int pad = g.center_pad, hop = g.hop;
+    const int open = plan.n_fft - hop, spr = plan.segs_per_row;
     for (long long row = blockIdx.y; row < g.rows; row += gridDim.y) {
         const float* prow = gpad + row * plan.pad_len;
         const float* erow = edge + row * (spr - 1) * open;
         float* orow = gwave + row * gwave_row_stride;
         for (int j = 4 * (int)(blockIdx.x * blockDim.x + threadIdx.x); j < L; j += 4 * (int)(gridDim.x * blockDim.x)) {
-            const int p = j + pad;
             if (plan.direct) {                               // already stored by the backward kernel (hop and pad are multiples of 4)
-                const int fc = p / hop;
+                const int fc = (j + pad) / hop;
                 if (fc < T && ola_direct(g, plan, fc)) continue;
             }
-            const int s = (int)((unsigned)p / (unsigned)seg_span), o = p - s * seg_span;
-            const bool images = pad > 0 && (j <= pad || j + 3 >= L - 1 - pad);      // some sample has a padding image
-            const bool in_zone = s >= 1 && s < spr && o + 3 < open, out_zone = s < 1 || s >= spr || (o >= open && o + 3 < seg_span);
-            if (j + 3 < L && p + 3 < covered && !images && (in_zone || out_zone)) {
-                f4u v = *reinterpret_cast<const f4u*>(prow + p);
-                if (in_zone) v += *reinterpret_cast<const f4u*>(erow + (long long)(s - 1) * open + o);
-                *reinterpret_cast<f4u*>(orow + j) = v;
-            } else {
-                for (int u = 0; u < 4 && j + u < L; ++u) orow[j + u] = one(prow, erow, j + u);
+            const int p = j + pad, seg_span = plan.seg_frames * hop;
+            const int s = (int)((unsigned)p / (unsigned)seg_span);
+            ola_fold_quad(g, plan, prow, erow, orow, j, s, p - s * seg_span);
+        }
+    }
+}
+
+// plan.direct: the backward kernel stored most runs itself — visit only the hop-runs it left (OlaRuns, host-computed):
+// the row's head and tail (padding images, the border of the frames' reach) and the first `zone_frames` runs of every segment
+// but the first.  Run k of a row -> frame slot fc; a thread owns four samples of one run.
+struct OlaRuns {
+    int head;          // runs 0 .. head - 1
+    int tail_first;    // runs tail_first .. last_run
+    int last_run;
+    int zone_frames;   // ceil((N - hop) / hop)
+};
+
+__global__ void __launch_bounds__(256)
+ola_fold_runs_kernel(FrameGeom g, const float* __restrict__ gpad, const float* __restrict__ edge, OlaPlan plan, OlaRuns runs,
+                     int zone_blocks, float* __restrict__ gwave, long long gwave_row_stride) {
+    // rows on grid y.  Blocks [0, zone_blocks): the segments' border zones, one thread per quad (one integer division per
+    // thread; a zone whose runs are all clean — no padding image, inside the row and the frames' reach — is two loads and a
+    // store).  Blocks behind them: one wave per head / tail run (frame slot, segment and offset wave-uniform).  The first
+    // version — one thread per quad of ANY run with three divisions and the general path — was instruction-bound (25 us at
+    // cfg-2); one wave per zone was latency-bound on its many tiny waves (50 us at fft_length 400).
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    const int L = (int)g.length, pad = g.center_pad, hop = g.hop;
+    const int open = plan.n_fft - hop, spr = plan.segs_per_row, quads = hop >> 2, S = plan.seg_frames;
+    const int n_tail = runs.last_run + 1 - runs.tail_first;
+    const int nq = runs.zone_frames * quads;                                 // quads per zone (< n_fft / 4)
+    const bool quad_aligned = (open & 3) == 0;                               // no quad straddles the end of the zone
+    for (long long row = blockIdx.y; row < g.rows; row += gridDim.y) {
+        const float* prow = gpad + row * plan.pad_len;
+        const float* erow = edge + row * (spr - 1) * open;
+        float* orow = gwave + row * gwave_row_stride;
+        if ((int)blockIdx.x < zone_blocks) {
+            const unsigned total = (unsigned)(spr - 1) * (unsigned)nq;
+            for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += (unsigned)zone_blocks * 256u) {
+                const int z = (int)(idx / (unsigned)nq), q = (int)(idx - (unsigned)z * (unsigned)nq);
+                const int s = z + 1, first = s * S, o = 4 * q, p = first * hop + o;
+                if (quad_aligned && first >= runs.head && first + runs.zone_frames <= runs.tail_first) {
+                    f4u v = *reinterpret_cast<const f4u*>(prow + p);
+                    if (o + 3 < open) v += *reinterpret_cast<const f4u*>(erow + (long long)(s - 1) * open + o);
+                    *reinterpret_cast<f4u*>(orow + (p - pad)) = v;
+                } else {
+                    const int fc = first + q / quads, j = p - pad;
+                    if (fc < runs.head || fc >= runs.tail_first || j < 0 || j >= L) continue;   // (head / tail runs: below)
+                    ola_fold_quad(g, plan, prow, erow, orow, j, s, o);
+                }
+            }
+        } else {
+            const int lane = threadIdx.x & 63;
+            const int k = ((int)blockIdx.x - zone_blocks) * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+            if (k >= runs.head + n_tail) continue;
+            const int fc = k < runs.head ? k : runs.tail_first + (k - runs.head);
+            const int s = fc / S, o0 = (fc - s * S) * hop;
+            for (int i = lane; i < quads; i += 64) {
+                const int j = fc * hop + 4 * i - pad;
+                if (j < 0 || j >= L) continue;
+                ola_fold_quad(g, plan, prow, erow, orow, j, s, o0 + 4 * i);
             }
         }
     }
@@ -1188,12 +1310,34 @@ static int ola_backward_entry(const float* wave, const float* window, const tac_
     }
     }
     if (rc != TAC_OK) return rc;
-    // ~16 workgroups per CU in flight, each thread walking its row with a stride: rows on y, a row's samples on x
     const unsigned fold_y = (unsigned)std::min<long long>(g.rows, 65535);
     const long long per_row = std::max<long long>(1, (long long)device_cu_count() * 16 / fold_y);
-    const unsigned fold_x = (unsigned)std::min<long long>((g.length + 1023) / 1024, per_row);
-    hipLaunchKernelGGL(ola_fold_kernel, dim3(fold_x, fold_y), dim3(256), 0, s, g, gpad, edge, plan, grad_wave,
-                       (long long)grad_row_stride);
+    if (plan.direct && g.length + g.center_pad < 0x40000000LL) {
+        // only the runs the backward kernel did not store itself (the complement of ola_direct(); the gradient tests run
+        // with NaN-filled outputs, so a run nobody writes cannot pass)
+        const int hop = d->hop, pad = g.center_pad, L = (int)g.length, Tn = (int)g.n_frames;
+        const bool plain = pad == 0 || g.pad_mode == PAD_CONSTANT;
+        OlaRuns runs;
+        runs.last_run = (L + pad - 1) / hop;
+        int f_lo = plain ? (pad + hop - 1) / hop : (2 * pad) / hop + 1;                     // first clean run
+        const int f_hi = plain ? (L + pad - hop >= 0 ? (L + pad - hop) / hop : -1) : (L - 1 - hop >= 0 ? (L - 1 - hop) / hop : -1);
+        f_lo = std::min(f_lo, runs.last_run + 1);
+        runs.head = f_lo;
+        runs.tail_first = std::max(f_lo, std::min(f_hi, Tn - 1) + 1);
+        runs.zone_frames = (plan.n_fft - hop + hop - 1) / hop;
+        const int ht_blocks = (runs.head + (runs.last_run + 1 - runs.tail_first) + 3) / 4;
+        const long long zone_quads = (long long)(plan.segs_per_row - 1) * runs.zone_frames * (hop >> 2);
+        if (zone_quads >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
+        const int zone_blocks = (int)std::min<long long>((zone_quads + 255) / 256, 2 * per_row);
+        if (ht_blocks + zone_blocks > 0)
+            hipLaunchKernelGGL(ola_fold_runs_kernel, dim3((unsigned)(zone_blocks + ht_blocks), fold_y), dim3(256), 0, s, g, gpad, edge,
+                               plan, runs, zone_blocks, grad_wave, (long long)grad_row_stride);
+    } else {
+        // ~16 workgroups per CU in flight, each thread walking its row with a stride: rows on y, a row's samples on x
+        const unsigned fold_x = (unsigned)std::min<long long>((g.length + 1023) / 1024, per_row);
+        hipLaunchKernelGGL(ola_fold_kernel, dim3(fold_x, fold_y), dim3(256), 0, s, g, gpad, edge, plan, grad_wave,
+                           (long long)grad_row_stride);
+    }
     TAC_HIP(hipGetLastError());
     return TAC_OK;
 }
