@@ -985,8 +985,12 @@ def backward_recomputes_spectrum(n_fft):
 def complex_norm_backward(z, grad_out, power):
     """(*, F, T, 2) pairs and (*, F, T) gradients in, (*, F, T, 2) out — all walked in z's dense storage order."""
     z = _pairs(z)
-    go = torch.empty_strided(z.shape[:-1], tuple(s // 2 for s in z.stride()[:-1]), dtype=torch.float32, device=z.device)
-    go.copy_(grad_out)
+    want = tuple(s // 2 for s in z.stride()[:-1])
+    if grad_out.dtype == torch.float32 and grad_out.shape == z.shape[:-1] and grad_out.stride() == want:
+        go = grad_out                                                 # already in z's storage order: no copy
+    else:
+        go = torch.empty_strided(z.shape[:-1], want, dtype=torch.float32, device=z.device)
+        go.copy_(grad_out)
     gz = torch.empty_strided(z.shape, z.stride(), dtype=torch.float32, device=z.device)
     n = go.numel()
     if n:
@@ -1000,8 +1004,11 @@ def complex_norm_backward(z, grad_out, power):
 
 def amplitude_to_db_backward(x, grad_out, amin):
     x = x if is_dense(x) else x.contiguous()
-    go = torch.empty_like(x)
-    go.copy_(grad_out)
+    if grad_out.dtype == torch.float32 and grad_out.shape == x.shape and grad_out.stride() == x.stride():
+        go = grad_out                                                 # already in x's storage order: no copy
+    else:
+        go = torch.empty_like(x)
+        go.copy_(grad_out)
     gx = torch.empty_like(x)
     if x.numel():
         with _native.on_device(x.device):
