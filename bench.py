@@ -268,7 +268,9 @@ def run(a):
         e1, ms1, _ = timed(one, a.steps)
         result['single_buffer'] = {'value': frames_per_step * a.steps / e1, 'ms_per_step': e1 / a.steps * 1e3,
                                    'kernel_ms_mean': ms1,
-                                   'note': 'same steps on one re-read input batch (Infinity-Cache resident)'}
+                                   'frac_of_hbm_peak': alg_bytes / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   'note': 'same steps on one re-read input batch (Infinity-Cache resident): the figure '
+                                           'rounds 1 and 2 reported as roofline.frac'}
 
     # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in
     # separate passes, gfx950 x2 FETCH correction applied — tools/summarize_profiles.py); bench.py cannot run the

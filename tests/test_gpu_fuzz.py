@@ -259,3 +259,36 @@ def test_fuzz_gradients_overlap_add_in_lds(tac):
         assert ran.get(entry) == 1 and 'tac_overlap_add_f32' not in ran, (tag, ran)
         assert entry == 'tac_spectrogram_backward_ola_f32' or 'tac_apply_filterbank_adjoint_f32' not in ran, (tag, ran)
         assert rel_err(host(got), want.numpy()) < (1e-3 if kind in ('mel_db', 'magnitude') else 1e-4), tag
+
+
+def test_fuzz_float64_chain(tac):
+    """csrc/chain_f64.hip over random STFT arguments and sizes of every kind its plan distinguishes (radix-4 only, with a
+    radix-2 / 3 / 5 pass, 8192 = twiddles from global memory, direct transform for odd lengths and halves with a prime
+    factor above 5) against the float64 oracle: complex STFT, |X|^p (+ dB) and the mel chain; launch counters assert the
+    float64 kernels ran."""
+    rng = np.random.default_rng(8000 + SEED)
+    sizes = [8, 12, 64, 100, 128, 256, 400, 480, 512, 1000, 1024, 2048, 4096, 6000, 8192, 77, 134, 331, 1202]
+    for case in range(max(12, CASES // 2)):
+        n, hop, win_length, center, pad_mode, lead, length = draw_stft_args(rng, sizes, max_rows=3, max_len_factor=5)
+        hop = max(hop, n // 16)                                          # (keeps the direct-transform cases small)
+        normalized, onesided = bool(rng.random() < 0.3), bool(rng.random() < 0.7)
+        x = signals.audio_like(lead + (length,), seed=5500 + case + 7919 * SEED).astype(np.float64)
+        x += 1e-9 * np.random.default_rng(case).standard_normal(x.shape)   # bits below float32
+        window = torch.from_numpy(signals.uniform((win_length,), seed=6500 + case).astype(np.float64) * 0.5 + 0.75)
+        kw = dict(win_length=win_length, center=center, pad_mode=pad_mode, normalized=normalized)
+        tag = ('f64', case, n, hop, kw, onesided, lead, length)
+        before = dict(tac._hip.launches)
+        want = torch_ref.stft(torch.from_numpy(x), n, hop, window=window, onesided=onesided, **kw).numpy()
+        got = host(tac.stft(dev(x), n, hop_length=hop, window=window.cuda(), onesided=onesided, **kw))
+        assert got.dtype == np.float64 and got.shape == want.shape, tag
+        assert np.abs(got - want).max() <= 2e-12 * max(np.abs(want).max(), 1e-300), tag
+        power = float(rng.choice([1.0, 2.0, 0.7]))
+        mels = int(rng.choice([5, 40, 80]))
+        bank = torch.from_numpy(signals.uniform((n // 2 + 1, mels), seed=6600 + case).astype(np.float64))
+        z = torch_ref.stft(torch.from_numpy(x), n, hop, window=window, **kw)
+        want_m = torch_ref.amplitude_to_db(torch_ref.apply_filterbank(torch_ref.complex_norm(z, power), bank)).numpy()
+        got_m = host(torch.ops.tac_amd.melspectrogram(dev(x), window.cuda(), bank.cuda(), n, hop, win_length, center, pad_mode,
+                                                      normalized, True, power, True, 1.0, 1e-7))
+        assert got_m.dtype == np.float64 and np.abs(got_m - want_m).max() < 1e-8, tag
+        ran = {k: v - before.get(k, 0) for k, v in tac._hip.launches.items() if v != before.get(k, 0)}
+        assert ran == {'tac_stft_f64': 1, 'tac_spectrogram_f64': 1, 'tac_apply_filterbank_f64': 1}, (tag, ran)
