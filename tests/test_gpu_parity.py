@@ -1531,6 +1531,12 @@ def test_coded_waveforms_fused_into_the_frame_load(tac, golden):
         wave = tac.MuLawDecoding(256)(codes.cuda()) + 0.0
         assert np.abs(host(got) - host(chain[1:](wave))).max() < 1e-4
         assert np.abs(host(chain(codes.to(dtype).cuda()[..., 3:])) - host(chain[1:](wave[..., 3:].contiguous()))).max() < 1e-4
+    # rows shorter than a frame (every frame gathers): the coded kernels decline, the chain converts first — same values
+    tiny = (signals.audio_like((2, 1, 333), seed=64) * 20000).astype(np.int16)
+    for n_fft, hop in ((400, 160), (512, 128)):
+        chain = torch.nn.Sequential(*tac.Melspectrogram(num_mels=40, sample_rate=16000, fft_length=n_fft, hop_length=hop),
+                                    tac.AmplitudeToDb()).cuda()
+        assert np.abs(host(chain(dev(tiny))) - host(chain(dev(tiny.astype(np.float32) / 32768.0)))).max() < 1e-4, n_fft
     z = tac.stft(dev(pcm), 512, 128)                                    # no coded frame load there: converted by a kernel first
     assert rel_err(host(z), host(tac.stft(dev(pcm.astype(np.float32) / 32768.0), 512, 128))) < 1e-6
 
