@@ -31,12 +31,16 @@ xm = torch.rand(1024, 1, 120000, device='cuda') * 2 - 1
 codes = tac.mu_law_encoding(xm, 256)
 stft400 = tac.STFT(400, 160).cuda()
 spec400 = tac.Spectrogram(400, 160, power=2.).cuda()
+x4k = torch.rand(64, 1, 480000, device='cuda') * 2 - 1
+p4k = tac.Spectrogram(4096, 1024, power=2.).cuda()(x4k)             # (64,1,2049,469)
+fb4k = tac.create_mel_filter(2049, 128, 0.0, 22050.0, False).cuda()
 cases = [
     ('STFT n_fft=400 hop=160 (mixed radix)', lambda: tac.realize(stft400(x)), x.numel() * 4 + 256 * 1001 * 201 * 8),
     ('Spectrogram n_fft=400 (mixed radix)', lambda: spec400(x), x.numel() * 4 + 256 * 1001 * 201 * 4),
     ('complex_norm (power 2)', lambda: tac.complex_norm(z, 2.0), z.numel() * 4 + z.numel() * 2),
     ('magphase', lambda: tac.magphase(z, 1.0), z.numel() * 4 + z.numel() * 4),
     ('apply_filterbank 1025x128', lambda: tac.apply_filterbank(p, fb), p.numel() * 4 + p.numel() // 1025 * 128 * 4),
+    ('apply_filterbank 2049x128 (4096 rows)', lambda: tac.apply_filterbank(p4k, fb4k), p4k.numel() * 4 + p4k.numel() // 2049 * 128 * 4),
     ('amplitude_to_db', lambda: tac.amplitude_to_db(p), p.numel() * 8),
     ('db_to_amplitude', lambda: tac.db_to_amplitude(p), p.numel() * 8),
     ('phase_vocoder rate 1.3', lambda: tac.phase_vocoder(z, 1.3, adv), z.numel() * 4 + int(z.numel() / 1.3) * 4),
@@ -52,4 +56,4 @@ for name, fn, nbytes in cases:
     if only and not any(o in name for o in only):
         continue
     ms = steady(fn)
-    print('%-28s %.4f ms   %7.1f MB   %5.2f TB/s  (%.0f %% of 8 TB/s)' % (name, ms, nbytes / 1e6, nbytes / ms / 1e9, 100 * nbytes / ms / 1e9 / 8))
+    print('%-38s %.4f ms   %7.1f MB   %5.2f TB/s  (%.0f %% of 8 TB/s)' % (name, ms, nbytes / 1e6, nbytes / ms / 1e9, 100 * nbytes / ms / 1e9 / 8))
