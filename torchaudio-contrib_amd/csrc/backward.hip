@@ -857,14 +857,23 @@ complex_norm_backward_kernel(const float* __restrict__ z, const float* __restric
         *reinterpret_cast<cf*>(gz + 2 * i) = norm_pow_grad(*reinterpret_cast<const cf*>(z + 2 * i), gout[i], power);
 }
 
-// d/dx of 10 (log10(clamp(x^2, amin)) - log10 ref) (functional.py:291-296): 20 / (ln 10 * x) where x^2 >= amin, else 0
+// d/dx of 10 (log10(clamp(x^2, amin)) - log10 ref) (functional.py:291-296): 20 / (ln 10 * x) where x^2 >= amin, else 0.
+// VEC: 16 bytes per lane and stream (all three pointers 16-byte aligned; the tail runs scalar).
+template <bool VEC>
 __global__ void __launch_bounds__(256)
 amplitude_to_db_backward_kernel(const float* __restrict__ x, const float* __restrict__ gout, long long n, float amin,
                                 float* __restrict__ gx) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const float v = x[i];
-        gx[i] = (v * v >= amin) ? gout[i] * (8.6858896380650366f / v) : 0.0f;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    auto one = [&](float v, float g) { return (v * v >= amin) ? g * (8.6858896380650366f / v) : 0.0f; };
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long long)gridDim.x * blockDim.x;
+    const long long n4 = VEC ? n >> 2 : 0;
+    for (long long i = tid; i < n4; i += nth) {
+        const f4 v = reinterpret_cast<const f4*>(x)[i], g = reinterpret_cast<const f4*>(gout)[i];
+        f4 r;
+        r.x = one(v.x, g.x); r.y = one(v.y, g.y); r.z = one(v.z, g.z); r.w = one(v.w, g.w);
+        reinterpret_cast<f4*>(gx)[i] = r;
     }
+    for (long long i = 4 * n4 + tid; i < n; i += nth) gx[i] = one(x[i], gout[i]);
 }
 
 template <int NC, int E>
@@ -1421,8 +1430,13 @@ int tac_amplitude_to_db_backward_f32(const float* x, const float* grad_out, int6
     using namespace tac;
     if (n == 0) return TAC_OK;
     if (!x || !grad_out || !grad_x || n < 0) return TAC_E_INVALID;
-    hipLaunchKernelGGL(amplitude_to_db_backward_kernel, dim3(bw_blocks(n)), dim3(256), 0, (hipStream_t)stream, x,
-                       grad_out, (long long)n, amin, grad_x);
+    const bool vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(grad_x)) & 15u) == 0;
+    if (vec)
+        hipLaunchKernelGGL(amplitude_to_db_backward_kernel<true>, dim3(bw_blocks((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
+                           grad_out, (long long)n, amin, grad_x);
+    else
+        hipLaunchKernelGGL(amplitude_to_db_backward_kernel<false>, dim3(bw_blocks(n)), dim3(256), 0, (hipStream_t)stream, x,
+                           grad_out, (long long)n, amin, grad_x);
     TAC_HIP(hipGetLastError());
     return TAC_OK;
 }
