@@ -361,3 +361,81 @@ def test_float64_size_coverage_matches_the_kernel_plan(tac):
     h64 = tac._ops.H64
     assert all(h64.covers(n) for n in (1, 4, 77, 134, 400, 2048, 4096, 6000, 8192, 5000))
     assert not any(h64.covers(n) for n in (4097, 8190, 8194, 16384, 4099 * 2))
+
+
+_OLA_RUNS_CHECK = r"""
+#include "ola_runs.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <set>
+#include <vector>
+// ola_direct() of csrc/ola_plan.hpp restated (it is device code): run f of a row was stored by the backward kernel itself
+static bool direct(int f, int S, int hop, int pad, int L, int T, int open, bool plain) {
+    if (f >= T) return false;
+    const int sg = f / S;
+    if (sg > 0 && (f - sg * S) * hop < open) return false;
+    const int jlo = f * hop - pad, jhi = jlo + hop - 1;
+    if (plain) return jlo >= 0 && jhi < L;
+    return jlo > pad && jhi < L - 1 - pad;
+}
+int main() {
+    srand(7);
+    int bad = 0, cases = 0;
+    const int sizes[5] = {2048, 1024, 512, 400, 256};
+    for (int it = 0; it < 6000; ++it) {
+        const int n = sizes[rand() % 5];
+        const int hop = n == 400 ? 4 * (13 + rand() % 88) : (n / 16) * (1 + rand() % 16);
+        if (hop % 4) continue;
+        const bool center = rand() % 10 < 7, plain_mode = rand() % 2;
+        const int pad = center ? n / 2 : 0;
+        const bool plain = pad == 0 || plain_mode;
+        const int L = n + 1 + rand() % (60 * hop);
+        const int T = 1 + (L + 2 * pad - n) / hop;
+        const int open = n - hop, smin = open > 0 ? (open + hop - 1) / hop : 1;
+        const int S = n == 400 ? 8 : smin + rand() % 10;
+        if (S < smin || T < 1) continue;
+        const int spr = (T + S - 1) / S;
+        std::set<int> want;
+        for (int j = 0; j < L; ++j)
+            if (!direct((j + pad) / hop, S, hop, pad, L, T, open, plain)) want.insert(j);
+        const tac::OlaRuns r = tac::ola_runs_for(L, pad, hop, n, T, plain);
+        std::vector<int> got;
+        auto emit = [&](int fc) {
+            for (int i = 0; i < hop; ++i) {
+                const int j = fc * hop + i - pad;
+                if (j >= 0 && j < L) got.push_back(j);
+            }
+        };
+        for (int fc = 0; fc < r.head; ++fc) emit(fc);                       // ola_fold_runs_kernel's three kinds of slots
+        for (int fc = r.tail_first; fc <= r.last_run; ++fc) emit(fc);
+        for (int s = 1; s < spr; ++s)
+            for (int q = 0; q < r.zone_frames; ++q) {
+                const int fc = s * S + q;
+                if (fc >= r.head && fc < r.tail_first) emit(fc);
+            }
+        std::set<int> uniq(got.begin(), got.end());
+        ++cases;
+        if (uniq.size() != got.size() || uniq != want) {
+            ++bad;
+            if (bad < 5) printf("n=%d hop=%d L=%d pad=%d plain=%d S=%d: got %zu (%zu unique), want %zu\n", n, hop, L, pad, (int)plain, S,
+                                got.size(), uniq.size(), want.size());
+        }
+    }
+    printf("cases=%d bad=%d\n", cases, bad);
+    return bad != 0 || cases < 3000;
+}
+"""
+
+
+def test_fold_kernel_visits_exactly_what_the_backward_kernels_left(tmp_path):
+    """csrc/ola_runs.hpp (plain C++, used by the host launch code of backward.hip): the head / tail / border-zone runs the fold
+    kernel walks are exactly the samples ola_direct() says the overlap-adding backward kernels did not store themselves — no
+    sample missed, none visited twice — over random fft sizes, hops, lengths, paddings and segment lengths.  (On the device
+    the gradient tests run with NaN-filled outputs for the same reason.)"""
+    src = tmp_path / 'runs.cpp'
+    src.write_text(_OLA_RUNS_CHECK)
+    exe = str(tmp_path / 'runs')
+    subprocess.run(['g++', '-O1', '-std=c++17', '-I', os.path.join(ROOT, 'torchaudio-contrib_amd', 'csrc'), '-o', exe, str(src)],
+                   check=True)
+    out = subprocess.run([exe], stdout=subprocess.PIPE, text=True)
+    assert out.returncode == 0 and out.stdout.strip().endswith('bad=0'), out.stdout

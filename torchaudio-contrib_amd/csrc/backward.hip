@@ -19,6 +19,7 @@
 //                                banks); other banks: the forward GEMM with the transposed matrix (tac_apply_filterbank_f32).
 #include "host_common.hpp"
 #include "ola_plan.hpp"
+#include "ola_runs.hpp"
 
 #include <algorithm>
 #include <type_traits>
@@ -707,13 +708,6 @@ ola_fold_kernel(FrameGeom g, const float* __restrict__ gpad, const float* __rest
 // plan.direct: the backward kernel stored most runs itself — visit only the hop-runs it left (OlaRuns, host-computed):
 // the row's head and tail (padding images, the border of the frames' reach) and the first `zone_frames` runs of every segment
 // but the first.  Run k of a row -> frame slot fc; a thread owns four samples of one run.
-struct OlaRuns {
-    int head;          // runs 0 .. head - 1
-    int tail_first;    // runs tail_first .. last_run
-    int last_run;
-    int zone_frames;   // ceil((N - hop) / hop)
-};
-
 __global__ void __launch_bounds__(256)
 ola_fold_runs_kernel(FrameGeom g, const float* __restrict__ gpad, const float* __restrict__ edge, OlaPlan plan, OlaRuns runs,
                      int zone_blocks, float* __restrict__ gwave, long long gwave_row_stride) {
@@ -1326,14 +1320,7 @@ static int ola_backward_entry(const float* wave, const float* window, const tac_
         // with NaN-filled outputs, so a run nobody writes cannot pass)
         const int hop = d->hop, pad = g.center_pad, L = (int)g.length, Tn = (int)g.n_frames;
         const bool plain = pad == 0 || g.pad_mode == PAD_CONSTANT;
-        OlaRuns runs;
-        runs.last_run = (L + pad - 1) / hop;
-        int f_lo = plain ? (pad + hop - 1) / hop : (2 * pad) / hop + 1;                     // first clean run
-        const int f_hi = plain ? (L + pad - hop >= 0 ? (L + pad - hop) / hop : -1) : (L - 1 - hop >= 0 ? (L - 1 - hop) / hop : -1);
-        f_lo = std::min(f_lo, runs.last_run + 1);
-        runs.head = f_lo;
-        runs.tail_first = std::max(f_lo, std::min(f_hi, Tn - 1) + 1);
-        runs.zone_frames = (plan.n_fft - hop + hop - 1) / hop;
+        const OlaRuns runs = ola_runs_for(L, pad, hop, plan.n_fft, Tn, plain);
         const int ht_blocks = (runs.head + (runs.last_run + 1 - runs.tail_first) + 3) / 4;
         const long long zone_quads = (long long)(plan.segs_per_row - 1) * runs.zone_frames * (hop >> 2);
         if (zone_quads >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
