@@ -186,8 +186,9 @@ int tac_phase_vocoder_f64(const double* spec, int64_t rows, int32_t n_freqs, int
                           const double* alpha, int64_t n_out, double* out, void* stream);
 
 /* (1d)-(6d) The path in float64 (the reference keeps f64 -> f64: functional.py:48-113, :116-128, :172-184, :187-201,
- *      :277-314).  Same argument meaning as the _f32 entry points with double data; d->n_fft: a power of two in
- *      [8, 8192] (N/2-point complex Stockham transform per workgroup in LDS) or any length <= 4096 (direct transform);
+ *      :277-314).  Same argument meaning as the _f32 entry points with double data; d->n_fft: any even length <= 8192 whose
+ *      half is 5-smooth (N/2-point mixed-radix complex Stockham transform per workgroup in LDS), or any other length
+ *      <= 4096 (direct O(N^2) transform per frame: meant for short odd sizes, see _hip64.py for the sizes Python routes there);
  *      tac_apply_filterbank_f64 takes the dense bank (no plan) and optionally applies amplitude_to_db to its result;
  *      tac_magphase_f64: mag and / or phase may be NULL (complex_norm / angle alone). */
 int tac_stft_f64(const double* wave, const double* window, const tac_stft_desc* d, double* out, void* stream);
@@ -319,6 +320,16 @@ int tac_amplitude_to_db_backward_f32(const float* x, const float* grad_out, int6
 int tac_hpss_f32(const float* mag, int64_t rows, int32_t n_freqs, int32_t n_frames, int64_t stride_r,
                  int64_t stride_f, int64_t stride_t, int32_t kernel_f, int32_t kernel_t, float power,
                  int hard, float* harm, float* perc, float* mask_harm, float* mask_perc, void* stream);
+
+/* (11) Diagnostics (bench.py's roofline object; no effect on results).
+ *      tac_last_route: name of the kernel instantiation the calling thread's last fused-chain launch (3b / 3c at fft_length
+ *        2048) took, as rocprofv3 prints it, e.g. "melspec_stream3_kernel<1024, 16, true, 0, 14, 12>" ("" before any).
+ *      tac_debug_clock_probe: while `buf` (DEVICE uint64[2 * capacity_pairs]) is set for the calling thread, every workgroup
+ *        b < capacity_pairs of those launches records buf[2b] = shader cycles (s_memtime) and buf[2b + 1] = ticks of the
+ *        100 MHz constant clock (s_memrealtime) its wave 0 spent in the frame loop: cycles / ticks x 100 MHz is the shader
+ *        clock the kernel actually ran at.  NULL clears it.  Four scalar instructions and one 16-byte store per workgroup. */
+const char* tac_last_route(void);
+int tac_debug_clock_probe(uint64_t* buf, int32_t capacity_pairs);
 
 #ifdef __cplusplus
 }

@@ -28,8 +28,20 @@ def test_library_exports_every_declared_symbol(tac):
     for name in declared:
         assert hasattr(h, name), name
     assert sorted(tac._native.EXPORTS) == declared
-    assert h.tac_abi_version() == 2
+    assert h.tac_abi_version() == tac._native.ABI_VERSION == 3
     assert h.tac_strerror(-3).decode().startswith('input too short')
+    # diagnostics (11): no launch yet on this thread, an empty probe is refused, NULL clears
+    assert isinstance(h.tac_last_route(), bytes)
+    assert h.tac_debug_clock_probe(ctypes.c_void_p(8), 0) == tac._native.TAC_E_INVALID
+    assert h.tac_debug_clock_probe(None, 0) == tac._native.TAC_OK
+
+
+def test_stale_library_is_refused(tac, monkeypatch):
+    """A libtac_amd.so built from older sources fails the ABI check when it is loaded, not at the first missing symbol."""
+    monkeypatch.setattr(tac._native, '_lib', None)
+    monkeypatch.setattr(tac._native, 'ABI_VERSION', 99)
+    with pytest.raises(tac._native.NativeLibraryError, match='ABI version 3'):
+        tac._native.lib()
 
 
 def test_geometry_helpers(tac):
@@ -254,6 +266,20 @@ assert torch.equal(ShardedPipeline(mel, gather=True)(wave), mel(wave))
 # a 2-D transposed local (M, T) view: dim 0 is not the physical dim 0, so it must not take the transposed fast path
 mt = torch.arange(6 * 5, dtype=torch.float32).reshape(5, 6).t()[2 * rank:2 * rank + 2]       # rows of a (6, 5) view
 assert torch.equal(all_gather_batch(mt, total_rows=4), torch.arange(30, dtype=torch.float32).reshape(5, 6).t()[:4])
+# the one-shot direct exchange (every rank sends its shard to each peer in one batched group of sends / receives): same results
+assert torch.equal(all_gather_batch(view, total_rows=5, method='p2p'), whole)                    # uneven, strided view
+assert torch.equal(all_gather_batch(shard_batch(even).clone(), total_rows=4, method='p2p'), even)
+assert torch.equal(all_gather_batch(mt, total_rows=4, method='p2p'), torch.arange(30, dtype=torch.float32).reshape(5, 6).t()[:4])
+os.environ['TAC_ALLGATHER'] = 'p2p'
+assert torch.equal(ShardedPipeline(torch.nn.Identity(), gather=True)(one), one)                  # a rank with zero rows
+assert torch.equal(ShardedPipeline(mel, gather=True)(wave), mel(wave))
+os.environ['TAC_ALLGATHER'] = 'ring'
+try:
+    all_gather_batch(view, total_rows=5)
+    raise SystemExit('an unknown TAC_ALLGATHER must raise')
+except ValueError:
+    pass
+os.environ['TAC_ALLGATHER'] = 'rccl'
 dist.barrier()
 dist.destroy_process_group()
 print('rank', rank, 'ok')
@@ -271,6 +297,62 @@ def test_gloo_world2_shard_and_allgather(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert 'rank %d ok' % r in o
+
+
+def test_gloo_world3_p2p_allgather(tmp_path):
+    """The direct exchange with three ranks (two peers per rank, staggered send order) and an uneven 7-row batch."""
+    script = tmp_path / 'worker3.py'
+    script.write_text(r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from torchaudio_contrib_amd.distributed import shard_batch, all_gather_batch
+rank, world = int(sys.argv[1]), 3
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=sys.argv[2], RANK=str(rank), WORLD_SIZE='3')
+dist.init_process_group('gloo', rank=rank, world_size=world)
+whole = torch.arange(7 * 2 * 3 * 4, dtype=torch.float32).reshape(7, 2, 3, 4)
+view = shard_batch(whole).transpose(-2, -1).contiguous().transpose(-2, -1)
+for method in ('p2p', 'rccl'):
+    assert torch.equal(all_gather_batch(view, total_rows=7, method=method), whole), (rank, method)
+even = torch.arange(6 * 5, dtype=torch.float32).reshape(6, 5)
+assert torch.equal(all_gather_batch(shard_batch(even).clone(), method='p2p'), even)
+dist.barrier()
+dist.destroy_process_group()
+print('rank', rank, 'ok')
+''' % ROOT)
+    port = str(31500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), port], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(3)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert 'rank %d ok' % r in o
+
+
+def test_forced_collective_in_a_group_of_one():
+    """all_gather_batch(force_collective=True) runs the real collective at world size 1 (what the RCCL smoke test of a 1-GPU
+    box relies on) and returns the shard unchanged, for both exchange methods and for the strided views the layers return."""
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from torchaudio_contrib_amd.distributed import all_gather_batch
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=sys.argv[1], RANK='0', WORLD_SIZE='1')
+dist.init_process_group('gloo', rank=0, world_size=1)
+calls = []
+real = dist.all_gather_into_tensor
+dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+phys = torch.arange(4 * 1 * 6 * 5, dtype=torch.float32).reshape(4, 1, 6, 5)
+view = phys.transpose(-2, -1)
+assert all_gather_batch(view) is view and not calls                           # the early return stays the default
+out = all_gather_batch(view, total_rows=4, force_collective=True)
+assert len(calls) == 1 and out.shape == view.shape and out.stride() == view.stride() and torch.equal(out, view)
+assert out.data_ptr() != view.data_ptr()
+assert torch.equal(all_gather_batch(view, force_collective=True, method='p2p'), view)
+dist.destroy_process_group()
+print('ok')
+''' % ROOT
+    out = subprocess.run([sys.executable, '-c', code, str(33500 + os.getpid() % 2000)], stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True, timeout=180)
+    assert out.returncode == 0 and 'ok' in out.stdout, out.stdout
 
 
 def test_bench_gpus_flag_is_real():

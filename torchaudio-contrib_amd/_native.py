@@ -35,7 +35,9 @@ EXPORTS = (
     'tac_fold_twosided_f32', 'tac_window_grad_partials', 'tac_window_grad_f32', 'tac_sum_slabs_f32',
     'tac_stft_f64', 'tac_spectrogram_f64', 'tac_apply_filterbank_f64', 'tac_magphase_f64', 'tac_amplitude_to_db_f64',
     'tac_db_to_amplitude_f64',
+    'tac_last_route', 'tac_debug_clock_probe',
 )
+ABI_VERSION = 3          # tac_abi_version() of the library this binding was written against (csrc/host_common.hip)
 
 
 class StftDesc(ctypes.Structure):
@@ -88,6 +90,12 @@ def lib():
                 '`python -c "import __graft_entry__ as g; g.build()"`).  There is no CPU fallback.'
                 % (LIB_PATH, CSRC))
         h = ctypes.CDLL(LIB_PATH)
+        h.tac_abi_version.restype = ctypes.c_int
+        found = h.tac_abi_version()
+        if found != ABI_VERSION:
+            raise NativeLibraryError(
+                '%s reports ABI version %d, this binding needs %d — rebuild it with `make -C %s`'
+                % (LIB_PATH, found, ABI_VERSION, CSRC))
         h.tac_strerror.restype = ctypes.c_char_p
         h.tac_strerror.argtypes = [ctypes.c_int]
         h.tac_last_hip_error.restype = ctypes.c_int
@@ -142,6 +150,10 @@ def lib():
         h.tac_window_grad_f32.argtypes = [_P, _P, _DESC, _P, _I64, _P]
         h.tac_sum_slabs_f32.argtypes = [_P, _I64, _I64, _P, _P]
         h.tac_hpss_f32.argtypes = [_P, _I64, _I32, _I32, _I64, _I64, _I64, _I32, _I32, _F, ctypes.c_int, _P, _P, _P, _P, _P]
+        h.tac_last_route.restype = ctypes.c_char_p
+        h.tac_last_route.argtypes = []
+        h.tac_debug_clock_probe.restype = ctypes.c_int
+        h.tac_debug_clock_probe.argtypes = [_P, _I32]
         for name in EXPORTS:
             fn = getattr(h, name)
             if name.endswith(('_f32', '_f64', '_i64', '_plan', '_supported', '_pack')):   # every launcher returns a TAC_* code

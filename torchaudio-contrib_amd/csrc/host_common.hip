@@ -2,6 +2,8 @@
 #include "host_common.hpp"
 
 #include <cmath>
+#include <cstdarg>
+#include <cstdio>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -9,6 +11,16 @@
 namespace tac {
 
 thread_local int g_last_hip_error = 0;
+thread_local char g_last_route[192] = "";
+thread_local unsigned long long* g_clock_probe = nullptr;
+thread_local int g_clock_probe_pairs = 0;
+
+void set_last_route(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_route, sizeof(g_last_route), fmt, ap);
+    va_end(ap);
+}
 
 int device_cu_count() {
     static thread_local int cached_dev = -1, cached_cus = 256;
@@ -51,12 +63,13 @@ int get_tables(int n_fft, Tables* out) {
         return TAC_OK;
     }
     if (!is_pow2(n_fft)) {                      // sizes with their own tables (stft_n400.hip)
-        *out = Tables{nullptr, nullptr};
+        *out = Tables{nullptr, nullptr, nullptr};
         return TAC_OK;
     }
     const int nc = n_fft / 2;
     const int n_post = nc / 2 + 1;
-    std::vector<cf> host((size_t)nc + n_post);
+    const size_t img_cf = n_fft == 2048 ? (size_t)(S3_IMG_TW1_F4 + S3_IMG_PTW_F4) * 2 : 0;
+    std::vector<cf> host((size_t)nc + n_post + img_cf);
     const double two_pi = 6.283185307179586476925286766559;
     for (int k = 0; k < nc; ++k) {
         double a = -two_pi * (double)k / (double)nc;
@@ -66,10 +79,24 @@ int get_tables(int n_fft, Tables* out) {
         double a = -two_pi * (double)k / (double)n_fft;
         host[nc + k] = mkc((float)std::cos(a), (float)std::sin(a));
     }
+    const size_t img_at = ((size_t)nc + n_post + 1) & ~(size_t)1;                 // 16-byte aligned
+    if (img_cf) {
+        host.resize(img_at + img_cf, mkc(0.0f, 0.0f));
+        float* tw1 = reinterpret_cast<float*>(host.data() + img_at);
+        for (int js = 0; js < 16; ++js)                                            // set js: W_NC^{js q (NC/256)}, q = 1..15; slot 15 = 1
+            for (int q = 0; q < 16; ++q) {
+                const cf wv = q ? host[(size_t)js * q * (nc / 256)] : mkc(1.0f, 0.0f);
+                tw1[js * S3_IMG_TW_STRIDE + 2 * (q ? q - 1 : 15)] = wv.x;
+                tw1[js * S3_IMG_TW_STRIDE + 2 * (q ? q - 1 : 15) + 1] = wv.y;
+            }
+        cf* ptw = host.data() + img_at + (size_t)S3_IMG_TW1_F4 * 2;
+        for (int tt = 0; tt < 64; ++tt)
+            for (int p = 0; p < 8; ++p) ptw[((p >> 1) * 64 + tt) * 2 + (p & 1)] = host[(size_t)nc + tt + p * 64];
+    }
     cf* dptr = nullptr;
     TAC_HIP(hipMalloc((void**)&dptr, host.size() * sizeof(cf)));
     TAC_HIP(hipMemcpy(dptr, host.data(), host.size() * sizeof(cf), hipMemcpyHostToDevice));
-    Tables t{dptr, dptr + nc};
+    Tables t{dptr, dptr + nc, img_cf ? reinterpret_cast<const float*>(dptr + img_at) : nullptr};
     cache[key] = t;
     *out = t;
     return TAC_OK;
@@ -129,7 +156,19 @@ const char* tac_strerror(int code) {
 
 int tac_last_hip_error(void) { return tac::g_last_hip_error; }
 
-int tac_abi_version(void) { return 2; }
+// 3: round 4 — tac_last_route / tac_debug_clock_probe; the float64 entry points and the coded-input / fused-backward
+//    launchers added during round 3 are counted from here as well (a library older than the binding fails its version check
+//    in _native.lib() instead of at the first missing symbol)
+int tac_abi_version(void) { return 3; }
+
+const char* tac_last_route(void) { return tac::g_last_route; }
+
+int tac_debug_clock_probe(uint64_t* buf, int32_t capacity_pairs) {
+    if (buf && capacity_pairs <= 0) return TAC_E_INVALID;
+    tac::g_clock_probe = reinterpret_cast<unsigned long long*>(buf);
+    tac::g_clock_probe_pairs = buf ? capacity_pairs : 0;
+    return TAC_OK;
+}
 
 int64_t tac_num_frames(int64_t L, int n_fft, int hop, int center) {
     if (L <= 0 || n_fft <= 0 || hop <= 0) return 0;

@@ -40,6 +40,11 @@ struct AdjEntry { float w0, w1; int b0, b1; };
 enum { FMT_F32 = 0, FMT_I16 = 1, FMT_MULAW_U8 = 2, FMT_MULAW_I64 = 3 };
 
 extern thread_local int g_last_hip_error;
+// diagnostics of include/tac_amd.h (11): the calling thread's last fused-chain kernel name and its clock-probe buffer
+extern thread_local char g_last_route[192];
+extern thread_local unsigned long long* g_clock_probe;
+extern thread_local int g_clock_probe_pairs;
+void set_last_route(const char* fmt, ...);
 
 inline int hip_fail(hipError_t e) {
     g_last_hip_error = (int)e;
@@ -54,7 +59,15 @@ inline int hip_fail(hipError_t e) {
 struct Tables {
     const cf* w_nc;   // exp(-2*pi*i*k/NC), k < NC          (NC = n_fft/2)
     const cf* w_n;    // exp(-2*pi*i*k/N),  k <= NC/2
+    // fft_length 2048 only (else null): the pass-1 twiddle sets and the R2C twiddles of the one-frame-per-wave kernels
+    // (melspec_stream3.hpp, stft_stream3.hpp), already in their LDS layout — S3_IMG_TW1_F4 16-byte chunks of
+    // [16 sets][ST_TW_STRIDE floats] followed by S3_IMG_PTW_F4 chunks of [pair >> 1][lane][pair & 1] — so that a workgroup's
+    // set-up copies them with two 16-byte loads per thread instead of computing table indices per element
+    const float* s3img;
 };
+constexpr int S3_IMG_TW_STRIDE = 36;                       // == ST_TW_STRIDE (melspec_stream.hpp)
+constexpr int S3_IMG_TW1_F4 = 16 * S3_IMG_TW_STRIDE / 4;   // 144
+constexpr int S3_IMG_PTW_F4 = 64 * 8 * 2 / 4;              // 256: 64 lanes x 8 pairs of complex values
 
 // immutable per-(n_fft, device) twiddle tables; first use allocates + uploads (synchronous)
 int get_tables(int n_fft, Tables* out);

@@ -377,7 +377,7 @@ static int launch_stream(FrameGeom g, const Tables& tb, const SparseArgs& sm, co
                     ((reinterpret_cast<uintptr_t>(samples) & (pair - 1)) == 0);
     }
     StreamArgs m{sm.wpack, sm.desc, info_host[1], {info_host[4], info_host[5], info_host[6], info_host[7]}, sm.wtot,
-                 sm.n_mels, sm.db, sm.amin, sm.log10_ref, sm.out, total, samples, lut};
+                 sm.n_mels, sm.db, sm.amin, sm.log10_ref, sm.out, total, samples, lut, 0, nullptr};
     long long blocks = (total + 2 * ST_WAVES - 1) / (2 * ST_WAVES);
     if (blocks > device_cu_count()) blocks = device_cu_count();
     if (blocks < 1) blocks = 1;
@@ -420,6 +420,12 @@ static int launch_stream(FrameGeom g, const Tables& tb, const SparseArgs& sm, co
         }
         long long b3 = (total + waves3 - 1) / waves3;
         if (b3 > device_cu_count()) b3 = device_cu_count();
+        m.chunk = (total + b3 - 1) / b3;
+        m.probe = (g_clock_probe && g_clock_probe_pairs >= b3) ? g_clock_probe : nullptr;
+        {
+            const int fast1 = (FMT == FMT_F32 && fast2) ? (fshort ? ST_FAST_STEPS1_SHORT : ST_FAST_STEPS1) : 0;
+            set_last_route("melspec_stream3_kernel<%d, %d, %s, %d, %d, %d>", NC, E, pow2 ? "true" : "false", FMT, fast1, waves3);
+        }
         TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(k3), 160 * 1024));
         hipLaunchKernelGGL(k3, dim3((unsigned)b3), dim3(waves3 * 64), lds3, stream, g, tb, m);
         TAC_HIP(hipGetLastError());

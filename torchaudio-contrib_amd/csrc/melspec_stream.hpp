@@ -62,6 +62,8 @@ struct StreamArgs {
     long long total;       // rows * T
     const void* samples;   // the waveform in its own sample format (SampleFormat; g.wave when float32)
     const float* lut;      // device float[256]: mu-law decode table for the coded formats
+    long long chunk;       // frames per workgroup = ceil(total / blocks) (melspec_stream3_kernel; the host divides once)
+    unsigned long long* probe;   // diagnostics (tac_debug_clock_probe): [2 * block] = {shader cycles, 100 MHz ticks} of wave 0's frame loop; or null
 };
 
 // sample formats of the frame load (tac_amd.h TAC_SAMPLES_*)

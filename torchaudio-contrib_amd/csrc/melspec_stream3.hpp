@@ -8,6 +8,8 @@
 // |X|^2 row written in place over the frame's exchange area (which is what lets twelve waves fit the LDS:
 // 12 x 8.7 KB + 20 KB of weights), no instruction of one frame interleaved with another's.
 #pragma once
+#include <type_traits>
+
 #include "melspec_stream.hpp"
 
 namespace tac {
@@ -22,6 +24,95 @@ __host__ __device__ inline size_t stream3_lds_bytes(int wtot, int waves, bool co
     size_t xa = ((size_t)C::F::PADDED * sizeof(cf) + 15) & ~(size_t)15;
     return (size_t)waves * xa + (((size_t)wtot * 4 + 15) & ~(size_t)15) + ST_TW_BYTES + 16 + 64 * (C::F::NPAIR + E) * sizeof(cf) + (coded ? 1024 : 0);
 }
+
+#ifndef TAC_S3_B64
+#define TAC_S3_B64 0          // A/B: exchange read-backs as single ds_read_b64 (2 LDS cycles each) instead of hipcc's merged ds_read2_b64 (8 per pair)
+#endif
+#ifndef TAC_S3_NOFENCE0
+#define TAC_S3_NOFENCE0 0     // A/B: no compiler fence between the first butterfly and its exchange writes (the writes may start early)
+#endif
+#ifndef TAC_S3_ADDTID
+#define TAC_S3_ADDTID 0       // A/B: lower half of the |X|^2 row written with ds_write_addtid_b32 (2 LDS cycles, no address register)
+#endif
+#ifndef TAC_S3_W0_REGS
+#define TAC_S3_W0_REGS 0      // A/B: the four weight quads of band slot 0 live in registers (16 VGPRs) instead of being re-read per frame
+#endif
+
+// LDS byte offset of a pointer into the workgroup's shared memory (the low half of its flat address)
+__device__ __forceinline__ unsigned lds_offset_of(const void* p) { return (unsigned)reinterpret_cast<unsigned long long>(p); }
+// one ds_read_b64 that hipcc's load/store optimizer cannot pair into a ds_read2_b64; the caller waits with lds_wait_all()
+template <int BYTE_OFF>
+__device__ __forceinline__ cf lds_read_b64_single(unsigned addr) {
+    cf r;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(BYTE_OFF) : "memory");
+    return r;
+}
+// s_waitcnt lgkmcnt(0) that the listed registers' uses cannot move above
+__device__ __forceinline__ void lds_wait_all(cf (&a)[16]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
+                   "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
+                 :: "memory");
+}
+__device__ __forceinline__ void lds_wait_all(cf (&a)[8], cf& b) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(b)
+                 :: "memory");
+}
+
+// ---- set-up shared by the one-frame-per-wave kernels (this file, stft_stream3.hpp): the loop-invariant tables into LDS.
+// The pass-1 twiddle sets and the R2C twiddles come from the library's table cache already in their LDS layout
+// (Tables::s3img, host_common.hip) and are copied as 16-byte chunks; the window pairs are read lane-contiguously (one
+// 8-byte load per element, no index arithmetic for a full-length window) and land as [element >> 1][lane][element & 1]
+// with the transform's scale folded in.  issue() only loads (so that every global load of the set-up is in flight before
+// the first LDS store), store() only stores.  Round 3 computed each entry's table index per thread: ~700 instructions
+// per wave and a 64-bit division for the chunk size, 4.3-4.7 us per launch (profiles/r03/ubench/stream3_cycles.txt).
+typedef float pf4 __attribute__((ext_vector_type(4)));
+template <class F, int THREADS>
+struct S3Setup {
+    static constexpr int TOT = S3_IMG_TW1_F4 + S3_IMG_PTW_F4;
+    static constexpr int NIMG = (TOT + THREADS - 1) / THREADS;
+    static constexpr int NWIN = (64 * F::E + THREADS - 1) / THREADS;
+    static_assert(F::N == 2048 && F::E == 16 && F::NPAIR == 8 && S3_IMG_TW_STRIDE == ST_TW_STRIDE, "image layout of get_tables()");
+    pf4 img[NIMG];
+    cf win[NWIN];
+    __device__ __forceinline__ void issue(const FrameGeom& g, const Tables& tb, int tid) {
+#pragma unroll
+        for (int u = 0; u < NIMG; ++u) {
+            const int c = tid + u * THREADS;
+            img[u] = reinterpret_cast<const pf4*>(tb.s3img)[c < TOT ? c : TOT - 1];
+        }
+        if (g.win_length == F::N) {
+            const cf* w2 = reinterpret_cast<const cf*>(g.window);
+#pragma unroll
+            for (int u = 0; u < NWIN; ++u) {
+                const int idx = tid + u * THREADS;
+                win[u] = w2[idx < 64 * F::E ? idx : 0];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NWIN; ++u) {
+                const int idx = tid + u * THREADS;
+                win[u] = window_pair(g, idx < 64 * F::E ? idx : 0);
+            }
+        }
+    }
+    // element m = lane + 64 q of the frame (complex pair of samples 2m, 2m + 1) is lane `lane`'s first-pass register q
+    __device__ __forceinline__ void store(float* twlds, cf* ptwl, cf* winl, float half, int tid) const {
+#pragma unroll
+        for (int u = 0; u < NIMG; ++u) {
+            const int c = tid + u * THREADS;
+            if (c < S3_IMG_TW1_F4) reinterpret_cast<pf4*>(twlds)[c] = img[u];
+            else if (c < TOT) reinterpret_cast<pf4*>(ptwl)[c - S3_IMG_TW1_F4] = img[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NWIN; ++u) {
+            const int idx = tid + u * THREADS;
+            const int q = idx >> 6, tt = idx & 63;
+            if (idx < 64 * F::E) winl[((q >> 1) * 64 + tt) * 2 + (q & 1)] = cscale(win[u], half);
+        }
+    }
+};
 
 #ifndef TAC_S3_PTW_REGS
 #define TAC_S3_PTW_REGS 0
@@ -60,7 +151,7 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     cf* const xa = reinterpret_cast<cf*>(smem_raw + (size_t)w * XA_BYTES);
     float* const prow = reinterpret_cast<float*>(xa);                               // the frame's |X|^2 row, in place
-    const long long chunk = (m.total + gridDim.x - 1) / gridDim.x;
+    const long long chunk = m.chunk;                     // ceil(total / gridDim.x), from the host (a 64-bit division is ~130 scalar instructions)
     const long long begin = (long long)blockIdx.x * chunk;
     const long long endl = begin + chunk < m.total ? begin + chunk : m.total;
     const int nloc = endl > begin ? (int)(endl - begin) : 0;
@@ -115,7 +206,6 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
 #endif
     // ---- tables into LDS.  Every global load of the set-up is issued before the first LDS store (loads of one loop iteration
     //      used to wait for the previous iteration's: a dozen serialized L2 round trips, 4.3 us of a 110 us kernel; now ~one)
-    typedef float pf4 __attribute__((ext_vector_type(4)));
     float* const wlds = reinterpret_cast<float*>(smem_raw + (size_t)WAVES * XA_BYTES);
     float* const twlds = wlds + ((m.wtot + 3) & ~3);
     unsigned* const next_frame = reinterpret_cast<unsigned*>(twlds + ST_TW_BYTES / 4);
@@ -131,20 +221,8 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         const int c = tid + u * WAVES * 64;
         wreg[u] = reinterpret_cast<const pf4*>(m.wl)[c < n4 ? c : n4 - 1];
     }
-    const int js1 = (tid >> 4) & 15, q1 = tid & 15;
-    const cf tw1v = tb.w_nc[js1 * q1 * (NC / 256)];
-    constexpr int NPT = (64 * F::NPAIR + WAVES * 64 - 1) / (WAVES * 64), NWT = (64 * E + WAVES * 64 - 1) / (WAVES * 64);
-    cf ptv[NPT], wnv[NWT];
-#pragma unroll
-    for (int u = 0; u < NPT; ++u) {
-        const int idx = tid + u * WAVES * 64, ic = idx < 64 * F::NPAIR ? idx : 0;
-        ptv[u] = tb.w_n[ic / F::NPAIR + (ic % F::NPAIR) * F::LPF];
-    }
-#pragma unroll
-    for (int u = 0; u < NWT; ++u) {
-        const int idx = tid + u * WAVES * 64, ic = idx < 64 * E ? idx : 0;
-        wnv[u] = window_pair(g, ic / E + (ic % E) * F::LPF);
-    }
+    S3Setup<F, WAVES * 64> setup;
+    setup.issue(g, tb, tid);
     cf tw2[3];
     {
         cf all[F::NTW];
@@ -177,27 +255,11 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     }
     for (int c = tid + WCH * WAVES * 64; c < n4; c += WAVES * 64)          // banks with more than 48 KB of weights: the rest, plainly
         reinterpret_cast<pf4*>(wlds)[c] = reinterpret_cast<const pf4*>(m.wl)[c];
-    if (tid < 16 * 16) {
-        const cf wv = q1 ? tw1v : mkc(1.0f, 0.0f);
-        twlds[js1 * ST_TW_STRIDE + 2 * (q1 ? q1 - 1 : 15)] = wv.x;
-        twlds[js1 * ST_TW_STRIDE + 2 * (q1 ? q1 - 1 : 15) + 1] = wv.y;
-    }
     if (tid == 0) *next_frame = WAVES;
-    // the eight R2C twiddles of a lane (re-read every frame: the register budget does not hold them) and the window pairs of its
-    // sixteen first-pass elements (scale folded in), as [read u][lane] 16-byte pairs: every ds_read_b128 of the wave is one
-    // contiguous kilobyte
-#pragma unroll
-    for (int u = 0; u < NPT; ++u) {
-        const int idx = tid + u * WAVES * 64;
-        const int tt = idx / F::NPAIR, p = idx - tt * F::NPAIR;
-        if (idx < 64 * F::NPAIR) ptwl[((p >> 1) * 64 + tt) * 2 + (p & 1)] = ptv[u];
-    }
-#pragma unroll
-    for (int u = 0; u < NWT; ++u) {
-        const int idx = tid + u * WAVES * 64;
-        const int tt = idx / E, q = idx - tt * E;
-        if (idx < 64 * E) winl[((q >> 1) * 64 + tt) * 2 + (q & 1)] = cscale(wnv[u], half);
-    }
+    // pass-1 twiddle sets, the eight R2C twiddles of a lane (re-read every frame: the register budget does not hold them) and
+    // the window pairs of its sixteen first-pass elements (scale folded in), as [read u][lane] 16-byte pairs: every
+    // ds_read_b128 of the wave is one contiguous kilobyte
+    setup.store(twlds, ptwl, winl, half, tid);
 #if TAC_S3_PTW_REGS
     cf ptw_regs[F::NPAIR];
 #pragma unroll
@@ -253,6 +315,13 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         a0 = __builtin_elementwise_fma(mkc(wv.x, wv.y), mkc(pv.x, pv.y), a0);
         a1 = __builtin_elementwise_fma(mkc(wv.z, wv.w), mkc(pv.z, pv.w), a1);
     };
+#if TAC_S3_W0_REGS
+    f4 w0_regs[ST_FAST_STEPS0];
+    if constexpr (FAST1 > 0) {
+#pragma unroll
+        for (int u = 0; u < ST_FAST_STEPS0; ++u) w0_regs[u] = (reinterpret_cast<const f4*>(wlds) + lane)[u * 64];
+    }
+#endif
     int i = w;
 #if !TAC_S3_EARLY_FIRST
     request(i);
@@ -263,6 +332,12 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
 #if TAC_S3_CYCLES
     const unsigned long long cyc0 = __builtin_readcyclecounter(), wall0 = wall_clock64();
 #endif
+    // diagnostics (tac_debug_clock_probe): shader cycles and 100 MHz ticks of wave 0's frame loop -> the clock the kernel ran at
+    unsigned long long probe_c = 0, probe_w = 0;
+    if (m.probe && w == 0) {
+        probe_c = __builtin_readcyclecounter();
+        probe_w = wall_clock64();
+    }
     while (i < nloc) {
         // the next frame of this wave (the counter's answer travels with the stage's other LDS traffic)
         unsigned ask = 0;
@@ -290,7 +365,9 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             Dft<16>::run_windowed(v, win);
 #endif
         }
+#if !TAC_S3_NOFENCE0
         wave_lds_fence();
+#endif
         cf tw1[16];
         {
             const f4* tl = reinterpret_cast<const f4*>(twlds + (t & 15) * ST_TW_STRIDE);
@@ -303,7 +380,19 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         }
         F::template pass_write<0, true>(v, xa, t, t);
         wave_lds_fence();
+#if TAC_S3_B64
+        {
+            const unsigned ra = lds_offset_of(xa + lds_pad(t));
+            auto rd = [&](auto qc) { constexpr int q = decltype(qc)::value; v[q] = lds_read_b64_single<lds_pad_c(q * (NC / 16)) * 8>(ra); };
+            rd(std::integral_constant<int, 0>{}); rd(std::integral_constant<int, 1>{}); rd(std::integral_constant<int, 2>{}); rd(std::integral_constant<int, 3>{});
+            rd(std::integral_constant<int, 4>{}); rd(std::integral_constant<int, 5>{}); rd(std::integral_constant<int, 6>{}); rd(std::integral_constant<int, 7>{});
+            rd(std::integral_constant<int, 8>{}); rd(std::integral_constant<int, 9>{}); rd(std::integral_constant<int, 10>{}); rd(std::integral_constant<int, 11>{});
+            rd(std::integral_constant<int, 12>{}); rd(std::integral_constant<int, 13>{}); rd(std::integral_constant<int, 14>{}); rd(std::integral_constant<int, 15>{});
+            lds_wait_all(v);
+        }
+#else
         F::template pass_readback<1>(v, xa, t);
+#endif
         // ---- s12
         F::template pass_twiddle<1, true>(v, tw1);
         F::template pass_butterflies<1>(v);
@@ -321,6 +410,18 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         F::template pass_write<2, true>(v, xa, t, t);
         wave_lds_fence();
         cf zm[F::NPAIR], zmid;
+#if TAC_S3_B64
+        {
+            static_assert(F::NPAIR == 8, "eight partners per lane");
+            const unsigned pa = lds_offset_of(xa + lds_pad(NC - t) - lds_pad_c(7 * F::LPF));      // partner of pair 7; pair p sits (7 - p) * 68 slots above
+            auto rd = [&](auto pc) { constexpr int p = decltype(pc)::value; zm[p] = lds_read_b64_single<lds_pad_c((7 - p) * F::LPF) * 8>(pa); };
+            rd(std::integral_constant<int, 0>{}); rd(std::integral_constant<int, 1>{}); rd(std::integral_constant<int, 2>{}); rd(std::integral_constant<int, 3>{});
+            rd(std::integral_constant<int, 4>{}); rd(std::integral_constant<int, 5>{}); rd(std::integral_constant<int, 6>{}); rd(std::integral_constant<int, 7>{});
+            zmid = lds_read_b64_single<0>(lds_offset_of(xa + lds_pad(NC / 2)));
+            lds_wait_all(zm, zmid);
+            if (t == 0) zm[0] = v[F::reg_of_spectrum(0)];
+        }
+#else
         {
             const cf* const pb = xa + lds_pad(NC - t);
 #pragma unroll
@@ -330,6 +431,7 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             }
             zmid = xa[lds_pad(NC / 2)];
         }
+#endif
         // ---- s3: R2C split -> |X|^p; the row overwrites the exchange area once every lane holds its partners
         cf pw[F::NPAIR];
 #if TAC_S3_PTW_REGS
@@ -351,12 +453,35 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             r2c_power_pair_x2(v[F::reg_of_spectrum(p)], zm[p], ptw[p], v[F::reg_of_spectrum(p + 1)], zm[p + 1], ptw[p + 1], pw[p], pw[p + 1]);
         const float pmid = 4.0f * cnorm2(zmid);
         wave_lds_fence();                                                   // all partner reads are in registers
+#if TAC_S3_ADDTID
+        {
+            // bins t + 64 p (p < 8) ascend with the lane: address = M0 + 256 p + 4 lane, no address register, 2 LDS cycles each
+            float lo[F::NPAIR];
+#pragma unroll
+            for (int p = 0; p < F::NPAIR; ++p) lo[p] = POW2 ? pw[p].x : __builtin_amdgcn_sqrtf(pw[p].x);
+            asm volatile("s_mov_b32 m0, %8\n\t"
+                         "ds_write_addtid_b32 %0\n\t"
+                         "ds_write_addtid_b32 %1 offset:256\n\t"
+                         "ds_write_addtid_b32 %2 offset:512\n\t"
+                         "ds_write_addtid_b32 %3 offset:768\n\t"
+                         "ds_write_addtid_b32 %4 offset:1024\n\t"
+                         "ds_write_addtid_b32 %5 offset:1280\n\t"
+                         "ds_write_addtid_b32 %6 offset:1536\n\t"
+                         "ds_write_addtid_b32 %7 offset:1792"
+                         :: "v"(lo[0]), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(lo[4]), "v"(lo[5]), "v"(lo[6]), "v"(lo[7]),
+                            "s"(lds_offset_of(prow))
+                         : "memory", "m0");
+#pragma unroll
+            for (int p = 0; p < F::NPAIR; ++p) prow[NC - (t + p * F::LPF)] = POW2 ? pw[p].y : __builtin_amdgcn_sqrtf(pw[p].y);
+        }
+#else
 #pragma unroll
         for (int p = 0; p < F::NPAIR; ++p) {
             const int kk = t + p * F::LPF;
             prow[kk] = POW2 ? pw[p].x : __builtin_amdgcn_sqrtf(pw[p].x);
             prow[NC - kk] = POW2 ? pw[p].y : __builtin_amdgcn_sqrtf(pw[p].y);
         }
+#endif
         if (t == 0) prow[NC / 2] = POW2 ? pmid : __builtin_amdgcn_sqrtf(pmid);
         if (t < C::PROW - NBINS) prow[NBINS + t] = 0.0f;                    // slack taps carry zero weights: keep them finite
         wave_lds_fence();
@@ -402,7 +527,11 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             f4 w0[ST_FAST_STEPS0], q0[ST_FAST_STEPS0], wa[B1], qa[B1];
 #pragma unroll
             for (int u = 0; u < ST_FAST_STEPS0; ++u) {
+#if TAC_S3_W0_REGS
+                w0[u] = w0_regs[u];
+#else
                 w0[u] = wp[u * 64];
+#endif
                 q0[u] = p0[u];
             }
 #pragma unroll
@@ -474,6 +603,13 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             }
         }
         wave_lds_fence();                                                   // the row is consumed: the area takes the next frame
+    }
+    if (m.probe && w == 0) {
+        const unsigned long long dc = __builtin_readcyclecounter() - probe_c, dw = wall_clock64() - probe_w;
+        if (lane == 0) {
+            m.probe[2 * blockIdx.x] = dc;
+            m.probe[2 * blockIdx.x + 1] = dw;
+        }
     }
 #if TAC_S3_CYCLES
     // debug build (tools/stream3_cycles.py): shader cycles and 100 MHz ticks of every wave's frame loop, over the first outputs

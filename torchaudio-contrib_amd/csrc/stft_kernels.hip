@@ -489,11 +489,22 @@ static int launch_pipe3(const FrameGeom& g, const Tables& tb, const StftEpilogue
     // 658 MB of stores either way and measure best with three (profiles/r03/ab_stream3.txt)
     static const int waves_env = [] { const char* e = getenv("TAC_STFT_S3_WAVES"); return e ? atoi(e) : 0; }();
     const int waves = waves_env ? waves_env : (PMODE == 0 ? 12 : 16);
+    // Row-store policy by footprint.  Nontemporal stores keep a cache-resident input resident (one re-read 164 MB batch: 0.150 /
+    // 0.113 ms complex / power rows against 0.188 / 0.133 ms with plain stores, which allocate in the 256 MiB Infinity Cache
+    // and evict the input); once input + output exceed that cache the input comes from HBM whatever the stores do, and plain
+    // stores measure 6 % faster on the complex rows (0.177 vs 0.188 ms; tools/ablation/README.md).  TAC_S3_STORES=nt|plain
+    // forces one form (A/B runs).
+    static const int forced = [] { const char* e = getenv("TAC_S3_STORES"); return !e ? -1 : (e[0] == 'p' ? 1 : 0); }();
+    const long long frames_total = g.rows * g.n_frames;
+    const double footprint = 4.0 * ((double)g.rows * (double)g.length + (double)frames_total * (PMODE == 0 ? 2.0 : 1.0) * (NC + 1));
+    const int plain = forced >= 0 ? forced : (footprint > 256.0 * 1024 * 1024 ? 1 : 0);
     auto go = [&](auto kern, int W, size_t bytes) {
         long long blocks = (groups + W - 1) / W;
         if (blocks > device_cu_count()) blocks = device_cu_count();
+        if (blocks < 1) blocks = 1;
+        const Stream3Launch lp{(frames_total + blocks - 1) / blocks, plain};
         TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes));
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W * 64), bytes, stream, g, tb, ep);
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W * 64), bytes, stream, g, tb, ep, lp);
         TAC_HIP(hipGetLastError());
         return (int)TAC_OK;
     };

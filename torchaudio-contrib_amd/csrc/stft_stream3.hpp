@@ -14,14 +14,20 @@ template <int NC, int E, int WAVES>
 __host__ __device__ inline size_t stft_stream3_lds_bytes() {
     using F = WaveFft<NC, E>;
     size_t xa = ((size_t)F::PADDED * sizeof(cf) + 15) & ~(size_t)15;
-    return (size_t)WAVES * xa + ST_TW_BYTES + 64 + 2 * 64 * 18 * sizeof(cf);
+    return (size_t)WAVES * xa + ST_TW_BYTES + 64 + 64 * (F::NPAIR + E) * sizeof(cf);
 }
+
+// launch parameters the host works out once: frames per workgroup (ceil(total / blocks)) and the row-store policy
+struct Stream3Launch {
+    long long chunk;
+    int plain_stores;       // 0: nontemporal row stores (keep a cache-resident input resident), 1: plain stores (see launch_pipe3)
+};
 
 // MODE: 0 complex rows, 1 |X|^2, 2 |X|, 3 |X|^2 in dB, 4 |X| in dB (spectral_row_value)
 // WAVES: 12 or 16 per workgroup (= per CU): the row-store form needs ~114 registers, so FOUR waves per SIMD fit as well
 template <int NC, int E, int MODE, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
-stft_stream3_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
+stft_stream3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
     using F = WaveFft<NC, E>;
     static_assert(F::G == 1 && E == 16 && radix_at(NC, 0) == 16, "fft_length 2048");
     constexpr int XA_BYTES = (F::PADDED * sizeof(cf) + 15) & ~15;
@@ -35,28 +41,15 @@ stft_stream3_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     cf* const xa = reinterpret_cast<cf*>(smem_raw + (size_t)w * XA_BYTES);
     float* const twlds = reinterpret_cast<float*>(smem_raw + (size_t)WAVES * XA_BYTES);
-    if (tid < 16 * 16) {
-        const int js = tid >> 4, q = tid & 15;
-        const cf wv = q ? tb.w_nc[js * q * (NC / 256)] : mkc(1.0f, 0.0f);
-        twlds[js * ST_TW_STRIDE + 2 * (q ? q - 1 : 15)] = wv.x;
-        twlds[js * ST_TW_STRIDE + 2 * (q ? q - 1 : 15) + 1] = wv.y;
-    }
     unsigned* const next_frame = reinterpret_cast<unsigned*>(twlds + ST_TW_BYTES / 4);
-    if (tid == 0) *next_frame = WAVES;
     cf* const ptwl = reinterpret_cast<cf*>(next_frame + 16);
-    for (int idx = tid; idx < 64 * F::NPAIR; idx += WAVES * 64) {
-        const int tt = idx / F::NPAIR, p = idx - tt * F::NPAIR;
-        ptwl[tt * 18 + p] = tb.w_n[tt + p * F::LPF];
-    }
+    cf* const winl = ptwl + 64 * F::NPAIR;
     const float half = 0.5f * g.scale;                    // the R2C split returns 2X: folded into the window
-    cf* const winl = ptwl + 64 * 18;
-    for (int idx = tid; idx < 64 * E; idx += WAVES * 64) {
-        const int tt = idx / E, q = idx - tt * E;
-        winl[tt * 18 + q] = cscale(window_pair(g, tt + q * F::LPF), half);
-    }
+    S3Setup<F, WAVES * 64> setup;                         // tables: every load in flight, then the LDS stores (melspec_stream3.hpp)
+    setup.issue(g, tb, tid);
 
     const long long total = g.rows * g.n_frames;
-    const long long chunk = (total + gridDim.x - 1) / gridDim.x;
+    const long long chunk = lp.chunk;
     const long long begin = (long long)blockIdx.x * chunk;
     const long long endl = begin + chunk < total ? begin + chunk : total;
     const int nloc = endl > begin ? (int)(endl - begin) : 0;
@@ -69,9 +62,6 @@ stft_stream3_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) tw2[q] = all[twiddles_before(NC, E, 2) + q];
     }
-    __syncthreads();
-    if (nloc <= 0) return;
-
     typedef float f4 __attribute__((ext_vector_type(4)));
     cf v[E];
     int mode = 0, row = 0;
@@ -91,12 +81,26 @@ stft_stream3_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 #pragma unroll
         for (int q = 0; q < E; ++q) v[q] = src[t + q * F::LPF];
     };
+    // the wave's first frame is requested behind the table loads and ahead of the LDS stores and the barrier: its HBM latency
+    // runs behind the rest of the set-up
+    if (nloc > 0) request(w);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tid == 0) *next_frame = WAVES;
+    setup.store(twlds, ptwl, winl, half, tid);
+    __syncthreads();
+    if (nloc <= 0) return;
+
     int i = w;
-    request(i);
     while (i < nloc) {
         unsigned ask = 0;
         if (t == 0) ask = __hip_atomic_fetch_add(next_frame, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const long long g0 = ((long long)row * T + fr) * LENF;      // this frame's row in the frame-major output
+#ifndef TAC_S3_VMCNT0
+#define TAC_S3_VMCNT0 0
+#endif
+#if TAC_S3_VMCNT0
+        __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): the previous row's stores are acknowledged before this frame starts
+#endif
         // ---- s0: window, pass 0, exchange
         if (mode != 1) {                                    // frames touching the padding gather their samples first
             int tz;
@@ -105,10 +109,10 @@ stft_stream3_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
         }
         {
             cf win[E];
-            const f4* wl = reinterpret_cast<const f4*>(winl + t * 18);
+            const f4* wl = reinterpret_cast<const f4*>(winl) + t;
 #pragma unroll
             for (int u = 0; u < E / 2; ++u) {
-                const f4 x = wl[u];
+                const f4 x = wl[u * 64];
                 win[2 * u] = mkc(x.x, x.y);
                 win[2 * u + 1] = mkc(x.z, x.w);
             }
@@ -150,10 +154,10 @@ stft_stream3_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
         // ---- s3: R2C split; the row overwrites the exchange area once every lane holds its partners
         cf ptw[F::NPAIR];
         {
-            const f4* pl = reinterpret_cast<const f4*>(ptwl + t * 18);
+            const f4* pl = reinterpret_cast<const f4*>(ptwl) + t;
 #pragma unroll
             for (int u = 0; u < F::NPAIR / 2; ++u) {
-                const f4 x = pl[u];
+                const f4 x = pl[u * 64];
                 ptw[2 * u] = mkc(x.x, x.y);
                 ptw[2 * u + 1] = mkc(x.z, x.w);
             }
@@ -216,15 +220,13 @@ stft_stream3_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
                 b[u] = s4[c[u]];
             }
             __builtin_amdgcn_sched_barrier(0);            // all LDS reads in flight before the first store issues
+            if (lp.plain_stores) {
 #pragma unroll
-#ifndef TAC_S3_NT
-#define TAC_S3_NT 1
-#endif
-#if TAC_S3_NT
-            for (int u = 0; u < NST; ++u) __builtin_nontemporal_store(b[u], &g4[c[u]]);
-#else
-            for (int u = 0; u < NST; ++u) g4[c[u]] = b[u];
-#endif
+                for (int u = 0; u < NST; ++u) g4[c[u]] = b[u];
+            } else {
+#pragma unroll
+                for (int u = 0; u < NST; ++u) __builtin_nontemporal_store(b[u], &g4[c[u]]);
+            }
         }
         {
             const int r = LENF - npre - 4 * nchunks;
