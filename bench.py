@@ -7,11 +7,17 @@ on N MI355X (BASELINE.json metric; workload = configs[1]: 256 x 1ch x 16 kHz x 1
 
 One step = one pass of the fused hot path over one device-resident synthetic batch per rank
 (weak scaling: per-GPU work fixed; ranks shard the batch axis, no data-path collective).  Rank 0
-prints ONE JSON line.  `roofline` is measured live with HIP events on the launch stream around the
-dominant (only) kernel; `cpu_baseline` times the CPU oracle (torch-CPU restatement of the reference's
-op sequence) on a bounded sample of the same workload on this box's host cores.
+prints ONE JSON line.  The K-step timed region (barrier + synchronize on both sides, max over ranks) is
+repeated `--repeats` times back to back and the MEDIAN region decides `value` / `ms_per_step`
+(`value_p10` / `value_p90` beside it), so the headline is not one 2 ms window.  `roofline` is measured
+live with HIP events on the launch stream around the dominant (only) kernel, names the kernel the
+library actually launched (tac_last_route), the shader clock that kernel ran at (tac_debug_clock_probe)
+and what binds it according to the committed counter passes; `cpu_baseline` times the CPU oracle
+(torch-CPU restatement of the reference's op sequence) on a bounded sample of the same workload on this
+box's host cores.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -40,6 +46,8 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--repeats', type=int, default=25,
+                    help='back-to-back repetitions of the K-step timed region; the median region is reported')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-stages', action='store_true')
     ap.add_argument('--config', choices=('cfg2', 'cfg3'), default='cfg2',
@@ -112,6 +120,58 @@ def cpu_baseline(x):
                          one_rows, torch.__version__)}
 
 
+N_SIMD = 256 * 4                                    # MI355X: 256 CUs x 4 SIMDs
+F32_VECTOR_PEAK_TFLOPS = 157.3                      # MI355X_MICROARCH.md: packed f32 vector peak
+
+
+def bound_from_counters(roof, route, clock_mhz):
+    """Fill roofline.traffic / valu_floor_ms / lds_busy / bound from the committed rocprofv3 counter passes of THIS kernel
+    (profiles/rNN/pmc_mel.json — bench.py cannot run the profiler on itself; instruction counts and busy cycles per launch
+    are properties of the kernel binary and the workload, the clock is measured live).  The entry must carry the name of
+    the kernel the library just launched; otherwise the fields stay null and say why."""
+    entry, source = None, None
+    for rnd in ('r04', 'r03'):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', rnd, 'pmc_mel.json')))
+        except Exception:            # noqa: BLE001
+            continue
+        for kname, d in pmc.items():
+            if route and route in kname:
+                entry, source = d, 'profiles/%s/pmc_mel.json' % rnd
+                break
+        if entry:
+            break
+    if entry is None:
+        roof['counters_note'] = 'no committed counter pass names the launched kernel (%s): traffic / bound not derived' % route
+        return
+    roof['counters_source'] = source + ' (rocprofv3 --pmc, separate passes; FETCH_SIZE x2 gfx950 correction applied)'
+    if 'hbm_traffic_bytes_per_launch' in entry:
+        roof['traffic'] = entry['hbm_traffic_bytes_per_launch']
+    busy = {}
+    kernel_cycles = None
+    if 'SQ_BUSY_CU_CYCLES' in entry:
+        kernel_cycles = entry['SQ_BUSY_CU_CYCLES'] / 256.0                     # per CU
+    if 'SQ_ACTIVE_INST_VALU' in entry:
+        valu_cycles = entry['SQ_ACTIVE_INST_VALU'] * 4.0 / N_SIMD               # counted in quad-cycles over all SIMDs
+        roof['valu_busy_cycles_per_simd'] = valu_cycles
+        if clock_mhz:
+            roof['valu_floor_ms'] = valu_cycles / (clock_mhz * 1e3)
+            roof['frac_of_valu_floor'] = roof['valu_floor_ms'] / roof['kernel_ms_mean']
+            busy['valu'] = roof['frac_of_valu_floor']
+        elif kernel_cycles:
+            busy['valu'] = valu_cycles / kernel_cycles
+    if 'SQ_LDS_IDX_ACTIVE' in entry and kernel_cycles:
+        roof['lds_busy'] = entry['SQ_LDS_IDX_ACTIVE'] / 256.0 / kernel_cycles
+        busy['lds'] = roof['lds_busy']
+    if 'SQ_VALU_MFMA_BUSY_CYCLES' in entry and kernel_cycles:
+        busy['mfma'] = entry['SQ_VALU_MFMA_BUSY_CYCLES'] / N_SIMD / kernel_cycles
+    busy['hbm'] = roof['frac']
+    roof['busy_fractions'] = busy
+    roof['bound'] = max(busy, key=busy.get)
+    roof['bound_note'] = ('the busiest resource by the counters; `frac` / `peak` stay the HBM figure the contract asks for '
+                          '(algorithmic bytes / kernel time / 8 TB/s)')
+
+
 def _free_port():
     import socket
     with socket.socket() as sock:
@@ -165,7 +225,9 @@ def run(a):
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != a.gpus:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d — launch one rank per GPU' % (a.gpus, world))
-    distributed = world > 1
+    # one process per GPU over RCCL whenever there is a rendezvous to join: N > 1 always, and N = 1 when launched through
+    # torchrun (the driver's launch line at N = 1 then exercises the same process-group / barrier / collective code)
+    distributed = world > 1 or ('MASTER_ADDR' in os.environ and 'RANK' in os.environ)
     import torch.distributed as dist
     if a.dry_run_cpu:
         BATCH, LENGTH = 4, 8192
@@ -231,13 +293,51 @@ def run(a):
             elapsed = float(t.item())
         return elapsed, ev0.elapsed_time(ev1) / steps, y
 
+    def quantile(vals, q):
+        v = sorted(vals)
+        return v[min(len(v) - 1, max(0, int(round(q * (len(v) - 1)))))]
+
+    def repeated(fn, steps, repeats):
+        """`repeats` timed regions of `steps` calls, back to back: (list of wall seconds, list of HIP-event ms per call, last y)"""
+        walls, evs, y = [], [], None
+        for _ in range(max(1, repeats)):
+            e, ms, y = timed(fn, steps)
+            walls.append(e)
+            evs.append(ms)
+        return walls, evs, y
+
     spin(step, 0.5)
     for _ in range(a.warmup):
         y = step()
-    elapsed, region_ms, y = timed(step, a.steps)
+    walls, region_mss, y = repeated(step, a.steps, a.repeats)
     assert type(y) is torch.Tensor and tuple(y.shape) == (BATCH, CHANNELS, N_MELS, frames)
     frames_per_step = world * BATCH * CHANNELS * frames
+    elapsed = quantile(walls, 0.5)                                       # the median region
     value = frames_per_step * a.steps / elapsed
+    region_ms = quantile(region_mss, 0.5)
+    route = tac._native.lib().tac_last_route().decode()                  # the kernel instantiation the launches took
+
+    # ---- the shader clock the kernel runs at, measured by the kernel itself: every workgroup's wave 0 records the shader
+    #      cycles and the 100 MHz ticks of its frame loop (tac_debug_clock_probe) during K more steps
+    clock_mhz = None
+    try:
+        probe = torch.zeros(2 * 1024, dtype=torch.int64, device=dev)
+        lib = tac._native.lib()
+        tac._native.check(lib.tac_debug_clock_probe(ctypes.c_void_p(probe.data_ptr()), 1024), 'tac_debug_clock_probe')
+        ratios = []
+        for _ in range(max(3, min(a.steps, 20))):
+            step()
+            torch.cuda.synchronize()
+            pr = probe.view(-1, 2).cpu()
+            ok = pr[:, 1] > 0
+            if bool(ok.any()):
+                ratios.append(float((pr[ok, 0].double() / pr[ok, 1].double()).median()) * 100.0)
+            probe.zero_()
+        lib.tac_debug_clock_probe(None, 0)
+        if ratios:
+            clock_mhz = quantile(ratios, 0.5)
+    except Exception:            # noqa: BLE001 — a diagnostic field
+        clock_mhz = None
 
     # ---- roofline of the dominant kernel (the fused melspec kernel is the only launch in a step)
     per_launch_mean_ms, med_ms = event_ms(step, min(a.steps, 50))      # (event pairs around single launches: + ~3 us each)
@@ -248,46 +348,41 @@ def run(a):
         'metric': 'mel frames/sec', 'value': value, 'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps,
         'warmup': a.warmup, 'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'repeats': len(walls), 'value_p10': frames_per_step * a.steps / quantile(walls, 0.9),
+        'value_p90': frames_per_step * a.steps / quantile(walls, 0.1),
+        'value_note': 'median of `repeats` back-to-back timed regions of `steps` steps each (barrier + synchronize on both '
+                      'sides of every region, max over ranks); p10 / p90 over the same regions',
+        'process_group': 'nccl' if distributed else None,
         'config': {'workload': 'Melspectrogram+AmplitudeToDb batch=%d/GPU x %dch x %dHz x %ds, fft_len=%d hop=%d '
                                '%d mel (%s)' % (BATCH, CHANNELS, sr, seconds, N_FFT, HOP, N_MELS, label),
                    'global_batch': world * BATCH, 'frames_per_step': frames_per_step,
                    'parallelism': 'batch-sharded x%d, no data-path collective' % world,
                    'input_buffers': '%d distinct device-resident batches of %.1f MB visited round-robin (%.0f MB > the '
                                     '256 MiB Infinity Cache)' % (nbuf, x.numel() * 4 / 1e6, nbuf * x.numel() * 4 / 1e6)},
-        'roofline': {'kernel': 'melspec_stream3_kernel<1024, 16, true, 0, 14, 12> (fused STFT + power + band-sparse mel + dB, one launch per step; 12 waves per CU)', 'bound': 'hbm',
+        'roofline': {'kernel': '%s (fused STFT + power + band-sparse mel + dB, one launch per step)' % route,
+                     'kernel_route': route, 'bound': 'hbm',
                      'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                      'traffic': None, 'alg_bytes_per_launch': alg_bytes, 'kernel_ms_mean': mean_ms,
+                     'kernel_ms_p10': quantile(region_mss, 0.1), 'kernel_ms_p90': quantile(region_mss, 0.9),
                      'kernel_ms_median': med_ms, 'kernel_ms_per_launch_events': per_launch_mean_ms,
-                     'timing': 'one HIP event pair on the launch stream around the K timed steps (one launch per step) / K; '
-                               'kernel_ms_per_launch_events / kernel_ms_median: event pairs around single launches'},
+                     'shader_clock_mhz': clock_mhz,
+                     'timing': 'median over `repeats` regions of: one HIP event pair on the launch stream around the K timed '
+                               'steps (one launch per step) / K; kernel_ms_per_launch_events / kernel_ms_median: event '
+                               'pairs around single launches; shader_clock_mhz: shader cycles / 100 MHz ticks of every '
+                               'workgroup\'s frame loop, recorded by the kernel (tac_debug_clock_probe)'},
     }
+    bound_from_counters(result['roofline'], route, clock_mhz)
     if nbuf > 1:
         # the same loop re-reading ONE batch (163.8 MB: it fits the Infinity Cache) — what rounds 1 and 2 reported
         one = lambda: model(x)
         spin(one, 0.2)
-        e1, ms1, _ = timed(one, a.steps)
+        w1, m1, _ = repeated(one, a.steps, max(1, a.repeats // 3))
+        e1, ms1 = quantile(w1, 0.5), quantile(m1, 0.5)
         result['single_buffer'] = {'value': frames_per_step * a.steps / e1, 'ms_per_step': e1 / a.steps * 1e3,
                                    'kernel_ms_mean': ms1,
                                    'frac_of_hbm_peak': alg_bytes / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                    'note': 'same steps on one re-read input batch (Infinity-Cache resident): the figure '
                                            'rounds 1 and 2 reported as roofline.frac'}
-
-    # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in
-    # separate passes, gfx950 x2 FETCH correction applied — tools/summarize_profiles.py); bench.py cannot run the
-    # profiler on itself, so the field is filled from that artefact when it is present.
-    for rnd in ('r03', 'r02', 'r01'):
-        try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', rnd, 'pmc_mel.json')))
-        except Exception:
-            continue
-        for kname, d in pmc.items():
-            if ('melspec_stream3_kernel<1024' in kname or 'melspec_stream_kernel<1024' in kname or 'melspec_sparse_kernel<1024' in kname) \
-                    and 'hbm_traffic_bytes_per_launch' in d:
-                result['roofline']['traffic'] = d['hbm_traffic_bytes_per_launch']
-                result['roofline']['traffic_source'] = ('profiles/%s/pmc_mel.json (rocprofv3 --pmc FETCH_SIZE / '
-                                                        'WRITE_SIZE)' % rnd)
-        if result['roofline']['traffic'] is not None:
-            break
 
     if rank == 0 and not a.no_stages and a.config == 'cfg2':
         stages = {}
@@ -344,18 +439,22 @@ def run(a):
 
     def gather_leg(mdl, inputs, rows_total, frames_step, steps):
         """compute + ONE RCCL all-gather of the (B/N, C, M, T) output shards"""
-        fn = rotating(lambda t: tac.distributed.all_gather_batch(mdl(t), total_rows=rows_total), inputs)
+        forced = world == 1                  # a group of one would return before the collective: run it anyway (RCCL smoke)
+        fn = rotating(lambda t: tac.distributed.all_gather_batch(mdl(t), total_rows=rows_total, force_collective=forced),
+                      inputs)
         try:        # a secondary figure: a failure here must not cost the headline line above
             for _ in range(3):
                 fn()
-            eg, _, _ = timed(fn, steps)
-            return {'value': frames_step * steps / eg, 'unit': 'frames/s', 'ms_per_step': eg / steps * 1e3}
+            wg, _, _ = repeated(fn, steps, max(1, a.repeats // 5))
+            eg = quantile(wg, 0.5)
+            return {'value': frames_step * steps / eg, 'unit': 'frames/s', 'ms_per_step': eg / steps * 1e3,
+                    'method': tac.distributed.default_method(), 'forced_at_world_1': forced}
         except Exception as exc:            # noqa: BLE001 — reported in the line, not swallowed
             return {'error': '%s: %s' % (type(exc).__name__, exc)}
 
     if distributed:
         result['with_allgather'] = gather_leg(model, xs, world * BATCH, frames_per_step, a.steps)
-        if a.config == 'cfg2':
+        if a.config == 'cfg2' and world > 1:
             # BASELINE configs[2]: every rank's 256 x 1 323 000 shard (sr 44 100), compute only and with the one
             # all-gather SURVEY §8e says dominates there (338.7 MB per rank)
             del xs[1:]
@@ -366,7 +465,8 @@ def run(a):
                 k3 = max(5, a.steps // 5)
                 s3 = rotating(m3, x3)
                 spin(s3, 0.2)
-                e3, ms3, _ = timed(s3, k3)
+                w3, m3s, _ = repeated(s3, k3, max(1, a.repeats // 5))
+                e3, ms3 = quantile(w3, 0.5), quantile(m3s, 0.5)
                 result['cfg3'] = {'workload': 'batch=%d/GPU x 1ch x %dHz x 30s (BASELINE configs[2] sharded over %d GPUs)'
                                               % (BATCH, CFG3_SR, world), 'steps': k3,
                                   'value': f3 * k3 / e3, 'unit': 'frames/s', 'ms_per_step': e3 / k3 * 1e3,

@@ -408,6 +408,34 @@ def test_apply_filterbank_streams_frame_major_spectrograms(tac):
         assert rel_err(got2, want[..., 1:-2]) < 1e-5, (n_fft, n_mels)
 
 
+@pytest.mark.timeout(120)
+def test_melbank_pack_bank_aware_placement_is_polynomial(tac):
+    """tac_melbank_pack places the band starts of every sixteen-lane LDS group by bipartite matching (lane -> bank residue,
+    smallest load per residue).  A slot in which fifteen narrow bands share ONE start next to a twelve-step band gives every
+    lane the same twelve candidate residues: no matching exists below two lanes per residue, and refusing the smaller cap
+    must not explore every eviction order (the visited set is shared by the whole augmenting search: Kuhn's algorithm).
+    Results are checked against float64 — placement only moves zero-weight taps."""
+    import time
+    n_fft, hop, f_bins = 2048, 512, 1025
+    fb = np.zeros((f_bins, 64), dtype=np.float32)
+    rng = np.random.default_rng(3)
+    for m in range(64):
+        if m % 16 == 0:
+            fb[300:348, m] = rng.random(48).astype(np.float32) + 0.1       # 12 four-tap steps: sets the slot's length
+        else:
+            fb[200:204, m] = rng.random(4).astype(np.float32) + 0.1        # one step, eleven steps of slack, all lanes alike
+    x = signals.audio_like((2, 1, 12000), seed=43)
+    chain = torch.nn.Sequential(tac.STFT(n_fft, hop), tac.ComplexNorm(2.0), tac.ApplyFilterbank(torch.from_numpy(fb))).cuda()
+    before = launches(tac)
+    t0 = time.perf_counter()
+    y = tac.realize(chain(dev(x)))
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 30.0
+    assert launched_since(tac, before) == {'tac_melspec_sparse_f32': 1}
+    p = np.abs(numpy_ref.stft(x, n_fft, hop)) ** 2
+    assert rel_err(host(y), np.einsum('...ft,fm->...mt', p, fb.astype(np.float64))) < 1e-5
+
+
 @pytest.mark.parametrize('n_fft', [1024, 400, 512, 2048])
 @pytest.mark.parametrize('path', ['sparse', 'mfma'])
 def test_fused_kernels_on_custom_filterbanks(tac, path, n_fft, monkeypatch):
@@ -1468,8 +1496,19 @@ def test_tables_follow_the_filterbank_and_window(tac):
     fb2 = tac.create_mel_filter(1025, 40, 0.0, 8000.0, False).cuda()
     a = host(tac.apply_filterbank(spec, fb2))
     fb2.data.mul_(4.0)
+    pack_of_fb = fb._tac_pack                                         # (another tensor's tables ...)
     tac.invalidate(fb2)
     assert rel_err(host(tac.apply_filterbank(spec, fb2)), 4.0 * a) < 1e-6
+    tac.realize(mel(x))
+    assert fb._tac_pack is pack_of_fb                                 # ... survive invalidate(fb2): no global epoch bump
+    # layers built under inference_mode hold tensors without a version counter: no caching for those, but they work
+    with torch.inference_mode():
+        mel_inf = tac.Melspectrogram(num_mels=64, sample_rate=16000, fft_length=2048, hop_length=512).cuda()
+        assert mel_inf[2].filterbank.is_inference()
+        y_inf = host(tac.realize(mel_inf(x)))
+        assert rel_err(y_inf, y0) < 1e-6                             # (a fresh layer: the original window and bank)
+        mel_inf[2].filterbank.mul_(2.0)                               # an in-place write nothing records
+        assert rel_err(host(tac.realize(mel_inf(x))), 2.0 * y_inf) < 1e-6
 
 
 def test_coded_waveforms_fused_into_the_frame_load(tac, golden):

@@ -78,8 +78,19 @@ def test_strict_mode_and_route_bookkeeping(tac):
         with pytest.raises(RuntimeError, match='strict mode'):
             _ops._composite_route('stft', 'dtype float64')
         assert tac.amplitude_to_db(torch.ones(3, dtype=torch.float64)).dtype == torch.float64   # CPU: unaffected
+        # backward passes are strict too by default ('backward: ...' reasons come from the autograd entry); a caller can keep
+        # strictness for forward calls only
+        with pytest.raises(RuntimeError, match='strict mode'):
+            _ops._composite_route('angle', 'backward: the op has no gradient kernel')
+        tac.set_strict(True, backward=False)
+        assert _ops.strict() and not _ops.strict_backward()
+        _ops._warned.add(('angle', 'backward: the op has no gradient kernel'))
+        _ops._composite_route('angle', 'backward: the op has no gradient kernel')          # runs (announced, counted)
+        with pytest.raises(RuntimeError, match='strict mode'):
+            _ops._composite_route('stft', 'dtype float64')
     finally:
         tac.set_strict(False)
+    assert not _ops.strict() and not _ops.strict_backward()
     with pytest.warns(tac.CompositeRouteWarning):
         _ops._warned.discard(('stft', 'test reason'))
         _ops._composite_route('stft', 'test reason')
@@ -438,11 +449,13 @@ def test_median_run_matches_nth_element(tmp_path):
 
 
 def test_float64_size_coverage_matches_the_kernel_plan(tac):
-    """``_hip64.covers`` restates ``plan_f64`` / ``geometry_f64`` of csrc/chain_f64.hip: every length <= 4096 (direct
-    transform when the half is not 5-smooth or the length is odd), above that only even lengths <= 8192 with a 5-smooth half."""
+    """``_hip64.covers``: even lengths <= 8192 with a 5-smooth half take the LDS Stockham transform of csrc/chain_f64.hip; other
+    lengths go to its O(N^2) direct transform only up to ``DIRECT_MAX`` (longer ones stay on the announced stock-torch route,
+    which is faster there although the kernel would accept any length <= 4096)."""
     h64 = tac._ops.H64
-    assert all(h64.covers(n) for n in (1, 4, 77, 134, 400, 2048, 4096, 6000, 8192, 5000))
-    assert not any(h64.covers(n) for n in (4097, 8190, 8194, 16384, 4099 * 2))
+    assert h64.DIRECT_MAX == 512
+    assert all(h64.covers(n) for n in (1, 4, 77, 134, 400, 511, 512, 2048, 4096, 6000, 8192, 5000))
+    assert not any(h64.covers(n) for n in (513, 1001, 4094, 4097, 8190, 8194, 16384, 4099 * 2))
 
 
 _OLA_RUNS_CHECK = r"""

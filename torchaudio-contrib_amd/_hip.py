@@ -6,6 +6,7 @@ device pointers, sizes and the caller's current HIP stream.  PyTorch only provid
 the stream.  There is no fallback in here: a missing ``libtac_amd.so`` or a failing launch raises.
 """
 import ctypes
+import itertools
 import math
 import os
 import threading
@@ -37,7 +38,15 @@ _epoch = 0
 _CACHE_ATTRS = ('_tac_pack', '_tac_plan', '_tac_T', '_tac_adj', '_tac_dft', '_tac_dftT')
 
 
+_unstamped = itertools.count()
+
+
 def _stamp(t):
+    """What identifies a tensor's contents cheaply.  Tensors created under ``torch.inference_mode`` carry no version counter
+    (reading it raises): they get a stamp that never repeats, i.e. their derived tables are rebuilt on every call rather
+    than risk serving a stale one after an in-place write nobody recorded."""
+    if t.is_inference():
+        return ('unversioned', next(_unstamped))
     return (t._version, t.data_ptr(), _epoch)
 
 
@@ -57,9 +66,12 @@ def invalidate(tensor=None):
                 delattr(tensor, name)
             except Exception:
                 pass
+    # only this tensor's entries go: the tables of every other window / filterbank stay valid (a global epoch bump would
+    # have each of them rebuilt, with a host synchronisation, on its next use)
     with _lock:
-        _epoch += 1                   # routes cached per geometry carry the epoch as well
-        _geometry_routes_clear()
+        for g in _geometry_cache.values():
+            for key in [k for k in g.routes if k[0] == id(tensor)]:
+                del g.routes[key]
 
 
 def _geometry_routes_clear():

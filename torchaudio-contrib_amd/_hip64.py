@@ -14,18 +14,29 @@ from . import _native
 _F64 = torch.float64
 
 
-def covers(n_fft):
-    """Even lengths <= 8192 whose half is 5-smooth (LDS Stockham transform, radix 4 / 2 / 3 / 5 passes) or any length
-    <= 4096 (direct transform) — ``plan_f64`` / ``geometry_f64`` in csrc/chain_f64.hip."""
-    if 1 <= n_fft <= 4096:
-        return True
-    if n_fft > 8192 or n_fft % 2:
+#: longest fft_length handed to the O(N^2) direct float64 transform of chain_f64.hip (odd lengths, halves with a prime
+#: factor above 5).  It costs 2 N^2 multiply-adds per frame in one lane's scalar loop — 0.5 M at 512, 33 M at 4094 — so above
+#: this the announced stock-torch route (hipFFT) is the faster one and is taken instead.
+DIRECT_MAX = 512
+
+
+def _half_is_5_smooth(n_fft):
+    if n_fft % 2:
         return False
     m = n_fft // 2
     for r in (2, 3, 5):
         while m % r == 0:
             m //= r
     return m == 1
+
+
+def covers(n_fft):
+    """Even lengths <= 8192 whose half is 5-smooth (LDS Stockham transform, radix 4 / 2 / 3 / 5 passes), or any other length
+    <= ``DIRECT_MAX`` (direct transform) — ``plan_f64`` / ``geometry_f64`` in csrc/chain_f64.hip accept more (any length
+    <= 4096 through the direct kernel), the Python layer does not route long non-smooth sizes there."""
+    if n_fft < 1 or n_fft > 8192:
+        return False
+    return _half_is_5_smooth(n_fft) or n_fft <= DIRECT_MAX
 
 
 def all_f64(*tensors):

@@ -44,19 +44,34 @@ class CompositeRouteWarning(UserWarning):
     """An op was evaluated by stock torch operators instead of the gfx950 kernels (float64 input, unsupported size)."""
 
 
-def set_strict(flag):
-    """With strict on, a tensor on a HIP device is never handed to the stock-torch route: the call raises instead."""
-    global _strict
+_strict_backward = None        # None: follow _strict
+
+
+def set_strict(flag, backward=None):
+    """With strict on, a tensor on a HIP device is never handed to the stock-torch route: the call raises instead.
+
+    That covers backward passes as well: the gradient of an op without a gradient kernel (``phase_vocoder``, ``angle``,
+    ``magphase``, ``hpss``, ``db_to_amplitude``), every float64 gradient and every double backward re-evaluate the op with
+    stock torch operators, so under ``set_strict(True)`` they RAISE (since round 3; earlier rounds let a backward pass through
+    when its forward had run on the kernels).  ``backward=False`` keeps strictness for forward calls only — those backward
+    passes then run, announced by ``CompositeRouteWarning`` and counted in ``composite_calls``; ``backward=None`` (default)
+    follows ``flag``."""
+    global _strict, _strict_backward
     _strict = bool(flag)
+    _strict_backward = None if backward is None else bool(backward)
 
 
 def strict():
     return _strict
 
 
+def strict_backward():
+    return _strict if _strict_backward is None else _strict_backward
+
+
 def _composite_route(op, reason):
     composite_calls[(op, reason)] = composite_calls.get((op, reason), 0) + 1
-    if _strict:
+    if strict_backward() if reason.startswith('backward: ') else _strict:
         raise RuntimeError('tac_amd::%s: %s is outside the gfx950 kernels and strict mode forbids the stock-torch '
                            'route' % (op, reason))
     if (op, reason) not in _warned:

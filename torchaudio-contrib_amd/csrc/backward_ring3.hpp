@@ -121,7 +121,7 @@ melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ 
         load_tw1(tw1);
         F::template pass_write<0, true>(v, xa, t, t);
         wave_lds_fence();
-        F::template pass_readback<1>(v, xa, t);
+        s3_readback_pass1<F>(v, xa, t);                     // (single ds_read_b64: TAC_S3_B64, melspec_stream3.hpp)
         F::template pass_twiddle<1, true>(v, tw1);
         F::template pass_butterflies<1>(v);
         F::exchange_1_2_in_registers(v);
@@ -186,15 +186,7 @@ melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ 
         }
         passes_after_first(std::true_type{});
         cf zm[F::NPAIR], zmid;
-        {
-            const cf* const pb = xa + lds_pad(NC - t);
-#pragma unroll
-            for (int p = 0; p < F::NPAIR; ++p) {
-                const cf z = pb[-lds_pad_c(p * F::LPF)];
-                zm[p] = (p == 0 && t == 0) ? v[F::reg_of_spectrum(0)] : z;
-            }
-            zmid = xa[lds_pad(NC / 2)];
-        }
+        s3_read_partners<F>(v, xa, zm, zmid, t);
         // the frame's mel-gradient row, for the per-bin gathers
         if constexpr (FUSE) {
 #pragma unroll
@@ -255,11 +247,7 @@ melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ 
         wave_lds_fence();
 #pragma unroll
         for (int p = 0; p < F::NPAIR; ++p) v[p] = u[p];
-        {
-            const cf* const src = xa + lds_pad(t);
-#pragma unroll
-            for (int q = F::NPAIR; q < E; ++q) v[q] = src[lds_pad_c(q * F::LPF)];
-        }
+        s3_read_strided<F::NPAIR, 8>(&v[F::NPAIR], xa + lds_pad(t));
         // ---- inverse transform: R[] in natural order at xa[lds_pad(i)]
         F::template pass_butterflies<0>(v);
         passes_after_first(std::false_type{});
@@ -285,6 +273,22 @@ melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ 
             const f4* wl = reinterpret_cast<const f4*>(winl) + t;
             const cf* const src = xa + lds_pad(t);
             cf acc[E];
+#if TAC_S3_B64
+            s3_read_strided<0, 8>(&acc[0], src);            // (two batches of eight: the kernel sits at its register cap)
+#pragma unroll
+            for (int uu = 0; uu < E / 4; ++uu) {
+                const f4 x = wl[uu * 64];
+                acc[2 * uu] = cmul_elem(acc[2 * uu], mkc(x.x, -x.y));        // (Re, -Im) R[m] · window / 2
+                acc[2 * uu + 1] = cmul_elem(acc[2 * uu + 1], mkc(x.z, -x.w));
+            }
+            s3_read_strided<8, 8>(&acc[8], src);
+#pragma unroll
+            for (int uu = E / 4; uu < E / 2; ++uu) {
+                const f4 x = wl[uu * 64];
+                acc[2 * uu] = cmul_elem(acc[2 * uu], mkc(x.x, -x.y));
+                acc[2 * uu + 1] = cmul_elem(acc[2 * uu + 1], mkc(x.z, -x.w));
+            }
+#else
 #pragma unroll
             for (int uu = 0; uu < E / 2; ++uu) {
                 const f4 x = wl[uu * 64];
@@ -292,6 +296,7 @@ melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ 
                 acc[2 * uu] = cmul_elem(r0, mkc(x.x, -x.y));                 // (Re, -Im) R[m] · window / 2
                 acc[2 * uu + 1] = cmul_elem(r1, mkc(x.z, -x.w));
             }
+#endif
 #pragma unroll
             for (int j = 0; j < R; ++j) acc[j] = cadd(acc[j], ring[j]);
 #pragma unroll

@@ -615,7 +615,11 @@ static int pack_lanes(const std::vector<float>& h, int n_freqs, int n_mels, floa
                 for (int cap = 1; cap <= 16; ++cap) {
                     std::vector<int> load[16];                               // lanes (indices into `lanes`) per residue
                     int choice[16];
-                    std::function<bool(int, unsigned)> place = [&](int i, unsigned seen) -> bool {
+                    // Kuhn's augmenting search with residue capacities: ONE visited set per top-level lane, shared by the whole
+                    // recursion (a residue that could not be freed once in this search cannot be freed later in it either), so
+                    // an infeasible cap is refused in O(lanes x candidates) instead of exploring every eviction order
+                    unsigned seen = 0;
+                    std::function<bool(int)> place = [&](int i) -> bool {
                         for (int c : cand[i]) {
                             const int r = (c / 4) & 15;
                             if (seen & (1u << r)) continue;
@@ -623,15 +627,21 @@ static int pack_lanes(const std::vector<float>& h, int n_freqs, int n_mels, floa
                             if ((int)load[r].size() < cap) { load[r].push_back(i); choice[i] = c; return true; }
                             for (size_t q = 0; q < load[r].size(); ++q) {
                                 const int other = load[r][q];
-                                load[r].erase(load[r].begin() + q);
-                                if (place(other, seen)) { load[r].push_back(i); choice[i] = c; return true; }
-                                load[r].insert(load[r].begin() + q, other);
+                                if (place(other)) {                       // `other` moved to another residue: its seat here goes to i
+                                    load[r].erase(std::find(load[r].begin(), load[r].end(), other));
+                                    load[r].push_back(i);
+                                    choice[i] = c;
+                                    return true;
+                                }
                             }
                         }
                         return false;
                     };
                     bool ok = true;
-                    for (int i = 0; i < 16 && ok; ++i) ok = place(i, 0u);
+                    for (int i = 0; i < 16 && ok; ++i) {
+                        seen = 0;
+                        ok = place(i);
+                    }
                     if (ok) {
                         for (int i = 0; i < 16; ++i) start[s * 64 + lanes[i]] = choice[i];
                         break;

@@ -26,13 +26,42 @@ __host__ __device__ inline size_t stream3_lds_bytes(int wtot, int waves, bool co
 }
 
 #ifndef TAC_S3_B64
-#define TAC_S3_B64 0          // A/B: exchange read-backs as single ds_read_b64 (2 LDS cycles each) instead of hipcc's merged ds_read2_b64 (8 per pair)
+#define TAC_S3_B64 1          // exchange read-backs as single ds_read_b64 (2 LDS cycles each) instead of hipcc's merged ds_read2_b64 (8 per pair):
+                              // -1.2 ... -2.0 % on the fused kernel, same-process A/B on three boxes (tools/ablation/README.md, round 4); 0 = hipcc's form
+#endif
+#ifndef TAC_S3_BPERM
+#define TAC_S3_BPERM 0        // A/B: R2C partners fetched lane to lane (ds_bpermute_b32) instead of through the exchange area
+#endif
+#ifndef TAC_S3_NODIV
+#define TAC_S3_NODIV 0        // A/B: (row, frame) of a dealt frame by conditional subtraction from the chunk's first (no division per frame)
+#endif
+#ifndef TAC_S3_PTW_EARLY
+#define TAC_S3_PTW_EARLY 0    // A/B: the R2C twiddle reads issued ahead of pass 2 (in flight behind its butterflies) instead of behind the partner reads
+#endif
+#ifndef TAC_S3_ROW_ST64
+#define TAC_S3_ROW_ST64 1     // the |X|^2 row written as eight ds_write2st64_b32 (two bins 64 apart per instruction) instead of hipcc's mix of
+                              // twelve ds_write_b32 + three write2st64: -0.65 % alone (same-process A/B, round 4); 0 = hipcc's form
 #endif
 #ifndef TAC_S3_NOFENCE0
 #define TAC_S3_NOFENCE0 0     // A/B: no compiler fence between the first butterfly and its exchange writes (the writes may start early)
 #endif
 #ifndef TAC_S3_ADDTID
 #define TAC_S3_ADDTID 0       // A/B: lower half of the |X|^2 row written with ds_write_addtid_b32 (2 LDS cycles, no address register)
+#endif
+#ifndef TAC_S3_STAMPS
+#define TAC_S3_STAMPS 0       // debug build of tools/r04/s3_stamps.py: per-wave cycle sums of the frame loop's stages overwrite the head of out[]
+#endif
+#if TAC_S3_STAMPS
+#define S3_STAMP(i)                                                          \
+    do {                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+        const unsigned long long now_ = __builtin_readcyclecounter();        \
+        stamp_acc[i] += now_ - stamp_last;        /* wave-uniform: SGPRs */  \
+        stamp_last = now_;                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+    } while (0)
+#else
+#define S3_STAMP(i) do { } while (0)
 #endif
 #ifndef TAC_S3_W0_REGS
 #define TAC_S3_W0_REGS 0      // A/B: the four weight quads of band slot 0 live in registers (16 VGPRs) instead of being re-read per frame
@@ -54,10 +83,85 @@ __device__ __forceinline__ void lds_wait_all(cf (&a)[16]) {
                    "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
                  :: "memory");
 }
+__device__ __forceinline__ void lds_wait_all8(cf* a) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                 :: "memory");
+}
 __device__ __forceinline__ void lds_wait_all(cf (&a)[8], cf& b) {
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(b)
                  :: "memory");
+}
+
+// ---- the two exchange read-backs of the one-frame-per-wave front end, shared by melspec_stream3_kernel and stft_stream3_kernel
+// (1) operands of pass 1 back from the exchange area
+template <class F>
+__device__ __forceinline__ void s3_readback_pass1(cf (&v)[16], const cf* xa, int t) {
+#if TAC_S3_B64
+    const unsigned ra = lds_offset_of(xa + lds_pad(t));
+    auto rd = [&](auto qc) { constexpr int q = decltype(qc)::value; v[q] = lds_read_b64_single<lds_pad_c(q * (F::NC / 16)) * 8>(ra); };
+    rd(std::integral_constant<int, 0>{}); rd(std::integral_constant<int, 1>{}); rd(std::integral_constant<int, 2>{}); rd(std::integral_constant<int, 3>{});
+    rd(std::integral_constant<int, 4>{}); rd(std::integral_constant<int, 5>{}); rd(std::integral_constant<int, 6>{}); rd(std::integral_constant<int, 7>{});
+    rd(std::integral_constant<int, 8>{}); rd(std::integral_constant<int, 9>{}); rd(std::integral_constant<int, 10>{}); rd(std::integral_constant<int, 11>{});
+    rd(std::integral_constant<int, 12>{}); rd(std::integral_constant<int, 13>{}); rd(std::integral_constant<int, 14>{}); rd(std::integral_constant<int, 15>{});
+    lds_wait_all(v);
+#else
+    F::template pass_readback<1>(v, xa, t);
+#endif
+}
+// (2) the R2C partners Z[NC - k] of the lane's eight pairs and Z[NC / 2], from the upper half of the spectrum in the exchange area
+template <class F>
+__device__ __forceinline__ void s3_read_partners(const cf (&v)[16], const cf* xa, cf (&zm)[8], cf& zmid, int t) {
+    constexpr int NC = F::NC;
+#if TAC_S3_B64
+    static_assert(F::NPAIR == 8, "eight partners per lane");
+    const unsigned pa = lds_offset_of(xa + lds_pad(NC - t) - lds_pad_c(7 * F::LPF));      // partner of pair 7; pair p sits (7 - p) * 68 slots above
+    auto rd = [&](auto pc) { constexpr int p = decltype(pc)::value; zm[p] = lds_read_b64_single<lds_pad_c((7 - p) * F::LPF) * 8>(pa); };
+    rd(std::integral_constant<int, 0>{}); rd(std::integral_constant<int, 1>{}); rd(std::integral_constant<int, 2>{}); rd(std::integral_constant<int, 3>{});
+    rd(std::integral_constant<int, 4>{}); rd(std::integral_constant<int, 5>{}); rd(std::integral_constant<int, 6>{}); rd(std::integral_constant<int, 7>{});
+    zmid = lds_read_b64_single<0>(lds_offset_of(xa + lds_pad(NC / 2)));
+    lds_wait_all(zm, zmid);
+    if (t == 0) zm[0] = v[F::reg_of_spectrum(0)];
+#else
+    const cf* const pb = xa + lds_pad(NC - t);
+#pragma unroll
+    for (int p = 0; p < F::NPAIR; ++p) {
+        const cf z = pb[-lds_pad_c(p * F::LPF)];
+        zm[p] = (p == 0 && t == 0) ? v[F::reg_of_spectrum(0)] : z;
+    }
+    zmid = xa[lds_pad(NC / 2)];
+#endif
+}
+// ... after the butterflies of the last pass: the half write of the spectrum, then the partners (or lane to lane: TAC_S3_BPERM)
+template <class F>
+__device__ __forceinline__ void s3_r2c_partners(const cf (&v)[16], cf* xa, cf (&zm)[8], cf& zmid, int t) {
+#if TAC_S3_BPERM
+    F::r2c_partners_bpermute(v, zm, zmid, t);
+#else
+    wave_lds_fence();
+    F::template pass_write<2, true>(v, xa, t, t);
+    wave_lds_fence();
+    s3_read_partners<F>(v, xa, zm, zmid, t);
+#endif
+}
+// eight / sixteen complex values 64 slots apart starting at `first` (a padded slot address of the exchange area)
+template <int N0, int CNT>
+__device__ __forceinline__ void s3_read_strided(cf* dst, const cf* first) {
+    static_assert(CNT == 8 || CNT == 16, "eight or sixteen values");
+#if TAC_S3_B64
+    const unsigned ra = lds_offset_of(first);
+    auto rd = [&](auto qc) { constexpr int q = decltype(qc)::value; if constexpr (q < CNT) dst[q] = lds_read_b64_single<lds_pad_c((N0 + q) * 64) * 8>(ra); };
+    rd(std::integral_constant<int, 0>{}); rd(std::integral_constant<int, 1>{}); rd(std::integral_constant<int, 2>{}); rd(std::integral_constant<int, 3>{});
+    rd(std::integral_constant<int, 4>{}); rd(std::integral_constant<int, 5>{}); rd(std::integral_constant<int, 6>{}); rd(std::integral_constant<int, 7>{});
+    rd(std::integral_constant<int, 8>{}); rd(std::integral_constant<int, 9>{}); rd(std::integral_constant<int, 10>{}); rd(std::integral_constant<int, 11>{});
+    rd(std::integral_constant<int, 12>{}); rd(std::integral_constant<int, 13>{}); rd(std::integral_constant<int, 14>{}); rd(std::integral_constant<int, 15>{});
+    if constexpr (CNT == 16) lds_wait_all(*reinterpret_cast<cf(*)[16]>(dst));
+    else lds_wait_all8(dst);
+#else
+#pragma unroll
+    for (int q = 0; q < CNT; ++q) dst[q] = first[lds_pad_c((N0 + q) * 64)];
+#endif
 }
 
 // ---- set-up shared by the one-frame-per-wave kernels (this file, stft_stream3.hpp): the loop-invariant tables into LDS.
@@ -115,8 +219,8 @@ struct S3Setup {
 };
 
 #ifndef TAC_S3_PTW_REGS
-#define TAC_S3_PTW_REGS 0
-#endif
+#define TAC_S3_PTW_REGS 1     // the lane's eight R2C twiddles live in registers (16 VGPRs: the kernel sits at 156 of 168) instead of four
+#endif                        // ds_read_b128 per frame: -0.6 % alone, -1.5 % together with TAC_S3_ROW_ST64 (same-process A/B, round 4)
 #ifndef TAC_S3_LDS_EXCHANGE
 #define TAC_S3_LDS_EXCHANGE 0
 #endif
@@ -168,12 +272,31 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     cf v[E];
     int mode = 0, row = 0;
     long long fr = 0;
+#if TAC_S3_NODIV
+    const unsigned row_b = (unsigned)begin / T, fr_b = (unsigned)begin - row_b * T;      // the chunk's first frame: one division per workgroup
+#endif
     auto request = [&](int i) {
         i = i < nloc ? i : nloc - 1;
+#if TAC_S3_NODIV
+        unsigned r = row_b, f = fr_b + (unsigned)place(i);
+        if (f >= T) {                                       // (wave-uniform) past the first row of the chunk
+            if (chunk <= (long long)T) {                    // a chunk of at most one row's worth of frames wraps once
+                f -= T;
+                ++r;
+            } else {
+                const unsigned q = f / T;
+                r += q;
+                f -= q * T;
+            }
+        }
+        row = (int)r;
+        fr = (long long)f;
+#else
         const unsigned gf = (unsigned)(begin + place(i));
         const unsigned r = gf / T;
         row = (int)r;
         fr = (long long)(gf - r * T);
+#endif
         const long long start = fr * (long long)g.hop - g.center_pad;
         const bool ok = g.vec2_ok && start >= 0 && start + F::N <= g.length;
         mode = ok ? 1 : 2;
@@ -338,6 +461,10 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         probe_c = __builtin_readcyclecounter();
         probe_w = wall_clock64();
     }
+#if TAC_S3_STAMPS
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_last = __builtin_readcyclecounter();
+#endif
     while (i < nloc) {
         // the next frame of this wave (the counter's answer travels with the stage's other LDS traffic)
         unsigned ask = 0;
@@ -365,6 +492,7 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             Dft<16>::run_windowed(v, win);
 #endif
         }
+        S3_STAMP(0);                                          // samples waited for, window reads, first butterfly
 #if !TAC_S3_NOFENCE0
         wave_lds_fence();
 #endif
@@ -380,19 +508,8 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         }
         F::template pass_write<0, true>(v, xa, t, t);
         wave_lds_fence();
-#if TAC_S3_B64
-        {
-            const unsigned ra = lds_offset_of(xa + lds_pad(t));
-            auto rd = [&](auto qc) { constexpr int q = decltype(qc)::value; v[q] = lds_read_b64_single<lds_pad_c(q * (NC / 16)) * 8>(ra); };
-            rd(std::integral_constant<int, 0>{}); rd(std::integral_constant<int, 1>{}); rd(std::integral_constant<int, 2>{}); rd(std::integral_constant<int, 3>{});
-            rd(std::integral_constant<int, 4>{}); rd(std::integral_constant<int, 5>{}); rd(std::integral_constant<int, 6>{}); rd(std::integral_constant<int, 7>{});
-            rd(std::integral_constant<int, 8>{}); rd(std::integral_constant<int, 9>{}); rd(std::integral_constant<int, 10>{}); rd(std::integral_constant<int, 11>{});
-            rd(std::integral_constant<int, 12>{}); rd(std::integral_constant<int, 13>{}); rd(std::integral_constant<int, 14>{}); rd(std::integral_constant<int, 15>{});
-            lds_wait_all(v);
-        }
-#else
-        F::template pass_readback<1>(v, xa, t);
-#endif
+        s3_readback_pass1<F>(v, xa, t);
+        S3_STAMP(1);                                          // exchange: write burst, read-back
         // ---- s12
         F::template pass_twiddle<1, true>(v, tw1);
         F::template pass_butterflies<1>(v);
@@ -404,39 +521,28 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
 #else
         F::exchange_1_2_in_registers(v);
 #endif
-        F::template pass_twiddle<2, true>(v, tw2);
-        F::template pass_butterflies<2>(v);
-        wave_lds_fence();
-        F::template pass_write<2, true>(v, xa, t, t);
-        wave_lds_fence();
-        cf zm[F::NPAIR], zmid;
-#if TAC_S3_B64
+#if TAC_S3_PTW_EARLY && !TAC_S3_PTW_REGS
+        cf ptw[F::NPAIR];
         {
-            static_assert(F::NPAIR == 8, "eight partners per lane");
-            const unsigned pa = lds_offset_of(xa + lds_pad(NC - t) - lds_pad_c(7 * F::LPF));      // partner of pair 7; pair p sits (7 - p) * 68 slots above
-            auto rd = [&](auto pc) { constexpr int p = decltype(pc)::value; zm[p] = lds_read_b64_single<lds_pad_c((7 - p) * F::LPF) * 8>(pa); };
-            rd(std::integral_constant<int, 0>{}); rd(std::integral_constant<int, 1>{}); rd(std::integral_constant<int, 2>{}); rd(std::integral_constant<int, 3>{});
-            rd(std::integral_constant<int, 4>{}); rd(std::integral_constant<int, 5>{}); rd(std::integral_constant<int, 6>{}); rd(std::integral_constant<int, 7>{});
-            zmid = lds_read_b64_single<0>(lds_offset_of(xa + lds_pad(NC / 2)));
-            lds_wait_all(zm, zmid);
-            if (t == 0) zm[0] = v[F::reg_of_spectrum(0)];
-        }
-#else
-        {
-            const cf* const pb = xa + lds_pad(NC - t);
+            const f4* pl = reinterpret_cast<const f4*>(ptwl) + t;
 #pragma unroll
-            for (int p = 0; p < F::NPAIR; ++p) {
-                const cf z = pb[-lds_pad_c(p * F::LPF)];
-                zm[p] = (p == 0 && t == 0) ? v[F::reg_of_spectrum(0)] : z;
+            for (int u = 0; u < F::NPAIR / 2; ++u) {
+                const f4 x = pl[u * 64];
+                ptw[2 * u] = mkc(x.x, x.y);
+                ptw[2 * u + 1] = mkc(x.z, x.w);
             }
-            zmid = xa[lds_pad(NC / 2)];
         }
 #endif
+        F::template pass_twiddle<2, true>(v, tw2);
+        F::template pass_butterflies<2>(v);
+        S3_STAMP(2);                                          // passes 1 and 2
+        cf zm[F::NPAIR], zmid;
+        s3_r2c_partners<F>(v, xa, zm, zmid, t);
         // ---- s3: R2C split -> |X|^p; the row overwrites the exchange area once every lane holds its partners
         cf pw[F::NPAIR];
 #if TAC_S3_PTW_REGS
         const cf (&ptw)[F::NPAIR] = ptw_regs;
-#else
+#elif !TAC_S3_PTW_EARLY
         cf ptw[F::NPAIR];
         {
             const f4* pl = reinterpret_cast<const f4*>(ptwl) + t;
@@ -474,6 +580,30 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
 #pragma unroll
             for (int p = 0; p < F::NPAIR; ++p) prow[NC - (t + p * F::LPF)] = POW2 ? pw[p].y : __builtin_amdgcn_sqrtf(pw[p].y);
         }
+#elif TAC_S3_ROW_ST64
+        {
+            // bins t + 64 p and t + 64 (p + 1) are 256 bytes apart: one ds_write2st64_b32 per pair of pairs (6 LDS cycles for two
+            // dwords against 4 + 4), lower half ascending from &prow[t], upper half descending onto &prow[NC - t - 448]
+            float lo[F::NPAIR], hi[F::NPAIR];
+#pragma unroll
+            for (int p = 0; p < F::NPAIR; ++p) {
+                lo[p] = POW2 ? pw[p].x : __builtin_amdgcn_sqrtf(pw[p].x);
+                hi[p] = POW2 ? pw[p].y : __builtin_amdgcn_sqrtf(pw[p].y);
+            }
+            const unsigned alo = lds_offset_of(prow + t), ahi = lds_offset_of(prow + (NC - t - 7 * F::LPF));
+            asm volatile("ds_write2st64_b32 %8, %0, %1 offset0:0 offset1:1\n\t"
+                         "ds_write2st64_b32 %8, %2, %3 offset0:2 offset1:3\n\t"
+                         "ds_write2st64_b32 %8, %4, %5 offset0:4 offset1:5\n\t"
+                         "ds_write2st64_b32 %8, %6, %7 offset0:6 offset1:7"
+                         :: "v"(lo[0]), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(lo[4]), "v"(lo[5]), "v"(lo[6]), "v"(lo[7]), "v"(alo)
+                         : "memory");
+            asm volatile("ds_write2st64_b32 %8, %0, %1 offset0:7 offset1:6\n\t"
+                         "ds_write2st64_b32 %8, %2, %3 offset0:5 offset1:4\n\t"
+                         "ds_write2st64_b32 %8, %4, %5 offset0:3 offset1:2\n\t"
+                         "ds_write2st64_b32 %8, %6, %7 offset0:1 offset1:0"
+                         :: "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(hi[4]), "v"(hi[5]), "v"(hi[6]), "v"(hi[7]), "v"(ahi)
+                         : "memory");
+        }
 #else
 #pragma unroll
         for (int p = 0; p < F::NPAIR; ++p) {
@@ -485,10 +615,12 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         if (t == 0) prow[NC / 2] = POW2 ? pmid : __builtin_amdgcn_sqrtf(pmid);
         if (t < C::PROW - NBINS) prow[NBINS + t] = 0.0f;                    // slack taps carry zero weights: keep them finite
         wave_lds_fence();
+        S3_STAMP(3);                                          // partner reads, R2C split, row in place
         // ---- the next frame's samples go out now (v is dead), they land during the contraction
         const int cur = i;
         i = (int)__builtin_amdgcn_readfirstlane(ask);
         request(i);
+        S3_STAMP(4);                                          // counter answer + sample request
         // ---- s4: filterbank contraction, dB, row store
         if constexpr (FAST1 > 0) {
             const int ci = cur < nloc ? cur : nloc - 1;
@@ -602,6 +734,7 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
                 }
             }
         }
+        S3_STAMP(5);                                          // contraction, dB, row store
         wave_lds_fence();                                                   // the row is consumed: the area takes the next frame
     }
     if (m.probe && w == 0) {
@@ -611,6 +744,13 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             m.probe[2 * blockIdx.x + 1] = dw;
         }
     }
+#if TAC_S3_STAMPS
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m.out[((long long)blockIdx.x * WAVES + w) * 8 + k] = (float)stamp_acc[k];
+    }
+#endif
 #if TAC_S3_CYCLES
     // debug build (tools/stream3_cycles.py): shader cycles and 100 MHz ticks of every wave's frame loop, over the first outputs
     __syncthreads();

@@ -66,20 +66,32 @@ stft_stream3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
     cf v[E];
     int mode = 0, row = 0;
     long long fr = 0;
-    auto request = [&](int i) {
+#ifndef TAC_S3_EARLYREQ
+#define TAC_S3_EARLYREQ 1       // the twelve-wave complex-row form requests the NEXT frame's samples into their own registers as soon as
+#endif                          // the current frame's are consumed (a whole frame of cover instead of the row stores' issue time): -1.1 ... -1.4 %
+                                // on the complex rows (same-process A/B); the real rows measure best with sixteen waves and the late request
+    constexpr bool EARLY = TAC_S3_EARLYREQ && WAVES == 12 && MODE == 0;
+    cf nx[EARLY ? E : 1];           // EARLY: the requested (next) frame's samples; v is the frame being transformed
+    int nmode = 0, nrow = 0;
+    long long nfr = 0;
+    auto request_into = [&](int i, cf* dst, int& mode_o, int& row_o, long long& fr_o) {
         i = i < nloc ? i : nloc - 1;
         const unsigned gf = (unsigned)(begin + i);
         const unsigned r = gf / T;
-        row = (int)r;
-        fr = (long long)(gf - r * T);
-        const long long start = fr * (long long)g.hop - g.center_pad;
+        row_o = (int)r;
+        fr_o = (long long)(gf - r * T);
+        const long long start = fr_o * (long long)g.hop - g.center_pad;
         const bool ok = g.vec2_ok && start >= 0 && start + F::N <= g.length;
-        mode = ok ? 1 : 2;
+        mode_o = ok ? 1 : 2;
         long long cs = start < 0 ? 0 : start;
         cs = cs + F::N <= g.length ? cs : g.length - F::N;
-        const cf* src = reinterpret_cast<const cf*>(g.wave + (long long)row * g.row_stride + cs);
+        const cf* src = reinterpret_cast<const cf*>(g.wave + (long long)row_o * g.row_stride + cs);
 #pragma unroll
-        for (int q = 0; q < E; ++q) v[q] = src[t + q * F::LPF];
+        for (int q = 0; q < E; ++q) dst[q] = src[t + q * F::LPF];
+    };
+    auto request = [&](int i) {
+        if constexpr (EARLY) request_into(i, nx, nmode, nrow, nfr);
+        else request_into(i, v, mode, row, fr);
     };
     // the wave's first frame is requested behind the table loads and ahead of the LDS stores and the barrier: its HBM latency
     // runs behind the rest of the set-up
@@ -93,7 +105,15 @@ stft_stream3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
     int i = w;
     while (i < nloc) {
         unsigned ask = 0;
+        int i_next = 0;
         if (t == 0) ask = __hip_atomic_fetch_add(next_frame, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if constexpr (EARLY) {                              // the frame requested during the previous one becomes current
+            mode = nmode;
+            row = nrow;
+            fr = nfr;
+#pragma unroll
+            for (int q = 0; q < E; ++q) v[q] = nx[q];
+        }
         const long long g0 = ((long long)row * T + fr) * LENF;      // this frame's row in the frame-major output
 #ifndef TAC_S3_VMCNT0
 #define TAC_S3_VMCNT0 0
@@ -107,6 +127,17 @@ stft_stream3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
             asm volatile("v_mov_b32 %0, %1" : "=v"(tz) : "v"(t));
             load_frame<F, false, true, true>(v, g, nullptr, xa, row, fr, tz, FetchF32{g.wave});
         }
+#ifndef TAC_S3_ABL_NOFFT
+#define TAC_S3_ABL_NOFFT 0      // timing-only ablation (WRONG RESULTS): no window, no transform — the frame loads and the row stores alone
+#endif
+#if TAC_S3_ABL_NOFFT
+        cf zm[F::NPAIR], zmid = v[0], ptw[F::NPAIR];
+#pragma unroll
+        for (int p = 0; p < F::NPAIR; ++p) {
+            zm[p] = v[F::NPAIR + p];
+            ptw[p] = mkc(1.0f, 0.0f);
+        }
+#else
         {
             cf win[E];
             const f4* wl = reinterpret_cast<const f4*>(winl) + t;
@@ -117,6 +148,12 @@ stft_stream3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
                 win[2 * u + 1] = mkc(x.z, x.w);
             }
             Dft<16>::run_windowed(v, win);
+        }
+        if constexpr (EARLY) {                              // nx is consumed: the next frame's samples go out now
+            i_next = (int)__builtin_amdgcn_readfirstlane(ask);
+            __builtin_amdgcn_sched_barrier(0);
+            request(i_next);
+            __builtin_amdgcn_sched_barrier(0);
         }
         wave_lds_fence();
         cf tw1[16];
@@ -131,26 +168,15 @@ stft_stream3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
         }
         F::template pass_write<0, true>(v, xa, t, t);
         wave_lds_fence();
-        F::template pass_readback<1>(v, xa, t);
+        s3_readback_pass1<F>(v, xa, t);
         // ---- s12
         F::template pass_twiddle<1, true>(v, tw1);
         F::template pass_butterflies<1>(v);
         F::exchange_1_2_in_registers(v);
         F::template pass_twiddle<2, true>(v, tw2);
         F::template pass_butterflies<2>(v);
-        wave_lds_fence();
-        F::template pass_write<2, true>(v, xa, t, t);
-        wave_lds_fence();
         cf zm[F::NPAIR], zmid;
-        {
-            const cf* const pb = xa + lds_pad(NC - t);
-#pragma unroll
-            for (int p = 0; p < F::NPAIR; ++p) {
-                const cf z = pb[-lds_pad_c(p * F::LPF)];
-                zm[p] = (p == 0 && t == 0) ? v[F::reg_of_spectrum(0)] : z;
-            }
-            zmid = xa[lds_pad(NC / 2)];
-        }
+        s3_r2c_partners<F>(v, xa, zm, zmid, t);
         // ---- s3: R2C split; the row overwrites the exchange area once every lane holds its partners
         cf ptw[F::NPAIR];
         {
@@ -162,6 +188,7 @@ stft_stream3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
                 ptw[2 * u + 1] = mkc(x.z, x.w);
             }
         }
+#endif
         const int a = (int)(g0 & 3);
         float* const stage = reinterpret_cast<float*>(xa) + a;      // LDS and global share their 16-byte phase
         if constexpr (MODE == 0) {
@@ -195,11 +222,24 @@ stft_stream3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
         wave_lds_fence();
         // ---- the next frame's samples are requested BEFORE this row's stores (gfx950 counts loads and stores in one
         //      in-order vmcnt: this way "my samples have landed" does not wait for the stores behind them)
-        i = (int)__builtin_amdgcn_readfirstlane(ask);
-        __builtin_amdgcn_sched_barrier(0);
-        request(i);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- the row leaves as 1 + NST + 1 unconditional stores: out-of-range lanes repeat a neighbour's element
+        if constexpr (EARLY) {
+            i = i_next;
+        } else {
+            i = (int)__builtin_amdgcn_readfirstlane(ask);
+            __builtin_amdgcn_sched_barrier(0);
+            request(i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- the row leaves as 1 + NSTA + 1 unconditional stores: out-of-range lanes repeat a neighbour's element.
+        //      TAC_S3_ALIGN128: every 16-byte wave-store starts on a 128-BYTE boundary of the output (lane 0 of store u holds chunk
+        //      64 u - S, S = the row's distance in chunks from the previous boundary): a store then covers eight whole cache lines
+        //      instead of seven whole and two partial ones.  Rows are 8200 / 4100 bytes, so without this nearly every store straddles: the
+        //      access pattern alone (tools/ubench/row_store_rate.hip, no arithmetic) moves 4.3 TB/s with rows of 8200 bytes and
+        //      4.8-5.0 TB/s with 128-byte aligned ones on the same box (4.1 vs 4.5-4.8 for the 4100-byte rows).
+#ifndef TAC_S3_ALIGN128
+#define TAC_S3_ALIGN128 0       // measured: the aligned form lowers the arithmetic-free floor of the access pattern (0.148 vs 0.176-0.186 ms,
+#endif                          // stft_stream3 with TAC_S3_ABL_NOFFT) but NOT the kernel (0.1767 vs 0.1743, 0.1946 vs 0.1930 ms): off
+        constexpr int NSTA = NST + (TAC_S3_ALIGN128 ? 1 : 0);
         float* const gdst = ep.out + g0;
         const int npre = (4 - a) & 3;
         const int nchunks = (LENF - npre) >> 2;
@@ -212,20 +252,23 @@ stft_stream3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
             const f4* const s4 = reinterpret_cast<const f4*>(stage + npre);
             f4* const g4 = reinterpret_cast<f4*>(gdst + npre);
             const int last = nchunks - 1;
-            f4 b[NST];
-            int c[NST];
+            const int S = TAC_S3_ALIGN128 ? (int)((8u - ((unsigned)(reinterpret_cast<unsigned long long>(g4) >> 4) & 7u)) & 7u) : 0;
+            f4 b[NSTA];
+            int c[NSTA];
 #pragma unroll
-            for (int u = 0; u < NST; ++u) {
-                c[u] = (t + 64 * u) < last ? (t + 64 * u) : last;
+            for (int u = 0; u < NSTA; ++u) {
+                int j = t + 64 * u - S;
+                j = j > 0 ? j : 0;
+                c[u] = j < last ? j : last;
                 b[u] = s4[c[u]];
             }
             __builtin_amdgcn_sched_barrier(0);            // all LDS reads in flight before the first store issues
             if (lp.plain_stores) {
 #pragma unroll
-                for (int u = 0; u < NST; ++u) g4[c[u]] = b[u];
+                for (int u = 0; u < NSTA; ++u) g4[c[u]] = b[u];
             } else {
 #pragma unroll
-                for (int u = 0; u < NST; ++u) __builtin_nontemporal_store(b[u], &g4[c[u]]);
+                for (int u = 0; u < NSTA; ++u) __builtin_nontemporal_store(b[u], &g4[c[u]]);
             }
         }
         {
