@@ -2,7 +2,7 @@
 # Run ON THE GPU BOX (via gpurun): rocprofv3 kernel trace of the bench command + separate PMC passes for the
 # dominant kernels.  Writes under gpurun_out/$1/; tools/summarize_profiles.py turns it into profiles/$1/.
 set -u
-tag=${1:-r03}
+tag=${1:-r04}
 out=gpurun_out/$tag
 export TMPDIR=/tmp
 mkdir -p $out

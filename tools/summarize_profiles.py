@@ -11,7 +11,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r04'
 src = os.path.join('gpurun_out', tag)
 dst = os.path.join('profiles', tag)
 os.makedirs(dst, exist_ok=True)
