@@ -6,7 +6,7 @@ import json
 import os
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r04'
 d = os.path.join('profiles', tag)
 bench = json.load(open(os.path.join(d, 'bench_N1.json')))
 stats = {}

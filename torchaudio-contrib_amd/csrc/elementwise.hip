@@ -1,6 +1,8 @@
 // elementwise.hip — HBM-bound streaming kernels of the path: complex_norm, amplitude_to_db,
 // db_to_amplitude, mu-law encode / decode (functional.py:116-128, 277-314, 317-354).
 // 16 B per lane per access where alignment allows, grid-stride over 256 CUs x 8 blocks.
+#include <cstdlib>
+
 #include "host_common.hpp"
 #include "exact_math.hpp"
 
@@ -8,8 +10,14 @@ namespace tac {
 
 constexpr int EW_THREADS = 256;
 
+// blocks per CU of the grid-stride kernels; TAC_EW_BLOCKS_PER_CU overrides (A/B: on this chip a pure fill runs 5.6 TB/s from
+// 2 blocks per CU and 4.4-4.6 from 4-16, a pure read needs >= 4 — tools/ubench/hbm_rate.hip)
+static inline int ew_blocks_per_cu() {
+    static const int v = [] { const char* e = getenv("TAC_EW_BLOCKS_PER_CU"); const int n = e ? atoi(e) : 0; return n > 0 ? n : 8; }();
+    return v;
+}
 static inline unsigned ew_blocks(long long work_items) {
-    long long cap = (long long)device_cu_count() * 8;
+    long long cap = (long long)device_cu_count() * ew_blocks_per_cu();
     long long want = (work_items + EW_THREADS - 1) / EW_THREADS;
     if (want < 1) want = 1;
     return (unsigned)(want < cap ? want : cap);
