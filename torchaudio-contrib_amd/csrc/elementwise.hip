@@ -10,14 +10,18 @@ namespace tac {
 
 constexpr int EW_THREADS = 256;
 
-// blocks per CU of the grid-stride kernels; TAC_EW_BLOCKS_PER_CU overrides (A/B: on this chip a pure fill runs 5.6 TB/s from
-// 2 blocks per CU and 4.4-4.6 from 4-16, a pure read needs >= 4 — tools/ubench/hbm_rate.hip)
-static inline int ew_blocks_per_cu() {
-    static const int v = [] { const char* e = getenv("TAC_EW_BLOCKS_PER_CU"); const int n = e ? atoi(e) : 0; return n > 0 ? n : 8; }();
+// Blocks per CU of the grid-stride kernels.  On this chip a pure fill runs 5.6 TB/s from 2 blocks of 256 threads per CU and
+// 4.4-4.6 from 4-16, a pure read needs >= 4 (tools/ubench/hbm_rate.hip) — so every kernel carries the count its read : write
+// mix measured best with at cfg-2 / cfg-5 sizes (profiles/r04/ab/batch11_ew_blocks.txt): complex_norm (2 : 1) 2 blocks =
+// 0.167 vs 0.189 ms with 8; magphase (1 : 1, two outputs) 3 = 0.247 vs 0.267; mu-law encode (1 : 2) 3 = 0.309 vs 0.345; the dB
+// pair and mu-law decode 8.  TAC_EW_BLOCKS_PER_CU overrides all of them (A/B runs).
+constexpr int EW_DEFAULT = 8, EW_COMPLEX_NORM = 2, EW_MAGPHASE = 3, EW_MULAW_ENCODE = 3;
+static inline int ew_blocks_override() {
+    static const int v = [] { const char* e = getenv("TAC_EW_BLOCKS_PER_CU"); const int n = e ? atoi(e) : 0; return n > 0 ? n : 0; }();
     return v;
 }
-static inline unsigned ew_blocks(long long work_items) {
-    long long cap = (long long)device_cu_count() * ew_blocks_per_cu();
+static inline unsigned ew_blocks(long long work_items, int per_cu = EW_DEFAULT) {
+    long long cap = (long long)device_cu_count() * (ew_blocks_override() ? ew_blocks_override() : per_cu);
     long long want = (work_items + EW_THREADS - 1) / EW_THREADS;
     if (want < 1) want = 1;
     return (unsigned)(want < cap ? want : cap);
@@ -283,7 +287,7 @@ int tac_complex_norm_f32(const float* x, int64_t n, float power, float* out, voi
     if (n == 0) return TAC_OK;
     if (!x || !out || n < 0) return TAC_E_INVALID;
     const bool vec = aligned16(x) && aligned16(out);
-    const unsigned blocks = ew_blocks(vec ? (n + 3) / 4 : n);
+    const unsigned blocks = ew_blocks(vec ? (n + 3) / 4 : n, EW_COMPLEX_NORM);
     if (vec) hipLaunchKernelGGL(complex_norm_kernel<true>, dim3(blocks), dim3(EW_THREADS), 0, (hipStream_t)stream, x, (long long)n, power, out);
     else hipLaunchKernelGGL(complex_norm_kernel<false>, dim3(blocks), dim3(EW_THREADS), 0, (hipStream_t)stream, x, (long long)n, power, out);
     TAC_HIP(hipGetLastError());
@@ -295,7 +299,7 @@ int tac_magphase_f32(const float* x, int64_t n, float power, float* mag, float* 
     if (n == 0) return TAC_OK;
     if (!x || !phase || n < 0) return TAC_E_INVALID;
     const bool vec = aligned16(x) && aligned16(phase) && (!mag || aligned16(mag));
-    const unsigned blocks = ew_blocks(vec ? (n + 3) / 4 : n);
+    const unsigned blocks = ew_blocks(vec ? (n + 3) / 4 : n, EW_MAGPHASE);
     const hipStream_t s = (hipStream_t)stream;
     if (mag) {
         if (vec) hipLaunchKernelGGL((magphase_kernel<true, true>), dim3(blocks), dim3(EW_THREADS), 0, s, x, (long long)n, power, mag, phase);
@@ -325,7 +329,7 @@ int tac_mulaw_encode_f32_i64(const float* x, int64_t n, int32_t n_quantize, cons
     const float mu = (float)(n_quantize - 1);
     const float l1p = exact_log1pf(mu);
     const bool vec = aligned16(x) && aligned16(out);
-    const unsigned blocks = ew_blocks(vec ? (n + 3) / 4 : n);
+    const unsigned blocks = ew_blocks(vec ? (n + 3) / 4 : n, EW_MULAW_ENCODE);
     long long* o = reinterpret_cast<long long*>(out);
     if (vec) hipLaunchKernelGGL(mulaw_encode_kernel<true>, dim3(blocks), dim3(EW_THREADS), 0, (hipStream_t)stream, x, (long long)n, mu, l1p, thresholds, n_pos, n_neg, zero_code, o);
     else hipLaunchKernelGGL(mulaw_encode_kernel<false>, dim3(blocks), dim3(EW_THREADS), 0, (hipStream_t)stream, x, (long long)n, mu, l1p, thresholds, n_pos, n_neg, zero_code, o);
