@@ -17,11 +17,23 @@ namespace tac {
 constexpr int S3_WAVES = 12;          // what ships
 constexpr int S3_WAVES_F32 = 15;      // A/B form (TAC_S3_WAVES=15): as many 128-register waves as the LDS holds next to a 128-band bank
 
+#ifndef TAC_S3_SWZ
+#define TAC_S3_SWZ 1          // first exchange XOR-swizzled instead of padded, partner exchange dense (no bank conflicts on either): complex rows
+                              // -1.05 %, power rows -1.3 %, fused kernel -0.2 % (same-process A/B, bit-identical results); 0 = the padded layout
+#endif
+// bytes of one wave's exchange area.  Padded layout: NC + NC / 16 + 1 slots.  Swizzled layout (TAC_S3_SWZ): the transform needs
+// NC dense slots, the gather path of edge frames still writes padded slots (<= 8696 B), and areas are 128-byte multiples so that
+// the swizzle is one XOR on the byte address
+template <class F>
+__host__ __device__ constexpr int s3_xa_bytes() {
+    return TAC_S3_SWZ ? (((F::NC + F::NC / 16 - 1) * (int)sizeof(cf) + 127) & ~127) : (((int)(F::PADDED * sizeof(cf)) + 15) & ~15);
+}
+
 // exchange areas + bank weights + pass-1 twiddles + frame counter + R2C twiddle table + window table [+ mu-law table]
 template <int NC, int E>
 __host__ __device__ inline size_t stream3_lds_bytes(int wtot, int waves, bool coded) {
     using C = StreamCfg<NC, E>;
-    size_t xa = ((size_t)C::F::PADDED * sizeof(cf) + 15) & ~(size_t)15;
+    size_t xa = (size_t)s3_xa_bytes<typename C::F>();
     return (size_t)waves * xa + (((size_t)wtot * 4 + 15) & ~(size_t)15) + ST_TW_BYTES + 16 + 64 * (C::F::NPAIR + E) * sizeof(cf) + (coded ? 1024 : 0);
 }
 
@@ -94,6 +106,58 @@ __device__ __forceinline__ void lds_wait_all(cf (&a)[8], cf& b) {
                  :: "memory");
 }
 
+// ---- TAC_S3_SWZ: the first exchange without padding.  Lane tt's first-pass output k (element 16 tt + k) lives in slot
+// 16 tt + (k ^ (tt & 15)): for a fixed k the sixteen lanes of a ds_write_b64 group hit sixteen different slots mod 16 (all 32
+// banks once); lane t of pass 1 reads element t + 64 q from block B = (t >> 4) + 4 q, slot 16 B + ((t & 15) ^ (B & 15)), and
+// B & 15 = (t >> 4) + 4 (q & 3): the 32 lanes of a ds_read_b64 group cover two whole 16-slot blocks 16 slots apart (all 64 banks
+// once), and a lane needs just FOUR base addresses (by q & 3) + immediate offsets 512 q.  The padded layout costs one conflict
+// cycle per single-b64 read-back (lanes 0 and 31 of a group share a bank) and ~2-way conflicts on the 16-byte first-pass writes.
+struct S3Swz {
+    unsigned w0;          // byte address of this lane's first-pass slot for k = 0; slot k is w0 ^ (8 k) (areas are 128-byte aligned)
+    unsigned r[4];        // byte address of this lane's pass-1 operand q = j (j = q & 3), minus 512 q
+    __device__ __forceinline__ void init(const cf* xa, int t) {
+        const unsigned base = lds_offset_of(xa);
+        w0 = base + 128u * (unsigned)t + 8u * (unsigned)(t & 15);
+        const unsigned a = (unsigned)t >> 4, k0 = (unsigned)t & 15u;
+#pragma unroll
+        for (unsigned j = 0; j < 4; ++j) r[j] = base + 8u * (16u * a + (k0 ^ (a + 4u * j)));
+    }
+};
+__device__ __forceinline__ void s3_write_pass0_swz(const cf (&v)[16], const S3Swz& z) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const unsigned addr = z.w0 ^ (8u * (unsigned)k);
+        asm volatile("ds_write_b64 %0, %1" :: "v"(addr), "v"(v[k]) : "memory");
+    }
+}
+__device__ __forceinline__ void s3_readback_pass1_swz(cf (&v)[16], const S3Swz& z) {
+    auto rd = [&](auto qc) { constexpr int q = decltype(qc)::value; v[q] = lds_read_b64_single<512 * q>(z.r[q & 3]); };
+    rd(std::integral_constant<int, 0>{}); rd(std::integral_constant<int, 1>{}); rd(std::integral_constant<int, 2>{}); rd(std::integral_constant<int, 3>{});
+    rd(std::integral_constant<int, 4>{}); rd(std::integral_constant<int, 5>{}); rd(std::integral_constant<int, 6>{}); rd(std::integral_constant<int, 7>{});
+    rd(std::integral_constant<int, 8>{}); rd(std::integral_constant<int, 9>{}); rd(std::integral_constant<int, 10>{}); rd(std::integral_constant<int, 11>{});
+    rd(std::integral_constant<int, 12>{}); rd(std::integral_constant<int, 13>{}); rd(std::integral_constant<int, 14>{}); rd(std::integral_constant<int, 15>{});
+    lds_wait_all(v);
+}
+// ... and the partner exchange dense: the upper half of the spectrum at xa[o] (lanes write and read consecutive slots)
+template <class F>
+__device__ __forceinline__ void s3_r2c_partners_dense(const cf (&v)[16], cf* xa, cf (&zm)[8], cf& zmid, int t) {
+    constexpr int NC = F::NC;
+    static_assert(NC == 1024 && F::E == 16 && radix_at(NC, 2) == 4, "16 . 16 . 4 plan");
+    wave_lds_fence();
+#pragma unroll
+    for (int b = 0; b < 4; ++b)                                               // butterfly b of the last pass: outputs k = 2, 3 (upper half)
+#pragma unroll
+        for (int k = 2; k < 4; ++k) xa[t + 64 * b + 256 * k] = v[b * 4 + k];
+    wave_lds_fence();
+    const unsigned pa = lds_offset_of(xa + (NC - t - 7 * 64));                // partner of pair 7; pair p sits (7 - p) * 64 slots above
+    auto rd = [&](auto pc) { constexpr int p = decltype(pc)::value; zm[p] = lds_read_b64_single<(7 - p) * 64 * 8>(pa); };
+    rd(std::integral_constant<int, 0>{}); rd(std::integral_constant<int, 1>{}); rd(std::integral_constant<int, 2>{}); rd(std::integral_constant<int, 3>{});
+    rd(std::integral_constant<int, 4>{}); rd(std::integral_constant<int, 5>{}); rd(std::integral_constant<int, 6>{}); rd(std::integral_constant<int, 7>{});
+    zmid = lds_read_b64_single<0>(lds_offset_of(xa + NC / 2));
+    lds_wait_all(zm, zmid);
+    if (t == 0) zm[0] = v[F::reg_of_spectrum(0)];                            // (slot NC is not stored: bin 0 pairs with itself)
+}
+
 // ---- the two exchange read-backs of the one-frame-per-wave front end, shared by melspec_stream3_kernel and stft_stream3_kernel
 // (1) operands of pass 1 back from the exchange area
 template <class F>
@@ -138,6 +202,8 @@ template <class F>
 __device__ __forceinline__ void s3_r2c_partners(const cf (&v)[16], cf* xa, cf (&zm)[8], cf& zmid, int t) {
 #if TAC_S3_BPERM
     F::r2c_partners_bpermute(v, zm, zmid, t);
+#elif TAC_S3_SWZ
+    s3_r2c_partners_dense<F>(v, xa, zm, zmid, t);
 #else
     wave_lds_fence();
     F::template pass_write<2, true>(v, xa, t, t);
@@ -241,8 +307,8 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     using C = StreamCfg<NC, E>;
     using F = typename C::F;
     constexpr int NBINS = C::NBINS;
-    constexpr int XA_BYTES = (F::PADDED * sizeof(cf) + 15) & ~15;
-    static_assert((int)(F::PADDED * sizeof(cf)) >= (int)(C::PROW * 4), "the power row fits the exchange area");
+    constexpr int XA_BYTES = s3_xa_bytes<F>();
+    static_assert(XA_BYTES >= (int)(C::PROW * 4), "the power row fits the exchange area");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 #ifndef TAC_S3_CYCLES
 #define TAC_S3_CYCLES 0
@@ -445,6 +511,10 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         for (int u = 0; u < ST_FAST_STEPS0; ++u) w0_regs[u] = (reinterpret_cast<const f4*>(wlds) + lane)[u * 64];
     }
 #endif
+#if TAC_S3_SWZ
+    S3Swz swz;
+    swz.init(xa, t);
+#endif
     int i = w;
 #if !TAC_S3_EARLY_FIRST
     request(i);
@@ -506,9 +576,15 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
                 tw1[2 * u + 1] = mkc(x.z, x.w);
             }
         }
+#if TAC_S3_SWZ
+        s3_write_pass0_swz(v, swz);
+        wave_lds_fence();
+        s3_readback_pass1_swz(v, swz);
+#else
         F::template pass_write<0, true>(v, xa, t, t);
         wave_lds_fence();
         s3_readback_pass1<F>(v, xa, t);
+#endif
         S3_STAMP(1);                                          // exchange: write burst, read-back
         // ---- s12
         F::template pass_twiddle<1, true>(v, tw1);

@@ -13,7 +13,7 @@ namespace tac {
 template <int NC, int E, int WAVES>
 __host__ __device__ inline size_t stft_stream3_lds_bytes() {
     using F = WaveFft<NC, E>;
-    size_t xa = ((size_t)F::PADDED * sizeof(cf) + 15) & ~(size_t)15;
+    size_t xa = (size_t)s3_xa_bytes<F>();
     return (size_t)WAVES * xa + ST_TW_BYTES + 64 + 64 * (F::NPAIR + E) * sizeof(cf);
 }
 
@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
 stft_stream3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
     using F = WaveFft<NC, E>;
     static_assert(F::G == 1 && E == 16 && radix_at(NC, 0) == 16, "fft_length 2048");
-    constexpr int XA_BYTES = (F::PADDED * sizeof(cf) + 15) & ~15;
+    constexpr int XA_BYTES = s3_xa_bytes<F>();
     constexpr int LENF = (MODE == 0 ? 2 : 1) * (NC + 1);
     constexpr int NST = ((LENF >> 2) + 63) / 64;          // 16-byte wave-stores per output row
     static_assert(XA_BYTES >= (LENF + 3) * 4, "the staged row (any 16-byte phase) fits the exchange area");
@@ -102,6 +102,10 @@ stft_stream3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
     __syncthreads();
     if (nloc <= 0) return;
 
+#if TAC_S3_SWZ
+    S3Swz swz;
+    swz.init(xa, t);
+#endif
     int i = w;
     while (i < nloc) {
         unsigned ask = 0;
@@ -166,9 +170,15 @@ stft_stream3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
                 tw1[2 * u + 1] = mkc(x.z, x.w);
             }
         }
+#if TAC_S3_SWZ
+        s3_write_pass0_swz(v, swz);
+        wave_lds_fence();
+        s3_readback_pass1_swz(v, swz);
+#else
         F::template pass_write<0, true>(v, xa, t, t);
         wave_lds_fence();
         s3_readback_pass1<F>(v, xa, t);
+#endif
         // ---- s12
         F::template pass_twiddle<1, true>(v, tw1);
         F::template pass_butterflies<1>(v);
