@@ -55,10 +55,12 @@ def invalidate(tensor=None):
     tensor: they are rebuilt from the current contents on the next call.  Needed only after a write PyTorch's version
     counter does not see (``t.data.mul_(2)``, raw-pointer writes); ordinary in-place ops are detected by themselves."""
     global _epoch
+    from . import _lazy
     if tensor is None:
         with _lock:
             _epoch += 1
             _geometry_routes_clear()
+            _lazy._plans.clear()
         return
     for name in _CACHE_ATTRS:
         if hasattr(tensor, name):
@@ -72,6 +74,8 @@ def invalidate(tensor=None):
         for g in _geometry_cache.values():
             for key in [k for k in g.routes if k[0] == id(tensor)]:
                 del g.routes[key]
+        for key in [k for k in _lazy._plans if id(tensor) in k[:2]]:         # bound-argument launchers built from it
+            del _lazy._plans[key]
 
 
 def _geometry_routes_clear():
@@ -339,6 +343,55 @@ def _fused_mel_route(g, fb, power):
     _, host = _filterbank_plan(fb)
     rc = _native.lib().tac_melspec_supported(g.desc, float(power), ctypes.cast(host, ctypes.c_void_p), fb.shape[1])
     return 'mfma' if rc == _native.TAC_OK else None
+
+
+class MelPlan(object):
+    """Bound-argument launcher of the fused band-sparse kernel for ONE (waveform layout, window, filterbank, parameters):
+    what ``melspectrogram`` below works out on every call — geometry, route, packed bank, ctypes conversions — done once.
+    ``launch(wave)`` then costs an allocation and one foreign call.  Valid while the window and the filterbank keep their
+    stamps (checked by the caller, ``_lazy.DeferredSpectral.realize``) and the device is current."""
+    __slots__ = ('fn', 'win_ptr', 'desc', 'power', 'wpack', 'dsc', 'info', 'wpack_ptr', 'dsc_ptr', 'info_ptr', 'n_mels',
+                 'db', 'ref', 'amin', 'shape', 'device', 'dev_index', 'window', 'fb', 'win_stamp', 'fb_stamp', 'layout')
+
+    def launch(self, wave):
+        out = torch.empty(self.shape, dtype=torch.float32, device=self.device)
+        rc = self.fn(wave.data_ptr(), self.win_ptr, self.desc, self.power, self.wpack_ptr, self.dsc_ptr, self.info_ptr,
+                     self.n_mels, self.db, self.ref, self.amin, out.data_ptr(),
+                     torch._C._cuda_getCurrentRawStream(self.dev_index))
+        if rc != _native.TAC_OK:
+            return None                     # (the general path reports it)
+        launches['tac_melspec_sparse_f32'] = launches.get('tac_melspec_sparse_f32', 0) + 1
+        return out.transpose(-2, -1)
+
+    def matches(self, wave):
+        """same layout, same device current, tables still those of the tensors' current contents"""
+        return (wave.shape, wave.stride(), wave.dtype) == self.layout and torch._C._cuda_getDevice() == self.dev_index \
+            and _stamp(self.window) == self.win_stamp and _stamp(self.fb) == self.fb_stamp
+
+
+def mel_plan(wave, window, fb, n_fft, hop, win_length, center, pad_mode, normalized, onesided, power, db, ref, amin):
+    """A ``MelPlan`` when this call is one launch of the fused band-sparse kernel on plain float32 tensors whose rows need no
+    copy, else None (the general ``melspectrogram`` handles everything)."""
+    if not (type(wave) is torch.Tensor and wave.dtype == torch.float32 and window.dtype == torch.float32
+            and window.is_contiguous() and fb.dtype == torch.float32 and fb.dim() == 2 and wave.is_cuda
+            and window.device == wave.device and fb.device == wave.device and not window.is_inference()
+            and not fb.is_inference()):
+        return None
+    g = geometry(wave, n_fft, hop, win_length, center, pad_mode, normalized, onesided)
+    if g.flatten or g.desc is None or fb.shape[0] != g.n_bins or _fused_mel_route(g, fb, power) != 'sparse':
+        return None
+    wpack, dsc, info = _melbank_pack(fb, g.n_fft)
+    p = MelPlan()
+    p.fn = _native.lib().tac_melspec_sparse_f32
+    p.window, p.fb, p.win_stamp, p.fb_stamp = window, fb, _stamp(window), _stamp(fb)
+    p.win_ptr, p.desc, p.power = window.data_ptr(), g.desc, float(power)
+    p.wpack, p.dsc, p.info = wpack, dsc, info                          # (kept alive with the plan)
+    p.wpack_ptr, p.dsc_ptr, p.info_ptr = wpack.data_ptr(), dsc.data_ptr(), ctypes.cast(info, ctypes.c_void_p)
+    p.n_mels, p.db, p.ref, p.amin = int(fb.shape[1]), 1 if db else 0, float(ref), float(amin)
+    p.shape = g.lead + (g.n_frames, int(fb.shape[1]))
+    p.device, p.dev_index = wave.device, wave.device.index
+    p.layout = (wave.shape, wave.stride(), wave.dtype)
+    return p
 
 
 def melspectrogram(wave, window, fb, n_fft, hop, win_length, center, pad_mode, normalized, onesided, power, db, ref,

@@ -27,6 +27,7 @@ import torch
 from torch.utils._pytree import tree_map
 
 _enabled = True
+_plans = {}             # (window id, filterbank id, stft args, power, dB) -> _hip.MelPlan of the fused chain
 
 
 def set_lazy_fusion(flag):
@@ -107,9 +108,10 @@ class DeferredWave(torch.Tensor):
 
 class _Source(object):
     """The STFT call a recipe starts from, plus what is needed to detect that its inputs changed meanwhile."""
-    __slots__ = ('wave', 'window', 'args', 'stream', 'stamps', 'lead', 'n_frames', 'n_bins', 'decode', 'grad')
+    __slots__ = ('wave', 'window', 'args', 'stream', 'stamps', 'lead', 'n_frames', 'n_bins', 'decode', 'grad', 'spec_layout')
 
     def __init__(self, wave, window, args):
+        self.spec_layout = None                 # (shape, strides) of the |X|^p stage when STFT.forward supplied a template
         self.decode = None                      # n_quantize when `wave` holds mu-law codes (from a DeferredWave)
         # gradient flows through this recipe: it must be materialised above autograd (see the module docstring)
         self.grad = bool(torch.is_grad_enabled() and isinstance(wave, torch.Tensor) and wave.requires_grad)
@@ -160,11 +162,31 @@ class DeferredSpectral(torch.Tensor):
         shape = src.lead + (src.n_bins, src.n_frames, 2)
         return cls(src, 'stft', shape, _transposed_strides(src.lead, (src.n_frames, src.n_bins, 2), -3, -2))
 
+    @staticmethod
+    def template(wave_shape, n_fft, hop, win_length, center, pad_mode, normalized, onesided):
+        """What ``from_stft`` derives from the input's SHAPE and the STFT arguments (``STFT.forward`` remembers it per shape)."""
+        lead = tuple(wave_shape[:-1])
+        n_frames = 1 + (wave_shape[-1] + (2 * (n_fft // 2) if center else 0) - n_fft) // hop
+        n_bins = n_fft // 2 + 1 if onesided else n_fft
+        return ((n_fft, hop, win_length, center, pad_mode, normalized, onesided), lead, n_frames, n_bins,
+                lead + (n_bins, n_frames, 2), _transposed_strides(lead, (n_frames, n_bins, 2), -3, -2),
+                lead + (n_bins, n_frames), _transposed_strides(lead, (n_frames, n_bins), -2, -1))
+
+    @classmethod
+    def from_template(cls, wave, window, tmpl):
+        src = _Source(wave, window, tmpl[0])
+        src.lead, src.n_frames, src.n_bins = tmpl[1], tmpl[2], tmpl[3]
+        src.spec_layout = (tmpl[6], tmpl[7])
+        return cls(src, 'stft', tmpl[4], tmpl[5])
+
     def pending(self):
         return self._value is None
 
     def with_norm(self, power):
         s = self._src
+        lay = s.spec_layout
+        if lay is not None:
+            return DeferredSpectral(s, 'spec', lay[0], lay[1], power=power)
         return DeferredSpectral(s, 'spec', s.lead + (s.n_bins, s.n_frames),
                                 _transposed_strides(s.lead, (s.n_frames, s.n_bins), -2, -1), power=power)
 
@@ -201,6 +223,33 @@ class DeferredSpectral(torch.Tensor):
         return call('melspectrogram', wave, s.window, self._fb, *s.args, float(self._power), db is not None,
                     float(ref), float(amin))
 
+    def _launch_planned(self, db):
+        """The fused mel chain through a cached bound-argument launcher (``_hip.MelPlan``: geometry, route, packed bank and
+        argument conversions done once per window / filterbank / layout); anything the plan does not cover, and the first
+        call, take ``_launch``."""
+        s = self._src
+        fb = self._fb
+        key = (id(s.window), id(fb), s.args, self._power, db)
+        plan = _plans.get(key)
+        if plan is not None and plan.window is s.window and plan.fb is fb and plan.matches(s.wave):
+            v = plan.launch(s.wave)
+            if v is not None:
+                return v
+        v = self._launch(db)
+        try:                                    # (a missing library / unsupported geometry was reported by _launch already)
+            from . import _hip
+            ref, amin = db if db is not None else (1.0, 1e-7)
+            plan = _hip.mel_plan(s.wave, s.window, fb, *s.args, float(self._power), db is not None, float(ref), float(amin))
+        except Exception:                       # noqa: BLE001 — the plan is an optimisation only
+            plan = None
+        if len(_plans) > 64:
+            _plans.clear()
+        if plan is not None:
+            _plans[key] = plan
+        else:
+            _plans.pop(key, None)
+        return v
+
     def realize(self, db=None):
         """Launch the recorded chain (with an ``amplitude_to_db(ref, amin)`` epilogue when ``db`` is given) and return
         an ordinary tensor; a chain without dB epilogue remembers its value."""
@@ -213,7 +262,8 @@ class DeferredSpectral(torch.Tensor):
         s.check_unchanged()
         device = s.wave.device
         if torch._C._cuda_getCurrentRawStream(device.index) == s.stream:
-            v = self._launch(db)
+            v = self._launch_planned(db) if (self._stage == 'mel' and not self._tracks_grad and s.decode is None) \
+                else self._launch(db)
         else:                                   # enqueue where forward() was called, then order the consumer behind it
             now = torch.cuda.current_stream(device)
             then = torch.cuda.ExternalStream(s.stream, device=device) if s.stream else torch.cuda.default_stream(device)

@@ -62,12 +62,30 @@ class STFT(_ModuleNoStateBuffers):
 
     def forward(self, waveforms):
         if torch.is_tensor(waveforms) and can_defer(waveforms, self.window):
-            # validate now, so errors surface here; the launch itself waits for the rest of the chain (_lazy.py)
-            n_fft, hop, win_length, window = F.resolve_stft_args(waveforms, self.fft_length, self.hop_length,
-                                                                 self.win_length, self.window)
-            _hip.check_stft_args(waveforms.shape, n_fft, hop, win_length, self.center, self.pad_mode)
-            return DeferredSpectral.from_stft(waveforms, window, n_fft, hop, win_length, bool(self.center),
-                                              self.pad_mode, bool(self.normalized), bool(self.onesided))
+            # validate now, so errors surface here; the launch itself waits for the rest of the chain (_lazy.py).  The
+            # resolved arguments and the recipe's shapes depend on the input's shape only: remembered per shape, so that a
+            # repeated call neither re-validates nor re-derives them (the attributes are read on every call: changing one
+            # is seen)
+            key = (waveforms.shape, self.fft_length, self.hop_length, self.win_length, self.center, self.pad_mode,
+                   self.normalized, self.onesided, id(self.window))
+            hit = self.__dict__.get('_recipes')
+            if hit is None:
+                hit = self.__dict__['_recipes'] = {}
+            tmpl = hit.get(key)
+            if tmpl is None or tmpl[0] is not self.window:
+                n_fft, hop, win_length, window = F.resolve_stft_args(waveforms, self.fft_length, self.hop_length,
+                                                                     self.win_length, self.window)
+                _hip.check_stft_args(waveforms.shape, n_fft, hop, win_length, self.center, self.pad_mode)
+                if window is self.window:
+                    if len(hit) > 32:
+                        hit.clear()
+                    tmpl = hit[key] = (window, DeferredSpectral.template(
+                        waveforms.shape, n_fft, hop, win_length, bool(self.center), self.pad_mode, bool(self.normalized),
+                        bool(self.onesided)))
+                else:       # (a window resolve_stft_args had to build or move: not remembered)
+                    return DeferredSpectral.from_stft(waveforms, window, n_fft, hop, win_length, bool(self.center),
+                                                      self.pad_mode, bool(self.normalized), bool(self.onesided))
+            return DeferredSpectral.from_template(waveforms, tmpl[0], tmpl[1])
         return F.stft(waveforms, self.fft_length, self.hop_length, self.win_length, self.window, self.center,
                       self.pad_mode, self.normalized, self.onesided)
 
