@@ -67,7 +67,7 @@ if sb:
     st = bench.get('stages', {})
     if 'stft_complex' in st and 'single_buffer_kernel_ms_mean' in st['stft_complex']:
         out.append('Stage kernels, rotating batches vs one re-read batch: complex STFT %.4f vs %.4f ms, power spectrogram %.4f vs '
-                   '%.4f ms — the complex STFT\'s 67 %% of round 2 was an Infinity-Cache-assisted figure; from HBM it is %.0f %%.'
+                   '%.4f ms (complex STFT from HBM: %.0f %% of 8 TB/s).'
                    % (st['stft_complex']['kernel_ms_mean'], st['stft_complex']['single_buffer_kernel_ms_mean'],
                       st['spectrogram_power']['kernel_ms_mean'], st['spectrogram_power']['single_buffer_kernel_ms_mean'],
                       100 * st['stft_complex']['frac_of_hbm_peak']))
@@ -125,8 +125,8 @@ out.append('The fused kernel and the complex STFT run 3 waves/SIMD, the power sp
            'waves draw frames from a workgroup counter), no scratch.  HBM traffic equals the algorithmic bytes to within 0.5 %: '
            'nothing is re-read; the fused kernel is bound by its VALU + LDS instruction streams — with three waves per SIMD the '
            'SIMD issues VALU work 3 x the per-wave VALU share above of its cycles and the LDS is busy as tabulated — not by memory.  '
-           '`ab_stream3.txt` holds the A/B runs of the wave counts (2 / 3 / 4 per SIMD) for every kernel re-cut this round; '
-           'DESIGN.md §3.3 the reasoning.')
+           '`ab/` holds the raw same-process A/B outputs of the round (tables: tools/ablation/README.md), `ubench/` the '
+           'micro-benchmark outputs; DESIGN.md §3.2 / §3.3 the reasoning.')
 for fname, what in (('kernel_stats_backward.csv',
                      '`tools/prof_driver.py grad 120`: forward + backward of the reference idiom `Sequential(*Melspectrogram(...), '
                      'AmplitudeToDb())` at cfg-2 with `requires_grad` on the waveform: the chain is deferred as usual (one fused '
@@ -189,9 +189,10 @@ out.append('`steady_state/time_steady.txt`, `steady_state/time_others.txt` — `
            'box (0.5 s spin-up per kernel, then 100 / 60 back-to-back launches with per-launch HIP events; medians): every other '
            'kernel of the library, incl. the fft_length-4096 Melspectrogram chain and `hpss`.')
 out.append('')
-out.append('Micro-benchmarks behind the design decisions (sources in `tools/ubench/`, outputs quoted in DESIGN.md): '
-           '`valu_rate` (scalar vs packed f32 issue rates), `lds_rate` (LDS access shapes at 8 waves/CU), `hbm_rate` '
-           '(write / read / 1:4 mix ceilings of this box: 4.5-5.6 / 6.4 / 5.1-5.7 TB/s).')
+out.append('Micro-benchmarks behind the design decisions (sources in `tools/ubench/`, outputs under `ubench/` of the round that ran '
+           'them): `valu_rate` (scalar vs packed f32 issue rates), `lds_rate` (LDS access shapes at 8 waves/CU), `hbm_rate` (write / '
+           'read / 1:4 mix ceilings: 4.4-5.6 / 6.5 / 5.1-5.6 TB/s), `row_store_rate` (the STFT rows\' access pattern without '
+           'arithmetic: 8200-byte rows 4.3 TB/s, 128-byte aligned 8192-byte rows 4.8-5.0 TB/s).')
 out.append('')
 out.append('`../r02/`, `../r01/` hold the same measurements for rounds 2 and 1 (two-waves-per-SIMD streaming kernel 0.127 ms on one re-read batch; three-phase fused kernel, 0.174 ms) and `../r01_baseline_v0/` for the first correct version (0.61 ms).')
 open(os.path.join(d, 'README.md'), 'w').write('\n'.join(out) + '\n')
