@@ -401,13 +401,12 @@ def run(a):
                 for _ in range(3):
                     spin(fn, 0.3)
                     rounds.append(event_ms(fn, 50))
-                rounds.sort()
-                ms, med = rounds[1]
+                ms, med = sorted(rounds)[1]
                 ms1, _ = event_ms(lambda: make(x), 50)
                 gbs = BATCH * CHANNELS * frames * per_frame / (ms * 1e-3) / 1e9
                 stages[name] = {'kernel_ms_mean': ms, 'kernel_ms_median': med, 'alg_bytes_per_frame': per_frame,
                                 'achieved_GBs': gbs, 'frac_of_hbm_peak': gbs / HBM_PEAK_GBS,
-                                'kernel_ms_mean_rounds': [r[0] for r in rounds],
+                                'kernel_ms_mean_rounds': [r[0] for r in rounds],        # (in the order they ran)
                                 'single_buffer_kernel_ms_mean': ms1}
             # the filterbank stage as a dense fp32 MFMA GEMM (a random 1025 x 128 bank is not band-sparse, so
             # apply_filterbank takes the GEMM kernel): executed flops = 2*F*M per frame against the 157.3 TFLOP/s f32 MFMA peak
