@@ -448,6 +448,90 @@ def test_median_run_matches_nth_element(tmp_path):
     assert out.returncode == 0 and out.stdout.strip() == 'bad=0', out.stdout
 
 
+def _emulate_pieces(plan, row):
+    """What melspec_stream3_kernel's piece contraction computes for one |X|^p row (float64): per lane and segment the dot
+    product of L four-tap steps, the shifted adds over a band's pieces, the staging write of the band's last piece."""
+    steps, first, band, index, w = plan
+    out = {}
+    base = 0
+    padded = np.concatenate([row, np.zeros(16)])
+    for s in range(3):
+        part = np.zeros(64)
+        for l in range(64):
+            f = first[s * 64 + l]
+            for j in range(steps[s]):
+                part[l] += float(np.dot(w[base + j, l].astype(np.float64), padded[f + 4 * j:f + 4 * j + 4]))
+        for l in range(64):
+            e = s * 64 + l
+            i, last = index[e] & 255, index[e] >= 256
+            if band[e] < 0:
+                assert part[l] == 0.0 and index[e] == 0                 # an unused lane-segment carries zero weights
+                continue
+            assert 0 <= i <= 2 and l % 16 >= i                          # the shifted reads stay inside the lane's 16-lane row
+            tot = part[l]
+            for d in range(1, i + 1):
+                assert band[e - d] == band[e] and (index[e - d] & 255) == i - d
+                tot += part[l - d]
+            if last:
+                assert band[e] not in out
+                out[band[e]] = tot
+        base += steps[s]
+    return out
+
+
+@pytest.mark.parametrize('n_mels,sr,htk', [(128, 16000, False), (128, 44100, False), (96, 22050, True), (128, 16000, True),
+                                            (96, 22050, False), (160, 16000, False)])
+def test_piece_layout_of_the_filterbank_matches_the_dense_product(tac, n_mels, sr, htk):
+    """tac_melbank_plan_pieces_host (csrc/mel_pieces.hpp): every band is stored exactly once, its pieces sit in adjacent
+    lanes of one 16-lane row, every read stays inside the row buffer, and the contraction emulated on the plan equals
+    row @ bank (reference functional.py:183-184) for random rows — for the standard banks the benchmark and the tests use."""
+    h = tac._native.lib()
+    fb = tac.create_mel_filter(1025, n_mels, 0.0, sr / 2.0, htk).numpy().astype(np.float32)
+    fb = np.ascontiguousarray(fb)
+    steps = (ctypes.c_int32 * 3)()
+    first, band, index = (np.zeros(192, dtype=np.int32) for _ in range(3))
+    w = np.zeros(256 * 24, dtype=np.float32)
+    rc = h.tac_melbank_plan_pieces_host(fb.ctypes.data, 1025, n_mels, ctypes.cast(steps, ctypes.c_void_p), first.ctypes.data,
+                                        band.ctypes.data, index.ctypes.data, w.ctypes.data, w.size)
+    assert rc == tac._native.TAC_OK, rc
+    steps = list(steps)
+    total = sum(steps)
+    assert total < 18 and all(1 <= x <= 7 for x in steps)
+    assert sorted(set(b for b in band if b >= 0)) == list(range(n_mels))
+    assert max(np.bincount(band[band >= 0])) <= 3                          # at most three pieces per band
+    assert (first % 4 == 0).all() and (first >= 0).all()
+    for s in range(3):
+        assert (first[s * 64:(s + 1) * 64] + 4 * steps[s] <= 1032).all()      # inside the 1025 + 7 floats of a row buffer
+    plan = (steps, first, band, index, w[:256 * total].reshape(total, 64, 4))
+    rng = np.random.default_rng(5)
+    for _ in range(3):
+        row = rng.random(1025)
+        got = _emulate_pieces(plan, row)
+        want = row @ fb.astype(np.float64)
+        err = max(abs(got[m] - want[m]) for m in range(n_mels))
+        assert err < 1e-9 * max(1.0, np.abs(want).max()), err
+    # starts of a 16-byte read group fall into different bank groups wherever the slack allows
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    worst = 0
+    for s in range(3):
+        for gi in range(4):
+            lanes = [l + 32 * (gi >> 1) for l in groups[gi & 1]]
+            res = [(first[s * 64 + l] // 4) % 16 for l in lanes]
+            worst = max(worst, max(res.count(r) for r in set(res)))
+    assert worst <= 6, worst
+
+
+def test_piece_layout_refuses_what_it_cannot_hold(tac):
+    h = tac._native.lib()
+    fb = np.ascontiguousarray(tac.create_mel_filter(1025, 40, 0.0, 8000.0, False).numpy().astype(np.float32))   # bands of 29 quads
+    steps = (ctypes.c_int32 * 3)()
+    first, band, index = (np.zeros(192, dtype=np.int32) for _ in range(3))
+    w = np.zeros(256 * 24, dtype=np.float32)
+    rc = h.tac_melbank_plan_pieces_host(fb.ctypes.data, 1025, 40, ctypes.cast(steps, ctypes.c_void_p), first.ctypes.data,
+                                        band.ctypes.data, index.ctypes.data, w.ctypes.data, w.size)
+    assert rc == tac._native.TAC_E_UNSUPPORTED
+
+
 def test_float64_size_coverage_matches_the_kernel_plan(tac):
     """``_hip64.covers``: even lengths <= 8192 with a 5-smooth half take the LDS Stockham transform of csrc/chain_f64.hip; other
     lengths go to its O(N^2) direct transform only up to ``DIRECT_MAX`` (longer ones stay on the announced stock-torch route,

@@ -42,7 +42,8 @@ packs = {}
 if op == 'mel':
     for name, h in libs:
         wpack = torch.empty(24576, device=dev); dsc = torch.empty(4096, dtype=torch.int32, device=dev); info = (I32 * 8)()
-        rc = h.tac_melbank_pack(P(fb.data_ptr()), 1025, n_mels, n_fft, P(wpack.data_ptr()), 24576, P(dsc.data_ptr()), 4096, ctypes.cast(info, P), stream)
+        # a build named "...+p" is timed on the PIECE layout of the bank (tac_melbank_pack with n_fft = -2048), others on the classic one
+        rc = h.tac_melbank_pack(P(fb.data_ptr()), 1025, n_mels, -2048 if name.endswith('+p') else n_fft, P(wpack.data_ptr()), 24576, P(dsc.data_ptr()), 4096, ctypes.cast(info, P), stream)
         assert rc == 0, (name, rc)
         packs[name] = (wpack, dsc, info)
 

@@ -23,6 +23,7 @@ TAC_E_LAUNCH = -4
 
 PAD_MODES = {'constant': 0, 'reflect': 1, 'replicate': 2, 'circular': 3}
 SAMPLES_F32, SAMPLES_I16, SAMPLES_MULAW_U8, SAMPLES_MULAW_I64 = 0, 1, 2, 3
+PACK_PIECES_2048, PIECES_MARK = -2048, -77          # tac_melbank_pack's piece layout (include/tac_amd.h)
 
 EXPORTS = (
     'tac_strerror', 'tac_last_hip_error', 'tac_abi_version', 'tac_num_frames', 'tac_num_bins',
@@ -35,7 +36,7 @@ EXPORTS = (
     'tac_fold_twosided_f32', 'tac_window_grad_partials', 'tac_window_grad_f32', 'tac_sum_slabs_f32',
     'tac_stft_f64', 'tac_spectrogram_f64', 'tac_apply_filterbank_f64', 'tac_magphase_f64', 'tac_amplitude_to_db_f64',
     'tac_db_to_amplitude_f64',
-    'tac_last_route', 'tac_debug_clock_probe',
+    'tac_last_route', 'tac_debug_clock_probe', 'tac_melbank_plan_pieces_host',
 )
 ABI_VERSION = 3          # tac_abi_version() of the library this binding was written against (csrc/host_common.hip)
 
@@ -150,6 +151,8 @@ def lib():
         h.tac_window_grad_f32.argtypes = [_P, _P, _DESC, _P, _I64, _P]
         h.tac_sum_slabs_f32.argtypes = [_P, _I64, _I64, _P, _P]
         h.tac_hpss_f32.argtypes = [_P, _I64, _I32, _I32, _I64, _I64, _I64, _I32, _I32, _F, ctypes.c_int, _P, _P, _P, _P, _P]
+        h.tac_melbank_plan_pieces_host.argtypes = [_P, _I32, _I32, _P, _P, _P, _P, _P, _I32]
+        h.tac_melbank_plan_pieces_host.restype = ctypes.c_int
         h.tac_last_route.restype = ctypes.c_char_p
         h.tac_last_route.argtypes = []
         h.tac_debug_clock_probe.restype = ctypes.c_int

@@ -29,6 +29,7 @@
 #include "sparse_phase.hpp"
 #include "melspec_stream.hpp"
 #include "melspec_stream3.hpp"
+#include "mel_pieces.hpp"
 
 namespace tac {
 
@@ -401,10 +402,24 @@ static int launch_stream(FrameGeom g, const Tables& tb, const SparseArgs& sm, co
     const int waves3 = (!coded && waves_f32 == S3_WAVES_F32 && stream3_lds_bytes<NC, E>(sm.wtot, S3_WAVES_F32, false) <= 160 * 1024)
                            ? S3_WAVES_F32 : S3_WAVES;
     const size_t lds3 = stream3_lds_bytes<NC, E>(sm.wtot, waves3, coded);
+    const bool pieces = info_host[7] == S3_PIECES_MARK;                    // piece layout of the bank (mel_pieces.hpp)
+    if (pieces && (coded || two_waves || waves3 != S3_WAVES || info_host[1] != 3 || sm.n_mels > 128 || lds3 > 160 * 1024)) return TAC_E_UNSUPPORTED;
     if (!two_waves && lds3 <= 160 * 1024) {
         void (*k3)(FrameGeom, Tables, StreamArgs);
+        int fast1_name = 0;
         if constexpr (FMT == FMT_F32) {
-            if (waves3 == S3_WAVES_F32) {
+            if (pieces) {
+                constexpr int W = S3_WAVES;
+                const int code = 1000 + 100 * info_host[4] + 10 * info_host[5] + info_host[6];
+                switch (code) {
+#define TAC_PIECES_CASE(C)                                                                                                  \
+    case C: k3 = pow2 ? melspec_stream3_kernel<NC, E, true, FMT, C, W> : melspec_stream3_kernel<NC, E, false, FMT, C, W>; break;
+                    TAC_PIECES_CASE(1345) TAC_PIECES_CASE(1456)
+#undef TAC_PIECES_CASE
+                    default: return TAC_E_UNSUPPORTED;
+                }
+                fast1_name = code;
+            } else if (waves3 == S3_WAVES_F32) {
                 constexpr int W = S3_WAVES_F32;
                 if (fast2 && fshort) k3 = pow2 ? melspec_stream3_kernel<NC, E, true, FMT, ST_FAST_STEPS1_SHORT, W> : melspec_stream3_kernel<NC, E, false, FMT, ST_FAST_STEPS1_SHORT, W>;
                 else if (fast2) k3 = pow2 ? melspec_stream3_kernel<NC, E, true, FMT, ST_FAST_STEPS1, W> : melspec_stream3_kernel<NC, E, false, FMT, ST_FAST_STEPS1, W>;
@@ -423,7 +438,7 @@ static int launch_stream(FrameGeom g, const Tables& tb, const SparseArgs& sm, co
         m.chunk = (total + b3 - 1) / b3;
         m.probe = (g_clock_probe && g_clock_probe_pairs >= b3) ? g_clock_probe : nullptr;
         {
-            const int fast1 = (FMT == FMT_F32 && fast2) ? (fshort ? ST_FAST_STEPS1_SHORT : ST_FAST_STEPS1) : 0;
+            const int fast1 = fast1_name ? fast1_name : ((FMT == FMT_F32 && fast2) ? (fshort ? ST_FAST_STEPS1_SHORT : ST_FAST_STEPS1) : 0);
             set_last_route("melspec_stream3_kernel<%d, %d, %s, %d, %d, %d>", NC, E, pow2 ? "true" : "false", FMT, fast1, waves3);
         }
         TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(k3), 160 * 1024));
@@ -676,14 +691,68 @@ static int pack_lanes(const std::vector<float>& h, int n_freqs, int n_mels, floa
     return TAC_OK;
 }
 
+// Piece layout (mel_pieces.hpp) for the fft_length-2048 streaming kernel: wpack = [total steps][64][4] weights, desc = first bins
+// at [s * 64 + l], the band a lane stores (or -1) at [256 + s * 64 + l], the piece index at [512 + s * 64 + l];
+// info_host = {weight floats, 3, 64, total steps, L0, L1, L2, PIECES_MARK}.
+static int pack_pieces(const std::vector<float>& h, int n_freqs, int n_mels, float* wpack, int wpack_cap, int32_t* desc,
+                       int desc_cap, int32_t* info_host, hipStream_t stream) {
+    PiecePlan p;
+    // (the kernel's deferred epilogue carries two band values per lane: n_mels <= 128; the planner itself takes up to 192)
+    if (desc_cap < 768 || n_mels > 128 || !plan_pieces(h.data(), n_freqs, n_mels, StreamCfg<1024, 16>::PROW, &p)) return TAC_E_UNSUPPORTED;
+    const long long wtot = 256LL * p.total_steps;
+    if (wtot > wpack_cap || stream3_lds_bytes<1024, 16>((int)wtot, S3_WAVES, false) > 160 * 1024) return TAC_E_UNSUPPORTED;
+    std::vector<int32_t> d(768, 0);
+    for (int e = 0; e < MP_SEGS * 64; ++e) {
+        d[e] = p.first[e];
+        d[256 + e] = p.band[e];
+        d[512 + e] = p.index[e];
+    }
+    TAC_HIP(hipMemcpyAsync(wpack, p.w.data(), p.w.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+    TAC_HIP(hipMemcpyAsync(desc, d.data(), d.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    TAC_HIP(hipStreamSynchronize(stream));
+    info_host[0] = (int32_t)wtot;
+    info_host[1] = MP_SEGS;
+    info_host[2] = 64;
+    info_host[3] = p.total_steps;
+    info_host[4] = p.L[0];
+    info_host[5] = p.L[1];
+    info_host[6] = p.L[2];
+    info_host[7] = S3_PIECES_MARK;
+    return TAC_OK;
+}
+
 }  // namespace tac
 
 extern "C" {
+
+int tac_melbank_plan_pieces_host(const float* fb_host, int32_t n_freqs, int32_t n_mels, int32_t* seg_steps, int32_t* first,
+                                 int32_t* band, int32_t* index, float* weights, int32_t weights_cap) {
+    using namespace tac;
+    if (!fb_host || !seg_steps || !first || !band || !index || !weights || n_freqs <= 0 || n_mels <= 0) return TAC_E_INVALID;
+    PiecePlan p;
+    if (!plan_pieces(fb_host, n_freqs, n_mels, StreamCfg<1024, 16>::PROW, &p)) return TAC_E_UNSUPPORTED;
+    if ((long long)p.w.size() > weights_cap) return TAC_E_INVALID;
+    for (int s = 0; s < MP_SEGS; ++s) seg_steps[s] = p.L[s];
+    for (int e = 0; e < MP_SEGS * 64; ++e) {
+        first[e] = p.first[e];
+        band[e] = p.band[e];
+        index[e] = p.index[e];
+    }
+    std::copy(p.w.begin(), p.w.end(), weights);
+    return TAC_OK;
+}
 
 int tac_melbank_pack(const float* fb, int32_t n_freqs, int32_t n_mels, int32_t n_fft, float* wpack,
                      int32_t wpack_cap, int32_t* desc, int32_t desc_cap, int32_t* info_host, void* stream) {
     using namespace tac;
     if (!fb || !wpack || !desc || !info_host || n_freqs <= 0 || n_mels <= 0) return TAC_E_INVALID;
+    if (n_fft == TAC_PACK_PIECES_2048) {                                         // the piece layout of the 2048 streaming kernel
+        if (n_freqs != 1025) return TAC_E_UNSUPPORTED;
+        std::vector<float> hp((size_t)n_freqs * n_mels);
+        TAC_HIP(hipMemcpyAsync(hp.data(), fb, hp.size() * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+        TAC_HIP(hipStreamSynchronize((hipStream_t)stream));
+        return pack_pieces(hp, n_freqs, n_mels, wpack, wpack_cap, desc, desc_cap, info_host, (hipStream_t)stream);
+    }
     // n_fft == 0: pack for the standalone filterbank kernel (32 lane groups, any number of bins)
     const int groups = n_fft == 0 ? FBS_WAVES * 4 : sparse_groups_for(n_fft);
     if (groups == 0 || (n_fft != 0 && n_freqs != n_fft / 2 + 1)) return TAC_E_UNSUPPORTED;

@@ -15,6 +15,7 @@
 namespace tac {
 
 constexpr int S3_WAVES = 12;          // what ships
+constexpr int S3_PIECES_MARK = -77;   // info_host[7] of a piece-layout pack (== TAC_PIECES_MARK, include/tac_amd.h)
 constexpr int S3_WAVES_F32 = 15;      // A/B form (TAC_S3_WAVES=15): as many 128-register waves as the LDS holds next to a 128-band bank
 
 #ifndef TAC_S3_SWZ
@@ -74,6 +75,9 @@ __host__ __device__ inline size_t stream3_lds_bytes(int wtot, int waves, bool co
     } while (0)
 #else
 #define S3_STAMP(i) do { } while (0)
+#endif
+#ifndef TAC_S3_PIECE_BATCH
+#define TAC_S3_PIECE_BATCH 5  // steps per request batch of the piece-layout contraction (two batches in flight)
 #endif
 #ifndef TAC_S3_W0_REGS
 #define TAC_S3_W0_REGS 0      // A/B: the four weight quads of band slot 0 live in registers (16 VGPRs) instead of being re-read per frame
@@ -422,6 +426,41 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     int lo_s[ST_MAX_SLOTS];
 #pragma unroll
     for (int s = 0; s < ST_MAX_SLOTS; ++s) lo_s[s] = s < m.nslot ? m.lo[s * 64 + lane] : 0;
+    // piece layout (FAST1 >= 1000 encodes the segment lengths, mel_pieces.hpp): the band this lane stores per segment (or -1)
+    // and how many left neighbours' partial sums belong to it
+    constexpr bool PIECES = FAST1 >= 1000;
+    // ... per segment: the float slot of the wave's staging row the lane writes its (shift-summed) value to — its band's when the
+    // lane holds the band's LAST piece, else a private dummy slot behind the 192 band slots, so that the write needs no predicate —
+    // and the piece's position inside its band (how many left neighbours to add)
+    constexpr int PC_STAGE = C::PROW + 8;                    // staging row: floats [PROW + 8, PROW + 8 + 256) of the exchange area
+    static_assert((PC_STAGE % 4) == 0 && (PC_STAGE + 256) * 4 <= XA_BYTES, "the staging row lies behind the power row, inside the area");
+    unsigned pc_meta[3] = {0, 0, 0};                         // staging slot | (piece index << 16): one register per segment
+    if constexpr (PIECES) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int b = m.lo[256 + s * 64 + lane], ix = m.lo[512 + s * 64 + lane];
+            pc_meta[s] = (unsigned)(PC_STAGE + ((b >= 0 && ix >= 256) ? b : 192 + lane)) | ((unsigned)(ix & 255) << 16);
+        }
+    }
+    // the band values of the wave's PREVIOUS frame, read back from the staging row at the end of that frame and still in flight:
+    // their epilogue and row stores run behind the next frame's first butterfly, so the staging round trip is off the wave's
+    // critical path (it is latency, not issue slots, that a twelve-wave CU is short of)
+    float pend[2] = {0.0f, 0.0f};
+    long long pend_frame = -1;
+    auto emit_pending = [&]() {
+        if constexpr (PIECES) {
+            if (pend_frame >= 0) {
+                float o0 = pend[0], o1 = pend[1];
+                if (m.db) {
+                    o0 = m.amin >= 1.1754944e-38f ? amp_to_db_fast(o0, m.amin, 10.0f * m.log10_ref) : amp_to_db(o0, m.amin, m.log10_ref);
+                    o1 = m.amin >= 1.1754944e-38f ? amp_to_db_fast(o1, m.amin, 10.0f * m.log10_ref) : amp_to_db(o1, m.amin, m.log10_ref);
+                }
+                float* orow = m.out + pend_frame * (long long)m.n_mels + lane;
+                if (lane < m.n_mels) orow[0] = o0;
+                if (64 + lane < m.n_mels) orow[64] = o1;
+            }
+        }
+    };
     float lutv = 0.0f;
     if (FMT >= FMT_MULAW_U8) lutv = m.lut[tid & 255];
     __builtin_amdgcn_sched_barrier(0);
@@ -506,7 +545,7 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     };
 #if TAC_S3_W0_REGS
     f4 w0_regs[ST_FAST_STEPS0];
-    if constexpr (FAST1 > 0) {
+    if constexpr (FAST1 > 0 && FAST1 < 1000) {
 #pragma unroll
         for (int u = 0; u < ST_FAST_STEPS0; ++u) w0_regs[u] = (reinterpret_cast<const f4*>(wlds) + lane)[u * 64];
     }
@@ -562,6 +601,7 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             Dft<16>::run_windowed(v, win);
 #endif
         }
+        emit_pending();                                       // (piece layout) the previous frame's epilogue + row stores
         S3_STAMP(0);                                          // samples waited for, window reads, first butterfly
 #if !TAC_S3_NOFENCE0
         wave_lds_fence();
@@ -698,7 +738,64 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         request(i);
         S3_STAMP(4);                                          // counter answer + sample request
         // ---- s4: filterbank contraction, dB, row store
-        if constexpr (FAST1 > 0) {
+        if constexpr (PIECES) {
+            // ---- piece layout: three segments of L0 / L1 / L2 steps, each a piece of a band; a band's pieces sit in adjacent lanes
+            //      of one 16-lane row and are summed with row-shift DPP reads; the lane of the last piece stores the band
+            constexpr int L0 = (FAST1 / 100) % 10, L1 = (FAST1 / 10) % 10, L2 = FAST1 % 10;
+            const int ci = cur < nloc ? cur : nloc - 1;
+            const f4* wp = reinterpret_cast<const f4*>(wlds) + lane;
+            const f4* p0 = reinterpret_cast<const f4*>(prow + lo_s[0]);
+            const f4* p1 = reinterpret_cast<const f4*>(prow + lo_s[1]);
+            const f4* p2 = reinterpret_cast<const f4*>(prow + lo_s[2]);
+            // the L0 + L1 + L2 steps as one flat list in two batches (A steps in flight, then the rest): every step is one 16-byte
+            // weight read [step][lane] + one 16-byte row read from its segment's run + two packed FMAs into its segment's sums
+            constexpr int ST = L0 + L1 + L2, BS = TAC_S3_PIECE_BATCH, NB = (ST + BS - 1) / BS;
+            cf a0 = mkc(0.f, 0.f), a1 = mkc(0.f, 0.f), b0 = mkc(0.f, 0.f), b1 = mkc(0.f, 0.f), c0 = mkc(0.f, 0.f), c1 = mkc(0.f, 0.f);
+            // (k is a constant after unrolling: the selects below fold)
+            auto rowq = [&](int k) { return k < L0 ? p0[k] : (k < L0 + L1 ? p1[k - L0] : p2[k - L0 - L1]); };
+            auto accum = [&](int k, f4 wv, f4 qv) {
+                if (k < L0) fma4(wv, qv, a0, a1);
+                else if (k < L0 + L1) fma4(wv, qv, b0, b1);
+                else fma4(wv, qv, c0, c1);
+            };
+            // batches of BS steps, two in flight: batch n + 1 is requested before batch n is consumed (the scheduling barriers keep
+            // hipcc from requesting everything at once, which spills)
+            f4 wq[2][BS], rq[2][BS];
+            auto request_batch = [&](int n) {
+#pragma unroll
+                for (int j = 0; j < BS; ++j)
+                    if (n * BS + j < ST) {
+                        wq[n & 1][j] = wp[(n * BS + j) * 64];
+                        rq[n & 1][j] = rowq(n * BS + j);
+                    }
+            };
+            request_batch(0);
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                if (n + 1 < NB) request_batch(n + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < BS; ++j)
+                    if (n * BS + j < ST) accum(n * BS + j, wq[n & 1][j], rq[n & 1][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            float vs[3] = {(a0.x + a0.y) + (a1.x + a1.y), (b0.x + b0.y) + (b1.x + b1.y), (c0.x + c0.y) + (c1.x + c1.y)};
+            // a band's pieces sit in adjacent lanes: partial sums of the one / two lanes to the left (row_shr: a lane at the start
+            // of its 16-lane row reads 0), then the lane of the last piece puts the band into the staging row; lane l then owns
+            // bands l, 64 + l (, 128 + l) like in the classic layout: one epilogue, coalesced row stores
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const float left1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(vs[s]), 0x111, 0xf, 0xf, false));
+                const float left2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(vs[s]), 0x112, 0xf, 0xf, false));
+                float tot = vs[s] + (pc_meta[s] >= 0x10000u ? left1 : 0.0f);
+                tot += pc_meta[s] >= 0x20000u ? left2 : 0.0f;
+                prow[pc_meta[s] & 0xffffu] = tot;
+            }
+            wave_lds_fence();
+            pend[0] = prow[PC_STAGE + lane];                 // (consumed behind the next frame's first butterfly: emit_pending)
+            pend[1] = prow[PC_STAGE + 64 + lane];
+            pend_frame = begin + place(ci);
+        } else if constexpr (FAST1 > 0) {
             const int ci = cur < nloc ? cur : nloc - 1;
             const f4* wp = reinterpret_cast<const f4*>(wlds) + lane;
             const f4* p0 = reinterpret_cast<const f4*>(prow + lo_s[0]);
@@ -731,7 +828,11 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
                     if (c + u < FAST1) fma4(wc[u], qc[u], b0, b1);
             }
             } else {
-            constexpr int B1 = (FAST1 + 1) / 2, B2 = FAST1 - B1;              // slot 1 in two batches
+#ifndef TAC_S3_ABL_STEPS1
+#define TAC_S3_ABL_STEPS1 0   // timing-only ablation (WRONG RESULTS): slot 1 runs this many steps instead of FAST1 (what a shorter contraction would buy)
+#endif
+            constexpr int EFF1 = TAC_S3_ABL_STEPS1 ? TAC_S3_ABL_STEPS1 : FAST1;
+            constexpr int B1 = (EFF1 + 1) / 2, B2 = EFF1 - B1;                // slot 1 in two batches
             f4 w0[ST_FAST_STEPS0], q0[ST_FAST_STEPS0], wa[B1], qa[B1];
 #pragma unroll
             for (int u = 0; u < ST_FAST_STEPS0; ++u) {
@@ -813,6 +914,7 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         S3_STAMP(5);                                          // contraction, dB, row store
         wave_lds_fence();                                                   // the row is consumed: the area takes the next frame
     }
+    emit_pending();                                           // (piece layout) the wave's last frame
     if (m.probe && w == 0) {
         const unsigned long long dc = __builtin_readcyclecounter() - probe_c, dw = wall_clock64() - probe_w;
         if (lane == 0) {
