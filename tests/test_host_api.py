@@ -417,6 +417,23 @@ template <int K> int check(int trials) {
             if (v[K / 2] != med[j]) ++bad;
         }
     }
+    for (int t = 0; t < trials; ++t) {                                      // runs of eight windows (two levels of sharing)
+        float w[K + 7];
+        const int mode = t % 4;
+        for (int i = 0; i < K + 7; ++i) {
+            if (mode == 0) w[i] = (float)rand() / RAND_MAX;
+            else if (mode == 1) w[i] = (float)(rand() % 5);
+            else if (mode == 2) w[i] = (rand() % 7 == 0) ? INFINITY : (float)(rand() % 100) - 50.f;
+            else w[i] = (float)i * ((t & 8) ? 1.f : -1.f);
+        }
+        float med[8];
+        median_run8<K>(w, med);
+        for (int j = 0; j < 8; ++j) {
+            std::vector<float> v(w + j, w + j + K);
+            std::nth_element(v.begin(), v.begin() + K / 2, v.end());
+            if (v[K / 2] != med[j]) ++bad;
+        }
+    }
     return bad;
 }
 int main() {
@@ -437,8 +454,8 @@ int main() {
 
 
 def test_median_run_matches_nth_element(tmp_path):
-    """csrc/median_run.hpp (the HPSS kernel's register sorting network and its shared-sort median selection of four
-    overlapping windows) is plain C++: compiled for the host and checked against std::nth_element for every width the
+    """csrc/median_run.hpp (the HPSS kernels' register sorting network and their shared-sort median selection of four /
+    eight overlapping windows) is plain C++: compiled for the host and checked against std::nth_element for every width the
     tile kernel is instantiated for — random values, heavy ties, infinities, sorted and reversed runs."""
     src = tmp_path / 'check.cpp'
     src.write_text(_MEDIAN_CHECK)

@@ -159,6 +159,223 @@ hpss_tile_kernel(const float* __restrict__ x, int NA, int NB, long long sr, long
     }
 }
 
+// hpss_tile8_kernel (round 4): the same tile with
+//  * runs of EIGHT windows per thread (median_run8: 56 instead of 97 min / max per median at K = 31), the NaN bookkeeping only
+//    in tiles that hold one;
+//  * 16-byte global accesses: the vector-memory pipe takes a wave's addresses four lanes a cycle whatever the width, and
+//    hpss_tile_kernel's 35 dword loads + 64 dword stores per thread cost it ~6 000 cycles per tile (0.25 ms of the 0.92).
+//    The fill reads whole 16-byte chunks wherever a chunk lies inside the row (edge chunks: four reflected scalar loads);
+//    results leave as 16-byte stores (4-byte aligned: rows of 1025 bins start anywhere) — 9 + 16 instructions per thread;
+//  * two thread -> output maps: along B (the fast axis, 16-byte LDS reads) a thread owns 2 rows x 8 consecutive columns and
+//    that is also the store map; along A it owns one column x 16 rows (two runs; LDS reads down the rows, a wave = 64
+//    consecutive columns), and the A medians cross the workgroup once through the (by then dead) tile.
+#ifndef TAC_HPSS_RUN8
+#define TAC_HPSS_RUN8 1
+#endif
+#ifndef TAC_HPSS_OCC8
+#define TAC_HPSS_OCC8 3
+#endif
+#ifndef TAC_HPSS_AMAP1
+#define TAC_HPSS_AMAP1 1       // 0: column pairs x 8 rows (8-byte LDS reads)
+#endif
+#ifndef TAC_HPSS_FILL16
+#define TAC_HPSS_FILL16 1      // 0: the flat dword loop
+#endif
+#ifndef TAC_HPSS_STORE16
+#define TAC_HPSS_STORE16 1     // 0: dword stores
+#endif
+#ifndef TAC_HPSS_NT
+#define TAC_HPSS_NT 0          // 1: nontemporal stores
+#endif
+#ifndef TAC_HPSS_STRIDE8
+#define TAC_HPSS_STRIDE8 96    // (100 / 104: 4 % slower, tools/ablation/README.md)
+#endif
+constexpr int HP8_STRIDE = TAC_HPSS_STRIDE8;  // floats per tile row
+constexpr int HP8_LDS_FLOATS = HP_ROWS * HP8_STRIDE;
+constexpr int HP8_EX = 68;                    // row stride of the 64 x 64 exchange of the A medians
+typedef float hp_f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <int K>
+__global__ void __launch_bounds__(256, TAC_HPSS_OCC8)
+hpss_tile8_kernel(const float* __restrict__ x, int NA, int NB, long long sr, long long sa, long long sb, int tiles_a,
+                  int tiles_b, int b_is_time, float power, int hard, float* __restrict__ harm_o, float* __restrict__ perc_o,
+                  float* __restrict__ mh_o, float* __restrict__ mp_o) {
+    constexpr int HALF = K / 2;
+    __shared__ __attribute__((aligned(16))) float tile[HP8_LDS_FLOATS];
+    const int tid = threadIdx.x;
+    const int per_row = tiles_a * tiles_b;
+    const long long row = blockIdx.x / per_row;
+    const int rem = (int)(blockIdx.x - row * per_row);
+    const int a0 = (rem / tiles_b) * HP_TILE, b0 = (rem % tiles_b) * HP_TILE;
+    const float* xr = x + row * sr;
+    bool seen_nan = false;
+#if TAC_HPSS_FILL16
+    if (sb == 1) {
+        constexpr int CH = HP_STRIDE / 4;                      // 24 chunks of four columns per tile row
+        for (int q = tid; q < HP_ROWS * CH; q += 256) {
+            const int r = q / CH, c4 = (q - r * CH) * 4;
+            const float* src = xr + (long long)reflect_clamped(a0 - 15 + r, NA) * sa;
+            const int b = b0 - HP_LEFT + c4;
+            hp_f4 v;
+            if (b >= 0 && b + 3 < NB) {
+                const hp_f4u u = *reinterpret_cast<const hp_f4u*>(src + b);
+                v.x = u.x; v.y = u.y; v.z = u.z; v.w = u.w;
+            } else {
+                v.x = src[reflect_clamped(b, NB)];
+                v.y = src[reflect_clamped(b + 1, NB)];
+                v.z = src[reflect_clamped(b + 2, NB)];
+                v.w = src[reflect_clamped(b + 3, NB)];
+            }
+            seen_nan |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
+            *reinterpret_cast<hp_f4*>(tile + r * HP8_STRIDE + c4) = v;
+        }
+    } else
+#endif
+    {
+        for (int i = tid; i < HP_ROWS * HP_STRIDE; i += 256) {
+            const int r = i / HP_STRIDE, c = i - r * HP_STRIDE;
+            const int a = reflect_clamped(a0 - 15 + r, NA), b = reflect_clamped(b0 - HP_LEFT + c, NB);
+            const float v = xr[(long long)a * sa + (long long)b * sb];
+            seen_nan |= v != v;
+            tile[r * HP8_STRIDE + c] = v;
+        }
+    }
+    const int tile_has_nan = __syncthreads_or(seen_nan ? 1 : 0);
+    // a window holds a NaN <=> its median is NaN (torch.median); the min / max network alone would drop it
+    auto run8 = [&](const float (&w)[K + 7], float (&med)[8]) {
+        median_run8<K>(w, med);
+        if (tile_has_nan) {                  // (workgroup-uniform; almost never taken)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                bool bad = false;
+#pragma unroll
+                for (int u = 0; u < K; ++u) bad |= w[j + u] != w[j + u];
+                med[j] = bad ? __builtin_nanf("") : med[j];
+            }
+        }
+    };
+    // ---- along B: thread (bx, ay) owns rows 2 ay, 2 ay + 1 and columns 8 bx .. 8 bx + 7 (also the store map)
+    const int bx = tid & 7, ay = tid >> 3;
+    constexpr int START = HP_LEFT - HALF, OFF = START & 3, NCH = (K + 7 + OFF + 3) / 4;
+    float medB[2][8], centre[2][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const hp_f4* src = reinterpret_cast<const hp_f4*>(tile + (2 * ay + 15 + i) * HP8_STRIDE + 8 * bx + (START - OFF));
+        float buf[4 * NCH];
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) {
+            const hp_f4 v = src[u];
+            buf[4 * u] = v.x; buf[4 * u + 1] = v.y; buf[4 * u + 2] = v.z; buf[4 * u + 3] = v.w;
+        }
+        float w[K + 7];
+#pragma unroll
+        for (int u = 0; u < K + 7; ++u) w[u] = buf[OFF + u];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) centre[i][j] = w[HALF + j];
+        run8(w, medB[i]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#if TAC_HPSS_AMAP1
+    // ---- along A: thread (cx, ry) owns column cx and rows 16 ry .. 16 ry + 15 (two runs)
+    const int cx = tid & 63, ry = tid >> 6;
+    float medA[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float w0[K + 7];
+        const float* src = tile + (16 * ry + 8 * h + 15 - HALF) * HP8_STRIDE + cx + HP_LEFT;
+#pragma unroll
+        for (int u = 0; u < K + 7; ++u) w0[u] = src[u * HP8_STRIDE];
+        run8(w0, medA[h]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();                         // every read of the tile is done: the A medians change maps through it
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tile[(16 * ry + 8 * h + i) * HP8_EX + cx] = medA[h][i];
+#else
+    // ---- along A: thread (cx, ry) owns rows 8 ry .. 8 ry + 7 and columns 2 cx, 2 cx + 1
+    const int cx = tid & 31, ry = tid >> 5;
+    float medA[2][8];
+    {
+        float w0[K + 7], w1[K + 7];
+        const float* src = tile + (8 * ry + 15 - HALF) * HP8_STRIDE + 2 * cx + HP_LEFT;
+#pragma unroll
+        for (int u = 0; u < K + 7; ++u) {
+            const hp_f2 v = *reinterpret_cast<const hp_f2*>(src + u * HP8_STRIDE);
+            w0[u] = v.x;
+            w1[u] = v.y;
+        }
+        run8(w0, medA[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        run8(w1, medA[1]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        hp_f2 v;
+        v.x = medA[0][i];
+        v.y = medA[1][i];
+        *reinterpret_cast<hp_f2*>(tile + (8 * ry + i) * HP8_EX + 2 * cx) = v;
+    }
+#endif
+    __syncthreads();
+    // ---- masks and stores in the B map
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int a = a0 + 2 * ay + i;
+        const int bq = b0 + 8 * bx;
+        const hp_f4 ma0 = *reinterpret_cast<const hp_f4*>(tile + (2 * ay + i) * HP8_EX + 8 * bx);
+        const hp_f4 ma1 = *reinterpret_cast<const hp_f4*>(tile + (2 * ay + i) * HP8_EX + 8 * bx + 4);
+        const float m_a[8] = {ma0.x, ma0.y, ma0.z, ma0.w, ma1.x, ma1.y, ma1.z, ma1.w};
+        float mh[8], mp[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float harm = b_is_time ? medB[i][j] : m_a[j];
+            const float perc = b_is_time ? m_a[j] : medB[i][j];
+            hpss_masks(harm, perc, power, hard, mh[j], mp[j]);
+        }
+#ifdef TAC_HPSS_ABL_NOSTORE
+        if (mh[0] + mp[7] != 123.0f) continue;
+#endif
+        if (a >= NA) continue;
+        const long long o = row * sr + (long long)a * sa + (long long)bq * sb;
+        auto put = [&](float* base, const float (&v)[8]) {
+#if TAC_HPSS_STORE16
+            if (sb == 1 && bq + 7 < NB) {
+                hp_f4u lo4, hi4;
+                lo4.x = v[0]; lo4.y = v[1]; lo4.z = v[2]; lo4.w = v[3];
+                hi4.x = v[4]; hi4.y = v[5]; hi4.z = v[6]; hi4.w = v[7];
+#if TAC_HPSS_NT
+                __builtin_nontemporal_store(lo4, reinterpret_cast<hp_f4u*>(base + o));
+                __builtin_nontemporal_store(hi4, reinterpret_cast<hp_f4u*>(base + o + 4));
+#else
+                *reinterpret_cast<hp_f4u*>(base + o) = lo4;
+                *reinterpret_cast<hp_f4u*>(base + o + 4) = hi4;
+#endif
+                return;
+            }
+#endif
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (bq + j < NB) base[o + (long long)j * sb] = v[j];
+        };
+        put(mh_o, mh);
+        put(mp_o, mp);
+        if (harm_o) {
+            float hv[8], pv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                hv[j] = centre[i][j] * mh[j];
+                pv[j] = centre[i][j] * mp[j];
+            }
+            put(harm_o, hv);
+            put(perc_o, pv);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 hpss_kernel(const float* __restrict__ x, long long rows, int F, int T, long long sr, long long sf, long long st, int kf,
             int kt, float power, int hard, float* __restrict__ harm_o, float* __restrict__ perc_o, float* __restrict__ mh_o,
@@ -216,8 +433,13 @@ static void launch_tile(const float* mag, long long rows, int F, int T, long lon
     const int NA = t_fast ? F : T, NB = t_fast ? T : F;
     const long long sa = t_fast ? sf : st, sb = t_fast ? st : sf;
     const int ta = (NA + HP_TILE - 1) / HP_TILE, tb = (NB + HP_TILE - 1) / HP_TILE;
+#if TAC_HPSS_RUN8
+    hipLaunchKernelGGL(hpss_tile8_kernel<K>, dim3((unsigned)(rows * ta * tb)), dim3(256), 0, stream, mag, NA, NB, sr, sa, sb,
+                       ta, tb, t_fast ? 1 : 0, power, hard, harm, perc, mh, mp);
+#else
     hipLaunchKernelGGL(hpss_tile_kernel<K>, dim3((unsigned)(rows * ta * tb)), dim3(256), 0, stream, mag, NA, NB, sr, sa, sb,
                        ta, tb, t_fast ? 1 : 0, power, hard, harm, perc, mh, mp);
+#endif
 }
 
 }  // namespace tac

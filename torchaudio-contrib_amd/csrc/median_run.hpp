@@ -15,6 +15,20 @@ TAC_HD void cswap_f(float& a, float& b) {
     a = lo;
     b = hi;
 }
+// three values in order: on the device one instruction each (v_min3 / v_med3 / v_max3), on the host three comparators
+TAC_HD void sort3_f(float& a, float& b, float& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float lo = __builtin_fminf(__builtin_fminf(a, b), c), md = __builtin_amdgcn_fmed3f(a, b, c),
+                hi = __builtin_fmaxf(__builtin_fmaxf(a, b), c);
+    a = lo;
+    b = md;
+    c = hi;
+#else
+    cswap_f(a, b);
+    cswap_f(b, c);
+    cswap_f(a, b);
+#endif
+}
 // Batcher odd-even mergesort of N values held in registers (comparators that would touch an index >= N are the ones
 // a +inf padding would make no-ops, so they are simply left out)
 template <int N>
@@ -51,5 +65,54 @@ TAC_HD void median_run4(const float (&w)[K + 3], float (&med)[4]) {
         cswap_f(e[1], e[2]);
         cswap_f(e[0], e[1]);
         med[j] = fminf(fminf(fmaxf(c0, e[2]), fmaxf(c1, e[1])), fminf(fmaxf(c2, e[0]), c3));
+    }
+}
+
+// medians of the EIGHT windows w[j .. j+K-1], j = 0..7, of K + 7 consecutive taps (K odd, >= 9) — two levels of sharing.
+// Level 0: the K - 7 taps all eight windows share, D = sorted w[7 .. K-1], once.  Level 1: windows 0..3 share D and
+// G = w[3..6], windows 4..7 share D and G = w[K .. K+3]: of the merged list C = D u G (what median_run4 sorts from scratch)
+// only the ranks M-3 .. M are needed, M = (K-1)/2, and rank r of the union of two sorted lists is
+//     min over t = 0..4 of max(D[r - t], G[t - 1])            (t = how many of its r + 1 smallest come from G),
+// eight min / max per rank.  Level 2 as in median_run4: the window's median is the 4th smallest of those four ranks and its
+// three own taps.  K = 31: 132 (sort 24) + 2 x (5 + 16) + 8 x 6.5 comparators = 56 min / max operations per median (run4: 97).
+template <int K>
+TAC_HD void median_run8(const float (&w)[K + 7], float (&med)[8]) {
+    static_assert(K >= 9 && (K & 1), "shared-sort form needs an odd K >= 9");
+    constexpr int N0 = K - 7, M = (K - 1) / 2;
+    float d[N0];
+#pragma unroll
+    for (int i = 0; i < N0; ++i) d[i] = w[7 + i];
+    sort_net<N0>(d);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float g[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[i] = h == 0 ? w[3 + i] : w[K + i];
+        sort_net<4>(g);
+        float c[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = M - 3 + q;
+            float val = 0.0f;
+            bool have = false;
+#pragma unroll
+            for (int t = 0; t <= 4; ++t) {
+                const int idx = r - t;                         // r + 1 - t values come from D: its element idx is the largest
+                if (idx > N0 - 1 || idx < -1) continue;        // (D has no such element / more than r + 1 taken from G)
+                const int ic = idx < 0 ? 0 : idx;
+                const float term = t == 0 ? d[ic] : (idx == -1 ? g[t - 1] : fmaxf(d[ic], g[t - 1]));
+                val = have ? fminf(val, term) : term;
+                have = true;
+            }
+            c[q] = val;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float e[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) e[u] = u < 3 - j ? w[4 * h + j + u] : w[4 * h + K + (u - (3 - j))];
+            sort3_f(e[0], e[1], e[2]);
+            med[4 * h + j] = fminf(fminf(fmaxf(c[0], e[2]), fmaxf(c[1], e[1])), fminf(fmaxf(c[2], e[0]), c[3]));
+        }
     }
 }

@@ -12,27 +12,73 @@
 namespace tac {
 
 constexpr int PV_THREADS = 256;
-#ifndef TAC_PV_HW_SINCOS
-#define TAC_PV_HW_SINCOS 1     // 0: library sincosf on the float64-reduced angle (0.293 vs 0.274 ms at cfg-2)
+#ifndef TAC_PV_FIXED
+#define TAC_PV_FIXED 1         // float32: running phase as a 32-bit fraction of a turn (0: round 3's float64 running sum)
+#endif
+#ifndef TAC_PV_AHEAD
+#define TAC_PV_AHEAD 8         // steps whose frames are in flight (round 3: 4)
+#endif
+#ifndef TAC_PV_PREFETCH0
+#define TAC_PV_PREFETCH0 1     // a step's FIRST frame, when it is not the previous step's second, is requested ahead as well
 #endif
 
 // Precision.  The reference evaluates the recurrence in the dtype of its input, and in float32 that is
 // ill-conditioned: `angle_1 - angle_0 - phase_advance` is rounded at the magnitude of the phase advance (up to
 // pi*hop, i.e. several hundred radians: spacing 6e-5) and the running sum at its own magnitude (thousands of
 // radians: spacing 5e-4), which is why the reference's own test runs it in float64 (tests/test_functional.py:85-88).
-// Here the samples, arctangents, magnitudes and outputs have the precision of T, but the phase increment and the
-// running sum are always carried in float64, so a float32 call agrees with the float64 evaluation of the same
-// inputs to ~1e-6 instead of ~1e-3; T = double is the reference's float64 path as is.
+// Only the running sum MODULO one turn reaches the output (it goes through cos / sin, functional.py:268-272), and modulo
+// one turn the reference's step `wrap(a1 - a0 - pa) + pa` (functional.py:258-264) is `a1 - a0`: the wrap subtracts whole
+// turns and the phase advance cancels.  The float32 kernel therefore keeps angles as signed 32-bit fractions of a turn
+// (2^-32 turn = 1.5e-9 rad) and the running sum as their wrapping integer sum — exact, whatever the number of steps and
+// the size of the phase advance —, which agrees with the float64 evaluation of the reference's formula to the accuracy
+// of the arctangents (1e-7 rad each).  A phase advance that is not finite poisons every step after the first, as the
+// reference's cumulative sum does.  T = double is the reference's float64 formula as is.
 template <class T>
 struct pv_math;
 template <>
 struct pv_math<float> {
-    // atan2f without the library's special-case ladder (~25 instructions instead of ~50; the kernel is bound by this
-    // arithmetic, not by memory): octant reduction to a = min / max in [0, 1], atan(a) = a P(a^2) with a degree-8 minimax P
-    // (max error 1.0e-7 rad in float32, fitted and checked over 2 M points by the script quoted in tools/ablation/README.md),
-    // signs restored.  atan2(0, 0) = 0 like the library; the errors telescope in the running sum (a step's second
-    // phase is the next step's first).
-    static __device__ __forceinline__ float atan2(float y, float x) {
+#if TAC_PV_FIXED
+    typedef unsigned ang_t;                                         // fraction of a turn, scaled by 2^32 (wrapping)
+    typedef unsigned acc_t;
+    // atan2 in TURNS without the library's special-case ladder: octant reduction to a = min / max in [0, 1],
+    // atan(a) / 2 pi = a P(a^2) with the degree-8 minimax P of round 3 (1.0e-7 rad; fitted and checked over 2 M points by the
+    // script quoted in tools/ablation/README.md) scaled by 1 / 2 pi, signs restored.  atan2(0, 0) = 0 like the library.
+    static __device__ __forceinline__ ang_t angle(float y, float x) {
+        const float ax = fabsf(x), ay = fabsf(y);
+        const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+        float a = mn * __builtin_amdgcn_rcpf(mx);
+        a = mx == 0.0f ? 0.0f : a;
+        const float s = a * a;
+        float p = (float)(0.0024567253421992064 * 0.15915494309189535);
+        p = fmaf(p, s, (float)(-0.014401361346244812 * 0.15915494309189535));
+        p = fmaf(p, s, (float)(0.03978123143315315 * 0.15915494309189535));
+        p = fmaf(p, s, (float)(-0.07234857976436615 * 0.15915494309189535));
+        p = fmaf(p, s, (float)(0.10498946160078049 * 0.15915494309189535));
+        p = fmaf(p, s, (float)(-0.14161229133605957 * 0.15915494309189535));
+        p = fmaf(p, s, (float)(0.19985906779766083 * 0.15915494309189535));
+        p = fmaf(p, s, (float)(-0.33332598209381104 * 0.15915494309189535));
+        p = fmaf(p, s, (float)(0.9999998807907104 * 0.15915494309189535));
+        float r = p * a;                                            // [0, 1/8] turn
+        r = ay > ax ? 0.25f - r : r;
+        r = x < 0.0f ? 0.5f - r : r;
+        // exact scaling by 2^32 ([0, 2^31] fits an unsigned); NaN converts to 0 (the magnitude carries it)
+        const unsigned u = (unsigned)(r * 4294967296.0f);
+        return __builtin_signbit(y) ? 0u - u : u;
+    }
+    static __device__ __forceinline__ acc_t open(ang_t a) { return a; }
+    static __device__ __forceinline__ acc_t step(acc_t acc, ang_t a1, ang_t a0, float) {
+        return acc + a1 - a0;                                       // wraps modulo one turn
+    }
+    static __device__ __forceinline__ float poison(float pa) { return pa - pa; }     // 0, or NaN for a non-finite advance
+    static __device__ __forceinline__ void sincos(acc_t acc, float bias, float* s, float* c) {
+        const float fr = (float)(int)acc * 2.3283064365386963e-10f + bias;                  // [-1/2, 1/2] turn for v_sin / v_cos
+        *s = __builtin_amdgcn_sinf(fr);
+        *c = __builtin_amdgcn_cosf(fr);
+    }
+#else
+    typedef float ang_t;
+    typedef double acc_t;
+    static __device__ __forceinline__ float angle(float y, float x) {
         const float ax = fabsf(x), ay = fabsf(y);
         const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
         float a = mn * __builtin_amdgcn_rcpf(mx);
@@ -52,24 +98,38 @@ struct pv_math<float> {
         r = x < 0.0f ? 3.141592653589793f - r : r;
         return copysignf(r, y);
     }
-    static __device__ __forceinline__ float hypot(float x, float y) { return sqrtf(x * x + y * y); }
-    static __device__ __forceinline__ void sincos(double a, float* s, float* c) {
-#if TAC_PV_HW_SINCOS
+    static __device__ __forceinline__ acc_t open(ang_t a) { return (double)a; }
+    static __device__ __forceinline__ acc_t step(acc_t acc, ang_t a1, ang_t a0, float pa) {
+        double ph = (double)a1 - (double)a0 - (double)pa;
+        ph = ph - 6.283185307179586 * rint(ph * 0.15915494309189535);
+        return acc + (ph + (double)pa);
+    }
+    static __device__ __forceinline__ float poison(float) { return 0.0f; }
+    static __device__ __forceinline__ void sincos(acc_t a, float, float* s, float* c) {
         const double tr = a * 0.15915494309189535;                  // reduced to a fraction of a turn in float64,
         const float fr = (float)(tr - rint(tr));                    // evaluated by the hardware's v_sin / v_cos (input in turns)
         *s = __builtin_amdgcn_sinf(fr);
         *c = __builtin_amdgcn_cosf(fr);
-#else
-        const double turns = rint(a * 0.15915494309189535);
-        sincosf((float)(a - turns * 6.283185307179586), s, c);      // reduced in float64, evaluated in float32
-#endif
     }
+#endif
+    static __device__ __forceinline__ float hypot(float x, float y) { return sqrtf(x * x + y * y); }
 };
 template <>
 struct pv_math<double> {
-    static __device__ __forceinline__ double atan2(double y, double x) { return ::atan2(y, x); }
+    typedef double ang_t;
+    typedef double acc_t;
+    static __device__ __forceinline__ double angle(double y, double x) { return ::atan2(y, x); }
     static __device__ __forceinline__ double hypot(double x, double y) { return sqrt(x * x + y * y); }
-    static __device__ __forceinline__ void sincos(double a, double* s, double* c) { ::sincos(a, s, c); }
+    static __device__ __forceinline__ acc_t open(ang_t a) { return a; }
+    static __device__ __forceinline__ acc_t step(acc_t acc, ang_t a1, ang_t a0, double pa) {
+        double ph = a1 - a0 - pa;
+        // (a reciprocal instead of the reference's division: where the two round differently the wrapped phase moves by
+        // exactly one turn, which the sine and cosine of the running sum do not see)
+        ph = ph - 6.283185307179586 * rint(ph * 0.15915494309189535);
+        return acc + (ph + pa);
+    }
+    static __device__ __forceinline__ double poison(double) { return 0.0; }
+    static __device__ __forceinline__ void sincos(acc_t a, double, double* s, double* c) { ::sincos(a, s, c); }
 };
 
 template <class T>
@@ -87,79 +147,91 @@ phase_vocoder_kernel(const T* __restrict__ spec, long long rows, int n_freqs, in
     const long long row = sid / n_freqs;
     const int f = (int)(sid - row * n_freqs);
     const T* base = spec + row * stride_r + (long long)f * stride_f;
-    T re0, im0, re1, im1;
-    auto frame = [&](int t, T& re, T& im) {     // the two frames past the end are the reference's zero padding
-        if (t >= n_frames) {
-            re = im = (T)0;
-            return;
-        }
-        const T2 v = *reinterpret_cast<const T2*>(base + (long long)t * stride_t);
-        re = v.x;
-        im = v.y;
-    };
-    const double two_pi = 6.283185307179586;
-    const double pa = (double)phase_advance[f];
-    frame(0, re0, im0);
-    double acc = (double)M::atan2(im0, re0);    // phase of the first input frame opens the running sum
-    T* o = out + (row * n_out * (long long)n_freqs + f) * 2;
-    // The second frame of step i is the first frame of step i + 1 whenever the grid advances by one input frame (every
-    // step for rate <= 1, most steps up to rate 2): its phase and magnitude are kept instead of being loaded and
-    // evaluated again (the grid is wave-uniform, so is the branch; the values are the ones that would be recomputed).
-    int t_kept = -1;
-    T ang_kept = (T)0, n_kept = (T)0;
-    // The loop is a chain of dependent steps, and a step's only long latency is the load of its second frame: left in
-    // the step it made every one of the n_out steps one HBM round trip long (0.336 ms at cfg-2, whatever the occupancy).
-    // The second frames of the next PV_AHEAD steps are therefore always in flight (their indices come from the grid,
-    // not from the recurrence), in a rotating set of registers.
-    constexpr int AHEAD = 4;
-    T2 ahead[AHEAD];
-    auto fetch = [&](int i) -> T2 {             // second frame of step i (clamped to the last step; zero past the input)
-        const int ic = i < n_out ? i : n_out - 1;
-        const int t = idx1[ic];
+    auto frame = [&](int t) -> T2 {             // the two frames past the end are the reference's zero padding
         const int tc = t < n_frames ? t : n_frames - 1;
         T2 v = *reinterpret_cast<const T2*>(base + (long long)tc * stride_t);
         if (t >= n_frames) v.x = v.y = (T)0;
         return v;
     };
+    const T pa = phase_advance[f];
+    const T2 first = frame(0);
+    typename M::acc_t acc = M::open(M::angle(first.y, first.x));    // phase of the first input frame opens the running sum
+    T bias = (T)0;
+    T* o = out + (row * n_out * (long long)n_freqs + f) * 2;
+    // The second frame of step i is the first frame of step i + 1 whenever the grid advances by one input frame (every
+    // step for rate <= 1, most steps up to rate 2): its phase and magnitude are kept instead of being loaded and
+    // evaluated again (the grid is wave-uniform, so is the branch; the values are the ones that would be recomputed).
+    int t_kept = -1;
+    typename M::ang_t ang_kept = 0;
+    T n_kept = (T)0;
+    // The loop is a chain of dependent steps, and a step's only long latency is the load of its frames: left in the
+    // step it made every one of the n_out steps one HBM round trip long (0.336 ms at cfg-2, whatever the occupancy).
+    // The frames of the next AHEAD steps are therefore always in flight (their indices come from the grid, not from the
+    // recurrence), in a rotating set of registers: the second frame always, the first one when it is not the previous
+    // step's second (rate > 1: round 3 loaded those inside the step).
+    constexpr int AHEAD = sizeof(T) == 8 ? 4 : TAC_PV_AHEAD;        // (float64: 16-byte pairs, round 3's depth)
+    T2 ahead1[AHEAD], ahead0[AHEAD];
+    auto request = [&](int i, T2& v0, T2& v1) {  // frames of step i (clamped to the last step)
+        const int ic = i < n_out ? i : n_out - 1;
+        v1 = frame(idx1[ic]);
+#if TAC_PV_PREFETCH0
+        if (ic == 0 || idx0[ic] != idx1[ic - 1]) v0 = frame(idx0[ic]);
+#endif
+    };
 #pragma unroll
-    for (int k = 0; k < AHEAD; ++k) ahead[k] = fetch(k);
+    for (int k = 0; k < AHEAD; ++k) {
+        ahead0[k] = first;
+        request(k, ahead0[k], ahead1[k]);
+    }
     for (int i0 = 0; i0 < n_out; i0 += AHEAD) {
 #pragma unroll
         for (int k = 0; k < AHEAD; ++k) {
             const int i = i0 + k;
             if (i >= n_out) break;
             const int t0 = idx0[i], t1 = idx1[i];
-            const T2 cur = ahead[k];
-            ahead[k] = fetch(i + AHEAD);
-            T ang0, n0;
+            const T2 cur1 = ahead1[k];
+            T2 cur0 = ahead0[k];
+            request(i + AHEAD, ahead0[k], ahead1[k]);
+#ifdef TAC_PV_ABL_COPY                       // timing-only ablation (wrong results): the access pattern without the arithmetic
+            {
+                if (t0 != t_kept) cur0 = frame(t0);
+                t_kept = t1;
+                T2 res;
+                res.x = cur1.x * alpha[i] + cur0.x;
+                res.y = cur1.y + cur0.y;
+                *reinterpret_cast<T2*>(o) = res;
+                o += 2 * (long long)n_freqs;
+                continue;
+            }
+#endif
+            typename M::ang_t ang0;
+            T n0;
             if (t0 == t_kept) {
                 ang0 = ang_kept;
                 n0 = n_kept;
             } else {
-                frame(t0, re0, im0);
-                ang0 = M::atan2(im0, re0);
-                n0 = M::hypot(re0, im0);
+#if !TAC_PV_PREFETCH0
+                cur0 = frame(t0);
+#endif
+                ang0 = M::angle(cur0.y, cur0.x);
+                n0 = M::hypot(cur0.x, cur0.y);
             }
-            re1 = cur.x;
-            im1 = cur.y;
-            const T ang1 = M::atan2(im1, re1), n1 = M::hypot(re1, im1);
+            const typename M::ang_t ang1 = M::angle(cur1.y, cur1.x);
+            const T n1 = M::hypot(cur1.x, cur1.y);
             t_kept = t1;
             ang_kept = ang1;
             n_kept = n1;
             const T w = alpha[i];
             const T mag = w * n1 + ((T)1 - w) * n0;
             T sn, cs;
-            M::sincos(acc, &sn, &cs);
+            M::sincos(acc, bias, &sn, &cs);
             T2 res;
             res.x = mag * cs;
             res.y = mag * sn;
             *reinterpret_cast<T2*>(o) = res;
             o += 2 * (long long)n_freqs;
-            double ph = (double)ang1 - (double)ang0 - pa;
-            // (a reciprocal instead of the reference's division: where the two round differently the wrapped phase moves by
-            // exactly one turn, which the sine and cosine of the running sum do not see)
-            ph = ph - two_pi * rint(ph * 0.15915494309189535);
-            acc += ph + pa;
+            acc = M::step(acc, ang1, ang0, pa);
+            if (i == 0) bias = M::poison(pa);
         }
     }
 }
