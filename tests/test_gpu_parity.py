@@ -1396,7 +1396,7 @@ def test_g8_hpss(tac, golden):
 
 
 def test_hpss_tile_kernel_every_width_both_layouts_and_nan(tac):
-    """The 64 x 64 tile kernel (equal odd widths 9 ... 31, shared-sort medians, csrc/hpss.hip) against a numpy restatement
+    """The 64 x 64 tile kernel (equal odd widths 9 ... 31, shared-sort medians of eight windows, csrc/hpss.hip) against a numpy restatement
     of beta_hpss.py:104-127: every width it is instantiated for, sizes that are not multiples of the tile (and smaller
     than it), the contiguous (F, T) layout and the frame-major strided layout the STFT kernels return; medians select
     existing values, so the enhanced spectrograms are compared exactly.  A NaN poisons exactly the windows that hold
@@ -1442,9 +1442,46 @@ def test_hpss_tile_kernel_every_width_both_layouts_and_nan(tac):
             assert np.array_equal(np.isnan(host(a)), np.isnan(b.numpy())), k
             ok = ~np.isnan(b.numpy())
             assert np.abs(host(a)[ok] - b.numpy()[ok]).max() <= 1e-6
-        got5 = tac.hpss(dev(s), (5, 9), 2.0, False)                          # the general one-thread-per-element kernel
+        got5 = tac.hpss(dev(s), (5, 9), 2.0, False)                          # unequal widths: the two-launch route
         want5 = tac.hpss(torch.from_numpy(s), (5, 9), 2.0, False)
         assert np.array_equal(np.isnan(host(got5[2])), np.isnan(want5[2].numpy()))
+
+
+def test_hpss_unequal_and_small_widths_both_layouts_and_nan(tac):
+    """Unequal or small filter widths (csrc/hpss.hip: hpss_axis_a_kernel + hpss_axis_b_kernel, one halo axis each, the first
+    launch's medians parked in the mask_perc buffer) against the same numpy restatement of beta_hpss.py:104-127, both
+    layouts, sizes off the tile grid; medians select existing values, so hard masks are compared exactly."""
+    rng = np.random.default_rng(11)
+    cases = [((1, 3), (2, 70, 131)), ((3, 1), (1, 65, 64)), ((5, 9), (2, 129, 200)), ((7, 31), (1, 257, 90)),
+             ((31, 9), (2, 64, 33)), ((13, 5), (1, 100, 17)), ((3, 3), (1, 513, 70)), ((1, 1), (1, 9, 9)), ((29, 31), (1, 40, 150))]
+    for (kf, kt), (rows, F, T) in cases:
+        s = (rng.random((rows, F, T), dtype=np.float32) * rng.integers(1, 4, (rows, F, T))).astype(np.float32)
+        padf = np.pad(s, ((0, 0), (kf // 2, kf // 2), (0, 0)), mode='reflect')
+        padt = np.pad(s, ((0, 0), (0, 0), (kt // 2, kt // 2)), mode='reflect')
+        perc = np.sort(np.stack([padf[:, i:i + F] for i in range(kf)], -1), -1)[..., kf // 2]
+        harm = np.sort(np.stack([padt[..., i:i + T] for i in range(kt)], -1), -1)[..., kt // 2]
+        for layout in ('contiguous', 'frame-major'):
+            x = dev(s) if layout == 'contiguous' else dev(np.ascontiguousarray(s.transpose(0, 2, 1))).transpose(1, 2)
+            before = launches(tac)
+            h, p, mh, mp = tac.hpss(x, (kf, kt), 1.0, False)
+            assert launched_since(tac, before) == {'tac_hpss_f32': 1}
+            assert mh.stride() == x.stride()
+            want_mh = (harm + np.float32(1e-6)) / (harm + perc + np.float32(1e-6))
+            want_mp = (perc + np.float32(1e-6)) / (harm + perc + np.float32(1e-6))
+            assert np.abs(host(mh) - want_mh).max() <= 2e-7 and np.abs(host(mp) - want_mp).max() <= 2e-7, (kf, kt, layout)
+            assert np.abs(host(h) - s * want_mh).max() <= 4e-7 * s.max() and np.abs(host(p) - s * want_mp).max() <= 4e-7 * s.max()
+            hard = tac.hpss(x, (kf, kt), 2.0, True)
+            assert np.array_equal(host(hard[2]), harm > perc) and np.array_equal(host(hard[3]), harm < perc), (kf, kt, layout)
+    s = rng.random((1, 90, 80), dtype=np.float32)
+    s[0, 40, 33] = np.nan
+    s[0, 2, 70] = np.nan
+    for ks in ((5, 9), (31, 3), (1, 7)):
+        got = tac.hpss(dev(s), ks, 2.0, False)
+        want = tac.hpss(torch.from_numpy(s), ks, 2.0, False)                 # CPU route: torch.median
+        for a, b in zip(got, want):
+            assert np.array_equal(np.isnan(host(a)), np.isnan(b.numpy())), ks
+            ok = ~np.isnan(b.numpy())
+            assert np.abs(host(a)[ok] - b.numpy()[ok]).max() <= 1e-6
 
 
 def test_g10_melspectrogram_fft_length_4096(tac, golden):

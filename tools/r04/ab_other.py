@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Same-process A/B of library builds for the SURVEY 8(f) rows (phase_vocoder, hpss): like ab_inproc.py, through the C ABI.
-    python tools/r04/ab_other.py pv[:rate] | hpss[:k] name=path [name=path ...]
+    python tools/r04/ab_other.py pv[:rate] | hpss[:k | :kfxkt] name=path [name=path ...]
 256 x 1025 x 313 frame-major complex spectrogram (cfg-2's STFT output); prints median / p10 / p90 per build and the median of
 per-round differences to the first build; the first launch of every build is compared with the first build's."""
 import ctypes, math, os, sys, time
@@ -38,14 +38,15 @@ if op.startswith('pv'):
                                      P(idx1.data_ptr()), P(alpha.data_ptr()), n_out, P(out.data_ptr()), stream)
         assert rc == 0, (name, rc)
 elif op.startswith('hpss'):
-    ksz = int(op.split(':')[1]) if ':' in op else 31
+    ksz = op.split(':')[1] if ':' in op else '31'
+    kf, kt = (int(v) for v in (ksz.split('x') if 'x' in ksz else (ksz, ksz)))        # hpss:31 or hpss:5x9 (freq x time)
     zs = [torch.rand(rows, T, F, device=dev) ** 2 for _ in range(nrot)]          # frame-major |X|^2, as the STFT kernels return it
     outs = [torch.empty(rows, T, F, device=dev) for _ in range(4)]
     out = outs[0]
     nbytes = zs[0].numel() * 20
 
     def launch(name, h, z):
-        rc = h.tac_hpss_f32(P(z.data_ptr()), rows, F, T, T * F, 1, F, ksz, ksz, 2.0, 0, P(outs[0].data_ptr()), P(outs[1].data_ptr()),
+        rc = h.tac_hpss_f32(P(z.data_ptr()), rows, F, T, T * F, 1, F, kf, kt, 2.0, 0, P(outs[0].data_ptr()), P(outs[1].data_ptr()),
                             P(outs[2].data_ptr()), P(outs[3].data_ptr()), stream)
         assert rc == 0, (name, rc)
 else:

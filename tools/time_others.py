@@ -49,7 +49,7 @@ cases = [
     ('hpss k=31 (frame-major |X|^2)', lambda: tac.hpss(p, 31, 2.0), p.numel() * 20),
     ('hpss k=17 (frame-major |X|^2)', lambda: tac.hpss(p, 17, 2.0), p.numel() * 20),
     ('hpss k=31 (contiguous)', lambda: tac.hpss(pc, 31, 2.0), p.numel() * 20),
-    ('hpss k=(5, 9) (general kernel)', lambda: tac.hpss(pc, (5, 9), 2.0), p.numel() * 20),
+    ('hpss k=(5, 9) (two launches)', lambda: tac.hpss(pc, (5, 9), 2.0), p.numel() * 20),
 ]
 only = sys.argv[1:]
 for name, fn, nbytes in cases:

@@ -4,16 +4,16 @@
 // from which soft ((h + eps) / (h + p + eps)) or hard (h > p) masks and the masked spectrograms follow.  The reference
 // loops over columns / rows calling torch.median.
 //
-// hpss_tile_kernel (equal odd widths 9 ... 31 — the reference only runs with equal widths, default 31): a 256-thread
-// workgroup owns a 64 x 64 tile of one spectrogram, staged ONCE in LDS with its reflect-padded halo (the fast memory
-// axis is the LDS column axis, so the fill is coalesced whatever the layout: contiguous (F, T) or the frame-major
-// strided views the STFT kernels return); a thread owns a 4 x 4 block of outputs.  Four consecutive windows along an
-// axis share K - 3 of their K taps: those are sorted once in registers (Batcher network) and each window's median is
-// selected from five of them and the window's three own taps (median_run.hpp) — 110 min/max operations per median
-// instead of the 382 of a full 32-sort per output.  A NaN anywhere in a window makes its median NaN, as torch.median
-// does (the min/max network alone would drop it).
-//
-// hpss_kernel: the general form (unequal or small widths): one thread per element, two full sorts.
+// Equal odd widths 9 ... 31 (the reference only runs with equal widths, default 31): hpss_tile8_kernel — a 256-thread
+// workgroup owns a 64 x 64 tile of one spectrogram, staged ONCE in LDS with its reflect-padded halo (the fast memory axis is
+// the LDS column axis, so the fill is coalesced whatever the layout: contiguous (F, T) or the frame-major strided views the
+// STFT kernels return).  EIGHT consecutive windows along an axis share K - 7 of their K taps: sorted once in registers
+// (Batcher network), merged with four more for each half of the run, each window's median selected from four ranks of that
+// and its three own taps (median_run.hpp: 56 min / max operations per median at K = 31; a full 32-sort per output is 382).
+// A NaN anywhere in a window makes its median NaN, as torch.median does (the min / max network alone would drop it).
+// Any other odd widths <= 31: hpss_axis_a_kernel + hpss_axis_b_kernel, the same tiles with one halo axis per launch.
+// hpss_tile_kernel (round 3: runs of four, 4 x 4 outputs per thread, dword accesses) and hpss_kernel (round 3: one thread per
+// element) are kept as the A/B baselines (-DTAC_HPSS_RUN8=0, -DTAC_HPSS_TWO_PASS=0) and for non-unit fast strides.
 #include "host_common.hpp"
 #include "median_run.hpp"
 
@@ -172,6 +172,9 @@ hpss_tile_kernel(const float* __restrict__ x, int NA, int NB, long long sr, long
 #ifndef TAC_HPSS_RUN8
 #define TAC_HPSS_RUN8 1
 #endif
+#ifndef TAC_HPSS_TWO_PASS
+#define TAC_HPSS_TWO_PASS 1    // unequal / small widths: hpss_axis_a_kernel + hpss_axis_b_kernel (0: round 3's hpss_kernel)
+#endif
 #ifndef TAC_HPSS_OCC8
 #define TAC_HPSS_OCC8 3
 #endif
@@ -195,6 +198,125 @@ constexpr int HP8_LDS_FLOATS = HP_ROWS * HP8_STRIDE;
 constexpr int HP8_EX = 68;                    // row stride of the 64 x 64 exchange of the A medians
 typedef float hp_f4u __attribute__((ext_vector_type(4), aligned(4)));
 
+// n_rows x COLS floats (COLS a multiple of 4) of a tile, from rows a_first .. and columns b_first .. of one spectrogram,
+// both reflected at the borders (positions only out-of-range outputs would use are clamped).  Returns "this thread saw a NaN".
+template <int COLS>
+__device__ __forceinline__ bool hp_fill(float* tile, int stride, const float* __restrict__ xr, int a_first, int n_rows,
+                                        int b_first, int NA, int NB, long long sa, long long sb, int tid) {
+    bool seen_nan = false;
+#if TAC_HPSS_FILL16
+    if (sb == 1) {
+        constexpr int CH = COLS / 4;
+        for (int q = tid; q < n_rows * CH; q += 256) {
+            const int r = q / CH, c4 = (q - r * CH) * 4;
+            const float* src = xr + (long long)reflect_clamped(a_first + r, NA) * sa;
+            const int b = b_first + c4;
+            hp_f4 v;
+            if (b >= 0 && b + 3 < NB) {
+                const hp_f4u u = *reinterpret_cast<const hp_f4u*>(src + b);
+                v.x = u.x; v.y = u.y; v.z = u.z; v.w = u.w;
+            } else {
+                v.x = src[reflect_clamped(b, NB)];
+                v.y = src[reflect_clamped(b + 1, NB)];
+                v.z = src[reflect_clamped(b + 2, NB)];
+                v.w = src[reflect_clamped(b + 3, NB)];
+            }
+            seen_nan |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
+            *reinterpret_cast<hp_f4*>(tile + r * stride + c4) = v;
+        }
+        return seen_nan;
+    }
+#endif
+    for (int i = tid; i < n_rows * COLS; i += 256) {
+        const int r = i / COLS, c = i - r * COLS;
+        const int a = reflect_clamped(a_first + r, NA), b = reflect_clamped(b_first + c, NB);
+        const float v = xr[(long long)a * sa + (long long)b * sb];
+        seen_nan |= v != v;
+        tile[r * stride + c] = v;
+    }
+    return seen_nan;
+}
+
+// eight windows of K taps with torch.median's NaN rule: a window that holds a NaN has a NaN median (the min / max network
+// alone would drop it); the bookkeeping runs only in tiles that hold one (workgroup-uniform flag, almost never set)
+template <int K>
+__device__ __forceinline__ void hp_run8(const float (&w)[K + 7], float (&med)[8], int tile_has_nan) {
+    median_run8_any<K>(w, med);
+    if (tile_has_nan) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            bool bad = false;
+#pragma unroll
+            for (int u = 0; u < K; ++u) bad |= w[j + u] != w[j + u];
+            med[j] = bad ? __builtin_nanf("") : med[j];
+        }
+    }
+}
+
+// masks and the four results of eight consecutive columns bq .. bq + 7 of row a (o = the offset of (a, bq))
+__device__ __forceinline__ void hp_emit8(bool row_ok, int bq, int NB, long long o, long long sb, const float (&m_a)[8],
+                                         const float (&m_b)[8], const float (&centre)[8], int b_is_time, float power,
+                                         int hard, float* harm_o, float* perc_o, float* mh_o, float* mp_o) {
+    float mh[8], mp[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float harm = b_is_time ? m_b[j] : m_a[j];
+        const float perc = b_is_time ? m_a[j] : m_b[j];
+        hpss_masks(harm, perc, power, hard, mh[j], mp[j]);
+    }
+#ifdef TAC_HPSS_ABL_NOSTORE
+    if (mh[0] + mp[7] != 123.0f) return;
+#endif
+    if (!row_ok) return;
+    auto put = [&](float* base, const float (&v)[8]) {
+#if TAC_HPSS_STORE16
+        if (sb == 1 && bq + 7 < NB) {
+            hp_f4u lo4, hi4;
+            lo4.x = v[0]; lo4.y = v[1]; lo4.z = v[2]; lo4.w = v[3];
+            hi4.x = v[4]; hi4.y = v[5]; hi4.z = v[6]; hi4.w = v[7];
+#if TAC_HPSS_NT
+            __builtin_nontemporal_store(lo4, reinterpret_cast<hp_f4u*>(base + o));
+            __builtin_nontemporal_store(hi4, reinterpret_cast<hp_f4u*>(base + o + 4));
+#else
+            *reinterpret_cast<hp_f4u*>(base + o) = lo4;
+            *reinterpret_cast<hp_f4u*>(base + o + 4) = hi4;
+#endif
+            return;
+        }
+#endif
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (bq + j < NB) base[o + (long long)j * sb] = v[j];
+    };
+    put(mh_o, mh);
+    put(mp_o, mp);
+    if (harm_o) {
+        float hv[8], pv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            hv[j] = centre[j] * mh[j];
+            pv[j] = centre[j] * mp[j];
+        }
+        put(harm_o, hv);
+        put(perc_o, pv);
+    }
+}
+
+// K + 7 taps of one tile row starting at column `first` (any alignment), read as 16-byte chunks
+template <int K>
+__device__ __forceinline__ void hp_row_taps(const float* tile_row, int first_aligned, float (&w)[K + 7]) {
+    constexpr int OFF = (HP_LEFT - K / 2) & 3, NCH = (K + 7 + OFF + 3) / 4;
+    const hp_f4* src = reinterpret_cast<const hp_f4*>(tile_row + first_aligned);
+    float buf[4 * NCH];
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+        const hp_f4 v = src[u];
+        buf[4 * u] = v.x; buf[4 * u + 1] = v.y; buf[4 * u + 2] = v.z; buf[4 * u + 3] = v.w;
+    }
+#pragma unroll
+    for (int u = 0; u < K + 7; ++u) w[u] = buf[OFF + u];
+}
+
 template <int K>
 __global__ void __launch_bounds__(256, TAC_HPSS_OCC8)
 hpss_tile8_kernel(const float* __restrict__ x, int NA, int NB, long long sr, long long sa, long long sb, int tiles_a,
@@ -208,71 +330,19 @@ hpss_tile8_kernel(const float* __restrict__ x, int NA, int NB, long long sr, lon
     const int rem = (int)(blockIdx.x - row * per_row);
     const int a0 = (rem / tiles_b) * HP_TILE, b0 = (rem % tiles_b) * HP_TILE;
     const float* xr = x + row * sr;
-    bool seen_nan = false;
-#if TAC_HPSS_FILL16
-    if (sb == 1) {
-        constexpr int CH = HP_STRIDE / 4;                      // 24 chunks of four columns per tile row
-        for (int q = tid; q < HP_ROWS * CH; q += 256) {
-            const int r = q / CH, c4 = (q - r * CH) * 4;
-            const float* src = xr + (long long)reflect_clamped(a0 - 15 + r, NA) * sa;
-            const int b = b0 - HP_LEFT + c4;
-            hp_f4 v;
-            if (b >= 0 && b + 3 < NB) {
-                const hp_f4u u = *reinterpret_cast<const hp_f4u*>(src + b);
-                v.x = u.x; v.y = u.y; v.z = u.z; v.w = u.w;
-            } else {
-                v.x = src[reflect_clamped(b, NB)];
-                v.y = src[reflect_clamped(b + 1, NB)];
-                v.z = src[reflect_clamped(b + 2, NB)];
-                v.w = src[reflect_clamped(b + 3, NB)];
-            }
-            seen_nan |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
-            *reinterpret_cast<hp_f4*>(tile + r * HP8_STRIDE + c4) = v;
-        }
-    } else
-#endif
-    {
-        for (int i = tid; i < HP_ROWS * HP_STRIDE; i += 256) {
-            const int r = i / HP_STRIDE, c = i - r * HP_STRIDE;
-            const int a = reflect_clamped(a0 - 15 + r, NA), b = reflect_clamped(b0 - HP_LEFT + c, NB);
-            const float v = xr[(long long)a * sa + (long long)b * sb];
-            seen_nan |= v != v;
-            tile[r * HP8_STRIDE + c] = v;
-        }
-    }
+    const bool seen_nan = hp_fill<HP_STRIDE>(tile, HP8_STRIDE, xr, a0 - 15, HP_ROWS, b0 - HP_LEFT, NA, NB, sa, sb, tid);
     const int tile_has_nan = __syncthreads_or(seen_nan ? 1 : 0);
-    // a window holds a NaN <=> its median is NaN (torch.median); the min / max network alone would drop it
-    auto run8 = [&](const float (&w)[K + 7], float (&med)[8]) {
-        median_run8<K>(w, med);
-        if (tile_has_nan) {                  // (workgroup-uniform; almost never taken)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                bool bad = false;
-#pragma unroll
-                for (int u = 0; u < K; ++u) bad |= w[j + u] != w[j + u];
-                med[j] = bad ? __builtin_nanf("") : med[j];
-            }
-        }
-    };
     // ---- along B: thread (bx, ay) owns rows 2 ay, 2 ay + 1 and columns 8 bx .. 8 bx + 7 (also the store map)
     const int bx = tid & 7, ay = tid >> 3;
-    constexpr int START = HP_LEFT - HALF, OFF = START & 3, NCH = (K + 7 + OFF + 3) / 4;
+    constexpr int START = HP_LEFT - HALF, OFF = START & 3;
     float medB[2][8], centre[2][8];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const hp_f4* src = reinterpret_cast<const hp_f4*>(tile + (2 * ay + 15 + i) * HP8_STRIDE + 8 * bx + (START - OFF));
-        float buf[4 * NCH];
-#pragma unroll
-        for (int u = 0; u < NCH; ++u) {
-            const hp_f4 v = src[u];
-            buf[4 * u] = v.x; buf[4 * u + 1] = v.y; buf[4 * u + 2] = v.z; buf[4 * u + 3] = v.w;
-        }
         float w[K + 7];
-#pragma unroll
-        for (int u = 0; u < K + 7; ++u) w[u] = buf[OFF + u];
+        hp_row_taps<K>(tile + (2 * ay + 15 + i) * HP8_STRIDE, 8 * bx + (START - OFF), w);
 #pragma unroll
         for (int j = 0; j < 8; ++j) centre[i][j] = w[HALF + j];
-        run8(w, medB[i]);
+        hp_run8<K>(w, medB[i], tile_has_nan);
         __builtin_amdgcn_sched_barrier(0);
     }
 #if TAC_HPSS_AMAP1
@@ -285,7 +355,7 @@ hpss_tile8_kernel(const float* __restrict__ x, int NA, int NB, long long sr, lon
         const float* src = tile + (16 * ry + 8 * h + 15 - HALF) * HP8_STRIDE + cx + HP_LEFT;
 #pragma unroll
         for (int u = 0; u < K + 7; ++u) w0[u] = src[u * HP8_STRIDE];
-        run8(w0, medA[h]);
+        hp_run8<K>(w0, medA[h], tile_has_nan);
         __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();                         // every read of the tile is done: the A medians change maps through it
@@ -306,9 +376,9 @@ hpss_tile8_kernel(const float* __restrict__ x, int NA, int NB, long long sr, lon
             w0[u] = v.x;
             w1[u] = v.y;
         }
-        run8(w0, medA[0]);
+        hp_run8<K>(w0, medA[0], tile_has_nan);
         __builtin_amdgcn_sched_barrier(0);
-        run8(w1, medA[1]);
+        hp_run8<K>(w1, medA[1], tile_has_nan);
         __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
@@ -329,50 +399,81 @@ hpss_tile8_kernel(const float* __restrict__ x, int NA, int NB, long long sr, lon
         const hp_f4 ma0 = *reinterpret_cast<const hp_f4*>(tile + (2 * ay + i) * HP8_EX + 8 * bx);
         const hp_f4 ma1 = *reinterpret_cast<const hp_f4*>(tile + (2 * ay + i) * HP8_EX + 8 * bx + 4);
         const float m_a[8] = {ma0.x, ma0.y, ma0.z, ma0.w, ma1.x, ma1.y, ma1.z, ma1.w};
-        float mh[8], mp[8];
+        hp_emit8(a < NA, bq, NB, row * sr + (long long)a * sa + (long long)bq * sb, sb, m_a, medB[i], centre[i], b_is_time,
+                 power, hard, harm_o, perc_o, mh_o, mp_o);
+    }
+}
+
+// Unequal (or small) widths, round 4: two launches over the same 64 x 64 output tiles, each with a halo along ONE axis.
+// hpss_axis_a_kernel<KA>: medians along A (the slow memory axis) into `tmp` — the caller's mask_perc buffer, no workspace.
+// hpss_axis_b_kernel<KB>: medians along B, the A medians read back from `tmp` (a thread reads exactly the sixteen elements it
+// then overwrites), masks and the four results.  (Round 3's one-thread-per-element kernel issued 64 dword loads per output and
+// ran at 7 % of the HBM peak; hpss_kernel below is kept as the A/B baseline and for non-unit fast strides.)
+template <int K>
+__global__ void __launch_bounds__(256)
+hpss_axis_a_kernel(const float* __restrict__ x, int NA, int NB, long long sr, long long sa, long long sb, int tiles_a,
+                   int tiles_b, float* __restrict__ tmp) {
+    constexpr int HALF = K / 2, ROWS = HP_TILE + K - 1;
+    __shared__ __attribute__((aligned(16))) float tile[ROWS * HP_TILE];
+    const int tid = threadIdx.x;
+    const int per_row = tiles_a * tiles_b;
+    const long long row = blockIdx.x / per_row;
+    const int rem = (int)(blockIdx.x - row * per_row);
+    const int a0 = (rem / tiles_b) * HP_TILE, b0 = (rem % tiles_b) * HP_TILE;
+    const bool seen_nan = hp_fill<HP_TILE>(tile, HP_TILE, x + row * sr, a0 - HALF, ROWS, b0, NA, NB, sa, sb, tid);
+    const int tile_has_nan = __syncthreads_or(seen_nan ? 1 : 0);
+    const int cx = tid & 63, ry = tid >> 6;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float harm = b_is_time ? medB[i][j] : m_a[j];
-            const float perc = b_is_time ? m_a[j] : medB[i][j];
-            hpss_masks(harm, perc, power, hard, mh[j], mp[j]);
+    for (int h = 0; h < 2; ++h) {
+        float w0[K + 7], med[8];
+        const float* src = tile + (16 * ry + 8 * h) * HP_TILE + cx;
+#pragma unroll
+        for (int u = 0; u < K + 7; ++u) w0[u] = src[u * HP_TILE];          // (row 16 ry + 8 h + u <= 62 + K = ROWS - 1)
+        hp_run8<K>(w0, med, tile_has_nan);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int a = a0 + 16 * ry + 8 * h + i, b = b0 + cx;
+            if (a < NA && b < NB) tmp[row * sr + (long long)a * sa + (long long)b * sb] = med[i];
         }
-#ifdef TAC_HPSS_ABL_NOSTORE
-        if (mh[0] + mp[7] != 123.0f) continue;
-#endif
-        if (a >= NA) continue;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int K>
+__global__ void __launch_bounds__(256)
+hpss_axis_b_kernel(const float* __restrict__ x, int NA, int NB, long long sr, long long sa, long long sb, int tiles_a,
+                   int tiles_b, int b_is_time, float power, int hard, float* harm_o, float* perc_o, float* mh_o,
+                   float* mp_o /* holds the A medians on entry */) {
+    constexpr int HALF = K / 2;
+    __shared__ __attribute__((aligned(16))) float tile[HP_TILE * HP_STRIDE];
+    const int tid = threadIdx.x;
+    const int per_row = tiles_a * tiles_b;
+    const long long row = blockIdx.x / per_row;
+    const int rem = (int)(blockIdx.x - row * per_row);
+    const int a0 = (rem / tiles_b) * HP_TILE, b0 = (rem % tiles_b) * HP_TILE;
+    const bool seen_nan = hp_fill<HP_STRIDE>(tile, HP_STRIDE, x + row * sr, a0, HP_TILE, b0 - HP_LEFT, NA, NB, sa, sb, tid);
+    const int tile_has_nan = __syncthreads_or(seen_nan ? 1 : 0);
+    const int bx = tid & 7, ay = tid >> 3;
+    constexpr int START = HP_LEFT - HALF, OFF = START & 3;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float w[K + 7], medB[8], centre[8], m_a[8];
+        hp_row_taps<K>(tile + (2 * ay + i) * HP_STRIDE, 8 * bx + (START - OFF), w);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) centre[j] = w[HALF + j];
+        hp_run8<K>(w, medB, tile_has_nan);
+        const int a = a0 + 2 * ay + i, bq = b0 + 8 * bx;
         const long long o = row * sr + (long long)a * sa + (long long)bq * sb;
-        auto put = [&](float* base, const float (&v)[8]) {
-#if TAC_HPSS_STORE16
-            if (sb == 1 && bq + 7 < NB) {
-                hp_f4u lo4, hi4;
-                lo4.x = v[0]; lo4.y = v[1]; lo4.z = v[2]; lo4.w = v[3];
-                hi4.x = v[4]; hi4.y = v[5]; hi4.z = v[6]; hi4.w = v[7];
-#if TAC_HPSS_NT
-                __builtin_nontemporal_store(lo4, reinterpret_cast<hp_f4u*>(base + o));
-                __builtin_nontemporal_store(hi4, reinterpret_cast<hp_f4u*>(base + o + 4));
-#else
-                *reinterpret_cast<hp_f4u*>(base + o) = lo4;
-                *reinterpret_cast<hp_f4u*>(base + o + 4) = hi4;
-#endif
-                return;
-            }
-#endif
+        if (a < NA && sb == 1 && bq + 7 < NB) {
+            const hp_f4u lo4 = *reinterpret_cast<const hp_f4u*>(mp_o + o), hi4 = *reinterpret_cast<const hp_f4u*>(mp_o + o + 4);
+            m_a[0] = lo4.x; m_a[1] = lo4.y; m_a[2] = lo4.z; m_a[3] = lo4.w;
+            m_a[4] = hi4.x; m_a[5] = hi4.y; m_a[6] = hi4.z; m_a[7] = hi4.w;
+        } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (bq + j < NB) base[o + (long long)j * sb] = v[j];
-        };
-        put(mh_o, mh);
-        put(mp_o, mp);
-        if (harm_o) {
-            float hv[8], pv[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                hv[j] = centre[i][j] * mh[j];
-                pv[j] = centre[i][j] * mp[j];
-            }
-            put(harm_o, hv);
-            put(perc_o, pv);
+            for (int j = 0; j < 8; ++j) m_a[j] = (a < NA && bq + j < NB) ? mp_o[o + (long long)j * sb] : 0.0f;
         }
+        hp_emit8(a < NA, bq, NB, o, sb, m_a, medB, centre, b_is_time, power, hard, harm_o, perc_o, mh_o, mp_o);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -471,6 +572,36 @@ int tac_hpss_f32(const float* mag, int64_t rows, int32_t n_freqs, int32_t n_fram
         TAC_HIP(hipGetLastError());
         return TAC_OK;
     }
+#if TAC_HPSS_TWO_PASS
+    if (tiles < 0x7fffffffLL) {
+        const bool t_fast = stride_t <= stride_f;
+        const int NA = t_fast ? n_freqs : n_frames, NB = t_fast ? n_frames : n_freqs;
+        const long long sa = t_fast ? stride_f : stride_t, sb = t_fast ? stride_t : stride_f;
+        const int ka = t_fast ? kernel_f : kernel_t, kb = t_fast ? kernel_t : kernel_f;
+        const int ta = (NA + HP_TILE - 1) / HP_TILE, tb = (NB + HP_TILE - 1) / HP_TILE;
+        const dim3 grid((unsigned)tiles);
+#define TAC_HPSS_ODD(M) M(1) M(3) M(5) M(7) M(9) M(11) M(13) M(15) M(17) M(19) M(21) M(23) M(25) M(27) M(29) M(31)
+#define TAC_HPSS_A(K)                                                                                                     \
+    case K:                                                                                                               \
+        hipLaunchKernelGGL(hpss_axis_a_kernel<K>, grid, dim3(256), 0, (hipStream_t)stream, mag, NA, NB,                   \
+                           (long long)stride_r, sa, sb, ta, tb, mask_perc);                                               \
+        break;
+#define TAC_HPSS_B(K)                                                                                                     \
+    case K:                                                                                                               \
+        hipLaunchKernelGGL(hpss_axis_b_kernel<K>, grid, dim3(256), 0, (hipStream_t)stream, mag, NA, NB,                   \
+                           (long long)stride_r, sa, sb, ta, tb, t_fast ? 1 : 0, power, hard, harm, perc, mask_harm,       \
+                           mask_perc);                                                                                    \
+        break;
+        switch (ka) { TAC_HPSS_ODD(TAC_HPSS_A) }
+        TAC_HIP(hipGetLastError());
+        switch (kb) { TAC_HPSS_ODD(TAC_HPSS_B) }
+#undef TAC_HPSS_A
+#undef TAC_HPSS_B
+#undef TAC_HPSS_ODD
+        TAC_HIP(hipGetLastError());
+        return TAC_OK;
+    }
+#endif
     const long long total = rows * (long long)n_freqs * n_frames;
     long long blocks = (total + 255) / 256;
     const long long cap = (long long)device_cu_count() * 16;

@@ -116,3 +116,21 @@ TAC_HD void median_run8(const float (&w)[K + 7], float (&med)[8]) {
         }
     }
 }
+
+// any odd K >= 1: the shared-sort form from 9 up, below that a sort of its own per window (at most 16 comparators)
+template <int K>
+TAC_HD void median_run8_any(const float (&w)[K + 7], float (&med)[8]) {
+    static_assert(K >= 1 && (K & 1), "odd widths only");
+    if constexpr (K >= 9) {
+        median_run8<K>(w, med);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v[K];
+#pragma unroll
+            for (int u = 0; u < K; ++u) v[u] = w[j + u];
+            sort_net<K>(v);
+            med[j] = v[K / 2];
+        }
+    }
+}

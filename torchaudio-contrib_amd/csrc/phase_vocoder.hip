@@ -16,10 +16,11 @@ constexpr int PV_THREADS = 256;
 #define TAC_PV_FIXED 1         // float32: running phase as a 32-bit fraction of a turn (0: round 3's float64 running sum)
 #endif
 #ifndef TAC_PV_AHEAD
-#define TAC_PV_AHEAD 8         // steps whose frames are in flight (round 3: 4)
+#define TAC_PV_AHEAD 4         // steps whose frames are in flight (8: no gain; 12 / 16: the register set spills, +60 %)
 #endif
 #ifndef TAC_PV_PREFETCH0
-#define TAC_PV_PREFETCH0 1     // a step's FIRST frame, when it is not the previous step's second, is requested ahead as well
+#define TAC_PV_PREFETCH0 0     // 1: a step's FIRST frame, when it is not the previous step's second, is requested ahead as well
+                               //    (-1 % at rate 1.3, +1 ... +4 % at rate 2: tools/ablation/README.md)
 #endif
 
 // Precision.  The reference evaluates the recurrence in the dtype of its input, and in float32 that is
@@ -167,8 +168,8 @@ phase_vocoder_kernel(const T* __restrict__ spec, long long rows, int n_freqs, in
     // The loop is a chain of dependent steps, and a step's only long latency is the load of its frames: left in the
     // step it made every one of the n_out steps one HBM round trip long (0.336 ms at cfg-2, whatever the occupancy).
     // The frames of the next AHEAD steps are therefore always in flight (their indices come from the grid, not from the
-    // recurrence), in a rotating set of registers: the second frame always, the first one when it is not the previous
-    // step's second (rate > 1: round 3 loaded those inside the step).
+    // recurrence), in a rotating set of registers: the second frame always; the first one, when it is not the previous
+    // step's second (rate > 1), is loaded inside the step unless TAC_PV_PREFETCH0 is set.
     constexpr int AHEAD = sizeof(T) == 8 ? 4 : TAC_PV_AHEAD;        // (float64: 16-byte pairs, round 3's depth)
     T2 ahead1[AHEAD], ahead0[AHEAD];
     auto request = [&](int i, T2& v0, T2& v1) {  // frames of step i (clamped to the last step)
