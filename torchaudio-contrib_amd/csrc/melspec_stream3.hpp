@@ -18,6 +18,9 @@ constexpr int S3_WAVES = 12;          // what ships
 constexpr int S3_PIECES_MARK = -77;   // info_host[7] of a piece-layout pack (== TAC_PIECES_MARK, include/tac_amd.h)
 constexpr int S3_WAVES_F32 = 15;      // A/B form (TAC_S3_WAVES=15): as many 128-register waves as the LDS holds next to a 128-band bank
 
+#ifndef TAC_S3_ABL_MFMA_X
+#define TAC_S3_ABL_MFMA_X 0   // timing-only ablation (wrong results): first exchange as MFMA transposes (see the frame loop)
+#endif
 #ifndef TAC_S3_SWZ
 #define TAC_S3_SWZ 1          // first exchange XOR-swizzled instead of padded, partner exchange dense (no bank conflicts on either): complex rows
                               // -1.05 %, power rows -1.3 %, fused kernel -0.2 % (same-process A/B, bit-identical results); 0 = the padded layout
@@ -606,6 +609,26 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
 #if !TAC_S3_NOFENCE0
         wave_lds_fence();
 #endif
+#if TAC_S3_ABL_MFMA_X
+        // timing-only ablation (WRONG RESULTS): the first exchange through the matrix pipe instead of the LDS — sixteen
+        // v_mfma_f32_16x16x1_4b_f32 per real matrix with a one-hot B operand copy A's rows into D's columns (x * 1 + 0): a 16 x 16
+        // transpose across lanes whose rows come out split over the four lane groups, which the rest of the transform is not
+        // written for; this build only measures what the LDS would gain.
+        {
+            typedef float f16v __attribute__((ext_vector_type(16)));
+            f16v accr = {0}, acci = {0};
+            const int l16 = t & 15;
+            float fone;                                     // 1.0 the compiler cannot hoist: the sixteen one-hot operands are
+            asm volatile("v_mov_b32 %0, 1.0" : "=v"(fone)); // re-made per frame from SGPR masks instead of living in sixteen VGPRs
+#pragma unroll
+            for (int k = 0; k < 16; ++k) accr = __builtin_amdgcn_mfma_f32_16x16x1f32(v[k].x, l16 == k ? fone : 0.0f, accr, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);                // (one chain after the other: 48 instead of 64 registers at the peak)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acci = __builtin_amdgcn_mfma_f32_16x16x1f32(v[k].y, l16 == k ? fone : 0.0f, acci, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = mkc(accr[k], acci[k]);
+        }
+#endif
         cf tw1[16];
         {
             const f4* tl = reinterpret_cast<const f4*>(twlds + (t & 15) * ST_TW_STRIDE);
@@ -616,7 +639,9 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
                 tw1[2 * u + 1] = mkc(x.z, x.w);
             }
         }
-#if TAC_S3_SWZ
+#if TAC_S3_ABL_MFMA_X
+        // (done above, ahead of the twiddle reads)
+#elif TAC_S3_SWZ
         s3_write_pass0_swz(v, swz);
         wave_lds_fence();
         s3_readback_pass1_swz(v, swz);
