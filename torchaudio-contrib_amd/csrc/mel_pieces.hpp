@@ -10,7 +10,7 @@
 // row in LDS, and lane l reads back bands l and 64 + l for the epilogue and two coalesced row stores.  (Storing from the last
 // piece's lane directly — three scattered, masked global stores — cost 4.3 % of the kernel; adding the partial sums into the
 // staging row with ds_add_f32 instead of the DPP reads cost 54 %: tools/ablation/README.md.)
-// STATUS (round 4): correct (114 GPU tests pass through it) and NOT faster — 0.1179 vs 0.1125 ms (+4.6 %) on the standard bank, although
+// STATUS (round 4): correct (the GPU suite passes through it) and NOT faster — 0.1179 vs 0.1125 ms (+4.6 %) on the standard bank, although
 // the same kernel with 12 contraction steps and no piece bookkeeping measures -5.3 %: the cross-lane sums, the staging round trip and
 // the 168 registers they need cost more than the six saved steps.  Opt-in (TAC_MEL_PIECES=1); the classic layout ships.
 // Reference: functional.py:172-184 (apply_filterbank) for the standard banks of functional.py:131-169.
