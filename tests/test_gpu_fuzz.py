@@ -267,7 +267,7 @@ def test_fuzz_float64_chain(tac):
     factor above 5) against the float64 oracle: complex STFT, |X|^p (+ dB) and the mel chain; launch counters assert the
     float64 kernels ran."""
     rng = np.random.default_rng(8000 + SEED)
-    sizes = [8, 12, 64, 100, 128, 256, 400, 480, 512, 1000, 1024, 2048, 4096, 6000, 8192, 77, 134, 331, 1202]
+    sizes = [8, 12, 64, 100, 128, 256, 400, 480, 512, 1000, 1024, 2048, 4096, 6000, 8192, 77, 134, 331, 502]    # (direct transform: <= 512, _hip64.DIRECT_MAX)
     for case in range(max(12, CASES // 2)):
         n, hop, win_length, center, pad_mode, lead, length = draw_stft_args(rng, sizes, max_rows=3, max_len_factor=5)
         hop = max(hop, n // 16)                                          # (keeps the direct-transform cases small)
@@ -292,3 +292,73 @@ def test_fuzz_float64_chain(tac):
         assert got_m.dtype == np.float64 and np.abs(got_m - want_m).max() < 1e-8, tag
         ran = {k: v - before.get(k, 0) for k, v in tac._hip.launches.items() if v != before.get(k, 0)}
         assert ran == {'tac_stft_f64': 1, 'tac_spectrogram_f64': 1, 'tac_apply_filterbank_f64': 1}, (tag, ran)
+
+
+def test_fuzz_hpss(tac):
+    """csrc/hpss.hip over random shapes, widths (equal: the fused tile kernel; unequal / small: the two-launch route), layouts
+    (contiguous (F, T), the frame-major strided view the STFT kernels return), powers and mask kinds against a numpy
+    restatement of beta_hpss.py:86-127.  Medians select existing values, so hard masks and the enhanced spectrograms behind
+    the soft masks are exact; a few NaNs are planted in some cases (torch.median: a window that holds one has a NaN median)."""
+    rng = np.random.default_rng(9000 + SEED)
+    odd = list(range(1, 32, 2))
+    for case in range(CASES):
+        rows = int(rng.integers(1, 4))
+        F, T = int(rng.integers(16, 300)), int(rng.integers(16, 300))
+        if rng.random() < 0.5:
+            kf = kt = int(rng.choice(odd[4:]))
+        else:
+            kf, kt = int(rng.choice(odd)), int(rng.choice(odd))
+        kf, kt = min(kf, 2 * ((F - 1) // 2) - 1 if F < 33 else kf), min(kt, 2 * ((T - 1) // 2) - 1 if T < 33 else kt)
+        kf, kt = max(kf, 1), max(kt, 1)
+        s = (rng.random((rows, F, T), dtype=np.float32) * rng.integers(1, 5, (rows, F, T))).astype(np.float32)
+        with_nan = rng.random() < 0.25
+        if with_nan:
+            for _ in range(int(rng.integers(1, 4))):
+                s[int(rng.integers(rows)), int(rng.integers(F)), int(rng.integers(T))] = np.nan
+        padf = np.pad(s, ((0, 0), (kf // 2, kf // 2), (0, 0)), mode='reflect')
+        padt = np.pad(s, ((0, 0), (0, 0), (kt // 2, kt // 2)), mode='reflect')
+        stf = np.stack([padf[:, i:i + F] for i in range(kf)], -1)
+        stt = np.stack([padt[..., i:i + T] for i in range(kt)], -1)
+        perc = np.sort(stf, -1)[..., kf // 2]
+        harm = np.sort(stt, -1)[..., kt // 2]
+        perc = np.where(np.isnan(stf).any(-1), np.float32(np.nan), perc)     # np.sort puts NaN last: restore torch.median's rule
+        harm = np.where(np.isnan(stt).any(-1), np.float32(np.nan), harm)
+        frame_major = bool(rng.random() < 0.5)
+        x = dev(np.ascontiguousarray(s.transpose(0, 2, 1))).transpose(1, 2) if frame_major else dev(s)
+        power = float(rng.choice([1.0, 2.0]))
+        tag = ('hpss', case, rows, F, T, kf, kt, frame_major, power, with_nan)
+        before = dict(tac._hip.launches)
+        h, p, mh, mp = tac.hpss(x, (kf, kt), power, False)
+        assert tac._hip.launches['tac_hpss_f32'] - before.get('tac_hpss_f32', 0) == 1, tag
+        hp, pp = harm.astype(np.float32) ** np.float32(power), perc.astype(np.float32) ** np.float32(power)
+        want_mh = (hp + np.float32(1e-6)) / (hp + pp + np.float32(1e-6))
+        want_mp = (pp + np.float32(1e-6)) / (hp + pp + np.float32(1e-6))
+        for got, want in ((mh, want_mh), (mp, want_mp), (h, s * want_mh), (p, s * want_mp)):
+            got = host(got)
+            assert np.array_equal(np.isnan(got), np.isnan(want)), tag
+            ok = ~np.isnan(want)
+            assert np.abs(got[ok] - want[ok]).max() <= 5e-7 * max(1.0, float(np.nanmax(s))), tag
+        hard = tac.hpss(x, (kf, kt), power, True)
+        ok = ~(np.isnan(harm) | np.isnan(perc))
+        assert np.array_equal(host(hard[2])[ok], (harm > perc)[ok]) and np.array_equal(host(hard[3])[ok], (harm < perc)[ok]), tag
+
+
+def test_fuzz_phase_vocoder(tac):
+    """csrc/phase_vocoder.hip (running phase as a 32-bit fraction of a turn) over random shapes, rates, phase advances and
+    layouts against the float64 evaluation of the reference's formula (functional.py:204-274) on the same float32 inputs."""
+    rng = np.random.default_rng(9500 + SEED)
+    for case in range(CASES):
+        lead = tuple(int(v) for v in rng.integers(1, 4, size=int(rng.integers(1, 3))))
+        F, T = int(rng.integers(3, 200)), int(rng.integers(2, 120))
+        rate = float(rng.choice([0.5, 0.7, 0.9, 1.1, 1.3, 1.5, 2.0, 2.7])) if rng.random() < 0.7 else float(rng.uniform(0.3, 3.0))
+        z = signals.audio_like(lead + (F, T, 2), seed=9600 + case + 7919 * SEED)
+        adv = torch.from_numpy((rng.uniform(0, 2000.0) * np.linspace(0, 1, F)).astype(np.float32))[..., None]
+        frame_major = bool(rng.random() < 0.5)
+        x = dev(np.ascontiguousarray(z.swapaxes(-3, -2))).transpose(-3, -2) if frame_major else dev(z)
+        tag = ('pv', case, lead, F, T, rate, frame_major)
+        want = torch_ref.phase_vocoder(torch.from_numpy(z).double(), rate, adv.double()).numpy()
+        before = dict(tac._hip.launches)
+        got = host(tac.phase_vocoder(x, rate, adv.cuda()))
+        assert tac._hip.launches['tac_phase_vocoder_f32'] - before.get('tac_phase_vocoder_f32', 0) == 1, tag
+        assert got.shape == want.shape and got.dtype == np.float32, tag
+        assert rel_err(got, want) < 2e-5, tag
