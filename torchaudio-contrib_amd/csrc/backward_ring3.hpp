@@ -86,6 +86,10 @@ melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ 
     cf v[E];
     float gq[4];
     int mode = 0;
+#ifndef TAC_BR3_NT
+#define TAC_BR3_NT 3           // 1 = nontemporal stores of the finished gradient samples, 2 = nontemporal loads of the mel-gradient row, 3 = both
+                               // (neither is read again: -0.3 / -0.4 / -0.8 % against plain accesses, same process, bit-identical)
+#endif
     auto request = [&](int r, int fr) {                     // samples + mel-gradient row of (row r, frame fr), unconditionally
         if constexpr (FUSE) {
             const float* gn = gmel + ((long long)r * T + fr) * fz.n_mels;
@@ -96,7 +100,11 @@ melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ 
                 gq[i] = 1e-3f * (float)b;
                 (void)gn;
 #else
+#if TAC_BR3_NT & 2
+                gq[i] = __builtin_nontemporal_load(gn + (b < fz.n_mels ? b : fz.n_mels - 1));
+#else
                 gq[i] = gn[b < fz.n_mels ? b : fz.n_mels - 1];
+#endif
 #endif
             }
         }
@@ -330,7 +338,13 @@ melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ 
             if (acc[0].x == 123.456f)                                         // (never true: the stores are compiled in but not executed)
 #endif
 #pragma unroll
-            for (int j = 0; j < H; ++j) *reinterpret_cast<cf*>(drow + 2 * (t + j * 64)) = acc[j];    // complete
+            for (int j = 0; j < H; ++j) {                                     // complete
+#if TAC_BR3_NT & 1
+                __builtin_nontemporal_store(acc[j], reinterpret_cast<cf*>(drow + 2 * (t + j * 64)));
+#else
+                *reinterpret_cast<cf*>(drow + 2 * (t + j * 64)) = acc[j];
+#endif
+            }
             if (last) {                                                       // the segment's open positions
 #pragma unroll
                 for (int j = H; j < E; ++j) *reinterpret_cast<cf*>(tail + 2 * (t + j * 64)) = acc[j];
