@@ -19,6 +19,20 @@ namespace tac {
 
 constexpr int BR_WAVES = 12;
 
+#ifndef TAC_BR3_NT
+#define TAC_BR3_NT 7           // nontemporal hints on what this launch touches once: 1 = stores of the finished gradient samples, 2 = loads of
+#endif                         // the gradient rows, 4 = loads of a frame's OLDEST hop (no later frame reads it).  L2-miss traffic of the
+                               // kernel at cfg-2 (rocprofv3 FETCH_SIZE + WRITE_SIZE): 631 -> 517 (3) -> 448 MB (7), 369 MB compulsory; time
+                               // -0.8 % (3), -1.1 % (7), bit-identical (tools/ablation/README.md)
+template <class T>
+__device__ __forceinline__ T br3_load_once(const T* p) {
+#if TAC_BR3_NT & 2
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
 template <int NC, int E>
 __host__ __device__ inline size_t ring3_lds_bytes(int mel_stride) {
     using F = WaveFft<NC, E>;
@@ -86,10 +100,6 @@ melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ 
     cf v[E];
     float gq[4];
     int mode = 0;
-#ifndef TAC_BR3_NT
-#define TAC_BR3_NT 3           // 1 = nontemporal stores of the finished gradient samples, 2 = nontemporal loads of the mel-gradient row, 3 = both
-                               // (neither is read again: -0.3 / -0.4 / -0.8 % against plain accesses, same process, bit-identical)
-#endif
     auto request = [&](int r, int fr) {                     // samples + mel-gradient row of (row r, frame fr), unconditionally
         if constexpr (FUSE) {
             const float* gn = gmel + ((long long)r * T + fr) * fz.n_mels;
@@ -100,11 +110,7 @@ melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ 
                 gq[i] = 1e-3f * (float)b;
                 (void)gn;
 #else
-#if TAC_BR3_NT & 2
-                gq[i] = __builtin_nontemporal_load(gn + (b < fz.n_mels ? b : fz.n_mels - 1));
-#else
-                gq[i] = gn[b < fz.n_mels ? b : fz.n_mels - 1];
-#endif
+                gq[i] = br3_load_once(gn + (b < fz.n_mels ? b : fz.n_mels - 1));
 #endif
             }
         }
@@ -123,7 +129,14 @@ melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ 
         (void)src;
 #else
 #pragma unroll
-        for (int q = 0; q < E; ++q) v[q] = src[t + q * F::LPF];
+        for (int q = 0; q < E; ++q) {
+#if TAC_BR3_NT & 4
+            if (q < H) v[q] = __builtin_nontemporal_load(src + t + q * F::LPF);      // the frame's oldest hop: no later frame reads it
+            else v[q] = src[t + q * F::LPF];
+#else
+            v[q] = src[t + q * F::LPF];
+#endif
+        }
 #endif
     };
     auto load_tw1 = [&](cf (&tw1)[16]) {
@@ -184,10 +197,10 @@ melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ 
             const float* gn = gmel + ((long long)row * T + f) * NBINS;
 #pragma unroll
             for (int p = 0; p < F::NPAIR; ++p) {
-                gk[p] = gn[t + p * F::LPF];
-                gm[p] = gn[NC - (t + p * F::LPF)];
+                gk[p] = br3_load_once(gn + t + p * F::LPF);
+                gm[p] = br3_load_once(gn + NC - (t + p * F::LPF));
             }
-            gmid_reg = gn[NC / 2];
+            gmid_reg = br3_load_once(gn + NC / 2);
         }
         // ---- forward transform of the frame
         if (mode != 1) {                                    // frames touching the padding gather their samples first

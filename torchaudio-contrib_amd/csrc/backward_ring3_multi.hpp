@@ -111,7 +111,14 @@ melspec_backward_ring3_multi_kernel(FrameGeom g, Tables tb, const float* __restr
         cs = cs + N <= g.length ? cs : g.length - N;
         const cf* src = reinterpret_cast<const cf*>(g.wave + (long long)r * g.row_stride + cs);
 #pragma unroll
-        for (int q = 0; q < E; ++q) v[q] = src[t + q * LPF];
+        for (int q = 0; q < E; ++q) {
+#if TAC_BR3_NT & 4
+            if (q < H) v[q] = __builtin_nontemporal_load(src + t + q * LPF);      // the frame's oldest hop: no later frame reads it
+            else v[q] = src[t + q * LPF];
+#else
+            v[q] = src[t + q * LPF];
+#endif
+        }
     };
 
     for (long long gi = (long long)blockIdx.x * WAVES + w; gi < ngroups; gi += (long long)gridDim.x * WAVES) {
@@ -142,7 +149,7 @@ melspec_backward_ring3_multi_kernel(FrameGeom g, Tables tb, const float* __restr
 #pragma unroll
                 for (int q = 0; q < MELQ; ++q) {
                     const int b = t + LPF * q;
-                    gq[q] = gn[b < fz.n_mels ? b : fz.n_mels - 1];
+                    gq[q] = br3_load_once(gn + (b < fz.n_mels ? b : fz.n_mels - 1));
                 }
             }
             float gk[F::NPAIR], gm[F::NPAIR], gmid_reg = 0.0f;
@@ -150,10 +157,10 @@ melspec_backward_ring3_multi_kernel(FrameGeom g, Tables tb, const float* __restr
                 const float* gn = gmel + ((long long)row * T + f) * NBINS;
 #pragma unroll
                 for (int p = 0; p < F::NPAIR; ++p) {
-                    gk[p] = gn[t + p * LPF];
-                    gm[p] = gn[NC - (t + p * LPF)];
+                    gk[p] = br3_load_once(gn + t + p * LPF);
+                    gm[p] = br3_load_once(gn + NC - (t + p * LPF));
                 }
-                gmid_reg = gn[NC / 2];
+                gmid_reg = br3_load_once(gn + NC / 2);
             }
             // ---- forward transform of the group's frames
             if (!fast) {
@@ -283,7 +290,13 @@ melspec_backward_ring3_multi_kernel(FrameGeom g, Tables tb, const float* __restr
                 for (int j = 0; j < R; ++j) acc[j] = cadd(acc[j], ring[j]);
                 if (live) {
 #pragma unroll
-                    for (int j = 0; j < H; ++j) *reinterpret_cast<cf*>(drow + 2 * (t + j * LPF)) = acc[j];    // complete
+                    for (int j = 0; j < H; ++j) {                                 // complete
+#if TAC_BR3_NT & 1
+                        __builtin_nontemporal_store(acc[j], reinterpret_cast<cf*>(drow + 2 * (t + j * LPF)));
+#else
+                        *reinterpret_cast<cf*>(drow + 2 * (t + j * LPF)) = acc[j];
+#endif
+                    }
                     if (last) {                                                   // the segment's open positions
 #pragma unroll
                         for (int j = H; j < E; ++j) *reinterpret_cast<cf*>(tail + 2 * (t + j * LPF)) = acc[j];
