@@ -1,6 +1,7 @@
 // pv_pattern.hip — the phase vocoder's ACCESS PATTERN with no arithmetic: 256 x 1025 series, 313 input frames -> 241 output
 // frames (rate 1.3); a lane walks the time axis of BINS consecutive bins (8 x BINS bytes per access), a wave's accesses are one
-// contiguous piece of a frame-major row (8 200-byte rows), DEPTH input frames in flight.  Is the kernel's floor (0.24 ms, 4.8 TB/s)
+// contiguous piece of a frame-major row (8 200-byte rows), DEPTH input frames in flight; one input frame is read per output step (the
+// kernel reads 313 frames for 241 steps at rate 1.3: its own arithmetic-free form is -DTAC_PV_ABL_COPY).  Is the kernel's floor
 // a property of 512-byte pieces (one bin per lane), i.e. would wider lanes move it?
 //   hipcc --offload-arch=gfx950 -O3 tools/ubench/pv_pattern.hip -o tools/ubench/build/pv_pattern
 #include <hip/hip_runtime.h>
@@ -64,7 +65,7 @@ static void run(const char* name, const float* in, float* out, const int* idx1, 
         ms.push_back(t);
     }
     std::sort(ms.begin(), ms.end());
-    const double bytes = (double)rows * F * 8.0 * (T + n_out);
+    const double bytes = (double)rows * F * 8.0 * (n_out + n_out);    // n_out frames read (the second frame of every step), n_out written
     printf("%-34s median %.4f ms   %.2f TB/s of %.0f MB\n", name, ms[30], bytes / ms[30] / 1e9, bytes / 1e6);
 }
 

@@ -12,6 +12,9 @@
 namespace tac {
 
 constexpr int PV_THREADS = 256;
+#ifndef TAC_PV_PHASOR
+#define TAC_PV_PHASOR 1        // float32: the running phase as a unit PHASOR advanced by complex products (no arctangent, sine or cosine)
+#endif
 #ifndef TAC_PV_FIXED
 #define TAC_PV_FIXED 1         // float32: running phase as a 32-bit fraction of a turn (0: round 3's float64 running sum)
 #endif
@@ -29,16 +32,54 @@ constexpr int PV_THREADS = 256;
 // radians: spacing 5e-4), which is why the reference's own test runs it in float64 (tests/test_functional.py:85-88).
 // Only the running sum MODULO one turn reaches the output (it goes through cos / sin, functional.py:268-272), and modulo
 // one turn the reference's step `wrap(a1 - a0 - pa) + pa` (functional.py:258-264) is `a1 - a0`: the wrap subtracts whole
-// turns and the phase advance cancels.  The float32 kernel therefore keeps angles as signed 32-bit fractions of a turn
-// (2^-32 turn = 1.5e-9 rad) and the running sum as their wrapping integer sum — exact, whatever the number of steps and
-// the size of the phase advance —, which agrees with the float64 evaluation of the reference's formula to the accuracy
-// of the arctangents (1e-7 rad each).  A phase advance that is not finite poisons every step after the first, as the
-// reference's cumulative sum does.  T = double is the reference's float64 formula as is.
+// turns and the phase advance cancels.  The float32 kernel therefore never forms the ill-conditioned sum: it carries
+// exp(i phase) as a unit phasor (TAC_PV_PHASOR, shipped) or, with -DTAC_PV_PHASOR=0, angles as 32-bit fractions of a turn and
+// their wrapping integer sum; either agrees with the float64 evaluation of the reference's formula to ~1e-6 rad, whatever
+// the number of steps and the size of the phase advance.  A phase advance that is not finite poisons every step after the
+// first, as the reference's cumulative sum does.  T = double is the reference's float64 formula as is.
 template <class T>
 struct pv_math;
 template <>
 struct pv_math<float> {
-#if TAC_PV_FIXED
+#if TAC_PV_PHASOR
+    // exp(i acc) itself is carried: exp(i (acc + a1 - a0)) = exp(i acc) * u1 * conj(u0) with u = z / |z| — four products per
+    // factor, one v_rsq_f32 per input frame, and a first-order renormalisation of the running phasor (|u|^2 is within 1e-6 of
+    // 1: u *= 1.5 - 0.5 |u|^2) instead of atan2 (25 instructions), v_sin and v_cos.  Rounding: ~1e-7 rad per step, unbiased
+    // (1.5e-6 rad after 241 steps; the arctangent form: 1e-7 per angle).  z = 0 has phase 0 like atan2(0, 0); components are
+    // rescaled by 2^+-90 before squaring when their larger one is outside [2^-60, 2^60], so |z|^2 neither underflows nor overflows.
+    typedef float ang_t __attribute__((ext_vector_type(2)));        // unit phasor
+    typedef ang_t acc_t;
+    static __device__ __forceinline__ void polar(float re, float im, ang_t& u, float& n) {
+        const float m = fmaxf(fabsf(re), fabsf(im));
+        const bool tiny = m < 8.673617379884035e-19f, huge = m > 1.152921504606847e18f;          // 2^-60, 2^60
+        const float up = tiny ? 1.2379400392853803e27f : (huge ? 8.077935669463161e-28f : 1.0f);  // 2^90, 2^-90
+        const float dn = tiny ? 8.077935669463161e-28f : (huge ? 1.2379400392853803e27f : 1.0f);
+        const float x = re * up, y = im * up;
+        const float n2 = fmaf(x, x, y * y);
+        const float r = __builtin_amdgcn_rsqf(n2);
+        const bool zero = !(n2 > 0.0f) && n2 == n2;                // (+0: the reference's atan2(0, 0) = 0; NaN stays NaN)
+        u.x = zero ? 1.0f : x * r;
+        u.y = zero ? 0.0f : y * r;
+        n = zero ? 0.0f : (n2 * r) * dn;
+    }
+    static __device__ __forceinline__ acc_t open(ang_t a) { return a; }
+    static __device__ __forceinline__ acc_t step(acc_t acc, ang_t a1, ang_t a0, float) {
+        ang_t w, v;
+        w.x = fmaf(a1.x, a0.x, a1.y * a0.y);                        // a1 * conj(a0)
+        w.y = fmaf(a1.y, a0.x, -(a1.x * a0.y));
+        v.x = fmaf(acc.x, w.x, -(acc.y * w.y));
+        v.y = fmaf(acc.x, w.y, acc.y * w.x);
+        const float g = fmaf(-0.5f, fmaf(v.x, v.x, v.y * v.y), 1.5f);
+        v.x *= g;
+        v.y *= g;
+        return v;
+    }
+    static __device__ __forceinline__ float poison(float pa) { return pa - pa; }     // 0, or NaN for a non-finite advance
+    static __device__ __forceinline__ void sincos(acc_t acc, float bias, float* s, float* c) {
+        *c = acc.x + bias;
+        *s = acc.y + bias;
+    }
+#elif TAC_PV_FIXED
     typedef unsigned ang_t;                                         // fraction of a turn, scaled by 2^32 (wrapping)
     typedef unsigned acc_t;
     // atan2 in TURNS without the library's special-case ladder: octant reduction to a = min / max in [0, 1],
@@ -65,6 +106,10 @@ struct pv_math<float> {
         // exact scaling by 2^32 ([0, 2^31] fits an unsigned); NaN converts to 0 (the magnitude carries it)
         const unsigned u = (unsigned)(r * 4294967296.0f);
         return __builtin_signbit(y) ? 0u - u : u;
+    }
+    static __device__ __forceinline__ void polar(float re, float im, ang_t& a, float& n) {
+        a = angle(im, re);
+        n = sqrtf(re * re + im * im);
     }
     static __device__ __forceinline__ acc_t open(ang_t a) { return a; }
     static __device__ __forceinline__ acc_t step(acc_t acc, ang_t a1, ang_t a0, float) {
@@ -99,6 +144,10 @@ struct pv_math<float> {
         r = x < 0.0f ? 3.141592653589793f - r : r;
         return copysignf(r, y);
     }
+    static __device__ __forceinline__ void polar(float re, float im, ang_t& a, float& n) {
+        a = angle(im, re);
+        n = sqrtf(re * re + im * im);
+    }
     static __device__ __forceinline__ acc_t open(ang_t a) { return (double)a; }
     static __device__ __forceinline__ acc_t step(acc_t acc, ang_t a1, ang_t a0, float pa) {
         double ph = (double)a1 - (double)a0 - (double)pa;
@@ -113,14 +162,15 @@ struct pv_math<float> {
         *c = __builtin_amdgcn_cosf(fr);
     }
 #endif
-    static __device__ __forceinline__ float hypot(float x, float y) { return sqrtf(x * x + y * y); }
 };
 template <>
 struct pv_math<double> {
     typedef double ang_t;
     typedef double acc_t;
-    static __device__ __forceinline__ double angle(double y, double x) { return ::atan2(y, x); }
-    static __device__ __forceinline__ double hypot(double x, double y) { return sqrt(x * x + y * y); }
+    static __device__ __forceinline__ void polar(double re, double im, ang_t& a, double& n) {
+        a = ::atan2(im, re);
+        n = sqrt(re * re + im * im);
+    }
     static __device__ __forceinline__ acc_t open(ang_t a) { return a; }
     static __device__ __forceinline__ acc_t step(acc_t acc, ang_t a1, ang_t a0, double pa) {
         double ph = a1 - a0 - pa;
@@ -156,14 +206,17 @@ phase_vocoder_kernel(const T* __restrict__ spec, long long rows, int n_freqs, in
     };
     const T pa = phase_advance[f];
     const T2 first = frame(0);
-    typename M::acc_t acc = M::open(M::angle(first.y, first.x));    // phase of the first input frame opens the running sum
+    typename M::ang_t ang_first;
+    T n_first;
+    M::polar(first.x, first.y, ang_first, n_first);
+    typename M::acc_t acc = M::open(ang_first);             // phase of the first input frame opens the running sum
     T bias = (T)0;
     T* o = out + (row * n_out * (long long)n_freqs + f) * 2;
     // The second frame of step i is the first frame of step i + 1 whenever the grid advances by one input frame (every
     // step for rate <= 1, most steps up to rate 2): its phase and magnitude are kept instead of being loaded and
     // evaluated again (the grid is wave-uniform, so is the branch; the values are the ones that would be recomputed).
     int t_kept = -1;
-    typename M::ang_t ang_kept = 0;
+    typename M::ang_t ang_kept = ang_first;
     T n_kept = (T)0;
     // The loop is a chain of dependent steps, and a step's only long latency is the load of its frames: left in the
     // step it made every one of the n_out steps one HBM round trip long (0.336 ms at cfg-2, whatever the occupancy).
@@ -214,11 +267,11 @@ phase_vocoder_kernel(const T* __restrict__ spec, long long rows, int n_freqs, in
 #if !TAC_PV_PREFETCH0
                 cur0 = frame(t0);
 #endif
-                ang0 = M::angle(cur0.y, cur0.x);
-                n0 = M::hypot(cur0.x, cur0.y);
+                M::polar(cur0.x, cur0.y, ang0, n0);
             }
-            const typename M::ang_t ang1 = M::angle(cur1.y, cur1.x);
-            const T n1 = M::hypot(cur1.x, cur1.y);
+            typename M::ang_t ang1;
+            T n1;
+            M::polar(cur1.x, cur1.y, ang1, n1);
             t_kept = t1;
             ang_kept = ang1;
             n_kept = n1;
