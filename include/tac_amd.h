@@ -191,9 +191,10 @@ int tac_phase_vocoder_f32(const float* spec, int64_t rows, int32_t n_freqs, int6
                           int64_t stride_r, int64_t stride_f, int64_t stride_t,
                           const float* phase_advance, const int32_t* idx0, const int32_t* idx1,
                           const float* alpha, int64_t n_out, float* out, void* stream);
-/*      The phase increment and its running sum are carried in float64 inside both kernels (the float32 recurrence is
- *      ill-conditioned, which is why the reference's own test runs in float64, tests/test_functional.py:69-116);
- *      the _f64 entry point is that float64 call site itself: same arguments with double data (strides in doubles). */
+/*      The float32 recurrence as written is ill-conditioned (which is why the reference's own test runs in float64,
+ *      tests/test_functional.py:69-116); the _f32 kernel carries exp(i phase) as a unit phasor instead of the running sum (only
+ *      the sum modulo one turn reaches the output) and agrees with the float64 evaluation to ~1e-6 rad; the _f64 entry point
+ *      is that float64 call site itself: same arguments with double data (strides in doubles), the formula as written. */
 int tac_phase_vocoder_f64(const double* spec, int64_t rows, int32_t n_freqs, int64_t n_frames,
                           int64_t stride_r, int64_t stride_f, int64_t stride_t,
                           const double* phase_advance, const int32_t* idx0, const int32_t* idx1,

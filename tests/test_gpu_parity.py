@@ -599,8 +599,9 @@ def test_g7_phase_vocoder_and_time_stretch(tac, golden):
         want = g['pv_rate%g' % rate]
         assert tuple(got.shape) == want.shape
         got = host(got)
-        # (1) The kernel carries the phase increment and its running sum in float64 (csrc/phase_vocoder.hip), so it
-        # agrees with the float64 evaluation of the reference's formula on the same float32 inputs to ~1e-6 ...
+        # (1) The kernel carries exp(i phase) as a unit phasor advanced by complex products (csrc/phase_vocoder.hip: modulo one
+        # turn the reference's wrapped step is a1 - a0), so it never forms the ill-conditioned float32 sum and agrees with
+        # the float64 evaluation of the reference's formula on the same float32 inputs to ~1e-6 ...
         want64 = torch_ref.phase_vocoder(torch.from_numpy(z).double(), rate, adv.double()).numpy()
         assert rel_err(got, want64) < 1e-5, rate
         # (2) ... while the golden is the reference's FLOAT32 evaluation, whose own rounding is what separates the two
@@ -901,8 +902,8 @@ def test_dtype_and_device_routes(tac):
         assert tuple(got.shape) == (1, 2, 1025, int(math.ceil(400 / rate)), 2)
         want = torch_ref.phase_vocoder(z, rate, adv)
         assert rel_err(host(got), want.numpy()) < 1e-9              # the reference's own bar is atol 1e-5
-    # the float32 call on the same data carries its phases in float64 too: within 3e-5 of the float64 evaluation
-    # (what is left is the two float32 arctangents per step; the reference's own float32 evaluation is ~1e-3 away)
+    # the float32 call on the same data never forms the ill-conditioned sum (unit phasor products): within 3e-5 of the float64
+    # evaluation (the reference's own float32 evaluation is ~1e-3 away)
     got32 = tac.phase_vocoder(z.float().cuda(), 1.3, adv.float().cuda())
     want64 = torch_ref.phase_vocoder(z.float().double(), 1.3, adv.float().double())
     assert got32.dtype == torch.float32 and rel_err(host(got32), want64.numpy()) < 3e-5
