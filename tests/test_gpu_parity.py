@@ -1485,6 +1485,28 @@ def test_hpss_unequal_and_small_widths_both_layouts_and_nan(tac):
             assert np.abs(host(a)[ok] - b.numpy()[ok]).max() <= 1e-6
 
 
+def test_hpss_mask_only_skips_the_masked_spectrograms(tac):
+    """mask_only=True (beta_hpss.py:123-124) takes the `hpss_masks` op: the same kernels with NULL harm / perc pointers, i.e.
+    without the two masked-spectrogram stores; masks bit-equal to the full call, equal widths (tile kernel) and unequal
+    (two launches), soft and hard, both layouts, and through the HPSS layer."""
+    rng = np.random.default_rng(13)
+    s = rng.random((2, 130, 97), dtype=np.float32)
+    for layout in ('contiguous', 'frame-major'):
+        x = dev(s) if layout == 'contiguous' else dev(np.ascontiguousarray(s.transpose(0, 2, 1))).transpose(1, 2)
+        for ks in (31, 9, (5, 9), (3, 31)):
+            for hard in (False, True):
+                full = tac.hpss(x, ks, 2.0, hard)
+                before = launches(tac)
+                only = tac.hpss(x, ks, 2.0, hard, True)
+                assert launched_since(tac, before) == {'tac_hpss_f32': 1}
+                assert only[0] is None and only[1] is None
+                assert torch.equal(only[2], full[2]) and torch.equal(only[3], full[3]), (layout, ks, hard)
+                assert only[2].stride() == x.stride()
+    layer = tac.HPSS(17, 1.0, mask_only=True).cuda()
+    out = layer(dev(s))
+    assert out[0] is None and torch.equal(out[2], tac.hpss(dev(s), 17, 1.0)[2])
+
+
 def test_g10_melspectrogram_fft_length_4096(tac, golden):
     """Melspectrogram (-> AmplitudeToDb) at fft_length 4096 against the reference's outputs (golden g10): no fully fused
     kernel fits the LDS at this size (two 1024-point exchange areas per wave + 41 KB of weights), so the chain is TWO

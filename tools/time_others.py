@@ -47,6 +47,7 @@ cases = [
     ('mu_law_encoding (cfg-5)', lambda: tac.mu_law_encoding(xm, 256), xm.numel() * 12),
     ('mu_law_decoding (cfg-5)', lambda: tac.mu_law_decoding(codes, 256), xm.numel() * 12),
     ('hpss k=31 (frame-major |X|^2)', lambda: tac.hpss(p, 31, 2.0), p.numel() * 20),
+    ('hpss k=31, mask_only', lambda: tac.hpss(p, 31, 2.0, False, True), p.numel() * 12),
     ('hpss k=17 (frame-major |X|^2)', lambda: tac.hpss(p, 17, 2.0), p.numel() * 20),
     ('hpss k=31 (contiguous)', lambda: tac.hpss(pc, 31, 2.0), p.numel() * 20),
     ('hpss k=(5, 9) (two launches)', lambda: tac.hpss(pc, (5, 9), 2.0), p.numel() * 20),

@@ -1106,22 +1106,25 @@ def hpss_supported(kernel_f, kernel_t):
     return kernel_f % 2 == 1 and kernel_t % 2 == 1 and 1 <= kernel_f <= 32 and 1 <= kernel_t <= 32
 
 
-def hpss(mag, kernel_f, kernel_t, power, hard):
-    """(harm, perc, mask_harm, mask_perc), float32, in the (dense) layout of ``mag``  (*, F, T)."""
+def hpss(mag, kernel_f, kernel_t, power, hard, masks_only=False):
+    """(harm, perc, mask_harm, mask_perc), float32, in the (dense) layout of ``mag``  (*, F, T); with ``masks_only`` the two
+    masks alone (the kernels then skip the two masked-spectrogram stores: 40 % of the traffic)."""
     mag = mag if is_dense(mag) else mag.contiguous()
     n_freqs, n_frames = mag.shape[-2], mag.shape[-1]
     rows = mag.reshape(-1, n_freqs, n_frames)
     if rows.data_ptr() != mag.data_ptr():                          # leading dims do not collapse in this layout
         mag = mag.contiguous()
         rows = mag.reshape(-1, n_freqs, n_frames)
-    outs = [torch.empty_like(mag) for _ in range(4)]
+    outs = [torch.empty_like(mag) for _ in range(2 if masks_only else 4)]
     if mag.numel():
+        null = ctypes.c_void_p(0)
         with _native.on_device(mag.device):
             rc = _native.lib().tac_hpss_f32(_native.ptr(rows), rows.shape[0], n_freqs, n_frames,
                                             rows.stride(0) if rows.shape[0] > 1 else 0, rows.stride(1), rows.stride(2),
-                                            kernel_f, kernel_t, float(power), 1 if hard else 0, _native.ptr(outs[0]),
-                                            _native.ptr(outs[1]), _native.ptr(outs[2]), _native.ptr(outs[3]),
-                                            _native.stream_ptr(mag.device))
+                                            kernel_f, kernel_t, float(power), 1 if hard else 0,
+                                            null if masks_only else _native.ptr(outs[0]),
+                                            null if masks_only else _native.ptr(outs[1]), _native.ptr(outs[-2]),
+                                            _native.ptr(outs[-1]), _native.stream_ptr(mag.device))
         _native.check(rc, 'tac_hpss_f32')
         _count('tac_hpss_f32')
     return tuple(outs)

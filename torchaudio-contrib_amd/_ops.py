@@ -615,4 +615,19 @@ def _hpss_cuda(mag, kernel_f, kernel_t, power, hard):
 _register('hpss', '(Tensor mag, int kernel_f, int kernel_t, float power, bool hard) -> (Tensor, Tensor, Tensor, Tensor)',
           _hpss_cuda, C.hpss, lambda mag, kernel_f, kernel_t, power, hard: tuple(_like_meta(mag) for _ in range(4)), 1)
 
+def _hpss_masks_cuda(mag, kernel_f, kernel_t, power, hard):
+    reason = _hip_dtype(mag)
+    if reason is None and not H.hpss_supported(kernel_f, kernel_t):
+        reason = 'kernel_size (%d, %d)' % (kernel_f, kernel_t)
+    if reason is not None:
+        _composite_route('hpss', reason)
+        return C.hpss(mag, kernel_f, kernel_t, power, hard)[2:]
+    outs = H.hpss(_f32(mag), kernel_f, kernel_t, power, hard, masks_only=True)
+    return outs if mag.dtype == torch.float32 else tuple(o.to(mag.dtype) for o in outs)
+
+
+_register('hpss_masks', '(Tensor mag, int kernel_f, int kernel_t, float power, bool hard) -> (Tensor, Tensor)',
+          _hpss_masks_cuda, lambda mag, kernel_f, kernel_t, power, hard: C.hpss(mag, kernel_f, kernel_t, power, hard)[2:],
+          lambda mag, kernel_f, kernel_t, power, hard: tuple(_like_meta(mag) for _ in range(2)), 1)
+
 ops = getattr(torch.ops, NS)

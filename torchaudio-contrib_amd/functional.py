@@ -233,9 +233,11 @@ def hpss(mag_specgrams, kernel_size=31, power=2.0, hard=False, mask_only=False):
     if kf // 2 >= x.shape[-2] or kt // 2 >= x.shape[-1]:
         raise RuntimeError('hpss: reflect padding (%d, %d) must be smaller than the spectrogram size %s'
                            % (kf // 2, kt // 2, tuple(x.shape[-2:])))
-    harm, perc, mask_h, mask_p = _call('hpss', x, int(kf), int(kt), float(power), bool(hard))
+    if mask_only:                                         # (the kernels skip the two masked-spectrogram stores)
+        harm = perc = None
+        mask_h, mask_p = _call('hpss_masks', x, int(kf), int(kt), float(power), bool(hard))
+    else:
+        harm, perc, mask_h, mask_p = _call('hpss', x, int(kf), int(kt), float(power), bool(hard))
     if hard:
         mask_h, mask_p = mask_h > 0.5, mask_p > 0.5
-    if mask_only:
-        return None, None, mask_h, mask_p
     return harm, perc, mask_h, mask_p
