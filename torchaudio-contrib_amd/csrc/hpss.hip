@@ -302,6 +302,93 @@ __device__ __forceinline__ void hp_emit8(bool row_ok, int bq, int NB, long long 
     }
 }
 
+// The same for the thread's 2 rows x 8 columns of the B map, stored through a per-wave transpose in LDS (TAC_HPSS_COALESCE): in the B map a
+// store instruction's lanes write 16-byte pieces 32 bytes apart (the other half of each lane's eight columns goes with the next
+// instruction), which the memory pipe cannot merge — one request per lane; staged as [16 rows][64 columns] (HP8_EX floats apart) and read
+// back with lane l on row l / 16 (+ 4 k), columns 4 (l % 16) .., every store instruction writes four whole 256-byte row segments.
+// `scratch`: this wave's 16 x HP8_EX floats; a_blk: first row of the wave's 16-row block (rows 2 (ay % 8) + i of it are this thread's).
+#ifndef TAC_HPSS_COALESCE
+#define TAC_HPSS_COALESCE 1
+#endif
+constexpr int HP8_SCRATCH = 16 * 68;          // floats per wave
+__device__ __forceinline__ void hp_emit_block(float* scratch, int tid, int a_blk, int b0, int NA, int NB, long long row_off,
+                                              long long sa, long long sb, const float (&m_a)[2][8], const float (&m_b)[2][8],
+                                              const float (&centre)[2][8], int b_is_time, float power, int hard, float* harm_o,
+                                              float* perc_o, float* mh_o, float* mp_o) {
+    const int lane = tid & 63, bx = lane & 7, lr = 2 * (lane >> 3);
+#if TAC_HPSS_COALESCE
+    if (sb == 1) {
+        float mh[2][8], mp[2][8];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float harm = b_is_time ? m_b[i][j] : m_a[i][j];
+                const float perc = b_is_time ? m_a[i][j] : m_b[i][j];
+                hpss_masks(harm, perc, power, hard, mh[i][j], mp[i][j]);
+            }
+#ifdef TAC_HPSS_ABL_NOSTORE
+        if (mh[0][0] + mp[1][7] != 123.0f) return;
+#endif
+        const int sr_ = lane >> 4, sc = 4 * (lane & 15);
+        auto put = [&](float* base, const float (&v)[2][8]) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                hp_f4 lo4, hi4;
+                lo4.x = v[i][0]; lo4.y = v[i][1]; lo4.z = v[i][2]; lo4.w = v[i][3];
+                hi4.x = v[i][4]; hi4.y = v[i][5]; hi4.z = v[i][6]; hi4.w = v[i][7];
+                hp_f4* dst = reinterpret_cast<hp_f4*>(scratch + (lr + i) * 68 + 8 * bx);
+                dst[0] = lo4;
+                dst[1] = hi4;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = sr_ + 4 * k;
+                const hp_f4 x4 = *reinterpret_cast<const hp_f4*>(scratch + r * 68 + sc);
+                const int a = a_blk + r, b = b0 + sc;
+                if (a < NA) {
+                    float* dst = base + row_off + (long long)a * sa + b;
+                    if (b + 3 < NB) {
+                        hp_f4u u;
+                        u.x = x4.x; u.y = x4.y; u.z = x4.z; u.w = x4.w;
+#if TAC_HPSS_NT
+                        __builtin_nontemporal_store(u, reinterpret_cast<hp_f4u*>(dst));
+#else
+                        *reinterpret_cast<hp_f4u*>(dst) = u;
+#endif
+                    } else {
+                        if (b < NB) dst[0] = x4.x;
+                        if (b + 1 < NB) dst[1] = x4.y;
+                        if (b + 2 < NB) dst[2] = x4.z;
+                    }
+                }
+            }
+        };
+        put(mh_o, mh);
+        put(mp_o, mp);
+        if (harm_o) {
+            float hv[2][8], pv[2][8];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    hv[i][j] = centre[i][j] * mh[i][j];
+                    pv[i][j] = centre[i][j] * mp[i][j];
+                }
+            put(harm_o, hv);
+            put(perc_o, pv);
+        }
+        return;
+    }
+#endif
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int a = a_blk + lr + i, bq = b0 + 8 * bx;
+        hp_emit8(a < NA, bq, NB, row_off + (long long)a * sa + (long long)bq * sb, sb, m_a[i], m_b[i], centre[i], b_is_time, power,
+                 hard, harm_o, perc_o, mh_o, mp_o);
+    }
+}
+
 // K + 7 taps of one tile row starting at column `first` (any alignment), read as 16-byte chunks
 template <int K>
 __device__ __forceinline__ void hp_row_taps(const float* tile_row, int first_aligned, float (&w)[K + 7]) {
@@ -391,17 +478,18 @@ hpss_tile8_kernel(const float* __restrict__ x, int NA, int NB, long long sr, lon
     }
 #endif
     __syncthreads();
-    // ---- masks and stores in the B map
+    // ---- masks and stores: the B map's values, stored through the wave's transpose area (behind the exchange rows, in the dead tile)
+    float m_a[2][8];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int a = a0 + 2 * ay + i;
-        const int bq = b0 + 8 * bx;
         const hp_f4 ma0 = *reinterpret_cast<const hp_f4*>(tile + (2 * ay + i) * HP8_EX + 8 * bx);
         const hp_f4 ma1 = *reinterpret_cast<const hp_f4*>(tile + (2 * ay + i) * HP8_EX + 8 * bx + 4);
-        const float m_a[8] = {ma0.x, ma0.y, ma0.z, ma0.w, ma1.x, ma1.y, ma1.z, ma1.w};
-        hp_emit8(a < NA, bq, NB, row * sr + (long long)a * sa + (long long)bq * sb, sb, m_a, medB[i], centre[i], b_is_time,
-                 power, hard, harm_o, perc_o, mh_o, mp_o);
+        m_a[i][0] = ma0.x; m_a[i][1] = ma0.y; m_a[i][2] = ma0.z; m_a[i][3] = ma0.w;
+        m_a[i][4] = ma1.x; m_a[i][5] = ma1.y; m_a[i][6] = ma1.z; m_a[i][7] = ma1.w;
     }
+    static_assert(HP_TILE * HP8_EX + 4 * HP8_SCRATCH <= HP8_LDS_FLOATS, "exchange rows + four transpose areas fit the tile");
+    hp_emit_block(tile + HP_TILE * HP8_EX + (tid >> 6) * HP8_SCRATCH, tid, a0 + 16 * (tid >> 6), b0, NA, NB, row * sr, sa, sb, m_a, medB,
+                  centre, b_is_time, power, hard, harm_o, perc_o, mh_o, mp_o);
 }
 
 // Unequal (or small) widths, round 4: two launches over the same 64 x 64 output tiles, each with a halo along ONE axis.
@@ -445,7 +533,7 @@ hpss_axis_b_kernel(const float* __restrict__ x, int NA, int NB, long long sr, lo
                    int tiles_b, int b_is_time, float power, int hard, float* harm_o, float* perc_o, float* mh_o,
                    float* mp_o /* holds the A medians on entry */) {
     constexpr int HALF = K / 2;
-    __shared__ __attribute__((aligned(16))) float tile[HP_TILE * HP_STRIDE];
+    __shared__ __attribute__((aligned(16))) float tile[HP_TILE * HP_STRIDE + 4 * HP8_SCRATCH];   // + the waves' store-transpose areas
     const int tid = threadIdx.x;
     const int per_row = tiles_a * tiles_b;
     const long long row = blockIdx.x / per_row;
@@ -455,26 +543,30 @@ hpss_axis_b_kernel(const float* __restrict__ x, int NA, int NB, long long sr, lo
     const int tile_has_nan = __syncthreads_or(seen_nan ? 1 : 0);
     const int bx = tid & 7, ay = tid >> 3;
     constexpr int START = HP_LEFT - HALF, OFF = START & 3;
+    float medB[2][8], centre[2][8], m_a[2][8];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        float w[K + 7], medB[8], centre[8], m_a[8];
+        float w[K + 7];
         hp_row_taps<K>(tile + (2 * ay + i) * HP_STRIDE, 8 * bx + (START - OFF), w);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) centre[j] = w[HALF + j];
-        hp_run8<K>(w, medB, tile_has_nan);
+        for (int j = 0; j < 8; ++j) centre[i][j] = w[HALF + j];
+        hp_run8<K>(w, medB[i], tile_has_nan);
+        // the A medians of these sixteen elements: read by the wave that overwrites them below (its 16 x 64 block), and waited
+        // for — they feed the masks — before any of its stores is issued
         const int a = a0 + 2 * ay + i, bq = b0 + 8 * bx;
         const long long o = row * sr + (long long)a * sa + (long long)bq * sb;
         if (a < NA && sb == 1 && bq + 7 < NB) {
             const hp_f4u lo4 = *reinterpret_cast<const hp_f4u*>(mp_o + o), hi4 = *reinterpret_cast<const hp_f4u*>(mp_o + o + 4);
-            m_a[0] = lo4.x; m_a[1] = lo4.y; m_a[2] = lo4.z; m_a[3] = lo4.w;
-            m_a[4] = hi4.x; m_a[5] = hi4.y; m_a[6] = hi4.z; m_a[7] = hi4.w;
+            m_a[i][0] = lo4.x; m_a[i][1] = lo4.y; m_a[i][2] = lo4.z; m_a[i][3] = lo4.w;
+            m_a[i][4] = hi4.x; m_a[i][5] = hi4.y; m_a[i][6] = hi4.z; m_a[i][7] = hi4.w;
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) m_a[j] = (a < NA && bq + j < NB) ? mp_o[o + (long long)j * sb] : 0.0f;
+            for (int j = 0; j < 8; ++j) m_a[i][j] = (a < NA && bq + j < NB) ? mp_o[o + (long long)j * sb] : 0.0f;
         }
-        hp_emit8(a < NA, bq, NB, o, sb, m_a, medB, centre, b_is_time, power, hard, harm_o, perc_o, mh_o, mp_o);
         __builtin_amdgcn_sched_barrier(0);
     }
+    hp_emit_block(tile + HP_TILE * HP_STRIDE + (tid >> 6) * HP8_SCRATCH, tid, a0 + 16 * (tid >> 6), b0, NA, NB, row * sr, sa, sb, m_a, medB,
+                  centre, b_is_time, power, hard, harm_o, perc_o, mh_o, mp_o);
 }
 
 __global__ void __launch_bounds__(256)
