@@ -166,9 +166,10 @@ hpss_tile_kernel(const float* __restrict__ x, int NA, int NB, long long sr, long
 //    hpss_tile_kernel's 35 dword loads + 64 dword stores per thread cost it ~6 000 cycles per tile (0.25 ms of the 0.92).
 //    The fill reads whole 16-byte chunks wherever a chunk lies inside the row (edge chunks: four reflected scalar loads);
 //    results leave as 16-byte stores (4-byte aligned: rows of 1025 bins start anywhere) — 9 + 16 instructions per thread;
-//  * two thread -> output maps: along B (the fast axis, 16-byte LDS reads) a thread owns 2 rows x 8 consecutive columns and
-//    that is also the store map; along A it owns one column x 16 rows (two runs; LDS reads down the rows, a wave = 64
-//    consecutive columns), and the A medians cross the workgroup once through the (by then dead) tile.
+//  * two thread -> output maps: along B (the fast axis, 16-byte LDS reads) a thread owns 2 rows x 8 consecutive columns, where the
+//    masks are formed too; along A it owns one column x 16 rows (two runs; LDS reads down the rows, a wave = 64 consecutive
+//    columns), and the A medians cross the workgroup once through the (by then dead) tile;
+//  * the results leave through a per-wave transpose in LDS (hp_emit_block): four whole 256-byte row segments per store instruction.
 #ifndef TAC_HPSS_RUN8
 #define TAC_HPSS_RUN8 1
 #endif
@@ -419,7 +420,7 @@ hpss_tile8_kernel(const float* __restrict__ x, int NA, int NB, long long sr, lon
     const float* xr = x + row * sr;
     const bool seen_nan = hp_fill<HP_STRIDE>(tile, HP8_STRIDE, xr, a0 - 15, HP_ROWS, b0 - HP_LEFT, NA, NB, sa, sb, tid);
     const int tile_has_nan = __syncthreads_or(seen_nan ? 1 : 0);
-    // ---- along B: thread (bx, ay) owns rows 2 ay, 2 ay + 1 and columns 8 bx .. 8 bx + 7 (also the store map)
+    // ---- along B: thread (bx, ay) owns rows 2 ay, 2 ay + 1 and columns 8 bx .. 8 bx + 7
     const int bx = tid & 7, ay = tid >> 3;
     constexpr int START = HP_LEFT - HALF, OFF = START & 3;
     float medB[2][8], centre[2][8];
@@ -494,8 +495,8 @@ hpss_tile8_kernel(const float* __restrict__ x, int NA, int NB, long long sr, lon
 
 // Unequal (or small) widths, round 4: two launches over the same 64 x 64 output tiles, each with a halo along ONE axis.
 // hpss_axis_a_kernel<KA>: medians along A (the slow memory axis) into `tmp` — the caller's mask_perc buffer, no workspace.
-// hpss_axis_b_kernel<KB>: medians along B, the A medians read back from `tmp` (a thread reads exactly the sixteen elements it
-// then overwrites), masks and the four results.  (Round 3's one-thread-per-element kernel issued 64 dword loads per output and
+// hpss_axis_b_kernel<KB>: medians along B, the A medians read back from `tmp` (a wave reads exactly the 16 x 64 block it then
+// overwrites, and has waited for those loads — they feed the masks — before its first store), masks and the four results.  (Round 3's one-thread-per-element kernel issued 64 dword loads per output and
 // ran at 7 % of the HBM peak; hpss_kernel below is kept as the A/B baseline and for non-unit fast strides.)
 template <int K>
 __global__ void __launch_bounds__(256)
