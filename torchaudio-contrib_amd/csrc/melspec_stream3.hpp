@@ -18,6 +18,9 @@ constexpr int S3_WAVES = 12;          // what ships
 constexpr int S3_PIECES_MARK = -77;   // info_host[7] of a piece-layout pack (== TAC_PIECES_MARK, include/tac_amd.h)
 constexpr int S3_WAVES_F32 = 15;      // A/B form (TAC_S3_WAVES=15): as many 128-register waves as the LDS holds next to a 128-band bank
 
+#ifndef TAC_S3_ABL_NOWEIGHTS
+#define TAC_S3_ABL_NOWEIGHTS 0
+#endif
 #ifndef TAC_S3_ABL_MFMA_X
 #define TAC_S3_ABL_MFMA_X 0   // timing-only ablation (wrong results): first exchange as MFMA transposes (see the frame loop)
 #endif
@@ -863,6 +866,8 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             for (int u = 0; u < ST_FAST_STEPS0; ++u) {
 #if TAC_S3_W0_REGS
                 w0[u] = w0_regs[u];
+#elif TAC_S3_ABL_NOWEIGHTS       // timing-only ablation (WRONG RESULTS): the weights cost no LDS read (what a consumer wave holding its
+                w0[u] = p0[u];         // bank in registers would save: DESIGN.md 7 (2))
 #else
                 w0[u] = wp[u * 64];
 #endif
@@ -870,7 +875,11 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             }
 #pragma unroll
             for (int u = 0; u < B1; ++u) {
+#if TAC_S3_ABL_NOWEIGHTS
+                wa[u] = p1[u];
+#else
                 wa[u] = wp[(ST_FAST_STEPS0 + u) * 64];
+#endif
                 qa[u] = p1[u];
             }
 #pragma unroll
@@ -878,7 +887,11 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             f4 wb[B2], qb[B2];
 #pragma unroll
             for (int u = 0; u < B2; ++u) {
+#if TAC_S3_ABL_NOWEIGHTS
+                wb[u] = p1[B1 + u];
+#else
                 wb[u] = wp[(ST_FAST_STEPS0 + B1 + u) * 64];
+#endif
                 qb[u] = p1[B1 + u];
             }
 #pragma unroll
