@@ -18,6 +18,9 @@ constexpr int S3_WAVES = 12;          // what ships
 constexpr int S3_PIECES_MARK = -77;   // info_host[7] of a piece-layout pack (== TAC_PIECES_MARK, include/tac_amd.h)
 constexpr int S3_WAVES_F32 = 15;      // A/B form (TAC_S3_WAVES=15): as many 128-register waves as the LDS holds next to a 128-band bank
 
+#ifndef TAC_S3_ABL_NOTABLES
+#define TAC_S3_ABL_NOTABLES 0
+#endif
 #ifndef TAC_S3_ABL_NOWEIGHTS
 #define TAC_S3_ABL_NOWEIGHTS 0
 #endif
@@ -560,6 +563,10 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     S3Swz swz;
     swz.init(xa, t);
 #endif
+#if TAC_S3_ABL_NOTABLES
+    float abl_seed = 0.5f + 1e-3f * (float)t;
+    asm volatile("" : "+v"(abl_seed));                      // (a value the compiler cannot fold)
+#endif
     int i = w;
 #if !TAC_S3_EARLY_FIRST
     request(i);
@@ -597,6 +604,10 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             Dft<16>::run_windowed(v, win_regs);
 #else
             cf win[E];
+#if TAC_S3_ABL_NOTABLES          // timing-only ablation (WRONG RESULTS): window and pass-1 twiddles cost no LDS read (one register each stands in)
+#pragma unroll
+            for (int u = 0; u < E; ++u) win[u] = mkc(abl_seed, abl_seed);
+#else
             const f4* wl = reinterpret_cast<const f4*>(winl) + t;
 #pragma unroll
             for (int u = 0; u < E / 2; ++u) {
@@ -604,6 +615,7 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
                 win[2 * u] = mkc(x.x, x.y);
                 win[2 * u + 1] = mkc(x.z, x.w);
             }
+#endif
             Dft<16>::run_windowed(v, win);
 #endif
         }
@@ -633,6 +645,10 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         }
 #endif
         cf tw1[16];
+#if TAC_S3_ABL_NOTABLES
+#pragma unroll
+        for (int u = 0; u < 16; ++u) tw1[u] = mkc(abl_seed, -abl_seed);
+#else
         {
             const f4* tl = reinterpret_cast<const f4*>(twlds + (t & 15) * ST_TW_STRIDE);
 #pragma unroll
@@ -642,6 +658,7 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
                 tw1[2 * u + 1] = mkc(x.z, x.w);
             }
         }
+#endif
 #if TAC_S3_ABL_MFMA_X
         // (done above, ahead of the twiddle reads)
 #elif TAC_S3_SWZ
