@@ -39,6 +39,7 @@ CFG3_SR, CFG3_LENGTH = 44100, 44100 * 30
 # Infinity Cache), so a step's samples cannot have stayed on-die from the step before: the headline and the stage
 # figures are HBM numbers.  The same loop over ONE batch (which fits the Infinity Cache) is reported beside them.
 NBUF = 4
+GATHER_CHUNKS = 8                                   # row pieces of the overlapped all-gather leg
 
 
 def parse():
@@ -130,7 +131,7 @@ def bound_from_counters(roof, route, clock_mhz):
     are properties of the kernel binary and the workload, the clock is measured live).  The entry must carry the name of
     the kernel the library just launched; otherwise the fields stay null and say why."""
     entry, source = None, None
-    for rnd in ('r04', 'r03'):
+    for rnd in ('r05', 'r04', 'r03'):
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', rnd, 'pmc_mel.json')))
         except Exception:            # noqa: BLE001
@@ -170,6 +171,106 @@ def bound_from_counters(roof, route, clock_mhz):
     roof['bound'] = max(busy, key=busy.get)
     roof['bound_note'] = ('the busiest resource by the counters; `frac` / `peak` stay the HBM figure the contract asks for '
                           '(algorithmic bytes / kernel time / 8 TB/s)')
+
+
+def rccl_debug_lines(path, limit=16):
+    """What RCCL said about itself (NCCL_DEBUG=INFO to a file): the channel / ring summary of the communicator and the
+    distinct "<bytes> Bytes -> Algo .. proto .." decisions, prefix stripped, first `limit` of each kind."""
+    import re
+    try:
+        text = open(path, errors='replace').read().splitlines()
+    except OSError as exc:
+        return {'error': str(exc)}
+    strip = lambda l: re.sub(r'^.*?NCCL INFO ', '', l).strip()
+    algo, topo, seen = [], [], set()
+    for line in text:
+        msg = strip(line)
+        if 'Bytes -> Algo' in msg or 'Algo' in msg and 'proto' in msg.lower():
+            key = re.sub(r'time [0-9.e+-]+', '', msg)
+            if key not in seen and len(algo) < limit:
+                seen.add(key)
+                algo.append(msg)
+        elif re.search(r'coll channels|p2p channels|Ring 0+ :|Trees? \[|NCCL version|RCCL version|nranks', msg):
+            if msg not in seen and len(topo) < limit:
+                seen.add(msg)
+                topo.append(msg)
+    return {'source': 'NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT,TUNING,GRAPH of rank 0 (%d lines)' % len(text),
+            'algo_proto': algo, 'communicator': topo}
+
+
+def extra_stages(stages, tac, dev, gen, model):
+    """Driver-timed figures for BASELINE configs[3] (multi-channel STFT + ComplexNorm at 4096 / 1024, full size: 17.7 GB of
+    algorithmic traffic in ONE launch), configs[4] (mu-law encode / decode, 12 B per sample each way) and the host-bound end of
+    the headline chain (1 / 4 / 16 rows: microseconds per call).  Each guarded by a free-memory check and its own try."""
+    def free_gb():
+        return torch.cuda.mem_get_info(dev)[0] / 1e9
+
+    try:        # configs[3]: 64 x 8ch x 48 kHz x 60 s, fft_length 4096, hop 1024, magnitude (reference layers.py:267-304)
+        b4, c4, l4, n4, h4 = 64, 8, 48000 * 60, 4096, 1024
+        t4, f4 = 1 + l4 // h4, n4 // 2 + 1
+        need = (b4 * c4 * l4 * 4 + b4 * c4 * t4 * f4 * 4) / 1e9 * 1.15
+        if free_gb() < need + 2:
+            stages['cfg4_spectrogram_4096'] = {'skipped': 'needs %.1f GB of device memory, %.1f free' % (need, free_gb())}
+        else:
+            torch.cuda.empty_cache()
+            x4 = torch.rand(b4, c4, l4, device=dev, generator=gen) * 2 - 1
+            spec4 = tac.Spectrogram(n4, h4, power=1.).to(dev)
+            fn = lambda: tac.realize(spec4(x4))
+            for _ in range(3):
+                fn()
+            ms, med = event_ms(fn, 12)
+            per_frame = 4 * h4 + 4 * f4
+            alg = b4 * c4 * t4 * per_frame
+            stages['cfg4_spectrogram_4096'] = {
+                'workload': 'Spectrogram(4096, 1024, power=1) on %d x %dch x %d samples (BASELINE configs[3], full size, one launch)' % (b4, c4, l4),
+                'kernel': 'stft_n4096_kernel (csrc/stft_n4096.hip), |X| rows',
+                'frames': b4 * c4 * t4, 'kernel_ms_mean': ms, 'kernel_ms_median': med, 'alg_bytes_per_frame': per_frame,
+                'alg_bytes_per_launch': alg, 'achieved_GBs': alg / (ms * 1e-3) / 1e9,
+                'frac_of_hbm_peak': alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'frames_per_s': b4 * c4 * t4 / (ms * 1e-3)}
+            del x4, spec4, fn
+            torch.cuda.empty_cache()
+    except Exception as exc:            # noqa: BLE001
+        stages['cfg4_spectrogram_4096'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
+
+    try:        # configs[4]: 1024 x 1ch x 24 kHz x 5 s, 256 levels (reference functional.py:317-354): f32 -> int64 -> f32
+        x5 = torch.rand(1024, 1, 24000 * 5, device=dev, generator=gen) * 2 - 1
+        enc, dec = tac.MuLawEncoding(256).to(dev), tac.MuLawDecoding(256).to(dev)
+        codes = enc(x5)
+        assert codes.dtype == torch.int64
+        for name, fn in (('cfg5_mulaw_encode', lambda: enc(x5)), ('cfg5_mulaw_decode', lambda: dec(codes))):
+            spin(fn, 0.2)
+            ms, med = event_ms(fn, 50)
+            alg = x5.numel() * 12
+            stages[name] = {'workload': '1024 x 1ch x 120 000 samples, 256 levels (BASELINE configs[4])', 'kernel_ms_mean': ms,
+                            'kernel_ms_median': med, 'alg_bytes_per_sample': 12, 'alg_bytes_per_launch': alg,
+                            'achieved_GBs': alg / (ms * 1e-3) / 1e9, 'frac_of_hbm_peak': alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            'samples_per_s': x5.numel() / (ms * 1e-3)}
+        del x5, codes
+    except Exception as exc:            # noqa: BLE001
+        stages['cfg5_mulaw'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
+
+    try:        # the host-bound end of the headline chain: wall time per call, launches back to back, 1 / 4 / 16 rows of 10 s
+        small = {}
+        for rows in (1, 4, 16):
+            xr = torch.rand(rows, CHANNELS, LENGTH, device=dev, generator=gen) * 2 - 1
+            fn = lambda: model(xr)
+            spin(fn, 0.2)
+            torch.cuda.synchronize()
+            n = 2000
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            t_host = time.perf_counter() - t0            # launches issued (the queue may still hold some)
+            torch.cuda.synchronize()
+            t_all = time.perf_counter() - t0
+            small['rows_%d' % rows] = {'us_per_call_host': t_host / n * 1e6, 'us_per_call': t_all / n * 1e6,
+                                        'frames_per_s': rows * CHANNELS * FRAMES * n / t_all}
+        small['note'] = ('Sequential(*Melspectrogram, AmplitudeToDb) on rows x 1 x 160 000 samples, 2000 calls back to back: '
+                         'us_per_call_host = Python + dispatch + launch per call (the floor for tiny batches), us_per_call = '
+                         'including the GPU draining the queue')
+        stages['small_batch'] = small
+    except Exception as exc:            # noqa: BLE001
+        stages['small_batch'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
 
 
 def _free_port():
@@ -235,8 +336,14 @@ def run(a):
         return dry_run_cpu(a, rank, world)
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit('bench.py: rank %d has no GPU (%d visible)' % (local_rank, torch.cuda.device_count()))
+    rccl_log = None
     if distributed:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if 'NCCL_DEBUG' not in os.environ:
+            # make the run self-explaining: RCCL's own account of the rings / channels it built and of the algorithm and protocol
+            # it picks per message size goes to a per-process file; rank 0 quotes it in the JSON line (`rccl_debug`)
+            rccl_log = '/tmp/tac_rccl_%d.log' % os.getpid()
+            os.environ.update(NCCL_DEBUG='INFO', NCCL_DEBUG_SUBSYS='INIT,TUNING,GRAPH', NCCL_DEBUG_FILE=rccl_log)
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     dev = torch.device('cuda', local_rank)
@@ -366,6 +473,10 @@ def run(a):
                      'kernel_ms_p10': quantile(region_mss, 0.1), 'kernel_ms_p90': quantile(region_mss, 0.9),
                      'kernel_ms_median': med_ms, 'kernel_ms_per_launch_events': per_launch_mean_ms,
                      'shader_clock_mhz': clock_mhz,
+                     'median_vs_mean_note': 'kernel_ms_mean is a K-launch region / K (launches back to back: no gap, no event '
+                                            'overhead); kernel_ms_median / kernel_ms_per_launch_events bracket EVERY launch with its '
+                                            'own event pair, which adds ~3 us of event processing per launch and lets the '
+                                            'queue drain between launches — it reads higher and is kept only as a cross-check',
                      'timing': 'median over `repeats` regions of: one HIP event pair on the launch stream around the K timed '
                                'steps (one launch per step) / K; kernel_ms_per_launch_events / kernel_ms_median: event '
                                'pairs around single launches; shader_clock_mhz: shader cycles / 100 MHz ticks of every '
@@ -442,20 +553,51 @@ def run(a):
                 stages['train_step_fwd_bwd'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
         except Exception as exc:            # noqa: BLE001 — reported in the line, not swallowed
             stages['error'] = '%s: %s' % (type(exc).__name__, exc)
+        # ---- the other BASELINE configs, each at its full size, one launch per call (round 5)
+        extra_stages(stages, tac, dev, gen, model)
         result['stages'] = stages
 
     def gather_leg(mdl, inputs, rows_total, frames_step, steps):
-        """compute + ONE RCCL all-gather of the (B/N, C, M, T) output shards"""
+        """compute + the ONE exchange of the (B/N, C, M, T) output shards, every form side by side: `rccl`
+        (all_gather_into_tensor) and `p2p` (direct sends to every peer), each serial (compute, then gather) and OVERLAPPED
+        (ShardedPipeline(overlap=True): the shard computed in row pieces, piece k exchanged while piece k + 1 is computed).
+        Top-level fields = the default method, serial (what earlier rounds reported)."""
         forced = world == 1                  # a group of one would return before the collective: run it anyway (RCCL smoke)
-        fn = rotating(lambda t: tac.distributed.all_gather_batch(mdl(t), total_rows=rows_total, force_collective=forced),
-                      inputs)
-        try:        # a secondary figure: a failure here must not cost the headline line above
-            for _ in range(3):
-                fn()
-            wg, _, _ = repeated(fn, steps, max(1, a.repeats // 5))
-            eg = quantile(wg, 0.5)
-            return {'value': frames_step * steps / eg, 'unit': 'frames/s', 'ms_per_step': eg / steps * 1e3,
-                    'method': tac.distributed.default_method(), 'forced_at_world_1': forced}
+
+        def serial(method):
+            return rotating(lambda t: tac.distributed.all_gather_batch(mdl(t), total_rows=rows_total, method=method,
+                                                                       force_collective=forced), inputs)
+
+        def overlapped(method):
+            # (what ShardedPipeline(overlap=True) does, on a batch that is already this rank's shard)
+            def one(t):
+                g = tac.distributed.ChunkedAllGather(rows_total, GATHER_CHUNKS, method=method, force_collective=forced)
+                for k in range(g.chunks):
+                    lb, le = g.local_rows(k)
+                    g.add(k, mdl(t[lb:le]))
+                return g.finish()
+            return rotating(one, inputs)
+
+        out = {}
+        try:        # secondary figures: a failure here must not cost the headline line above
+            for name, make in (('rccl', lambda: serial('rccl')), ('p2p', lambda: serial('p2p')),
+                               ('rccl_overlap', lambda: overlapped('rccl')), ('p2p_overlap', lambda: overlapped('p2p'))):
+                try:
+                    fn = make()
+                    for _ in range(3):
+                        fn()
+                    wg, _, _ = repeated(fn, steps, max(1, a.repeats // 5))
+                    eg = quantile(wg, 0.5)
+                    out[name] = {'value': frames_step * steps / eg, 'unit': 'frames/s', 'ms_per_step': eg / steps * 1e3}
+                except Exception as exc:            # noqa: BLE001
+                    out[name] = {'error': '%s: %s' % (type(exc).__name__, exc)}
+            default = tac.distributed.default_method()
+            top = dict(out.get(default, {}))
+            top.update({'method': default, 'forced_at_world_1': forced, 'chunks_overlapped': GATHER_CHUNKS, 'forms': out,
+                        'note': 'forms: serial = compute then one exchange; *_overlap = the shard computed in %d row pieces, each '
+                                'piece exchanged (async, the communicator\'s stream) while the next is computed — expected '
+                                '~max(compute, exchange) instead of their sum (DESIGN.md §6)' % GATHER_CHUNKS})
+            return top
         except Exception as exc:            # noqa: BLE001 — reported in the line, not swallowed
             return {'error': '%s: %s' % (type(exc).__name__, exc)}
 
@@ -482,6 +624,14 @@ def run(a):
             except Exception as exc:        # noqa: BLE001
                 result['cfg3'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
 
+    if distributed:
+        # every rank's shader clock under the headline kernel (eight GPUs in one chassis need not clock alike: the first thing to
+        # compare when the N = 8 efficiency is below the N = 1 line's)
+        clocks = [None] * world
+        dist.all_gather_object(clocks, clock_mhz)
+        result['roofline']['shader_clock_mhz_per_rank'] = clocks
+        if rccl_log:
+            result['rccl_debug'] = rccl_debug_lines(rccl_log)
     if rank == 0 and world == 1 and x_host is not None:
         result['cpu_baseline'] = cpu_baseline(x_host)
     if rank == 0:

@@ -45,6 +45,19 @@ assert torch.equal(g2, y)
 # the wrapper a caller would use, gather included
 pipe = ShardedPipeline(model, gather=True)
 assert torch.equal(pipe(x), y)
+# ... and its overlapped form: the shard computed in 8 row pieces, every piece's collective (async, RCCL's stream) posted while the
+# next piece is computed, staged pieces moved to their place on a side stream — same tensor, same layout
+n0 = len(calls)
+for method in ('rccl', 'p2p'):
+    yo = ShardedPipeline(model, gather=True, overlap=True, chunks=8, method=method, force_collective=True)(x)
+    torch.cuda.synchronize()
+    assert yo.shape == y.shape and yo.stride() == y.stride() and torch.equal(yo, y), method
+assert len(calls) == n0 + 8, 'eight chunk collectives went through RCCL'
+t0 = time.perf_counter()
+for _ in range(5):
+    ShardedPipeline(model, gather=True, overlap=True, chunks=8, force_collective=True)(x)
+torch.cuda.synchronize()
+print('RCCL_OVERLAPPED_STEP_MS %%.3f (compute + 8 chunk gathers at world 1)' %% ((time.perf_counter() - t0) / 5 * 1e3))
 # timing of the forced collective (device-local at world 1: what RCCL's launch + copy costs without a wire)
 for _ in range(3):
     all_gather_batch(y, total_rows=rows, force_collective=True)

@@ -339,6 +339,63 @@ print('rank', rank, 'ok')
         assert 'rank %d ok' % r in o
 
 
+_OVERLAP_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import torchaudio_contrib_amd as tac
+from torchaudio_contrib_amd.distributed import shard_batch, all_gather_batch, ShardedPipeline, ChunkedAllGather
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=sys.argv[3], RANK=str(rank), WORLD_SIZE=str(world))
+dist.init_process_group('gloo', rank=rank, world_size=world)
+
+
+class FrameMajor(torch.nn.Module):          # what the layers return: a (.., M, T) view of a frame-major buffer
+    def forward(self, x):
+        return (x * 2.0).transpose(-2, -1).contiguous().transpose(-2, -1)
+
+
+for rows in (1, 2, 5, 7, 12):               # fewer rows than ranks, uneven shards, even shards
+    whole = torch.arange(rows * 2 * 3 * 4, dtype=torch.float32).reshape(rows, 2, 3, 4)
+    for method in ('rccl', 'p2p'):
+        for chunks in (1, 2, 3, 5, 64):     # one piece, uneven pieces, more pieces than rows
+            got = ShardedPipeline(FrameMajor(), overlap=True, chunks=chunks, method=method)(whole)
+            assert got.shape == whole.shape and torch.equal(got, whole * 2.0), (rank, rows, method, chunks)
+            assert got.stride() == FrameMajor()(whole).stride(), 'the gathered batch keeps the frame-major layout'
+# pieces must come in order, and all of them
+g = ChunkedAllGather(4 * world, 2)
+try:
+    g.add(1, torch.zeros(2, 3))
+    raise SystemExit('out-of-order piece accepted')
+except ValueError:
+    pass
+# the real chain (CPU route of the ops): overlapped == serial == whole batch
+mel = torch.nn.Sequential(*tac.Melspectrogram(num_mels=8, sample_rate=8000, fft_length=64, hop_length=16), tac.AmplitudeToDb())
+wave = torch.arange(5 * 1 * 400, dtype=torch.float32).reshape(5, 1, 400).sin()
+ref = mel(wave)
+for method in ('rccl', 'p2p'):
+    assert torch.equal(ShardedPipeline(mel, overlap=True, chunks=2, method=method)(wave), ref)
+    assert torch.equal(ShardedPipeline(mel, overlap=False, method=method)(wave), ref)
+dist.barrier()
+dist.destroy_process_group()
+print('rank', rank, 'ok')
+'''
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_gloo_overlapped_allgather(tmp_path, world):
+    """ChunkedAllGather / ShardedPipeline(overlap=True): the exchange of row piece k posted while piece k + 1 is computed gives
+    the same batch as the one-shot gather — chunk order, uneven chunk tails, uneven and empty shards, both methods."""
+    script = tmp_path / 'worker_overlap.py'
+    script.write_text(_OVERLAP_WORKER % ROOT)
+    port = str(33500 + (os.getpid() + 7 * world) % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), port], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert 'rank %d ok' % r in o
+
+
 def test_forced_collective_in_a_group_of_one():
     """all_gather_batch(force_collective=True) runs the real collective at world size 1 (what the RCCL smoke test of a 1-GPU
     box relies on) and returns the shard unchanged, for both exchange methods and for the strided views the layers return."""

@@ -135,18 +135,164 @@ def all_gather_batch(local, total_rows=None, group=None, method=None, force_coll
     return out.transpose(-2, -1) if transposed else out
 
 
+def _physical(local):
+    """(frame-major contiguous buffer, transposed?) of a (.., M, T) output view or a plain row-major tensor — the layout rule of
+    :func:`all_gather_batch`, decided from the strides alone so that every rank takes the same branch."""
+    transposed = local.dim() >= 3 and not _row_major(local) and _row_major(local.transpose(-2, -1))
+    phys = local.transpose(-2, -1) if transposed else (local if _row_major(local) else local.contiguous())
+    return (phys if phys.is_contiguous() else phys.contiguous()), transposed
+
+
+class ChunkedAllGather(object):
+    """The one all-gather of :func:`all_gather_batch`, cut into row chunks so that it OVERLAPS the computation.
+
+    At BASELINE configs[2] a rank computes its 338.7 MB shard in ~0.9 ms and the exchange takes 5.5 - 8 ms over xGMI
+    (DESIGN.md §6): run back to back the step is their sum.  Rows are independent (reference functional.py:89-91), so the shard
+    is produced in ``chunks`` pieces and the exchange of piece k is posted — asynchronously, on the communicator's own stream —
+    as soon as piece k exists, while piece k + 1 is being computed: the step becomes ~max(compute, exchange) + one piece.
+
+    Every rank cuts ``[0, biggest)`` (``biggest`` = the largest shard) into the same ``chunks`` pieces (:func:`shard_bounds`);
+    a rank whose shard is a row shorter simply has a shorter (or empty) last piece.  ``add(k, local)`` takes this rank's rows of
+    piece k (the pipeline's output view for them), ``finish()`` waits and returns the gathered batch in rank order — the same
+    tensor :func:`all_gather_batch` returns.  Methods: ``p2p`` posts the piece straight into its final place in every peer's
+    output (no staging; sizes are known to all ranks, empty messages are skipped on both sides); ``rccl`` gathers the piece with
+    ``all_gather_into_tensor`` into a staging block (pieces of short ranks padded) and moves it to its place with one strided
+    copy on a side stream.
+    """
+
+    def __init__(self, total_rows, chunks, group=None, method=None, force_collective=False):
+        self.group = group
+        self.force = force_collective            # a group of one still goes through the communicator (RCCL smoke on a 1-GPU box)
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.method = default_method() if method is None else method
+        if self.method not in METHODS:
+            raise ValueError('method must be one of %r, got %r' % (METHODS, self.method))
+        self.total_rows = int(total_rows)
+        bounds = [shard_bounds(self.total_rows, self.world, r) for r in range(self.world)]
+        self.sizes = [e - b for b, e in bounds]
+        self.offsets = [b for b, _ in bounds]
+        self.biggest = max(self.sizes) if self.sizes else 0
+        self.chunks = max(1, min(int(chunks), max(1, self.biggest)))
+        self.pieces = [shard_bounds(self.biggest, self.chunks, k) for k in range(self.chunks)]
+        self.out = None
+        self.transposed = False
+        self._pending = []
+        self._side = None
+        self._next = 0
+
+    def local_rows(self, k, rank=None):
+        """[begin, end) of piece k inside the shard of ``rank`` (default: this rank) — clipped to the rows it owns"""
+        n = self.sizes[self.rank if rank is None else rank]
+        b, e = self.pieces[k]
+        return min(b, n), min(e, n)
+
+    def _setup(self, phys, transposed):
+        self.transposed = transposed
+        self.out = torch.empty((self.total_rows,) + tuple(phys.shape[1:]), dtype=phys.dtype, device=phys.device)
+        if phys.is_cuda and self.method == 'rccl':
+            self._side = torch.cuda.Stream(device=phys.device)
+
+    def _peer(self, r):
+        return dist.get_global_rank(self.group, r) if self.group is not None else r
+
+    def add(self, k, local):
+        from ._lazy import realize
+        if k != self._next:
+            raise ValueError('pieces must be added in order: expected %d, got %d' % (self._next, k))
+        self._next += 1
+        phys, transposed = _physical(realize(local))
+        if self.out is None:
+            self._setup(phys, transposed)
+        lb, le = self.local_rows(k)
+        if phys.shape[0] != le - lb:
+            raise ValueError('piece %d of rank %d has %d rows, expected %d' % (k, self.rank, phys.shape[0], le - lb))
+        if self.world == 1 and not self.force:
+            self.out[lb:le].copy_(phys)
+            return
+        if self.method == 'p2p':
+            me = self.offsets[self.rank]
+            if le > lb:
+                self.out[me + lb:me + le].copy_(phys)
+            ops = []
+            for step in range(1, self.world):
+                to, frm = (self.rank + step) % self.world, (self.rank - step) % self.world
+                if le > lb:
+                    ops.append(dist.P2POp(dist.isend, phys, self._peer(to), self.group))
+                fb, fe = self.local_rows(k, frm)
+                if fe > fb:
+                    ops.append(dist.P2POp(dist.irecv, self.out[self.offsets[frm] + fb:self.offsets[frm] + fe], self._peer(frm), self.group))
+            if ops:
+                self._pending.append((dist.batch_isend_irecv(ops), phys))          # (phys stays referenced until the sends are done)
+            return
+        # rccl: one all_gather_into_tensor per piece into a staging block, then to its place
+        b, e = self.pieces[k]
+        c = e - b
+        if c == 0:
+            return
+        if le - lb == c:
+            send = phys
+        else:
+            send = phys.new_empty((c,) + tuple(phys.shape[1:]))
+            send[:le - lb] = phys
+        stage = torch.empty((self.world * c,) + tuple(phys.shape[1:]), dtype=phys.dtype, device=phys.device)
+        work = dist.all_gather_into_tensor(stage, send, group=self.group, async_op=True)
+        self._pending.append((work, stage, send, k))
+        if self._side is not None:                     # the move runs behind the collective on a side stream: the compute stream never waits
+            stage.record_stream(self._side)
+            with torch.cuda.stream(self._side):
+                work.wait()
+                self._place(stage, k)
+
+    def _place(self, stage, k):
+        b, e = self.pieces[k]
+        c = e - b
+        if all(n == self.sizes[0] for n in self.sizes):
+            n = self.sizes[0]
+            trail = tuple(self.out.shape[1:])
+            self.out.view((self.world, n) + trail)[:, b:e].copy_(stage.view((self.world, c) + trail))
+        else:
+            for r in range(self.world):
+                rb, re_ = self.local_rows(k, r)
+                if re_ > rb:
+                    self.out[self.offsets[r] + rb:self.offsets[r] + re_].copy_(stage[r * c:r * c + (re_ - rb)])
+
+    def finish(self):
+        if self._next != self.chunks:
+            raise ValueError('%d of %d pieces were added' % (self._next, self.chunks))
+        for item in self._pending:
+            if self.method == 'p2p':
+                for req in item[0]:
+                    req.wait()
+            elif self._side is None:
+                item[0].wait()
+                self._place(item[1], item[3])
+        if self._side is not None:
+            torch.cuda.current_stream(self.out.device).wait_stream(self._side)
+        self._pending = []
+        return self.out.transpose(-2, -1) if self.transposed else self.out
+
+
 class ShardedPipeline(torch.nn.Module):
     """Wrap a feature pipeline: run it on this rank's batch shard, optionally all-gather the result."""
 
-    def __init__(self, pipeline, gather=True, group=None):
+    def __init__(self, pipeline, gather=True, group=None, overlap=False, chunks=8, method=None, force_collective=False):
+        """``overlap=True``: the shard is computed in ``chunks`` row pieces and the exchange of each piece runs while the
+        next one is computed (:class:`ChunkedAllGather`); the result is the same tensor."""
         super(ShardedPipeline, self).__init__()
         self.pipeline = pipeline
         self.gather = gather
         self.group = group
+        self.overlap = overlap
+        self.chunks = chunks
+        self.method = method
+        self.force_collective = force_collective
 
     def forward(self, whole_batch):
         world = dist.get_world_size(self.group)
         rank = dist.get_rank(self.group)
+        if self.gather and self.overlap and whole_batch.shape[0] > 0:
+            return self._forward_overlapped(whole_batch, world, rank)
         shard = shard_batch(whole_batch, world, rank)
         if shard.shape[0] == 0 and whole_batch.shape[0] > 0:
             # fewer rows than ranks: this rank owns none.  It must still enter the collective (the others would hang
@@ -158,4 +304,17 @@ class ShardedPipeline(torch.nn.Module):
         if not self.gather:
             from ._lazy import realize
             return realize(local)
-        return all_gather_batch(local, total_rows=whole_batch.shape[0], group=self.group)
+        return all_gather_batch(local, total_rows=whole_batch.shape[0], group=self.group, method=self.method,
+                                force_collective=self.force_collective)
+
+    def _forward_overlapped(self, whole_batch, world, rank):
+        shard = shard_batch(whole_batch, world, rank)
+        g = ChunkedAllGather(whole_batch.shape[0], self.chunks, group=self.group, method=self.method, force_collective=self.force_collective)
+        for k in range(g.chunks):
+            lb, le = g.local_rows(k)
+            if le > lb:
+                piece = self.pipeline(shard[lb:le])
+            else:       # a short (or empty) shard has nothing in this piece: zero rows of the right layout
+                piece = self.pipeline(whole_batch[:1])[:0]
+            g.add(k, piece)
+        return g.finish()
