@@ -332,7 +332,8 @@ int tac_amplitude_to_db_backward_f32(const float* x, const float* grad_out, int6
  *      strides.  kernel_f (percussive filter, along frequency) and kernel_t (harmonic filter, along time) odd, <= 32;
  *      reflect padding (needs kernel/2 < size: TAC_E_SHORT_INPUT otherwise); masks soft ((h+eps)/(h+p+eps), eps 1e-6) or
  *      hard (1.0 / 0.0); harm / perc may both be NULL (masks only).  The outputs must not overlap mag or one another
- *      (unequal widths take two launches and park the first one's medians in mask_perc). */
+ *      (unequal widths take two launches and park the first one's medians in mask_perc): overlapping address ranges are
+ *      refused with TAC_E_INVALID. */
 int tac_hpss_f32(const float* mag, int64_t rows, int32_t n_freqs, int32_t n_frames, int64_t stride_r,
                  int64_t stride_f, int64_t stride_t, int32_t kernel_f, int32_t kernel_t, float power,
                  int hard, float* harm, float* perc, float* mask_harm, float* mask_perc, void* stream);

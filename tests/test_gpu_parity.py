@@ -636,6 +636,25 @@ def test_g7_phase_vocoder_and_time_stretch(tac, golden):
         ts(stft)
 
 
+def test_phase_vocoder_infinite_input_poisons_only_its_frames(tac):
+    """An infinite component has a finite angle in the reference (atan2: functional.py:221-229) and an infinite magnitude: only the
+    output frames interpolated from it are non-finite, every later frame of the bin is ordinary.  The float32 kernel carries the
+    running phase as a unit phasor — the value must not turn that phasor into NaN (round-4 advisor finding)."""
+    import math
+    z = signals.audio_like((1, 1, 33, 30, 2), seed=77)
+    z[0, 0, 5, 7, 0] = np.inf                       # +inf real part, finite imaginary part: angle 0
+    z[0, 0, 9, 11, 1] = -np.inf                     # -inf imaginary part: angle -pi/2
+    z[0, 0, 12, 3, :] = (-np.inf, np.inf)           # both: angle 3 pi / 4
+    adv = torch.linspace(0, math.pi * 16, 33)[..., None]
+    for rate in (1.3, 0.6):
+        got = host(tac.phase_vocoder(dev(z), rate, adv.cuda()))
+        want = torch_ref.phase_vocoder(torch.from_numpy(z).double(), rate, adv.double()).numpy()
+        fin = np.isfinite(want).all(-1)
+        assert (np.isfinite(got).all(-1) == fin).all(), 'the same (bin, frame) positions are non-finite'
+        assert not fin.all() and fin.mean() > 0.95
+        assert np.abs(got[fin] - want[fin]).max() < 1e-5 * np.abs(want[fin]).max()
+
+
 def test_non_finite_samples_poison_the_same_frames(tac):
     """A NaN / Inf sample makes every bin of the frames that contain it NaN in the reference (the FFT mixes it
     into all of them); the kernels must poison exactly those frames — across the window, the reflect padding and
@@ -1485,6 +1504,40 @@ def test_hpss_unequal_and_small_widths_both_layouts_and_nan(tac):
             assert np.abs(host(a)[ok] - b.numpy()[ok]).max() <= 1e-6
 
 
+def test_hpss_overlapping_buffers_are_refused(tac):
+    """include/tac_amd.h (10): outputs overlapping the input or one another are an error (TAC_E_INVALID), not silent corruption —
+    the two-launch route of unequal widths parks its first medians in mask_perc."""
+    import ctypes
+    P = ctypes.c_void_p
+    lib = tac._native.lib()
+    x = torch.rand(2, 40, 50, device='cuda')
+    a, b = torch.empty_like(x), torch.empty_like(x)
+    stream = tac._native.stream_ptr(x.device)
+    args = lambda mh, mp: (P(x.data_ptr()), 2, 40, 50, 2000, 50, 1, 9, 5, 2.0, 0, None, None, P(mh), P(mp), stream)
+    assert lib.tac_hpss_f32(*args(a.data_ptr(), b.data_ptr())) == tac._native.TAC_OK
+    assert lib.tac_hpss_f32(*args(a.data_ptr(), x.data_ptr())) == tac._native.TAC_E_INVALID          # mask_perc is the input
+    assert lib.tac_hpss_f32(*args(a.data_ptr(), a.data_ptr() + 400)) == tac._native.TAC_E_INVALID    # the two masks overlap
+    torch.cuda.synchronize()
+
+
+def test_float64_long_non_smooth_length_is_a_composite_route(tac):
+    """Since round 4 the float64 route takes even lengths whose half is 5-smooth (<= 8192) and any length <= 512; other float64
+    lengths (here 1001) go to torch's GPU operators: an error under strict mode, a CompositeRouteWarning otherwise — and the
+    result is still the reference's."""
+    x = torch.from_numpy(signals.audio_like((2, 1, 6000), seed=91)).double().cuda()
+    with pytest.raises(RuntimeError, match='strict mode'):
+        tac.stft(x, 1001, 250)
+    tac.set_strict(False)
+    try:
+        tac._ops._warned.clear()
+        with pytest.warns(tac.CompositeRouteWarning):
+            z = tac.stft(x, 1001, 250)
+        assert z.dtype == torch.float64
+        assert rel_err(host(z), torch_ref.stft(x.cpu(), 1001, 250).numpy()) < 1e-12
+    finally:
+        tac.set_strict(True)
+
+
 def test_hpss_mask_only_skips_the_masked_spectrograms(tac):
     """mask_only=True (beta_hpss.py:123-124) takes the `hpss_masks` op: the same kernels with NULL harm / perc pointers, i.e.
     without the two masked-spectrogram stores; masks bit-equal to the full call, equal widths (tile kernel) and unequal
@@ -1552,6 +1605,9 @@ def test_tables_follow_the_filterbank_and_window(tac):
     win.data.mul_(3.0)
     tac.invalidate()                                                  # everything
     assert rel_err(host(tac.realize(mel(x))), 9.0 * y0) < 1e-6
+    fb.data.mul_(2.0)
+    tac.invalidate(mel[2].filterbank.data)                            # through an alias that carries no tables: everything goes
+    assert rel_err(host(tac.realize(mel(x))), 18.0 * y0) < 1e-6
     spec = tac.Spectrogram(2048, 512, power=2.).cuda()(x)
     fb2 = tac.create_mel_filter(1025, 40, 0.0, 8000.0, False).cuda()
     a = host(tac.apply_filterbank(spec, fb2))

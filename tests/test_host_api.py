@@ -396,6 +396,23 @@ def test_gloo_overlapped_allgather(tmp_path, world):
         assert 'rank %d ok' % r in o
 
 
+def test_invalidate_through_an_alias_drops_everything():
+    """invalidate(t) drops only t's tables when t is the object they hang on; an alias that carries none (t.data, a view) cannot
+    name that object, so it invalidates globally instead of silently doing nothing (round-4 advisor finding)."""
+    from torchaudio_contrib_amd import _hip
+    t = torch.rand(8, 4)
+    t._tac_pack = ('stamp', 'tables')
+    e0 = _hip._epoch
+    _hip.invalidate(t)
+    assert not hasattr(t, '_tac_pack') and _hip._epoch == e0              # targeted
+    t._tac_pack = ('stamp', 'tables')
+    _hip.invalidate(t.data)                                                # an alias: nothing cached on it
+    assert _hip._epoch == e0 + 1, 'global invalidation'
+    assert _hip._stamp(t)[2] == e0 + 1                                     # every stamp taken before is now stale
+    _hip.invalidate(t[2:])
+    assert _hip._epoch == e0 + 2
+
+
 def test_forced_collective_in_a_group_of_one():
     """all_gather_batch(force_collective=True) runs the real collective at world size 1 (what the RCCL smoke test of a 1-GPU
     box relies on) and returns the shard unchanged, for both exchange methods and for the strided views the layers return."""

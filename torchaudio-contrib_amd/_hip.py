@@ -53,7 +53,9 @@ def _stamp(t):
 def invalidate(tensor=None):
     """Forget the tables derived from ``tensor`` (a window or filterbank), or — without an argument — from every
     tensor: they are rebuilt from the current contents on the next call.  Needed only after a write PyTorch's version
-    counter does not see (``t.data.mul_(2)``, raw-pointer writes); ordinary in-place ops are detected by themselves."""
+    counter does not see (``t.data.mul_(2)``, raw-pointer writes); ordinary in-place ops are detected by themselves.
+    Pass the tensor object the layers were given (``invalidate(module.filterbank)``): only its tables are dropped.  Passing an
+    alias that carries no tables itself (``module.filterbank.data``, a view) is allowed and invalidates everything."""
     global _epoch
     from . import _lazy
     if tensor is None:
@@ -62,12 +64,22 @@ def invalidate(tensor=None):
             _geometry_routes_clear()
             _lazy._plans.clear()
         return
+    carried = False
     for name in _CACHE_ATTRS:
         if hasattr(tensor, name):
+            carried = True
             try:
                 delattr(tensor, name)
             except Exception:
                 pass
+    with _lock:
+        carried = carried or any(k[0] == id(tensor) for g in _geometry_cache.values() for k in g.routes) \
+            or any(id(tensor) in k[:2] for k in _lazy._plans)
+    if not carried:
+        # nothing is cached ON this object: it is an alias of the tensor the tables hang on (`module.filterbank.data`, a view,
+        # a second wrapper of the same storage) — which object that is cannot be told from here, so everything goes
+        invalidate()
+        return
     # only this tensor's entries go: the tables of every other window / filterbank stay valid (a global epoch bump would
     # have each of them rebuilt, with a host synchronisation, on its next use)
     with _lock:

@@ -27,7 +27,14 @@ import torch
 from torch.utils._pytree import tree_map
 
 _enabled = True
-_plans = {}             # (window id, filterbank id, stft args, power, dB) -> _hip.MelPlan of the fused chain
+_plans = {}             # (window id, filterbank id, stft args, power, dB) -> _hip.MelPlan of the fused chain, or a negative
+                        # entry (_NO_PLAN, window, filterbank, layout) for a call no plan covers; mutated under _hip._lock
+_NO_PLAN = object()
+
+
+def _hip_lock():
+    from . import _hip
+    return _hip._lock
 
 
 def set_lazy_fusion(flag):
@@ -231,10 +238,16 @@ class DeferredSpectral(torch.Tensor):
         fb = self._fb
         key = (id(s.window), id(fb), s.args, self._power, db)
         plan = _plans.get(key)
-        if plan is not None and plan.window is s.window and plan.fb is fb and plan.matches(s.wave):
+        if type(plan) is tuple:                 # negative entry
+            if plan[1] is s.window and plan[2] is fb and plan[3] == (s.wave.shape, s.wave.stride(), s.wave.dtype):
+                return self._launch(db)         # ... for exactly this call: the general path, no new plan
+        elif plan is not None and plan.window is s.window and plan.fb is fb and plan.matches(s.wave):
             v = plan.launch(s.wave)
             if v is not None:
                 return v
+            with _hip_lock():                   # its launch was refused: remember that instead of rebuilding it on every call
+                _plans[key] = (_NO_PLAN, s.window, fb, (s.wave.shape, s.wave.stride(), s.wave.dtype))
+            return self._launch(db)
         v = self._launch(db)
         try:                                    # (a missing library / unsupported geometry was reported by _launch already)
             from . import _hip
@@ -242,12 +255,13 @@ class DeferredSpectral(torch.Tensor):
             plan = _hip.mel_plan(s.wave, s.window, fb, *s.args, float(self._power), db is not None, float(ref), float(amin))
         except Exception:                       # noqa: BLE001 — the plan is an optimisation only
             plan = None
-        if len(_plans) > 64:
-            _plans.clear()
-        if plan is not None:
-            _plans[key] = plan
-        else:
-            _plans.pop(key, None)
+        with _hip_lock():                       # (invalidate() walks and prunes this dict under the same lock)
+            if len(_plans) > 64:
+                _plans.clear()
+            if plan is not None:
+                _plans[key] = plan
+            else:
+                _plans[key] = (_NO_PLAN, s.window, fb, (s.wave.shape, s.wave.stride(), s.wave.dtype))
         return v
 
     def realize(self, db=None):

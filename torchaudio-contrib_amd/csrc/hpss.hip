@@ -377,6 +377,7 @@ __device__ __forceinline__ void hp_emit_block(float* scratch, int tid, int a_blk
                 dst[0] = lo4;
                 dst[1] = hi4;
             }
+            wave_lds_fence();               // (wave-synchronous transpose: every lane's slots are written before any lane reads)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int c = lane + 64 * k, r = c / CPR, sc = 4 * (c % CPR);
@@ -399,6 +400,7 @@ __device__ __forceinline__ void hp_emit_block(float* scratch, int tid, int a_blk
                     }
                 }
             }
+            wave_lds_fence();               // ... and read back before the next array's values overwrite them
         };
 #ifndef TAC_HPSS_ABL_ARRAYS
 #define TAC_HPSS_ABL_ARRAYS 4  // timing-only ablation: how many of the four result arrays are stored
@@ -925,6 +927,22 @@ int tac_hpss_f32(const float* mag, int64_t rows, int32_t n_freqs, int32_t n_fram
     if (kernel_f < 1 || kernel_t < 1 || !(kernel_f & 1) || !(kernel_t & 1) || kernel_f > 32 || kernel_t > 32)
         return TAC_E_UNSUPPORTED;
     if (kernel_f / 2 >= n_freqs || kernel_t / 2 >= n_frames) return TAC_E_SHORT_INPUT;      // reflect padding needs pad < size
+    {
+        // the outputs must not overlap the input or one another (header, (10)): every kernel reads halos of mag while other
+        // workgroups store, and the two-launch route parks its first medians in mask_perc.  Checked on the address ranges the
+        // strides span (non-negative strides; anything else is left to the caller).
+        if (stride_r >= 0 && stride_f >= 0 && stride_t >= 0) {
+            const unsigned long long span = 4ull * (unsigned long long)((rows - 1) * stride_r + (long long)(n_freqs - 1) * stride_f +
+                                                                        (long long)(n_frames - 1) * stride_t + 1);
+            const void* ptrs[5] = {mag, mask_harm, mask_perc, harm, perc};
+            for (int i = 0; i < 5; ++i)
+                for (int j = i + 1; j < 5; ++j) {
+                    if (!ptrs[i] || !ptrs[j]) continue;
+                    const unsigned long long a = reinterpret_cast<unsigned long long>(ptrs[i]), b = reinterpret_cast<unsigned long long>(ptrs[j]);
+                    if (a < b + span && b < a + span) return TAC_E_INVALID;
+                }
+        }
+    }
     const long long tiles = rows * ((n_freqs + HP_TILE - 1) / HP_TILE) * ((n_frames + HP_TILE - 1) / HP_TILE);
     if (kernel_f == kernel_t && kernel_f >= 9 && tiles < 0x7fffffffLL) {
 #define TAC_HPSS_CASE(K)                                                                                                   \

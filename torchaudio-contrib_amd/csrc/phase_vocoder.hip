@@ -54,13 +54,18 @@ struct pv_math<float> {
         const bool tiny = m < 8.673617379884035e-19f, huge = m > 1.152921504606847e18f;          // 2^-60, 2^60
         const float up = tiny ? 1.2379400392853803e27f : (huge ? 8.077935669463161e-28f : 1.0f);  // 2^90, 2^-90
         const float dn = tiny ? 8.077935669463161e-28f : (huge ? 1.2379400392853803e27f : 1.0f);
-        const float x = re * up, y = im * up;
+        // an infinite component: the angle atan2 gives it (0, +-pi/2, pi, +-pi/4, +-3 pi/4: infinite components count as +-1,
+        // finite ones as 0) and an infinite magnitude — inf * 2^-90 = inf, rsq(inf) = 0 and inf * 0 would make the PHASOR NaN and
+        // poison every later frame of the bin, where the reference only loses the frames that touch the value
+        const bool inf = m == __builtin_inff();
+        const float x = inf ? (fabsf(re) == m ? copysignf(1.0f, re) : 0.0f) : re * up;
+        const float y = inf ? (fabsf(im) == m ? copysignf(1.0f, im) : 0.0f) : im * up;
         const float n2 = fmaf(x, x, y * y);
         const float r = __builtin_amdgcn_rsqf(n2);
         const bool zero = !(n2 > 0.0f) && n2 == n2;                // (+0: the reference's atan2(0, 0) = 0; NaN stays NaN)
         u.x = zero ? 1.0f : x * r;
         u.y = zero ? 0.0f : y * r;
-        n = zero ? 0.0f : (n2 * r) * dn;
+        n = zero ? 0.0f : (inf ? m : (n2 * r) * dn);
     }
     static __device__ __forceinline__ acc_t open(ang_t a) { return a; }
     static __device__ __forceinline__ acc_t step(acc_t acc, ang_t a1, ang_t a0, float) {
