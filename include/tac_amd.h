@@ -101,18 +101,12 @@ int tac_melspec_f32(const float* wave, const float* window, const tac_stft_desc*
  *      for n_fft = 2048 the pack is the lane layout of the streaming kernel (lane l owns bands l, 64 + l, ...; at most
  *      256 bands): wpack = float[steps][64][2] zero-padded pair weights, desc = int32[slots][64] first bins,
  *      info_host = {weight floats, slots, 64, total steps, steps of slot 0..3}; wpack_cap >= 8192.
- *      n_fft = TAC_PACK_PIECES_2048 asks for the PIECE layout of the fft_length-2048 streaming kernel instead (round 4): a lane
- *      runs three segments of L0 / L1 / L2 four-tap steps, each holding a piece of a band; a band takes up to three pieces in
- *      adjacent lanes, summed after the contraction with row-shift adds, the lane of the last piece stores the band.  12
- *      steps instead of 18 for the standard 128-band bank.  wpack = float[steps][64][4], desc = int32[768] (first bins at
- *      [s * 64 + l], stored band or -1 at [256 + ...], piece index at [512 + ...]), info_host = {weight floats, 3, 64, total
- *      steps, L0, L1, L2, TAC_PIECES_MARK}; TAC_E_UNSUPPORTED when no segment triple of the library fits the bank (callers
- *      then pack with n_fft = 2048).  float32 waveforms only (the coded formats keep the classic layout).
- *      tac_melbank_plan_pieces_host: the same plan for a HOST copy of the bank into host arrays (seg_steps int32[3]; first /
- *      band / index int32[192]; weights float[weights_cap >= 256 * (L0 + L1 + L2)]) — no device access; tests emulate the
- *      kernel's contraction on it. */
-#define TAC_PACK_PIECES_2048 (-2048)
-#define TAC_PIECES_MARK (-77)
+ *      tac_melbank_plan_pieces_host (a host tool, no device access): the PIECE layout of round 4 for a host copy of the bank —
+ *      a lane runs three segments of L0 / L1 / L2 four-tap steps, each holding a piece of a band; a band takes up to three
+ *      pieces in adjacent lanes; 12 steps instead of 18 for the standard 128-band bank.  seg_steps int32[3]; first / band /
+ *      index int32[192]; weights float[weights_cap >= 256 * (L0 + L1 + L2)]; TAC_E_UNSUPPORTED when no segment triple fits.
+ *      The kernel form that contracted this layout measured 3 - 5 % slower than the lane layout and is not shipped
+ *      (tools/ablation/README.md); tests emulate its contraction on the plan. */
 int tac_melbank_pack(const float* fb, int32_t n_freqs, int32_t n_mels, int32_t n_fft, float* wpack,
                      int32_t wpack_cap, int32_t* desc, int32_t desc_cap, int32_t* info_host, void* stream);
 int tac_melbank_plan_pieces_host(const float* fb_host, int32_t n_freqs, int32_t n_mels, int32_t* seg_steps, int32_t* first,

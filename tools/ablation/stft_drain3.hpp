@@ -129,7 +129,7 @@ stft_drain3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
     using F = WaveFft<NC, E>;
     using D = Drain3Cfg<NC, E, MODE, TW, DW>;
     static_assert(F::G == 1 && E == 16 && radix_at(NC, 0) == 16, "fft_length 2048");
-    static_assert(TAC_S3_SWZ, "swizzled exchange");
+    
     constexpr int WAVES = TW + DW;
     constexpr int XA_BYTES = D::XA;
     constexpr int LENF = D::LENF;
@@ -549,7 +549,7 @@ stft_drain3i_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
     using F = WaveFft<NC, E>;
     using D = Drain3iCfg<NC, E, MODE, TW, DW>;
     static_assert(F::G == 1 && E == 16 && radix_at(NC, 0) == 16, "fft_length 2048");
-    static_assert(TAC_S3_SWZ, "swizzled exchange");
+    
     constexpr int WAVES = TW + DW;
     constexpr int XA_BYTES = D::XA;
     constexpr int LENF = D::LENF;

@@ -316,23 +316,6 @@ def _melbank_pack(fb, n_fft):
     return result
 
 
-#: A/B knob: TAC_MEL_PIECES=1 selects the piece layout of the filterbank (csrc/mel_pieces.hpp) for the fft_length-2048 fused
-#: kernel.  Off by default: correct, 12 instead of 18 contraction steps, and 4.6 % SLOWER (tools/ablation/README.md, round 4)
-MEL_PIECES = os.environ.get('TAC_MEL_PIECES', '0') == '1'
-
-
-def _melbank_pack_f32_2048(fb):
-    """The pack the float32 fused kernel at fft_length 2048 takes: the classic lane layout, or — with TAC_MEL_PIECES=1 — the
-    piece layout (csrc/mel_pieces.hpp: a band split over up to three adjacent lanes, 12 instead of 18 contraction steps for the
-    standard 128-band bank) when the bank fits one of the library's segment triples.  (The coded-input kernels always keep the
-    classic layout.)"""
-    if MEL_PIECES:
-        pieces = _melbank_pack(fb, _native.PACK_PIECES_2048)
-        if pieces is not None:
-            return pieces
-    return _melbank_pack(fb, 2048)
-
-
 def _filterbank_plan(fb):
     """(device int32 plan, host ctypes copy): non-zero bin range per 16-band tile, computed by a device kernel.
     The plan rides on the filterbank tensor object itself (a module's constant buffer is scanned once — the only
@@ -409,7 +392,7 @@ def mel_plan(wave, window, fb, n_fft, hop, win_length, center, pad_mode, normali
     g = geometry(wave, n_fft, hop, win_length, center, pad_mode, normalized, onesided)
     if g.flatten or g.desc is None or fb.shape[0] != g.n_bins or _fused_mel_route(g, fb, power) != 'sparse':
         return None
-    wpack, dsc, info = _melbank_pack_f32_2048(fb) if g.n_fft == 2048 else _melbank_pack(fb, g.n_fft)
+    wpack, dsc, info = _melbank_pack(fb, g.n_fft)
     p = MelPlan()
     p.fn = _native.lib().tac_melspec_sparse_f32
     p.window, p.fb, p.win_stamp, p.fb_stamp = window, fb, _stamp(window), _stamp(fb)
@@ -448,7 +431,7 @@ def melspectrogram(wave, window, fb, n_fft, hop, win_length, center, pad_mode, n
     src = _rows_of(wave, g)
     out = torch.empty(g.lead + (g.n_frames, n_mels), dtype=torch.float32, device=wave.device)
     if route == 'sparse':          # band-sparse contraction (the faster form for triangular banks)
-        wpack, desc, info = _melbank_pack_f32_2048(fb) if g.n_fft == 2048 else _melbank_pack(fb, g.n_fft)
+        wpack, desc, info = _melbank_pack(fb, g.n_fft)
         with _native.on_device(wave.device):
             rc = _native.lib().tac_melspec_sparse_f32(
                 _native.ptr(src), _native.ptr(window), g.desc, float(power), _native.ptr(wpack), _native.ptr(desc),

@@ -23,7 +23,6 @@ TAC_E_LAUNCH = -4
 
 PAD_MODES = {'constant': 0, 'reflect': 1, 'replicate': 2, 'circular': 3}
 SAMPLES_F32, SAMPLES_I16, SAMPLES_MULAW_U8, SAMPLES_MULAW_I64 = 0, 1, 2, 3
-PACK_PIECES_2048, PIECES_MARK = -2048, -77          # tac_melbank_pack's piece layout (include/tac_amd.h)
 
 EXPORTS = (
     'tac_strerror', 'tac_last_hip_error', 'tac_abi_version', 'tac_num_frames', 'tac_num_bins',

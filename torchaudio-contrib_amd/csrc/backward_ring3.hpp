@@ -156,7 +156,7 @@ melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ 
         load_tw1(tw1);
         F::template pass_write<0, true>(v, xa, t, t);
         wave_lds_fence();
-        s3_readback_pass1<F>(v, xa, t);                     // (single ds_read_b64: TAC_S3_B64, melspec_stream3.hpp)
+        s3_readback_pass1<F>(v, xa, t);                     // (single ds_read_b64s, melspec_stream3.hpp)
         F::template pass_twiddle<1, true>(v, tw1);
         F::template pass_butterflies<1>(v);
         F::exchange_1_2_in_registers(v);
@@ -321,7 +321,6 @@ melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ 
             const f4* wl = reinterpret_cast<const f4*>(winl) + t;
             const cf* const src = xa + lds_pad(t);
             cf acc[E];
-#if TAC_S3_B64
             s3_read_strided<0, 8>(&acc[0], src);            // (two batches of eight: the kernel sits at its register cap)
 #pragma unroll
             for (int uu = 0; uu < E / 4; ++uu) {
@@ -336,15 +335,6 @@ melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ 
                 acc[2 * uu] = cmul_elem(acc[2 * uu], mkc(x.x, -x.y));
                 acc[2 * uu + 1] = cmul_elem(acc[2 * uu + 1], mkc(x.z, -x.w));
             }
-#else
-#pragma unroll
-            for (int uu = 0; uu < E / 2; ++uu) {
-                const f4 x = wl[uu * 64];
-                const cf r0 = src[lds_pad_c((2 * uu) * 64)], r1 = src[lds_pad_c((2 * uu + 1) * 64)];
-                acc[2 * uu] = cmul_elem(r0, mkc(x.x, -x.y));                 // (Re, -Im) R[m] · window / 2
-                acc[2 * uu + 1] = cmul_elem(r1, mkc(x.z, -x.w));
-            }
-#endif
 #pragma unroll
             for (int j = 0; j < R; ++j) acc[j] = cadd(acc[j], ring[j]);
 #if TAC_BR3_ABL == 2

@@ -394,37 +394,14 @@ static int launch_stream(FrameGeom g, const Tables& tb, const SparseArgs& sm, co
     // Round 3: the three-waves-per-SIMD form (melspec_stream3.hpp) is the route; TAC_STREAM2=1 selects round 2's two-frame
     // rotation (kept for A/B runs and for tools/stream_timing.py)
     static const bool two_waves = getenv("TAC_STREAM2") != nullptr;
-    // 12 waves per CU ship; TAC_S3_WAVES=15 selects the 128-register form (four waves on three of the SIMDs), measured
-    // 11 % SLOWER at cfg-2 (0.125 vs 0.113 ms: its 48 bytes of scratch and the chunked contraction cost more than the extra
-    // waves hide — profiles/r03/ab_stream3.txt)
-    static const int waves_f32 = [] { const char* e = getenv("TAC_S3_WAVES"); return e ? atoi(e) : S3_WAVES; }();
+    // 12 waves per CU (a 15-wave / 128-register form measured 11 % slower: tools/ablation/README.md)
     constexpr bool coded = FMT != FMT_F32;
-    const int waves3 = (!coded && waves_f32 == S3_WAVES_F32 && stream3_lds_bytes<NC, E>(sm.wtot, S3_WAVES_F32, false) <= 160 * 1024)
-                           ? S3_WAVES_F32 : S3_WAVES;
+    constexpr int waves3 = S3_WAVES;
     const size_t lds3 = stream3_lds_bytes<NC, E>(sm.wtot, waves3, coded);
-    const bool pieces = info_host[7] == S3_PIECES_MARK;                    // piece layout of the bank (mel_pieces.hpp)
-    if (pieces && (coded || two_waves || waves3 != S3_WAVES || info_host[1] != 3 || sm.n_mels > 128 || lds3 > 160 * 1024)) return TAC_E_UNSUPPORTED;
     if (!two_waves && lds3 <= 160 * 1024) {
         void (*k3)(FrameGeom, Tables, StreamArgs);
-        int fast1_name = 0;
         if constexpr (FMT == FMT_F32) {
-            if (pieces) {
-                constexpr int W = S3_WAVES;
-                const int code = 1000 + 100 * info_host[4] + 10 * info_host[5] + info_host[6];
-                switch (code) {
-#define TAC_PIECES_CASE(C)                                                                                                  \
-    case C: k3 = pow2 ? melspec_stream3_kernel<NC, E, true, FMT, C, W> : melspec_stream3_kernel<NC, E, false, FMT, C, W>; break;
-                    TAC_PIECES_CASE(1345) TAC_PIECES_CASE(1456)
-#undef TAC_PIECES_CASE
-                    default: return TAC_E_UNSUPPORTED;
-                }
-                fast1_name = code;
-            } else if (waves3 == S3_WAVES_F32) {
-                constexpr int W = S3_WAVES_F32;
-                if (fast2 && fshort) k3 = pow2 ? melspec_stream3_kernel<NC, E, true, FMT, ST_FAST_STEPS1_SHORT, W> : melspec_stream3_kernel<NC, E, false, FMT, ST_FAST_STEPS1_SHORT, W>;
-                else if (fast2) k3 = pow2 ? melspec_stream3_kernel<NC, E, true, FMT, ST_FAST_STEPS1, W> : melspec_stream3_kernel<NC, E, false, FMT, ST_FAST_STEPS1, W>;
-                else k3 = pow2 ? melspec_stream3_kernel<NC, E, true, FMT, 0, W> : melspec_stream3_kernel<NC, E, false, FMT, 0, W>;
-            } else {
+            {
                 constexpr int W = S3_WAVES;
                 if (fast2 && fshort) k3 = pow2 ? melspec_stream3_kernel<NC, E, true, FMT, ST_FAST_STEPS1_SHORT, W> : melspec_stream3_kernel<NC, E, false, FMT, ST_FAST_STEPS1_SHORT, W>;
                 else if (fast2) k3 = pow2 ? melspec_stream3_kernel<NC, E, true, FMT, ST_FAST_STEPS1, W> : melspec_stream3_kernel<NC, E, false, FMT, ST_FAST_STEPS1, W>;
@@ -438,7 +415,7 @@ static int launch_stream(FrameGeom g, const Tables& tb, const SparseArgs& sm, co
         m.chunk = (total + b3 - 1) / b3;
         m.probe = (g_clock_probe && g_clock_probe_pairs >= b3) ? g_clock_probe : nullptr;
         {
-            const int fast1 = fast1_name ? fast1_name : ((FMT == FMT_F32 && fast2) ? (fshort ? ST_FAST_STEPS1_SHORT : ST_FAST_STEPS1) : 0);
+            const int fast1 = (FMT == FMT_F32 && fast2) ? (fshort ? ST_FAST_STEPS1_SHORT : ST_FAST_STEPS1) : 0;
             set_last_route("melspec_stream3_kernel<%d, %d, %s, %d, %d, %d>", NC, E, pow2 ? "true" : "false", FMT, fast1, waves3);
         }
         TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(k3), 160 * 1024));
@@ -691,36 +668,6 @@ static int pack_lanes(const std::vector<float>& h, int n_freqs, int n_mels, floa
     return TAC_OK;
 }
 
-// Piece layout (mel_pieces.hpp) for the fft_length-2048 streaming kernel: wpack = [total steps][64][4] weights, desc = first bins
-// at [s * 64 + l], the band a lane stores (or -1) at [256 + s * 64 + l], the piece index at [512 + s * 64 + l];
-// info_host = {weight floats, 3, 64, total steps, L0, L1, L2, PIECES_MARK}.
-static int pack_pieces(const std::vector<float>& h, int n_freqs, int n_mels, float* wpack, int wpack_cap, int32_t* desc,
-                       int desc_cap, int32_t* info_host, hipStream_t stream) {
-    PiecePlan p;
-    // (the kernel's deferred epilogue carries two band values per lane: n_mels <= 128; the planner itself takes up to 192)
-    if (desc_cap < 768 || n_mels > 128 || !plan_pieces(h.data(), n_freqs, n_mels, StreamCfg<1024, 16>::PROW, &p)) return TAC_E_UNSUPPORTED;
-    const long long wtot = 256LL * p.total_steps;
-    if (wtot > wpack_cap || stream3_lds_bytes<1024, 16>((int)wtot, S3_WAVES, false) > 160 * 1024) return TAC_E_UNSUPPORTED;
-    std::vector<int32_t> d(768, 0);
-    for (int e = 0; e < MP_SEGS * 64; ++e) {
-        d[e] = p.first[e];
-        d[256 + e] = p.band[e];
-        d[512 + e] = p.index[e];
-    }
-    TAC_HIP(hipMemcpyAsync(wpack, p.w.data(), p.w.size() * sizeof(float), hipMemcpyHostToDevice, stream));
-    TAC_HIP(hipMemcpyAsync(desc, d.data(), d.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-    TAC_HIP(hipStreamSynchronize(stream));
-    info_host[0] = (int32_t)wtot;
-    info_host[1] = MP_SEGS;
-    info_host[2] = 64;
-    info_host[3] = p.total_steps;
-    info_host[4] = p.L[0];
-    info_host[5] = p.L[1];
-    info_host[6] = p.L[2];
-    info_host[7] = S3_PIECES_MARK;
-    return TAC_OK;
-}
-
 }  // namespace tac
 
 extern "C" {
@@ -746,13 +693,7 @@ int tac_melbank_pack(const float* fb, int32_t n_freqs, int32_t n_mels, int32_t n
                      int32_t wpack_cap, int32_t* desc, int32_t desc_cap, int32_t* info_host, void* stream) {
     using namespace tac;
     if (!fb || !wpack || !desc || !info_host || n_freqs <= 0 || n_mels <= 0) return TAC_E_INVALID;
-    if (n_fft == TAC_PACK_PIECES_2048) {                                         // the piece layout of the 2048 streaming kernel
-        if (n_freqs != 1025) return TAC_E_UNSUPPORTED;
-        std::vector<float> hp((size_t)n_freqs * n_mels);
-        TAC_HIP(hipMemcpyAsync(hp.data(), fb, hp.size() * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
-        TAC_HIP(hipStreamSynchronize((hipStream_t)stream));
-        return pack_pieces(hp, n_freqs, n_mels, wpack, wpack_cap, desc, desc_cap, info_host, (hipStream_t)stream);
-    }
+    if (n_fft < 0) return TAC_E_UNSUPPORTED;          // (round 4's piece layout, TAC_PACK_PIECES_2048: its kernel form is not shipped)
     // n_fft == 0: pack for the standalone filterbank kernel (32 lane groups, any number of bins)
     const int groups = n_fft == 0 ? FBS_WAVES * 4 : sparse_groups_for(n_fft);
     if (groups == 0 || (n_fft != 0 && n_freqs != n_fft / 2 + 1)) return TAC_E_UNSUPPORTED;

@@ -14,29 +14,19 @@
 
 namespace tac {
 
-constexpr int S3_WAVES = 12;          // what ships
-constexpr int S3_PIECES_MARK = -77;   // info_host[7] of a piece-layout pack (== TAC_PIECES_MARK, include/tac_amd.h)
-constexpr int S3_WAVES_F32 = 15;      // A/B form (TAC_S3_WAVES=15): as many 128-register waves as the LDS holds next to a 128-band bank
+constexpr int S3_WAVES = 12;
 
-#ifndef TAC_S3_ABL_NOTABLES
-#define TAC_S3_ABL_NOTABLES 0
-#endif
-#ifndef TAC_S3_ABL_NOWEIGHTS
-#define TAC_S3_ABL_NOWEIGHTS 0
-#endif
-#ifndef TAC_S3_ABL_MFMA_X
-#define TAC_S3_ABL_MFMA_X 0   // timing-only ablation (wrong results): first exchange as MFMA transposes (see the frame loop)
-#endif
-#ifndef TAC_S3_SWZ
-#define TAC_S3_SWZ 1          // first exchange XOR-swizzled instead of padded, partner exchange dense (no bank conflicts on either): complex rows
-                              // -1.05 %, power rows -1.3 %, fused kernel -0.2 % (same-process A/B, bit-identical results); 0 = the padded layout
-#endif
-// bytes of one wave's exchange area.  Padded layout: NC + NC / 16 + 1 slots.  Swizzled layout (TAC_S3_SWZ): the transform needs
-// NC dense slots, the gather path of edge frames still writes padded slots (<= 8696 B), and areas are 128-byte multiples so that
-// the swizzle is one XOR on the byte address
+// Frozen in round 5 (the knobs, their ablation branches and the piece-layout / 15-wave / stamp variants of this kernel are in
+// tools/ablation/stream3_lab_knobs_r05.patch with the measurement that decided each): first exchange XOR-swizzled instead of
+// padded and partner exchange dense (no bank conflicts on either side: complex rows -1.05 %, power rows -1.3 %, fused kernel
+// -0.2 %); exchange read-backs as single ds_read_b64 (2 LDS cycles each; hipcc merges pairs into ds_read2_b64 at 8: -1.2 ... -2.0 %);
+// the |X|^2 row written as eight ds_write2st64_b32 (-0.65 %); the lane's eight R2C twiddles in registers (-0.6 %, -1.5 % together
+// with the row pairs); the wave's first frame requested behind the table loads; frames dealt from the middle of the chunk.
+// bytes of one wave's exchange area: the transform needs NC dense slots (swizzled layout), the gather path of edge frames still
+// writes padded slots (<= 8696 B), and areas are 128-byte multiples so that the swizzle is one XOR on the byte address
 template <class F>
 __host__ __device__ constexpr int s3_xa_bytes() {
-    return TAC_S3_SWZ ? (((F::NC + F::NC / 16 - 1) * (int)sizeof(cf) + 127) & ~127) : (((int)(F::PADDED * sizeof(cf)) + 15) & ~15);
+    return ((F::NC + F::NC / 16 - 1) * (int)sizeof(cf) + 127) & ~127;
 }
 
 // exchange areas + bank weights + pass-1 twiddles + frame counter + R2C twiddle table + window table [+ mu-law table]
@@ -46,51 +36,6 @@ __host__ __device__ inline size_t stream3_lds_bytes(int wtot, int waves, bool co
     size_t xa = (size_t)s3_xa_bytes<typename C::F>();
     return (size_t)waves * xa + (((size_t)wtot * 4 + 15) & ~(size_t)15) + ST_TW_BYTES + 16 + 64 * (C::F::NPAIR + E) * sizeof(cf) + (coded ? 1024 : 0);
 }
-
-#ifndef TAC_S3_B64
-#define TAC_S3_B64 1          // exchange read-backs as single ds_read_b64 (2 LDS cycles each) instead of hipcc's merged ds_read2_b64 (8 per pair):
-                              // -1.2 ... -2.0 % on the fused kernel, same-process A/B on three boxes (tools/ablation/README.md, round 4); 0 = hipcc's form
-#endif
-#ifndef TAC_S3_BPERM
-#define TAC_S3_BPERM 0        // A/B: R2C partners fetched lane to lane (ds_bpermute_b32) instead of through the exchange area
-#endif
-#ifndef TAC_S3_NODIV
-#define TAC_S3_NODIV 0        // A/B: (row, frame) of a dealt frame by conditional subtraction from the chunk's first (no division per frame)
-#endif
-#ifndef TAC_S3_PTW_EARLY
-#define TAC_S3_PTW_EARLY 0    // A/B: the R2C twiddle reads issued ahead of pass 2 (in flight behind its butterflies) instead of behind the partner reads
-#endif
-#ifndef TAC_S3_ROW_ST64
-#define TAC_S3_ROW_ST64 1     // the |X|^2 row written as eight ds_write2st64_b32 (two bins 64 apart per instruction) instead of hipcc's mix of
-                              // twelve ds_write_b32 + three write2st64: -0.65 % alone (same-process A/B, round 4); 0 = hipcc's form
-#endif
-#ifndef TAC_S3_NOFENCE0
-#define TAC_S3_NOFENCE0 0     // A/B: no compiler fence between the first butterfly and its exchange writes (the writes may start early)
-#endif
-#ifndef TAC_S3_ADDTID
-#define TAC_S3_ADDTID 0       // A/B: lower half of the |X|^2 row written with ds_write_addtid_b32 (2 LDS cycles, no address register)
-#endif
-#ifndef TAC_S3_STAMPS
-#define TAC_S3_STAMPS 0       // debug build of tools/r04/s3_stamps.py: per-wave cycle sums of the frame loop's stages overwrite the head of out[]
-#endif
-#if TAC_S3_STAMPS
-#define S3_STAMP(i)                                                          \
-    do {                                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                   \
-        const unsigned long long now_ = __builtin_readcyclecounter();        \
-        stamp_acc[i] += now_ - stamp_last;        /* wave-uniform: SGPRs */  \
-        stamp_last = now_;                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                   \
-    } while (0)
-#else
-#define S3_STAMP(i) do { } while (0)
-#endif
-#ifndef TAC_S3_PIECE_BATCH
-#define TAC_S3_PIECE_BATCH 5  // steps per request batch of the piece-layout contraction (two batches in flight)
-#endif
-#ifndef TAC_S3_W0_REGS
-#define TAC_S3_W0_REGS 0      // A/B: the four weight quads of band slot 0 live in registers (16 VGPRs) instead of being re-read per frame
-#endif
 
 // LDS byte offset of a pointer into the workgroup's shared memory (the low half of its flat address)
 __device__ __forceinline__ unsigned lds_offset_of(const void* p) { return (unsigned)reinterpret_cast<unsigned long long>(p); }
@@ -119,7 +64,7 @@ __device__ __forceinline__ void lds_wait_all(cf (&a)[8], cf& b) {
                  :: "memory");
 }
 
-// ---- TAC_S3_SWZ: the first exchange without padding.  Lane tt's first-pass output k (element 16 tt + k) lives in slot
+// ---- the first exchange without padding.  Lane tt's first-pass output k (element 16 tt + k) lives in slot
 // 16 tt + (k ^ (tt & 15)): for a fixed k the sixteen lanes of a ds_write_b64 group hit sixteen different slots mod 16 (all 32
 // banks once); lane t of pass 1 reads element t + 64 q from block B = (t >> 4) + 4 q, slot 16 B + ((t & 15) ^ (B & 15)), and
 // B & 15 = (t >> 4) + 4 (q & 3): the 32 lanes of a ds_read_b64 group cover two whole 16-slot blocks 16 slots apart (all 64 banks
@@ -175,7 +120,6 @@ __device__ __forceinline__ void s3_r2c_partners_dense(const cf (&v)[16], cf* xa,
 // (1) operands of pass 1 back from the exchange area
 template <class F>
 __device__ __forceinline__ void s3_readback_pass1(cf (&v)[16], const cf* xa, int t) {
-#if TAC_S3_B64
     const unsigned ra = lds_offset_of(xa + lds_pad(t));
     auto rd = [&](auto qc) { constexpr int q = decltype(qc)::value; v[q] = lds_read_b64_single<lds_pad_c(q * (F::NC / 16)) * 8>(ra); };
     rd(std::integral_constant<int, 0>{}); rd(std::integral_constant<int, 1>{}); rd(std::integral_constant<int, 2>{}); rd(std::integral_constant<int, 3>{});
@@ -183,15 +127,11 @@ __device__ __forceinline__ void s3_readback_pass1(cf (&v)[16], const cf* xa, int
     rd(std::integral_constant<int, 8>{}); rd(std::integral_constant<int, 9>{}); rd(std::integral_constant<int, 10>{}); rd(std::integral_constant<int, 11>{});
     rd(std::integral_constant<int, 12>{}); rd(std::integral_constant<int, 13>{}); rd(std::integral_constant<int, 14>{}); rd(std::integral_constant<int, 15>{});
     lds_wait_all(v);
-#else
-    F::template pass_readback<1>(v, xa, t);
-#endif
 }
 // (2) the R2C partners Z[NC - k] of the lane's eight pairs and Z[NC / 2], from the upper half of the spectrum in the exchange area
 template <class F>
 __device__ __forceinline__ void s3_read_partners(const cf (&v)[16], const cf* xa, cf (&zm)[8], cf& zmid, int t) {
     constexpr int NC = F::NC;
-#if TAC_S3_B64
     static_assert(F::NPAIR == 8, "eight partners per lane");
     const unsigned pa = lds_offset_of(xa + lds_pad(NC - t) - lds_pad_c(7 * F::LPF));      // partner of pair 7; pair p sits (7 - p) * 68 slots above
     auto rd = [&](auto pc) { constexpr int p = decltype(pc)::value; zm[p] = lds_read_b64_single<lds_pad_c((7 - p) * F::LPF) * 8>(pa); };
@@ -200,35 +140,16 @@ __device__ __forceinline__ void s3_read_partners(const cf (&v)[16], const cf* xa
     zmid = lds_read_b64_single<0>(lds_offset_of(xa + lds_pad(NC / 2)));
     lds_wait_all(zm, zmid);
     if (t == 0) zm[0] = v[F::reg_of_spectrum(0)];
-#else
-    const cf* const pb = xa + lds_pad(NC - t);
-#pragma unroll
-    for (int p = 0; p < F::NPAIR; ++p) {
-        const cf z = pb[-lds_pad_c(p * F::LPF)];
-        zm[p] = (p == 0 && t == 0) ? v[F::reg_of_spectrum(0)] : z;
-    }
-    zmid = xa[lds_pad(NC / 2)];
-#endif
 }
-// ... after the butterflies of the last pass: the half write of the spectrum, then the partners (or lane to lane: TAC_S3_BPERM)
+// ... after the butterflies of the last pass: the half write of the spectrum, then the partners
 template <class F>
 __device__ __forceinline__ void s3_r2c_partners(const cf (&v)[16], cf* xa, cf (&zm)[8], cf& zmid, int t) {
-#if TAC_S3_BPERM
-    F::r2c_partners_bpermute(v, zm, zmid, t);
-#elif TAC_S3_SWZ
     s3_r2c_partners_dense<F>(v, xa, zm, zmid, t);
-#else
-    wave_lds_fence();
-    F::template pass_write<2, true>(v, xa, t, t);
-    wave_lds_fence();
-    s3_read_partners<F>(v, xa, zm, zmid, t);
-#endif
 }
 // eight / sixteen complex values 64 slots apart starting at `first` (a padded slot address of the exchange area)
 template <int N0, int CNT>
 __device__ __forceinline__ void s3_read_strided(cf* dst, const cf* first) {
     static_assert(CNT == 8 || CNT == 16, "eight or sixteen values");
-#if TAC_S3_B64
     const unsigned ra = lds_offset_of(first);
     auto rd = [&](auto qc) { constexpr int q = decltype(qc)::value; if constexpr (q < CNT) dst[q] = lds_read_b64_single<lds_pad_c((N0 + q) * 64) * 8>(ra); };
     rd(std::integral_constant<int, 0>{}); rd(std::integral_constant<int, 1>{}); rd(std::integral_constant<int, 2>{}); rd(std::integral_constant<int, 3>{});
@@ -237,10 +158,6 @@ __device__ __forceinline__ void s3_read_strided(cf* dst, const cf* first) {
     rd(std::integral_constant<int, 12>{}); rd(std::integral_constant<int, 13>{}); rd(std::integral_constant<int, 14>{}); rd(std::integral_constant<int, 15>{});
     if constexpr (CNT == 16) lds_wait_all(*reinterpret_cast<cf(*)[16]>(dst));
     else lds_wait_all8(dst);
-#else
-#pragma unroll
-    for (int q = 0; q < CNT; ++q) dst[q] = first[lds_pad_c((N0 + q) * 64)];
-#endif
 }
 
 // ---- set-up shared by the one-frame-per-wave kernels (this file, stft_stream3.hpp): the loop-invariant tables into LDS.
@@ -297,23 +214,10 @@ struct S3Setup {
     }
 };
 
-#ifndef TAC_S3_PTW_REGS
-#define TAC_S3_PTW_REGS 1     // the lane's eight R2C twiddles live in registers (16 VGPRs: the kernel sits at 156 of 168) instead of four
-#endif                        // ds_read_b128 per frame: -0.6 % alone, -1.5 % together with TAC_S3_ROW_ST64 (same-process A/B, round 4)
-#ifndef TAC_S3_LDS_EXCHANGE
-#define TAC_S3_LDS_EXCHANGE 0
-#endif
-#ifndef TAC_S3_CHUNK
-#define TAC_S3_CHUNK 5
-#endif
-#ifndef TAC_S3_WIN_REGS
-#define TAC_S3_WIN_REGS 0
-#endif
 // FAST1: 0 = any bank the lane layout takes; otherwise the number of steps of slot 1 in the (4, FAST1)-step two-slot layout of
 // a 128-band bank (what tac_melbank_pack produces for the standard mel banks): the contraction fully unrolled
 // FMT: sample format of the frame load (FMT_*): float32, int16 PCM, mu-law codes as uint8 / int64 (converted in registers)
-// WAVES: waves per workgroup (= per CU).  12 is three per SIMD; 15 (four on three of the SIMDs: what the LDS holds next to a
-// 128-band bank) caps the registers at 128, which costs a handful of loop-invariant reloads per frame
+// WAVES: waves per workgroup (= per CU): 12, three per SIMD
 template <int NC, int E, bool POW2, int FMT, int FAST1, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64, (WAVES + 3) / 4)
 melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
@@ -323,12 +227,6 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     constexpr int XA_BYTES = s3_xa_bytes<F>();
     static_assert(XA_BYTES >= (int)(C::PROW * 4), "the power row fits the exchange area");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-#ifndef TAC_S3_CYCLES
-#define TAC_S3_CYCLES 0
-#endif
-#if TAC_S3_CYCLES
-    const unsigned long long wall_entry = wall_clock64();
-#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -341,41 +239,19 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     const unsigned T = (unsigned)g.n_frames;
     const int t = lane;
 
-#ifndef TAC_S3_ROTATE_DEAL
-#define TAC_S3_ROTATE_DEAL 1
-#endif
     // the i-th frame dealt is frame (i + nloc / 2) mod nloc of the chunk: a chunk is often a whole row, whose first and last frames
     // touch the padding and take the slower gather path — they are dealt in the middle of the run, not as its tail
-    const int deal_shift = TAC_S3_ROTATE_DEAL ? (nloc >> 1) : 0;
+    const int deal_shift = nloc >> 1;
     auto place = [&](int i) { const int j = i + deal_shift; return j < nloc ? j : j - nloc; };
     cf v[E];
     int mode = 0, row = 0;
     long long fr = 0;
-#if TAC_S3_NODIV
-    const unsigned row_b = (unsigned)begin / T, fr_b = (unsigned)begin - row_b * T;      // the chunk's first frame: one division per workgroup
-#endif
     auto request = [&](int i) {
         i = i < nloc ? i : nloc - 1;
-#if TAC_S3_NODIV
-        unsigned r = row_b, f = fr_b + (unsigned)place(i);
-        if (f >= T) {                                       // (wave-uniform) past the first row of the chunk
-            if (chunk <= (long long)T) {                    // a chunk of at most one row's worth of frames wraps once
-                f -= T;
-                ++r;
-            } else {
-                const unsigned q = f / T;
-                r += q;
-                f -= q * T;
-            }
-        }
-        row = (int)r;
-        fr = (long long)f;
-#else
         const unsigned gf = (unsigned)(begin + place(i));
         const unsigned r = gf / T;
         row = (int)r;
         fr = (long long)(gf - r * T);
-#endif
         const long long start = fr * (long long)g.hop - g.center_pad;
         const bool ok = g.vec2_ok && start >= 0 && start + F::N <= g.length;
         mode = ok ? 1 : 2;
@@ -403,9 +279,6 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             }
         }
     };
-#ifndef TAC_S3_EARLY_FIRST
-#define TAC_S3_EARLY_FIRST 1
-#endif
     // ---- tables into LDS.  Every global load of the set-up is issued before the first LDS store (loads of one loop iteration
     //      used to wait for the previous iteration's: a dozen serialized L2 round trips, 4.3 us of a 110 us kernel; now ~one)
     float* const wlds = reinterpret_cast<float*>(smem_raw + (size_t)WAVES * XA_BYTES);
@@ -435,55 +308,13 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     int lo_s[ST_MAX_SLOTS];
 #pragma unroll
     for (int s = 0; s < ST_MAX_SLOTS; ++s) lo_s[s] = s < m.nslot ? m.lo[s * 64 + lane] : 0;
-    // piece layout (FAST1 >= 1000 encodes the segment lengths, mel_pieces.hpp): the band this lane stores per segment (or -1)
-    // and how many left neighbours' partial sums belong to it
-    constexpr bool PIECES = FAST1 >= 1000;
-    // ... per segment: the float slot of the wave's staging row the lane writes its (shift-summed) value to — its band's when the
-    // lane holds the band's LAST piece, else a private dummy slot behind the 192 band slots, so that the write needs no predicate —
-    // and the piece's position inside its band (how many left neighbours to add)
-    constexpr int PC_STAGE = C::PROW + 8;                    // staging row: floats [PROW + 8, PROW + 8 + 256) of the exchange area
-    static_assert((PC_STAGE % 4) == 0 && (PC_STAGE + 256) * 4 <= XA_BYTES, "the staging row lies behind the power row, inside the area");
-    unsigned pc_meta[3] = {0, 0, 0};                         // staging slot | (piece index << 16): one register per segment
-    if constexpr (PIECES) {
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const int b = m.lo[256 + s * 64 + lane], ix = m.lo[512 + s * 64 + lane];
-            pc_meta[s] = (unsigned)(PC_STAGE + ((b >= 0 && ix >= 256) ? b : 192 + lane)) | ((unsigned)(ix & 255) << 16);
-        }
-    }
-    // the band values of the wave's PREVIOUS frame, read back from the staging row at the end of that frame and still in flight:
-    // their epilogue and row stores run behind the next frame's first butterfly, so the staging round trip is off the wave's
-    // critical path (it is latency, not issue slots, that a twelve-wave CU is short of)
-    float pend[2] = {0.0f, 0.0f};
-    long long pend_frame = -1;
-    auto emit_pending = [&]() {
-        if constexpr (PIECES) {
-            if (pend_frame >= 0) {
-                float o0 = pend[0], o1 = pend[1];
-                if (m.db) {
-                    o0 = m.amin >= 1.1754944e-38f ? amp_to_db_fast(o0, m.amin, 10.0f * m.log10_ref) : amp_to_db(o0, m.amin, m.log10_ref);
-                    o1 = m.amin >= 1.1754944e-38f ? amp_to_db_fast(o1, m.amin, 10.0f * m.log10_ref) : amp_to_db(o1, m.amin, m.log10_ref);
-                }
-                float* orow = m.out + pend_frame * (long long)m.n_mels + lane;
-                if (lane < m.n_mels) orow[0] = o0;
-                if (64 + lane < m.n_mels) orow[64] = o1;
-            }
-        }
-    };
     float lutv = 0.0f;
     if (FMT >= FMT_MULAW_U8) lutv = m.lut[tid & 255];
     __builtin_amdgcn_sched_barrier(0);
-#if TAC_S3_CYCLES
-    const unsigned long long wall_a = wall_clock64();                  // loads issued
-    __builtin_amdgcn_s_waitcnt(0x0F70);                                // (debug) vmcnt(0)
-    const unsigned long long wall_b = wall_clock64();                  // loads landed
-#endif
-#if TAC_S3_EARLY_FIRST
     // the wave's first frame is requested BEHIND the table loads (one in-order vmcnt: the tables' wait then leaves these sixteen
     // loads outstanding) and ahead of the LDS stores and the barrier: its HBM latency runs behind the rest of the set-up
     if (nloc > 0) request(w);
     __builtin_amdgcn_sched_barrier(0);
-#endif
     // ---- stores
 #pragma unroll
     for (int u = 0; u < WCH; ++u) {
@@ -493,26 +324,14 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     for (int c = tid + WCH * WAVES * 64; c < n4; c += WAVES * 64)          // banks with more than 48 KB of weights: the rest, plainly
         reinterpret_cast<pf4*>(wlds)[c] = reinterpret_cast<const pf4*>(m.wl)[c];
     if (tid == 0) *next_frame = WAVES;
-    // pass-1 twiddle sets, the eight R2C twiddles of a lane (re-read every frame: the register budget does not hold them) and
-    // the window pairs of its sixteen first-pass elements (scale folded in), as [read u][lane] 16-byte pairs: every
+    // pass-1 twiddle sets and the window pairs of its sixteen first-pass elements (scale folded in), as [read u][lane] 16-byte pairs: every
     // ds_read_b128 of the wave is one contiguous kilobyte
     setup.store(twlds, ptwl, winl, half, tid);
-#if TAC_S3_PTW_REGS
-    cf ptw_regs[F::NPAIR];
+    cf ptw_regs[F::NPAIR];                                  // the lane's eight R2C twiddles (16 VGPRs: the kernel sits at 156 of 168)
 #pragma unroll
     for (int p = 0; p < F::NPAIR; ++p) ptw_regs[p] = tb.w_n[t + p * F::LPF];
-#endif
     float* const lutlds = reinterpret_cast<float*>(winl + 64 * E);                 // mu-law decode table (coded inputs)
     if (FMT >= FMT_MULAW_U8 && tid < 256) lutlds[tid] = lutv;
-#if TAC_S3_WIN_REGS
-    cf win_regs[E];
-    load_window_regs<F>(win_regs, g, t);
-#pragma unroll
-    for (int e = 0; e < E; ++e) win_regs[e] = cscale(win_regs[e], half);
-#endif
-#if TAC_S3_CYCLES
-    const unsigned long long wall_c = wall_clock64();                  // stores issued
-#endif
     __syncthreads();
     if (nloc <= 0) return;
 
@@ -552,41 +371,15 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         a0 = __builtin_elementwise_fma(mkc(wv.x, wv.y), mkc(pv.x, pv.y), a0);
         a1 = __builtin_elementwise_fma(mkc(wv.z, wv.w), mkc(pv.z, pv.w), a1);
     };
-#if TAC_S3_W0_REGS
-    f4 w0_regs[ST_FAST_STEPS0];
-    if constexpr (FAST1 > 0 && FAST1 < 1000) {
-#pragma unroll
-        for (int u = 0; u < ST_FAST_STEPS0; ++u) w0_regs[u] = (reinterpret_cast<const f4*>(wlds) + lane)[u * 64];
-    }
-#endif
-#if TAC_S3_SWZ
     S3Swz swz;
     swz.init(xa, t);
-#endif
-#if TAC_S3_ABL_NOTABLES
-    float abl_seed = 0.5f + 1e-3f * (float)t;
-    asm volatile("" : "+v"(abl_seed));                      // (a value the compiler cannot fold)
-#endif
     int i = w;
-#if !TAC_S3_EARLY_FIRST
-    request(i);
-#endif
-#ifndef TAC_S3_CYCLES
-#define TAC_S3_CYCLES 0
-#endif
-#if TAC_S3_CYCLES
-    const unsigned long long cyc0 = __builtin_readcyclecounter(), wall0 = wall_clock64();
-#endif
     // diagnostics (tac_debug_clock_probe): shader cycles and 100 MHz ticks of wave 0's frame loop -> the clock the kernel ran at
     unsigned long long probe_c = 0, probe_w = 0;
     if (m.probe && w == 0) {
         probe_c = __builtin_readcyclecounter();
         probe_w = wall_clock64();
     }
-#if TAC_S3_STAMPS
-    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long stamp_last = __builtin_readcyclecounter();
-#endif
     while (i < nloc) {
         // the next frame of this wave (the counter's answer travels with the stage's other LDS traffic)
         unsigned ask = 0;
@@ -600,14 +393,7 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             load_frame<F, false, true, true>(v, g, nullptr, xa, row, fr, tz, Fetch{m.samples, lutlds});
         }
         {
-#if TAC_S3_WIN_REGS
-            Dft<16>::run_windowed(v, win_regs);
-#else
             cf win[E];
-#if TAC_S3_ABL_NOTABLES          // timing-only ablation (WRONG RESULTS): window and pass-1 twiddles cost no LDS read (one register each stands in)
-#pragma unroll
-            for (int u = 0; u < E; ++u) win[u] = mkc(abl_seed, abl_seed);
-#else
             const f4* wl = reinterpret_cast<const f4*>(winl) + t;
 #pragma unroll
             for (int u = 0; u < E / 2; ++u) {
@@ -615,40 +401,10 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
                 win[2 * u] = mkc(x.x, x.y);
                 win[2 * u + 1] = mkc(x.z, x.w);
             }
-#endif
             Dft<16>::run_windowed(v, win);
-#endif
         }
-        emit_pending();                                       // (piece layout) the previous frame's epilogue + row stores
-        S3_STAMP(0);                                          // samples waited for, window reads, first butterfly
-#if !TAC_S3_NOFENCE0
         wave_lds_fence();
-#endif
-#if TAC_S3_ABL_MFMA_X
-        // timing-only ablation (WRONG RESULTS): the first exchange through the matrix pipe instead of the LDS — sixteen
-        // v_mfma_f32_16x16x1_4b_f32 per real matrix with a one-hot B operand copy A's rows into D's columns (x * 1 + 0): a 16 x 16
-        // transpose across lanes whose rows come out split over the four lane groups, which the rest of the transform is not
-        // written for; this build only measures what the LDS would gain.
-        {
-            typedef float f16v __attribute__((ext_vector_type(16)));
-            f16v accr = {0}, acci = {0};
-            const int l16 = t & 15;
-            float fone;                                     // 1.0 the compiler cannot hoist: the sixteen one-hot operands are
-            asm volatile("v_mov_b32 %0, 1.0" : "=v"(fone)); // re-made per frame from SGPR masks instead of living in sixteen VGPRs
-#pragma unroll
-            for (int k = 0; k < 16; ++k) accr = __builtin_amdgcn_mfma_f32_16x16x1f32(v[k].x, l16 == k ? fone : 0.0f, accr, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);                // (one chain after the other: 48 instead of 64 registers at the peak)
-#pragma unroll
-            for (int k = 0; k < 16; ++k) acci = __builtin_amdgcn_mfma_f32_16x16x1f32(v[k].y, l16 == k ? fone : 0.0f, acci, 0, 0, 0);
-#pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = mkc(accr[k], acci[k]);
-        }
-#endif
         cf tw1[16];
-#if TAC_S3_ABL_NOTABLES
-#pragma unroll
-        for (int u = 0; u < 16; ++u) tw1[u] = mkc(abl_seed, -abl_seed);
-#else
         {
             const f4* tl = reinterpret_cast<const f4*>(twlds + (t & 15) * ST_TW_STRIDE);
 #pragma unroll
@@ -658,90 +414,25 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
                 tw1[2 * u + 1] = mkc(x.z, x.w);
             }
         }
-#endif
-#if TAC_S3_ABL_MFMA_X
-        // (done above, ahead of the twiddle reads)
-#elif TAC_S3_SWZ
         s3_write_pass0_swz(v, swz);
         wave_lds_fence();
         s3_readback_pass1_swz(v, swz);
-#else
-        F::template pass_write<0, true>(v, xa, t, t);
-        wave_lds_fence();
-        s3_readback_pass1<F>(v, xa, t);
-#endif
-        S3_STAMP(1);                                          // exchange: write burst, read-back
         // ---- s12
         F::template pass_twiddle<1, true>(v, tw1);
         F::template pass_butterflies<1>(v);
-#if TAC_S3_LDS_EXCHANGE
-        wave_lds_fence();                                   // (A/B) the pass 1 -> 2 exchange through the LDS area instead of permlane swaps
-        F::template pass_write<1, true>(v, xa, t, t);
-        wave_lds_fence();
-        F::template pass_readback<2>(v, xa, t);
-#else
         F::exchange_1_2_in_registers(v);
-#endif
-#if TAC_S3_PTW_EARLY && !TAC_S3_PTW_REGS
-        cf ptw[F::NPAIR];
-        {
-            const f4* pl = reinterpret_cast<const f4*>(ptwl) + t;
-#pragma unroll
-            for (int u = 0; u < F::NPAIR / 2; ++u) {
-                const f4 x = pl[u * 64];
-                ptw[2 * u] = mkc(x.x, x.y);
-                ptw[2 * u + 1] = mkc(x.z, x.w);
-            }
-        }
-#endif
         F::template pass_twiddle<2, true>(v, tw2);
         F::template pass_butterflies<2>(v);
-        S3_STAMP(2);                                          // passes 1 and 2
         cf zm[F::NPAIR], zmid;
         s3_r2c_partners<F>(v, xa, zm, zmid, t);
         // ---- s3: R2C split -> |X|^p; the row overwrites the exchange area once every lane holds its partners
         cf pw[F::NPAIR];
-#if TAC_S3_PTW_REGS
         const cf (&ptw)[F::NPAIR] = ptw_regs;
-#elif !TAC_S3_PTW_EARLY
-        cf ptw[F::NPAIR];
-        {
-            const f4* pl = reinterpret_cast<const f4*>(ptwl) + t;
-#pragma unroll
-            for (int u = 0; u < F::NPAIR / 2; ++u) {
-                const f4 x = pl[u * 64];
-                ptw[2 * u] = mkc(x.x, x.y);
-                ptw[2 * u + 1] = mkc(x.z, x.w);
-            }
-        }
-#endif
 #pragma unroll
         for (int p = 0; p < F::NPAIR; p += 2)
             r2c_power_pair_x2(v[F::reg_of_spectrum(p)], zm[p], ptw[p], v[F::reg_of_spectrum(p + 1)], zm[p + 1], ptw[p + 1], pw[p], pw[p + 1]);
         const float pmid = 4.0f * cnorm2(zmid);
         wave_lds_fence();                                                   // all partner reads are in registers
-#if TAC_S3_ADDTID
-        {
-            // bins t + 64 p (p < 8) ascend with the lane: address = M0 + 256 p + 4 lane, no address register, 2 LDS cycles each
-            float lo[F::NPAIR];
-#pragma unroll
-            for (int p = 0; p < F::NPAIR; ++p) lo[p] = POW2 ? pw[p].x : __builtin_amdgcn_sqrtf(pw[p].x);
-            asm volatile("s_mov_b32 m0, %8\n\t"
-                         "ds_write_addtid_b32 %0\n\t"
-                         "ds_write_addtid_b32 %1 offset:256\n\t"
-                         "ds_write_addtid_b32 %2 offset:512\n\t"
-                         "ds_write_addtid_b32 %3 offset:768\n\t"
-                         "ds_write_addtid_b32 %4 offset:1024\n\t"
-                         "ds_write_addtid_b32 %5 offset:1280\n\t"
-                         "ds_write_addtid_b32 %6 offset:1536\n\t"
-                         "ds_write_addtid_b32 %7 offset:1792"
-                         :: "v"(lo[0]), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(lo[4]), "v"(lo[5]), "v"(lo[6]), "v"(lo[7]),
-                            "s"(lds_offset_of(prow))
-                         : "memory", "m0");
-#pragma unroll
-            for (int p = 0; p < F::NPAIR; ++p) prow[NC - (t + p * F::LPF)] = POW2 ? pw[p].y : __builtin_amdgcn_sqrtf(pw[p].y);
-        }
-#elif TAC_S3_ROW_ST64
         {
             // bins t + 64 p and t + 64 (p + 1) are 256 bytes apart: one ds_write2st64_b32 per pair of pairs (6 LDS cycles for two
             // dwords against 4 + 4), lower half ascending from &prow[t], upper half descending onto &prow[NC - t - 448]
@@ -765,138 +456,30 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
                          :: "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(hi[4]), "v"(hi[5]), "v"(hi[6]), "v"(hi[7]), "v"(ahi)
                          : "memory");
         }
-#else
-#pragma unroll
-        for (int p = 0; p < F::NPAIR; ++p) {
-            const int kk = t + p * F::LPF;
-            prow[kk] = POW2 ? pw[p].x : __builtin_amdgcn_sqrtf(pw[p].x);
-            prow[NC - kk] = POW2 ? pw[p].y : __builtin_amdgcn_sqrtf(pw[p].y);
-        }
-#endif
         if (t == 0) prow[NC / 2] = POW2 ? pmid : __builtin_amdgcn_sqrtf(pmid);
         if (t < C::PROW - NBINS) prow[NBINS + t] = 0.0f;                    // slack taps carry zero weights: keep them finite
         wave_lds_fence();
-        S3_STAMP(3);                                          // partner reads, R2C split, row in place
         // ---- the next frame's samples go out now (v is dead), they land during the contraction
         const int cur = i;
         i = (int)__builtin_amdgcn_readfirstlane(ask);
         request(i);
-        S3_STAMP(4);                                          // counter answer + sample request
         // ---- s4: filterbank contraction, dB, row store
-        if constexpr (PIECES) {
-            // ---- piece layout: three segments of L0 / L1 / L2 steps, each a piece of a band; a band's pieces sit in adjacent lanes
-            //      of one 16-lane row and are summed with row-shift DPP reads; the lane of the last piece stores the band
-            constexpr int L0 = (FAST1 / 100) % 10, L1 = (FAST1 / 10) % 10, L2 = FAST1 % 10;
-            const int ci = cur < nloc ? cur : nloc - 1;
-            const f4* wp = reinterpret_cast<const f4*>(wlds) + lane;
-            const f4* p0 = reinterpret_cast<const f4*>(prow + lo_s[0]);
-            const f4* p1 = reinterpret_cast<const f4*>(prow + lo_s[1]);
-            const f4* p2 = reinterpret_cast<const f4*>(prow + lo_s[2]);
-            // the L0 + L1 + L2 steps as one flat list in two batches (A steps in flight, then the rest): every step is one 16-byte
-            // weight read [step][lane] + one 16-byte row read from its segment's run + two packed FMAs into its segment's sums
-            constexpr int ST = L0 + L1 + L2, BS = TAC_S3_PIECE_BATCH, NB = (ST + BS - 1) / BS;
-            cf a0 = mkc(0.f, 0.f), a1 = mkc(0.f, 0.f), b0 = mkc(0.f, 0.f), b1 = mkc(0.f, 0.f), c0 = mkc(0.f, 0.f), c1 = mkc(0.f, 0.f);
-            // (k is a constant after unrolling: the selects below fold)
-            auto rowq = [&](int k) { return k < L0 ? p0[k] : (k < L0 + L1 ? p1[k - L0] : p2[k - L0 - L1]); };
-            auto accum = [&](int k, f4 wv, f4 qv) {
-                if (k < L0) fma4(wv, qv, a0, a1);
-                else if (k < L0 + L1) fma4(wv, qv, b0, b1);
-                else fma4(wv, qv, c0, c1);
-            };
-            // batches of BS steps, two in flight: batch n + 1 is requested before batch n is consumed (the scheduling barriers keep
-            // hipcc from requesting everything at once, which spills)
-            f4 wq[2][BS], rq[2][BS];
-            auto request_batch = [&](int n) {
-#pragma unroll
-                for (int j = 0; j < BS; ++j)
-                    if (n * BS + j < ST) {
-                        wq[n & 1][j] = wp[(n * BS + j) * 64];
-                        rq[n & 1][j] = rowq(n * BS + j);
-                    }
-            };
-            request_batch(0);
-#pragma unroll
-            for (int n = 0; n < NB; ++n) {
-                if (n + 1 < NB) request_batch(n + 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < BS; ++j)
-                    if (n * BS + j < ST) accum(n * BS + j, wq[n & 1][j], rq[n & 1][j]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            float vs[3] = {(a0.x + a0.y) + (a1.x + a1.y), (b0.x + b0.y) + (b1.x + b1.y), (c0.x + c0.y) + (c1.x + c1.y)};
-            // a band's pieces sit in adjacent lanes: partial sums of the one / two lanes to the left (row_shr: a lane at the start
-            // of its 16-lane row reads 0), then the lane of the last piece puts the band into the staging row; lane l then owns
-            // bands l, 64 + l (, 128 + l) like in the classic layout: one epilogue, coalesced row stores
-#pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                const float left1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(vs[s]), 0x111, 0xf, 0xf, false));
-                const float left2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(vs[s]), 0x112, 0xf, 0xf, false));
-                float tot = vs[s] + (pc_meta[s] >= 0x10000u ? left1 : 0.0f);
-                tot += pc_meta[s] >= 0x20000u ? left2 : 0.0f;
-                prow[pc_meta[s] & 0xffffu] = tot;
-            }
-            wave_lds_fence();
-            pend[0] = prow[PC_STAGE + lane];                 // (consumed behind the next frame's first butterfly: emit_pending)
-            pend[1] = prow[PC_STAGE + 64 + lane];
-            pend_frame = begin + place(ci);
-        } else if constexpr (FAST1 > 0) {
+        if constexpr (FAST1 > 0) {
             const int ci = cur < nloc ? cur : nloc - 1;
             const f4* wp = reinterpret_cast<const f4*>(wlds) + lane;
             const f4* p0 = reinterpret_cast<const f4*>(prow + lo_s[0]);
             const f4* p1 = reinterpret_cast<const f4*>(prow + lo_s[1]);
             cf a0 = mkc(0.f, 0.f), a1 = mkc(0.f, 0.f), b0 = mkc(0.f, 0.f), b1 = mkc(0.f, 0.f);
-            if constexpr ((WAVES + 3) / 4 >= 4) {
-            // four waves per SIMD leave 128 registers: the taps arrive in chunks of TAC_S3_CHUNK steps, the other waves cover the waits
-            {
-                f4 w0[ST_FAST_STEPS0], q0[ST_FAST_STEPS0];
-#pragma unroll
-                for (int u = 0; u < ST_FAST_STEPS0; ++u) {
-                    w0[u] = wp[u * 64];
-                    q0[u] = p0[u];
-                }
-#pragma unroll
-                for (int u = 0; u < ST_FAST_STEPS0; ++u) fma4(w0[u], q0[u], a0, a1);
-            }
-#pragma unroll
-            for (int c = 0; c < FAST1; c += TAC_S3_CHUNK) {
-                constexpr int CH = TAC_S3_CHUNK;
-                f4 wc[CH], qc[CH];
-#pragma unroll
-                for (int u = 0; u < CH; ++u)
-                    if (c + u < FAST1) {
-                        wc[u] = wp[(ST_FAST_STEPS0 + c + u) * 64];
-                        qc[u] = p1[c + u];
-                    }
-#pragma unroll
-                for (int u = 0; u < CH; ++u)
-                    if (c + u < FAST1) fma4(wc[u], qc[u], b0, b1);
-            }
-            } else {
-#ifndef TAC_S3_ABL_STEPS1
-#define TAC_S3_ABL_STEPS1 0   // timing-only ablation (WRONG RESULTS): slot 1 runs this many steps instead of FAST1 (what a shorter contraction would buy)
-#endif
-            constexpr int EFF1 = TAC_S3_ABL_STEPS1 ? TAC_S3_ABL_STEPS1 : FAST1;
-            constexpr int B1 = (EFF1 + 1) / 2, B2 = EFF1 - B1;                // slot 1 in two batches
+            constexpr int B1 = (FAST1 + 1) / 2, B2 = FAST1 - B1;              // slot 1 in two batches
             f4 w0[ST_FAST_STEPS0], q0[ST_FAST_STEPS0], wa[B1], qa[B1];
 #pragma unroll
             for (int u = 0; u < ST_FAST_STEPS0; ++u) {
-#if TAC_S3_W0_REGS
-                w0[u] = w0_regs[u];
-#elif TAC_S3_ABL_NOWEIGHTS       // timing-only ablation (WRONG RESULTS): the weights cost no LDS read (what a consumer wave holding its
-                w0[u] = p0[u];         // bank in registers would save: DESIGN.md 7 (2))
-#else
                 w0[u] = wp[u * 64];
-#endif
                 q0[u] = p0[u];
             }
 #pragma unroll
             for (int u = 0; u < B1; ++u) {
-#if TAC_S3_ABL_NOWEIGHTS
-                wa[u] = p1[u];
-#else
                 wa[u] = wp[(ST_FAST_STEPS0 + u) * 64];
-#endif
                 qa[u] = p1[u];
             }
 #pragma unroll
@@ -904,18 +487,13 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             f4 wb[B2], qb[B2];
 #pragma unroll
             for (int u = 0; u < B2; ++u) {
-#if TAC_S3_ABL_NOWEIGHTS
-                wb[u] = p1[B1 + u];
-#else
                 wb[u] = wp[(ST_FAST_STEPS0 + B1 + u) * 64];
-#endif
                 qb[u] = p1[B1 + u];
             }
 #pragma unroll
             for (int u = 0; u < B1; ++u) fma4(wa[u], qa[u], b0, b1);
 #pragma unroll
             for (int u = 0; u < B2; ++u) fma4(wb[u], qb[u], b0, b1);
-            }
             float v0 = (a0.x + a0.y) + (a1.x + a1.y), v1 = (b0.x + b0.y) + (b1.x + b1.y);
             if (m.db) {
                 v0 = fast_db ? amp_to_db_fast(v0, m.amin, ten_log10_ref) : amp_to_db(v0, m.amin, m.log10_ref);
@@ -966,10 +544,8 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
                 }
             }
         }
-        S3_STAMP(5);                                          // contraction, dB, row store
         wave_lds_fence();                                                   // the row is consumed: the area takes the next frame
     }
-    emit_pending();                                           // (piece layout) the wave's last frame
     if (m.probe && w == 0) {
         const unsigned long long dc = __builtin_readcyclecounter() - probe_c, dw = wall_clock64() - probe_w;
         if (lane == 0) {
@@ -977,28 +553,6 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             m.probe[2 * blockIdx.x + 1] = dw;
         }
     }
-#if TAC_S3_STAMPS
-    __syncthreads();
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) m.out[((long long)blockIdx.x * WAVES + w) * 8 + k] = (float)stamp_acc[k];
-    }
-#endif
-#if TAC_S3_CYCLES
-    // debug build (tools/stream3_cycles.py): shader cycles and 100 MHz ticks of every wave's frame loop, over the first outputs
-    __syncthreads();
-    if (lane == 0) {
-        m.out[((long long)blockIdx.x * WAVES + w) * 2] = (float)(__builtin_readcyclecounter() - cyc0);
-        m.out[((long long)blockIdx.x * WAVES + w) * 2 + 1] = (float)(wall_clock64() - wall0);
-        if (w == 0) m.out[(long long)gridDim.x * WAVES * 2 + blockIdx.x] = (float)(wall0 - wall_entry);   // set-up: entry -> loop
-        if (w == 0 && blockIdx.x == 7) {
-            m.out[(long long)gridDim.x * WAVES * 2 + gridDim.x + 0] = (float)(wall_a - wall_entry);
-            m.out[(long long)gridDim.x * WAVES * 2 + gridDim.x + 1] = (float)(wall_b - wall_a);
-            m.out[(long long)gridDim.x * WAVES * 2 + gridDim.x + 2] = (float)(wall_c - wall_b);
-            m.out[(long long)gridDim.x * WAVES * 2 + gridDim.x + 3] = (float)(wall0 - wall_c);
-        }
-    }
-#endif
 }
 
 }  // namespace tac

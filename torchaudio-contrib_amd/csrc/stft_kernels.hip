@@ -488,11 +488,7 @@ static int launch_pipe3(const FrameGeom& g, const Tables& tb, const StftEpilogue
     // real rows: four waves per SIMD (0.134 -> 0.115 ms at cfg-2, inputs in the Infinity Cache); complex rows are bound by their
     // 658 MB of stores either way and measure best with three (profiles/r03/ab_stream3.txt)
     static const int waves_env = [] { const char* e = getenv("TAC_STFT_S3_WAVES"); return e ? atoi(e) : 0; }();
-#ifdef TAC_S3_FORCE_WAVES
-    const int waves = TAC_S3_FORCE_WAVES;                   // (A/B builds loaded side by side in one process)
-#else
     const int waves = waves_env ? waves_env : (PMODE == 0 ? 12 : 16);
-#endif
     // Row-store policy: nontemporal.  It keeps a cache-resident input resident (one re-read 164 MB batch: 0.150 / 0.113 ms
     // complex / power rows against 0.188 / 0.133 ms with plain stores, which allocate in the 256 MiB Infinity Cache and evict
     // the input), and with the input coming from HBM it measured equal or better than plain stores on every box of round 4
@@ -500,11 +496,7 @@ static int launch_pipe3(const FrameGeom& g, const Tables& tb, const StftEpilogue
     // 6 % in favour of plain stores did not reproduce.  TAC_S3_STORES=nt|plain forces one form (A/B runs).
     static const int forced = [] { const char* e = getenv("TAC_S3_STORES"); return !e ? -1 : (e[0] == 'p' ? 1 : 0); }();
     const long long frames_total = g.rows * g.n_frames;
-#ifdef TAC_S3_FORCE_STORES
-    const int plain = TAC_S3_FORCE_STORES;                 // (A/B builds loaded side by side in one process: tools/r04/ab_inproc.py)
-#else
     const int plain = forced >= 0 ? forced : 0;
-#endif
     auto go = [&](auto kern, int W, size_t bytes) {
         long long blocks = (groups + W - 1) / W;
         if (blocks > device_cu_count()) blocks = device_cu_count();

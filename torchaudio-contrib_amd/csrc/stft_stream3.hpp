@@ -66,11 +66,10 @@ stft_stream3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
     cf v[E];
     int mode = 0, row = 0;
     long long fr = 0;
-#ifndef TAC_S3_EARLYREQ
-#define TAC_S3_EARLYREQ 1       // the twelve-wave complex-row form requests the NEXT frame's samples into their own registers as soon as
-#endif                          // the current frame's are consumed (a whole frame of cover instead of the row stores' issue time): -1.1 ... -1.4 %
-                                // on the complex rows (same-process A/B); the real rows measure best with sixteen waves and the late request
-    constexpr bool EARLY = TAC_S3_EARLYREQ && WAVES == 12 && MODE == 0;
+    // the twelve-wave complex-row form requests the NEXT frame's samples into their own registers as soon as the current frame's are
+    // consumed (a whole frame of cover instead of the row stores' issue time): -1.1 ... -1.4 % on the complex rows (same-process
+    // A/B); the real rows measure best with sixteen waves and the late request
+    constexpr bool EARLY = WAVES == 12 && MODE == 0;
     cf nx[EARLY ? E : 1];           // EARLY: the requested (next) frame's samples; v is the frame being transformed
     int nmode = 0, nrow = 0;
     long long nfr = 0;
@@ -102,10 +101,8 @@ stft_stream3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
     __syncthreads();
     if (nloc <= 0) return;
 
-#if TAC_S3_SWZ
     S3Swz swz;
     swz.init(xa, t);
-#endif
     int i = w;
     while (i < nloc) {
         unsigned ask = 0;
@@ -119,29 +116,12 @@ stft_stream3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
             for (int q = 0; q < E; ++q) v[q] = nx[q];
         }
         const long long g0 = ((long long)row * T + fr) * LENF;      // this frame's row in the frame-major output
-#ifndef TAC_S3_VMCNT0
-#define TAC_S3_VMCNT0 0
-#endif
-#if TAC_S3_VMCNT0
-        __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): the previous row's stores are acknowledged before this frame starts
-#endif
         // ---- s0: window, pass 0, exchange
         if (mode != 1) {                                    // frames touching the padding gather their samples first
             int tz;
             asm volatile("v_mov_b32 %0, %1" : "=v"(tz) : "v"(t));
             load_frame<F, false, true, true>(v, g, nullptr, xa, row, fr, tz, FetchF32{g.wave});
         }
-#ifndef TAC_S3_ABL_NOFFT
-#define TAC_S3_ABL_NOFFT 0      // timing-only ablation (WRONG RESULTS): no window, no transform — the frame loads and the row stores alone
-#endif
-#if TAC_S3_ABL_NOFFT
-        cf zm[F::NPAIR], zmid = v[0], ptw[F::NPAIR];
-#pragma unroll
-        for (int p = 0; p < F::NPAIR; ++p) {
-            zm[p] = v[F::NPAIR + p];
-            ptw[p] = mkc(1.0f, 0.0f);
-        }
-#else
         {
             cf win[E];
             const f4* wl = reinterpret_cast<const f4*>(winl) + t;
@@ -170,15 +150,9 @@ stft_stream3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
                 tw1[2 * u + 1] = mkc(x.z, x.w);
             }
         }
-#if TAC_S3_SWZ
         s3_write_pass0_swz(v, swz);
         wave_lds_fence();
         s3_readback_pass1_swz(v, swz);
-#else
-        F::template pass_write<0, true>(v, xa, t, t);
-        wave_lds_fence();
-        s3_readback_pass1<F>(v, xa, t);
-#endif
         // ---- s12
         F::template pass_twiddle<1, true>(v, tw1);
         F::template pass_butterflies<1>(v);
@@ -198,7 +172,6 @@ stft_stream3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
                 ptw[2 * u + 1] = mkc(x.z, x.w);
             }
         }
-#endif
         const int a = (int)(g0 & 3);
         float* const stage = reinterpret_cast<float*>(xa) + a;      // LDS and global share their 16-byte phase
         if constexpr (MODE == 0) {
@@ -240,16 +213,9 @@ stft_stream3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
             request(i);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // ---- the row leaves as 1 + NSTA + 1 unconditional stores: out-of-range lanes repeat a neighbour's element.
-        //      TAC_S3_ALIGN128: every 16-byte wave-store starts on a 128-BYTE boundary of the output (lane 0 of store u holds chunk
-        //      64 u - S, S = the row's distance in chunks from the previous boundary): a store then covers eight whole cache lines
-        //      instead of seven whole and two partial ones.  Rows are 8200 / 4100 bytes, so without this nearly every store straddles: the
-        //      access pattern alone (tools/ubench/row_store_rate.hip, no arithmetic) moves 4.3 TB/s with rows of 8200 bytes and
-        //      4.8-5.0 TB/s with 128-byte aligned ones on the same box (4.1 vs 4.5-4.8 for the 4100-byte rows).
-#ifndef TAC_S3_ALIGN128
-#define TAC_S3_ALIGN128 0       // measured: the aligned form lowers the arithmetic-free floor of the access pattern (0.148 vs 0.176-0.186 ms,
-#endif                          // stft_stream3 with TAC_S3_ABL_NOFFT) but NOT the kernel (0.1767 vs 0.1743, 0.1946 vs 0.1930 ms): off
-        constexpr int NSTA = NST + (TAC_S3_ALIGN128 ? 1 : 0);
+        // ---- the row leaves as 1 + NST + 1 unconditional stores: out-of-range lanes repeat a neighbour's element.  (Stores shifted
+        //      onto 128-byte boundaries lower the arithmetic-free floor of this access pattern, 0.148 vs 0.176-0.186 ms, but not
+        //      the kernel: tools/ablation/README.md, rounds 4 and 5.)
         float* const gdst = ep.out + g0;
         const int npre = (4 - a) & 3;
         const int nchunks = (LENF - npre) >> 2;
@@ -262,23 +228,21 @@ stft_stream3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
             const f4* const s4 = reinterpret_cast<const f4*>(stage + npre);
             f4* const g4 = reinterpret_cast<f4*>(gdst + npre);
             const int last = nchunks - 1;
-            const int S = TAC_S3_ALIGN128 ? (int)((8u - ((unsigned)(reinterpret_cast<unsigned long long>(g4) >> 4) & 7u)) & 7u) : 0;
-            f4 b[NSTA];
-            int c[NSTA];
+            f4 b[NST];
+            int c[NST];
 #pragma unroll
-            for (int u = 0; u < NSTA; ++u) {
-                int j = t + 64 * u - S;
-                j = j > 0 ? j : 0;
+            for (int u = 0; u < NST; ++u) {
+                const int j = t + 64 * u;
                 c[u] = j < last ? j : last;
                 b[u] = s4[c[u]];
             }
             __builtin_amdgcn_sched_barrier(0);            // all LDS reads in flight before the first store issues
             if (lp.plain_stores) {
 #pragma unroll
-                for (int u = 0; u < NSTA; ++u) g4[c[u]] = b[u];
+                for (int u = 0; u < NST; ++u) g4[c[u]] = b[u];
             } else {
 #pragma unroll
-                for (int u = 0; u < NSTA; ++u) __builtin_nontemporal_store(b[u], &g4[c[u]]);
+                for (int u = 0; u < NST; ++u) __builtin_nontemporal_store(b[u], &g4[c[u]]);
             }
         }
         {
