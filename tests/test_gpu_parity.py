@@ -1525,15 +1525,16 @@ def test_float64_long_non_smooth_length_is_a_composite_route(tac):
     lengths (here 1001) go to torch's GPU operators: an error under strict mode, a CompositeRouteWarning otherwise — and the
     result is still the reference's."""
     x = torch.from_numpy(signals.audio_like((2, 1, 6000), seed=91)).double().cuda()
+    win = torch.hann_window(1001, dtype=torch.float64)
     with pytest.raises(RuntimeError, match='strict mode'):
-        tac.stft(x, 1001, 250)
+        tac.stft(x, 1001, 250, window=win.cuda())
     tac.set_strict(False)
     try:
         tac._ops._warned.clear()
         with pytest.warns(tac.CompositeRouteWarning):
-            z = tac.stft(x, 1001, 250)
+            z = tac.stft(x, 1001, 250, window=win.cuda())
         assert z.dtype == torch.float64
-        assert rel_err(host(z), torch_ref.stft(x.cpu(), 1001, 250).numpy()) < 1e-12
+        assert rel_err(host(z), torch_ref.stft(x.cpu(), 1001, 250, window=win).numpy()) < 1e-12
     finally:
         tac.set_strict(True)
 
