@@ -1587,6 +1587,37 @@ def test_g10_melspectrogram_fft_length_4096(tac, golden):
     assert np.abs(host(chain(dev(xl))) - want).max() < DB_ABS
 
 
+def test_compiled_binding_carries_the_fused_call(tac):
+    """The steady state of the reference idiom launches through the compiled binding (one C++ call: layout and stamp checks,
+    allocation, stream, tac_melspec_sparse_f32) — same bits as the ctypes launcher of the same plan, also through the
+    dispatcher op, and a plan stops matching when its filterbank changes."""
+    from torchaudio_contrib_amd import _lazy
+    assert tac._native.binding() == 'compiled'
+    x = dev(signals.audio_like((3, 1, 30000), seed=501))
+    model = torch.nn.Sequential(*tac.Melspectrogram(num_mels=128, sample_rate=16000, fft_length=2048, hop_length=512),
+                                tac.AmplitudeToDb()).cuda()
+    y0 = model(x)                                                     # general path + plan
+    plans = [p for p in _lazy._plans.values() if type(p) is not tuple and p.fb is model[2].filterbank]
+    assert len(plans) == 1 and plans[0].cplan is not None
+    plan = plans[0]
+    n0, before = plan.cplan.launches, launches(tac)
+    y1 = model(x)
+    assert plan.cplan.launches == n0 + 1 and launched_since(tac, before) == {'tac_melspec_sparse_f32': 1}
+    assert type(y1) is torch.Tensor and y1.stride() == y0.stride() and torch.equal(y1, y0)
+    assert torch.equal(plan.launch(x), y0)                            # the ctypes launcher of the same plan
+    assert torch.equal(torch.ops.tac_amd.melspec_planned(x, plan.cplan.register()), y0)     # ... and the dispatcher op
+    meta = torch.ops.tac_amd.melspec_planned(x.to('meta'), plan.cplan.register())
+    assert meta.shape == y0.shape and meta.stride() == y0.stride()
+    assert plan.cplan.launch(x[:2]) is None                           # another layout: not this plan's call
+    model[2].filterbank.mul_(2.0)                                     # recorded by the version counter: the plan stops matching
+    assert plan.cplan.launch(x) is None
+    y2 = model(x)
+    fresh = torch.nn.Sequential(*tac.Melspectrogram(num_mels=128, sample_rate=16000, fft_length=2048, hop_length=512),
+                                tac.AmplitudeToDb()).cuda()
+    fresh[2].filterbank.mul_(2.0)
+    assert torch.equal(y2, fresh(x)) and not torch.equal(y2, y0)      # the new contents, not the stale tables
+
+
 def test_tables_follow_the_filterbank_and_window(tac):
     """The packed weights / plans / transposes derived from a filterbank or window are cached on the tensor, stamped with
     its version counter and data pointer: every in-place torch op is seen.  A write PyTorch itself does not record —

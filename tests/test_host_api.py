@@ -396,6 +396,22 @@ def test_gloo_overlapped_allgather(tmp_path, world):
         assert 'rank %d ok' % r in o
 
 
+def test_compiled_binding_loads_and_registers_its_op():
+    """csrc/binding/tac_ext.cpp: the extension module loads next to the ctypes binding and registers tac_amd::melspec_planned
+    (CUDA + Meta kernels) with the dispatcher; TAC_AMD_EXT=0 falls back to ctypes."""
+    import torchaudio_contrib_amd as tac
+    assert os.path.exists(tac._native.EXT_PATH), 'run `make -C torchaudio-contrib_amd/csrc` (or __graft_entry__.build())'
+    assert tac._native.binding() == 'compiled' and tac._native.ext().ABI == 1
+    schema = str(torch.ops.tac_amd.melspec_planned.default._schema)
+    assert 'Tensor wave' in schema and 'int plan' in schema
+    with pytest.raises(RuntimeError, match='unknown plan'):
+        torch.ops.tac_amd.melspec_planned(torch.zeros(2, 8, device='meta'), 12345)
+    out = subprocess.run([sys.executable, '-c', 'import sys; sys.path.insert(0, %r); import torchaudio_contrib_amd as t; '
+                          'print(t._native.binding())' % ROOT], env=dict(os.environ, TAC_AMD_EXT='0'),
+                         stdout=subprocess.PIPE, text=True)
+    assert out.stdout.strip() == 'ctypes'
+
+
 def test_invalidate_through_an_alias_drops_everything():
     """invalidate(t) drops only t's tables when t is the object they hang on; an alias that carries none (t.data, a view) cannot
     name that object, so it invalidates globally instead of silently doing nothing (round-4 advisor finding)."""

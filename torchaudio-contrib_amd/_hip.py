@@ -63,6 +63,9 @@ def invalidate(tensor=None):
             _epoch += 1
             _geometry_routes_clear()
             _lazy._plans.clear()
+            ext = _native.ext()
+            if ext is not None:
+                ext.set_epoch(_epoch)           # (plans a caller still holds stop matching)
         return
     carried = False
     for name in _CACHE_ATTRS:
@@ -363,7 +366,18 @@ class MelPlan(object):
     ``launch(wave)`` then costs an allocation and one foreign call.  Valid while the window and the filterbank keep their
     stamps (checked by the caller, ``_lazy.DeferredSpectral.realize``) and the device is current."""
     __slots__ = ('fn', 'win_ptr', 'desc', 'power', 'wpack', 'dsc', 'info', 'wpack_ptr', 'dsc_ptr', 'info_ptr', 'n_mels',
-                 'db', 'ref', 'amin', 'shape', 'device', 'dev_index', 'window', 'fb', 'win_stamp', 'fb_stamp', 'layout')
+                 'db', 'ref', 'amin', 'shape', 'device', 'dev_index', 'window', 'fb', 'win_stamp', 'fb_stamp', 'layout', 'cplan')
+
+    def run(self, wave):
+        """``matches`` + ``launch`` in one: the result, or None when the plan does not apply (any more).  With the compiled
+        binding (csrc/binding/tac_ext.cpp) the checks, the allocation, the stream lookup and the foreign call are one C++ call."""
+        c = self.cplan
+        if c is not None:
+            v = c.launch(wave)
+            if v is not None:
+                launches['tac_melspec_sparse_f32'] = launches.get('tac_melspec_sparse_f32', 0) + 1
+            return v
+        return self.launch(wave) if self.matches(wave) else None
 
     def launch(self, wave):
         out = torch.empty(self.shape, dtype=torch.float32, device=self.device)
@@ -403,6 +417,15 @@ def mel_plan(wave, window, fb, n_fft, hop, win_length, center, pad_mode, normali
     p.shape = g.lead + (g.n_frames, int(fb.shape[1]))
     p.device, p.dev_index = wave.device, wave.device.index
     p.layout = (wave.shape, wave.stride(), wave.dtype)
+    p.cplan = None
+    ext = _native.ext()
+    if ext is not None:
+        try:
+            p.cplan = ext.MelPlan(ctypes.cast(p.fn, ctypes.c_void_p).value, wave, window, fb, wpack, dsc, bytes(g.desc),
+                                  [int(v) for v in info], p.power, p.n_mels, bool(db), p.ref, p.amin, [int(n) for n in p.shape],
+                                  _epoch)
+        except Exception:                       # noqa: BLE001 — the ctypes launcher above covers the call
+            p.cplan = None
     return p
 
 

@@ -241,13 +241,20 @@ class DeferredSpectral(torch.Tensor):
         if type(plan) is tuple:                 # negative entry
             if plan[1] is s.window and plan[2] is fb and plan[3] == (s.wave.shape, s.wave.stride(), s.wave.dtype):
                 return self._launch(db)         # ... for exactly this call: the general path, no new plan
-        elif plan is not None and plan.window is s.window and plan.fb is fb and plan.matches(s.wave):
-            v = plan.launch(s.wave)
+        elif plan is not None and plan.window is s.window and plan.fb is fb:
+            v = plan.run(s.wave)                # layout / device / stamps checked, output allocated, kernel launched
             if v is not None:
                 return v
+            if not plan.matches(s.wave):        # a different layout or new contents: the general path, then a new plan below
+                return self._replan(key, db)
             with _hip_lock():                   # its launch was refused: remember that instead of rebuilding it on every call
                 _plans[key] = (_NO_PLAN, s.window, fb, (s.wave.shape, s.wave.stride(), s.wave.dtype))
             return self._launch(db)
+        return self._replan(key, db)
+
+    def _replan(self, key, db):
+        s = self._src
+        fb = self._fb
         v = self._launch(db)
         try:                                    # (a missing library / unsupported geometry was reported by _launch already)
             from . import _hip

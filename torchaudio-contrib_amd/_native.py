@@ -55,13 +55,19 @@ class NativeLibraryError(RuntimeError):
 def build(verbose=False):
     """Compile every HIP source for gfx950 into libtac_amd.so (hipcc cross-compiles without a GPU)."""
     cmd = ['make', '-C', CSRC, '-j', str(min(8, os.cpu_count() or 1))]
-    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    proc = subprocess.run(cmd + ['../libtac_amd.so'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or proc.returncode != 0:
         print(proc.stdout)
     if proc.returncode != 0:
         raise NativeLibraryError('building libtac_amd.so failed:\n' + proc.stdout[-4000:])
-    global _lib
+    # the compiled PyTorch binding of the hot call (host C++ against the torch headers): an accelerator of the call, ctypes
+    # remains the general binding — a failure here is reported, not fatal
+    proc = subprocess.run(cmd + ['ext'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or proc.returncode != 0:
+        print(proc.stdout[-4000:])
+    global _lib, _ext, _ext_tried
     _lib = None
+    _ext, _ext_tried = None, False
     return LIB_PATH
 
 
@@ -162,6 +168,44 @@ def lib():
                 fn.restype = ctypes.c_int
         _lib = h
     return _lib
+
+
+EXT_PATH = os.path.join(_HERE, '_tac_ext.so')
+_ext = None
+_ext_tried = False
+
+
+def ext():
+    """The compiled PyTorch binding of the hot call (csrc/binding/tac_ext.cpp -> _tac_ext.so), or None when it is not built /
+    disabled with TAC_AMD_EXT=0 / built against a different torch — ctypes then carries every call (the general binding)."""
+    global _ext, _ext_tried
+    if _ext_tried:
+        return _ext
+    with _lock:
+        if _ext_tried:
+            return _ext
+        mod = None
+        if os.environ.get('TAC_AMD_EXT', '1') != '0' and os.path.exists(EXT_PATH):
+            try:
+                import importlib.util
+                spec = importlib.util.spec_from_file_location(__package__ + '._tac_ext', EXT_PATH)
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                if getattr(mod, 'ABI', None) != 1:
+                    mod = None
+            except Exception as exc:            # noqa: BLE001 — the extension is an accelerator of the call, not the product
+                import warnings
+                warnings.warn('torchaudio_contrib_amd: compiled binding %s not usable (%s: %s); using ctypes' %
+                              (EXT_PATH, type(exc).__name__, exc))
+                mod = None
+        _ext = mod
+        _ext_tried = True
+    return _ext
+
+
+def binding():
+    """'compiled' when the fused chain launches through _tac_ext.so, else 'ctypes'."""
+    return 'compiled' if ext() is not None else 'ctypes'
 
 
 def check(rc, what):
