@@ -8,6 +8,11 @@
 // waveform — no padded copy, no framed copy, no separate window multiply.
 #include "host_common.hpp"
 #include "stft_stream3.hpp"
+#include "stft_ring3.hpp"
+
+#ifndef TAC_S3_RING_TW
+#define TAC_S3_RING_TW 12         // transform waves of the hop-ring form (+ one loader wave)
+#endif
 
 
 #ifndef TAC_STFT_TIMING
@@ -507,6 +512,28 @@ static int launch_pipe3(const FrameGeom& g, const Tables& tb, const StftEpilogue
         TAC_HIP(hipGetLastError());
         return (int)TAC_OK;
     };
+    if constexpr (PMODE == 0) {
+        // Complex rows (round 5): the samples through the LDS hop ring (stft_ring3.hpp) — every hop loaded ONCE per CU by a loader
+        // wave (LDS-DMA) instead of four times by the frames that share it: -6 ... -9 % same process on every box of the round, all
+        // of what loading only the new hop can give (profiles/r05/ab/batch14_ab_ring_scan.txt), bit-identical.  Conditions: hop =
+        // fft_length / 4, whole hops of padding, 16-byte aligned hops, 31-bit hop ids.  The real rows stay on the sixteen-wave
+        // form: next to a ring the LDS holds twelve exchange areas, and twelve waves + ring only equal sixteen without (-0.9 %).
+        static const bool off = [] { const char* e = getenv("TAC_S3_RING"); return e && e[0] == '0'; }();
+        constexpr int TWv = TAC_S3_RING_TW;
+        using RC = Ring3Cfg<NC, E, PMODE, TWv>;
+        if (!off && !waves_env && g.hop == RC::HOP && g.vec4_ok && (g.center_pad % RC::HOP) == 0 && g.rows * (g.n_frames + 4) < 0x7fffffffLL &&
+            (reinterpret_cast<uintptr_t>(ep.out) & 15u) == 0) {
+            long long blocks = (groups + TWv - 1) / TWv;
+            if (blocks > device_cu_count()) blocks = device_cu_count();
+            if (blocks < 1) blocks = 1;
+            const Stream3Launch lp{(frames_total + blocks - 1) / blocks, plain};
+            auto kern = stft_ring3_kernel<NC, E, PMODE, TWv>;
+            TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), RC::BYTES));
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3((TWv + 1) * 64), RC::BYTES, stream, g, tb, ep, lp);
+            TAC_HIP(hipGetLastError());
+            return (int)TAC_OK;
+        }
+    }
     if (waves == 12) return go(stft_stream3_kernel<NC, E, PMODE, 12>, 12, stft_stream3_lds_bytes<NC, E, 12>());
     return go(stft_stream3_kernel<NC, E, PMODE, 16>, 16, stft_stream3_lds_bytes<NC, E, 16>());
 }
