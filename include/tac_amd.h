@@ -240,6 +240,10 @@ int tac_mulaw_decode_i64_f32(const int64_t* codes, int64_t n, int32_t n_quantize
  *      through the closed form. */
 int tac_mulaw_decode_f32_f32(const float* codes, int64_t n, int32_t n_quantize, const float* lut,
                              float* out, void* stream);
+/*      float64 (round 5): the same formulas evaluated in double, as the reference's CPU path does for double input
+ *      (functional.py:329-335, 349-354); codes as int64 (codes_are_i64 != 0) or double. */
+int tac_mulaw_encode_f64_i64(const double* x, int64_t n, int32_t n_quantize, int64_t* out, void* stream);
+int tac_mulaw_decode_f64(const void* codes, int32_t codes_are_i64, int64_t n, int32_t n_quantize, double* out, void* stream);
 
 /* (9) Gradients (the reference differentiates through stock torch ops).  All asynchronous on `stream`,
  *     caller-allocated outputs, float32, the frame-major layouts of the forward entry points.

@@ -902,16 +902,21 @@ def test_dtype_and_device_routes(tac):
     assert rel_err(host(zh), host(tac.stft(x.half().float(), 256, 64))) == 0.0
     assert tac.amplitude_to_db(x.bfloat16()).dtype == torch.bfloat16
     assert tac.complex_norm(zh.half(), 2.0).dtype == torch.float16
-    with pytest.raises(RuntimeError, match='strict mode'):
-        tac.mu_law_encoding(x.double())
-    tac.set_strict(False)
-    try:
-        tac._ops._warned.clear()
-        with pytest.warns(tac.CompositeRouteWarning, match='float64'):
-            c64 = tac.mu_law_encoding(x.double())
-        assert c64.dtype == torch.int64 and (c64 - tac.mu_law_encoding(x)).abs().max().item() <= 1
-    finally:
-        tac.set_strict(True)
+    # float64 mu-law has its own kernels since round 5 (strict mode accepts it): the formulas in double, as the reference's
+    # CPU path evaluates them for double input — codes equal to the oracle's, decoded values within a few ulps
+    before = launches(tac)
+    xd = torch.from_numpy(signals.uniform((200000,), seed=77, scale=1.2)).double()
+    c64 = tac.mu_law_encoding(xd.cuda())
+    assert c64.dtype == torch.int64 and launched_since(tac, before) == {'tac_mulaw_encode_f64_i64': 1}
+    want = torch_ref.mu_law_encoding(xd, 256)
+    assert int((c64.cpu() != want).sum()) == 0
+    assert int((tac.mu_law_encoding(xd.cuda(), 1024).cpu() != torch_ref.mu_law_encoding(xd, 1024)).sum()) == 0
+    for codes in (want.cuda(), want.double().cuda() + 0.25):                      # integer and fractional float64 codes
+        before = launches(tac)
+        d64 = tac.mu_law_decoding(codes, 256, dtype=torch.float64) if not codes.is_floating_point() else tac.mu_law_decoding(codes, 256)
+        assert d64.dtype == torch.float64 and launched_since(tac, before) == {'tac_mulaw_decode_f64': 1}
+        ref64 = torch_ref.mu_law_decoding(codes.cpu(), 256, dtype=torch.float64)
+        assert np.abs(host(d64) - ref64.numpy()).max() < 1e-14
     z = torch.randn(1, 2, 1025, 400, 2, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
     adv = torch.linspace(0, math.pi * 256, 1025, dtype=torch.float64)[..., None]
     for rate in (0.5, 1.01, 1.3):                                  # reference tests/test_functional.py:69

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(tac):
     for name in declared:
         assert hasattr(h, name), name
     assert sorted(tac._native.EXPORTS) == declared
-    assert h.tac_abi_version() == tac._native.ABI_VERSION == 3
+    assert h.tac_abi_version() == tac._native.ABI_VERSION == 4
     assert h.tac_strerror(-3).decode().startswith('input too short')
     # diagnostics (11): no launch yet on this thread, an empty probe is refused, NULL clears
     assert isinstance(h.tac_last_route(), bytes)

@@ -713,6 +713,32 @@ def mu_law_decoding_float(codes, n_quantize):
                                                                    None if lut is None else _native.ptr(lut), o, s))
 
 
+def mu_law_encoding_f64(x, n_quantize):
+    """float64 waveform -> int64 codes, the formula in double (reference functional.py:329-335 on double input)."""
+    x = x if x.is_contiguous() else x.contiguous()
+    out = torch.empty(x.shape, dtype=torch.int64, device=x.device)
+    if x.numel():
+        with _native.on_device(x.device):
+            rc = _native.lib().tac_mulaw_encode_f64_i64(_native.ptr(x), x.numel(), n_quantize, _native.ptr(out),
+                                                        _native.stream_ptr(x.device))
+        _native.check(rc, 'tac_mulaw_encode_f64_i64')
+        _count('tac_mulaw_encode_f64_i64')
+    return out
+
+
+def mu_law_decoding_f64(codes, n_quantize):
+    """int64 or float64 codes -> float64 (reference functional.py:349-354 evaluated in double)."""
+    codes = codes if codes.is_contiguous() else codes.contiguous()
+    out = torch.empty(codes.shape, dtype=torch.float64, device=codes.device)
+    if codes.numel():
+        with _native.on_device(codes.device):
+            rc = _native.lib().tac_mulaw_decode_f64(_native.ptr(codes), 1 if codes.dtype == torch.int64 else 0, codes.numel(),
+                                                    n_quantize, _native.ptr(out), _native.stream_ptr(codes.device))
+        _native.check(rc, 'tac_mulaw_decode_f64')
+        _count('tac_mulaw_decode_f64')
+    return out
+
+
 # ----------------------------------------------------------------------------- gradients
 def transposed_bank(fb):
     """(M, F) contiguous transpose of a filterbank, cached on the tensor per version (the adjoint of the filterbank

@@ -30,14 +30,14 @@ EXPORTS = (
     'tac_melbank_pack', 'tac_melspec_sparse_f32',
     'tac_apply_filterbank_f32', 'tac_apply_filterbank_sparse_f32', 'tac_apply_filterbank_sparse_db_f32', 'tac_complex_norm_f32', 'tac_magphase_f32', 'tac_phase_vocoder_f32', 'tac_phase_vocoder_f64', 'tac_amplitude_to_db_f32',
     'tac_db_to_amplitude_f32', 'tac_mulaw_encode_f32_i64', 'tac_mulaw_decode_i64_f32',
-    'tac_mulaw_decode_f32_f32',
+    'tac_mulaw_decode_f32_f32', 'tac_mulaw_encode_f64_i64', 'tac_mulaw_decode_f64',
     'tac_stft_backward_f32', 'tac_stft_norm_backward_f32', 'tac_spectrogram_backward_f32', 'tac_spectrogram_backward_ola_workspace', 'tac_spectrogram_backward_ola_f32', 'tac_melspectrogram_backward_ola_f32', 'tac_melspectrogram_backward_f32', 'tac_filterbank_adjoint_pack', 'tac_apply_filterbank_adjoint_f32', 'tac_overlap_add_f32', 'tac_complex_norm_backward_f32', 'tac_amplitude_to_db_backward_f32', 'tac_hpss_f32', 'tac_melspec_sparse_coded_f32', 'tac_pcm16_to_f32',
     'tac_fold_twosided_f32', 'tac_window_grad_partials', 'tac_window_grad_f32', 'tac_sum_slabs_f32',
     'tac_stft_f64', 'tac_spectrogram_f64', 'tac_apply_filterbank_f64', 'tac_magphase_f64', 'tac_amplitude_to_db_f64',
     'tac_db_to_amplitude_f64',
     'tac_last_route', 'tac_debug_clock_probe', 'tac_melbank_plan_pieces_host',
 )
-ABI_VERSION = 3          # tac_abi_version() of the library this binding was written against (csrc/host_common.hip)
+ABI_VERSION = 4          # tac_abi_version() of the library this binding was written against (csrc/host_common.hip)
 
 
 class StftDesc(ctypes.Structure):
@@ -162,6 +162,9 @@ def lib():
         h.tac_last_route.argtypes = []
         h.tac_debug_clock_probe.restype = ctypes.c_int
         h.tac_debug_clock_probe.argtypes = [_P, _I32]
+        h.tac_mulaw_encode_f64_i64.argtypes = [_P, _I64, _I32, _P, _P]
+        h.tac_mulaw_decode_f64.argtypes = [_P, _I32, _I64, _I32, _P, _P]
+        h.tac_mulaw_decode_f64.restype = ctypes.c_int
         for name in EXPORTS:
             fn = getattr(h, name)
             if name.endswith(('_f32', '_f64', '_i64', '_plan', '_supported', '_pack')):   # every launcher returns a TAC_* code

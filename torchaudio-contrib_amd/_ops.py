@@ -564,6 +564,8 @@ _register('db_to_amplitude', '(Tensor x, float ref) -> Tensor',
 def _mu_law_encoding_cuda(x, n_quantize):
     if not x.is_floating_point():
         x = x.to(torch.float)                              # reference functional.py:329-330
+    if x.dtype == torch.float64:
+        return H.mu_law_encoding_f64(x, n_quantize)        # the formula in double, like the reference's CPU path on double input
     reason = _hip_dtype(x)
     if reason is not None:
         _composite_route('mu_law_encoding', reason)
@@ -581,8 +583,12 @@ def _mu_law_decoding_cuda(codes, n_quantize, dtype):
             return H.mu_law_decoding_int(codes, n_quantize)
         if dtype in _WIDEN:
             return H.mu_law_decoding_int(codes, n_quantize).to(dtype)
+        if dtype == torch.float64:
+            return H.mu_law_decoding_f64(codes.to(torch.int64), n_quantize)
         _composite_route('mu_law_decoding', 'dtype %s' % str(dtype).replace('torch.', ''))
         return C.mu_law_decoding(codes, n_quantize, dtype)
+    if codes.dtype == torch.float64:
+        return H.mu_law_decoding_f64(codes, n_quantize)
     reason = _hip_dtype(codes)
     if reason is not None:
         _composite_route('mu_law_decoding', reason)

@@ -129,6 +129,33 @@ __device__ __forceinline__ long long mulaw_formula(float x, float mu, float log1
 
 constexpr int MULAW_MAX_THR = 1024;
 
+// float64: the same op order in double
+__global__ void __launch_bounds__(EW_THREADS)
+mulaw_encode_f64_kernel(const double* __restrict__ x, long long n, double mu, long long* __restrict__ out) {
+#pragma clang fp contract(off)
+    const double l1p = log1p(mu);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const double v = x[j];
+        const double sgn = (v > 0.0) ? 1.0 : ((v < 0.0) ? -1.0 : v);
+        const double q = (sgn * log1p(mu * fabs(v)) / l1p + 1.0) / 2.0 * mu + 0.5;
+        out[j] = (fabs(q) < 9.2233720368547758e18) ? (long long)q : (long long)0x8000000000000000ULL;
+    }
+}
+
+template <class CODE>
+__global__ void __launch_bounds__(EW_THREADS)
+mulaw_decode_f64_kernel(const CODE* __restrict__ codes, long long n, double mu, double* __restrict__ out) {
+#pragma clang fp contract(off)
+    const double l1p = log1p(mu);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const double y = ((double)codes[j] / mu) * 2.0 - 1.0;
+        const double sgn = (y > 0.0) ? 1.0 : ((y < 0.0) ? -1.0 : y);
+        out[j] = sgn * (exp(fabs(y) * l1p) - 1.0) / mu;
+    }
+}
+
 template <bool VEC>
 __global__ void __launch_bounds__(EW_THREADS)
 mulaw_encode_kernel(const float* __restrict__ x, long long n, float mu, float log1p_mu, const int* __restrict__ thr,
@@ -358,6 +385,35 @@ int tac_mulaw_decode_f32_f32(const float* codes, int64_t n, int32_t n_quantize, 
     if (n_quantize < 2) return TAC_E_INVALID;
     const float mu = (float)(n_quantize - 1);
     return tac::launch_unary(codes, n, tac::MulawExpandOp{mu, tac::exact_log1pf(mu), lut, n_quantize}, out, stream);
+}
+
+// ---- float64 mu-law (round 5): the reference's formulas evaluated in double like its CPU path does for double input
+//      (functional.py:329-335, 349-354).  Elementwise, 8 bytes in / 8 out; the transition between two codes sits where
+//      (comp + 1) / 2 * mu + 0.5 crosses an integer — a double log1p that differs from the host's by an ulp moves a code only for
+//      inputs within ~1e-16 (relative) of such a point.
+int tac_mulaw_encode_f64_i64(const double* x, int64_t n, int32_t n_quantize, int64_t* out, void* stream) {
+    using namespace tac;
+    if (n == 0) return TAC_OK;
+    if (!x || !out || n < 0 || n_quantize < 2) return TAC_E_INVALID;
+    hipLaunchKernelGGL(mulaw_encode_f64_kernel, dim3(ew_blocks(n, EW_MULAW_ENCODE)), dim3(EW_THREADS), 0, (hipStream_t)stream, x,
+                       (long long)n, (double)(n_quantize - 1), reinterpret_cast<long long*>(out));
+    TAC_HIP(hipGetLastError());
+    return TAC_OK;
+}
+
+int tac_mulaw_decode_f64(const void* codes, int32_t codes_are_i64, int64_t n, int32_t n_quantize, double* out, void* stream) {
+    using namespace tac;
+    if (n == 0) return TAC_OK;
+    if (!codes || !out || n < 0 || n_quantize < 2) return TAC_E_INVALID;
+    const double mu = (double)(n_quantize - 1);
+    if (codes_are_i64)
+        hipLaunchKernelGGL(mulaw_decode_f64_kernel<long long>, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                           static_cast<const long long*>(codes), (long long)n, mu, out);
+    else
+        hipLaunchKernelGGL(mulaw_decode_f64_kernel<double>, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                           static_cast<const double*>(codes), (long long)n, mu, out);
+    TAC_HIP(hipGetLastError());
+    return TAC_OK;
 }
 
 // ---- helpers of the general gradient routes (gradients of two-sided outputs, of the window and of the filterbank)

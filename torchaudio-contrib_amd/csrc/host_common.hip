@@ -156,10 +156,11 @@ const char* tac_strerror(int code) {
 
 int tac_last_hip_error(void) { return tac::g_last_hip_error; }
 
+// 4: round 5 — tac_mulaw_encode_f64_i64 / tac_mulaw_decode_f64; tac_melbank_pack no longer takes the piece layout
 // 3: round 4 — tac_last_route / tac_debug_clock_probe; the float64 entry points and the coded-input / fused-backward
 //    launchers added during round 3 are counted from here as well (a library older than the binding fails its version check
 //    in _native.lib() instead of at the first missing symbol)
-int tac_abi_version(void) { return 3; }
+int tac_abi_version(void) { return 4; }
 
 const char* tac_last_route(void) { return tac::g_last_route; }
 
