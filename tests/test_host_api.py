@@ -40,7 +40,7 @@ def test_stale_library_is_refused(tac, monkeypatch):
     """A libtac_amd.so built from older sources fails the ABI check when it is loaded, not at the first missing symbol."""
     monkeypatch.setattr(tac._native, '_lib', None)
     monkeypatch.setattr(tac._native, 'ABI_VERSION', 99)
-    with pytest.raises(tac._native.NativeLibraryError, match='ABI version 3'):
+    with pytest.raises(tac._native.NativeLibraryError, match='ABI version 4'):
         tac._native.lib()
 
 
