@@ -237,7 +237,7 @@ def extra_stages(stages, tac, dev, gen, model):
         enc, dec = tac.MuLawEncoding(256).to(dev), tac.MuLawDecoding(256).to(dev)
         codes = enc(x5)
         assert codes.dtype == torch.int64
-        for name, fn in (('cfg5_mulaw_encode', lambda: enc(x5)), ('cfg5_mulaw_decode', lambda: dec(codes))):
+        for name, fn in (('cfg5_mulaw_encode', lambda: enc(x5)), ('cfg5_mulaw_decode', lambda: tac.realize(dec(codes)))):     # (MuLawDecoding defers: realize launches it)
             spin(fn, 0.2)
             ms, med = event_ms(fn, 50)
             alg = x5.numel() * 12

@@ -12,11 +12,22 @@ bench = json.load(open(os.path.join(d, 'bench_N1.json')))
 stats = {}
 for r in csv.DictReader(open(os.path.join(d, 'kernel_stats.csv'))):
     stats[r['Name']] = r
+stage_stats = {}
+if os.path.exists(os.path.join(d, 'kernel_stats_stages.csv')):      # (round 5: the headline trace runs without the stages)
+    for r in csv.DictReader(open(os.path.join(d, 'kernel_stats_stages.csv'))):
+        stage_stats[r['Name']] = r
 FRAMES = 256 * 313
 
 
 def kern(sub):
-    for name, r in stats.items():
+    if isinstance(sub, tuple):
+        for one in sub:
+            got = kern(one)
+            if got[0]:
+                return got
+        return None, 0, float('nan')
+    table = stats if ('melspec_stream3' in sub or not stage_stats) else stage_stats
+    for name, r in table.items():
         if sub in name:
             return name.split('(')[0].replace('void tac::', ''), int(r['Calls']), float(r['AverageNs']) / 1e6
     return None, 0, float('nan')
@@ -32,7 +43,7 @@ def pmc(k):
 
 rows = []
 for label, sub, key, per_frame in (('fused STFT + power + band-sparse mel + dB', 'melspec_stream3_kernel<1024', 'mel', 2560),
-                                   ('complex STFT', 'stft_stream3_kernel<1024, 16, 0', 'stft', 10248),
+                                   ('complex STFT', ('stft_ring3_kernel<1024, 16, 0', 'stft_stream3_kernel<1024, 16, 0'), 'stft', 10248),
                                    ('power spectrogram', 'stft_stream3_kernel<1024, 16, 1', 'spec', 6148)):
     name, calls, ms = kern(sub)
     c = pmc(key)
@@ -46,7 +57,8 @@ out.append('* `bench_N1.json` — the JSON line of `python bench.py` (N=1, cfg-2
            '%.4f ms per step; CPU baseline on that box %.0f K frames/s (%d threads).'
            % (bench['value'] / 1e6, bench['ms_per_step'], bench['cpu_baseline']['value'] / 1e3, bench['cpu_baseline']['cores']))
 out.append('* `kernel_stats.csv` — `rocprofv3 --kernel-trace --stats -- python bench.py --steps 50 --warmup 10 '
-           '--no-cpu-baseline` (long torch kernel names truncated).')
+           '--no-cpu-baseline --no-stages` (the headline steps alone; long torch kernel names truncated); `kernel_stats_stages.csv` '
+           '— the same command with its stages (the stage kernels\' rows below come from it).')
 out.append('* `pmc_mel.json`, `pmc_stft.json`, `pmc_spec.json` — per-launch means from separate `--pmc` passes '
            '(FETCH_SIZE; WRITE_SIZE; SQ_* set 1; SQ_*/LDS set 2) around `tools/prof_driver.py {mel,stft,spec}`.  HBM bytes '
            'per launch use the corrections of `MI355X_MICROARCH.md` (FETCH_SIZE in KB, x2 on gfx950 for wide coalesced '

@@ -24,6 +24,10 @@ for f in glob.glob(src + '/kt/**/*kernel_stats.csv', recursive=True):
                 w.writerow([r[0][:160]] + r[1:])
             else:
                 w.writerow([r[0][:100] + '...'] + r[1:])
+for f in glob.glob(src + '/kt_stages/**/*kernel_stats.csv', recursive=True):
+    rows = [r for r in csv.reader(open(f)) if r and (r[0] == 'Name' or 'tac::' in r[0])]
+    with open(os.path.join(dst, 'kernel_stats_stages.csv'), 'w') as o:
+        csv.writer(o).writerows([[r[0][:160]] + r[1:] for r in rows])
 if os.path.exists(src + '/bench_N1.json'):
     shutil.copy(src + '/bench_N1.json', dst + '/bench_N1.json')
 for sub, name in (('kt_grad', 'kernel_stats_backward.csv'), ('kt_gradf', 'kernel_stats_backward_fused_op.csv'),
