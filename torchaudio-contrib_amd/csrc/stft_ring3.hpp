@@ -188,8 +188,12 @@ stft_ring3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
                 const int h = id - (int)(r * HR);                                      // hop of the row
                 const float* src = g.wave + (long long)r * g.row_stride + (long long)h * D::HOP + 4 * t;
                 unsigned char* dst = ring + (size_t)slot * D::HOPB;
-                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-                __builtin_amdgcn_global_load_lds(src + 256, (__attribute__((address_space(3))) void*)(dst + 1024), 16, 0, 0);
+#ifndef TAC_R3_AUX
+#define TAC_R3_AUX 2       // cache policy of the hop loads: 2 = nontemporal (a hop is read once per launch — the next CU's chunk shares
+#endif                     // nothing with this one — so it need not stay in the L2 / Infinity Cache the row stores are streaming
+                           // through): -3.8 % same process against 0 (default policy), sc0 (1) +2.0 % (profiles/r05/ab/batch17)
+                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 16, 0, TAC_R3_AUX);
+                __builtin_amdgcn_global_load_lds(src + 256, (__attribute__((address_space(3))) void*)(dst + 1024), 16, 0, TAC_R3_AUX);
                 // the hop issued PF - 1 hops ago has landed (loads complete in order): publish it
 #pragma unroll
                 for (int k = 0; k + 1 < D::PF; ++k) fifo[k] = fifo[k + 1];
