@@ -512,12 +512,12 @@ static int launch_pipe3(const FrameGeom& g, const Tables& tb, const StftEpilogue
         TAC_HIP(hipGetLastError());
         return (int)TAC_OK;
     };
-    if constexpr (PMODE == 0) {
-        // Complex rows (round 5): the samples through the LDS hop ring (stft_ring3.hpp) — every hop loaded ONCE per CU by a loader
-        // wave (LDS-DMA) instead of four times by the frames that share it: -6 ... -9 % same process on every box of the round, all
-        // of what loading only the new hop can give (profiles/r05/ab/batch14_ab_ring_scan.txt), bit-identical.  Conditions: hop =
-        // fft_length / 4, whole hops of padding, 16-byte aligned hops, 31-bit hop ids.  The real rows stay on the sixteen-wave
-        // form: next to a ring the LDS holds twelve exchange areas, and twelve waves + ring only equal sixteen without (-0.9 %).
+    {
+        // Round 5: the samples through the LDS hop ring (stft_ring3.hpp) — every hop loaded ONCE per CU by a loader wave (LDS-DMA,
+        // nontemporal) instead of four times by the frames that share it.  Same process against the forms below: complex rows
+        // -6 ... -9 % (+ -3.8 % from the nontemporal policy), real rows -8.3 % (12 + 1 waves with the ring against 16 without),
+        // bit-identical (profiles/r05/ab/batch14, batch17, batch19).  Conditions: hop = fft_length / 4, whole hops of padding,
+        // 16-byte aligned hops, 31-bit hop ids.
         static const bool off = [] { const char* e = getenv("TAC_S3_RING"); return e && e[0] == '0'; }();
         constexpr int TWv = TAC_S3_RING_TW;
         using RC = Ring3Cfg<NC, E, PMODE, TWv>;
