@@ -9,6 +9,15 @@
 namespace tac {
 
 constexpr int EW_THREADS = 256;
+// nontemporal 16-byte store of a float4 (through a native vector type: the builtin takes only those).  Round 5, same box, alternating
+// processes (profiles/r05/ab/batch21 ... 23): for the 1 : 1 maps whose output nobody re-reads inside the launch — the unary map
+// (dB both ways) 68 -> 73 % of the HBM peak, mu-law decode 70 -> 72 % — it pays; for complex_norm / magphase it does not (+-1 %),
+// for the mu-law encoder's int64 stores it costs 40 %, and nontemporal LOADS cost 3 - 9 % everywhere: those stay plain.
+typedef float ew_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ew_store_once(float4* p, float4 v) {
+    const ew_f4 u = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(u, reinterpret_cast<ew_f4*>(p));
+}
 
 // Blocks per CU of the grid-stride kernels.  On this chip a pure fill runs 5.6 TB/s from 2 blocks of 256 threads per CU and
 // 4.4-4.6 from 4-16, a pure read needs >= 4 (tools/ubench/hbm_rate.hip) — so every kernel carries the count its read : write
@@ -108,7 +117,7 @@ __global__ void __launch_bounds__(EW_THREADS) unary_kernel(const float* __restri
         float4* o4 = reinterpret_cast<float4*>(out);
         for (long long j = i; j < n4; j += stride) {
             float4 a = x4[j];
-            o4[j] = make_float4(op(a.x), op(a.y), op(a.z), op(a.w));
+            ew_store_once(o4 + j, make_float4(op(a.x), op(a.y), op(a.z), op(a.w)));
         }
         for (long long j = n4 * 4 + i; j < n; j += stride) out[j] = op(x[j]);
     } else {
@@ -226,7 +235,7 @@ mulaw_decode_i64_kernel(const long long* __restrict__ codes, long long n, int nq
         float4* o4 = reinterpret_cast<float4*>(out);
         for (long long j = i; j < n4; j += stride) {
             longlong2 a = c2[2 * j], b = c2[2 * j + 1];
-            o4[j] = make_float4(decode(a.x), decode(a.y), decode(b.x), decode(b.y));
+            ew_store_once(o4 + j, make_float4(decode(a.x), decode(a.y), decode(b.x), decode(b.y)));
         }
         for (long long j = n4 * 4 + i; j < n; j += stride) out[j] = decode(codes[j]);
     } else {
