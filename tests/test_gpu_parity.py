@@ -351,6 +351,37 @@ def test_stft_parameter_sweep_vs_oracle(tac):
     assert checked == 64
 
 
+def test_hop_ring_rows_on_every_chunk_shape(tac):
+    """The fft_length-2048 / hop-512 rows go through the LDS hop ring (csrc/stft_ring3.hpp): a loader wave, per-frame consumed
+    marks, hop ids per audio row.  Shapes that stress its bookkeeping against the oracle — a single short row (every frame but a few
+    touches the padding), rows of a handful of frames (a workgroup's chunk spans several rows: the ids jump, the ring's marks
+    lap), many short rows, no centring (hops start at 0), a short window, and more frames per workgroup than ring slots and marks;
+    complex rows, |X|^2 rows and dB rows; and the launch really is the ring kernel's where its conditions hold."""
+    cases = [((1, 1, 4096), {}), ((1, 1, 2048 + 512 * 3), {}), ((7, 1, 5000), {}), ((3, 2, 9000), {'center': False}),
+             ((40, 1, 6144), {}), ((2, 1, 70000), {'win_length': 1200}), ((1, 3, 40000), {'pad_mode': 'constant'}),
+             ((5, 1, 2048 * 4 + 4), {})]
+    for shape, kw in cases:
+        x = signals.audio_like(shape, seed=sum(shape))
+        want = torch_ref.stft(torch.from_numpy(x), 2048, 512, **kw)
+        got = tac.stft(dev(x), 2048, 512, **kw)
+        assert tac._native.lib().tac_last_route().startswith(b'stft_ring3_kernel<1024, 16, 0,'), (shape, kw)
+        assert rel_err(host(got), want.numpy()) < 2e-6, (shape, kw)
+        p_want = torch_ref.complex_norm(want, 2.0).numpy()
+        spec = tac.Spectrogram(2048, 512, power=2., **kw).cuda()
+        assert rel_err(host(spec(dev(x))), p_want) < 1e-5, (shape, kw)
+        assert tac._native.lib().tac_last_route().startswith(b'stft_ring3_kernel<1024, 16, 1,'), (shape, kw)
+        db = host(torch.nn.Sequential(tac.Spectrogram(2048, 512, power=2., **kw), tac.AmplitudeToDb()).cuda()(dev(x)))
+        keep = p_want > 1e-6 * p_want.max()
+        assert np.abs(db - torch_ref.amplitude_to_db(torch.from_numpy(p_want)).numpy())[keep].max() < DB_ABS, (shape, kw)
+    # the same rows with a hop the ring does not take (and rows whose hops are not 16-byte aligned) still agree: the other kernel
+    x = signals.audio_like((3, 1, 20000), seed=5)
+    assert rel_err(host(tac.stft(dev(x), 2048, 500)), torch_ref.stft(torch.from_numpy(x), 2048, 500).numpy()) < 2e-6
+    assert tac._native.lib().tac_last_route().startswith(b'stft_stream3_kernel<1024, 16, 0,')
+    xo = dev(signals.audio_like((3, 1, 20001), seed=6))[..., 1:]                 # row starts off a 16-byte boundary
+    assert rel_err(host(tac.stft(xo, 2048, 512)), torch_ref.stft(xo.cpu(), 2048, 512).numpy()) < 2e-6
+    assert not tac._native.lib().tac_last_route().startswith(b'stft_ring3')
+
+
 @pytest.mark.parametrize('power', [1, 2, 0.7])
 @pytest.mark.parametrize('shape', [(1, 2, 1025, 400, 2), (1025, 400, 2)])
 def test_complex_norm(tac, shape, power):

@@ -528,12 +528,14 @@ static int launch_pipe3(const FrameGeom& g, const Tables& tb, const StftEpilogue
             if (blocks < 1) blocks = 1;
             const Stream3Launch lp{(frames_total + blocks - 1) / blocks, plain};
             auto kern = stft_ring3_kernel<NC, E, PMODE, TWv>;
+            set_last_route("stft_ring3_kernel<%d, %d, %d, %d>", NC, E, PMODE, TWv);
             TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), RC::BYTES));
             hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3((TWv + 1) * 64), RC::BYTES, stream, g, tb, ep, lp);
             TAC_HIP(hipGetLastError());
             return (int)TAC_OK;
         }
     }
+    set_last_route("stft_stream3_kernel<%d, %d, %d, %d>", NC, E, PMODE, waves == 12 ? 12 : 16);
     if (waves == 12) return go(stft_stream3_kernel<NC, E, PMODE, 12>, 12, stft_stream3_lds_bytes<NC, E, 12>());
     return go(stft_stream3_kernel<NC, E, PMODE, 16>, 16, stft_stream3_lds_bytes<NC, E, 16>());
 }
