@@ -515,7 +515,7 @@ def run(a):
                 ms, med = sorted(rounds)[1]
                 ms1, _ = event_ms(lambda: make(x), 50)
                 gbs = BATCH * CHANNELS * frames * per_frame / (ms * 1e-3) / 1e9
-                stages[name] = {'kernel_ms_mean': ms, 'kernel_ms_median': med, 'alg_bytes_per_frame': per_frame,
+                stages[name] = {'kernel_route': tac._native.lib().tac_last_route().decode() or None, 'kernel_ms_mean': ms, 'kernel_ms_median': med, 'alg_bytes_per_frame': per_frame,
                                 'achieved_GBs': gbs, 'frac_of_hbm_peak': gbs / HBM_PEAK_GBS,
                                 'kernel_ms_mean_rounds': [r[0] for r in rounds],        # (in the order they ran)
                                 'single_buffer_kernel_ms_mean': ms1}
