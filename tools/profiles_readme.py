@@ -44,7 +44,7 @@ def pmc(k):
 rows = []
 for label, sub, key, per_frame in (('fused STFT + power + band-sparse mel + dB', 'melspec_stream3_kernel<1024', 'mel', 2560),
                                    ('complex STFT', ('stft_ring3_kernel<1024, 16, 0', 'stft_stream3_kernel<1024, 16, 0'), 'stft', 10248),
-                                   ('power spectrogram', 'stft_stream3_kernel<1024, 16, 1', 'spec', 6148)):
+                                   ('power spectrogram', ('stft_ring3_kernel<1024, 16, 1', 'stft_stream3_kernel<1024, 16, 1'), 'spec', 6148)):
     name, calls, ms = kern(sub)
     c = pmc(key)
     alg = FRAMES * per_frame
