@@ -663,6 +663,12 @@ def dry_run_cpu(a, rank, world):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         gathered = tac.distributed.all_gather_batch(y, total_rows=world * BATCH)
         assert tuple(gathered.shape) == (world * BATCH, CHANNELS, N_MELS, FRAMES)
+        for method in ('rccl', 'p2p'):          # the overlapped forms of the gather leg: same tensor
+            g = tac.distributed.ChunkedAllGather(world * BATCH, 2, method=method)
+            for k in range(g.chunks):
+                lb, le = g.local_rows(k)
+                g.add(k, model(x[lb:le]))
+            assert torch.equal(g.finish(), gathered), method
     if rank == 0:
         print(json.dumps({'metric': 'mel frames/sec', 'value': world * BATCH * CHANNELS * FRAMES * a.steps / float(t.item()),
                           'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
