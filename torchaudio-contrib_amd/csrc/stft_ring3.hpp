@@ -21,7 +21,10 @@
 //     frame of the chunk not yet consumed (it scans the per-frame marks in order); it never runs more than R hops ahead of B(c),
 //     which is also what bounds the marks' ring.
 // The first unconsumed frame can always get its hops (R >= 4 + waves in flight), so the protocol cannot deadlock; waits are
-// bounded anyway.  Replaces torch.stft (reference functional.py:99-107) [+ complex_norm (functional.py:126-128)].
+// bounded anyway.  Shipped for every row mode (complex, |X|^2, |X|, dB): same process against stft_stream3_kernel complex rows
+// -6 ... -9 % and a further -3.8 % from the nontemporal hop loads, real rows -8.3 % (12 + 1 waves with the ring against 16 without),
+// bit-identical (profiles/r05/ab/batch14, batch17, batch19).
+// Replaces torch.stft (reference functional.py:99-107) [+ complex_norm (functional.py:126-128)] [+ amplitude_to_db (291-296)].
 #pragma once
 #include "stft_stream3.hpp"
 
