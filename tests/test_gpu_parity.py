@@ -373,6 +373,14 @@ def test_hop_ring_rows_on_every_chunk_shape(tac):
         db = host(torch.nn.Sequential(tac.Spectrogram(2048, 512, power=2., **kw), tac.AmplitudeToDb()).cuda()(dev(x)))
         keep = p_want > 1e-6 * p_want.max()
         assert np.abs(db - torch_ref.amplitude_to_db(torch.from_numpy(p_want)).numpy())[keep].max() < DB_ABS, (shape, kw)
+    # hop = fft_length / 8 takes the ring too (eight 1 KB hops per frame)
+    for shape, kw in (((2, 1, 30000), {}), ((1, 2, 9000), {'center': False}), ((9, 1, 4100), {})):
+        x = signals.audio_like(shape, seed=sum(shape) + 1)
+        want = torch_ref.stft(torch.from_numpy(x), 2048, 256, **kw)
+        assert rel_err(host(tac.stft(dev(x), 2048, 256, **kw)), want.numpy()) < 2e-6, (shape, kw)
+        assert tac._native.lib().tac_last_route().startswith(b'stft_ring3_kernel<1024, 16, 0, 12, 8>'), (shape, kw)
+        spec = tac.Spectrogram(2048, 256, power=1., **kw).cuda()
+        assert rel_err(host(spec(dev(x))), torch_ref.complex_norm(want, 1.0).numpy()) < 1e-5, (shape, kw)
     # the same rows with a hop the ring does not take (and rows whose hops are not 16-byte aligned) still agree: the other kernel
     x = signals.audio_like((3, 1, 20000), seed=5)
     assert rel_err(host(tac.stft(dev(x), 2048, 500)), torch_ref.stft(torch.from_numpy(x), 2048, 500).numpy()) < 2e-6

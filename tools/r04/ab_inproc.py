@@ -29,7 +29,7 @@ for name, path in builds:
 dev = torch.device('cuda', 0)
 nrot = int(os.environ.get('TAC_ROTATE', '4'))
 N = int(os.environ.get('TAC_AB_N', '300'))
-rows, L, n_fft, hop, n_mels = 256, 160000, 2048, 512, 128
+rows, L, n_fft, hop, n_mels = 256, 160000, 2048, int(os.environ.get('TAC_AB_HOP', '512')), 128
 T = 1 + L // hop
 xs = [torch.rand(rows, L, device=dev) * 2 - 1 for _ in range(nrot)]
 window = torch.hann_window(n_fft, device=dev)

@@ -516,23 +516,29 @@ static int launch_pipe3(const FrameGeom& g, const Tables& tb, const StftEpilogue
         // Round 5: the samples through the LDS hop ring (stft_ring3.hpp) — every hop loaded ONCE per CU by a loader wave (LDS-DMA,
         // nontemporal) instead of four times by the frames that share it.  Same process against the forms below: complex rows
         // -6 ... -9 % (+ -3.8 % from the nontemporal policy), real rows -8.3 % (12 + 1 waves with the ring against 16 without),
-        // bit-identical (profiles/r05/ab/batch14, batch17, batch19).  Conditions: hop = fft_length / 4, whole hops of padding,
+        // bit-identical (profiles/r05/ab/batch14, batch17, batch19).  Conditions: hop = fft_length / 4 or / 8, whole hops of padding,
         // 16-byte aligned hops, 31-bit hop ids.
         static const bool off = [] { const char* e = getenv("TAC_S3_RING"); return e && e[0] == '0'; }();
         constexpr int TWv = TAC_S3_RING_TW;
-        using RC = Ring3Cfg<NC, E, PMODE, TWv>;
-        if (!off && !waves_env && g.hop == RC::HOP && g.vec4_ok && (g.center_pad % RC::HOP) == 0 && g.rows * (g.n_frames + 4) < 0x7fffffffLL &&
-            (reinterpret_cast<uintptr_t>(ep.out) & 15u) == 0) {
+        auto ring = [&](auto hpf_tag) {
+            constexpr int HPF = decltype(hpf_tag)::value;
+            using RC = Ring3Cfg<NC, E, PMODE, TWv, HPF>;
             long long blocks = (groups + TWv - 1) / TWv;
             if (blocks > device_cu_count()) blocks = device_cu_count();
             if (blocks < 1) blocks = 1;
             const Stream3Launch lp{(frames_total + blocks - 1) / blocks, plain};
-            auto kern = stft_ring3_kernel<NC, E, PMODE, TWv>;
-            set_last_route("stft_ring3_kernel<%d, %d, %d, %d>", NC, E, PMODE, TWv);
+            auto kern = stft_ring3_kernel<NC, E, PMODE, TWv, HPF>;
+            set_last_route("stft_ring3_kernel<%d, %d, %d, %d, %d>", NC, E, PMODE, TWv, HPF);
             TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), RC::BYTES));
             hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3((TWv + 1) * 64), RC::BYTES, stream, g, tb, ep, lp);
             TAC_HIP(hipGetLastError());
             return (int)TAC_OK;
+        };
+        const int hpf = g.hop > 0 && (2 * NC) % g.hop == 0 ? 2 * NC / g.hop : 0;
+        if (!off && !waves_env && (hpf == 4 || hpf == 8) && g.vec4_ok && (g.center_pad % g.hop) == 0 &&
+            g.rows * (g.n_frames + 8) < 0x7fffffffLL && (reinterpret_cast<uintptr_t>(ep.out) & 15u) == 0) {
+            if (hpf == 4) return ring(std::integral_constant<int, 4>{});
+            return ring(std::integral_constant<int, 8>{});      // (hop = fft_length / 2: thirteen 4 KB hops do not fit beside twelve areas)
         }
     }
     set_last_route("stft_stream3_kernel<%d, %d, %d, %d>", NC, E, PMODE, waves == 12 ? 12 : 16);

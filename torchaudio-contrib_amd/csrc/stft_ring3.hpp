@@ -30,10 +30,12 @@
 
 namespace tac {
 
-template <int NC, int E, int MODE, int TW>
+// HPF: hops per frame (fft_length / hop): 4 (the benchmark's 2048 / 512) or 8 (2 does not fit: thirteen 4 KB hops beside twelve areas)
+template <int NC, int E, int MODE, int TW, int HPF = 4>
 struct Ring3Cfg {
     using F = WaveFft<NC, E>;
-    static constexpr int HOP = 2 * NC / 4;                                   // samples per hop
+    static_assert(HPF == 4 || HPF == 8, "hop = fft_length / 4 or / 8");
+    static constexpr int HOP = 2 * NC / HPF;                                 // samples per hop
     static constexpr int HOPB = HOP * 4;                                     // bytes per ring slot
     static constexpr int XA = s3_xa_bytes<F>();
     static constexpr int TABLES = ST_TW_BYTES + 64 + 64 * (F::NPAIR + E) * (int)sizeof(cf);
@@ -46,8 +48,9 @@ struct Ring3Cfg {
 #define TAC_S3_RING_PF 0
 #endif
     // hops the loader keeps in flight: as far ahead as the ring allows beyond the frames being transformed (vmcnt counts to 63)
-    static constexpr int PF = TAC_S3_RING_PF ? TAC_S3_RING_PF : (R - TW - 3 > 24 ? 24 : R - TW - 3);
-    static_assert(R >= TW + 4 + 2 && R < MARKS - TW - 4 && BYTES <= LDS_MAX, "ring");
+    static constexpr int PF = TAC_S3_RING_PF ? TAC_S3_RING_PF : (R - TW - (HPF - 1) > 24 ? 24 : R - TW - (HPF - 1));
+    static constexpr int LPH = HOPB / 1024;                                  // LDS-DMA instructions (1 KB each) per hop
+    static_assert(R >= TW + HPF + 2 && R < MARKS - TW - 4 && BYTES <= LDS_MAX && PF >= 1 && LPH * (PF - 1) <= 63, "ring");
 };
 
 // word >= want (wrap-safe), polled by the whole wave; bounded
@@ -63,11 +66,11 @@ __device__ __forceinline__ void ring3_wait(unsigned addr, unsigned want) {
 
 // MODE as in stft_stream3_kernel.  Launch conditions (host): hop == fft_length / 4, center_pad a multiple of the hop, 16-byte
 // aligned hops (FrameGeom::vec4_ok), rows * (T + 4) < 2^31, rows of at least two frames.
-template <int NC, int E, int MODE, int TW>
+template <int NC, int E, int MODE, int TW, int HPF = 4>
 __global__ void __launch_bounds__((TW + 1) * 64, (TW + 1 + 3) / 4)
 stft_ring3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
     using F = WaveFft<NC, E>;
-    using D = Ring3Cfg<NC, E, MODE, TW>;
+    using D = Ring3Cfg<NC, E, MODE, TW, HPF>;
     static_assert(F::G == 1 && E == 16 && radix_at(NC, 0) == 16, "fft_length 2048");
     constexpr int WAVES = TW + 1;
     constexpr int XA_BYTES = D::XA;
@@ -98,7 +101,7 @@ stft_ring3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
     const long long endl = begin + chunk < total ? begin + chunk : total;
     const int nloc = endl > begin ? (int)(endl - begin) : 0;
     const unsigned T = (unsigned)g.n_frames;
-    const unsigned HR = T + 4u;                           // ids per audio row
+    const unsigned HR = T + (unsigned)HPF;                // ids per audio row
     const int padh = g.center_pad / D::HOP;               // hops of padding in front of frame 0
     // frame i of the chunk: (row, frame in the row, interior?, id of its first hop — also a lower bound for edge frames)
     auto locate = [&](int i, unsigned& r, unsigned& f, bool& ok, int& b) {
@@ -173,7 +176,7 @@ stft_ring3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
             int b;
             locate(i, r, f, ok, b);
             if (!ok) continue;
-            for (int id = next_id > b ? next_id : b; id <= b + 3; ++id) {
+            for (int id = next_id > b ? next_id : b; id <= b + HPF - 1; ++id) {
                 if (id - R >= bc) advance();
                 if (id - R >= bc) {                       // the slot still holds a hop somebody needs
                     // ... and that somebody may be waiting for one of the hops still in flight: everything issued is published
@@ -195,19 +198,20 @@ stft_ring3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
 #define TAC_R3_AUX 2       // cache policy of the hop loads: 2 = nontemporal (a hop is read once per launch — the next CU's chunk shares
 #endif                     // nothing with this one — so it need not stay in the L2 / Infinity Cache the row stores are streaming
                            // through): -3.8 % same process against 0 (default policy), sc0 (1) +2.0 % (profiles/r05/ab/batch17)
-                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 16, 0, TAC_R3_AUX);
-                __builtin_amdgcn_global_load_lds(src + 256, (__attribute__((address_space(3))) void*)(dst + 1024), 16, 0, TAC_R3_AUX);
+#pragma unroll
+                for (int k = 0; k < D::LPH; ++k)
+                    __builtin_amdgcn_global_load_lds(src + 256 * k, (__attribute__((address_space(3))) void*)(dst + 1024 * k), 16, 0, TAC_R3_AUX);
                 // the hop issued PF - 1 hops ago has landed (loads complete in order): publish it
 #pragma unroll
                 for (int k = 0; k + 1 < D::PF; ++k) fifo[k] = fifo[k + 1];
                 fifo[D::PF - 1] = id;
-                __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * (D::PF - 1)) & 15) | (((2 * (D::PF - 1)) >> 4) << 14));     // vmcnt(2 (PF - 1))
+                __builtin_amdgcn_s_waitcnt(0x0F70 | ((D::LPH * (D::PF - 1)) & 15) | (((D::LPH * (D::PF - 1)) >> 4) << 14));     // vmcnt(LPH (PF - 1))
                 if (fifo[0] >= 0) {
                     const unsigned lv = (unsigned)fifo[0] + 1u;
                     asm volatile("ds_write_b32 %0, %1" :: "v"(loaded_addr), "v"(lv) : "memory");
                 }
             }
-            next_id = b + 4;
+            next_id = b + HPF;
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): everything issued is in the ring
         if (fifo[D::PF - 1] >= 0) {
@@ -248,16 +252,17 @@ stft_ring3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
         const unsigned mark_addr = marks_addr + 4u * (unsigned)(i & (D::MARKS - 1)), mark = (unsigned)i + 1u;
         // ---- s0: the samples (ring, or gathered from memory for frames touching the padding), window, pass 0, exchange
         if (ok) {
-            unsigned sa[4];                                 // byte address of this lane's first pair in each of the four hops
+            unsigned sa[HPF];                               // byte address of this lane's first pair in each of the frame's hops
             {
                 unsigned s = (unsigned)b % (unsigned)R;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < HPF; ++j) {
                     sa[j] = ring_lane + s * (unsigned)D::HOPB;
                     s = s + 1 == (unsigned)R ? 0u : s + 1;
                 }
             }
-            auto rd = [&](auto qc) { constexpr int q = decltype(qc)::value; v[q] = lds_read_b64_single<512 * (q & 3)>(sa[q >> 2]); };
+            // element m = t + 64 q of the frame: hop (q HPF) / 16, pair t + 64 (q mod (16 / HPF)) of it
+            auto rd = [&](auto qc) { constexpr int q = decltype(qc)::value; v[q] = lds_read_b64_single<512 * (q % (16 / HPF))>(sa[(q * HPF) >> 4]); };
             // the loader's progress is read WITH the samples (one round trip instead of two; LDS operations complete in order, so a
             // `loaded` that covers the frame means the reads behind it saw the hops)
             unsigned have;
@@ -268,9 +273,9 @@ stft_ring3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
             rd(std::integral_constant<int, 12>{}); rd(std::integral_constant<int, 13>{}); rd(std::integral_constant<int, 14>{}); rd(std::integral_constant<int, 15>{});
             lds_wait_all(v);
             asm volatile("" : "+v"(have));                  // (its read completed with the others: no use may move above the wait)
-            if ((int)((unsigned)__builtin_amdgcn_readfirstlane((int)have) - ((unsigned)b + 4u)) < 0) {
+            if ((int)((unsigned)__builtin_amdgcn_readfirstlane((int)have) - ((unsigned)b + (unsigned)HPF)) < 0) {
                 // (rare: the loader was not that far yet when the reads above were issued — wait, read again)
-                ring3_wait(loaded_addr, (unsigned)b + 4u);
+                ring3_wait(loaded_addr, (unsigned)b + (unsigned)HPF);
                 rd(std::integral_constant<int, 0>{}); rd(std::integral_constant<int, 1>{}); rd(std::integral_constant<int, 2>{}); rd(std::integral_constant<int, 3>{});
                 rd(std::integral_constant<int, 4>{}); rd(std::integral_constant<int, 5>{}); rd(std::integral_constant<int, 6>{}); rd(std::integral_constant<int, 7>{});
                 rd(std::integral_constant<int, 8>{}); rd(std::integral_constant<int, 9>{}); rd(std::integral_constant<int, 10>{}); rd(std::integral_constant<int, 11>{});
