@@ -32,7 +32,7 @@ extern "C" {
 
 #define TAC_OK 0
 #define TAC_E_INVALID (-1)      /* bad argument (null pointer, non-positive size, ...)        */
-#define TAC_E_UNSUPPORTED (-2)  /* n_fft not a power of two in [32, 4096] (nor 400), n_mels too large…  */
+#define TAC_E_UNSUPPORTED (-2)  /* n_fft not a power of two in [32, 32768] (nor 400), n_mels too large…  */
 #define TAC_E_SHORT_INPUT (-3)  /* signal too short for the requested padding / n_fft          */
 #define TAC_E_LAUNCH (-4)       /* HIP runtime error; see tac_last_hip_error()                 */
 
@@ -56,7 +56,8 @@ typedef struct tac_stft_desc {
     int64_t rows;        /* batch*channel                                              */
     int64_t length;      /* samples per row (L)                                        */
     int64_t row_stride;  /* elements between consecutive rows of `wave`                */
-    int32_t n_fft;       /* power of two, 32..4096; or 400 (STFT / spectrogram, one-sided) */
+    int32_t n_fft;       /* power of two, 32..4096; or 400 (STFT / spectrogram, one-sided); 8192 / 16384 / 32768: the forward
+                            STFT / spectrogram rows only (tac_stft_f32, tac_spectrogram_f32: four-step kernel, stft_big.hip) */
     int32_t hop;         /* > 0                                                        */
     int32_t win_length;  /* 1..n_fft; window is zero-padded centred to n_fft           */
     int32_t center;      /* 1: pad n_fft/2 both sides with pad_mode                    */
@@ -327,10 +328,11 @@ int tac_amplitude_to_db_backward_f32(const float* x, const float* grad_out, int6
 
 /* (10) hpss, beta_hpss.py:35-127: median-filter harmonic / percussive separation of a magnitude
  *      spectrogram.  mag element (r, f, t) at mag[r*stride_r + f*stride_f + t*stride_t]; the four outputs use the same
- *      strides.  kernel_f (percussive filter, along frequency) and kernel_t (harmonic filter, along time) odd, <= 32;
+ *      strides.  kernel_f (percussive filter, along frequency) and kernel_t (harmonic filter, along time) odd, <= 63
+ *      (TAC_E_UNSUPPORTED above; equal widths 9 ... 31 are one launch, every other combination two);
  *      reflect padding (needs kernel/2 < size: TAC_E_SHORT_INPUT otherwise); masks soft ((h+eps)/(h+p+eps), eps 1e-6) or
  *      hard (1.0 / 0.0); harm / perc may both be NULL (masks only).  The outputs must not overlap mag or one another
- *      (unequal widths take two launches and park the first one's medians in mask_perc): overlapping address ranges are
+ *      (the two-launch route parks the first launch's medians in mask_perc): overlapping address ranges are
  *      refused with TAC_E_INVALID. */
 int tac_hpss_f32(const float* mag, int64_t rows, int32_t n_freqs, int32_t n_frames, int64_t stride_r,
                  int64_t stride_f, int64_t stride_t, int32_t kernel_f, int32_t kernel_t, float power,

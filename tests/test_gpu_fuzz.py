@@ -300,7 +300,7 @@ def test_fuzz_hpss(tac):
     restatement of beta_hpss.py:86-127.  Medians select existing values, so hard masks and the enhanced spectrograms behind
     the soft masks are exact; a few NaNs are planted in some cases (torch.median: a window that holds one has a NaN median)."""
     rng = np.random.default_rng(9000 + SEED)
-    odd = list(range(1, 32, 2))
+    odd = list(range(1, 64, 2))           # (33 ... 63 since round 5: the two-launch route with a 32-column halo)
     for case in range(CASES):
         rows = int(rng.integers(1, 4))
         F, T = int(rng.integers(16, 300)), int(rng.integers(16, 300))
@@ -308,7 +308,7 @@ def test_fuzz_hpss(tac):
             kf = kt = int(rng.choice(odd[4:]))
         else:
             kf, kt = int(rng.choice(odd)), int(rng.choice(odd))
-        kf, kt = min(kf, 2 * ((F - 1) // 2) - 1 if F < 33 else kf), min(kt, 2 * ((T - 1) // 2) - 1 if T < 33 else kt)
+        kf, kt = min(kf, 2 * ((F - 1) // 2) - 1 if F < 65 else kf), min(kt, 2 * ((T - 1) // 2) - 1 if T < 65 else kt)
         kf, kt = max(kf, 1), max(kt, 1)
         s = (rng.random((rows, F, T), dtype=np.float32) * rng.integers(1, 5, (rows, F, T))).astype(np.float32)
         with_nan = rng.random() < 0.25

@@ -233,6 +233,47 @@ def test_non_power_of_two_and_large_n_fft(tac, golden):
         tac.set_strict(True)
 
 
+def test_fft_length_8192_to_32768_four_step_kernel(tac):
+    """fft_length 8192 / 16384 / 32768 (csrc/stft_big.hip, round 5: one frame per workgroup, S = 4 / 8 / 16 wave-level 1024-point
+    transforms, an S-point column DFT and the R2C split; reference functional.py:99-107 takes any fft_length) against the float64
+    restatement (oracle/numpy_ref.py): complex rows one- and two-sided, every pad mode, centre off, short windows, hops that are
+    not 16-byte aligned (the gathered load), normalisation; |X|^p rows with p = 2, 1, 0.7 and the dB epilogue; the Melspectrogram
+    chain (two launches).  Strict mode is on: nothing here may touch torch's operators."""
+    x = signals.audio_like((2, 1, 90000), seed=77)
+    cases = [(8192, 2048, {}), (16384, 4096, {}), (32768, 8192, {}), (16384, 1000, dict(onesided=False)),
+             (8192, 4099, dict(center=False, normalized=True)), (32768, 16384, dict(pad_mode='constant', win_length=30000)),
+             (16384, 2050, dict(pad_mode='replicate', win_length=401)), (8192, 512, dict(pad_mode='circular', onesided=False)),
+             (32768, 7001, dict(center=False))]
+    for n, hop, kw in cases:
+        before = launches(tac)
+        got = host(tac.stft(dev(x), n, hop_length=hop, **kw))
+        assert launched_since(tac, before) == {'tac_stft_f32': 1}, (n, hop, kw)
+        ref = numpy_ref.stft(x, n, hop, **kw)
+        assert got.shape[:-1] == ref.shape
+        assert rel_err(got[..., 0] + 1j * got[..., 1], ref) < 5e-6, (n, hop, kw)
+    xs = x[0, :, :40000]                                   # a row shorter than the 32768 frame + padding on both sides
+    got = host(tac.stft(dev(xs), 32768, hop_length=8192))
+    assert rel_err(got[..., 0] + 1j * got[..., 1], numpy_ref.stft(xs, 32768, 8192)) < 5e-6
+    for n, hop in ((8192, 2048), (16384, 4096), (32768, 8192)):
+        mag2 = np.abs(numpy_ref.stft(x, n, hop)) ** 2
+        for power in (2.0, 1.0, 0.7):
+            before = launches(tac)
+            got = host(tac.Spectrogram(n, hop, power=power).cuda()(dev(x)))
+            assert launched_since(tac, before) == {'tac_spectrogram_f32': 1}
+            assert rel_err(got, mag2 ** (power / 2)) < 1e-5, (n, power)
+        chain = torch.nn.Sequential(*tac.Spectrogram(n, hop, power=2.), tac.AmplitudeToDb()).cuda()
+        want_db = 10.0 * np.log10(np.maximum(mag2 ** 2, 1e-7))                 # (amplitude_to_db squares its input)
+        big = mag2 > 1e-6 * mag2.max()
+        assert np.abs(host(chain(dev(x))) - want_db)[big].max() < DB_ABS, n
+        mel = tac.Melspectrogram(num_mels=64, sample_rate=44100, fft_length=n, hop_length=hop).cuda()
+        want_mel = torch_ref.melspectrogram(torch.from_numpy(x), num_mels=64, sample_rate=44100, n_fft=n, hop=hop).numpy()
+        assert rel_err(host(mel(dev(x))), want_mel) < 2e-5, n
+    # gradients: 8192 keeps the DFT-matrix adjoint; above that the op is differentiated through torch's operators (announced)
+    xg = dev(x[:, :, :40000]).requires_grad_(True)
+    with pytest.raises(RuntimeError, match='strict mode'):
+        tac.stft(xg, 16384, hop_length=4096).square().sum().backward()
+
+
 def test_rows_shorter_than_a_frame(tac):
     """Signals shorter than fft_length (centred: every frame touches the padding, the clamped whole-frame requests of the
     persistent kernels have nothing to read): complex stft, power dB and fused mel dB of every kernel family against the CPU
@@ -1452,8 +1493,8 @@ def test_g8_hpss(tac, golden):
     try:
         tac._ops._warned.clear()
         with pytest.warns(tac.CompositeRouteWarning, match='kernel_size'):
-            wide = tac.hpss(dev(mag), 41, 2.0)
-        want = torch_ref.hpss(torch.from_numpy(mag), 41, 2.0)
+            wide = tac.hpss(dev(mag), 65, 2.0)
+        want = torch_ref.hpss(torch.from_numpy(mag), 65, 2.0)
         assert np.abs(host(wide[2]) - want[2].numpy()).max() < 1e-6
     finally:
         tac.set_strict(True)
@@ -1517,7 +1558,10 @@ def test_hpss_unequal_and_small_widths_both_layouts_and_nan(tac):
     layouts, sizes off the tile grid; medians select existing values, so hard masks are compared exactly."""
     rng = np.random.default_rng(11)
     cases = [((1, 3), (2, 70, 131)), ((3, 1), (1, 65, 64)), ((5, 9), (2, 129, 200)), ((7, 31), (1, 257, 90)),
-             ((31, 9), (2, 64, 33)), ((13, 5), (1, 100, 17)), ((3, 3), (1, 513, 70)), ((1, 1), (1, 9, 9)), ((29, 31), (1, 40, 150))]
+             ((31, 9), (2, 64, 33)), ((13, 5), (1, 100, 17)), ((3, 3), (1, 513, 70)), ((1, 1), (1, 9, 9)), ((29, 31), (1, 40, 150)),
+             # widths 33 ... 63 (round 5: the same two launches, a 32-column halo): equal and unequal, shortest legal axes
+             ((33, 33), (2, 70, 131)), ((63, 63), (1, 129, 200)), ((41, 5), (1, 257, 90)), ((7, 47), (2, 64, 33)),
+             ((63, 33), (1, 32, 17)), ((55, 61), (1, 100, 300)), ((37, 63), (1, 513, 32))]
     for (kf, kt), (rows, F, T) in cases:
         s = (rng.random((rows, F, T), dtype=np.float32) * rng.integers(1, 4, (rows, F, T))).astype(np.float32)
         padf = np.pad(s, ((0, 0), (kf // 2, kf // 2), (0, 0)), mode='reflect')
@@ -1539,7 +1583,7 @@ def test_hpss_unequal_and_small_widths_both_layouts_and_nan(tac):
     s = rng.random((1, 90, 80), dtype=np.float32)
     s[0, 40, 33] = np.nan
     s[0, 2, 70] = np.nan
-    for ks in ((5, 9), (31, 3), (1, 7)):
+    for ks in ((5, 9), (31, 3), (1, 7), (45, 45), (63, 35)):
         got = tac.hpss(dev(s), ks, 2.0, False)
         want = tac.hpss(torch.from_numpy(s), ks, 2.0, False)                 # CPU route: torch.median
         for a, b in zip(got, want):

@@ -528,7 +528,10 @@ template <int K> int check(int trials) {
 }
 int main() {
     int b = check<9>(4000) + check<11>(4000) + check<13>(4000) + check<15>(4000) + check<17>(4000) + check<19>(4000) +
-            check<21>(4000) + check<23>(4000) + check<25>(4000) + check<27>(4000) + check<29>(4000) + check<31>(4000);
+            check<21>(4000) + check<23>(4000) + check<25>(4000) + check<27>(4000) + check<29>(4000) + check<31>(4000) +
+            check<33>(1000) + check<35>(1000) + check<37>(1000) + check<39>(1000) + check<41>(1000) + check<43>(1000) +
+            check<45>(1000) + check<47>(1000) + check<49>(1000) + check<51>(1000) + check<53>(1000) + check<55>(1000) +
+            check<57>(1000) + check<59>(1000) + check<61>(1000) + check<63>(1000);
     float a[32];
     for (int t = 0; t < 2000; ++t) {
         for (int i = 0; i < 32; ++i) a[i] = (float)(rand() % 50);

@@ -140,9 +140,9 @@ def check_stft_args(shape, n_fft, hop, win_length, center, pad_mode):
 
 
 def fft_kernel_size(n_fft):
-    """power-of-two sizes in [32, 4096] take the wave-level FFT kernels; every other size up to 8192 is evaluated
-    as a windowed-DFT matrix product on the fp32 matrix cores (``_stft_dft``) — except the sizes of
-    ``mixed_radix_size``."""
+    """power-of-two sizes in [32, 4096] take the wave-level FFT kernels (``big_fft_size``: 8192 ... 32768 the four-step
+    kernel); every other size up to 8192 is evaluated as a windowed-DFT matrix product on the fp32 matrix cores
+    (``_stft_dft``) — except the sizes of ``mixed_radix_size``."""
     return (n_fft & (n_fft - 1)) == 0 and 32 <= n_fft <= 4096
 
 
@@ -152,7 +152,18 @@ def mixed_radix_size(n_fft):
     return n_fft == 400
 
 
+def big_fft_size(n_fft):
+    """fft_length 8192 / 16384 / 32768: one frame per workgroup as a four-step transform over the wave-level 1024-point FFT
+    (csrc/stft_big.hip, round 5) — forward stft / spectrogram rows of every form; gradients at 8192 keep the DFT-matrix
+    adjoint, above that they are a composite route."""
+    return n_fft in (8192, 16384, 32768)
+
+
 def hip_covers_n_fft(n_fft):
+    return fft_kernel_size(n_fft) or n_fft <= 8192 or big_fft_size(n_fft)
+
+
+def hip_covers_backward(n_fft):
     return fft_kernel_size(n_fft) or n_fft <= 8192
 
 
@@ -179,9 +190,9 @@ def geometry(wave, n_fft, hop, win_length, center, pad_mode, normalized, oneside
     g.center, g.pad_mode, g.normalized, g.onesided = bool(center), pad_mode, bool(normalized), bool(onesided)
     g.n_frames = stft_frames(length, n_fft, hop, center)
     g.n_bins = n_fft // 2 + 1 if onesided else n_fft
-    g.fft_kernel = fft_kernel_size(n_fft)
+    g.fft_kernel = fft_kernel_size(n_fft) or big_fft_size(n_fft)
     if not g.fft_kernel and n_fft > 8192:
-        raise NotImplementedError('stft: fft_length %d is outside the HIP path (power of two in [32, 4096], or any '
+        raise NotImplementedError('stft: fft_length %d is outside the HIP path (power of two in [32, 32768], or any '
                                   'length <= 8192 through the DFT-matrix kernel)' % n_fft)
     g.mixed_radix = mixed_radix_size(n_fft)
     g.desc = None if not (g.fft_kernel or g.mixed_radix) else _native.StftDesc(
@@ -1018,7 +1029,7 @@ def _frame_gradients(gs, window, g):
     """one-sided gradient spectrum (rows, T, F, 2) -> frame gradients (rows, T, n_fft), window and scale applied."""
     frames = torch.empty((g.rows, g.n_frames, g.n_fft), dtype=torch.float32, device=gs.device)
     with _native.on_device(gs.device):
-        if g.fft_kernel or g.mixed_radix:
+        if fft_kernel_size(g.n_fft) or g.mixed_radix:
             rc = _native.lib().tac_stft_backward_f32(_native.ptr(gs), _native.ptr(window), _desc(g, onesided=1),
                                                      _native.ptr(frames), _native.stream_ptr(gs.device))
             _native.check(rc, 'tac_stft_backward_f32')
@@ -1147,7 +1158,7 @@ def amplitude_to_db_backward(x, grad_out, amin):
 
 # ----------------------------------------------------------------------------- hpss
 def hpss_supported(kernel_f, kernel_t):
-    return kernel_f % 2 == 1 and kernel_t % 2 == 1 and 1 <= kernel_f <= 32 and 1 <= kernel_t <= 32
+    return kernel_f % 2 == 1 and kernel_t % 2 == 1 and 1 <= kernel_f <= 63 and 1 <= kernel_t <= 63
 
 
 def hpss(mag, kernel_f, kernel_t, power, hard, masks_only=False):

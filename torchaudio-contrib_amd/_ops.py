@@ -191,7 +191,7 @@ def _fast_backward(needs, n_fft, onesided):
 def _stft_hip_backward(saved, rest, needs, grads):
     wave, window = saved
     n_fft, hop, win_length, center, pad_mode, normalized, onesided = rest[:7]
-    if grads[0] is None or not H.hip_covers_n_fft(n_fft):
+    if grads[0] is None or not H.hip_covers_backward(n_fft):
         return None
     window = window.contiguous()
     if _fast_backward(needs, n_fft, onesided):
@@ -212,7 +212,7 @@ def _spectrogram_general_backward(wave, window, geo, power, g, need_wave, need_w
 def _spectrogram_hip_backward(saved, rest, needs, grads):
     wave, window = saved
     n_fft, hop, win_length, center, pad_mode, normalized, onesided, power, db, ref, amin = rest
-    if grads[0] is None or not H.hip_covers_n_fft(n_fft):
+    if grads[0] is None or not H.hip_covers_backward(n_fft):
         return None
     window = window.contiguous()
     g = grads[0]
@@ -232,7 +232,7 @@ def _spectrogram_hip_backward(saved, rest, needs, grads):
 def _melspectrogram_hip_backward(saved, rest, needs, grads):
     wave, window, bank = saved
     n_fft, hop, win_length, center, pad_mode, normalized, onesided, power, db, ref, amin = rest
-    if grads[0] is None or not H.hip_covers_n_fft(n_fft):
+    if grads[0] is None or not H.hip_covers_backward(n_fft):
         return None
     window = window.contiguous()
     g = grads[0]

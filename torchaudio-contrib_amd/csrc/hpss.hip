@@ -11,7 +11,8 @@
 // (Batcher network), merged with four more for each half of the run, each window's median selected from four ranks of that
 // and its three own taps (median_run.hpp: 56 min / max operations per median at K = 31; a full 32-sort per output is 382).
 // A NaN anywhere in a window makes its median NaN, as torch.median does (the min / max network alone would drop it).
-// Any other odd widths <= 31: hpss_axis_a_kernel + hpss_axis_b_kernel, the same tiles with one halo axis per launch.
+// Any other odd widths <= 63 (33 ... 63 since round 5: the default of the reference is 31, but its argument is free):
+// hpss_axis_a_kernel + hpss_axis_b_kernel, the same tiles with one halo axis per launch.
 // hpss_tile_kernel (round 3: runs of four, 4 x 4 outputs per thread, dword accesses) and hpss_kernel (round 3: one thread per
 // element) are kept as the A/B baselines (-DTAC_HPSS_RUN8=0, -DTAC_HPSS_TWO_PASS=0) and for non-unit fast strides.
 #include "host_common.hpp"
@@ -431,9 +432,9 @@ __device__ __forceinline__ void hp_emit_block(float* scratch, int tid, int a_blk
 }
 
 // K + 7 taps of one tile row starting at column `first` (any alignment), read as 16-byte chunks
-template <int K>
+template <int K, int LEFT = HP_LEFT>
 __device__ __forceinline__ void hp_row_taps(const float* tile_row, int first_aligned, float (&w)[K + 7]) {
-    constexpr int OFF = (HP_LEFT - K / 2) & 3, NCH = (K + 7 + OFF + 3) / 4;
+    constexpr int OFF = (LEFT - K / 2) & 3, NCH = (K + 7 + OFF + 3) / 4;
     const hp_f4* src = reinterpret_cast<const hp_f4*>(tile_row + first_aligned);
     float buf[4 * NCH];
 #pragma unroll
@@ -775,8 +776,10 @@ __global__ void __launch_bounds__(256)
 hpss_axis_b_kernel(const float* __restrict__ x, int NA, int NB, long long sr, long long sa, long long sb, int tiles_a,
                    int tiles_b, long long total_tiles, int b_is_time, float power, int hard, float* harm_o, float* perc_o, float* mh_o,
                    float* mp_o /* holds the A medians on entry */) {
-    constexpr int HALF = K / 2;
-    __shared__ __attribute__((aligned(16))) float tile[HP_TILE * HP_STRIDE + 4 * HP8_SCRATCH];   // + the waves' store-transpose areas
+    // widths above 31 (round 5): a 32-column low-side halo and 128-float rows (32 + 64 + 31 = 127); the rest is unchanged
+    constexpr int HALF = K / 2, LEFT = K <= 31 ? HP_LEFT : 32, STRIDE = K <= 31 ? HP_STRIDE : 128;
+    static_assert(HALF <= LEFT && LEFT + HP_TILE + HALF <= STRIDE, "halo does not fit the tile row");
+    __shared__ __attribute__((aligned(16))) float tile[HP_TILE * STRIDE + 4 * HP8_SCRATCH];   // + the waves' store-transpose areas
     const int tid = threadIdx.x;
     const int per_row = tiles_a * tiles_b;
     const long long tile_id = hp_tile_of_block(total_tiles);
@@ -784,15 +787,15 @@ hpss_axis_b_kernel(const float* __restrict__ x, int NA, int NB, long long sr, lo
     const long long row = tile_id / per_row;
     const int rem = (int)(tile_id - row * per_row);
     const int a0 = (rem / tiles_b) * HP_TILE, b0 = (rem % tiles_b) * HP_TILE;
-    const bool seen_nan = hp_fill<HP_STRIDE>(tile, HP_STRIDE, x + row * sr, a0, HP_TILE, b0 - HP_LEFT, NA, NB, sa, sb, tid);
+    const bool seen_nan = hp_fill<STRIDE>(tile, STRIDE, x + row * sr, a0, HP_TILE, b0 - LEFT, NA, NB, sa, sb, tid);
     const int tile_has_nan = __syncthreads_or(seen_nan ? 1 : 0);
     const int bx = tid & 7, ay = tid >> 3;
-    constexpr int START = HP_LEFT - HALF, OFF = START & 3;
+    constexpr int START = LEFT - HALF, OFF = START & 3;
     float medB[2][8], centre[2][8], m_a[2][8];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         float w[K + 7];
-        hp_row_taps<K>(tile + (2 * ay + i) * HP_STRIDE, 8 * bx + (START - OFF), w);
+        hp_row_taps<K, LEFT>(tile + (2 * ay + i) * STRIDE, 8 * bx + (START - OFF), w);
 #pragma unroll
         for (int j = 0; j < 8; ++j) centre[i][j] = w[HALF + j];
         hp_run8<K>(w, medB[i], tile_has_nan);
@@ -810,7 +813,7 @@ hpss_axis_b_kernel(const float* __restrict__ x, int NA, int NB, long long sr, lo
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    hp_emit_block(tile + HP_TILE * HP_STRIDE + (tid >> 6) * HP8_SCRATCH, tid, a0 + 16 * (tid >> 6), b0, NA, NB, row * sr, sa, sb, m_a, medB,
+    hp_emit_block(tile + HP_TILE * STRIDE + (tid >> 6) * HP8_SCRATCH, tid, a0 + 16 * (tid >> 6), b0, NA, NB, row * sr, sa, sb, m_a, medB,
                   centre, b_is_time, power, hard, harm_o, perc_o, mh_o, mp_o);
 }
 
@@ -924,7 +927,7 @@ int tac_hpss_f32(const float* mag, int64_t rows, int32_t n_freqs, int32_t n_fram
     if (rows == 0 || n_freqs == 0 || n_frames == 0) return TAC_OK;
     if (!mag || !mask_harm || !mask_perc || (harm == nullptr) != (perc == nullptr)) return TAC_E_INVALID;
     if (rows < 0 || n_freqs < 0 || n_frames < 0) return TAC_E_INVALID;
-    if (kernel_f < 1 || kernel_t < 1 || !(kernel_f & 1) || !(kernel_t & 1) || kernel_f > 32 || kernel_t > 32)
+    if (kernel_f < 1 || kernel_t < 1 || !(kernel_f & 1) || !(kernel_t & 1) || kernel_f > 63 || kernel_t > 63)
         return TAC_E_UNSUPPORTED;
     if (kernel_f / 2 >= n_freqs || kernel_t / 2 >= n_frames) return TAC_E_SHORT_INPUT;      // reflect padding needs pad < size
     {
@@ -944,7 +947,7 @@ int tac_hpss_f32(const float* mag, int64_t rows, int32_t n_freqs, int32_t n_fram
         }
     }
     const long long tiles = rows * ((n_freqs + HP_TILE - 1) / HP_TILE) * ((n_frames + HP_TILE - 1) / HP_TILE);
-    if (kernel_f == kernel_t && kernel_f >= 9 && tiles < 0x7fffffffLL) {
+    if (kernel_f == kernel_t && kernel_f >= 9 && kernel_f <= 31 && tiles < 0x7fffffffLL) {
 #define TAC_HPSS_CASE(K)                                                                                                   \
     case K:                                                                                                               \
         launch_tile<K>(mag, rows, n_freqs, n_frames, stride_r, stride_f, stride_t, power, hard, harm, perc, mask_harm,   \
@@ -966,7 +969,8 @@ int tac_hpss_f32(const float* mag, int64_t rows, int32_t n_freqs, int32_t n_fram
         const int ka = t_fast ? kernel_f : kernel_t, kb = t_fast ? kernel_t : kernel_f;
         const int ta = (NA + HP_TILE - 1) / HP_TILE, tb = (NB + HP_TILE - 1) / HP_TILE;
         const dim3 grid(hp_grid_for(tiles));
-#define TAC_HPSS_ODD(M) M(1) M(3) M(5) M(7) M(9) M(11) M(13) M(15) M(17) M(19) M(21) M(23) M(25) M(27) M(29) M(31)
+#define TAC_HPSS_ODD(M) M(1) M(3) M(5) M(7) M(9) M(11) M(13) M(15) M(17) M(19) M(21) M(23) M(25) M(27) M(29) M(31)            \
+    M(33) M(35) M(37) M(39) M(41) M(43) M(45) M(47) M(49) M(51) M(53) M(55) M(57) M(59) M(61) M(63)
 #define TAC_HPSS_A(K)                                                                                                     \
     case K:                                                                                                               \
         hipLaunchKernelGGL(hpss_axis_a_kernel<K>, grid, dim3(256), 0, (hipStream_t)stream, mag, NA, NB,                   \
@@ -988,6 +992,7 @@ int tac_hpss_f32(const float* mag, int64_t rows, int32_t n_freqs, int32_t n_fram
         return TAC_OK;
     }
 #endif
+    if (kernel_f > 32 || kernel_t > 32) return TAC_E_UNSUPPORTED;      // (the one-thread-per-element form sorts 32 taps)
     const long long total = rows * (long long)n_freqs * n_frames;
     long long blocks = (total + 255) / 256;
     const long long cap = (long long)device_cu_count() * 16;

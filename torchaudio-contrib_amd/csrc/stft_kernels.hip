@@ -601,6 +601,9 @@ static int launch_stft(const FrameGeom& g, const Tables& tb, const StftEpilogue&
 int try_launch_n4096(const FrameGeom& g, const StftEpilogue& ep, int mode, hipStream_t stream);
 int try_launch_small(int n_fft, const FrameGeom& g, const Tables& tb, const StftEpilogue& ep, int mode, hipStream_t stream);
 int try_launch_n400(const FrameGeom& g, const StftEpilogue& ep, int mode, hipStream_t stream);   // stft_n400.hip
+int launch_stft_big(int n_fft, const FrameGeom& g, const StftEpilogue& ep, int mode, hipStream_t stream);   // stft_big.hip
+
+static inline bool is_big_fft(int n_fft) { return n_fft == 8192 || n_fft == 16384 || n_fft == 32768; }
 
 template <int MODE>
 static int dispatch_stft(int n_fft, const FrameGeom& g, const Tables& tb, const StftEpilogue& ep, hipStream_t s) {
@@ -626,6 +629,9 @@ static int dispatch_stft(int n_fft, const FrameGeom& g, const Tables& tb, const 
             return launch_stft<2048, 32, MODE>(g, tb, ep, s);
         }
         case 400: return try_launch_n400(g, ep, MODE, s);          // 200 = 8 x 25 mixed radix; plain one-sided epilogues
+        case 8192:
+        case 16384:
+        case 32768: return launch_stft_big(n_fft, g, ep, MODE, s);      // four-step transform, one frame per workgroup
         default: return TAC_E_UNSUPPORTED;
     }
 }
@@ -639,7 +645,7 @@ int tac_stft_f32(const float* wave, const float* window, const tac_stft_desc* d,
     if (!out) return TAC_E_INVALID;
     FrameGeom g;
     int64_t T = 0;
-    int rc = make_geometry(wave, window, d, &g, &T);
+    int rc = make_geometry(wave, window, d, &g, &T, d && is_big_fft(d->n_fft));
     if (rc != TAC_OK) return rc;
     Tables tb;
     rc = get_tables(d->n_fft, &tb);
@@ -654,7 +660,7 @@ int tac_spectrogram_f32(const float* wave, const float* window, const tac_stft_d
     if (!out) return TAC_E_INVALID;
     FrameGeom g;
     int64_t T = 0;
-    int rc = make_geometry(wave, window, d, &g, &T);
+    int rc = make_geometry(wave, window, d, &g, &T, d && is_big_fft(d->n_fft));
     if (rc != TAC_OK) return rc;
     Tables tb;
     rc = get_tables(d->n_fft, &tb);
