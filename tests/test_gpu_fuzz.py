@@ -76,6 +76,39 @@ def test_fuzz_stft(tac):
         assert rel_err(got, want) < 5e-6, tag
 
 
+def test_fuzz_stft_big(tac):
+    """fft_length 8192 / 16384 / 32768 (csrc/stft_big.hip): random hops (aligned or not), window lengths, pad modes, sidedness,
+    row counts; complex rows and |X|^p rows with the dB epilogue against torch's CPU operators."""
+    rng = np.random.default_rng(1500 + SEED)
+    for case in range(max(4, CASES // 4)):
+        n = int(rng.choice([8192, 16384, 32768]))
+        hop = int(rng.integers(n // 8, n + 1)) if rng.random() < 0.5 else int(rng.choice([n // 4, n // 2, n // 8]))
+        win_length = n if rng.random() < 0.6 else int(rng.integers(n // 4, n + 1))
+        center = bool(rng.random() < 0.75)
+        pad_mode = str(rng.choice(['reflect', 'constant', 'replicate', 'circular']))
+        lead = tuple(int(v) for v in rng.integers(1, 4, size=int(rng.integers(1, 3))))
+        lo = n + 1 if center else n
+        length = int(rng.integers(lo, lo + 6 * n))
+        normalized, onesided = bool(rng.random() < 0.3), bool(rng.random() < 0.7)
+        x = signals.audio_like(lead + (length,), seed=5500 + case + 7919 * SEED)
+        window = None if rng.random() < 0.5 else \
+            torch.from_numpy(signals.uniform((win_length,), seed=6500 + case) * 0.5 + 0.75)
+        kw = dict(win_length=win_length, center=center, pad_mode=pad_mode, normalized=normalized, onesided=onesided)
+        want = torch_ref.stft(torch.from_numpy(x), n, hop, window=window, **kw)
+        wdev = None if window is None else window.cuda()
+        tag = ('stft_big', case, n, hop, kw, lead, length, window is not None)
+        before = dict(tac._hip.launches)
+        got = host(tac.stft(dev(x), n, hop_length=hop, window=wdev, **kw))
+        assert tac._hip.launches['tac_stft_f32'] - before.get('tac_stft_f32', 0) == 1, tag
+        assert got.shape == tuple(want.shape), tag
+        assert rel_err(got, want.numpy()) < 5e-6, tag
+        power = float(rng.choice([1.0, 2.0, 0.7]))
+        mag = torch_ref.complex_norm(want.double(), power)
+        gs = host(torch.ops.tac_amd.spectrogram(dev(x), torch.hann_window(win_length).cuda() if wdev is None else wdev, n, hop, win_length,
+                                                 center, pad_mode, normalized, onesided, power, False, 1.0, 1e-7))
+        assert rel_err(gs, mag.numpy()) < 2e-5, tag + (power,)
+
+
 def test_fuzz_spectrogram(tac):
     rng = np.random.default_rng(2000 + SEED)
     for case in range(CASES):
