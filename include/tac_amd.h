@@ -340,7 +340,7 @@ int tac_hpss_f32(const float* mag, int64_t rows, int32_t n_freqs, int32_t n_fram
 
 /* (11) Diagnostics (bench.py's roofline object; no effect on results).
  *      tac_last_route: name of the kernel instantiation the calling thread's last fused-chain launch (3b / 3c at fft_length
- *        2048) or last fft_length-2048 STFT / spectrogram launch (1, 2: "stft_ring3_kernel<...>" / "stft_stream3_kernel<...>") took, as rocprofv3 prints it, e.g. "melspec_stream3_kernel<1024, 16, true, 0, 14, 12>" ("" before any).
+ *        2048) or last fft_length-2048 STFT / spectrogram launch (1, 2: "stft_ring3_kernel<...>" / "stft_stream3_kernel<...>"; fft_length >= 8192: "stft_big_kernel<...>") took, as rocprofv3 prints it, e.g. "melspec_stream3_kernel<1024, 16, true, 0, 14, 12>" ("" before any).
  *      tac_debug_clock_probe: while `buf` (DEVICE uint64[2 * capacity_pairs]) is set for the calling thread, every workgroup
  *        b < capacity_pairs of those launches records buf[2b] = shader cycles (s_memtime) and buf[2b + 1] = ticks of the
  *        100 MHz constant clock (s_memrealtime) its wave 0 spent in the frame loop: cycles / ticks x 100 MHz is the shader

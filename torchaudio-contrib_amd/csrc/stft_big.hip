@@ -202,6 +202,7 @@ static int launch_big(const FrameGeom& g, const StftEpilogue& ep, hipStream_t st
     TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), bytes));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * WAVES), bytes, stream, g, tb1k, tbn, ep, win_vec4);
     TAC_HIP(hipGetLastError());
+    set_last_route("stft_big_kernel<%d, %d, %d>", S, MODE, WAVES);
     return TAC_OK;
 }
 
