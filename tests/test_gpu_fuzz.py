@@ -24,7 +24,8 @@ CASES = int(os.environ.get('TAC_FUZZ_CASES', '32'))
 SEED = int(os.environ.get('TAC_FUZZ_SEED', '0'))
 DB_ABS = 1e-3
 FFT_SIZES = [32, 64, 128, 256, 400, 512, 1024, 2048, 4096]
-ODD_SIZES = [100, 300, 1000, 1536, 3000]          # windowed-DFT matrix route
+ODD_SIZES = [100, 300, 1000, 1536, 3000, 882, 960, 6000,      # generic Stockham kernel (even, 7-smooth half: csrc/stft_smooth.hip)
+             77, 501, 1018, 2602]                          # windowed-DFT matrix route (odd, or a half with a larger prime factor)
 
 
 @pytest.fixture(scope='module')

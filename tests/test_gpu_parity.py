@@ -200,17 +200,19 @@ def test_fused_mel_parameter_sweep_vs_oracle(tac):
 
 
 def test_non_power_of_two_and_large_n_fft(tac, golden):
-    """fft_length outside the FFT kernels' power-of-two range runs as a windowed-DFT matrix product on the fp32
-    MFMA (reference: torch.stft accepts any n_fft, SURVEY §8 a-1 [probed] N=400)."""
+    """fft_length outside the FFT kernels (powers of two, 400, even lengths with a 7-smooth half) runs as a windowed-DFT matrix
+    product on the fp32 MFMA (reference: torch.stft accepts any n_fft, SURVEY §8 a-1 [probed] N=400)."""
     base = signals.audio_like((1, 2, 20000), seed=4)
     z = tac.stft(dev(base[..., :6000]), 400, hop_length=160)
     want = golden('g4_variants')['n400_h160']
     assert tuple(z.shape) == want.shape
     assert rel_err(host(z), want) < 5e-6
     x = signals.audio_like((2, 1, 30000), seed=31)
-    for n, hop, kw in ((8192, 2048, {}), (6000, 1500, dict(win_length=4800)), (100, 30, dict(onesided=False)),
-                       (1000, 250, dict(center=False, normalized=True))):
+    for n, hop, kw in ((1001, 250, {}), (2018, 500, dict(win_length=1600)), (77, 30, dict(onesided=False)),
+                       (5006, 1250, dict(center=False, normalized=True)), (16, 4, {})):   # odd, or a half with a prime factor above 7
+        before = launches(tac)
         got = host(tac.stft(dev(x), n, hop_length=hop, **kw))
+        assert launched_since(tac, before) == {'tac_apply_filterbank_f32': 1}, n
         ref = numpy_ref.stft(x, n, hop, **kw)
         assert got.shape[:-1] == ref.shape
         assert rel_err(got[..., 0] + 1j * got[..., 1], ref) < 5e-6
@@ -231,6 +233,50 @@ def test_non_power_of_two_and_large_n_fft(tac, golden):
         assert rel_err(got[..., 0] + 1j * got[..., 1], ref) < 5e-6
     finally:
         tac.set_strict(True)
+
+
+def test_smooth_fft_lengths_generic_stockham_kernel(tac):
+    """Even fft_lengths with a 7-smooth half that are not powers of two (480 / 960 / 1200 / 1920: 10 - 40 ms at 48 kHz, 882: 20 ms at
+    44.1 kHz; csrc/stft_smooth.hip, round 5: radix 4 / 2 / 3 / 5 / 7 Stockham passes, `group` frames per workgroup) against the
+    float64 restatement: complex rows one- and two-sided, pad modes, centre off, short windows, odd hops (scalar loads),
+    normalisation, tiny and maximal sizes; |X|^p rows and dB; the Melspectrogram chain.  Strict mode is on."""
+    x = signals.audio_like((3, 2, 20000), seed=78)
+    cases = [(480, 120, {}), (882, 441, {}), (960, 240, dict(onesided=False)), (1200, 300, dict(center=False, normalized=True)),
+             (1920, 480, dict(pad_mode='constant', win_length=1000)), (3000, 751, dict(pad_mode='replicate')),
+             (6000, 1500, dict(win_length=4800)), (8100, 2025, dict(pad_mode='circular')), (12, 5, dict(onesided=False)),
+             (14, 7, {}), (100, 30, dict(onesided=False)), (1000, 250, dict(center=False, normalized=True)), (7168, 1792, {}),
+             (1536, 384, dict(win_length=3)), (2450, 613, {})]
+    for n, hop, kw in cases:
+        before = launches(tac)
+        got = host(tac.stft(dev(x), n, hop_length=hop, **kw))
+        assert launched_since(tac, before) == {'tac_stft_f32': 1}, (n, hop, kw)
+        assert tac._native.lib().tac_last_route().decode() == 'stft_smooth_kernel<0>'
+        ref = numpy_ref.stft(x, n, hop, **kw)
+        assert got.shape[:-1] == ref.shape
+        assert rel_err(got[..., 0] + 1j * got[..., 1], ref) < 5e-6, (n, hop, kw)
+    got = host(tac.stft(dev(x[0, :, :700]), 960, hop_length=240))          # rows shorter than a frame
+    assert rel_err(got[..., 0] + 1j * got[..., 1], numpy_ref.stft(x[0, :, :700], 960, 240)) < 5e-6
+    for n, hop in ((960, 240), (1200, 300), (882, 441), (6000, 1500)):
+        mag2 = np.abs(numpy_ref.stft(x, n, hop)) ** 2
+        for power in (2.0, 1.0, 0.7):
+            before = launches(tac)
+            got = host(tac.Spectrogram(n, hop, power=power).cuda()(dev(x)))
+            assert launched_since(tac, before) == {'tac_spectrogram_f32': 1}
+            assert rel_err(got, mag2 ** (power / 2)) < 1e-5, (n, power)
+        chain = torch.nn.Sequential(*tac.Spectrogram(n, hop, power=2.), tac.AmplitudeToDb()).cuda()
+        want_db = 10.0 * np.log10(np.maximum(mag2 ** 2, 1e-7))                 # (amplitude_to_db squares its input)
+        big = mag2 > 1e-6 * mag2.max()
+        assert np.abs(host(chain(dev(x))) - want_db)[big].max() < DB_ABS, n
+        mel = tac.Melspectrogram(num_mels=40, sample_rate=48000, fft_length=n, hop_length=hop).cuda()
+        want_mel = torch_ref.melspectrogram(torch.from_numpy(x), num_mels=40, sample_rate=48000, n_fft=n, hop=hop).numpy()
+        assert rel_err(host(mel(dev(x))), want_mel) < 2e-5, n
+    xg = dev(x).requires_grad_(True)                       # gradients keep the DFT-matrix adjoint: no stock-torch route
+    routed = dict(tac._ops.composite_calls)
+    (g1,) = torch.autograd.grad(tac.Spectrogram(960, 240, power=2.).cuda()(xg).sum(), xg)
+    assert tac._ops.composite_calls == routed
+    xr = torch.from_numpy(x).double().requires_grad_(True)
+    (g0,) = torch.autograd.grad(torch_ref.spectrogram(xr, 960, 240, window=torch.hann_window(960, dtype=torch.float64), power=2.0).sum(), xr)
+    assert rel_err(host(g1), g0.numpy()) < 1e-4
 
 
 def test_fft_length_8192_to_32768_four_step_kernel(tac):

@@ -103,7 +103,7 @@ class StftGeometry(object):
     """Validated geometry of one stft call on one input layout (the checks ``torch.stft`` performs, reference
     functional.py:99-107), cached per (shape, strides, parameters) so that a repeated call costs a dict lookup."""
     __slots__ = ('lead', 'length', 'rows', 'row_stride', 'flatten', 'n_fft', 'hop', 'win_length', 'center',
-                 'pad_mode', 'normalized', 'onesided', 'n_frames', 'n_bins', 'fft_kernel', 'mixed_radix', 'desc',
+                 'pad_mode', 'normalized', 'onesided', 'n_frames', 'n_bins', 'fft_kernel', 'pow2_kernel', 'mixed_radix', 'desc',
                  'stft_shape', 'spec_shape', 'routes')
 
 
@@ -141,8 +141,8 @@ def check_stft_args(shape, n_fft, hop, win_length, center, pad_mode):
 
 def fft_kernel_size(n_fft):
     """power-of-two sizes in [32, 4096] take the wave-level FFT kernels (``big_fft_size``: 8192 ... 32768 the four-step
-    kernel); every other size up to 8192 is evaluated as a windowed-DFT matrix product on the fp32 matrix cores
-    (``_stft_dft``) — except the sizes of ``mixed_radix_size``."""
+    kernel; ``smooth_fft_size``: even lengths with a 7-smooth half the generic Stockham kernel); every other size up to 8192
+    is evaluated as a windowed-DFT matrix product on the fp32 matrix cores (``_stft_dft``) — except ``mixed_radix_size``."""
     return (n_fft & (n_fft - 1)) == 0 and 32 <= n_fft <= 4096
 
 
@@ -157,6 +157,19 @@ def big_fft_size(n_fft):
     (csrc/stft_big.hip, round 5) — forward stft / spectrogram rows of every form; gradients at 8192 keep the DFT-matrix
     adjoint, above that they are a composite route."""
     return n_fft in (8192, 16384, 32768)
+
+
+def smooth_fft_size(n_fft):
+    """even fft_length <= 8192 (not a power of two, not 400) whose half is 7-smooth — 480, 960, 1200, 1920, 882 ...: generic
+    Stockham passes of radix 4 / 2 / 3 / 5 / 7 (csrc/stft_smooth.hip, round 5) for the forward stft / spectrogram rows; their
+    gradients keep the DFT-matrix adjoint.  Mirrors ``stft_smooth_covers`` of the library."""
+    if n_fft < 8 or n_fft % 2 or n_fft > 8192 or n_fft & (n_fft - 1) == 0 or n_fft == 400:
+        return False
+    m = n_fft // 2
+    for r in (2, 3, 5, 7):
+        while m % r == 0:
+            m //= r
+    return m == 1
 
 
 def hip_covers_n_fft(n_fft):
@@ -190,7 +203,8 @@ def geometry(wave, n_fft, hop, win_length, center, pad_mode, normalized, oneside
     g.center, g.pad_mode, g.normalized, g.onesided = bool(center), pad_mode, bool(normalized), bool(onesided)
     g.n_frames = stft_frames(length, n_fft, hop, center)
     g.n_bins = n_fft // 2 + 1 if onesided else n_fft
-    g.fft_kernel = fft_kernel_size(n_fft) or big_fft_size(n_fft)
+    g.fft_kernel = fft_kernel_size(n_fft) or big_fft_size(n_fft) or smooth_fft_size(n_fft)   # tac_stft_f32 / tac_spectrogram_f32 take it
+    g.pow2_kernel = fft_kernel_size(n_fft)                  # ... and the fused chains / gradient kernels of the power-of-two sizes
     if not g.fft_kernel and n_fft > 8192:
         raise NotImplementedError('stft: fft_length %d is outside the HIP path (power of two in [32, 32768], or any '
                                   'length <= 8192 through the DFT-matrix kernel)' % n_fft)
@@ -356,7 +370,7 @@ def _filterbank_plan(fb):
 def _fused_mel_route(g, fb, power):
     """'sparse' / 'mfma' when one fused kernel covers this geometry + filterbank, else None (then the caller chains
     the spectrogram, filterbank and dB kernels)."""
-    if not ((g.fft_kernel or g.mixed_radix) and g.onesided and g.n_fft <= 2048 and fb.dim() == 2 and
+    if not ((g.pow2_kernel or g.mixed_radix) and g.onesided and g.n_fft <= 2048 and fb.dim() == 2 and
             fb.shape[0] == g.n_bins and 0 < fb.shape[1] <= 512 and fb.is_contiguous()):
         return None
     if g.mixed_radix:       # fft_length 400: only the band-sparse form has a fused kernel
@@ -1209,7 +1223,7 @@ def melspectrogram_coded(samples, window, fb, n_fft, hop, win_length, center, pa
     the frame load.  Returns None when the single-kernel route does not cover the configuration — the caller then
     converts first and takes the float32 path."""
     g = geometry(samples, n_fft, hop, win_length, center, pad_mode, normalized, onesided)
-    if not ((g.fft_kernel or g.mixed_radix) and g.onesided and g.n_fft in (256, 400, 512, 1024, 2048) and fb.dim() == 2
+    if not ((g.pow2_kernel or g.mixed_radix) and g.onesided and g.n_fft in (256, 400, 512, 1024, 2048) and fb.dim() == 2
             and fb.shape[0] == g.n_bins
             and fb.is_contiguous() and power in (1.0, 2.0) and MEL_PATH != 'mfma'):
         return None

@@ -602,6 +602,8 @@ int try_launch_n4096(const FrameGeom& g, const StftEpilogue& ep, int mode, hipSt
 int try_launch_small(int n_fft, const FrameGeom& g, const Tables& tb, const StftEpilogue& ep, int mode, hipStream_t stream);
 int try_launch_n400(const FrameGeom& g, const StftEpilogue& ep, int mode, hipStream_t stream);   // stft_n400.hip
 int launch_stft_big(int n_fft, const FrameGeom& g, const StftEpilogue& ep, int mode, hipStream_t stream);   // stft_big.hip
+bool stft_smooth_covers(int n_fft);                                                                           // stft_smooth.hip
+int launch_stft_smooth(int n_fft, const FrameGeom& g, const StftEpilogue& ep, int mode, hipStream_t stream);
 
 static inline bool is_big_fft(int n_fft) { return n_fft == 8192 || n_fft == 16384 || n_fft == 32768; }
 
@@ -632,7 +634,8 @@ static int dispatch_stft(int n_fft, const FrameGeom& g, const Tables& tb, const 
         case 8192:
         case 16384:
         case 32768: return launch_stft_big(n_fft, g, ep, MODE, s);      // four-step transform, one frame per workgroup
-        default: return TAC_E_UNSUPPORTED;
+        default:                                                    // even lengths with a 7-smooth half: generic Stockham passes
+            return stft_smooth_covers(n_fft) ? launch_stft_smooth(n_fft, g, ep, MODE, s) : TAC_E_UNSUPPORTED;
     }
 }
 
@@ -645,7 +648,7 @@ int tac_stft_f32(const float* wave, const float* window, const tac_stft_desc* d,
     if (!out) return TAC_E_INVALID;
     FrameGeom g;
     int64_t T = 0;
-    int rc = make_geometry(wave, window, d, &g, &T, d && is_big_fft(d->n_fft));
+    int rc = make_geometry(wave, window, d, &g, &T, d && (is_big_fft(d->n_fft) || stft_smooth_covers(d->n_fft)));
     if (rc != TAC_OK) return rc;
     Tables tb;
     rc = get_tables(d->n_fft, &tb);
@@ -660,7 +663,7 @@ int tac_spectrogram_f32(const float* wave, const float* window, const tac_stft_d
     if (!out) return TAC_E_INVALID;
     FrameGeom g;
     int64_t T = 0;
-    int rc = make_geometry(wave, window, d, &g, &T, d && is_big_fft(d->n_fft));
+    int rc = make_geometry(wave, window, d, &g, &T, d && (is_big_fft(d->n_fft) || stft_smooth_covers(d->n_fft)));
     if (rc != TAC_OK) return rc;
     Tables tb;
     rc = get_tables(d->n_fft, &tb);

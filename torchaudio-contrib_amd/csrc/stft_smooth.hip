@@ -1,0 +1,243 @@
+// stft_smooth.hip — fft_lengths that are not powers of two (round 5; reference functional.py:99-107 takes any fft_length: 480, 960,
+// 1200, 1920 ... are the 10 / 20 / 25 / 40 ms windows of 48 kHz audio, 882 = 20 ms at 44.1 kHz): any EVEN N <= 8192 whose half
+// M = N / 2 is 7-smooth, as an M-point complex Stockham transform of radix 4 / 2 / 3 / 5 / 7 passes + the real-input split.
+//
+// One 256-thread workgroup transforms `group` = 2048 / M frames side by side (small M: keeps the threads busy), ping-ponging
+// between two LDS buffers; the M + 1 twiddles exp(-2 pi i k / N) sit in LDS too (rounded once from double on the host).  Interior
+// frames are loaded as 8-byte sample pairs, frames touching the padding sample by sample; rows leave as 8-byte (complex) or
+// 4-byte (|X|^p, dB) stores of consecutive bins.  The same plain design as the float64 chain (chain_f64.hip) — these sizes are
+// not the measured path; before round 5 they ran as a windowed-DFT matrix product on the fp32 matrix cores (O(N^2): 2 - 16 x
+// slower than torch.stft on the same GPU, tools/r05/time_nonpow2.py), which remains the route of odd and non-smooth lengths.
+// fft_length 400 keeps its own kernel (stft_n400.hip).
+#include "host_common.hpp"
+
+#include <cmath>
+#include <map>
+#include <mutex>
+#include <vector>
+
+namespace tac {
+namespace {
+
+constexpr int SM_THREADS = 256;
+
+// radices of the M-point transform: 4s, then a 2, then 3s, 5s, 7s — so the counter of a radix-4 / radix-2 pass is a power of two
+struct SmoothPlan {
+    int n, group;
+    int r[16];
+};
+
+bool smooth_plan(int n_fft, SmoothPlan* plan) {
+    plan->n = 0;
+    plan->group = 1;
+    if (n_fft < 8 || (n_fft & 1) || n_fft > 8192 || is_pow2(n_fft)) return false;
+    int m = n_fft / 2;
+    const int radices[5] = {4, 2, 3, 5, 7};
+    for (int r : radices)
+        while (m % r == 0 && plan->n < 16) {
+            plan->r[plan->n++] = r;
+            m /= r;
+        }
+    const int per = 2048 / (n_fft / 2);
+    plan->group = per < 1 ? 1 : (per > 16 ? 16 : per);
+    return m == 1 && plan->n > 0;
+}
+
+int smooth_twiddles(int n_fft, const cf** out) {
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, const cf*> cache;
+    int dev = 0;
+    TAC_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_pair(n_fft, dev);
+    auto it = cache.find(key);
+    if (it != cache.end()) {
+        *out = it->second;
+        return TAC_OK;
+    }
+    const int M = n_fft / 2;
+    std::vector<cf> host((size_t)M + 1);
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int k = 0; k <= M; ++k) {
+        const double a = -two_pi * (double)k / (double)n_fft;
+        float c = (float)std::cos(a), s = (float)std::sin(a);
+        if ((4LL * k) % n_fft == 0) {                                        // exact quarter turns stay exact
+            const int quad = (int)((4LL * k) / n_fft) & 3;
+            c = quad == 0 ? 1.0f : (quad == 2 ? -1.0f : 0.0f);
+            s = quad == 1 ? -1.0f : (quad == 3 ? 1.0f : 0.0f);
+        }
+        host[k] = mkc(c, s);
+    }
+    cf* dptr = nullptr;
+    TAC_HIP(hipMalloc((void**)&dptr, host.size() * sizeof(cf)));
+    TAC_HIP(hipMemcpy(dptr, host.data(), host.size() * sizeof(cf), hipMemcpyHostToDevice));
+    cache[key] = dptr;
+    *out = dptr;
+    return TAC_OK;
+}
+
+// one radix-3 / 5 / 7 Stockham pass over the workgroup's frames: the small transform's roots W_R^(t u) = W_N^((N / R)(t u mod R))
+// come from the table
+template <int R, class Twiddle>
+__device__ __forceinline__ void smooth_pass_odd(const cf* __restrict__ src, cf* __restrict__ dst, int M, int N, int ns, int frames,
+                                                int tid, Twiddle wn) {
+    const int cnt = M / R, step = cnt / ns, unit_r = N / R;
+    cf root[R];                                                              // W_R^t, t < R (root[0] unused)
+#pragma unroll
+    for (int t = 1; t < R; ++t) root[t] = wn(unit_r * t);
+    for (int jj = tid; jj < frames * cnt; jj += SM_THREADS) {
+        const int f = frames == 1 ? 0 : jj / cnt, j = jj - f * cnt, base = f * M;
+        const int k = j % ns, q = k * step;
+        cf v[R];
+        v[0] = src[base + j];
+#pragma unroll
+        for (int t = 1; t < R; ++t) v[t] = cmul(src[base + j + t * cnt], wn(2 * t * q));
+        const int j0 = base + (j - k) * R + k;
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            cf acc = v[0];
+#pragma unroll
+            for (int t = 1; t < R; ++t) acc = (t * u) % R == 0 ? cadd(acc, v[t]) : cadd(acc, cmul(v[t], root[(t * u) % R]));
+            dst[j0 + u * ns] = acc;
+        }
+    }
+}
+
+// MODE 0: complex rows [F][2]; 1: |X|^power rows [F] (+ dB)
+template <int MODE>
+__global__ void __launch_bounds__(SM_THREADS)
+stft_smooth_kernel(FrameGeom g, const cf* __restrict__ tw, StftEpilogue ep, SmoothPlan plan, int N) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf* const wl = reinterpret_cast<cf*>(smem_raw);
+    const int M = N >> 1, tid = threadIdx.x, G = plan.group;
+    cf* const bufa = wl + M + 1;
+    cf* const bufb = bufa + G * M;
+    for (int i = tid; i <= M; i += SM_THREADS) wl[i] = tw[i];
+    auto wn = [&](int j) -> cf {                                             // exp(-2 pi i j / N), 0 <= j < N
+        const int r = j >= M ? j - M : j;
+        const cf v = wl[r];
+        return j >= M ? mkc(-v.x, -v.y) : v;
+    };
+    const int F = ep.onesided ? M + 1 : N;
+    const long long T = g.n_frames, units = g.rows * T;
+    const int L = (int)g.length;
+    for (long long first = (long long)blockIdx.x * G; first < units; first += (long long)gridDim.x * G) {
+        const int frames = (int)(units - first < G ? units - first : G);
+        __syncthreads();                                                      // the previous group's split has read its buffer
+        for (int ii = tid; ii < frames * M; ii += SM_THREADS) {
+            const int f = frames == 1 ? 0 : ii / M, i = ii - f * M;
+            const long long unit = first + f, row = unit / T;
+            const float* __restrict__ rp = g.wave + row * g.row_stride;
+            const long long s0 = (unit - row * T) * g.hop - g.center_pad;
+            cf x;
+            if (g.vec2_ok && s0 >= 0 && s0 + N <= g.length) {
+                x = *reinterpret_cast<const cf*>(rp + s0 + 2 * i);
+            } else {
+                bool z0, z1;
+                const int j0 = padded_index((int)s0 + 2 * i, L, g.pad_mode, &z0);
+                const int j1 = padded_index((int)s0 + 2 * i + 1, L, g.pad_mode, &z1);
+                const float a = rp[j0], b = rp[j1];
+                x = mkc(z0 ? 0.0f : a, z1 ? 0.0f : b);
+            }
+            bufa[ii] = cmul_elem(x, window_pair(g, i));
+        }
+        __syncthreads();
+        cf* src = bufa;
+        cf* dst = bufb;
+        int ns = 1;
+        for (int p = 0; p < plan.n; ++p) {                                    // Stockham passes, ns = product of the radices so far
+            const int r = plan.r[p], cnt = M / r, step = cnt / ns;            // pass twiddle W_M^(t k step) = W_N^(2 t k step)
+            if (r == 4) {
+                for (int jj = tid; jj < frames * cnt; jj += SM_THREADS) {
+                    const int f = frames == 1 ? 0 : jj / cnt, j = jj - f * cnt, base = f * M;
+                    const int k = j & (ns - 1), q = k * step;
+                    const cf v0 = src[base + j], v1 = cmul(src[base + j + cnt], wn(2 * q)),
+                             v2 = cmul(src[base + j + 2 * cnt], wn(4 * q)), v3 = cmul(src[base + j + 3 * cnt], wn(6 * q));
+                    const cf s0c = cadd(v0, v2), s1c = csub(v0, v2), s2c = cadd(v1, v3), s3c = csub(v1, v3);
+                    const int j0 = base + ((j - k) << 2) + k;
+                    dst[j0] = cadd(s0c, s2c);
+                    dst[j0 + ns] = mkc(s1c.x + s3c.y, s1c.y - s3c.x);         // s1 - i s3
+                    dst[j0 + 2 * ns] = csub(s0c, s2c);
+                    dst[j0 + 3 * ns] = mkc(s1c.x - s3c.y, s1c.y + s3c.x);
+                }
+            } else if (r == 2) {
+                for (int jj = tid; jj < frames * cnt; jj += SM_THREADS) {
+                    const int f = frames == 1 ? 0 : jj / cnt, j = jj - f * cnt, base = f * M;
+                    const int k = j & (ns - 1);
+                    const cf v0 = src[base + j], v1 = cmul(src[base + j + cnt], wn(2 * k * step));
+                    const int j0 = base + ((j - k) << 1) + k;
+                    dst[j0] = cadd(v0, v1);
+                    dst[j0 + ns] = csub(v0, v1);
+                }
+            } else if (r == 3) {
+                smooth_pass_odd<3>(src, dst, M, N, ns, frames, tid, wn);
+            } else if (r == 5) {
+                smooth_pass_odd<5>(src, dst, M, N, ns, frames, tid, wn);
+            } else {
+                smooth_pass_odd<7>(src, dst, M, N, ns, frames, tid, wn);
+            }
+            __syncthreads();
+            cf* t = src; src = dst; dst = t;
+            ns *= r;
+        }
+        // real-input split: X[k] = (Z[k] + conj Z[M-k]) / 2 - i W_N^k (Z[k] - conj Z[M-k]) / 2, k = 0..M
+        for (int kk = tid; kk < frames * (M + 1); kk += SM_THREADS) {
+            const int f = frames == 1 ? 0 : kk / (M + 1), k = kk - f * (M + 1);
+            const cf* __restrict__ z = src + f * M;
+            const long long unit = first + f;
+            const cf a = z[k == M ? 0 : k], braw = z[k == 0 ? 0 : M - k];
+            const cf b = mkc(braw.x, -braw.y);
+            const cf e = cscale(cadd(a, b), 0.5f), o = cscale(csub(a, b), 0.5f);
+            const cf wo = cmul(k == M ? mkc(-1.0f, 0.0f) : wn(k), o);
+            const cf X = cscale(mkc(e.x + wo.y, e.y - wo.x), g.scale);       // e - i (w o)
+            if constexpr (MODE == 0) {
+                cf* const o2 = reinterpret_cast<cf*>(ep.out) + unit * F;
+                o2[k] = X;
+                if (!ep.onesided && k > 0 && k < M) o2[N - k] = mkc(X.x, -X.y);
+            } else {
+                const float s = cnorm2(X);
+                float val = (ep.power == 2.0f) ? s : ((ep.power == 1.0f) ? sqrtf(s) : powf(sqrtf(s), ep.power));
+                if (ep.db) val = amp_to_db(val, ep.amin, ep.log10_ref);
+                float* const o1 = ep.out + unit * F;
+                o1[k] = val;
+                if (!ep.onesided && k > 0 && k < M) o1[N - k] = val;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+bool stft_smooth_covers(int n_fft) {
+    SmoothPlan plan;
+    return n_fft != 400 && smooth_plan(n_fft, &plan);
+}
+
+// Entry used by stft_kernels.hip's dispatcher (mode 0: complex rows, 1: |X|^power rows with the optional dB epilogue).
+int launch_stft_smooth(int n_fft, const FrameGeom& g, const StftEpilogue& ep, int mode, hipStream_t stream) {
+    SmoothPlan plan;
+    if (!smooth_plan(n_fft, &plan)) return TAC_E_UNSUPPORTED;
+    const cf* tw = nullptr;
+    const int rc = smooth_twiddles(n_fft, &tw);
+    if (rc != TAC_OK) return rc;
+    const int M = n_fft / 2;
+    const long long units = g.rows * g.n_frames;
+    const size_t lds = ((size_t)(M + 1) + 2 * (size_t)M * plan.group) * sizeof(cf);
+    int per_cu = (int)((160 * 1024) / lds);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+    long long blocks = (units + plan.group - 1) / plan.group;
+    const long long cap = (long long)device_cu_count() * per_cu;
+    if (blocks > cap) blocks = cap;
+    if (mode == 0) {
+        TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(stft_smooth_kernel<0>), (int)lds));
+        hipLaunchKernelGGL(stft_smooth_kernel<0>, dim3((unsigned)blocks), dim3(SM_THREADS), lds, stream, g, tw, ep, plan, n_fft);
+    } else {
+        TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(stft_smooth_kernel<1>), (int)lds));
+        hipLaunchKernelGGL(stft_smooth_kernel<1>, dim3((unsigned)blocks), dim3(SM_THREADS), lds, stream, g, tw, ep, plan, n_fft);
+    }
+    TAC_HIP(hipGetLastError());
+    set_last_route("stft_smooth_kernel<%d>", mode == 0 ? 0 : 1);
+    return TAC_OK;
+}
+
+}  // namespace tac
