@@ -32,7 +32,7 @@ extern "C" {
 
 #define TAC_OK 0
 #define TAC_E_INVALID (-1)      /* bad argument (null pointer, non-positive size, ...)        */
-#define TAC_E_UNSUPPORTED (-2)  /* n_fft not a power of two in [32, 32768] (nor 400), n_mels too large…  */
+#define TAC_E_UNSUPPORTED (-2)  /* n_fft neither a power of two in [32, 32768] nor even with a 7-smooth half, n_mels too large…  */
 #define TAC_E_SHORT_INPUT (-3)  /* signal too short for the requested padding / n_fft          */
 #define TAC_E_LAUNCH (-4)       /* HIP runtime error; see tac_last_hip_error()                 */
 
@@ -56,8 +56,9 @@ typedef struct tac_stft_desc {
     int64_t rows;        /* batch*channel                                              */
     int64_t length;      /* samples per row (L)                                        */
     int64_t row_stride;  /* elements between consecutive rows of `wave`                */
-    int32_t n_fft;       /* power of two, 32..4096; or 400 (STFT / spectrogram, one-sided); 8192 / 16384 / 32768: the forward
-                            STFT / spectrogram rows only (tac_stft_f32, tac_spectrogram_f32: four-step kernel, stft_big.hip) */
+    int32_t n_fft;       /* power of two, 32..4096; or 400 (STFT / spectrogram, one-sided); 8192 / 16384 / 32768, and any even length
+                            <= 8192 whose half is 7-smooth (480, 882, 960, 1200, 1920 ...): the forward STFT / spectrogram rows only
+                            (tac_stft_f32, tac_spectrogram_f32: stft_big.hip / stft_smooth.hip) */
     int32_t hop;         /* > 0                                                        */
     int32_t win_length;  /* 1..n_fft; window is zero-padded centred to n_fft           */
     int32_t center;      /* 1: pad n_fft/2 both sides with pad_mode                    */

@@ -250,7 +250,7 @@ def test_smooth_fft_lengths_generic_stockham_kernel(tac):
         before = launches(tac)
         got = host(tac.stft(dev(x), n, hop_length=hop, **kw))
         assert launched_since(tac, before) == {'tac_stft_f32': 1}, (n, hop, kw)
-        assert tac._native.lib().tac_last_route().decode() == 'stft_smooth_kernel<0>'
+        assert tac._native.lib().tac_last_route().decode() .startswith('stft_smooth_kernel<0, ')
         ref = numpy_ref.stft(x, n, hop, **kw)
         assert got.shape[:-1] == ref.shape
         assert rel_err(got[..., 0] + 1j * got[..., 1], ref) < 5e-6, (n, hop, kw)

@@ -2,8 +2,9 @@
 // 1200, 1920 ... are the 10 / 20 / 25 / 40 ms windows of 48 kHz audio, 882 = 20 ms at 44.1 kHz): any EVEN N <= 8192 whose half
 // M = N / 2 is 7-smooth, as an M-point complex Stockham transform of radix 4 / 2 / 3 / 5 / 7 passes + the real-input split.
 //
-// One 256-thread workgroup transforms `group` = 2048 / M frames side by side (small M: keeps the threads busy), ping-ponging
-// between two LDS buffers; the M + 1 twiddles exp(-2 pi i k / N) sit in LDS too (rounded once from double on the host).  Interior
+// M <= 1024: one frame per WAVE (four per 256-thread workgroup, each wave walking its own frames with wave-level fences between
+// the passes — no barrier); larger M: one frame per workgroup.  A frame ping-pongs between two LDS buffers; the M + 1 twiddles
+// exp(-2 pi i k / N) sit in LDS too (rounded once from double on the host).  Interior
 // frames are loaded as 8-byte sample pairs, frames touching the padding sample by sample; rows leave as 8-byte (complex) or
 // 4-byte (|X|^p, dB) stores of consecutive bins.  The same plain design as the float64 chain (chain_f64.hip) — these sizes are
 // not the measured path; before round 5 they ran as a windowed-DFT matrix product on the fp32 matrix cores (O(N^2): 2 - 16 x
@@ -23,13 +24,12 @@ constexpr int SM_THREADS = 256;
 
 // radices of the M-point transform: 4s, then a 2, then 3s, 5s, 7s — so the counter of a radix-4 / radix-2 pass is a power of two
 struct SmoothPlan {
-    int n, group;
+    int n;
     int r[16];
 };
 
 bool smooth_plan(int n_fft, SmoothPlan* plan) {
     plan->n = 0;
-    plan->group = 1;
     if (n_fft < 8 || (n_fft & 1) || n_fft > 8192 || is_pow2(n_fft)) return false;
     int m = n_fft / 2;
     const int radices[5] = {4, 2, 3, 5, 7};
@@ -38,8 +38,6 @@ bool smooth_plan(int n_fft, SmoothPlan* plan) {
             plan->r[plan->n++] = r;
             m /= r;
         }
-    const int per = 2048 / (n_fft / 2);
-    plan->group = per < 1 ? 1 : (per > 16 ? 16 : per);
     return m == 1 && plan->n > 0;
 }
 
@@ -76,23 +74,31 @@ int smooth_twiddles(int n_fft, const cf** out) {
     return TAC_OK;
 }
 
-// one radix-3 / 5 / 7 Stockham pass over the workgroup's frames: the small transform's roots W_R^(t u) = W_N^((N / R)(t u mod R))
-// come from the table
-template <int R, class Twiddle>
-__device__ __forceinline__ void smooth_pass_odd(const cf* __restrict__ src, cf* __restrict__ dst, int M, int N, int ns, int frames,
-                                                int tid, Twiddle wn) {
+// j mod n for 0 <= j < 2^22 and a pass-constant n: one multiply by the reciprocal and a fix-up instead of an integer division
+__device__ __forceinline__ int fast_mod(int j, int n, float inv_n) {
+    int q = (int)((float)j * inv_n);
+    int r = j - q * n;
+    r = r < 0 ? r + n : r;
+    return r >= n ? r - n : r;
+}
+
+// one radix-3 / 5 / 7 Stockham pass over a frame: the small transform's roots W_R^(t u) = W_N^((N / R)(t u mod R)) come from the
+// table
+template <int R, int TPF, class Twiddle>
+__device__ __forceinline__ void smooth_pass_odd(const cf* __restrict__ src, cf* __restrict__ dst, int M, int N, int ns, int lt,
+                                                Twiddle wn) {
     const int cnt = M / R, step = cnt / ns, unit_r = N / R;
+    const float inv_ns = 1.0f / (float)ns;
     cf root[R];                                                              // W_R^t, t < R (root[0] unused)
 #pragma unroll
     for (int t = 1; t < R; ++t) root[t] = wn(unit_r * t);
-    for (int jj = tid; jj < frames * cnt; jj += SM_THREADS) {
-        const int f = frames == 1 ? 0 : jj / cnt, j = jj - f * cnt, base = f * M;
-        const int k = j % ns, q = k * step;
+    for (int j = lt; j < cnt; j += TPF) {
+        const int k = fast_mod(j, ns, inv_ns), q = k * step;
         cf v[R];
-        v[0] = src[base + j];
+        v[0] = src[j];
 #pragma unroll
-        for (int t = 1; t < R; ++t) v[t] = cmul(src[base + j + t * cnt], wn(2 * t * q));
-        const int j0 = base + (j - k) * R + k;
+        for (int t = 1; t < R; ++t) v[t] = cmul(src[j + t * cnt], wn(2 * t * q));
+        const int j0 = (j - k) * R + k;
 #pragma unroll
         for (int u = 0; u < R; ++u) {
             cf acc = v[0];
@@ -103,89 +109,99 @@ __device__ __forceinline__ void smooth_pass_odd(const cf* __restrict__ src, cf* 
     }
 }
 
-// MODE 0: complex rows [F][2]; 1: |X|^power rows [F] (+ dB)
-template <int MODE>
+// MODE 0: complex rows [F][2]; 1: |X|^power rows [F] (+ dB).  TPF: threads per frame — 64 (M <= 1024: one frame per wave, the four
+// waves of a workgroup walk their own frames and only wave-level fences separate the passes) or 256 (one frame per workgroup,
+// barriers).  LDS: [M + 1 twiddles][256 / TPF frames][2][M].
+template <int MODE, int TPF>
 __global__ void __launch_bounds__(SM_THREADS)
-stft_smooth_kernel(FrameGeom g, const cf* __restrict__ tw, StftEpilogue ep, SmoothPlan plan, int N) {
+stft_smooth_kernel(FrameGeom g, const cf* __restrict__ tw, StftEpilogue ep, SmoothPlan plan, int N, int win_vec2) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int SLOTS = SM_THREADS / TPF;
     cf* const wl = reinterpret_cast<cf*>(smem_raw);
-    const int M = N >> 1, tid = threadIdx.x, G = plan.group;
-    cf* const bufa = wl + M + 1;
-    cf* const bufb = bufa + G * M;
+    const int M = N >> 1, tid = threadIdx.x, lt = tid % TPF;
+    const int slot = __builtin_amdgcn_readfirstlane(tid / TPF);
+    cf* const bufa = wl + M + 1 + slot * 2 * M;
+    cf* const bufb = bufa + M;
     for (int i = tid; i <= M; i += SM_THREADS) wl[i] = tw[i];
+    __syncthreads();
     auto wn = [&](int j) -> cf {                                             // exp(-2 pi i j / N), 0 <= j < N
         const int r = j >= M ? j - M : j;
         const cf v = wl[r];
         return j >= M ? mkc(-v.x, -v.y) : v;
     };
+    auto sync = [&]() {
+        if constexpr (TPF == 64) wave_lds_fence();
+        else __syncthreads();
+    };
     const int F = ep.onesided ? M + 1 : N;
     const long long T = g.n_frames, units = g.rows * T;
     const int L = (int)g.length;
-    for (long long first = (long long)blockIdx.x * G; first < units; first += (long long)gridDim.x * G) {
-        const int frames = (int)(units - first < G ? units - first : G);
-        __syncthreads();                                                      // the previous group's split has read its buffer
-        for (int ii = tid; ii < frames * M; ii += SM_THREADS) {
-            const int f = frames == 1 ? 0 : ii / M, i = ii - f * M;
-            const long long unit = first + f, row = unit / T;
-            const float* __restrict__ rp = g.wave + row * g.row_stride;
-            const long long s0 = (unit - row * T) * g.hop - g.center_pad;
-            cf x;
-            if (g.vec2_ok && s0 >= 0 && s0 + N <= g.length) {
-                x = *reinterpret_cast<const cf*>(rp + s0 + 2 * i);
+    for (long long unit = (long long)blockIdx.x * SLOTS + slot; unit < units; unit += (long long)gridDim.x * SLOTS) {
+        const long long row = unit / T;
+        const float* __restrict__ rp = g.wave + row * g.row_stride;
+        const long long s0 = (unit - row * T) * g.hop - g.center_pad;
+        if (g.vec2_ok && s0 >= 0 && s0 + N <= g.length) {                     // (uniform per frame)
+            const cf* __restrict__ xp = reinterpret_cast<const cf*>(rp + s0);
+            if (win_vec2) {
+                const cf* __restrict__ wp = reinterpret_cast<const cf*>(g.window);
+#pragma unroll 4
+                for (int i = lt; i < M; i += TPF) bufa[i] = cmul_elem(xp[i], wp[i]);
             } else {
+#pragma unroll 2
+                for (int i = lt; i < M; i += TPF) bufa[i] = cmul_elem(xp[i], window_pair(g, i));
+            }
+        } else {
+            for (int i = lt; i < M; i += TPF) {
                 bool z0, z1;
                 const int j0 = padded_index((int)s0 + 2 * i, L, g.pad_mode, &z0);
                 const int j1 = padded_index((int)s0 + 2 * i + 1, L, g.pad_mode, &z1);
                 const float a = rp[j0], b = rp[j1];
-                x = mkc(z0 ? 0.0f : a, z1 ? 0.0f : b);
+                bufa[i] = cmul_elem(mkc(z0 ? 0.0f : a, z1 ? 0.0f : b), window_pair(g, i));
             }
-            bufa[ii] = cmul_elem(x, window_pair(g, i));
         }
-        __syncthreads();
+        sync();
         cf* src = bufa;
         cf* dst = bufb;
         int ns = 1;
         for (int p = 0; p < plan.n; ++p) {                                    // Stockham passes, ns = product of the radices so far
             const int r = plan.r[p], cnt = M / r, step = cnt / ns;            // pass twiddle W_M^(t k step) = W_N^(2 t k step)
             if (r == 4) {
-                for (int jj = tid; jj < frames * cnt; jj += SM_THREADS) {
-                    const int f = frames == 1 ? 0 : jj / cnt, j = jj - f * cnt, base = f * M;
+#pragma unroll 2
+                for (int j = lt; j < cnt; j += TPF) {
                     const int k = j & (ns - 1), q = k * step;
-                    const cf v0 = src[base + j], v1 = cmul(src[base + j + cnt], wn(2 * q)),
-                             v2 = cmul(src[base + j + 2 * cnt], wn(4 * q)), v3 = cmul(src[base + j + 3 * cnt], wn(6 * q));
+                    const cf v0 = src[j], v1 = cmul(src[j + cnt], wn(2 * q)), v2 = cmul(src[j + 2 * cnt], wn(4 * q)),
+                             v3 = cmul(src[j + 3 * cnt], wn(6 * q));
                     const cf s0c = cadd(v0, v2), s1c = csub(v0, v2), s2c = cadd(v1, v3), s3c = csub(v1, v3);
-                    const int j0 = base + ((j - k) << 2) + k;
+                    const int j0 = ((j - k) << 2) + k;
                     dst[j0] = cadd(s0c, s2c);
                     dst[j0 + ns] = mkc(s1c.x + s3c.y, s1c.y - s3c.x);         // s1 - i s3
                     dst[j0 + 2 * ns] = csub(s0c, s2c);
                     dst[j0 + 3 * ns] = mkc(s1c.x - s3c.y, s1c.y + s3c.x);
                 }
             } else if (r == 2) {
-                for (int jj = tid; jj < frames * cnt; jj += SM_THREADS) {
-                    const int f = frames == 1 ? 0 : jj / cnt, j = jj - f * cnt, base = f * M;
+#pragma unroll 2
+                for (int j = lt; j < cnt; j += TPF) {
                     const int k = j & (ns - 1);
-                    const cf v0 = src[base + j], v1 = cmul(src[base + j + cnt], wn(2 * k * step));
-                    const int j0 = base + ((j - k) << 1) + k;
+                    const cf v0 = src[j], v1 = cmul(src[j + cnt], wn(2 * k * step));
+                    const int j0 = ((j - k) << 1) + k;
                     dst[j0] = cadd(v0, v1);
                     dst[j0 + ns] = csub(v0, v1);
                 }
             } else if (r == 3) {
-                smooth_pass_odd<3>(src, dst, M, N, ns, frames, tid, wn);
+                smooth_pass_odd<3, TPF>(src, dst, M, N, ns, lt, wn);
             } else if (r == 5) {
-                smooth_pass_odd<5>(src, dst, M, N, ns, frames, tid, wn);
+                smooth_pass_odd<5, TPF>(src, dst, M, N, ns, lt, wn);
             } else {
-                smooth_pass_odd<7>(src, dst, M, N, ns, frames, tid, wn);
+                smooth_pass_odd<7, TPF>(src, dst, M, N, ns, lt, wn);
             }
-            __syncthreads();
+            sync();
             cf* t = src; src = dst; dst = t;
             ns *= r;
         }
         // real-input split: X[k] = (Z[k] + conj Z[M-k]) / 2 - i W_N^k (Z[k] - conj Z[M-k]) / 2, k = 0..M
-        for (int kk = tid; kk < frames * (M + 1); kk += SM_THREADS) {
-            const int f = frames == 1 ? 0 : kk / (M + 1), k = kk - f * (M + 1);
-            const cf* __restrict__ z = src + f * M;
-            const long long unit = first + f;
-            const cf a = z[k == M ? 0 : k], braw = z[k == 0 ? 0 : M - k];
+#pragma unroll 2
+        for (int k = lt; k <= M; k += TPF) {
+            const cf a = src[k == M ? 0 : k], braw = src[k == 0 ? 0 : M - k];
             const cf b = mkc(braw.x, -braw.y);
             const cf e = cscale(cadd(a, b), 0.5f), o = cscale(csub(a, b), 0.5f);
             const cf wo = cmul(k == M ? mkc(-1.0f, 0.0f) : wn(k), o);
@@ -203,6 +219,7 @@ stft_smooth_kernel(FrameGeom g, const cf* __restrict__ tw, StftEpilogue ep, Smoo
                 if (!ep.onesided && k > 0 && k < M) o1[N - k] = val;
             }
         }
+        sync();                                                               // the next frame's deposit follows these reads
     }
 }
 
@@ -222,21 +239,24 @@ int launch_stft_smooth(int n_fft, const FrameGeom& g, const StftEpilogue& ep, in
     if (rc != TAC_OK) return rc;
     const int M = n_fft / 2;
     const long long units = g.rows * g.n_frames;
-    const size_t lds = ((size_t)(M + 1) + 2 * (size_t)M * plan.group) * sizeof(cf);
+    const int tpf = M <= 1024 ? 64 : 256, slots = SM_THREADS / tpf;
+    const size_t lds = ((size_t)(M + 1) + 2 * (size_t)M * slots) * sizeof(cf);
     int per_cu = (int)((160 * 1024) / lds);
     per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
-    long long blocks = (units + plan.group - 1) / plan.group;
+    long long blocks = (units + slots - 1) / slots;
     const long long cap = (long long)device_cu_count() * per_cu;
     if (blocks > cap) blocks = cap;
-    if (mode == 0) {
-        TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(stft_smooth_kernel<0>), (int)lds));
-        hipLaunchKernelGGL(stft_smooth_kernel<0>, dim3((unsigned)blocks), dim3(SM_THREADS), lds, stream, g, tw, ep, plan, n_fft);
-    } else {
-        TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(stft_smooth_kernel<1>), (int)lds));
-        hipLaunchKernelGGL(stft_smooth_kernel<1>, dim3((unsigned)blocks), dim3(SM_THREADS), lds, stream, g, tw, ep, plan, n_fft);
-    }
+    const int win_vec2 = g.win_length == n_fft && (reinterpret_cast<uintptr_t>(g.window) & 7u) == 0;
+    auto go = [&](auto kern) -> int {
+        TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SM_THREADS), lds, stream, g, tw, ep, plan, n_fft, win_vec2);
+        return TAC_OK;
+    };
+    const int rl = mode == 0 ? (tpf == 64 ? go(stft_smooth_kernel<0, 64>) : go(stft_smooth_kernel<0, 256>))
+                             : (tpf == 64 ? go(stft_smooth_kernel<1, 64>) : go(stft_smooth_kernel<1, 256>));
+    if (rl != TAC_OK) return rl;
     TAC_HIP(hipGetLastError());
-    set_last_route("stft_smooth_kernel<%d>", mode == 0 ? 0 : 1);
+    set_last_route("stft_smooth_kernel<%d, %d>", mode == 0 ? 0 : 1, tpf);
     return TAC_OK;
 }
 
