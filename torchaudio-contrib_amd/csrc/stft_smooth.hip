@@ -3,7 +3,7 @@
 // M = N / 2 is 7-smooth, as an M-point complex Stockham transform of radix 4 / 2 / 3 / 5 / 7 passes + the real-input split.
 //
 // M <= 1024: one frame per WAVE (four per 256-thread workgroup, each wave walking its own frames with wave-level fences between
-// the passes — no barrier); larger M: one frame per workgroup.  A frame ping-pongs between two LDS buffers; the M + 1 twiddles
+// the passes — no barrier); larger M: one frame per workgroup.  A frame ping-pongs between two LDS buffers; the N twiddles
 // exp(-2 pi i k / N) sit in LDS too (rounded once from double on the host).  Interior
 // frames are loaded as 8-byte sample pairs, frames touching the padding sample by sample; rows leave as 8-byte (complex) or
 // 4-byte (|X|^p, dB) stores of consecutive bins.  The same plain design as the float64 chain (chain_f64.hip) — these sizes are
@@ -53,10 +53,9 @@ int smooth_twiddles(int n_fft, const cf** out) {
         *out = it->second;
         return TAC_OK;
     }
-    const int M = n_fft / 2;
-    std::vector<cf> host((size_t)M + 1);
+    std::vector<cf> host((size_t)n_fft);                                     // all N roots: a lookup is one LDS read, no wrap
     const double two_pi = 6.283185307179586476925286766559;
-    for (int k = 0; k <= M; ++k) {
+    for (int k = 0; k < n_fft; ++k) {
         const double a = -two_pi * (double)k / (double)n_fft;
         float c = (float)std::cos(a), s = (float)std::sin(a);
         if ((4LL * k) % n_fft == 0) {                                        // exact quarter turns stay exact
@@ -111,8 +110,8 @@ __device__ __forceinline__ void smooth_pass_odd(const cf* __restrict__ src, cf* 
 
 // MODE 0: complex rows [F][2]; 1: |X|^power rows [F] (+ dB).  TPF: threads per frame — 64 (M <= 1024: one frame per wave, the four
 // waves of a workgroup walk their own frames and only wave-level fences separate the passes) or 256 (one frame per workgroup,
-// barriers).  LDS: [M + 1 twiddles][256 / TPF frames][2][M].
-template <int MODE, int TPF>
+// barriers).  LDS: [N twiddles][256 / TPF frames][2][M].
+template <int MODE, int TPF, bool FULL = true>
 __global__ void __launch_bounds__(SM_THREADS)
 stft_smooth_kernel(FrameGeom g, const cf* __restrict__ tw, StftEpilogue ep, SmoothPlan plan, int N, int win_vec2) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -120,11 +119,14 @@ stft_smooth_kernel(FrameGeom g, const cf* __restrict__ tw, StftEpilogue ep, Smoo
     cf* const wl = reinterpret_cast<cf*>(smem_raw);
     const int M = N >> 1, tid = threadIdx.x, lt = tid % TPF;
     const int slot = __builtin_amdgcn_readfirstlane(tid / TPF);
-    cf* const bufa = wl + M + 1 + slot * 2 * M;
+    // FULL: all N roots in LDS (a lookup is one read); else the first M + 1 and W^(j) = -W^(j - M) — the largest sizes, where the
+    // full table would leave room for one workgroup per CU only
+    cf* const bufa = wl + (FULL ? N : M + 1) + slot * 2 * M;
     cf* const bufb = bufa + M;
-    for (int i = tid; i <= M; i += SM_THREADS) wl[i] = tw[i];
+    for (int i = tid; i < (FULL ? N : M + 1); i += SM_THREADS) wl[i] = tw[i];
     __syncthreads();
     auto wn = [&](int j) -> cf {                                             // exp(-2 pi i j / N), 0 <= j < N
+        if constexpr (FULL) return wl[j];
         const int r = j >= M ? j - M : j;
         const cf v = wl[r];
         return j >= M ? mkc(-v.x, -v.y) : v;
@@ -165,7 +167,18 @@ stft_smooth_kernel(FrameGeom g, const cf* __restrict__ tw, StftEpilogue ep, Smoo
         int ns = 1;
         for (int p = 0; p < plan.n; ++p) {                                    // Stockham passes, ns = product of the radices so far
             const int r = plan.r[p], cnt = M / r, step = cnt / ns;            // pass twiddle W_M^(t k step) = W_N^(2 t k step)
-            if (r == 4) {
+            if (r == 4 && ns == 1) {                                          // first pass: every twiddle is 1
+#pragma unroll 2
+                for (int j = lt; j < cnt; j += TPF) {
+                    const cf v0 = src[j], v1 = src[j + cnt], v2 = src[j + 2 * cnt], v3 = src[j + 3 * cnt];
+                    const cf s0c = cadd(v0, v2), s1c = csub(v0, v2), s2c = cadd(v1, v3), s3c = csub(v1, v3);
+                    cf* const d = dst + 4 * j;
+                    d[0] = cadd(s0c, s2c);
+                    d[1] = mkc(s1c.x + s3c.y, s1c.y - s3c.x);
+                    d[2] = csub(s0c, s2c);
+                    d[3] = mkc(s1c.x - s3c.y, s1c.y + s3c.x);
+                }
+            } else if (r == 4) {
 #pragma unroll 2
                 for (int j = lt; j < cnt; j += TPF) {
                     const int k = j & (ns - 1), q = k * step;
@@ -204,7 +217,7 @@ stft_smooth_kernel(FrameGeom g, const cf* __restrict__ tw, StftEpilogue ep, Smoo
             const cf a = src[k == M ? 0 : k], braw = src[k == 0 ? 0 : M - k];
             const cf b = mkc(braw.x, -braw.y);
             const cf e = cscale(cadd(a, b), 0.5f), o = cscale(csub(a, b), 0.5f);
-            const cf wo = cmul(k == M ? mkc(-1.0f, 0.0f) : wn(k), o);
+            const cf wo = cmul(wn(k), o);                                    // (W_N^M = -1 is in the table)
             const cf X = cscale(mkc(e.x + wo.y, e.y - wo.x), g.scale);       // e - i (w o)
             if constexpr (MODE == 0) {
                 cf* const o2 = reinterpret_cast<cf*>(ep.out) + unit * F;
@@ -240,7 +253,9 @@ int launch_stft_smooth(int n_fft, const FrameGeom& g, const StftEpilogue& ep, in
     const int M = n_fft / 2;
     const long long units = g.rows * g.n_frames;
     const int tpf = M <= 1024 ? 64 : 256, slots = SM_THREADS / tpf;
-    const size_t lds = ((size_t)(M + 1) + 2 * (size_t)M * slots) * sizeof(cf);
+    const size_t lds_full = ((size_t)n_fft + 2 * (size_t)M * slots) * sizeof(cf), lds_half = lds_full - (size_t)(M - 1) * sizeof(cf);
+    const bool full = !((160 * 1024) / lds_full < 2 && (160 * 1024) / lds_half >= 2);       // (6000: 96 KB against 72 KB)
+    const size_t lds = full ? lds_full : lds_half;
     int per_cu = (int)((160 * 1024) / lds);
     per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
     long long blocks = (units + slots - 1) / slots;
@@ -252,8 +267,8 @@ int launch_stft_smooth(int n_fft, const FrameGeom& g, const StftEpilogue& ep, in
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SM_THREADS), lds, stream, g, tw, ep, plan, n_fft, win_vec2);
         return TAC_OK;
     };
-    const int rl = mode == 0 ? (tpf == 64 ? go(stft_smooth_kernel<0, 64>) : go(stft_smooth_kernel<0, 256>))
-                             : (tpf == 64 ? go(stft_smooth_kernel<1, 64>) : go(stft_smooth_kernel<1, 256>));
+    const int rl = mode == 0 ? (tpf == 64 ? go(stft_smooth_kernel<0, 64>) : (full ? go(stft_smooth_kernel<0, 256>) : go(stft_smooth_kernel<0, 256, false>)))
+                             : (tpf == 64 ? go(stft_smooth_kernel<1, 64>) : (full ? go(stft_smooth_kernel<1, 256>) : go(stft_smooth_kernel<1, 256, false>)));
     if (rl != TAC_OK) return rl;
     TAC_HIP(hipGetLastError());
     set_last_route("stft_smooth_kernel<%d, %d>", mode == 0 ? 0 : 1, tpf);
