@@ -1188,11 +1188,14 @@ def test_autograd_matches_the_reference_chain(tac, shape, n_fft, hop, mels):
 @pytest.mark.parametrize('n_fft,hop,win_length,onesided,center,pad_mode,normalized', [
     (400, 160, None, True, True, 'reflect', False),       # the speech front end (mixed-radix forward kernel)
     (400, 100, 320, False, True, 'constant', True),       # ... two-sided, short window, normalized
-    (300, 75, None, True, True, 'reflect', False),        # DFT-matrix size
+    (300, 75, None, True, True, 'reflect', False),        # generic Stockham kernel (7-smooth half), forward and adjoint
     (250, 100, 200, True, False, 'reflect', False),       # ... not centred, short window
+    (1001, 250, None, True, True, 'reflect', False),      # odd: DFT-matrix product, forward and adjoint
+    (1018, 254, 800, False, True, 'constant', False),     # half = 509 (prime): DFT matrix, two-sided
     (512, 128, None, False, True, 'replicate', False),    # two-sided power of two
     (2048, 500, 1500, True, True, 'circular', False),     # window gradient at an FFT size, hop not a multiple of 128
-    (4500, 1125, None, True, True, 'reflect', False),     # beyond the FFT kernels: DFT matrix
+    (4500, 1125, None, True, True, 'reflect', False),     # one frame per workgroup in the generic Stockham kernel
+    (882, 441, 800, False, True, 'replicate', True),      # radix 7, two-sided, normalized
 ])
 def test_general_gradient_routes_under_strict(tac, n_fft, hop, win_length, onesided, center, pad_mode, normalized):
     """The reference differentiates through every argument with stock torch (functional.py:99-107, 183-184).  Under

@@ -1043,7 +1043,7 @@ def _frame_gradients(gs, window, g):
     """one-sided gradient spectrum (rows, T, F, 2) -> frame gradients (rows, T, n_fft), window and scale applied."""
     frames = torch.empty((g.rows, g.n_frames, g.n_fft), dtype=torch.float32, device=gs.device)
     with _native.on_device(gs.device):
-        if fft_kernel_size(g.n_fft) or g.mixed_radix:
+        if fft_kernel_size(g.n_fft) or g.mixed_radix or smooth_fft_size(g.n_fft):
             rc = _native.lib().tac_stft_backward_f32(_native.ptr(gs), _native.ptr(window), _desc(g, onesided=1),
                                                      _native.ptr(frames), _native.stream_ptr(gs.device))
             _native.check(rc, 'tac_stft_backward_f32')

@@ -899,6 +899,9 @@ static int launch_stft_backward(const FrameGeom& g, const Tables& tb, const floa
     return TAC_OK;
 }
 
+bool stft_smooth_covers(int n_fft);                                                                           // stft_smooth.hip
+int launch_stft_smooth_backward(int n_fft, const FrameGeom& g, const float* grad_spec, float* grad_frames, hipStream_t stream);
+
 static int stft_backward_entry(const float* spec, const float* gnorm, float power, const float* window, const tac_stft_desc* d,
                                float* grad_frames, void* stream, bool from_wave = false, const AdjEntry* adj = nullptr,
                                int n_mels = 0) {
@@ -908,9 +911,12 @@ static int stft_backward_entry(const float* spec, const float* gnorm, float powe
     int64_t T = 0;
     // from_wave: `spec` IS the waveform.  Otherwise the geometry helper wants a waveform pointer for its alignment flags
     // only and the spectrum stands in.
-    int rc = make_geometry(spec, window, d, &g, &T);
+    // even lengths with a 7-smooth half (stft_smooth.hip): the plain form only — frame gradients from a gradient spectrum
+    const bool smooth = !gnorm && !from_wave && !adj && stft_smooth_covers(d->n_fft);
+    int rc = make_geometry(spec, window, d, &g, &T, smooth);
     if (rc != TAC_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
+    if (smooth) return launch_stft_smooth_backward(d->n_fft, g, spec, grad_frames, s);
     if (d->n_fft == 400)                                   // the mixed-radix form (stft_n400.hip)
         return launch_n400_backward(g, spec, gnorm, power, grad_frames, s, from_wave, adj, n_mels);
     if (adj) return TAC_E_UNSUPPORTED;                     // (the filterbank adjoint inside the frame-gradient kernel: fft_length 400 only)

@@ -108,6 +108,63 @@ __device__ __forceinline__ void smooth_pass_odd(const cf* __restrict__ src, cf* 
     }
 }
 
+// the M-point forward transform of one frame: Stockham passes from `bufa`, ping-ponging with `bufb`; returns the buffer that holds
+// the spectrum in natural order.  `sync` separates the passes (a wave-level fence at one frame per wave, else a barrier).
+template <int TPF, class Twiddle, class Sync>
+__device__ __forceinline__ cf* smooth_transform(cf* bufa, cf* bufb, const SmoothPlan& plan, int M, int N, int lt, Twiddle wn,
+                                                Sync sync) {
+    cf* src = bufa;
+    cf* dst = bufb;
+    int ns = 1;
+    for (int p = 0; p < plan.n; ++p) {                                    // Stockham passes, ns = product of the radices so far
+        const int r = plan.r[p], cnt = M / r, step = cnt / ns;            // pass twiddle W_M^(t k step) = W_N^(2 t k step)
+        if (r == 4 && ns == 1) {                                          // first pass: every twiddle is 1
+#pragma unroll 2
+            for (int j = lt; j < cnt; j += TPF) {
+                const cf v0 = src[j], v1 = src[j + cnt], v2 = src[j + 2 * cnt], v3 = src[j + 3 * cnt];
+                const cf s0c = cadd(v0, v2), s1c = csub(v0, v2), s2c = cadd(v1, v3), s3c = csub(v1, v3);
+                cf* const d = dst + 4 * j;
+                d[0] = cadd(s0c, s2c);
+                d[1] = mkc(s1c.x + s3c.y, s1c.y - s3c.x);
+                d[2] = csub(s0c, s2c);
+                d[3] = mkc(s1c.x - s3c.y, s1c.y + s3c.x);
+            }
+        } else if (r == 4) {
+#pragma unroll 2
+            for (int j = lt; j < cnt; j += TPF) {
+                const int k = j & (ns - 1), q = k * step;
+                const cf v0 = src[j], v1 = cmul(src[j + cnt], wn(2 * q)), v2 = cmul(src[j + 2 * cnt], wn(4 * q)),
+                         v3 = cmul(src[j + 3 * cnt], wn(6 * q));
+                const cf s0c = cadd(v0, v2), s1c = csub(v0, v2), s2c = cadd(v1, v3), s3c = csub(v1, v3);
+                const int j0 = ((j - k) << 2) + k;
+                dst[j0] = cadd(s0c, s2c);
+                dst[j0 + ns] = mkc(s1c.x + s3c.y, s1c.y - s3c.x);         // s1 - i s3
+                dst[j0 + 2 * ns] = csub(s0c, s2c);
+                dst[j0 + 3 * ns] = mkc(s1c.x - s3c.y, s1c.y + s3c.x);
+            }
+        } else if (r == 2) {
+#pragma unroll 2
+            for (int j = lt; j < cnt; j += TPF) {
+                const int k = j & (ns - 1);
+                const cf v0 = src[j], v1 = cmul(src[j + cnt], wn(2 * k * step));
+                const int j0 = ((j - k) << 1) + k;
+                dst[j0] = cadd(v0, v1);
+                dst[j0 + ns] = csub(v0, v1);
+            }
+        } else if (r == 3) {
+            smooth_pass_odd<3, TPF>(src, dst, M, N, ns, lt, wn);
+        } else if (r == 5) {
+            smooth_pass_odd<5, TPF>(src, dst, M, N, ns, lt, wn);
+        } else {
+            smooth_pass_odd<7, TPF>(src, dst, M, N, ns, lt, wn);
+        }
+        sync();
+        cf* t = src; src = dst; dst = t;
+        ns *= r;
+    }
+    return src;
+}
+
 // MODE 0: complex rows [F][2]; 1: |X|^power rows [F] (+ dB).  TPF: threads per frame — 64 (M <= 1024: one frame per wave, the four
 // waves of a workgroup walk their own frames and only wave-level fences separate the passes) or 256 (one frame per workgroup,
 // barriers).  LDS: [N twiddles][256 / TPF frames][2][M].
@@ -162,55 +219,7 @@ stft_smooth_kernel(FrameGeom g, const cf* __restrict__ tw, StftEpilogue ep, Smoo
             }
         }
         sync();
-        cf* src = bufa;
-        cf* dst = bufb;
-        int ns = 1;
-        for (int p = 0; p < plan.n; ++p) {                                    // Stockham passes, ns = product of the radices so far
-            const int r = plan.r[p], cnt = M / r, step = cnt / ns;            // pass twiddle W_M^(t k step) = W_N^(2 t k step)
-            if (r == 4 && ns == 1) {                                          // first pass: every twiddle is 1
-#pragma unroll 2
-                for (int j = lt; j < cnt; j += TPF) {
-                    const cf v0 = src[j], v1 = src[j + cnt], v2 = src[j + 2 * cnt], v3 = src[j + 3 * cnt];
-                    const cf s0c = cadd(v0, v2), s1c = csub(v0, v2), s2c = cadd(v1, v3), s3c = csub(v1, v3);
-                    cf* const d = dst + 4 * j;
-                    d[0] = cadd(s0c, s2c);
-                    d[1] = mkc(s1c.x + s3c.y, s1c.y - s3c.x);
-                    d[2] = csub(s0c, s2c);
-                    d[3] = mkc(s1c.x - s3c.y, s1c.y + s3c.x);
-                }
-            } else if (r == 4) {
-#pragma unroll 2
-                for (int j = lt; j < cnt; j += TPF) {
-                    const int k = j & (ns - 1), q = k * step;
-                    const cf v0 = src[j], v1 = cmul(src[j + cnt], wn(2 * q)), v2 = cmul(src[j + 2 * cnt], wn(4 * q)),
-                             v3 = cmul(src[j + 3 * cnt], wn(6 * q));
-                    const cf s0c = cadd(v0, v2), s1c = csub(v0, v2), s2c = cadd(v1, v3), s3c = csub(v1, v3);
-                    const int j0 = ((j - k) << 2) + k;
-                    dst[j0] = cadd(s0c, s2c);
-                    dst[j0 + ns] = mkc(s1c.x + s3c.y, s1c.y - s3c.x);         // s1 - i s3
-                    dst[j0 + 2 * ns] = csub(s0c, s2c);
-                    dst[j0 + 3 * ns] = mkc(s1c.x - s3c.y, s1c.y + s3c.x);
-                }
-            } else if (r == 2) {
-#pragma unroll 2
-                for (int j = lt; j < cnt; j += TPF) {
-                    const int k = j & (ns - 1);
-                    const cf v0 = src[j], v1 = cmul(src[j + cnt], wn(2 * k * step));
-                    const int j0 = ((j - k) << 1) + k;
-                    dst[j0] = cadd(v0, v1);
-                    dst[j0 + ns] = csub(v0, v1);
-                }
-            } else if (r == 3) {
-                smooth_pass_odd<3, TPF>(src, dst, M, N, ns, lt, wn);
-            } else if (r == 5) {
-                smooth_pass_odd<5, TPF>(src, dst, M, N, ns, lt, wn);
-            } else {
-                smooth_pass_odd<7, TPF>(src, dst, M, N, ns, lt, wn);
-            }
-            sync();
-            cf* t = src; src = dst; dst = t;
-            ns *= r;
-        }
+        cf* const src = smooth_transform<TPF>(bufa, bufb, plan, M, N, lt, wn, sync);
         // real-input split: X[k] = (Z[k] + conj Z[M-k]) / 2 - i W_N^k (Z[k] - conj Z[M-k]) / 2, k = 0..M
 #pragma unroll 2
         for (int k = lt; k <= M; k += TPF) {
@@ -231,6 +240,65 @@ stft_smooth_kernel(FrameGeom g, const cf* __restrict__ tw, StftEpilogue ep, Smoo
                 o1[k] = val;
                 if (!ep.onesided && k > 0 && k < M) o1[N - k] = val;
             }
+        }
+        sync();                                                               // the next frame's deposit follows these reads
+    }
+}
+
+// Adjoint of the forward kernel up to the overlap-add (tac_stft_backward_f32): grad_frames[unit][n] = window[n] * scale *
+// Re sum_{k <= M} G[k] e^{+2 pi i k n / N}.  With n = 2 m + b the two real M-point inverse transforms pack into one complex one,
+//     Z[k] = (G[k] + conj G[M-k]) / 2 + (i / 2) conj(W_N^k) (G[k] - conj G[M-k])   (0 < k < M),   Z[0] = Re(G[0] + G[M]) + i Re(G[0] - G[M]),
+//     z = IDFT_M(Z) = conj(DFT_M(conj Z)),  y[2m] = Re z[m],  y[2m+1] = Im z[m]
+// — the forward passes run on conj Z and the result is conjugated on the way out.
+template <int TPF, bool FULL = true>
+__global__ void __launch_bounds__(SM_THREADS)
+stft_smooth_backward_kernel(FrameGeom g, const cf* __restrict__ tw, const cf* __restrict__ grad_spec, float* __restrict__ grad_frames,
+                            SmoothPlan plan, int N) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int SLOTS = SM_THREADS / TPF;
+    cf* const wl = reinterpret_cast<cf*>(smem_raw);
+    const int M = N >> 1, tid = threadIdx.x, lt = tid % TPF;
+    const int slot = __builtin_amdgcn_readfirstlane(tid / TPF);
+    cf* const bufa = wl + (FULL ? N : M + 1) + slot * 2 * M;
+    cf* const bufb = bufa + M;
+    for (int i = tid; i < (FULL ? N : M + 1); i += SM_THREADS) wl[i] = tw[i];
+    __syncthreads();
+    auto wn = [&](int j) -> cf {
+        if constexpr (FULL) return wl[j];
+        const int r = j >= M ? j - M : j;
+        const cf v = wl[r];
+        return j >= M ? mkc(-v.x, -v.y) : v;
+    };
+    auto sync = [&]() {
+        if constexpr (TPF == 64) wave_lds_fence();
+        else __syncthreads();
+    };
+    const long long units = g.rows * g.n_frames;
+    for (long long unit = (long long)blockIdx.x * SLOTS + slot; unit < units; unit += (long long)gridDim.x * SLOTS) {
+        const cf* __restrict__ G = grad_spec + unit * (M + 1);
+#pragma unroll 2
+        for (int k = lt; k < M; k += TPF) {
+            cf zc;                                                            // conj Z[k]
+            if (k == 0) {
+                const cf g0 = G[0], gm = G[M];
+                zc = mkc(g0.x + gm.x, -(g0.x - gm.x));
+            } else {
+                const cf a = G[k], braw = G[M - k];
+                const cf b = mkc(braw.x, -braw.y);
+                const cf e = cscale(cadd(a, b), 0.5f), o = cscale(csub(a, b), 0.5f);
+                const cf w = wn(k);
+                const cf wo = cmul(mkc(w.x, -w.y), o);                        // conj(W_N^k) o
+                zc = mkc(e.x - wo.y, -(e.y + wo.x));                          // conj(e + i wo)
+            }
+            bufa[k] = zc;
+        }
+        sync();
+        const cf* const res = smooth_transform<TPF>(bufa, bufb, plan, M, N, lt, wn, sync);
+        float* const out = grad_frames + unit * N;
+#pragma unroll 2
+        for (int m = lt; m < M; m += TPF) {
+            const cf v = res[m], w = window_pair(g, m);
+            *reinterpret_cast<cf*>(out + 2 * m) = mkc(v.x * w.x * g.scale, -v.y * w.y * g.scale);
         }
         sync();                                                               // the next frame's deposit follows these reads
     }
@@ -272,6 +340,38 @@ int launch_stft_smooth(int n_fft, const FrameGeom& g, const StftEpilogue& ep, in
     if (rl != TAC_OK) return rl;
     TAC_HIP(hipGetLastError());
     set_last_route("stft_smooth_kernel<%d, %d>", mode == 0 ? 0 : 1, tpf);
+    return TAC_OK;
+}
+
+// Frame gradients from a one-sided gradient spectrum (stft_backward_entry of backward.hip): grad_spec[rows][T][M + 1][2] ->
+// grad_frames[rows][T][N].
+int launch_stft_smooth_backward(int n_fft, const FrameGeom& g, const float* grad_spec, float* grad_frames, hipStream_t stream) {
+    SmoothPlan plan;
+    if (!smooth_plan(n_fft, &plan)) return TAC_E_UNSUPPORTED;
+    const cf* tw = nullptr;
+    const int rc = smooth_twiddles(n_fft, &tw);
+    if (rc != TAC_OK) return rc;
+    const int M = n_fft / 2;
+    const long long units = g.rows * g.n_frames;
+    const int tpf = M <= 1024 ? 64 : 256, slots = SM_THREADS / tpf;
+    const size_t lds_full = ((size_t)n_fft + 2 * (size_t)M * slots) * sizeof(cf), lds_half = lds_full - (size_t)(M - 1) * sizeof(cf);
+    const bool full = !((160 * 1024) / lds_full < 2 && (160 * 1024) / lds_half >= 2);
+    const size_t lds = full ? lds_full : lds_half;
+    int per_cu = (int)((160 * 1024) / lds);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+    long long blocks = (units + slots - 1) / slots;
+    const long long cap = (long long)device_cu_count() * per_cu;
+    if (blocks > cap) blocks = cap;
+    auto go = [&](auto kern) -> int {
+        TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SM_THREADS), lds, stream, g, tw, reinterpret_cast<const cf*>(grad_spec),
+                           grad_frames, plan, n_fft);
+        return TAC_OK;
+    };
+    const int rl = tpf == 64 ? go(stft_smooth_backward_kernel<64>)
+                             : (full ? go(stft_smooth_backward_kernel<256>) : go(stft_smooth_backward_kernel<256, false>));
+    if (rl != TAC_OK) return rl;
+    TAC_HIP(hipGetLastError());
     return TAC_OK;
 }
 
