@@ -252,7 +252,7 @@ int tac_mulaw_decode_f64(const void* codes, int32_t codes_are_i64, int64_t n, in
  *     tac_stft_backward_f32: adjoint of (1) up to the overlap-add: grad_spec[rows][T][F][2] (one-sided) ->
  *       grad_frames[rows][T][n_fft] = window[n] * scale * Re sum_k grad_spec[k] e^{+2 pi i k n / n_fft}  (one inverse
  *       real FFT per frame on the same wave-level FFT as the forward pass; the even lengths with a 7-smooth half of (1): the
- *       generic Stockham passes of stft_smooth.hip; not 8192 and above).
+ *       generic Stockham passes of stft_smooth.hip, which also serve fft_length 8192; not 16384 / 32768).
  *     tac_stft_norm_backward_f32: the same with the gradient spectrum formed on load from the spectrum itself,
  *       spec[rows][T][F][2], and the gradient of |spec|^power, grad_norm[rows][T][F] (the adjoint of
  *       functional.py:116-128 folded in: Spectrogram's backward in one pass, no gradient spectrum in memory).

@@ -315,8 +315,16 @@ def test_fft_length_8192_to_32768_four_step_kernel(tac):
         mel = tac.Melspectrogram(num_mels=64, sample_rate=44100, fft_length=n, hop_length=hop).cuda()
         want_mel = torch_ref.melspectrogram(torch.from_numpy(x), num_mels=64, sample_rate=44100, n_fft=n, hop=hop).numpy()
         assert rel_err(host(mel(dev(x))), want_mel) < 2e-5, n
-    # gradients: 8192 keeps the DFT-matrix adjoint; above that the op is differentiated through torch's operators (announced)
+    # gradients: 8192 through the generic Stockham adjoint (csrc/stft_smooth.hip: radix-4 / 2 passes, one frame per workgroup);
+    # above that the op is differentiated through torch's operators (announced)
     xg = dev(x[:, :, :40000]).requires_grad_(True)
+    before = launches(tac)
+    (g1,) = torch.autograd.grad(tac.Spectrogram(8192, 2048, power=2.).cuda()(xg).sum(), xg)
+    ran = launched_since(tac, before)
+    assert ran.get('tac_stft_backward_f32') == 1 and 'tac_apply_filterbank_f32' not in ran, ran
+    xr = torch.from_numpy(x[:, :, :40000]).double().requires_grad_(True)
+    (g0,) = torch.autograd.grad(torch_ref.spectrogram(xr, 8192, 2048, window=torch.hann_window(8192, dtype=torch.float64), power=2.0).sum(), xr)
+    assert rel_err(host(g1), g0.numpy()) < 1e-4
     with pytest.raises(RuntimeError, match='strict mode'):
         tac.stft(xg, 16384, hop_length=4096).square().sum().backward()
 

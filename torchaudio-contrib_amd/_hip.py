@@ -154,8 +154,8 @@ def mixed_radix_size(n_fft):
 
 def big_fft_size(n_fft):
     """fft_length 8192 / 16384 / 32768: one frame per workgroup as a four-step transform over the wave-level 1024-point FFT
-    (csrc/stft_big.hip, round 5) — forward stft / spectrogram rows of every form; gradients at 8192 keep the DFT-matrix
-    adjoint, above that they are a composite route."""
+    (csrc/stft_big.hip, round 5) — forward stft / spectrogram rows of every form; gradients at 8192 take the generic
+    Stockham adjoint of csrc/stft_smooth.hip, above that they are a composite route."""
     return n_fft in (8192, 16384, 32768)
 
 
@@ -1043,7 +1043,7 @@ def _frame_gradients(gs, window, g):
     """one-sided gradient spectrum (rows, T, F, 2) -> frame gradients (rows, T, n_fft), window and scale applied."""
     frames = torch.empty((g.rows, g.n_frames, g.n_fft), dtype=torch.float32, device=gs.device)
     with _native.on_device(gs.device):
-        if fft_kernel_size(g.n_fft) or g.mixed_radix or smooth_fft_size(g.n_fft):
+        if fft_kernel_size(g.n_fft) or g.mixed_radix or smooth_fft_size(g.n_fft) or g.n_fft == 8192:
             rc = _native.lib().tac_stft_backward_f32(_native.ptr(gs), _native.ptr(window), _desc(g, onesided=1),
                                                      _native.ptr(frames), _native.stream_ptr(gs.device))
             _native.check(rc, 'tac_stft_backward_f32')

@@ -912,7 +912,8 @@ static int stft_backward_entry(const float* spec, const float* gnorm, float powe
     // from_wave: `spec` IS the waveform.  Otherwise the geometry helper wants a waveform pointer for its alignment flags
     // only and the spectrum stands in.
     // even lengths with a 7-smooth half (stft_smooth.hip): the plain form only — frame gradients from a gradient spectrum
-    const bool smooth = !gnorm && !from_wave && !adj && stft_smooth_covers(d->n_fft);
+    // (and fft_length 8192, whose forward kernel is stft_big.hip: radix-4 / 2 passes, one frame per workgroup)
+    const bool smooth = !gnorm && !from_wave && !adj && (stft_smooth_covers(d->n_fft) || d->n_fft == 8192);
     int rc = make_geometry(spec, window, d, &g, &T, smooth);
     if (rc != TAC_OK) return rc;
     hipStream_t s = (hipStream_t)stream;

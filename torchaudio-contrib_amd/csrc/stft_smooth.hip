@@ -28,9 +28,10 @@ struct SmoothPlan {
     int r[16];
 };
 
-bool smooth_plan(int n_fft, SmoothPlan* plan) {
+// (powers of two have their own forward kernels; the adjoint of fft_length 8192 is the one place they pass through here)
+bool smooth_plan(int n_fft, SmoothPlan* plan, bool allow_pow2 = false) {
     plan->n = 0;
-    if (n_fft < 8 || (n_fft & 1) || n_fft > 8192 || is_pow2(n_fft)) return false;
+    if (n_fft < 8 || (n_fft & 1) || n_fft > 8192 || (is_pow2(n_fft) && !allow_pow2)) return false;
     int m = n_fft / 2;
     const int radices[5] = {4, 2, 3, 5, 7};
     for (int r : radices)
@@ -347,7 +348,7 @@ int launch_stft_smooth(int n_fft, const FrameGeom& g, const StftEpilogue& ep, in
 // grad_frames[rows][T][N].
 int launch_stft_smooth_backward(int n_fft, const FrameGeom& g, const float* grad_spec, float* grad_frames, hipStream_t stream) {
     SmoothPlan plan;
-    if (!smooth_plan(n_fft, &plan)) return TAC_E_UNSUPPORTED;
+    if (!smooth_plan(n_fft, &plan, n_fft == 8192)) return TAC_E_UNSUPPORTED;
     const cf* tw = nullptr;
     const int rc = smooth_twiddles(n_fft, &tw);
     if (rc != TAC_OK) return rc;
