@@ -12,7 +12,10 @@
 typedef float v4 __attribute__((ext_vector_type(4)));
 typedef float v2 __attribute__((ext_vector_type(2)));
 
-template <int WAVES, bool NT, bool NEW_ONLY>
+// ORDER 0: every workgroup walks its own contiguous chunk of frames (what the STFT kernels do: 256 far-apart write streams);
+// ORDER 1 (round 5): frames dealt round-robin over ALL waves of the grid — turn i, workgroup c, wave w writes row
+// i * (grid * WAVES) + c * WAVES + w: one tight window of grid * WAVES rows moving through the output.
+template <int WAVES, bool NT, bool NEW_ONLY, int ORDER = 0>
 __global__ void __launch_bounds__(WAVES * 64) rows_k(const float* __restrict__ in, char* __restrict__ out, int frames_per_row, int rows,
                                                      int row_bytes, long long in_row_stride) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -24,10 +27,14 @@ __global__ void __launch_bounds__(WAVES * 64) rows_k(const float* __restrict__ i
     const long long begin = (long long)blockIdx.x * chunk;
     const int nloc = (int)((begin + chunk < total ? begin + chunk : total) - begin);
     int i = w;
-    while (i < nloc) {
+    while (ORDER == 0 ? i < nloc : true) {
         unsigned ask = 0;
         if (lane == 0) ask = atomicAdd(&counter, 1u);
-        const long long gf = begin + i;
+        // ORDER 2: the same with the workgroups of one XCD (blockIdx % 8) side by side: every XCD's L2 sees one contiguous window
+        const long long slot = ORDER == 2 ? (long long)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (long long)blockIdx.x;
+        const long long gf = ORDER == 0 ? begin + i
+                                        : (long long)(i / WAVES) * ((long long)gridDim.x * WAVES) + slot * WAVES + (i % WAVES);
+        if (ORDER != 0 && gf >= total) break;
         const int r = (int)(gf / frames_per_row), f = (int)(gf - (long long)r * frames_per_row);
         const v2* src = reinterpret_cast<const v2*>(in + (long long)r * in_row_stride + (long long)f * 512);
         v2 v[16];
@@ -97,6 +104,16 @@ int main() {
         run(rows_k<16, true, false>, 16, "16 waves, nt stores, frame reads");
         run(rows_k<16, true, true>, 16, "16 waves, nt stores, new-hop reads");
         run(rows_k<12, true, true>, 12, "12 waves, nt stores, new-hop reads");
+        run(rows_k<12, true, true, 1>, 12, "12 waves, nt, new-hop, global order");
+        run(rows_k<8, true, true, 1>, 8, " 8 waves, nt, new-hop, global order");
+        run(rows_k<4, true, true, 1>, 4, " 4 waves, nt, new-hop, global order");
+        run(rows_k<16, true, true, 1>, 16, "16 waves, nt, new-hop, global order");
+        run(rows_k<12, true, true, 2>, 12, "12 waves, nt, new-hop, global order by XCD");
+        run(rows_k<8, true, true, 2>, 8, " 8 waves, nt, new-hop, global order by XCD");
+        run(rows_k<16, true, true, 2>, 16, "16 waves, nt, new-hop, global order by XCD");
+        run(rows_k<12, false, true, 1>, 12, "12 waves, plain, new-hop, global order");
+        run(rows_k<8, true, true, 0>, 8, " 8 waves, nt, new-hop reads");
+        run(rows_k<4, true, true, 0>, 4, " 4 waves, nt, new-hop reads");
     }
     return 0;
 }
