@@ -9,7 +9,8 @@
 // stft_stream3_kernel (a CU's waves work on ADJACENT frames, so the CU writes one contiguous region) and shares the samples
 // through the LDS instead:
 //
-//   * a workgroup is TW transform waves + ONE loader wave.  The loader walks the workgroup's chunk of frames and brings every hop
+//   * a workgroup is TW transform waves + ONE loader wave.  The loader walks the workgroup's frames (its contiguous chunk — real
+//     rows — or its blocks of the global order — complex rows, see KB in the kernel) and brings every hop
 //     (512 samples = 2 KB) an interior frame needs into a ring of R slots, once, with gfx950's LDS-DMA loads
 //     (global_load_lds_dwordx4: global -> LDS without registers, lane l's 16 bytes land at M0 + 16 l; tools/ubench/lds_dma.hip) —
 //     PF hops in flight, published in order (in-order vmcnt) through one LDS word `loaded`;
@@ -95,22 +96,46 @@ stft_ring3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
     S3Setup<F, WAVES * 64> setup;
     setup.issue(g, tb, tid);
 
+    // KB > 0: GLOBAL BLOCK ORDER (round 5, late) — an audio row is cut into blocks of KB consecutive frames, the blocks of all rows
+    // are numbered in output order and block q goes to workgroup slot q mod G at turn q / G, so that at any time the whole grid
+    // writes ONE tight window of G * KB adjacent rows of the output (0: every workgroup walks its own contiguous chunk — 256
+    // far-apart streams).  The store pattern alone gains 3 - 7 % (8 200-byte rows) from it (tools/ubench/row_store_rate.hip);
+    // the complex-row kernel, bit-identical, -2.4 ... -3.9 % on the boxes where it runs slowest (0.171 - 0.175 ms) and
+    // +0.3 ... +1.5 % on the fastest (0.157 - 0.164): shipped for the complex rows.  The real rows stay in chunk order: a block
+    // reads 15 hops for 12 frames and their loader, whose one LDS round trip per hop is just under the frame interval there, cannot
+    // take 25 % more (+13.5 %; profiles/r05/ab/batch50 ... 54).
+    // (hop = fft_length / 8 would read 19 hops per 12 frames: chunk order too)
+    constexpr int KB = MODE == 0 && HPF == 4 ? 12 : 0, PB = KB + HPF - 1;     // frames per block, hop ids per block (dense: KB + HPF - 1 hops are read)
     const long long total = g.rows * g.n_frames;
     const long long chunk = lp.chunk;
     const long long begin = (long long)blockIdx.x * chunk;
     const long long endl = begin + chunk < total ? begin + chunk : total;
-    const int nloc = endl > begin ? (int)(endl - begin) : 0;
     const unsigned T = (unsigned)g.n_frames;
-    const unsigned HR = T + (unsigned)HPF;                // ids per audio row
+    const unsigned G = gridDim.x;
+    // workgroups of one XCD (blockIdx % 8) side by side: every XCD's L2 sees one contiguous part of the window
+    const unsigned slot = (G & 7u) == 0 ? (blockIdx.x & 7u) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const unsigned nb = KB ? (T + (unsigned)(KB ? KB : 1) - 1) / (unsigned)(KB ? KB : 1) : 0;      // blocks per audio row
+    const unsigned nblocks = (unsigned)g.rows * nb;
+    const int nloc = KB ? (slot < nblocks ? (int)((nblocks - slot + G - 1) / G) * KB : 0) : (endl > begin ? (int)(endl - begin) : 0);
+    const unsigned HR = T + (unsigned)HPF;                // ids per audio row (chunk order)
     const int padh = g.center_pad / D::HOP;               // hops of padding in front of frame 0
-    // frame i of the chunk: (row, frame in the row, interior?, id of its first hop — also a lower bound for edge frames)
+    // frame i of the workgroup: (row, frame in the row — >= T: a hole behind a row's last block —, interior?, id of its first hop
+    // — also a lower bound for edge frames)
     auto locate = [&](int i, unsigned& r, unsigned& f, bool& ok, int& b) {
-        const unsigned gf = (unsigned)(begin + i);
-        r = gf / T;
-        f = gf - r * T;
+        if constexpr (KB > 0) {
+            const unsigned j = (unsigned)i / (unsigned)KB, k = (unsigned)i - j * (unsigned)KB;
+            const unsigned q = j * G + slot;
+            r = q / nb;
+            f = (q - r * nb) * (unsigned)KB + k;
+            b = (int)(j * (unsigned)PB + k);
+        } else {
+            const unsigned gf = (unsigned)(begin + i);
+            r = gf / T;
+            f = gf - r * T;
+            b = (int)(r * HR) + (int)f - padh;
+        }
         const long long start = (long long)f * D::HOP - g.center_pad;
-        ok = start >= 0 && start + F::N <= g.length;
-        b = (int)(r * HR) + (int)f - padh;
+        ok = f < T && start >= 0 && start + F::N <= g.length;
     };
     typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -191,7 +216,7 @@ stft_ring3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
                     }
                 }
                 const unsigned slot = (unsigned)id % (unsigned)R;
-                const int h = id - (int)(r * HR);                                      // hop of the row
+                const int h = KB > 0 ? (int)f - padh + (id - b) : id - (int)(r * HR);  // hop of the row
                 const float* src = g.wave + (long long)r * g.row_stride + (long long)h * D::HOP + 4 * t;
                 unsigned char* dst = ring + (size_t)slot * D::HOPB;
 #ifndef TAC_R3_AUX
@@ -248,7 +273,14 @@ stft_ring3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
         int b;
         locate(i, row, fru, ok, b);
         const long long fr = (long long)fru;
-        const long long g0 = (begin + i) * (long long)LENF;         // this frame's row in the frame-major output
+        if (KB > 0 && fru >= T) {                           // a hole behind the last block of an audio row: nothing to do
+            if (i >= D::MARKS) ring3_wait(front_addr, (unsigned)(i - D::MARKS) + 1u);
+            const unsigned hm_addr = marks_addr + 4u * (unsigned)(i & (D::MARKS - 1)), hm = (unsigned)i + 1u;
+            asm volatile("ds_write_b32 %0, %1" :: "v"(hm_addr), "v"(hm) : "memory");
+            i = (int)__builtin_amdgcn_readfirstlane(ask);
+            continue;
+        }
+        const long long g0 = (KB > 0 ? (long long)row * T + fr : begin + i) * (long long)LENF;     // this frame's row in the frame-major output
         const unsigned mark_addr = marks_addr + 4u * (unsigned)(i & (D::MARKS - 1)), mark = (unsigned)i + 1u;
         // ---- s0: the samples (ring, or gathered from memory for frames touching the padding), window, pass 0, exchange
         if (ok) {
