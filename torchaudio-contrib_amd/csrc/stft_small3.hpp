@@ -79,9 +79,18 @@ stft_small3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, LaneMel mel, const v
     const int T = (int)g.n_frames;
     const int upr = (T + G - 1) / G;                       // units per row
     const int total = (int)g.rows * upr;
-    const int chunk = (total + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int begin = (int)blockIdx.x * chunk;
-    const int end = begin + chunk < total ? begin + chunk : total;
+    // GORDER (round 5, complex rows): units dealt round-robin over all waves of the grid — local index u is unit (u / WAVES) G_W +
+    // slot WAVES + u % WAVES (the slots of one XCD side by side) — so that the grid writes one tight window of adjacent rows instead
+    // of one stream per workgroup: fft_length 512 / 1024 / 256 complex rows -8 / -6 / -6 % (process-level, alternating,
+    // profiles/r05/ab/batch57); the real rows (half the bytes per unit) measure +-0 ... +2 % and keep their chunks.
+    constexpr bool TAC_SM3_GORDER = MODE == 0 && !MEL;
+    const int GW = (int)gridDim.x * WAVES;
+    const int gslot = (gridDim.x & 7u) == 0 ? (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+    const int nfull = total / GW, grem = total - nfull * GW - gslot * WAVES;
+    const int chunk = TAC_SM3_GORDER ? nfull * WAVES + (grem < 0 ? 0 : (grem > WAVES ? WAVES : grem)) : (total + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int begin = TAC_SM3_GORDER ? 0 : (int)blockIdx.x * chunk;
+    const int end = TAC_SM3_GORDER ? chunk : (begin + chunk < total ? begin + chunk : total);
+    auto unit_of = [&](int u) { return TAC_SM3_GORDER ? (u / WAVES) * GW + gslot * WAVES + u % WAVES : u; };
     constexpr int LENF = (MODE == 0 ? 2 : 1) * (NC + 1);
     constexpr int NST = (((G * LENF) >> 2) + 63) / 64;    // 16-byte wave-stores per unit
 
@@ -105,7 +114,7 @@ stft_small3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, LaneMel mel, const v
     cf v[1][E];
     bool fast = false;
     auto request = [&](int unit) {
-        unit = unit < end ? unit : end - 1;
+        unit = unit_of(unit < end ? unit : end - 1);
         const int urow = unit / upr;
         const int frame = (unit - urow * upr) * G + sub;
         const long long start = (long long)frame * g.hop - g.center_pad;
@@ -173,8 +182,8 @@ stft_small3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, LaneMel mel, const v
 
     while (unit < end) {
         const int nxt = grab();
-        const int urow = unit / upr;
-        const int uframe0 = (unit - urow * upr) * G;
+        const int urow = unit_of(unit) / upr;
+        const int uframe0 = (unit_of(unit) - urow * upr) * G;
         // ---- window, pass 0 (units with frames in the padding or past the end of the row gather their samples first)
         if (!fast) {
             int tz;

@@ -48,11 +48,15 @@ stft_stream3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
     S3Setup<F, WAVES * 64> setup;                         // tables: every load in flight, then the LDS stores (melspec_stream3.hpp)
     setup.issue(g, tb, tid);
 
+    // Frames are dealt round-robin over all waves of the grid (round 5) — local index i is frame (i / WAVES) G_W + slot WAVES + i %
+    // WAVES, the slots of one XCD (blockIdx % 8) side by side — so that the grid writes ONE tight window of adjacent rows instead of
+    // one stream per workgroup: complex rows -4.1 %, real rows -2.6 % same process (profiles/r05/ab/batch54; the store pattern alone:
+    // tools/ubench/row_store_rate.hip).  lp.chunk is not used.
     const long long total = g.rows * g.n_frames;
-    const long long chunk = lp.chunk;
-    const long long begin = (long long)blockIdx.x * chunk;
-    const long long endl = begin + chunk < total ? begin + chunk : total;
-    const int nloc = endl > begin ? (int)(endl - begin) : 0;
+    const unsigned GW = gridDim.x * WAVES;
+    const unsigned gslot = (gridDim.x & 7u) == 0 ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const long long nfull = total / GW, rem = total - nfull * GW - (long long)gslot * WAVES;
+    const int nloc = (int)(nfull * WAVES + (rem < 0 ? 0 : (rem > WAVES ? WAVES : rem)));
     const unsigned T = (unsigned)g.n_frames;
 
     cf tw2[3];
@@ -75,7 +79,7 @@ stft_stream3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
     long long nfr = 0;
     auto request_into = [&](int i, cf* dst, int& mode_o, int& row_o, long long& fr_o) {
         i = i < nloc ? i : nloc - 1;
-        const unsigned gf = (unsigned)(begin + i);
+        const unsigned gf = ((unsigned)i / WAVES) * GW + gslot * WAVES + (unsigned)i % WAVES;
         const unsigned r = gf / T;
         row_o = (int)r;
         fr_o = (long long)(gf - r * T);
