@@ -728,3 +728,34 @@ def test_fold_kernel_visits_exactly_what_the_backward_kernels_left(tmp_path):
                    check=True)
     out = subprocess.run([exe], stdout=subprocess.PIPE, text=True)
     assert out.returncode == 0 and out.stdout.strip().endswith('bad=0'), out.stdout
+
+
+def test_ring_loader_assembly_has_no_compiler_inserted_memory_waits(tmp_path):
+    """The hop-ring kernel's loader wave (csrc/stft_ring3.hpp) counts its LDS-DMA loads itself: one s_waitcnt vmcnt(2 (PF - 1)) per
+    hop, vmcnt(0) at the flush and at the end.  The compiler's wait-count pass tracks the address registers of
+    __builtin_amdgcn_global_load_lds and inserts vmcnt(0) wherever the register allocator reuses one of them — in front of the marks
+    poll or of the next load, which serialises the loader on the memory latency (+106 % on the whole kernel, measured in round 5 on a
+    source change that only touched the loader's bookkeeping: tools/ablation/README.md).  Whether that happens depends on register
+    allocation, so the build is checked: inside the loader's loops of every instantiation exactly the three expected waits."""
+    hipcc = '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc')
+    out = tmp_path / 'stft_kernels.s'
+    csrc = os.path.join(ROOT, 'torchaudio-contrib_amd', 'csrc')
+    subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-slp-vectorize', '--cuda-device-only', '-S',
+                    '-w', os.path.join(csrc, 'stft_kernels.hip'), '-o', str(out)], check=True, cwd=csrc)
+    text = out.read_text()
+    import re
+    seen = 0
+    for m in re.finditer(r'\n(_ZN3tac17stft_ring3_kernelILi1024ELi16ELi(\d)ELi12ELi(\d)E\w*):', text):
+        hpf = int(m.group(3))
+        body = text[m.end():text.index('.Lfunc_end', m.end())]
+        loader = body[body.index('s_setprio 3'):]
+        loops = loader[loader.index('\n.LBB'):]                     # (the straight-line prologue may wait for the set-up loads)
+        waits = re.findall(r's_waitcnt vmcnt\((\d+)\)', loops)
+        lph, ring = (2, 21) if hpf == 4 else (1, 43)
+        pf = min(24, ring - 12 - (hpf - 1))
+        assert waits == ['0', str(lph * (pf - 1)), '0'], (m.group(1), waits)
+        assert loops.count('global_load_lds_dwordx4') == lph
+        seen += 1
+    assert seen == 10                                               # five row modes x two hops per frame

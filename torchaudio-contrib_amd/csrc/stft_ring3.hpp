@@ -13,7 +13,9 @@
 //     rows — or its blocks of the global order — complex rows, see KB in the kernel) and brings every hop
 //     (512 samples = 2 KB) an interior frame needs into a ring of R slots, once, with gfx950's LDS-DMA loads
 //     (global_load_lds_dwordx4: global -> LDS without registers, lane l's 16 bytes land at M0 + 16 l; tools/ubench/lds_dma.hip) —
-//     PF hops in flight, published in order (in-order vmcnt) through one LDS word `loaded`;
+//     PF hops in flight, published in order (in-order vmcnt) through one LDS word `loaded`.  The loader counts its loads itself; the
+//     compiler must not add memory waits of its own in its loops (it does when the register allocator reuses a pending load's
+//     address register: +106 % on the kernel) — tests/test_host_api.py checks the built assembly for exactly the expected waits;
 //   * hop h of audio row r has the id r * (T + 4) + h and lives in slot id mod R; the frame starting at hop h0 takes ids
 //     B .. B + 3 (B = r * (T + 4) + h0), waits for loaded > B + 3, reads its sixteen complex pairs per lane with ds_read_b64
 //     (conflict-free: consecutive lanes, consecutive 8 bytes) and marks itself consumed; the transform waves issue no global load
