@@ -45,7 +45,8 @@ struct Ring3Cfg {
     static constexpr int MARKS = 64;                                         // ring of per-frame "consumed" marks
     static constexpr int CTRL = MARKS * 4 + 64;                              // + loaded, front, frame counter
     static constexpr int LDS_MAX = 160 * 1024;
-    static constexpr int R = (LDS_MAX - TW * XA - TABLES - CTRL) / HOPB;     // hops in the ring
+    static constexpr int R_LDS = (LDS_MAX - TW * XA - TABLES - CTRL) / HOPB;     // hops the LDS has room for
+    static constexpr int R = R_LDS < MARKS - TW - 4 ? R_LDS : MARKS - TW - 5;    // hops in the ring (bounded by the marks' ring)
     static constexpr int BYTES = R * HOPB + TW * XA + TABLES + CTRL;
 #ifndef TAC_S3_RING_PF
 #define TAC_S3_RING_PF 0
