@@ -207,5 +207,13 @@ out.append('Micro-benchmarks behind the design decisions (sources in `tools/uben
            'arithmetic: 8200-byte rows 4.3 TB/s, 128-byte aligned 8192-byte rows 4.8-5.0 TB/s).')
 out.append('')
 out.append('`../r02/`, `../r01/` hold the same measurements for rounds 2 and 1 (two-waves-per-SIMD streaming kernel 0.127 ms on one re-read batch; three-phase fused kernel, 0.174 ms) and `../r01_baseline_v0/` for the first correct version (0.61 ms).')
+if os.path.exists(os.path.join(d, 'kernel_stats_big_fft.csv')):
+    out.append('')
+    out.append('`kernel_stats_big_fft.csv`, `kernel_stats_nonpow2.csv` — `rocprofv3 --kernel-trace --stats` of `tools/r05/time_big_fft.py` / '
+               '`tools/r05/time_nonpow2.py`: the kernel families added in round 5 beside torch.stft\'s rocFFT kernels in the same process — '
+               '`stft_big_kernel<S, mode, waves>` (fft_length 8192 / 16384 / 32768 = S 4 / 8 / 16: 0.317 / 0.349 / 0.562 ms complex rows, '
+               '0.286 / 0.322 / 0.547 ms |X|^2 rows for 16 x 2.88 M samples), `stft_smooth_kernel<mode, threads per frame, full table>` '
+               '(480 ... 2048: 0.542 ms mean over the sizes timed; above: 0.670 ms; 6000: 0.844 ms), the float64 kernels and the HPSS widths '
+               '33 ... 63.  `ab/batch48 ... 66`: the store-pattern micro-benchmark in global order and the kernel A/Bs that followed.')
 open(os.path.join(d, 'README.md'), 'w').write('\n'.join(out) + '\n')
 print('\n'.join(out))
