@@ -5,9 +5,9 @@
 // instructions and of its L2 -> CU bytes (as many bytes as the complex rows store) are re-reads, on a kernel that runs at the
 // board's power limit and whose loads queue behind its own row stores.  Loading only a frame's NEW hop measures -6 ... -12 %
 // (timing-only ablation, profiles/r05/ab/batch9_ab_newhop.txt); keeping the shared hops in a wave's registers (consecutive frames
-// per wave) gives that back through its output pattern (batch10 / 11).  This form keeps the frame -> wave dealing of
-// stft_stream3_kernel (a CU's waves work on ADJACENT frames, so the CU writes one contiguous region) and shares the samples
-// through the LDS instead:
+// per wave) gives that back through its output pattern (batch10 / 11).  This form keeps one frame per wave with a CU's waves on
+// ADJACENT frames (so that a CU — and, in the complex rows' global block order, the whole grid — writes one contiguous region)
+// and shares the samples through the LDS instead:
 //
 //   * a workgroup is TW transform waves + ONE loader wave.  The loader walks the workgroup's frames (its contiguous chunk — real
 //     rows — or its blocks of the global order — complex rows, see KB in the kernel) and brings every hop
@@ -16,8 +16,8 @@
 //     PF hops in flight, published in order (in-order vmcnt) through one LDS word `loaded`.  The loader counts its loads itself; the
 //     compiler must not add memory waits of its own in its loops (it does when the register allocator reuses a pending load's
 //     address register: +106 % on the kernel) — tests/test_host_api.py checks the built assembly for exactly the expected waits;
-//   * hop h of audio row r has the id r * (T + 4) + h and lives in slot id mod R; the frame starting at hop h0 takes ids
-//     B .. B + 3 (B = r * (T + 4) + h0), waits for loaded > B + 3, reads its sixteen complex pairs per lane with ds_read_b64
+//   * hop h of audio row r has the id r * (T + 4) + h (block order: 15 dense ids per block of twelve frames) and lives in slot
+//     id mod R; the frame starting at hop h0 takes ids B .. B + 3 (B = r * (T + 4) + h0), waits for loaded > B + 3, reads its sixteen complex pairs per lane with ds_read_b64
 //     (conflict-free: consecutive lanes, consecutive 8 bytes) and marks itself consumed; the transform waves issue no global load
 //     at all (frames touching the padding still gather theirs from memory, as before);
 //   * the loader overwrites a slot only when every frame that can need its old content has consumed: ids below B(c), c = the first
