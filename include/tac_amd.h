@@ -350,6 +350,13 @@ int tac_hpss_f32(const float* mag, int64_t rows, int32_t n_freqs, int32_t n_fram
 const char* tac_last_route(void);
 int tac_debug_clock_probe(uint64_t* buf, int32_t capacity_pairs);
 
+/* (12) Route selection of the fft_length-2048 kernels (process-wide; results agree to float32 rounding, ~2e-7 of a frame's
+ *      largest bin): where the 1024-point transform of a frame runs.  mode 0 = VALU (radix 16 . 16 . 4 through the LDS,
+ *      melspec_stream3_kernel / stft_ring3_kernel: rounds 3 - 5), 1 = matrix pipe (two chained 32 x 32 complex DFT products on
+ *      v_mfma_f32_32x32x16_f16 with fp16 hi / lo operand pairs, melspec_mfma_kernel: round 6), -1 = the default (environment
+ *      TAC_FFT_PIPE=valu|mfma, else the build's default).  Returns the previous mode. */
+int tac_set_fft_pipe(int mode);
+
 #ifdef __cplusplus
 }
 #endif

@@ -113,6 +113,41 @@ def test_g2_melspectrogram_db(tac, golden):
         tac.set_lazy_fusion(True)
 
 
+def test_g2_melspectrogram_on_the_matrix_pipe(tac, golden):
+    """Round 6: the fused fft_length-2048 chain with the 1024-point transform as two chained 32 x 32 complex DFT products on
+    v_mfma_f32_32x32x16_f16 (fp16 hi / lo operand pairs, csrc/melspec_mfma.hpp; tools/emulate_mfma_fft.py is its CPU emulation) —
+    an opt-in route (slower on MI355X: tools/ablation/README.md, round 6), held to the same golden vectors as the default one:
+    reference layers.py:307-381 through the unmodified reference, tests/golden/make_golden.py."""
+    g = golden('g2_cfg2_slice')
+    x = dev(signals.audio_like((2, 1, 160000), seed=2))
+    mel = tac.Melspectrogram(num_mels=128, sample_rate=16000, fft_length=2048, hop_length=512).cuda()
+    full = torch.nn.Sequential(*mel, tac.AmplitudeToDb()).cuda()
+    valu = full(x)
+    assert tac._native.lib().tac_last_route().decode().startswith('melspec_stream3_kernel')
+    prev = tac.set_fft_pipe('mfma')
+    try:
+        out = tac.realize(mel(x))
+        assert tac._native.lib().tac_last_route().decode().startswith('melspec_mfma_kernel')
+        assert rel_err(host(out), g['mel']) < 1e-5
+        y = full(x)
+        assert np.abs(host(y) - g['mel_db']).max() < DB_ABS
+        assert (y - valu).abs().max().item() < 1e-3
+        # power 1 (the magnitude chain), another bank (40 bands: the general contraction loop), frames that touch the padding
+        # on short rows, samples at PCM scale and tiny ones (the per-frame power-of-two scaling of the fp16 operands)
+        for scale in (1.0, 32768.0, 1e-12):
+            xs = dev(signals.audio_like((3, 2, 9000), seed=5)) * scale
+            for kw in (dict(num_mels=40, power=1.), dict(num_mels=128, power=2.), dict(num_mels=80, power=2., htk=True)):
+                m2 = tac.Melspectrogram(sample_rate=16000, fft_length=2048, hop_length=512, **kw).cuda()
+                got = tac.realize(m2(xs))
+                assert tac._native.lib().tac_last_route().decode().startswith('melspec_mfma_kernel')
+                tac.set_fft_pipe('valu')
+                want = tac.realize(m2(xs))
+                tac.set_fft_pipe('mfma')
+                assert rel_err(host(got), host(want)) < 2e-6, (scale, kw)
+    finally:
+        tac.set_fft_pipe(prev)
+
+
 STFT_CASES = {
     'n4096_h1024': dict(n=4096, kw=dict(hop_length=1024), full=True),
     'n512_h128_win400': dict(n=512, kw=dict(hop_length=128, win_length=400)),

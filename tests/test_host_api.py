@@ -28,19 +28,25 @@ def test_library_exports_every_declared_symbol(tac):
     for name in declared:
         assert hasattr(h, name), name
     assert sorted(tac._native.EXPORTS) == declared
-    assert h.tac_abi_version() == tac._native.ABI_VERSION == 4
+    assert h.tac_abi_version() == tac._native.ABI_VERSION == 5
     assert h.tac_strerror(-3).decode().startswith('input too short')
     # diagnostics (11): no launch yet on this thread, an empty probe is refused, NULL clears
     assert isinstance(h.tac_last_route(), bytes)
     assert h.tac_debug_clock_probe(ctypes.c_void_p(8), 0) == tac._native.TAC_E_INVALID
     assert h.tac_debug_clock_probe(None, 0) == tac._native.TAC_OK
+    # route selection (12): the previous mode comes back, anything else than -1 / 0 / 1 is refused and changes nothing
+    assert tac.set_fft_pipe('mfma') in (None, 'valu', 'mfma')
+    assert h.tac_set_fft_pipe(7) == tac._native.TAC_E_INVALID
+    assert tac.set_fft_pipe('valu') == 'mfma' and tac.set_fft_pipe(None) == 'valu' and tac.set_fft_pipe(None) is None
+    with pytest.raises(ValueError):
+        tac.set_fft_pipe('tensor')
 
 
 def test_stale_library_is_refused(tac, monkeypatch):
     """A libtac_amd.so built from older sources fails the ABI check when it is loaded, not at the first missing symbol."""
     monkeypatch.setattr(tac._native, '_lib', None)
     monkeypatch.setattr(tac._native, 'ABI_VERSION', 99)
-    with pytest.raises(tac._native.NativeLibraryError, match='ABI version 4'):
+    with pytest.raises(tac._native.NativeLibraryError, match='ABI version 5'):
         tac._native.lib()
 
 

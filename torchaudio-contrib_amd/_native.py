@@ -35,9 +35,9 @@ EXPORTS = (
     'tac_fold_twosided_f32', 'tac_window_grad_partials', 'tac_window_grad_f32', 'tac_sum_slabs_f32',
     'tac_stft_f64', 'tac_spectrogram_f64', 'tac_apply_filterbank_f64', 'tac_magphase_f64', 'tac_amplitude_to_db_f64',
     'tac_db_to_amplitude_f64',
-    'tac_last_route', 'tac_debug_clock_probe', 'tac_melbank_plan_pieces_host',
+    'tac_last_route', 'tac_debug_clock_probe', 'tac_melbank_plan_pieces_host', 'tac_set_fft_pipe',
 )
-ABI_VERSION = 4          # tac_abi_version() of the library this binding was written against (csrc/host_common.hip)
+ABI_VERSION = 5          # tac_abi_version() of the library this binding was written against (csrc/host_common.hip)
 
 
 class StftDesc(ctypes.Structure):
@@ -162,6 +162,8 @@ def lib():
         h.tac_last_route.argtypes = []
         h.tac_debug_clock_probe.restype = ctypes.c_int
         h.tac_debug_clock_probe.argtypes = [_P, _I32]
+        h.tac_set_fft_pipe.restype = ctypes.c_int
+        h.tac_set_fft_pipe.argtypes = [ctypes.c_int]
         h.tac_mulaw_encode_f64_i64.argtypes = [_P, _I64, _I32, _P, _P]
         h.tac_mulaw_decode_f64.argtypes = [_P, _I32, _I64, _I32, _P, _P]
         h.tac_mulaw_decode_f64.restype = ctypes.c_int

@@ -4,6 +4,8 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -20,6 +22,17 @@ void set_last_route(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_last_route, sizeof(g_last_route), fmt, ap);
     va_end(ap);
+}
+
+#ifndef TAC_FFT_PIPE_DEFAULT_MFMA
+#define TAC_FFT_PIPE_DEFAULT_MFMA 0   // 1: the fft_length-2048 kernels run their transform on the matrix pipe unless told otherwise
+#endif
+std::atomic<int> g_fft_pipe{-1};
+bool fft_pipe_mfma() {
+    const int m = g_fft_pipe.load(std::memory_order_relaxed);
+    if (m >= 0) return m == 1;
+    static const int env = [] { const char* e = getenv("TAC_FFT_PIPE"); return !e ? -1 : (e[0] == 'm' ? 1 : 0); }();
+    return env >= 0 ? env == 1 : TAC_FFT_PIPE_DEFAULT_MFMA != 0;
 }
 
 int device_cu_count() {
@@ -160,7 +173,13 @@ int tac_last_hip_error(void) { return tac::g_last_hip_error; }
 // 3: round 4 — tac_last_route / tac_debug_clock_probe; the float64 entry points and the coded-input / fused-backward
 //    launchers added during round 3 are counted from here as well (a library older than the binding fails its version check
 //    in _native.lib() instead of at the first missing symbol)
-int tac_abi_version(void) { return 4; }
+// 5: round 6 — tac_set_fft_pipe
+int tac_abi_version(void) { return 5; }
+
+int tac_set_fft_pipe(int mode) {
+    if (mode < -1 || mode > 1) return TAC_E_INVALID;
+    return tac::g_fft_pipe.exchange(mode);
+}
 
 const char* tac_last_route(void) { return tac::g_last_route; }
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 #include "../../include/tac_amd.h"
 #include "fft_core.hpp"
@@ -73,6 +74,10 @@ constexpr int S3_IMG_PTW_F4 = 64 * 8 * 2 / 4;              // 256: 64 lanes x 8 
 int get_tables(int n_fft, Tables* out);
 
 int device_cu_count();
+
+// tac_set_fft_pipe / TAC_FFT_PIPE: true when the fft_length-2048 kernels are to run their transform on the matrix pipe
+extern std::atomic<int> g_fft_pipe;
+bool fft_pipe_mfma();
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) — a process that uses several GPUs sets it
 // on each of them; thread-safe.

@@ -29,6 +29,7 @@
 #include "sparse_phase.hpp"
 #include "melspec_stream.hpp"
 #include "melspec_stream3.hpp"
+#include "melspec_mfma.hpp"
 #include "mel_pieces.hpp"
 
 namespace tac {
@@ -397,6 +398,27 @@ static int launch_stream(FrameGeom g, const Tables& tb, const SparseArgs& sm, co
     // 12 waves per CU (a 15-wave / 128-register form measured 11 % slower: tools/ablation/README.md)
     constexpr bool coded = FMT != FMT_F32;
     constexpr int waves3 = S3_WAVES;
+    // Round 6: the transform on the matrix pipe (melspec_mfma.hpp; float32 samples).  tac_set_fft_pipe() / TAC_FFT_PIPE=valu|mfma select the form.
+    if constexpr (FMT == FMT_F32 && NC == 1024) {
+        const bool use_mfma = fft_pipe_mfma();
+        constexpr int WM = 12;
+        const size_t ldsm = mfma_lds_bytes<NC, E>(sm.wtot, WM);
+        if (use_mfma && !two_waves && ldsm <= 160 * 1024) {
+            void (*km)(FrameGeom, Tables, StreamArgs);
+            if (fast2 && fshort) km = pow2 ? melspec_mfma_kernel<true, ST_FAST_STEPS1_SHORT, WM> : melspec_mfma_kernel<false, ST_FAST_STEPS1_SHORT, WM>;
+            else if (fast2) km = pow2 ? melspec_mfma_kernel<true, ST_FAST_STEPS1, WM> : melspec_mfma_kernel<false, ST_FAST_STEPS1, WM>;
+            else km = pow2 ? melspec_mfma_kernel<true, 0, WM> : melspec_mfma_kernel<false, 0, WM>;
+            long long bm = (total + WM - 1) / WM;
+            if (bm > device_cu_count()) bm = device_cu_count();
+            m.chunk = (total + bm - 1) / bm;
+            m.probe = (g_clock_probe && g_clock_probe_pairs >= bm) ? g_clock_probe : nullptr;
+            set_last_route("melspec_mfma_kernel<%s, %d, %d>", pow2 ? "true" : "false", fast2 ? (fshort ? ST_FAST_STEPS1_SHORT : ST_FAST_STEPS1) : 0, WM);
+            TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(km), 160 * 1024));
+            hipLaunchKernelGGL(km, dim3((unsigned)bm), dim3(WM * 64), ldsm, stream, g, tb, m);
+            TAC_HIP(hipGetLastError());
+            return TAC_OK;
+        }
+    }
     const size_t lds3 = stream3_lds_bytes<NC, E>(sm.wtot, waves3, coded);
     if (!two_waves && lds3 <= 160 * 1024) {
         void (*k3)(FrameGeom, Tables, StreamArgs);
