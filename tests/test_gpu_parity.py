@@ -134,17 +134,26 @@ def test_g2_melspectrogram_on_the_matrix_pipe(tac, golden):
         assert (y - valu).abs().max().item() < 1e-3
         # power 1 (the magnitude chain), another bank (40 bands: the general contraction loop), frames that touch the padding
         # on short rows, samples at PCM scale and tiny ones (the per-frame power-of-two scaling of the fp16 operands)
+        fused = 0
         for scale in (1.0, 32768.0, 1e-12):
             xs = dev(signals.audio_like((3, 2, 9000), seed=5)) * scale
-            for num_mels, power, htk in ((40, 1., False), (128, 2., False), (80, 2., True)):
+            for num_mels, power, htk in ((128, 1., False), (128, 2., False), (96, 2., False), (80, 2., True)):
                 bank = tac.MelFilterbank(num_freqs=1025, num_mels=num_mels, sample_rate=16000, htk=htk).get_filterbank()
                 m2 = torch.nn.Sequential(tac.STFT(2048, hop_length=512), tac.ComplexNorm(power), tac.ApplyFilterbank(bank)).cuda()
+                before = launches(tac)
                 got = tac.realize(m2(xs))
-                assert tac._native.lib().tac_last_route().decode().startswith('melspec_mfma_kernel')
+                # (a bank the one-band-per-lane layout rejects takes the three-phase kernel under either setting)
+                streamed = launched_since(tac, before) == {'tac_melspec_sparse_f32': 1}
+                took = tac._native.lib().tac_last_route().decode()
                 tac.set_fft_pipe('valu')
                 want = tac.realize(m2(xs))
+                if streamed:
+                    assert took.startswith('melspec_mfma_kernel'), took
+                    assert tac._native.lib().tac_last_route().decode().startswith('melspec_stream3_kernel')
+                    fused += 1
                 tac.set_fft_pipe('mfma')
                 assert rel_err(host(got), host(want)) < 2e-6, (scale, num_mels, power, htk)
+        assert fused >= 6
     finally:
         tac.set_fft_pipe(prev)
 

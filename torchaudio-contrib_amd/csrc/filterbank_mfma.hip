@@ -7,12 +7,16 @@
 // and `fb` the windowed DFT matrix.  Exact f32 on v_mfma_f32_32x32x2_f32 — bf16 would break the 1e-4 parity budget
 // and gfx950 has no xf32.
 //
-// Workgroup = 4 waves = 128 frames x 128 columns, each wave a 64 x 64 quadrant (2 x 2 MFMA tiles of 32 x 32, 64
-// accumulator registers).  K is walked in 32-deep chunks through LDS: A^T as [32][132] (k-major, so a wave's operand
-// read is 32 consecutive frames — conflict-free — and the global->LDS writes are too), B as [32][132] rows written
-// 16 bytes at a time.  The next chunk's 8 x 16-byte global loads per thread are issued before the current chunk's
-// 64 MFMAs per wave.  With a plan (tac_filterbank_plan) the K range of a column tile shrinks to the union of its
-// 16-band tiles' supports (block-sparse banks); plan == NULL runs dense.
+// Workgroup = 8 waves = 64 frames x 128 columns, each wave ONE 32 x 32 MFMA tile (16 accumulator registers).  Round 6: until then
+// four waves held 2 x 2 tiles each on a 128 x 128 (or 64 x 128) workgroup tile, two workgroups per CU: cfg-2's 80 128 frames were
+// 626 (1 252) tiles for 512 slots — 1.22 (2.45) rounds paid as 2 (3) — and every chunk cost two barriers around a single LDS buffer:
+// matrix pipe 63 % busy, 57 % of the f32 MFMA peak (profiles/r05/pmc_fb.json).  Now the unit of work a SIMD sees is one 32 x 32 tile
+// over the whole K range (80 128 x 128 outputs = 10 016 tiles on 1 024 SIMDs: 9.78 rounds paid as 10), three workgroups = six waves
+// per SIMD keep the matrix pipe fed across each other's barriers, and K is walked in 32-deep chunks through TWO LDS buffers: the next
+// chunk's global loads are issued before the current chunk's 16 MFMAs per wave and deposited into the other buffer after them — one
+// barrier per chunk.  A^T as [32][68] (k-major: a wave's operand read is 32 consecutive frames, the global -> LDS writes 64), B as
+// [32][132] rows written 16 bytes at a time.  With a plan (tac_filterbank_plan) the K range of a column tile shrinks to the union
+// of its 16-band tiles' supports (block-sparse banks); plan == NULL runs dense.
 #include "host_common.hpp"
 
 namespace tac {
@@ -20,22 +24,30 @@ namespace tac {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float gm_f4 __attribute__((ext_vector_type(4)));
 
-constexpr int GM_TN = 128, GM_KC = 32, GM_LD = 132;
+constexpr int GM_TM = 64, GM_TN = 128, GM_KC = 32, GM_LDA = 66, GM_LDB = 132, GM_THREADS = 512;
 
-// TM = frames per workgroup: 128 (each wave a 64 x 64 quadrant) or 64 (each wave 32 x 64) — the smaller tile halves
-// the work quantum when a problem is only a few tiles per CU (cfg-2: 2.4 tiles of 128 per CU, i.e. 3 rounds for 2.4)
-template <int GM_TM>
-__global__ void __launch_bounds__(256, 2)
+// element i of (v.x, v.y, v.z, v.w, 0, 0, 0): the tail of a row read 16 bytes at a time from a clamped address
+__device__ __forceinline__ float gm_pick(gm_f4 v, int i) {
+    const float lo = (i & 1) ? v.y : v.x, hi = (i & 1) ? v.w : v.z;
+    return i < 4 ? ((i & 2) ? hi : lo) : 0.0f;
+}
+
+// VA: spec is read 16 bytes at a time along the frequency axis (stride_f == 1, n_freqs >= 4); VB: the bank's rows likewise
+// (n_mels a multiple of four).  The requests of a chunk are UNCONDITIONAL loads from clamped addresses — no branch, no select on a
+// loaded value before the deposit (round 5's per-element conditions made the compiler wait for every load right where it was
+// issued: the prefetch never ran ahead, and every chunk paid a memory round trip) — and what lies outside the matrices is zeroed
+// when the chunk is deposited.
+template <bool VA, bool VB>
+__global__ void __launch_bounds__(GM_THREADS, 6)
 gemm_fb_kernel(const float* __restrict__ spec, long long stride_r, long long stride_f, long long stride_t, int n_freqs,
                long long n_frames, long long frame_tiles, int col_tiles, const float* __restrict__ fb,
                const int* __restrict__ plan, int n_mels, float* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) float at_lds[GM_KC * GM_LD];       // A^T chunk: [k][frame]
-    __shared__ __attribute__((aligned(16))) float b_lds[GM_KC * GM_LD];        // B chunk:   [k][column]
+    __shared__ __attribute__((aligned(16))) float at_lds[2][GM_KC * GM_LDA];   // A^T chunks: [k][frame]
+    __shared__ __attribute__((aligned(16))) float b_lds[2][GM_KC * GM_LDB];    // B chunks:   [k][column]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int MI = GM_TM / 64;                                              // 32-row MFMA tiles per wave along M
-    const int wm = w >> 1, wn = w & 1;                                          // the wave's (32*MI) x 64 quadrant
+    const int wm = w >> 2, wn = w & 3;                                          // the wave's 32 x 32 tile of the 64 x 128
     long long bid = blockIdx.x;
     const int ct = (int)(bid % col_tiles);
     bid /= col_tiles;
@@ -60,103 +72,118 @@ gemm_fb_kernel(const float* __restrict__ spec, long long stride_r, long long str
         klo = (klo / GM_KC) * GM_KC;
     }
 
-    // global -> register staging of one chunk: A as 4 x (4 consecutive k of one frame), B as 4 x (4 consecutive columns)
-    constexpr int AJ = GM_TM / 32;                                              // 16-byte A loads per thread per chunk
-    const int a_i = tid & (GM_TM - 1), a_kq = tid / GM_TM;                      // frame within tile, k slice (4*AJ each)
-    const int b_j4 = tid & 31, b_k = tid >> 5;                                  // column group, k row (0..7, +8 per step)
+    // one chunk per thread: A = 4 consecutive k of one frame — eight consecutive lanes cover the 128 bytes of a frame's chunk
+    // (LDA = 66: the transposed LDS writes of a wave, 8 frames x 32 k, hit 64 different banks) —, B = 2 x (4 consecutive columns)
+    const int a_i = tid >> 3, a_kq = tid & 7;                                   // frame within tile, k slice (4 each)
+    const int b_j4 = tid & 31, b_k = tid >> 5;                                  // column group, k row (0..15, +16)
     const long long a_frame = f0 + a_i;
     const bool a_live = a_frame < n_frames;
     const float* a_src = srow + (a_live ? a_frame : n_frames - 1) * stride_t;
-    gm_f4 ra[AJ], rb[4];
+    const int col = c0 + 4 * b_j4;
+    const bool b_in = col < n_mels;
+    const float* b_src = fb + (b_in ? col : 0);
+    struct Stage { gm_f4 a, b0, b1; };
     auto fetch = [&](int kc) {
-#pragma unroll
-        for (int j = 0; j < AJ; ++j) {
-            const int k = kc + a_kq * (4 * AJ) + 4 * j;
-            gm_f4 v;
-            if (stride_f == 1 && k + 4 <= n_freqs) {
-                v = *reinterpret_cast<const gm_f4*>(a_src + k);                  // dword alignment is all a global load needs
-            } else {
-                v.x = k < n_freqs ? a_src[(long long)k * stride_f] : 0.0f;
-                v.y = k + 1 < n_freqs ? a_src[(long long)(k + 1) * stride_f] : 0.0f;
-                v.z = k + 2 < n_freqs ? a_src[(long long)(k + 2) * stride_f] : 0.0f;
-                v.w = k + 3 < n_freqs ? a_src[(long long)(k + 3) * stride_f] : 0.0f;
-            }
-            ra[j] = a_live ? v : gm_f4{0.0f, 0.0f, 0.0f, 0.0f};
+        Stage st;
+        const int k = kc + 4 * a_kq;
+        if constexpr (VA) {
+            const int kk = k < n_freqs - 4 ? k : n_freqs - 4;
+            st.a = *reinterpret_cast<const gm_f4*>(a_src + kk);                 // dword alignment is all a global load needs
+        } else {
+            const int last = n_freqs - 1;
+            st.a.x = a_src[(long long)(k < last ? k : last) * stride_f];
+            st.a.y = a_src[(long long)(k + 1 < last ? k + 1 : last) * stride_f];
+            st.a.z = a_src[(long long)(k + 2 < last ? k + 2 : last) * stride_f];
+            st.a.w = a_src[(long long)(k + 3 < last ? k + 3 : last) * stride_f];
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = kc + b_k + 8 * j;
-            const int col = c0 + 4 * b_j4;
-            gm_f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (k < n_freqs) {
-                const float* bp = fb + (long long)k * n_mels + col;
-                if (col + 4 <= n_mels) {
-                    v = *reinterpret_cast<const gm_f4*>(bp);
-                } else {
-                    v.x = col < n_mels ? bp[0] : 0.0f;
-                    v.y = col + 1 < n_mels ? bp[1] : 0.0f;
-                    v.z = col + 2 < n_mels ? bp[2] : 0.0f;
-                    v.w = col + 3 < n_mels ? bp[3] : 0.0f;
-                }
-            }
-            rb[j] = v;
+        const int r0 = kc + b_k, r1 = r0 + 16, lastr = n_freqs - 1;
+        const float* p0 = b_src + (long long)(r0 < lastr ? r0 : lastr) * n_mels;
+        const float* p1 = b_src + (long long)(r1 < lastr ? r1 : lastr) * n_mels;
+        if constexpr (VB) {
+            st.b0 = *reinterpret_cast<const gm_f4*>(p0);
+            st.b1 = *reinterpret_cast<const gm_f4*>(p1);
+        } else {
+            const int c1 = col + 1 < n_mels ? 1 : 0, c2 = col + 2 < n_mels ? 2 : 0, c3 = col + 3 < n_mels ? 3 : 0;   // (clamped: masked at the deposit)
+            st.b0.x = p0[0]; st.b0.y = p0[c1]; st.b0.z = p0[c2]; st.b0.w = p0[c3];
+            st.b1.x = p1[0]; st.b1.y = p1[c1]; st.b1.z = p1[c2]; st.b1.w = p1[c3];
         }
+        return st;
     };
-    auto deposit = [&]() {
-#pragma unroll
-        for (int j = 0; j < AJ; ++j) {
-            const int k = a_kq * (4 * AJ) + 4 * j;
-            at_lds[(k + 0) * GM_LD + a_i] = ra[j].x;
-            at_lds[(k + 1) * GM_LD + a_i] = ra[j].y;
-            at_lds[(k + 2) * GM_LD + a_i] = ra[j].z;
-            at_lds[(k + 3) * GM_LD + a_i] = ra[j].w;
+    auto deposit = [&](int buf, const Stage& st, int kc) {
+        float* at = at_lds[buf];
+        const int k = kc + 4 * a_kq, kl = 4 * a_kq;
+        gm_f4 va;
+        if constexpr (VA) {
+            const int sh = k < n_freqs - 4 ? 0 : k - (n_freqs - 4);             // (> 0 only in the row's last chunk)
+            va.x = gm_pick(st.a, sh); va.y = gm_pick(st.a, sh + 1); va.z = gm_pick(st.a, sh + 2); va.w = gm_pick(st.a, sh + 3);
+        } else {
+            va.x = k < n_freqs ? st.a.x : 0.0f; va.y = k + 1 < n_freqs ? st.a.y : 0.0f;
+            va.z = k + 2 < n_freqs ? st.a.z : 0.0f; va.w = k + 3 < n_freqs ? st.a.w : 0.0f;
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            *reinterpret_cast<gm_f4*>(b_lds + (b_k + 8 * j) * GM_LD + 4 * b_j4) = rb[j];
+        at[(kl + 0) * GM_LDA + a_i] = a_live ? va.x : 0.0f;
+        at[(kl + 1) * GM_LDA + a_i] = a_live ? va.y : 0.0f;
+        at[(kl + 2) * GM_LDA + a_i] = a_live ? va.z : 0.0f;
+        at[(kl + 3) * GM_LDA + a_i] = a_live ? va.w : 0.0f;
+        const bool in0 = b_in && kc + b_k < n_freqs, in1 = b_in && kc + b_k + 16 < n_freqs;
+        gm_f4 v0, v1;
+        v0.x = in0 ? st.b0.x : 0.0f; v0.y = in0 && col + 1 < n_mels ? st.b0.y : 0.0f;
+        v0.z = in0 && col + 2 < n_mels ? st.b0.z : 0.0f; v0.w = in0 && col + 3 < n_mels ? st.b0.w : 0.0f;
+        v1.x = in1 ? st.b1.x : 0.0f; v1.y = in1 && col + 1 < n_mels ? st.b1.y : 0.0f;
+        v1.z = in1 && col + 2 < n_mels ? st.b1.z : 0.0f; v1.w = in1 && col + 3 < n_mels ? st.b1.w : 0.0f;
+        *reinterpret_cast<gm_f4*>(b_lds[buf] + b_k * GM_LDB + 4 * b_j4) = v0;
+        *reinterpret_cast<gm_f4*>(b_lds[buf] + (b_k + 16) * GM_LDB + 4 * b_j4) = v1;
     };
 
-    f32x16 acc[MI][2];
+    f32x16 acc;
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int nj = 0; nj < 2; ++nj)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][nj][r] = 0.0f;
-
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     const int li = lane & 31, lk = lane >> 5;
-    if (klo < khi) fetch(klo);
-    for (int kc = klo; kc < khi; kc += GM_KC) {
-        __syncthreads();                                   // the previous chunk's operand reads are done
-        deposit();
-        __syncthreads();
-        if (kc + GM_KC < khi) fetch(kc + GM_KC);           // in flight during this chunk's MFMAs
+    auto compute = [&](int b) {
+        const float* at = at_lds[b] + wm * 32 + li;
+        const float* bt = b_lds[b] + wn * 32 + li;
 #pragma unroll
         for (int k2 = 0; k2 < GM_KC / 2; ++k2) {
             const int k = 2 * k2 + lk;
-            const float b0 = b_lds[k * GM_LD + wn * 64 + li], b1 = b_lds[k * GM_LD + wn * 64 + 32 + li];
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                const float a = at_lds[k * GM_LD + wm * (32 * MI) + 32 * mi + li];
-                acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[mi][0], 0, 0, 0);
-                acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[mi][1], 0, 0, 0);
-            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(at[k * GM_LDA], bt[k * GM_LDB], acc, 0, 0, 0);
         }
+    };
+    // two register stages, the loop unrolled by two: the loads of chunk c + 2 go out while chunk c is multiplied and chunk c + 1
+    // (requested a whole iteration earlier) is deposited — a global load has two chunks' time to land; one barrier per chunk.
+    // The requests are unconditional (past the end they repeat the last chunk): a request under a condition makes the compiler's
+    // wait-count bookkeeping assume the worst of both paths and wait for everything in flight.
+    const int nch = klo < khi ? (khi - klo + GM_KC - 1) / GM_KC : 0;
+    auto chunk_at = [&](int c) { return klo + (c < nch ? c : nch - 1) * GM_KC; };
+    if (nch > 0) {
+        Stage s0 = fetch(chunk_at(0));
+        Stage s1 = fetch(chunk_at(1));
+        __builtin_amdgcn_sched_barrier(0);
+        deposit(0, s0, chunk_at(0));
+        __syncthreads();
+        for (int c = 0; c + 2 <= nch; c += 2) {
+            s0 = fetch(chunk_at(c + 2));
+            __builtin_amdgcn_sched_barrier(0);             // (the scheduler would sink the requests to where their registers are used)
+            compute(0);
+            __builtin_amdgcn_sched_barrier(0);
+            deposit(1, s1, chunk_at(c + 1));
+            __syncthreads();
+            s1 = fetch(chunk_at(c + 3));
+            __builtin_amdgcn_sched_barrier(0);
+            compute(1);
+            __builtin_amdgcn_sched_barrier(0);
+            deposit(0, s0, chunk_at(c + 2));               // (unconditional as well — under a condition the compiler sinks the request
+            __syncthreads();                               //  itself into the branch; past the end the buffer is not read again)
+        }
+        if (nch & 1) compute(0);
     }
     // D[i][j] of a 32 x 32 tile: j = lane % 32, i = 8*(r / 4) + 4*(lane / 32) + r % 4
+    const int ocol = c0 + wn * 32 + li;
+    if (ocol < n_mels) {
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int nj = 0; nj < 2; ++nj) {
-            const int col = c0 + wn * 64 + nj * 32 + li;
-            if (col < n_mels) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long long frame = f0 + wm * (32 * MI) + mi * 32 + 8 * (r >> 2) + 4 * lk + (r & 3);
-                    if (frame < n_frames) out[(row * n_frames + frame) * n_mels + col] = acc[mi][nj][r];
-                }
-            }
+        for (int r = 0; r < 16; ++r) {
+            const long long frame = f0 + wm * 32 + 8 * (r >> 2) + 4 * lk + (r & 3);
+            if (frame < n_frames) out[(row * n_frames + frame) * n_mels + ocol] = acc[r];
         }
+    }
 }
 
 }  // namespace tac
@@ -176,19 +203,15 @@ int tac_apply_filterbank_f32(const float* spec, int64_t rows, int32_t n_freqs, i
         rows = 1;
     }
     const int col_tiles = (n_mels + GM_TN - 1) / GM_TN;
-    const long long tiles128 = rows * ((n_frames + 127) / 128) * col_tiles;
-    const int tm = tiles128 < 8LL * device_cu_count() ? 64 : 128;               // few tiles per CU: halve the quantum
-    const long long frame_tiles = (n_frames + tm - 1) / tm;
+    const long long frame_tiles = (n_frames + GM_TM - 1) / GM_TM;
     const long long blocks = rows * frame_tiles * col_tiles;
     if (blocks > 0x7fffffffLL) return TAC_E_UNSUPPORTED;
-    if (tm == 64)
-        hipLaunchKernelGGL(gemm_fb_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, spec,
-                           (long long)stride_r, (long long)stride_f, (long long)stride_t, n_freqs, (long long)n_frames,
-                           frame_tiles, col_tiles, fb, fb_plan, n_mels, out);
-    else
-        hipLaunchKernelGGL(gemm_fb_kernel<128>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, spec,
-                           (long long)stride_r, (long long)stride_f, (long long)stride_t, n_freqs, (long long)n_frames,
-                           frame_tiles, col_tiles, fb, fb_plan, n_mels, out);
+    const bool va = stride_f == 1 && n_freqs >= 4, vb = (n_mels & 3) == 0;
+    auto kern = va ? (vb ? gemm_fb_kernel<true, true> : gemm_fb_kernel<true, false>)
+                   : (vb ? gemm_fb_kernel<false, true> : gemm_fb_kernel<false, false>);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(GM_THREADS), 0, (hipStream_t)stream, spec,
+                       (long long)stride_r, (long long)stride_f, (long long)stride_t, n_freqs, (long long)n_frames,
+                       frame_tiles, col_tiles, fb, fb_plan, n_mels, out);
     TAC_HIP(hipGetLastError());
     return TAC_OK;
 }
