@@ -265,9 +265,21 @@ def extra_stages(stages, tac, dev, gen, model):
             t_all = time.perf_counter() - t0
             small['rows_%d' % rows] = {'us_per_call_host': t_host / n * 1e6, 'us_per_call': t_all / n * 1e6,
                                         'frames_per_s': rows * CHANNELS * FRAMES * n / t_all}
+            # the same chain bound to one call (tac.planned, round 6): what a caller of many small batches uses
+            fast = tac.planned(model, xr)
+            spin(lambda: fast(xr), 0.1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fast(xr)
+            t_host = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            t_all = time.perf_counter() - t0
+            small['rows_%d' % rows]['planned'] = {'fused': bool(fast.fused()), 'us_per_call_host': t_host / n * 1e6,
+                                                   'us_per_call': t_all / n * 1e6, 'frames_per_s': rows * CHANNELS * FRAMES * n / t_all}
         small['note'] = ('Sequential(*Melspectrogram, AmplitudeToDb) on rows x 1 x 160 000 samples, 2000 calls back to back: '
                          'us_per_call_host = Python + dispatch + launch per call (the floor for tiny batches), us_per_call = '
-                         'including the GPU draining the queue')
+                         'including the GPU draining the queue; planned = the same chain through tac.planned(model, x): one bound call')
         stages['small_batch'] = small
     except Exception as exc:            # noqa: BLE001
         stages['small_batch'] = {'error': '%s: %s' % (type(exc).__name__, exc)}

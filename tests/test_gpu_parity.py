@@ -1043,7 +1043,20 @@ def test_deferred_chain_is_safe(tac):
     y = full(buf)
     buf.copy_(b)                                   # next batch lands in the same buffer
     assert type(y) is torch.Tensor and np.array_equal(host(y), want_a)
-    plain = torch.nn.Sequential(*mel).cuda()       # user-owned container ending in ApplyFilterbank: stays pending
+    # round 6: a user-owned container that ENDS in ApplyFilterbank hands back an ordinary tensor, launched before forward
+    # returns (type(nn.Sequential(*Melspectrogram(...))(x)) is torch.Tensor, as with the reference's eager layers) ...
+    ended = torch.nn.Sequential(*mel).cuda()
+    buf = a.clone()
+    y = ended(buf)
+    buf.copy_(b)
+    assert type(y) is torch.Tensor and np.array_equal(host(y), host(mel(a)))
+    assert type(torch.nn.Sequential(torch.nn.Sequential(mel[0], mel[1]), mel[2]).cuda()(a)) is torch.Tensor    # ... through nesting,
+    assert type(torch.nn.Sequential(mel[0], mel[1]).cuda()(a)) is torch.Tensor and type(torch.nn.Sequential(mel[0]).cuda()(a)) is torch.Tensor
+    inner = torch.nn.Sequential(torch.nn.Sequential(*mel), tac.AmplitudeToDb()).cuda()      # ... while a container that goes on still fuses
+    before = launches(tac)
+    assert type(inner(a)) is torch.Tensor and sum(launched_since(tac, before).values()) == 1
+    # layers called one by one (the reference's tests/test_layers.py:98-101 style) keep deferring: the safety net below is theirs
+    plain = lambda t: mel[2](mel[1](mel[0](t)))
     buf = a.clone()
     pend = plain(buf)
     assert isinstance(pend, tac.DeferredSpectral) and pend.pending()
@@ -1067,6 +1080,38 @@ def test_deferred_chain_is_safe(tac):
         out = pend * 1.0
     side.synchronize()
     assert np.array_equal(host(out), host(mel(a)))
+
+
+def test_planned_chain_is_one_bound_launch(tac):
+    """tac.planned(model, example) (round 6): the reference idiom (layers.py:307-381) bound to ONE call — layout / stamp checks,
+    allocation, stream lookup, launch — for callers that run many small batches; same values as the module chain, an ordinary
+    tensor, and anything the binding does not cover goes through the chain itself."""
+    x = dev(signals.audio_like((4, 1, 20000), seed=61))
+    mel = tac.Melspectrogram(num_mels=128, sample_rate=16000, fft_length=2048, hop_length=512).cuda()
+    model = torch.nn.Sequential(*mel, tac.AmplitudeToDb()).cuda()
+    want = model(x)
+    fast = tac.planned(model, x)
+    assert fast.fused()
+    before = launches(tac)
+    y = fast(x)
+    assert type(y) is torch.Tensor and launched_since(tac, before) == {'tac_melspec_sparse_f32': 1}
+    assert y.shape == want.shape and y.stride() == want.stride() and torch.equal(y, want)
+    assert torch.equal(fast(x[:2]), model(x[:2]))                    # another layout: the chain itself
+    lin = tac.planned(torch.nn.Sequential(*mel), x)                  # no dB stage
+    assert lin.fused() and torch.equal(lin(x), mel(x))
+    nested = tac.planned(torch.nn.Sequential(torch.nn.Sequential(*mel), tac.AmplitudeToDb(ref=2.0, amin=1e-6)).cuda(), x)
+    assert nested.fused() and torch.equal(nested(x), torch.nn.Sequential(*mel, tac.AmplitudeToDb(ref=2.0, amin=1e-6)).cuda()(x))
+    mel[2].filterbank.mul_(0.5)                                      # new contents of a bound constant: seen, not stale
+    assert torch.equal(fast(x), model(x)) and not torch.equal(fast(x), want)
+    xg = x.clone().requires_grad_(True)                              # a gradient: the chain's autograd path
+    yg = fast(xg)
+    assert yg.requires_grad
+    (g1,) = torch.autograd.grad(yg.sum(), xg)
+    xg2 = x.clone().requires_grad_(True)
+    (g2,) = torch.autograd.grad(model(xg2).sum(), xg2)
+    assert torch.equal(g1, g2)
+    other = tac.planned(torch.nn.Sequential(tac.STFT(2048, hop_length=512), tac.ComplexNorm(2.)).cuda(), x)    # not a mel chain
+    assert not other.fused() and type(other(x)) is torch.Tensor and torch.equal(other(x), tac.Spectrogram(2048, hop_length=512, power=2.).cuda()(x))
 
 
 def test_dtype_and_device_routes(tac):

@@ -765,3 +765,79 @@ def test_ring_loader_assembly_has_no_compiler_inserted_memory_waits(tmp_path):
         assert loops.count('global_load_lds_dwordx4') == lph
         seen += 1
     assert seen == 10                                               # five row modes x two hops per frame
+
+
+def test_chain_end_detection(tac, monkeypatch):
+    """_lazy.ends_chain: a deferring layer is told that it is the LAST stage of the user's nn.Sequential (through nesting) — then it
+    hands back an ordinary tensor (reference layers are eager: layers.py:84-102) — and only then.  The compiled walk
+    (csrc/binding/tac_ext.cpp chain_end) and the Python walk must agree."""
+    import torch
+    from torchaudio_contrib_amd import _lazy
+    seen = []
+
+    class Probe(torch.nn.Module):
+        def forward(self, x):
+            seen.append(bool(_lazy.ends_chain(self)))
+            return x
+
+    class Factory(torch.nn.Sequential):
+        _tac_realizes = True
+
+    class Wrapper(torch.nn.Module):
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+
+        def forward(self, x):
+            return self.inner(x)
+
+    a, b, c = Probe(), Probe(), Probe()
+    x = torch.zeros(1)
+
+    def run(m):
+        del seen[:]
+        m(x)
+        return list(seen)
+
+    def check():
+        S = torch.nn.Sequential
+        assert run(S(a, b, c)) == [False, False, True]
+        assert run(S(S(a, b), c)) == [False, False, True]
+        assert run(S(c, S(a, b))) == [False, False, True]                 # call order c, a, b: b ends the chain through the nesting
+        assert run(S(S(S(a)))) == [True]
+        assert run(a) == [False]                                          # a direct call keeps deferring (tests/test_layers.py:98-101 style)
+        assert run(Wrapper(S(a, b))) == [False, True]                     # a user module around the container: its output is an end
+        assert run(Factory(a, b)) == [False, False] and run(S(Factory(a, b))) == [False, False]   # the factories' container realises by itself
+        hook = b.register_forward_hook(lambda m, i, o: None)              # (nn.Module._call_impl's slow path: more frames in between)
+        try:
+            assert run(S(a, b)) == [False, True]
+        finally:
+            hook.remove()
+
+    check()
+    compiled = tac._native.binding() == 'compiled' and getattr(tac._native.ext(), 'chain_end_supported', False)
+    if compiled:
+        assert _lazy.ends_chain is tac._native.ext().ends_chain          # the layers now call the compiled walk directly
+        import importlib, types
+        # ... and the Python walk gives the same answers: a fresh copy of the function, with the hand-over switched off
+        src = importlib.util.find_spec('torchaudio_contrib_amd._lazy').origin
+        text = open(src).read()
+        start = text.index('def ends_chain(module):')
+        end = text.index('class PlannedChain')
+        ns = {'sys': sys, '_SEQ_FORWARD_CODE': _lazy._SEQ_FORWARD_CODE, '_MODULE_PY': _lazy._MODULE_PY, '_ends_chain_resolved': True}
+        exec(compile(text[start:end], src, 'exec'), ns)
+        monkeypatch.setattr(_lazy, 'ends_chain', ns['ends_chain'])
+        check()
+
+
+def test_planned_chain_falls_back_on_cpu(tac):
+    """tac.planned(model, example): on a CPU example there is nothing to bind — the callable is the model (BASELINE configs[0] is a
+    CPU configuration), same values, an ordinary tensor."""
+    import torch
+    model = torch.nn.Sequential(*tac.Melspectrogram(num_mels=32, sample_rate=16000, fft_length=512, hop_length=256), tac.AmplitudeToDb())
+    x = torch.from_numpy(np.random.RandomState(0).randn(2, 1, 4000).astype(np.float32))
+    fast = tac.planned(model, x)
+    assert isinstance(fast, tac.PlannedChain) and not fast.fused()
+    y = fast(x)
+    assert type(y) is torch.Tensor and torch.equal(y, model(x))
+    assert type(torch.nn.Sequential(*tac.Melspectrogram(num_mels=32, sample_rate=16000, fft_length=512, hop_length=256))(x)) is torch.Tensor

@@ -8,7 +8,7 @@ from . import _native
 from . import _ops
 from ._ops import set_strict, CompositeRouteWarning
 from ._hip import invalidate
-from ._lazy import realize, set_lazy_fusion, lazy_fusion_enabled, DeferredSpectral, DeferredWave
+from ._lazy import realize, set_lazy_fusion, lazy_fusion_enabled, DeferredSpectral, DeferredWave, planned, PlannedChain
 from . import functional
 from . import layers
 from .functional import *      # noqa: F401,F403

@@ -23,6 +23,8 @@ Safety of the deferral (the reference is eager; these make the difference unobse
     graph is the one eager evaluation would have built.  (``__torch_dispatch__`` runs below autograd: a value
     materialised there would be cut off from the waveform, so reaching it with a gradient-carrying recipe raises.)
 """
+import sys
+
 import torch
 from torch.utils._pytree import tree_map
 
@@ -393,6 +395,103 @@ def _compute_transposed_strides(lead, tail, a, b):
     a, b = a % n, b % n
     strides[a], strides[b] = strides[b], strides[a]
     return tuple(strides)
+
+
+_SEQ_FORWARD_CODE = torch.nn.Sequential.forward.__code__
+_MODULE_PY = torch.nn.Module.__call__.__code__.co_filename           # torch/nn/modules/module.py: __call__ / _call_impl frames
+
+
+_ends_chain_resolved = False
+
+
+def ends_chain(module):
+    """True when ``module`` — a deferring layer, asked from inside its ``forward`` — produces the END of a layer chain: it was
+    called by an ``nn.Sequential`` as that container's LAST child, through any nesting of such containers, and the outermost of
+    them by something that is not a container.  Nothing can fuse behind such a result, so the layer launches the chain and hands
+    back an ordinary ``torch.Tensor`` — ``type(nn.Sequential(*Melspectrogram(...))(x)) is torch.Tensor``, as with the reference.
+    A direct call of the layer, a container that goes on after it (``..., AmplitudeToDb()``), or a factory container (which
+    realises by itself) keep the result deferred.  One walk over the caller frames: ~0.2 us per layer in the compiled binding
+    (``chain_end`` of csrc/binding/tac_ext.cpp), ~1.5 us here (``sys._getframe``, ``f_locals``) without it."""
+    global ends_chain, _ends_chain_resolved
+    if not _ends_chain_resolved:                # first call: hand over to the compiled walk when the binding offers it
+        _ends_chain_resolved = True
+        try:
+            from . import _native
+            ext = _native.ext()
+            if ext is not None and getattr(ext, 'chain_end_supported', False):
+                ext.chain_end_init(_SEQ_FORWARD_CODE, _MODULE_PY)
+                ends_chain = ext.ends_chain     # (callers read _lazy.ends_chain at call time)
+                return ext.chain_end(module, 1) == 1
+        except Exception:                       # noqa: BLE001 — the Python walk below answers
+            pass
+    f = sys._getframe(2)
+    child = module
+    while True:
+        while f is not None and f.f_code.co_filename == _MODULE_PY:
+            f = f.f_back
+        if f is None or f.f_code is not _SEQ_FORWARD_CODE:
+            return child is not module          # called by user code: the end of the chain iff we came out of a container
+        cont = f.f_locals.get('self')
+        mods = cont.__dict__.get('_modules') if cont is not None else None      # (plain dict reads: nn.Module.__getattr__ is slow)
+        if not mods or getattr(type(cont), '_tac_realizes', False) or next(reversed(mods.values())) is not child:
+            return False
+        child = cont
+        f = f.f_back
+
+
+class PlannedChain(object):
+    """``planned(model, example)``: the layer chain ``model`` bound to ONE launch for inputs laid out like ``example``.
+
+    The reference's idiom pays five ``nn.Module`` calls and three deferred intermediates per forward (~16 us of host time on
+    MI355X: ``bench.py`` ``stages.small_batch``); for callers who run many small batches this object makes the same call — layout
+    and content-stamp checks, output allocation, current-stream lookup, one launch of the fused kernel — in one step (~5 us).
+    Bound at construction: the STFT arguments, the window and filterbank TENSORS (their contents are re-checked on every call) and
+    the dB parameters; after changing a module attribute build a new one.  Anything the fused kernel does not cover (another
+    layout or device, a waveform that requires grad, a chain it does not recognise) goes through ``model`` itself."""
+
+    def __init__(self, model, example):
+        from . import layers as L, functional as F, _hip
+        self.model = model
+        self.plan = None
+        kids = []
+
+        def flat(m):
+            if isinstance(m, torch.nn.Sequential):
+                for c in m:
+                    flat(c)
+            else:
+                kids.append(m)
+        flat(model)
+        db = None
+        if kids and type(kids[-1]) is L.AmplitudeToDb:
+            db = (float(kids[-1].ref), float(kids[-1].amin))
+            kids = kids[:-1]
+        if len(kids) == 3 and type(kids[0]) is L.STFT and type(kids[1]) is L.ComplexNorm and type(kids[2]) is L.ApplyFilterbank \
+                and lazy_fusion_enabled() and type(example) is torch.Tensor and example.is_cuda:
+            st, fb = kids[0], kids[2].filterbank
+            n_fft, hop, win_length, window = F.resolve_stft_args(example, st.fft_length, st.hop_length, st.win_length, st.window)
+            _hip.check_stft_args(example.shape, n_fft, hop, win_length, st.center, st.pad_mode)
+            if window is st.window:
+                ref, amin = db if db is not None else (1.0, 1e-7)
+                self.plan = _hip.mel_plan(example, window, fb, n_fft, hop, win_length, bool(st.center), st.pad_mode,
+                                          bool(st.normalized), bool(st.onesided), float(kids[1].power), db is not None, ref, amin)
+
+    def fused(self):
+        """whether calls take the bound one-launch path (else they are ``model(x)``)"""
+        return self.plan is not None
+
+    def __call__(self, x):
+        p = self.plan
+        if p is not None and not (x.requires_grad and torch.is_grad_enabled()):
+            v = p.run(x)
+            if v is not None:
+                return v
+        return realize(self.model(x))
+
+
+def planned(model, example):
+    """A callable equivalent to ``model`` with the whole chain bound to one launch (``PlannedChain``)."""
+    return PlannedChain(model, example)
 
 
 def realize(x):

@@ -12,6 +12,7 @@
 //
 // Host code only (the kernels live in libtac_amd.so): built with g++ against the torch headers by csrc/Makefile.
 #include <torch/extension.h>
+#include <frameobject.h>
 #include <ATen/record_function.h>
 #include <c10/hip/HIPFunctions.h>
 #include <c10/hip/HIPStream.h>
@@ -105,7 +106,59 @@ TORCH_LIBRARY_IMPL(tac_amd, Meta, m) {
     m.impl("melspec_planned", &melspec_planned_meta);
 }
 
+// ---- _lazy.ends_chain in C (round 6): is `module`, asked from inside its forward(), the LAST child of the nn.Sequential that called
+// it — through any nesting of such containers — with the outermost of them called by something that is not a container?  The Python
+// form of the same walk (sys._getframe, f_locals) costs ~1.5 us per layer; this one reads the frames' code objects and first
+// local directly (CPython 3.8 - 3.10 frame layout; other interpreters report -1 and the Python walk answers).
+PyObject* g_seq_forward_code = nullptr;     // nn.Sequential.forward.__code__
+PyObject* g_module_py = nullptr;            // co_filename of nn.Module.__call__ (the _call_impl / _wrapped_call_impl frames)
+PyObject* g_str_modules = nullptr;          // interned "_modules", "_tac_realizes"
+PyObject* g_str_realizes = nullptr;
+
+int chain_end(PyObject* module, int skip) {
+#if PY_VERSION_HEX >= 0x030B0000 || PY_VERSION_HEX < 0x03080000
+    (void)module;
+    (void)skip;
+    return -1;
+#else
+    if (!g_seq_forward_code || !g_module_py) return -1;
+    PyFrameObject* f = PyEval_GetFrame();               // the Python frame this function was called from (borrowed): the layer's
+    for (int i = 0; f && i < skip; ++i) f = f->f_back;  // forward(), or `skip` wrappers below it
+    if (!f) return -1;
+    f = f->f_back;                                      // forward() was called by nn.Module._call_impl
+    PyObject* child = module;
+    for (;;) {
+        while (f && (f->f_code->co_filename == g_module_py || PyUnicode_Compare(f->f_code->co_filename, g_module_py) == 0)) f = f->f_back;
+        if (!f || (PyObject*)f->f_code != g_seq_forward_code) return child != module ? 1 : 0;
+        PyObject* cont = f->f_code->co_argcount > 0 ? f->f_localsplus[0] : nullptr;     // `self` of Sequential.forward
+        if (!cont) return 0;
+        PyObject** dp = _PyObject_GetDictPtr(cont);
+        PyObject* mods = (dp && *dp) ? PyDict_GetItem(*dp, g_str_modules) : nullptr;      // borrowed
+        if (!mods || !PyDict_Check(mods) || PyDict_Size(mods) == 0) return 0;
+        if (_PyType_Lookup(Py_TYPE(cont), g_str_realizes)) return 0;                      // a factory container realises by itself
+        PyObject *key, *value, *last = nullptr;
+        Py_ssize_t pos = 0;
+        while (PyDict_Next(mods, &pos, &key, &value)) last = value;                      // (insertion order; a handful of children)
+        if (last != child) return 0;
+        child = cont;
+        f = f->f_back;
+    }
+#endif
+}
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+    m.def("chain_end_init", [](py::object seq_forward_code, py::object module_py) {
+        Py_XDECREF(g_seq_forward_code);
+        Py_XDECREF(g_module_py);
+        g_seq_forward_code = seq_forward_code.inc_ref().ptr();
+        g_module_py = module_py.inc_ref().ptr();
+        if (!g_str_modules) g_str_modules = PyUnicode_InternFromString("_modules");
+        if (!g_str_realizes) g_str_realizes = PyUnicode_InternFromString("_tac_realizes");
+    });
+    m.def("chain_end", [](py::handle module, int skip) { return chain_end(module.ptr(), skip); });
+    // called straight from a layer's forward(): True / False (only offered where chain_end answers: chain_end_supported)
+    m.def("ends_chain", [](py::handle module) { return chain_end(module.ptr(), 0) == 1; });
+    m.attr("chain_end_supported") = (PY_VERSION_HEX < 0x030B0000 && PY_VERSION_HEX >= 0x03080000);
     m.doc() = "compiled binding of the fused Melspectrogram launch (C ABI of libtac_amd.so behind it)";
     m.attr("ABI") = 1;
     m.def("set_epoch", [](int64_t e) { g_epoch.store(e, std::memory_order_relaxed); });

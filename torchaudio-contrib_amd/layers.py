@@ -14,6 +14,7 @@ import torch.nn as nn
 
 from . import functional as F
 from . import _hip
+from . import _lazy
 from ._lazy import DeferredSpectral, DeferredWave, can_defer, can_defer_codes, lazy_fusion_enabled, realize
 
 
@@ -83,9 +84,11 @@ class STFT(_ModuleNoStateBuffers):
                         waveforms.shape, n_fft, hop, win_length, bool(self.center), self.pad_mode, bool(self.normalized),
                         bool(self.onesided)))
                 else:       # (a window resolve_stft_args had to build or move: not remembered)
-                    return DeferredSpectral.from_stft(waveforms, window, n_fft, hop, win_length, bool(self.center),
-                                                      self.pad_mode, bool(self.normalized), bool(self.onesided))
-            return DeferredSpectral.from_template(waveforms, tmpl[0], tmpl[1])
+                    d = DeferredSpectral.from_stft(waveforms, window, n_fft, hop, win_length, bool(self.center),
+                                                   self.pad_mode, bool(self.normalized), bool(self.onesided))
+                    return d.realize() if _lazy.ends_chain(self) else d
+            d = DeferredSpectral.from_template(waveforms, tmpl[0], tmpl[1])
+            return d.realize() if _lazy.ends_chain(self) else d        # (the last layer of a user's nn.Sequential: an ordinary tensor)
         return F.stft(waveforms, self.fft_length, self.hop_length, self.win_length, self.window, self.center,
                       self.pad_mode, self.normalized, self.onesided)
 
@@ -107,7 +110,8 @@ class ComplexNorm(nn.Module):
     def forward(self, complex_tensor):
         if isinstance(complex_tensor, DeferredSpectral) and complex_tensor.pending() \
                 and complex_tensor._stage == 'stft':
-            return complex_tensor.with_norm(self.power)
+            d = complex_tensor.with_norm(self.power)
+            return d.realize() if _lazy.ends_chain(self) else d
         return F.complex_norm(complex_tensor, self.power)
 
     def __repr__(self):
@@ -129,7 +133,8 @@ class ApplyFilterbank(_ModuleNoStateBuffers):
         if isinstance(x, DeferredSpectral) and x.pending() and x._stage == 'spec' \
                 and fb.dim() == 2 and fb.shape[0] == x._src.n_bins and fb.device == x._src.wave.device \
                 and fb.dtype == torch.float32 and not (fb.requires_grad and torch.is_grad_enabled()):
-            return x.with_filterbank(fb)
+            d = x.with_filterbank(fb)
+            return d.realize() if _lazy.ends_chain(self) else d
         return F.apply_filterbank(x, fb)
 
 
@@ -198,6 +203,7 @@ class _FusedSequential(nn.Sequential):
     """``nn.Sequential`` returned by the factories: children stay individually usable and ``*``-unpackable; a
     whole-chain call is ONE ``tac_amd::spectrogram`` / ``tac_amd::melspectrogram`` op (one kernel on a HIP device,
     differentiable, traceable by ``torch.compile``) and returns an ordinary tensor."""
+    _tac_realizes = True            # (_lazy.ends_chain: this container launches what its children deferred by itself)
 
     def forward(self, input):
         kids = list(self._modules.values())
