@@ -1,4 +1,6 @@
 #!/usr/bin/env python
+# NOTE (round 6): the timing / probe switches this tool builds with left the product sources; apply tools/ablation/lab_knobs_r06.patch
+# (patch -p1 at the repo root) to a scratch tree first.
 """Debug: with a -DTAC_SP_TIMING=1 build (TAC_AMD_LIB=...), print per-phase cycle sums per wave of the fused
 band-sparse mel kernel at cfg-2.   python tools/mel_phase_timing.py [nblocks]"""
 import os, sys

@@ -1,4 +1,6 @@
 #!/usr/bin/env python
+# NOTE (round 6): the timing / probe switches this tool builds with left the product sources; apply tools/ablation/lab_knobs_r06.patch
+# (patch -p1 at the repo root) to a scratch tree first.
 """Diagnostic: shader cycles and wall time (100 MHz ticks) of the MEDIAN phase of hpss tiles, against the number of result arrays the
 kernel stores (-DTAC_HPSS_PROBE -DTAC_HPSS_ABL_ARRAYS=n builds).  Same cycles + longer time = the clock dropped; more cycles = stalls.
     python tools/r04/hpss_probe.py name=lib.so ..."""

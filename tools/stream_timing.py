@@ -1,4 +1,6 @@
 #!/usr/bin/env python
+# NOTE (round 6): the timing / probe switches this tool builds with left the product sources; apply tools/ablation/lab_knobs_r06.patch
+# (patch -p1 at the repo root) to a scratch tree first.
 """Debug: with a -DTAC_ST_TIMING=1 build (TAC_AMD_LIB=...), per-wave cycle sums of the streaming mel kernel at cfg-2 by
 stage (either thread of the wave): s0 window + pass 0, s1 pass 1, s2 pass 2, s3 R2C + |X|^2 row (+ next request),
 s4 contraction + dB + store."""

@@ -19,18 +19,11 @@ namespace tac {
 
 constexpr int BR_WAVES = 12;
 
-#ifndef TAC_BR3_NT
-#define TAC_BR3_NT 7           // nontemporal hints on what this launch touches once: 1 = stores of the finished gradient samples, 2 = loads of
-#endif                         // the gradient rows, 4 = loads of a frame's OLDEST hop (no later frame reads it).  L2-miss traffic of the
                                // kernel at cfg-2 (rocprofv3 FETCH_SIZE + WRITE_SIZE): 631 -> 517 (3) -> 448 MB (7), 369 MB compulsory; time
                                // -0.8 % (3), -1.1 % (7), bit-identical (tools/ablation/README.md)
 template <class T>
 __device__ __forceinline__ T br3_load_once(const T* p) {
-#if TAC_BR3_NT & 2
     return __builtin_nontemporal_load(p);
-#else
-    return *p;
-#endif
 }
 
 template <int NC, int E>
@@ -106,12 +99,7 @@ melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ 
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int b = t + 64 * i;
-#if TAC_BR3_ABL == 1
-                gq[i] = 1e-3f * (float)b;
-                (void)gn;
-#else
                 gq[i] = br3_load_once(gn + (b < fz.n_mels ? b : fz.n_mels - 1));
-#endif
             }
         }
         const long long start = (long long)fr * hop - g.center_pad;
@@ -120,24 +108,11 @@ melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ 
         long long cs = start < 0 ? 0 : start;
         cs = cs + N <= g.length ? cs : g.length - N;
         const cf* src = reinterpret_cast<const cf*>(g.wave + (long long)r * g.row_stride + cs);
-#ifndef TAC_BR3_ABL
-#define TAC_BR3_ABL 0          // timing-only ablations (WRONG RESULTS): 1 = no sample / gradient-row loads, 2 = no gradient stores
-#endif
-#if TAC_BR3_ABL == 1
-#pragma unroll
-        for (int q = 0; q < E; ++q) v[q] = mkc(1e-3f * (float)(t + q), 2e-3f * (float)(fr + q));
-        (void)src;
-#else
 #pragma unroll
         for (int q = 0; q < E; ++q) {
-#if TAC_BR3_NT & 4
             if (q < H) v[q] = __builtin_nontemporal_load(src + t + q * F::LPF);      // the frame's oldest hop: no later frame reads it
             else v[q] = src[t + q * F::LPF];
-#else
-            v[q] = src[t + q * F::LPF];
-#endif
         }
-#endif
     };
     auto load_tw1 = [&](cf (&tw1)[16]) {
         const f4* tl = reinterpret_cast<const f4*>(twlds + (t & 15) * ST_TW_STRIDE);
@@ -219,19 +194,6 @@ melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ 
             }
             Dft<16>::run_windowed(v, win);
         }
-#ifndef TAC_BR3_TOUCH
-#define TAC_BR3_TOUCH 0        // A/B: the NEXT frame's 64 cache lines touched (one dword per line and lane) a whole frame before they are
-#endif                         // requested, so that the request finds them in the L2 instead of waiting out an HBM / Infinity-Cache miss
-#if TAC_BR3_TOUCH
-        float touch_reg;
-        {
-            const long long nstart = (long long)nf * hop - g.center_pad;
-            long long ncs = nstart < 0 ? 0 : nstart;
-            ncs = ncs + N <= g.length ? ncs : g.length - N;
-            const float* tp = g.wave + (long long)nrow * g.row_stride + ncs + 32 * t;          // line t of the frame (128 B apart)
-            asm volatile("global_load_dword %0, %1, off" : "=v"(touch_reg) : "v"(tp) : "memory");
-        }
-#endif
         passes_after_first(std::true_type{});
         cf zm[F::NPAIR], zmid;
         s3_read_partners<F>(v, xa, zm, zmid, t);
@@ -337,16 +299,9 @@ melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ 
             }
 #pragma unroll
             for (int j = 0; j < R; ++j) acc[j] = cadd(acc[j], ring[j]);
-#if TAC_BR3_ABL == 2
-            if (acc[0].x == 123.456f)                                         // (never true: the stores are compiled in but not executed)
-#endif
 #pragma unroll
             for (int j = 0; j < H; ++j) {                                     // complete
-#if TAC_BR3_NT & 1
                 __builtin_nontemporal_store(acc[j], reinterpret_cast<cf*>(drow + 2 * (t + j * 64)));
-#else
-                *reinterpret_cast<cf*>(drow + 2 * (t + j * 64)) = acc[j];
-#endif
             }
             if (last) {                                                       // the segment's open positions
 #pragma unroll
@@ -357,9 +312,6 @@ melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ 
             for (int j = H; j < E; ++j) ring[j - H] = fresh ? mkc(0.0f, 0.0f) : acc[j];
         }
         wave_lds_fence();
-#if TAC_BR3_TOUCH
-        asm volatile("s_waitcnt vmcnt(63)" :: "v"(touch_reg));   // (no wait in practice: keeps the touch's register reserved up to here; the load is ~a frame old)
-#endif
         if (!more) break;
         seg = nseg; row = nrow; sidx = nsidx; f0 = nf0; f1 = nf1; f = nf;
     }

@@ -112,12 +112,8 @@ melspec_backward_ring3_multi_kernel(FrameGeom g, Tables tb, const float* __restr
         const cf* src = reinterpret_cast<const cf*>(g.wave + (long long)r * g.row_stride + cs);
 #pragma unroll
         for (int q = 0; q < E; ++q) {
-#if TAC_BR3_NT & 4
             if (q < H) v[q] = __builtin_nontemporal_load(src + t + q * LPF);      // the frame's oldest hop: no later frame reads it
             else v[q] = src[t + q * LPF];
-#else
-            v[q] = src[t + q * LPF];
-#endif
         }
     };
 
@@ -291,11 +287,7 @@ melspec_backward_ring3_multi_kernel(FrameGeom g, Tables tb, const float* __restr
                 if (live) {
 #pragma unroll
                     for (int j = 0; j < H; ++j) {                                 // complete
-#if TAC_BR3_NT & 1
                         __builtin_nontemporal_store(acc[j], reinterpret_cast<cf*>(drow + 2 * (t + j * LPF)));
-#else
-                        *reinterpret_cast<cf*>(drow + 2 * (t + j * LPF)) = acc[j];
-#endif
                     }
                     if (last) {                                                   // the segment's open positions
 #pragma unroll

@@ -140,7 +140,7 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Phase stamps for the timing builds of the tools (TAC_STFT_TIMING): NoStamp compiles to nothing.
+// Phase stamps for timing builds (tools/ablation/lab_knobs_r06.patch restores them): NoStamp compiles to nothing.
 struct NoStamp {
     __device__ __forceinline__ void mark(int) {}
 };
@@ -235,9 +235,6 @@ __device__ __forceinline__ cf mul_w32(cf v, int m) {
     return cmulc(v, C[m], S[m]);
 }
 
-#ifndef TAC_DFT16_FOLD
-#define TAC_DFT16_FOLD 0        // A/B (round 4): eighth-turn factors of the radix-16 butterfly folded into the consuming adds as FMAs
-#endif
 template <int R>
 struct Dft;
 
@@ -280,45 +277,6 @@ struct Dft<16> {
             if constexpr (WINDOWED) dft4_windowed(a[c][0], a[c][1], a[c][2], a[c][3], win[c], win[c + 4], win[c + 8], win[c + 12]);
             else dft4(a[c][0], a[c][1], a[c][2], a[c][3]);
         }
-#if TAC_DFT16_FOLD
-        // The four eighth-turn factors W16^2 = c (1 - i), W16^6 = -c (1 + i), c = sqrt(1/2), are not applied to their element:
-        // x (1 -+ i) is one rotating add and the scale c rides on the consuming butterfly's adds as packed FMAs — 4 packed
-        // instructions fewer per radix-16 butterfly (8 per frame), and one rounding less per folded product.
-        a[1][1] = mul_w16<1>(a[1][1]); a[1][3] = mul_w16<3>(a[1][3]);
-        a[3][1] = mul_w16<3>(a[3][1]); a[3][3] = mul_w16<9>(a[3][3]);
-        const cf cpp = mkc(TAC_SQRT_HALF, TAC_SQRT_HALF), cnn = mkc(-TAC_SQRT_HALF, -TAC_SQRT_HALF);
-        {   // r = 0: no factors
-            cf b0 = a[0][0], b1 = a[1][0], b2 = a[2][0], b3 = a[3][0];
-            dft4(b0, b1, b2, b3);
-            v[0] = b0; v[4] = b1; v[8] = b2; v[12] = b3;
-        }
-        {   // r = 1: b2 = W16^2 a[2][1] = c u, u = a (1 - i)
-            const cf u = cadd_rot(a[2][1], a[2][1]);
-            const cf b0 = a[0][1], b1 = a[1][1], b3 = a[3][1];
-            const cf s02 = __builtin_elementwise_fma(u, cpp, b0), d02 = __builtin_elementwise_fma(u, cnn, b0);
-            const cf s13 = cadd(b1, b3), d13 = csub(b1, b3);
-            v[1] = cadd(s02, s13); v[5] = cadd_rot(d02, d13); v[9] = csub(s02, s13); v[13] = csub_rot(d02, d13);
-        }
-        {   // r = 2: b1 = W16^2 a[1][2] = c u1, b2 = -i a[2][2] (dft4_rot2), b3 = W16^6 a[3][2] = -c u3, u3 = a (1 + i)
-            const cf u1 = cadd_rot(a[1][2], a[1][2]), u3 = csub_rot(a[3][2], a[3][2]);
-            const cf S = csub(u1, u3), D = cadd(u1, u3);             // b1 + b3 = c S, b1 - b3 = c D
-            const cf s02 = cadd_rot(a[0][2], a[2][2]), d02 = csub_rot(a[0][2], a[2][2]);
-            v[2] = __builtin_elementwise_fma(S, cpp, s02);
-            v[10] = __builtin_elementwise_fma(S, cnn, s02);
-            cf o1, o3;                                               // d02 -+ i c D:  (x + c D.y, y - c D.x) and (x - c D.y, y + c D.x)
-            const cf cpn = mkc(TAC_SQRT_HALF, -TAC_SQRT_HALF), cnp = mkc(-TAC_SQRT_HALF, TAC_SQRT_HALF);
-            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1]" : "=v"(o1) : "v"(D), "v"(cpn), "v"(d02));
-            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1]" : "=v"(o3) : "v"(D), "v"(cnp), "v"(d02));
-            v[6] = o1; v[14] = o3;
-        }
-        {   // r = 3: b2 = W16^6 a[2][3] = -c u, u = a (1 + i)
-            const cf u = csub_rot(a[2][3], a[2][3]);
-            const cf b0 = a[0][3], b1 = a[1][3], b3 = a[3][3];
-            const cf s02 = __builtin_elementwise_fma(u, cnn, b0), d02 = __builtin_elementwise_fma(u, cpp, b0);
-            const cf s13 = cadd(b1, b3), d13 = csub(b1, b3);
-            v[3] = cadd(s02, s13); v[7] = cadd_rot(d02, d13); v[11] = csub(s02, s13); v[15] = csub_rot(d02, d13);
-        }
-#else
         a[1][1] = mul_w16<1>(a[1][1]); a[1][2] = mul_w16<2>(a[1][2]); a[1][3] = mul_w16<3>(a[1][3]);
         a[2][1] = mul_w16<2>(a[2][1]); /* a[2][2]·W16^4 = -i: folded into column 2's butterfly */ a[2][3] = mul_w16<6>(a[2][3]);
         a[3][1] = mul_w16<3>(a[3][1]); a[3][2] = mul_w16<6>(a[3][2]); a[3][3] = mul_w16<9>(a[3][3]);
@@ -329,7 +287,6 @@ struct Dft<16> {
             else dft4(b0, b1, b2, b3);
             v[r] = b0; v[r + 4] = b1; v[r + 8] = b2; v[r + 12] = b3;
         }
-#endif
     }
 };
 

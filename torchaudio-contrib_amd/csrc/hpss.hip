@@ -145,9 +145,6 @@ hpss_tile_kernel(const float* __restrict__ x, int NA, int NB, long long sr, long
                 hpss_masks(harm, perc, power, hard, mh, mp);
                 const long long o = row * sr + (long long)a * sa + (long long)b * sb;
                 const float v = w[HALF + j];                           // the window's own centre tap
-#ifdef TAC_HPSS_ABL_NOSTORE
-                if (mh + mp != 123.0f) continue;
-#endif
                 mh_o[o] = mh;
                 mp_o[o] = mp;
                 if (harm_o) {
@@ -160,37 +157,17 @@ hpss_tile_kernel(const float* __restrict__ x, int NA, int NB, long long sr, long
     }
 }
 
-#ifdef TAC_HPSS_PROBE   // diagnostic builds only (tools/r04/hpss_probe.py): shader cycles and 100 MHz ticks of the median phase of every tile
-__device__ unsigned long long hp_probe[4];
-#define HP_PROBE_BEGIN() const unsigned long long pc0 = __builtin_readcyclecounter(), pr0 = __builtin_amdgcn_s_memrealtime()
-#define HP_PROBE_END()                                                                                                     \
-    do {                                                                                                                   \
-        if (threadIdx.x == 0) {                                                                                            \
-            atomicAdd(&hp_probe[0], __builtin_readcyclecounter() - pc0);                                                   \
-            atomicAdd(&hp_probe[1], __builtin_amdgcn_s_memrealtime() - pr0);                                               \
-            atomicAdd(&hp_probe[2], 1ull);                                                                                 \
-        }                                                                                                                  \
-    } while (0)
-#else
 #define HP_PROBE_BEGIN()
 #define HP_PROBE_END()
-#endif
-// Tile of a workgroup, XCD-aware (TAC_HPSS_XCD): workgroups go to the eight XCDs round-robin (block b -> XCD b % 8), and each XCD has
+// Tile of a workgroup, XCD-aware: workgroups go to the eight XCDs round-robin (block b -> XCD b % 8), and each XCD has
 // its own L2.  With tile = block, spatial neighbours always sit on DIFFERENT XCDs and every halo is fetched from HBM again (rocprofv3:
 // 873 MB read per launch for a 328 MB spectrogram); giving every XCD a contiguous eighth of the tiles — tile = (b % 8) * ceil(total / 8)
 // + b / 8, the grid rounded up to a multiple of eight — keeps neighbours behind one L2.  Correct for any placement; only speed depends on it.
-#ifndef TAC_HPSS_XCD
-#define TAC_HPSS_XCD 1
-#endif
 __device__ __forceinline__ long long hp_tile_of_block(long long total) {
-#if TAC_HPSS_XCD
     const long long per_xcd = (total + 7) / 8;
     return (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-#else
-    return blockIdx.x;
-#endif
 }
-static inline unsigned hp_grid_for(long long total) { return TAC_HPSS_XCD ? (unsigned)(((total + 7) / 8) * 8) : (unsigned)total; }
+static inline unsigned hp_grid_for(long long total) { return (unsigned)(((total + 7) / 8) * 8); }
 
 // hpss_tile8_kernel (round 4): the same tile with
 //  * runs of EIGHT windows per thread (median_run8: 56 instead of 97 min / max per median at K = 31), the NaN bookkeeping only
@@ -203,26 +180,8 @@ static inline unsigned hp_grid_for(long long total) { return TAC_HPSS_XCD ? (uns
 //    masks are formed too; along A it owns one column x 16 rows (two runs; LDS reads down the rows, a wave = 64 consecutive
 //    columns), and the A medians cross the workgroup once through the (by then dead) tile;
 //  * the results leave through a per-wave transpose in LDS (hp_emit_block): four whole 256-byte row segments per store instruction.
-#ifndef TAC_HPSS_RUN8
-#define TAC_HPSS_RUN8 1
-#endif
-#ifndef TAC_HPSS_TWO_PASS
-#define TAC_HPSS_TWO_PASS 1    // unequal / small widths: hpss_axis_a_kernel + hpss_axis_b_kernel (0: round 3's hpss_kernel)
-#endif
 #ifndef TAC_HPSS_OCC8
 #define TAC_HPSS_OCC8 3
-#endif
-#ifndef TAC_HPSS_AMAP1
-#define TAC_HPSS_AMAP1 1       // 0: column pairs x 8 rows (8-byte LDS reads)
-#endif
-#ifndef TAC_HPSS_FILL16
-#define TAC_HPSS_FILL16 1      // 0: the flat dword loop
-#endif
-#ifndef TAC_HPSS_STORE16
-#define TAC_HPSS_STORE16 1     // 0: dword stores
-#endif
-#ifndef TAC_HPSS_NT
-#define TAC_HPSS_NT 0          // 1: nontemporal stores
 #endif
 #ifndef TAC_HPSS_STRIDE8
 #define TAC_HPSS_STRIDE8 96    // (100 / 104: 4 % slower, tools/ablation/README.md)
@@ -238,7 +197,6 @@ template <int COLS>
 __device__ __forceinline__ bool hp_fill(float* tile, int stride, const float* __restrict__ xr, int a_first, int n_rows,
                                         int b_first, int NA, int NB, long long sa, long long sb, int tid) {
     bool seen_nan = false;
-#if TAC_HPSS_FILL16
     if (sb == 1) {
         constexpr int CH = COLS / 4;
         for (int q = tid; q < n_rows * CH; q += 256) {
@@ -260,7 +218,6 @@ __device__ __forceinline__ bool hp_fill(float* tile, int stride, const float* __
         }
         return seen_nan;
     }
-#endif
     for (int i = tid; i < n_rows * COLS; i += 256) {
         const int r = i / COLS, c = i - r * COLS;
         const int a = reflect_clamped(a_first + r, NA), b = reflect_clamped(b_first + c, NB);
@@ -298,26 +255,16 @@ __device__ __forceinline__ void hp_emit8(bool row_ok, int bq, int NB, long long 
         const float perc = b_is_time ? m_a[j] : m_b[j];
         hpss_masks(harm, perc, power, hard, mh[j], mp[j]);
     }
-#ifdef TAC_HPSS_ABL_NOSTORE
-    if (mh[0] + mp[7] != 123.0f) return;
-#endif
     if (!row_ok) return;
     auto put = [&](float* base, const float (&v)[8]) {
-#if TAC_HPSS_STORE16
         if (sb == 1 && bq + 7 < NB) {
             hp_f4u lo4, hi4;
             lo4.x = v[0]; lo4.y = v[1]; lo4.z = v[2]; lo4.w = v[3];
             hi4.x = v[4]; hi4.y = v[5]; hi4.z = v[6]; hi4.w = v[7];
-#if TAC_HPSS_NT
-            __builtin_nontemporal_store(lo4, reinterpret_cast<hp_f4u*>(base + o));
-            __builtin_nontemporal_store(hi4, reinterpret_cast<hp_f4u*>(base + o + 4));
-#else
             *reinterpret_cast<hp_f4u*>(base + o) = lo4;
             *reinterpret_cast<hp_f4u*>(base + o + 4) = hi4;
-#endif
             return;
         }
-#endif
 #pragma unroll
         for (int j = 0; j < 8; ++j)
             if (bq + j < NB) base[o + (long long)j * sb] = v[j];
@@ -336,14 +283,11 @@ __device__ __forceinline__ void hp_emit8(bool row_ok, int bq, int NB, long long 
     }
 }
 
-// The same for the thread's 2 rows x 8 columns of the B map, stored through a per-wave transpose in LDS (TAC_HPSS_COALESCE): in the B map a
+// The same for the thread's 2 rows x 8 columns of the B map, stored through a per-wave transpose in LDS: in the B map a
 // store instruction's lanes write 16-byte pieces 32 bytes apart (the other half of each lane's eight columns goes with the next
 // instruction), which the memory pipe cannot merge — one request per lane; staged as [16 rows][64 columns] (HP8_EX floats apart) and read
 // back with lane l on row l / 16 (+ 4 k), columns 4 (l % 16) .., every store instruction writes four whole 256-byte row segments.
 // `scratch`: this wave's 16 x HP8_EX floats; a_blk: first row of the wave's 16-row block (rows 2 (ay % 8) + i of it are this thread's).
-#ifndef TAC_HPSS_COALESCE
-#define TAC_HPSS_COALESCE 1
-#endif
 constexpr int HP8_SCRATCH = 16 * 68;          // floats per wave (64-column tiles)
 // TB: columns of the tile (64: a wave's block is 16 rows x 64 columns; 128: 8 x 128; 256: 4 x 256 — a store instruction then writes
 // 1 KB of one row)
@@ -354,7 +298,6 @@ __device__ __forceinline__ void hp_emit_block(float* scratch, int tid, int a_blk
                                               float* perc_o, float* mh_o, float* mp_o) {
     constexpr int NBX = TB / 8, PITCH = TB + 4, CPR = TB / 4;
     const int lane = tid & 63, bx = lane % NBX, lr = 2 * (lane / NBX);
-#if TAC_HPSS_COALESCE
     if (sb == 1) {
         float mh[2][8], mp[2][8];
 #pragma unroll
@@ -365,9 +308,6 @@ __device__ __forceinline__ void hp_emit_block(float* scratch, int tid, int a_blk
                 const float perc = b_is_time ? m_a[i][j] : m_b[i][j];
                 hpss_masks(harm, perc, power, hard, mh[i][j], mp[i][j]);
             }
-#ifdef TAC_HPSS_ABL_NOSTORE
-        if (mh[0][0] + mp[1][7] != 123.0f) return;
-#endif
         auto put = [&](float* base, const float (&v)[2][8]) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -389,11 +329,7 @@ __device__ __forceinline__ void hp_emit_block(float* scratch, int tid, int a_blk
                     if (b + 3 < NB) {
                         hp_f4u u;
                         u.x = x4.x; u.y = x4.y; u.z = x4.z; u.w = x4.w;
-#if TAC_HPSS_NT
-                        __builtin_nontemporal_store(u, reinterpret_cast<hp_f4u*>(dst));
-#else
                         *reinterpret_cast<hp_f4u*>(dst) = u;
-#endif
                     } else {
                         if (b < NB) dst[0] = x4.x;
                         if (b + 1 < NB) dst[1] = x4.y;
@@ -403,11 +339,8 @@ __device__ __forceinline__ void hp_emit_block(float* scratch, int tid, int a_blk
             }
             wave_lds_fence();               // ... and read back before the next array's values overwrite them
         };
-#ifndef TAC_HPSS_ABL_ARRAYS
-#define TAC_HPSS_ABL_ARRAYS 4  // timing-only ablation: how many of the four result arrays are stored
-#endif
-        if (TAC_HPSS_ABL_ARRAYS >= 1) put(mh_o, mh);
-        if (TAC_HPSS_ABL_ARRAYS >= 2) put(mp_o, mp);
+        put(mh_o, mh);
+        put(mp_o, mp);
         if (harm_o) {
             float hv[2][8], pv[2][8];
 #pragma unroll
@@ -417,12 +350,11 @@ __device__ __forceinline__ void hp_emit_block(float* scratch, int tid, int a_blk
                     hv[i][j] = centre[i][j] * mh[i][j];
                     pv[i][j] = centre[i][j] * mp[i][j];
                 }
-            if (TAC_HPSS_ABL_ARRAYS >= 3) put(harm_o, hv);
-            if (TAC_HPSS_ABL_ARRAYS >= 4) put(perc_o, pv);
+            put(harm_o, hv);
+            put(perc_o, pv);
         }
         return;
     }
-#endif
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int a = a_blk + lr + i, bq = b0 + 8 * bx;
@@ -477,7 +409,6 @@ hpss_tile8_kernel(const float* __restrict__ x, int NA, int NB, long long sr, lon
         hp_run8<K>(w, medB[i], tile_has_nan);
         __builtin_amdgcn_sched_barrier(0);
     }
-#if TAC_HPSS_AMAP1
     // ---- along A: thread (cx, ry) owns column cx and rows 16 ry .. 16 ry + 15 (two runs)
     const int cx = tid & 63, ry = tid >> 6;
     float medA[2][8];
@@ -496,33 +427,6 @@ hpss_tile8_kernel(const float* __restrict__ x, int NA, int NB, long long sr, lon
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int i = 0; i < 8; ++i) tile[(16 * ry + 8 * h + i) * HP8_EX + cx] = medA[h][i];
-#else
-    // ---- along A: thread (cx, ry) owns rows 8 ry .. 8 ry + 7 and columns 2 cx, 2 cx + 1
-    const int cx = tid & 31, ry = tid >> 5;
-    float medA[2][8];
-    {
-        float w0[K + 7], w1[K + 7];
-        const float* src = tile + (8 * ry + 15 - HALF) * HP8_STRIDE + 2 * cx + HP_LEFT;
-#pragma unroll
-        for (int u = 0; u < K + 7; ++u) {
-            const hp_f2 v = *reinterpret_cast<const hp_f2*>(src + u * HP8_STRIDE);
-            w0[u] = v.x;
-            w1[u] = v.y;
-        }
-        hp_run8<K>(w0, medA[0], tile_has_nan);
-        __builtin_amdgcn_sched_barrier(0);
-        hp_run8<K>(w1, medA[1], tile_has_nan);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        hp_f2 v;
-        v.x = medA[0][i];
-        v.y = medA[1][i];
-        *reinterpret_cast<hp_f2*>(tile + (8 * ry + i) * HP8_EX + 2 * cx) = v;
-    }
-#endif
     __syncthreads();
     // ---- masks and stores: the B map's values, stored through the wave's transpose area (behind the exchange rows, in the dead tile)
     float m_a[2][8];
@@ -542,12 +446,6 @@ hpss_tile8_kernel(const float* __restrict__ x, int NA, int NB, long long sr, lon
 // The four result arrays leave as TB * 4-byte row segments; the store pattern ALONE (tools/ubench/tile_store_rate.hip) runs at 3.95 TB/s
 // with 256-byte segments, 4.58 with 512, 5.07 with 1 024 — 64 x 64 tiles spend 0.33 ms just writing.  Same maps: along B a thread owns
 // 2 rows x 8 columns, along A one column x 16 rows; fast axis contiguous only.
-#ifndef TAC_HPSS_TA
-#define TAC_HPSS_TA 64
-#endif
-#ifndef TAC_HPSS_TB
-#define TAC_HPSS_TB 64
-#endif
 template <int K, int TA, int TB>
 __global__ void __launch_bounds__(256, TAC_HPSS_OCC8)
 hpss_tilew_kernel(const float* __restrict__ x, int NA, int NB, long long sr, long long sa, int tiles_a, int tiles_b,
@@ -607,132 +505,8 @@ hpss_tilew_kernel(const float* __restrict__ x, int NA, int NB, long long sr, lon
                       centre, b_is_time, power, hard, harm_o, perc_o, mh_o, mp_o);
 }
 
-// hpss_tile8p_kernel: hpss_tile8_kernel as PERSISTENT workgroups that walk tiles and request the NEXT tile's samples BEFORE they issue
-// the current tile's stores.  A CU's vector-memory path is in order: with one tile per workgroup, a neighbour's tile fill queues
-// behind this workgroup's 64 KB of stores, nothing overlaps, and the kernel's time is compute + 0.06 ms per result array (measured:
-// 0.36 + 4 x 0.06 ms at K = 31, profiles/r04/ab/batch35).  With the loads ahead of the stores in the queue they return first (vmcnt
-// counts in order), the next tile is deposited and computed while the stores drain.  Fast axis contiguous only (sb == 1).
-#ifndef TAC_HPSS_PERSIST
-#define TAC_HPSS_PERSIST 0     // measured: +5 % at K = 31, -1 % at K = 9 (tools/ablation/README.md) — the stores are not what the fills wait behind
-#endif
-#ifndef TAC_HPSS_PERSIST_WGS
-#define TAC_HPSS_PERSIST_WGS 3     // workgroups per CU
-#endif
-template <int K>
-__global__ void __launch_bounds__(256, TAC_HPSS_PERSIST_WGS)
-hpss_tile8p_kernel(const float* __restrict__ x, int NA, int NB, long long sr, long long sa, int tiles_a, int tiles_b,
-                   long long total_tiles, int b_is_time, float power, int hard, float* __restrict__ harm_o,
-                   float* __restrict__ perc_o, float* __restrict__ mh_o, float* __restrict__ mp_o) {
-    constexpr int HALF = K / 2, CH = HP_STRIDE / 4, NCHUNK = HP_ROWS * CH, NPRE = (NCHUNK + 255) / 256;
-    __shared__ __attribute__((aligned(16))) float tile[HP8_LDS_FLOATS];
-    const int tid = threadIdx.x;
-    const int per_row = tiles_a * tiles_b;
-    hp_f4 pre[NPRE];
-    auto request = [&](long long t) {                         // tile t's samples (+ halo) into registers, 16 bytes per chunk
-        const long long row = t / per_row;
-        const int rem = (int)(t - row * per_row);
-        const int a0 = (rem / tiles_b) * HP_TILE, b0 = (rem % tiles_b) * HP_TILE;
-        const float* xr = x + row * sr;
-        int tv = tid;
-        asm volatile("" : "+v"(tv));                          // (the chunk coordinates are re-derived per tile, not kept in 18 registers)
-#pragma unroll
-        for (int j = 0; j < NPRE; ++j) {
-            const int q = tv + 256 * j;
-            const int qc = q < NCHUNK ? q : NCHUNK - 1;
-            const int r = qc / CH, c4 = (qc - r * CH) * 4;
-            const float* src = xr + (long long)reflect_clamped(a0 - 15 + r, NA) * sa;
-            const int b = b0 - HP_LEFT + c4;
-            if (b >= 0 && b + 3 < NB) {
-                const hp_f4u u = *reinterpret_cast<const hp_f4u*>(src + b);
-                pre[j].x = u.x; pre[j].y = u.y; pre[j].z = u.z; pre[j].w = u.w;
-            } else {
-                pre[j].x = src[reflect_clamped(b, NB)];
-                pre[j].y = src[reflect_clamped(b + 1, NB)];
-                pre[j].z = src[reflect_clamped(b + 2, NB)];
-                pre[j].w = src[reflect_clamped(b + 3, NB)];
-            }
-        }
-    };
-    auto deposit = [&]() -> bool {
-        bool seen_nan = false;
-        int tv = tid;
-        asm volatile("" : "+v"(tv));
-#pragma unroll
-        for (int j = 0; j < NPRE; ++j) {
-            const int q = tv + 256 * j;
-            if (q < NCHUNK) {
-                const int r = q / CH, c4 = (q - r * CH) * 4;
-                const hp_f4 v = pre[j];
-                seen_nan |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
-                *reinterpret_cast<hp_f4*>(tile + r * HP8_STRIDE + c4) = v;
-            }
-        }
-        return seen_nan;
-    };
-#if TAC_HPSS_XCD
-    const long long per_xcd = (total_tiles + 7) / 8, xcd_first = (long long)(blockIdx.x & 7) * per_xcd;
-    const long long xcd_end = xcd_first + per_xcd < total_tiles ? xcd_first + per_xcd : total_tiles;
-    const long long t_step = gridDim.x >> 3;                  // (the launcher makes the grid a multiple of eight)
-    long long t = xcd_first + (blockIdx.x >> 3);
-#else
-    const long long xcd_end = total_tiles, t_step = gridDim.x;
-    long long t = blockIdx.x;
-#endif
-    if (t >= xcd_end) return;
-    request(t);
-    const int bx = tid & 7, ay = tid >> 3;
-    const int cx = tid & 63, ry = tid >> 6;
-    constexpr int START = HP_LEFT - HALF, OFF = START & 3;
-    while (true) {
-        const int tile_has_nan = __syncthreads_or(deposit() ? 1 : 0);
-        const long long row = t / per_row;
-        const int rem = (int)(t - row * per_row);
-        const int a0 = (rem / tiles_b) * HP_TILE, b0 = (rem % tiles_b) * HP_TILE;
-        float medB[2][8], centre[2][8];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float w[K + 7];
-            hp_row_taps<K>(tile + (2 * ay + 15 + i) * HP8_STRIDE, 8 * bx + (START - OFF), w);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) centre[i][j] = w[HALF + j];
-            hp_run8<K>(w, medB[i], tile_has_nan);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        float medA[2][8];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float w0[K + 7];
-            const float* src = tile + (16 * ry + 8 * h + 15 - HALF) * HP8_STRIDE + cx + HP_LEFT;
-#pragma unroll
-            for (int u = 0; u < K + 7; ++u) w0[u] = src[u * HP8_STRIDE];
-            hp_run8<K>(w0, medA[h], tile_has_nan);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();                         // every read of the tile is done: the A medians change maps through it
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) tile[(16 * ry + 8 * h + i) * HP8_EX + cx] = medA[h][i];
-        __syncthreads();
-        float m_a[2][8];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const hp_f4 ma0 = *reinterpret_cast<const hp_f4*>(tile + (2 * ay + i) * HP8_EX + 8 * bx);
-            const hp_f4 ma1 = *reinterpret_cast<const hp_f4*>(tile + (2 * ay + i) * HP8_EX + 8 * bx + 4);
-            m_a[i][0] = ma0.x; m_a[i][1] = ma0.y; m_a[i][2] = ma0.z; m_a[i][3] = ma0.w;
-            m_a[i][4] = ma1.x; m_a[i][5] = ma1.y; m_a[i][6] = ma1.z; m_a[i][7] = ma1.w;
-        }
-        const long long t_next = t + t_step;
-        const bool more = t_next < xcd_end;
-        if (more) request(t_next);               // ahead of this tile's stores in the CU's in-order memory queue
-        __builtin_amdgcn_sched_barrier(0);
-        hp_emit_block(tile + HP_TILE * HP8_EX + (tid >> 6) * HP8_SCRATCH, tid, a0 + 16 * (tid >> 6), b0, NA, NB, row * sr, sa, 1, m_a,
-                      medB, centre, b_is_time, power, hard, harm_o, perc_o, mh_o, mp_o);
-        if (!more) break;
-        __syncthreads();                         // exchange rows and transpose areas are dead: the tile may be overwritten
-        t = t_next;
-    }
-}
+// (hpss_tile8p_kernel — the same as persistent workgroups that request the next tile before storing the current one: +5 % at K = 31,
+// -1 % at K = 9, tools/ablation/README.md — lives in tools/ablation/lab_knobs_r06.patch.)
 
 // Unequal (or small) widths, round 4: two launches over the same 64 x 64 output tiles, each with a halo along ONE axis.
 // hpss_axis_a_kernel<KA>: medians along A (the slow memory axis) into `tmp` — the caller's mask_perc buffer, no workspace.
@@ -874,51 +648,15 @@ static void launch_tile(const float* mag, long long rows, int F, int T, long lon
     const int NA = t_fast ? F : T, NB = t_fast ? T : F;
     const long long sa = t_fast ? sf : st, sb = t_fast ? st : sf;
     const int ta = (NA + HP_TILE - 1) / HP_TILE, tb = (NB + HP_TILE - 1) / HP_TILE;
-#if TAC_HPSS_RUN8
-#if TAC_HPSS_TA != 64 || TAC_HPSS_TB != 64       // (A/B builds only: 32 x 128 measures +7 %, 16 x 256 +42 % — tools/ablation/README.md)
-    if (sb == 1) {
-        constexpr int TA = TAC_HPSS_TA, TB = TAC_HPSS_TB;
-        const int wa = (NA + TA - 1) / TA, wb = (NB + TB - 1) / TB;
-        const long long total = rows * (long long)wa * wb;
-        hipLaunchKernelGGL((hpss_tilew_kernel<K, TA, TB>), dim3(hp_grid_for(total)), dim3(256), 0, stream, mag, NA, NB, sr, sa, wa, wb,
-                           total, t_fast ? 1 : 0, power, hard, harm, perc, mh, mp);
-        return;
-    }
-#endif
-#if TAC_HPSS_PERSIST
-    if (sb == 1) {
-        const long long total = rows * (long long)ta * tb;
-        long long blocks = (long long)device_cu_count() * TAC_HPSS_PERSIST_WGS;
-        if (blocks > total) blocks = total;
-        blocks = (blocks + 7) / 8 * 8;
-        hipLaunchKernelGGL(hpss_tile8p_kernel<K>, dim3((unsigned)blocks), dim3(256), 0, stream, mag, NA, NB, sr, sa, ta, tb, total,
-                           t_fast ? 1 : 0, power, hard, harm, perc, mh, mp);
-        return;
-    }
-#endif
     const long long total_tiles = rows * (long long)ta * tb;
     hipLaunchKernelGGL(hpss_tile8_kernel<K>, dim3(hp_grid_for(total_tiles)), dim3(256), 0, stream, mag, NA, NB, sr, sa, sb, ta, tb,
                        total_tiles, t_fast ? 1 : 0, power, hard, harm, perc, mh, mp);
-#else
-    hipLaunchKernelGGL(hpss_tile_kernel<K>, dim3((unsigned)(rows * ta * tb)), dim3(256), 0, stream, mag, NA, NB, sr, sa, sb,
-                       ta, tb, t_fast ? 1 : 0, power, hard, harm, perc, mh, mp);
-#endif
 }
 
 }  // namespace tac
 
 extern "C" {
 
-#ifdef TAC_HPSS_PROBE
-int tac_debug_hpss_probe(unsigned long long* out4, int reset) {
-    if (out4 && hipMemcpyFromSymbol(out4, HIP_SYMBOL(tac::hp_probe), 4 * sizeof(unsigned long long)) != hipSuccess) return -1;
-    if (reset) {
-        const unsigned long long z[4] = {0, 0, 0, 0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(tac::hp_probe), z, sizeof(z)) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#endif
 
 int tac_hpss_f32(const float* mag, int64_t rows, int32_t n_freqs, int32_t n_frames, int64_t stride_r, int64_t stride_f,
                  int64_t stride_t, int32_t kernel_f, int32_t kernel_t, float power, int hard, float* harm, float* perc,
@@ -961,7 +699,6 @@ int tac_hpss_f32(const float* mag, int64_t rows, int32_t n_freqs, int32_t n_fram
         TAC_HIP(hipGetLastError());
         return TAC_OK;
     }
-#if TAC_HPSS_TWO_PASS
     if (tiles < 0x7fffffffLL) {
         const bool t_fast = stride_t <= stride_f;
         const int NA = t_fast ? n_freqs : n_frames, NB = t_fast ? n_frames : n_freqs;
@@ -991,7 +728,6 @@ int tac_hpss_f32(const float* mag, int64_t rows, int32_t n_freqs, int32_t n_fram
         TAC_HIP(hipGetLastError());
         return TAC_OK;
     }
-#endif
     if (kernel_f > 32 || kernel_t > 32) return TAC_E_UNSUPPORTED;      // (the one-thread-per-element form sorts 32 taps)
     const long long total = rows * (long long)n_freqs * n_frames;
     long long blocks = (total + 255) / 256;

@@ -47,14 +47,7 @@ struct MelArgs {
 
 enum { STEP_EDGE = 1 << 20 };                // step: k | tile << 12 | edge
 
-#ifndef TAC_MEL_TIMING
-#define TAC_MEL_TIMING 0   // 1: overwrite out[...] with per-phase cycle sums (s_memtime), debug only
-#endif
-#if TAC_MEL_TIMING
-#define TAC_STAMP(i) do { long long _n = clock64(); tacc[i] += (float)(_n - tlast); tlast = _n; } while (0)
-#else
 #define TAC_STAMP(i) do {} while (0)
-#endif
 
 template <int WAVES, int CAP>
 struct MelTables {
@@ -181,10 +174,6 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
             breg[i] = ok ? fbl[ok ? u : 0] : 0.0f;
         }
     }
-#if TAC_MEL_TIMING
-    float tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long tlast = clock64();
-#endif
     for (int tile = begin; tile < end; ++tile) {
         const int row = tile / tiles_per_row;
         const long long f0 = (long long)(tile - row * tiles_per_row) * TILE;
@@ -256,11 +245,6 @@ melspec_kernel(FrameGeom g, Tables tb, MelArgs m, MelPlan plan) {
         // of them are behind the barrier above), and the barrier after phase A orders these partial reads
         // before the next phase-B writes.
     }
-#if TAC_MEL_TIMING
-    __syncthreads();
-    if (lane == 0)
-        for (int i = 0; i < 6; ++i) m.out[((long long)blockIdx.x * WAVES + w) * 8 + i] = tacc[i];
-#endif
 }
 
 template <int NC, int E, int TILE, int BUDGET>

@@ -22,9 +22,6 @@
 #include <atomic>
 #include <vector>
 
-#ifndef TAC_SP_TIMING
-#define TAC_SP_TIMING 0   // 1: debug builds of tools/mel_phase_timing.py — phase cycle sums overwrite the head of out[]
-#endif
 
 #include "sparse_phase.hpp"
 #include "melspec_stream.hpp"
@@ -163,12 +160,7 @@ melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the tile loop is entered with nothing in flight
 
-#if TAC_SP_TIMING
-    CycleStamp st;
-    st.init();
-#else
     NoStamp st;
-#endif
     for (int tile = begin; tile < end; ++tile) {
         const int row = tile / tiles_per_row;
         const long long f0 = (long long)(tile - row * tiles_per_row) * TILE;
@@ -194,12 +186,6 @@ melspec_sparse_kernel(FrameGeom g, Tables tb, SparseArgs m) {
         sparse_phase_c<WAVES * 64>(otile, ostr, tid, TILE, m, g, row, f0);
         // the barrier after the next phase A orders these otile reads before the next phase-B writes
     }
-#if TAC_SP_TIMING
-    st.mark(0);
-    __syncthreads();
-    if (lane == 0)
-        for (int i = 0; i < 12; ++i) m.out[((long long)blockIdx.x * WAVES + w) * 16 + i] = st.acc[i];
-#endif
 }
 
 // ---------------------------------------------------------------- standalone band-sparse filterbank

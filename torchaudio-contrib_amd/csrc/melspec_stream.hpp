@@ -23,12 +23,6 @@
 #pragma once
 #include "mel_common.hpp"
 
-#ifndef TAC_EXP_TW1_EARLY
-#define TAC_EXP_TW1_EARLY 0  // experiment: pass-1 twiddle reads issued ahead of the stage's LDS write burst
-#endif
-#ifndef TAC_ST_TIMING
-#define TAC_ST_TIMING 0     // 1: debug builds of tools/stream_timing.py — per-wave cycle sums overwrite the head of out[]
-#endif
 
 namespace tac {
 
@@ -161,14 +155,7 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     for (int s = 0; s < ST_MAX_SLOTS; ++s) lo_s[s] = s < m.nslot ? m.lo[s * 64 + lane] : 0;
     __syncthreads();                                                   // the only barrier of the kernel (tables in place)
 
-#if TAC_ST_TIMING
-    float tstamp[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const long long tstart = clock64();
-    long long tlast = tstart;
-#define ST_MARK(k) do { const long long now_ = clock64(); tstamp[k] += (float)(now_ - tlast); tlast = now_; } while (0)
-#else
 #define ST_MARK(k) do { } while (0)
-#endif
     cf vA[E], vB[E];
     cf zmA[F::NPAIR], zmB[F::NPAIR], zmidA = mkc(0.f, 0.f), zmidB = mkc(0.f, 0.f);
 
@@ -257,11 +244,6 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     };
     // s0: windowed samples -> pass-0 butterflies -> exchange 0 (write, read-back issued)
     auto s0 = [&](cf (&v)[E], int mode, int row, long long fr) {
-#if TAC_ST_TIMING
-        ST_MARK(1);                                                    // (diagnostic split: what precedes the wait for the samples ...
-        asm volatile("" : : "v"(v[E - 1]), "v"(v[0]));                 //  ... the wait itself (loads return in order) ...
-        ST_MARK(3);                                                    //  ... is booked under stamp 3)
-#endif
         if (mode == 1) {
             decode(v);
         } else {                                                       // edge / unaligned frame: gathered through the exchange
@@ -277,21 +259,11 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     auto s0b = [&](cf (&v)[E], int mode, auto&& before_writes) {
         if (mode == 1) Dft<16>::run_windowed(v, win);
         else F::template pass_butterflies<0>(v);
-#if TAC_ST_TIMING > 1
-        asm volatile("" : "+v"(v[0]), "+v"(v[5]), "+v"(v[10]), "+v"(v[15]));
-        ST_MARK(8);                                                    // (fine stamps: previous drain + butterflies)
-#endif
         wave_lds_fence();
         before_writes();
         F::template pass_write<0, true>(v, xa, t, t);
-#if TAC_ST_TIMING > 1
-        ST_MARK(9);                                                    // exchange write issue
-#endif
         wave_lds_fence();
         F::template pass_readback<1>(v, xa, t);
-#if TAC_ST_TIMING > 1
-        ST_MARK(10);                                                   // write drain + read issue
-#endif
     };
     // FAST2: pass 1's twiddles are requested at the end of the stage that precedes the s12 they are for (one set of
     // registers serves both threads)
@@ -317,9 +289,6 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         else F::template pass_twiddle<2>(v, tw);
         F::template pass_butterflies<2>(v);
         wave_lds_fence();
-#if TAC_EXP_TW1_EARLY
-        if (reload_tw1) tw1_issue(tw1);                                // for the other thread's s12: ahead of this stage's LDS burst
-#endif
         F::template pass_write<2, true>(v, xa, t, t);
         wave_lds_fence();
         // partners Z[NC - t - 64 p]: one address register, the rest are immediates (pad(a - c) = pad(a) - pad(c) for
@@ -503,18 +472,12 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
 #pragma unroll 1
         while (iA < nloc || iB < nloc) {
             s0(vA, modeA, rowA_, frA);
-#if TAC_EXP_TW1_EARLY
-            s0b(vA, modeA, [&]() { tw1_issue(tw1); });
-#else
             s0b(vA, modeA, []() {});
             tw1_issue(tw1);
-#endif
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(1);
             s12(vB, zmB, zmidB, tw1, true);
-#if !TAC_EXP_TW1_EARLY
             tw1_issue(tw1);
-#endif
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(2);
             s12(vA, zmA, zmidA, tw1, false);
@@ -564,16 +527,8 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
             s0b(vB, modeB, []() {});
             __builtin_amdgcn_sched_barrier(0);
             ST_MARK(1);
-#if TAC_ST_TIMING
-            tstamp[7] += 2.0f;
-#endif
         }
     }
-#if TAC_ST_TIMING
-    tstamp[0] = (float)(clock64() - tstart);
-    if (lane == 0)
-        for (int i = 0; i < 12; ++i) m.out[((long long)blockIdx.x * 8 + w) * 12 + i] = tstamp[i];
-#endif
 }
 
 }  // namespace tac

@@ -12,18 +12,8 @@
 namespace tac {
 
 constexpr int PV_THREADS = 256;
-#ifndef TAC_PV_PHASOR
-#define TAC_PV_PHASOR 1        // float32: the running phase as a unit PHASOR advanced by complex products (no arctangent, sine or cosine)
-#endif
-#ifndef TAC_PV_FIXED
-#define TAC_PV_FIXED 1         // float32: running phase as a 32-bit fraction of a turn (0: round 3's float64 running sum)
-#endif
 #ifndef TAC_PV_AHEAD
 #define TAC_PV_AHEAD 4         // steps whose frames are in flight (8: no gain; 12 / 16: the register set spills, +60 %)
-#endif
-#ifndef TAC_PV_PREFETCH0
-#define TAC_PV_PREFETCH0 0     // 1: a step's FIRST frame, when it is not the previous step's second, is requested ahead as well
-                               //    (-1 % at rate 1.3, +1 ... +4 % at rate 2: tools/ablation/README.md)
 #endif
 
 // Precision.  The reference evaluates the recurrence in the dtype of its input, and in float32 that is
@@ -33,15 +23,13 @@ constexpr int PV_THREADS = 256;
 // Only the running sum MODULO one turn reaches the output (it goes through cos / sin, functional.py:268-272), and modulo
 // one turn the reference's step `wrap(a1 - a0 - pa) + pa` (functional.py:258-264) is `a1 - a0`: the wrap subtracts whole
 // turns and the phase advance cancels.  The float32 kernel therefore never forms the ill-conditioned sum: it carries
-// exp(i phase) as a unit phasor (TAC_PV_PHASOR, shipped) or, with -DTAC_PV_PHASOR=0, angles as 32-bit fractions of a turn and
-// their wrapping integer sum; either agrees with the float64 evaluation of the reference's formula to ~1e-6 rad, whatever
+// exp(i phase) as a unit phasor (the 32-bit-fraction-of-a-turn form of round 4 is in tools/ablation/lab_knobs_r06.patch); it agrees with the float64 evaluation of the reference's formula to ~1e-6 rad, whatever
 // the number of steps and the size of the phase advance.  A phase advance that is not finite poisons every step after the
 // first, as the reference's cumulative sum does.  T = double is the reference's float64 formula as is.
 template <class T>
 struct pv_math;
 template <>
 struct pv_math<float> {
-#if TAC_PV_PHASOR
     // exp(i acc) itself is carried: exp(i (acc + a1 - a0)) = exp(i acc) * u1 * conj(u0) with u = z / |z| — four products per
     // factor, one v_rsq_f32 per input frame, and a first-order renormalisation of the running phasor (|u|^2 is within 1e-6 of
     // 1: u *= 1.5 - 0.5 |u|^2) instead of atan2 (25 instructions), v_sin and v_cos.  Rounding: ~1e-7 rad per step, unbiased
@@ -84,89 +72,6 @@ struct pv_math<float> {
         *c = acc.x + bias;
         *s = acc.y + bias;
     }
-#elif TAC_PV_FIXED
-    typedef unsigned ang_t;                                         // fraction of a turn, scaled by 2^32 (wrapping)
-    typedef unsigned acc_t;
-    // atan2 in TURNS without the library's special-case ladder: octant reduction to a = min / max in [0, 1],
-    // atan(a) / 2 pi = a P(a^2) with the degree-8 minimax P of round 3 (1.0e-7 rad; fitted and checked over 2 M points by the
-    // script quoted in tools/ablation/README.md) scaled by 1 / 2 pi, signs restored.  atan2(0, 0) = 0 like the library.
-    static __device__ __forceinline__ ang_t angle(float y, float x) {
-        const float ax = fabsf(x), ay = fabsf(y);
-        const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-        float a = mn * __builtin_amdgcn_rcpf(mx);
-        a = mx == 0.0f ? 0.0f : a;
-        const float s = a * a;
-        float p = (float)(0.0024567253421992064 * 0.15915494309189535);
-        p = fmaf(p, s, (float)(-0.014401361346244812 * 0.15915494309189535));
-        p = fmaf(p, s, (float)(0.03978123143315315 * 0.15915494309189535));
-        p = fmaf(p, s, (float)(-0.07234857976436615 * 0.15915494309189535));
-        p = fmaf(p, s, (float)(0.10498946160078049 * 0.15915494309189535));
-        p = fmaf(p, s, (float)(-0.14161229133605957 * 0.15915494309189535));
-        p = fmaf(p, s, (float)(0.19985906779766083 * 0.15915494309189535));
-        p = fmaf(p, s, (float)(-0.33332598209381104 * 0.15915494309189535));
-        p = fmaf(p, s, (float)(0.9999998807907104 * 0.15915494309189535));
-        float r = p * a;                                            // [0, 1/8] turn
-        r = ay > ax ? 0.25f - r : r;
-        r = x < 0.0f ? 0.5f - r : r;
-        // exact scaling by 2^32 ([0, 2^31] fits an unsigned); NaN converts to 0 (the magnitude carries it)
-        const unsigned u = (unsigned)(r * 4294967296.0f);
-        return __builtin_signbit(y) ? 0u - u : u;
-    }
-    static __device__ __forceinline__ void polar(float re, float im, ang_t& a, float& n) {
-        a = angle(im, re);
-        n = sqrtf(re * re + im * im);
-    }
-    static __device__ __forceinline__ acc_t open(ang_t a) { return a; }
-    static __device__ __forceinline__ acc_t step(acc_t acc, ang_t a1, ang_t a0, float) {
-        return acc + a1 - a0;                                       // wraps modulo one turn
-    }
-    static __device__ __forceinline__ float poison(float pa) { return pa - pa; }     // 0, or NaN for a non-finite advance
-    static __device__ __forceinline__ void sincos(acc_t acc, float bias, float* s, float* c) {
-        const float fr = (float)(int)acc * 2.3283064365386963e-10f + bias;                  // [-1/2, 1/2] turn for v_sin / v_cos
-        *s = __builtin_amdgcn_sinf(fr);
-        *c = __builtin_amdgcn_cosf(fr);
-    }
-#else
-    typedef float ang_t;
-    typedef double acc_t;
-    static __device__ __forceinline__ float angle(float y, float x) {
-        const float ax = fabsf(x), ay = fabsf(y);
-        const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-        float a = mn * __builtin_amdgcn_rcpf(mx);
-        a = mx == 0.0f ? 0.0f : a;
-        const float s = a * a;
-        float p = 0.0024567253421992064f;
-        p = fmaf(p, s, -0.014401361346244812f);
-        p = fmaf(p, s, 0.03978123143315315f);
-        p = fmaf(p, s, -0.07234857976436615f);
-        p = fmaf(p, s, 0.10498946160078049f);
-        p = fmaf(p, s, -0.14161229133605957f);
-        p = fmaf(p, s, 0.19985906779766083f);
-        p = fmaf(p, s, -0.33332598209381104f);
-        p = fmaf(p, s, 0.9999998807907104f);
-        float r = p * a;
-        r = ay > ax ? 1.5707963267948966f - r : r;
-        r = x < 0.0f ? 3.141592653589793f - r : r;
-        return copysignf(r, y);
-    }
-    static __device__ __forceinline__ void polar(float re, float im, ang_t& a, float& n) {
-        a = angle(im, re);
-        n = sqrtf(re * re + im * im);
-    }
-    static __device__ __forceinline__ acc_t open(ang_t a) { return (double)a; }
-    static __device__ __forceinline__ acc_t step(acc_t acc, ang_t a1, ang_t a0, float pa) {
-        double ph = (double)a1 - (double)a0 - (double)pa;
-        ph = ph - 6.283185307179586 * rint(ph * 0.15915494309189535);
-        return acc + (ph + (double)pa);
-    }
-    static __device__ __forceinline__ float poison(float) { return 0.0f; }
-    static __device__ __forceinline__ void sincos(acc_t a, float, float* s, float* c) {
-        const double tr = a * 0.15915494309189535;                  // reduced to a fraction of a turn in float64,
-        const float fr = (float)(tr - rint(tr));                    // evaluated by the hardware's v_sin / v_cos (input in turns)
-        *s = __builtin_amdgcn_sinf(fr);
-        *c = __builtin_amdgcn_cosf(fr);
-    }
-#endif
 };
 template <>
 struct pv_math<double> {
@@ -227,15 +132,12 @@ phase_vocoder_kernel(const T* __restrict__ spec, long long rows, int n_freqs, in
     // step it made every one of the n_out steps one HBM round trip long (0.336 ms at cfg-2, whatever the occupancy).
     // The frames of the next AHEAD steps are therefore always in flight (their indices come from the grid, not from the
     // recurrence), in a rotating set of registers: the second frame always; the first one, when it is not the previous
-    // step's second (rate > 1), is loaded inside the step unless TAC_PV_PREFETCH0 is set.
+    // step's second (rate > 1), is loaded inside the step.
     constexpr int AHEAD = sizeof(T) == 8 ? 4 : TAC_PV_AHEAD;        // (float64: 16-byte pairs, round 3's depth)
     T2 ahead1[AHEAD], ahead0[AHEAD];
     auto request = [&](int i, T2& v0, T2& v1) {  // frames of step i (clamped to the last step)
         const int ic = i < n_out ? i : n_out - 1;
         v1 = frame(idx1[ic]);
-#if TAC_PV_PREFETCH0
-        if (ic == 0 || idx0[ic] != idx1[ic - 1]) v0 = frame(idx0[ic]);
-#endif
     };
 #pragma unroll
     for (int k = 0; k < AHEAD; ++k) {
@@ -251,27 +153,13 @@ phase_vocoder_kernel(const T* __restrict__ spec, long long rows, int n_freqs, in
             const T2 cur1 = ahead1[k];
             T2 cur0 = ahead0[k];
             request(i + AHEAD, ahead0[k], ahead1[k]);
-#ifdef TAC_PV_ABL_COPY                       // timing-only ablation (wrong results): the access pattern without the arithmetic
-            {
-                if (t0 != t_kept) cur0 = frame(t0);
-                t_kept = t1;
-                T2 res;
-                res.x = cur1.x * alpha[i] + cur0.x;
-                res.y = cur1.y + cur0.y;
-                *reinterpret_cast<T2*>(o) = res;
-                o += 2 * (long long)n_freqs;
-                continue;
-            }
-#endif
             typename M::ang_t ang0;
             T n0;
             if (t0 == t_kept) {
                 ang0 = ang_kept;
                 n0 = n_kept;
             } else {
-#if !TAC_PV_PREFETCH0
                 cur0 = frame(t0);
-#endif
                 M::polar(cur0.x, cur0.y, ang0, n0);
             }
             typename M::ang_t ang1;

@@ -15,17 +15,10 @@
 #endif
 
 
-#ifndef TAC_STFT_TIMING
-#define TAC_STFT_TIMING 0   // 1: debug builds of tools/stft_phase_timing.py — per-phase cycle sums overwrite the head of out[]
-#endif
 
 namespace tac {
 
-#if TAC_STFT_TIMING
-using StftStamp = CycleStamp;
-#else
 using StftStamp = NoStamp;
-#endif
 
 constexpr int STFT_WAVES = 4;
 
@@ -83,9 +76,6 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
     const float hscale = 0.5f * g.scale;                  // the R2C split returns 2·X
 
     StftStamp st;
-#if TAC_STFT_TIMING
-    st.init();
-#endif
     // units are taken from a workgroup counter (behind the wave slots), not dealt out in fixed strides: the older of two
     // waves that share a SIMD wins the issue arbitration and would finish its share long before the other
     unsigned* const next_unit = reinterpret_cast<unsigned*>(smem + WAVES * WAVE_SLOTS);
@@ -260,11 +250,6 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
         st.mark(11);                                        // output row streamed out (store issue)
         unit = nxt_unit;
     }
-#if TAC_STFT_TIMING
-    __syncthreads();
-    if (lane == 0)
-        for (int i = 0; i < 12; ++i) ep.out[((long long)blockIdx.x * WAVES + w) * 16 + i] = st.acc[i];
-#endif
 }
 
 // ---------------------------------------------------------------- software-pipelined variant
@@ -276,9 +261,6 @@ stft_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 // (clamped duplicate lanes instead of predication) so the compiler can wait with an exact vmcnt(#stores) while
 // the stores drain behind the next frame's butterflies, and the window comes from LDS (lgkmcnt, not vmcnt).
 // (A three-waves-per-SIMD form with the twiddles in LDS measured equal, 0.163 vs 0.158 ms, and was dropped: tools/ablation/.)
-#ifndef TAC_PIPE_EARLY_REQ
-#define TAC_PIPE_EARLY_REQ 1    // 0: round 2's placement (request behind the FFT passes); 1 measured -3..7 % on the power spectrogram, rotating inputs
-#endif
 template <int NC, int E, int MODE, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64, 2)
 stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
@@ -328,9 +310,6 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
 
 
     StftStamp st;
-#if TAC_STFT_TIMING
-    st.init();
-#endif
     while (unit < end) {
         const int nxt = grab();
         st.mark(0);
@@ -353,7 +332,6 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
             load_frame<F, false>(v[0], g, nullptr, lds, urow, uframe, t);   // frames touching the padding
         }
         st.mark(8);
-#if TAC_PIPE_EARLY_REQ
         // request the next frame as soon as this one's samples have left their registers: a whole frame of cover
         __builtin_amdgcn_sched_barrier(0);
         {
@@ -361,19 +339,9 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
             if (nxt < end) pre = prefetch_frame_raw_x<F>(raw, g, nxt / T, nxt % T, t);
         }
         __builtin_amdgcn_sched_barrier(0);
-#endif
         F::template run<1, StftStamp, true>(v, ldsv, tw, t, st, t);         // lower-half spectrum stays in registers
         st.mark(9);
 
-#if !TAC_PIPE_EARLY_REQ
-        // request the next frame now: it lands while this frame is split, staged and stored
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            pre = false;
-            if (nxt < end) pre = prefetch_frame_raw_x<F>(raw, g, nxt / T, nxt % T, t);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         st.mark(1);                                         // next frame's loads issued
 
         const long long g0 = ((long long)urow * T + uframe) * LENF;
@@ -460,11 +428,6 @@ stft_pipe_kernel(FrameGeom g, Tables tb, StftEpilogue ep) {
         st.mark(11);
         unit = nxt;
     }
-#if TAC_STFT_TIMING
-    __syncthreads();
-    if (t == 0)
-        for (int i = 0; i < 12; ++i) ep.out[((long long)blockIdx.x * WAVES + w) * 16 + i] = st.acc[i];
-#endif
 }
 
 constexpr int PIPE_WAVES = 8;      // one 8-wave workgroup per CU: both waves of every SIMD draw frames from the same counter

@@ -48,11 +48,8 @@ struct Ring3Cfg {
     static constexpr int R_LDS = (LDS_MAX - TW * XA - TABLES - CTRL) / HOPB;     // hops the LDS has room for
     static constexpr int R = R_LDS < MARKS - TW - 4 ? R_LDS : MARKS - TW - 5;    // hops in the ring (bounded by the marks' ring)
     static constexpr int BYTES = R * HOPB + TW * XA + TABLES + CTRL;
-#ifndef TAC_S3_RING_PF
-#define TAC_S3_RING_PF 0
-#endif
     // hops the loader keeps in flight: as far ahead as the ring allows beyond the frames being transformed (vmcnt counts to 63)
-    static constexpr int PF = TAC_S3_RING_PF ? TAC_S3_RING_PF : (R - TW - (HPF - 1) > 24 ? 24 : R - TW - (HPF - 1));
+    static constexpr int PF = R - TW - (HPF - 1) > 24 ? 24 : R - TW - (HPF - 1);
     static constexpr int LPH = HOPB / 1024;                                  // LDS-DMA instructions (1 KB each) per hop
     static_assert(R >= TW + HPF + 2 && R < MARKS - TW - 4 && BYTES <= LDS_MAX && PF >= 1 && LPH * (PF - 1) <= 63, "ring");
 };
@@ -222,13 +219,12 @@ stft_ring3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
                 const int h = KB > 0 ? (int)f - padh + (id - b) : id - (int)(r * HR);  // hop of the row
                 const float* src = g.wave + (long long)r * g.row_stride + (long long)h * D::HOP + 4 * t;
                 unsigned char* dst = ring + (size_t)slot * D::HOPB;
-#ifndef TAC_R3_AUX
-#define TAC_R3_AUX 2       // cache policy of the hop loads: 2 = nontemporal (a hop is read once per launch — the next CU's chunk shares
-#endif                     // nothing with this one — so it need not stay in the L2 / Infinity Cache the row stores are streaming
-                           // through): -3.8 % same process against 0 (default policy), sc0 (1) +2.0 % (profiles/r05/ab/batch17)
+                // cache policy 2 = nontemporal: a hop is read once per launch — the next CU's chunk shares nothing with this one —
+                // so it need not stay in the L2 / Infinity Cache the row stores are streaming through: -3.8 % same process against
+                // the default policy, sc0 +2.0 % (profiles/r05/ab/batch17)
 #pragma unroll
                 for (int k = 0; k < D::LPH; ++k)
-                    __builtin_amdgcn_global_load_lds(src + 256 * k, (__attribute__((address_space(3))) void*)(dst + 1024 * k), 16, 0, TAC_R3_AUX);
+                    __builtin_amdgcn_global_load_lds(src + 256 * k, (__attribute__((address_space(3))) void*)(dst + 1024 * k), 16, 0, 2);
                 // the hop issued PF - 1 hops ago has landed (loads complete in order): publish it
 #pragma unroll
                 for (int k = 0; k + 1 < D::PF; ++k) fifo[k] = fifo[k + 1];
