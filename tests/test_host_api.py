@@ -374,6 +374,39 @@ try:
     raise SystemExit('out-of-order piece accepted')
 except ValueError:
     pass
+# ... and look like the first one (trailing shape, dtype, layout): a piece that does not is refused, not misplaced
+g = ChunkedAllGather(4 * world, 2)
+g.add(0, torch.zeros(2, 3))
+for bad in (torch.zeros(2, 4), torch.zeros(2, 3, dtype=torch.float64)):
+    try:
+        g.add(1, bad)
+        raise SystemExit('a piece of another layout was accepted')
+    except ValueError:
+        g._next = 1
+g.add(1, torch.zeros(2, 3))
+g.finish()
+
+
+class Counting(torch.nn.Module):            # a stateful pipeline: how often, and on how many rows, was it called?
+    def __init__(self):
+        super().__init__()
+        self.calls, self.rows = 0, 0
+
+    def forward(self, x):
+        self.calls += 1
+        self.rows += x.shape[0]
+        return x + 1.0
+
+
+# a rank never runs the pipeline on rows it does not own more than the ONE borrowed row an empty shard needs for the layout
+for rows in (1, 2, 5, 7):
+    whole = torch.arange(rows * 3, dtype=torch.float32).reshape(rows, 3)
+    own = shard_batch(whole, world, rank).shape[0]
+    for chunks in (1, 3, 8):
+        pipe = Counting()
+        got = ShardedPipeline(pipe, overlap=True, chunks=chunks)(whole)
+        assert torch.equal(got, whole + 1.0)
+        assert pipe.rows == (own if own else 1) and pipe.calls <= max(1, min(chunks, own if own else 1)), (rank, rows, chunks, pipe.calls, pipe.rows)
 # the real chain (CPU route of the ops): overlapped == serial == whole batch
 mel = torch.nn.Sequential(*tac.Melspectrogram(num_mels=8, sample_rate=8000, fft_length=64, hop_length=16), tac.AmplitudeToDb())
 wave = torch.arange(5 * 1 * 400, dtype=torch.float32).reshape(5, 1, 400).sin()

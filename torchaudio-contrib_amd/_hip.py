@@ -391,7 +391,8 @@ class MelPlan(object):
     ``launch(wave)`` then costs an allocation and one foreign call.  Valid while the window and the filterbank keep their
     stamps (checked by the caller, ``_lazy.DeferredSpectral.realize``) and the device is current."""
     __slots__ = ('fn', 'win_ptr', 'desc', 'power', 'wpack', 'dsc', 'info', 'wpack_ptr', 'dsc_ptr', 'info_ptr', 'n_mels',
-                 'db', 'ref', 'amin', 'shape', 'device', 'dev_index', 'window', 'fb', 'win_stamp', 'fb_stamp', 'layout', 'cplan')
+                 'db', 'ref', 'amin', 'shape', 'device', 'dev_index', 'window', 'fb', 'win_stamp', 'fb_stamp', 'layout', 'cplan',
+                 'last_rc')
 
     def run(self, wave):
         """``matches`` + ``launch`` in one: the result, or None when the plan does not apply (any more).  With the compiled
@@ -401,6 +402,8 @@ class MelPlan(object):
             v = c.launch(wave)
             if v is not None:
                 launches['tac_melspec_sparse_f32'] = launches.get('tac_melspec_sparse_f32', 0) + 1
+            else:
+                self.last_rc = c.last_rc
             return v
         return self.launch(wave) if self.matches(wave) else None
 
@@ -410,6 +413,7 @@ class MelPlan(object):
                      self.n_mels, self.db, self.ref, self.amin, out.data_ptr(),
                      torch._C._cuda_getCurrentRawStream(self.dev_index))
         if rc != _native.TAC_OK:
+            self.last_rc = rc
             return None                     # (the general path reports it)
         launches['tac_melspec_sparse_f32'] = launches.get('tac_melspec_sparse_f32', 0) + 1
         return out.transpose(-2, -1)
@@ -443,6 +447,7 @@ def mel_plan(wave, window, fb, n_fft, hop, win_length, center, pad_mode, normali
     p.device, p.dev_index = wave.device, wave.device.index
     p.layout = (wave.shape, wave.stride(), wave.dtype)
     p.cplan = None
+    p.last_rc = 0
     ext = _native.ext()
     if ext is not None:
         try:

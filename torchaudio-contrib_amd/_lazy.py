@@ -249,8 +249,11 @@ class DeferredSpectral(torch.Tensor):
                 return v
             if not plan.matches(s.wave):        # a different layout or new contents: the general path, then a new plan below
                 return self._replan(key, db)
-            with _hip_lock():                   # its launch was refused: remember that instead of rebuilding it on every call
-                _plans[key] = (_NO_PLAN, s.window, fb, (s.wave.shape, s.wave.stride(), s.wave.dtype))
+            from . import _native
+            if plan.last_rc in (_native.TAC_E_UNSUPPORTED, _native.TAC_E_INVALID):
+                with _hip_lock():               # refused for what the call IS: remember that instead of rebuilding the plan on every call
+                    _plans[key] = (_NO_PLAN, s.window, fb, (s.wave.shape, s.wave.stride(), s.wave.dtype))
+            # (a HIP runtime error — TAC_E_LAUNCH — may be transient: the plan stays, the general path reports this call's error)
             return self._launch(db)
         return self._replan(key, db)
 

@@ -15,6 +15,7 @@
 #include <frameobject.h>
 #include <ATen/record_function.h>
 #include <c10/hip/HIPFunctions.h>
+#include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 
 #include <atomic>
@@ -45,25 +46,32 @@ struct MelPlan {
     const void* win_ptr = nullptr;
     const void* fb_ptr = nullptr;
     int64_t epoch = 0;
-    int64_t launches = 0;
+    std::atomic<int64_t> launches{0};        // (plans are shared between threads)
+    std::atomic<int> last_rc{0};             // TAC_* code of the last refused launch (0: none)
 
+    // (the waveform's device need not be the CURRENT one: launch() switches to it for the call)
     bool matches(const at::Tensor& wave) const {
         return wave.scalar_type() == at::kFloat && wave.is_cuda() && wave.device().index() == dev && wave.sizes() == wave_sizes &&
-               wave.strides() == wave_strides && c10::hip::current_device() == dev && epoch == g_epoch.load(std::memory_order_relaxed) &&
+               wave.strides() == wave_strides && epoch == g_epoch.load(std::memory_order_relaxed) &&
                window._version() == win_version && window.data_ptr() == win_ptr && fb._version() == fb_version &&
                fb.data_ptr() == fb_ptr;
     }
 
     // the (.., n_mels, frames) view of a fresh frame-major buffer, or an undefined tensor when the plan does not apply (any more)
+    // or the launch was refused (last_rc says with which code)
     at::Tensor launch(const at::Tensor& wave) {
         if (!matches(wave)) return at::Tensor();
         RECORD_USER_SCOPE("tac_amd::melspectrogram (planned)");
+        const c10::hip::HIPGuard device_guard(dev);
         at::Tensor out = at::empty(out_shape, wave.options());
         void* stream = c10::hip::getCurrentHIPStream(dev).stream();
         const int rc = fn(wave.data_ptr<float>(), static_cast<const float*>(win_ptr), desc.data(), power, wpack.data_ptr<float>(),
                           dsc.data_ptr<int32_t>(), info.data(), n_mels, db, ref, amin, out.data_ptr<float>(), stream);
-        if (rc != 0) return at::Tensor();
-        ++launches;
+        if (rc != 0) {
+            last_rc.store(rc, std::memory_order_relaxed);
+            return at::Tensor();
+        }
+        launches.fetch_add(1, std::memory_order_relaxed);
         return out.transpose(-2, -1);
     }
 };
@@ -73,6 +81,11 @@ std::vector<std::shared_ptr<MelPlan>> g_plans;      // ids handed to the dispatc
 
 int64_t register_plan(const std::shared_ptr<MelPlan>& p) {
     std::lock_guard<std::mutex> lock(g_mutex);
+    for (size_t i = 0; i < g_plans.size(); ++i)      // an id drop_plan freed is handed out again: the table does not grow with time
+        if (!g_plans[i]) {
+            g_plans[i] = p;
+            return (int64_t)i;
+        }
     g_plans.push_back(p);
     return (int64_t)g_plans.size() - 1;
 }
@@ -207,7 +220,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         })
         .def("matches", &MelPlan::matches)
         .def("register", [](std::shared_ptr<MelPlan> p) { return register_plan(p); })
-        .def_readonly("launches", &MelPlan::launches)
+        .def_property_readonly("launches", [](const MelPlan& p) { return p.launches.load(); })
+        .def_property_readonly("last_rc", [](const MelPlan& p) { return p.last_rc.load(); })
         .def_property_readonly("window", [](const MelPlan& p) { return p.window; })
         .def_property_readonly("fb", [](const MelPlan& p) { return p.fb; });
 }

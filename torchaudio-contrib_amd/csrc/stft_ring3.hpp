@@ -24,7 +24,7 @@
 //     frame of the chunk not yet consumed (it scans the per-frame marks in order); it never runs more than R hops ahead of B(c),
 //     which is also what bounds the marks' ring.
 // The first unconsumed frame can always get its hops (R >= 4 + waves in flight), so the protocol cannot deadlock; waits are
-// bounded anyway.  Shipped for every row mode (complex, |X|^2, |X|, dB): same process against stft_stream3_kernel complex rows
+// bounded anyway, and a bound that expires traps (ring3_wait).  Shipped for every row mode (complex, |X|^2, |X|, dB): same process against stft_stream3_kernel complex rows
 // -6 ... -9 % and a further -3.8 % from the nontemporal hop loads, real rows -8.3 % (12 + 1 waves with the ring against 16 without),
 // bit-identical (profiles/r05/ab/batch14, batch17, batch19).
 // Replaces torch.stft (reference functional.py:99-107) [+ complex_norm (functional.py:126-128)] [+ amplitude_to_db (291-296)].
@@ -54,15 +54,19 @@ struct Ring3Cfg {
     static_assert(R >= TW + HPF + 2 && R < MARKS - TW - 4 && BYTES <= LDS_MAX && PF >= 1 && LPH * (PF - 1) <= 63, "ring");
 };
 
-// word >= want (wrap-safe), polled by the whole wave; bounded
+// word >= want (wrap-safe), polled by the whole wave.  Bounded — ~0.1 s at full clock, far beyond anything a profiler or a throttled
+// clock stretches a hop load to —, and a bound that expires is a protocol failure: the wave TRAPS (the launch fails, the host sees
+// hipErrorLaunchFailure at its next synchronisation) instead of going on with a ring it may not read — garbage rows with no error
+// code are not an outcome.
 __device__ __forceinline__ void ring3_wait(unsigned addr, unsigned want) {
-    for (int guard = 0; guard < (1 << 17); ++guard) {
+    for (int guard = 0; guard < (1 << 20); ++guard) {
         unsigned v;
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
         v = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
-        if ((int)(v - want) >= 0) break;
+        if ((int)(v - want) >= 0) return;
         __builtin_amdgcn_s_sleep(1);
     }
+    __builtin_trap();
 }
 
 // MODE as in stft_stream3_kernel.  Launch conditions (host): hop == fft_length / 4, center_pad a multiple of the hop, 16-byte
@@ -211,9 +215,10 @@ stft_ring3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
                         const unsigned lv = (unsigned)fifo[D::PF - 1] + 1u;
                         asm volatile("ds_write_b32 %0, %1" :: "v"(loaded_addr), "v"(lv) : "memory");
                     }
-                    for (int guard = 0; id - R >= bc && guard < (1 << 17); ++guard) {
+                    for (int guard = 0; id - R >= bc && guard < (1 << 20); ++guard) {
                         if (!advance()) __builtin_amdgcn_s_sleep(2);
                     }
+                    if (id - R >= bc) __builtin_trap();    // (a slot somebody still needs is never overwritten: see ring3_wait)
                 }
                 const unsigned slot = (unsigned)id % (unsigned)R;
                 const int h = KB > 0 ? (int)f - padh + (id - b) : id - (int)(r * HR);  // hop of the row

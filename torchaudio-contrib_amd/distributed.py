@@ -204,6 +204,13 @@ class ChunkedAllGather(object):
         phys, transposed = _physical(realize(local))
         if self.out is None:
             self._setup(phys, transposed)
+        elif tuple(phys.shape[1:]) != tuple(self.out.shape[1:]) or phys.dtype != self.out.dtype or transposed != self.transposed \
+                or phys.device != self.out.device:
+            # (the first piece fixed the gathered tensor's trailing shape, dtype and layout: a later piece that differs would be
+            # placed wrongly without a word)
+            raise ValueError('piece %d has trailing shape %r, dtype %s, transposed=%r on %s; the first piece had %r, %s, %r on %s'
+                             % (k, tuple(phys.shape[1:]), phys.dtype, transposed, phys.device, tuple(self.out.shape[1:]),
+                                self.out.dtype, self.transposed, self.out.device))
         lb, le = self.local_rows(k)
         if phys.shape[0] != le - lb:
             raise ValueError('piece %d of rank %d has %d rows, expected %d' % (k, self.rank, phys.shape[0], le - lb))
@@ -310,11 +317,18 @@ class ShardedPipeline(torch.nn.Module):
     def _forward_overlapped(self, whole_batch, world, rank):
         shard = shard_batch(whole_batch, world, rank)
         g = ChunkedAllGather(whole_batch.shape[0], self.chunks, group=self.group, method=self.method, force_collective=self.force_collective)
+        from ._lazy import realize
+        last = None
         for k in range(g.chunks):
             lb, le = g.local_rows(k)
             if le > lb:
-                piece = self.pipeline(shard[lb:le])
-            else:       # a short (or empty) shard has nothing in this piece: zero rows of the right layout
-                piece = self.pipeline(whole_batch[:1])[:0]
+                piece = last = realize(self.pipeline(shard[lb:le]))
+            elif last is not None:
+                # a short shard has nothing in this piece: zero rows laid out like the pieces before (no further pipeline call — a
+                # stateful module must not see rows this rank does not own, nor more calls than the rows it owns explain)
+                piece = last[:0]
+            else:
+                # an EMPTY shard has no piece to take the layout from: ONE call on a borrowed row, its zero rows reused for every piece
+                piece = last = realize(self.pipeline(whole_batch[:1]))[:0]
             g.add(k, piece)
         return g.finish()
