@@ -56,9 +56,10 @@ typedef struct tac_stft_desc {
     int64_t rows;        /* batch*channel                                              */
     int64_t length;      /* samples per row (L)                                        */
     int64_t row_stride;  /* elements between consecutive rows of `wave`                */
-    int32_t n_fft;       /* power of two, 32..4096; or 400 (STFT / spectrogram, one-sided); 8192 / 16384 / 32768, and any even length
-                            <= 8192 whose half is 7-smooth (480, 882, 960, 1200, 1920 ...): the forward STFT / spectrogram rows only
-                            (tac_stft_f32, tac_spectrogram_f32: stft_big.hip / stft_smooth.hip) */
+    int32_t n_fft;       /* power of two, 32..4096; or 400 (STFT / spectrogram, one-sided); any even length <= 8192 whose half is
+                            7-smooth (480, 882, 960, 1200, 1920 ...) and 8192: the STFT / spectrogram rows AND their gradient
+                            (tac_stft_f32, tac_spectrogram_f32, tac_stft_backward_f32: stft_smooth.hip); 16384 / 32768: the forward
+                            rows only (stft_big.hip) */
     int32_t hop;         /* > 0                                                        */
     int32_t win_length;  /* 1..n_fft; window is zero-padded centred to n_fft           */
     int32_t center;      /* 1: pad n_fft/2 both sides with pad_mode                    */
@@ -335,7 +336,9 @@ int tac_amplitude_to_db_backward_f32(const float* x, const float* grad_out, int6
  *      reflect padding (needs kernel/2 < size: TAC_E_SHORT_INPUT otherwise); masks soft ((h+eps)/(h+p+eps), eps 1e-6) or
  *      hard (1.0 / 0.0); harm / perc may both be NULL (masks only).  The outputs must not overlap mag or one another
  *      (the two-launch route parks the first launch's medians in mask_perc): overlapping address ranges are
- *      refused with TAC_E_INVALID. */
+ *      refused with TAC_E_INVALID.  The test is conservative: it compares the whole address SPANS of the five tensors (first to last
+ *      element touched), so interleaved outputs that never share an element — channel slices of one stacked buffer — are refused
+ *      as well, and it is skipped when a stride is negative. */
 int tac_hpss_f32(const float* mag, int64_t rows, int32_t n_freqs, int32_t n_frames, int64_t stride_r,
                  int64_t stride_f, int64_t stride_t, int32_t kernel_f, int32_t kernel_t, float power,
                  int hard, float* harm, float* perc, float* mask_harm, float* mask_perc, void* stream);

@@ -161,8 +161,8 @@ def big_fft_size(n_fft):
 
 def smooth_fft_size(n_fft):
     """even fft_length <= 8192 (not a power of two, not 400) whose half is 7-smooth — 480, 960, 1200, 1920, 882 ...: generic
-    Stockham passes of radix 4 / 2 / 3 / 5 / 7 (csrc/stft_smooth.hip, round 5) for the forward stft / spectrogram rows; their
-    gradients keep the DFT-matrix adjoint.  Mirrors ``stft_smooth_covers`` of the library."""
+    Stockham passes of radix 4 / 2 / 3 / 5 / 7 (csrc/stft_smooth.hip, round 5) for the forward stft / spectrogram rows AND their
+    gradients (``stft_smooth_backward_kernel`` behind ``tac_stft_backward_f32``: the same passes on conjugated data; 8192 as well).  Mirrors ``stft_smooth_covers`` of the library."""
     if n_fft < 8 or n_fft % 2 or n_fft > 8192 or n_fft & (n_fft - 1) == 0 or n_fft == 400:
         return False
     m = n_fft // 2
