@@ -131,7 +131,7 @@ def bound_from_counters(roof, route, clock_mhz):
     are properties of the kernel binary and the workload, the clock is measured live).  The entry must carry the name of
     the kernel the library just launched; otherwise the fields stay null and say why."""
     entry, source = None, None
-    for rnd in ('r05', 'r04', 'r03'):
+    for rnd in ('r06', 'r05', 'r04', 'r03'):
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', rnd, 'pmc_mel.json')))
         except Exception:            # noqa: BLE001

@@ -55,18 +55,20 @@ struct Ring3Cfg {
 };
 
 // word >= want (wrap-safe), polled by the whole wave.  Bounded — ~0.1 s at full clock, far beyond anything a profiler or a throttled
-// clock stretches a hop load to —, and a bound that expires is a protocol failure: the wave TRAPS (the launch fails, the host sees
-// hipErrorLaunchFailure at its next synchronisation) instead of going on with a ring it may not read — garbage rows with no error
-// code are not an outcome.
+// clock stretches a hop load to —, and a bound that expires is a protocol failure: the wave TRAPS (s_trap 2, what llvm.trap lowers
+// to: the queue goes into its error state, the host sees hipErrorLaunchFailure at its next synchronisation) instead of going on
+// with a ring it may not read — garbage rows with no error code are not an outcome.  (As inline assembly: __builtin_trap() is
+// noreturn, and the changed control flow cost this register-tight kernel 8 % on the |X|^2 rows — profiles/r06/ab/batch7.)
 __device__ __forceinline__ void ring3_wait(unsigned addr, unsigned want) {
+    bool ok = false;
     for (int guard = 0; guard < (1 << 20); ++guard) {
         unsigned v;
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
         v = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
-        if ((int)(v - want) >= 0) return;
+        if ((int)(v - want) >= 0) { ok = true; break; }
         __builtin_amdgcn_s_sleep(1);
     }
-    __builtin_trap();
+    if (!ok) asm volatile("s_trap 2");
 }
 
 // MODE as in stft_stream3_kernel.  Launch conditions (host): hop == fft_length / 4, center_pad a multiple of the hop, 16-byte
@@ -218,7 +220,7 @@ stft_ring3_kernel(FrameGeom g, Tables tb, StftEpilogue ep, Stream3Launch lp) {
                     for (int guard = 0; id - R >= bc && guard < (1 << 20); ++guard) {
                         if (!advance()) __builtin_amdgcn_s_sleep(2);
                     }
-                    if (id - R >= bc) __builtin_trap();    // (a slot somebody still needs is never overwritten: see ring3_wait)
+                    if (id - R >= bc) asm volatile("s_trap 2");    // (a slot somebody still needs is never overwritten: see ring3_wait)
                 }
                 const unsigned slot = (unsigned)id % (unsigned)R;
                 const int h = KB > 0 ? (int)f - padh + (id - b) : id - (int)(r * HR);  // hop of the row
