@@ -1798,23 +1798,28 @@ def test_hpss_mask_only_skips_the_masked_spectrograms(tac):
 
 
 def test_g10_melspectrogram_fft_length_4096(tac, golden):
-    """Melspectrogram (-> AmplitudeToDb) at fft_length 4096 against the reference's outputs (golden g10): no fully fused
-    kernel fits the LDS at this size (two 1024-point exchange areas per wave + 41 KB of weights), so the chain is TWO
-    launches — the 4096-point spectrogram kernel and the band-sparse streaming filterbank kernel with the dB epilogue
-    riding on it (round 2: three, with the dense MFMA GEMM in the middle).  Also the standalone apply_filterbank on
-    2049-bin rows, dB off."""
+    """Melspectrogram (-> AmplitudeToDb) at fft_length 4096 against the reference's outputs (golden g10): ONE launch since
+    round 6 — the twelve-wave form of the 4096 kernel runs both 1024-point transforms through one exchange area, which leaves
+    the LDS for the bank's 42 KB of weights beside eleven waves (rounds 2 - 5: two launches, the |X|^p rows crossing HBM).  A
+    spectrogram the caller made first still takes the standalone band-sparse filterbank kernel on 2049-bin rows."""
     g = golden('g10_mel4096')
     x = dev(signals.audio_like((2, 2, 30000), seed=71))
     mel = tac.Melspectrogram(num_mels=128, sample_rate=44100, fft_length=4096, hop_length=1024).cuda()
     before = launches(tac)
     got = tac.realize(mel(x))
-    assert launched_since(tac, before) == {'tac_spectrogram_f32': 1, 'tac_apply_filterbank_sparse_f32': 1}
+    assert launched_since(tac, before) == {'tac_melspec_sparse_f32': 1}
     assert rel_err(host(got), g['mel']) < 1e-5
     chain = torch.nn.Sequential(*mel, tac.AmplitudeToDb()).cuda()
     before = launches(tac)
     got_db = chain(x)
-    assert launched_since(tac, before) == {'tac_spectrogram_f32': 1, 'tac_apply_filterbank_sparse_db_f32': 1}
+    assert launched_since(tac, before) == {'tac_melspec_sparse_f32': 1}
     assert np.abs(host(got_db) - g['mel_db']).max() < DB_ABS
+    # the unfused pieces: the spectrogram rows, then the standalone filterbank kernel (with and without the dB epilogue)
+    spec = tac.realize(tac.Spectrogram(4096, hop_length=1024, power=2.0).cuda()(x))
+    before = launches(tac)
+    got2 = tac.apply_filterbank(spec, mel[-1].filterbank)
+    assert launched_since(tac, before) == {'tac_apply_filterbank_sparse_f32': 1}
+    assert rel_err(host(got2), g['mel']) < 1e-5
     mel80 = tac.Melspectrogram(num_mels=80, sample_rate=48000, fft_length=4096, hop_length=1024, htk=True, min_freq=50.0).cuda()
     assert rel_err(host(tac.realize(mel80(x))), g['mel80_htk']) < 1e-5
     # a longer input: more frames than waves, rows of different phase

@@ -370,7 +370,7 @@ def _filterbank_plan(fb):
 def _fused_mel_route(g, fb, power):
     """'sparse' / 'mfma' when one fused kernel covers this geometry + filterbank, else None (then the caller chains
     the spectrogram, filterbank and dB kernels)."""
-    if not ((g.pow2_kernel or g.mixed_radix) and g.onesided and g.n_fft <= 2048 and fb.dim() == 2 and
+    if not ((g.pow2_kernel or g.mixed_radix) and g.onesided and g.n_fft <= 4096 and fb.dim() == 2 and
             fb.shape[0] == g.n_bins and 0 < fb.shape[1] <= 512 and fb.is_contiguous()):
         return None
     if g.mixed_radix:       # fft_length 400: only the band-sparse form has a fused kernel
@@ -378,7 +378,7 @@ def _fused_mel_route(g, fb, power):
         return 'sparse' if ok else None
     if power in (1.0, 2.0) and MEL_PATH != 'mfma' and _melbank_pack(fb, g.n_fft) is not None:
         return 'sparse'
-    if MEL_PATH == 'sparse':
+    if MEL_PATH == 'sparse' or g.n_fft > 2048:      # (fft_length 4096: only the band-sparse form has a fused kernel)
         return None
     _, host = _filterbank_plan(fb)
     rc = _native.lib().tac_melspec_supported(g.desc, float(power), ctypes.cast(host, ctypes.c_void_p), fb.shape[1])

@@ -43,6 +43,11 @@ int launch_small_mel_entry(int n_fft, const FrameGeom& g, const Tables& tb, floa
                            hipStream_t stream, int fmt = FMT_F32, const void* samples = nullptr, const float* lut = nullptr);
 int pack_small(int n_fft, const std::vector<float>& h, int n_freqs, int n_mels, float* wpack, int wpack_cap, int32_t* desc,
                int desc_cap, int32_t* info_host, hipStream_t stream);
+// stft_n4096.hip: fft_length 4096 (the twelve-wave form of its real-valued rows + the contraction, stft_n4096_s3.hpp)
+int launch_n4096_mel(const FrameGeom& g, float power, const float* wpack, const int32_t* desc, const int32_t* info_host, int n_mels,
+                     int db, float amin, float log10_ref, float* out, hipStream_t stream);
+int pack_n4096_mel(const std::vector<float>& h, int n_freqs, int n_mels, float* wpack, int wpack_cap, int32_t* desc, int desc_cap,
+                   int32_t* info_host, hipStream_t stream);
 
 constexpr int SP_TILE = 16;
 constexpr int SP_MAX_W = 3072;               // floats of packed weights that may live in LDS (12 KB)
@@ -322,6 +327,7 @@ static int sparse_groups_for(int n_fft) {
         case 1024: return sparse_groups<512, 16>();
         case 2048: return 64;                                                // one band per lane and slot (melspec_stream.hpp)
         case 400: return LM_MARK + 8;                                        // eight lanes per frame (stft_n400.hip, mel_lanes.hpp)
+        case 4096: return LM_MARK + 4096;                                    // == N4M_MARK (stft_n4096_s3.hpp)
         default: return 0;
     }
 }
@@ -710,6 +716,8 @@ int tac_melbank_pack(const float* fb, int32_t n_freqs, int32_t n_mels, int32_t n
     TAC_HIP(hipStreamSynchronize((hipStream_t)stream));
     if (n_fft == 2048)
         return pack_lanes(h, n_freqs, n_mels, wpack, wpack_cap, desc, desc_cap, info_host, (hipStream_t)stream);
+    if (n_fft == 4096)                                                      // the one-launch chain of stft_n4096_s3.hpp
+        return pack_n4096_mel(h, n_freqs, n_mels, wpack, wpack_cap, desc, desc_cap, info_host, (hipStream_t)stream);
     if (n_fft == 0 && n_freqs >= 8 && (n_freqs + 3) / 4 <= FBL_CHUNKS_WIDE * 64) {   // standalone: one frame per wave
         const int rc = pack_lane_mel(h, n_freqs, n_mels, 64, fbl_pitch(n_freqs), 2, fbl_fly(n_freqs), LM_MAX_STEPS_WAVE, fbl_base_lds(n_freqs),
                                      wpack, wpack_cap, desc, desc_cap, info_host, (hipStream_t)stream);
@@ -779,8 +787,16 @@ int tac_melspec_sparse_f32(const float* wave, const float* window, const tac_stf
                            int db, float db_ref, float db_amin, float* out, void* stream) {
     using namespace tac;
     if (!wpack || !desc || !info_host || !out || !d || n_mels <= 0) return TAC_E_INVALID;
-    if (!d->onesided || d->n_fft > 2048) return TAC_E_UNSUPPORTED;
+    if (!d->onesided || d->n_fft > 4096) return TAC_E_UNSUPPORTED;
     if (power != 2.0f && power != 1.0f) return TAC_E_UNSUPPORTED;
+    if (d->n_fft == 4096) {                                                         // stft_n4096.hip: the twelve-wave form + contraction
+        FrameGeom g4;
+        int64_t T4 = 0;
+        const int rc4 = make_geometry(wave, window, d, &g4, &T4);
+        if (rc4 != TAC_OK) return rc4;
+        return launch_n4096_mel(g4, power, wpack, desc, info_host, n_mels, db ? 1 : 0, db_amin, db ? log10f(db_ref) : 0.0f, out,
+                                (hipStream_t)stream);
+    }
     const bool lanes_pack = info_host[2] >= LM_MARK;                               // mel_lanes.hpp layout
     if (!lanes_pack && info_host[2] != sparse_groups_for(d->n_fft)) return TAC_E_INVALID;   // pack built for another geometry
     FrameGeom g;

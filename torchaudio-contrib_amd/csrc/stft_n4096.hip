@@ -17,6 +17,9 @@
 // two 3-wave workgroups left two SIMDs with a single wave), frames drawn from a workgroup counter.
 #include "host_common.hpp"
 
+#include <algorithm>
+#include <vector>
+
 namespace tac {
 
 constexpr int N4K_WAVES = 8;
@@ -264,6 +267,116 @@ stft_n4096_kernel(FrameGeom g, Tables tb1k, Tables tb4k, StftEpilogue ep) {
     }
 }
 
+}  // namespace tac
+
+#include "stft_n4096_s3.hpp"
+
+namespace tac {
+
+template <int MODE, int WAVES, bool MEL>
+static int launch_n4096_s3(const FrameGeom& g, const Tables& tb2k, const Tables& tb4k, const StftEpilogue& ep, const N4Mel& mel,
+                           hipStream_t stream) {
+    const long long units = g.rows * g.n_frames;
+    if (units >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
+    const size_t bytes = n4096_s3_lds_bytes(WAVES) + (MEL ? n4096_mel_lds_bytes(mel.nslot, mel.wtot) : 0);
+    if (bytes > 160 * 1024) return TAC_E_UNSUPPORTED;
+    long long blocks = (units + WAVES - 1) / WAVES;
+    const long long cap = (long long)device_cu_count();      // one workgroup per CU
+    if (blocks > cap) blocks = cap;
+    auto kern = stft_n4096_s3_kernel<MODE, WAVES, MEL>;
+    TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), bytes, stream, g, tb2k, tb4k, ep, mel);
+    TAC_HIP(hipGetLastError());
+    return TAC_OK;
+}
+
+// ---- the filterbank table of the fused form (tac_melbank_pack, n_fft == 4096): lane l owns bands l, 64 + l, ...; slot s runs the
+// step PAIRS of its widest band; a band's run starts at a multiple of four bins, shifted down (zero weights in front) where the padded
+// run would leave the row and its three zeroed slack floats.  info: [0] floats of weights, [1] slots, [2] N4M_MARK, [3] steps,
+// [4] waves per workgroup the table leaves room for.
+int pack_n4096_mel(const std::vector<float>& h, int n_freqs, int n_mels, float* wpack, int wpack_cap, int32_t* desc, int desc_cap,
+                   int32_t* info_host, hipStream_t stream) {
+    constexpr int LIMIT = 2049 + 3;
+    const int nslot = (n_mels + 63) / 64;
+    if (n_freqs != 2049 || n_mels < 1 || nslot > N4M_MAX_SLOTS || 64 * nslot + N4M_MAX_SLOTS > desc_cap) return TAC_E_UNSUPPORTED;
+    std::vector<int> lo(64 * nslot, 0), hi(64 * nslot, 0), first(64 * nslot, 0), pairs(N4M_MAX_SLOTS, 1);
+    for (int m = 0; m < n_mels; ++m) {
+        int l0 = n_freqs, h0 = 0;
+        for (int f = 0; f < n_freqs; ++f)
+            if (h[(size_t)f * n_mels + m] != 0.0f) { l0 = f < l0 ? f : l0; h0 = f + 1; }
+        if (h0 > l0) {
+            lo[m] = l0;
+            hi[m] = h0;
+            first[m] = l0 & ~3;
+            pairs[m / 64] = std::max(pairs[m / 64], (h0 - first[m] + 7) / 8);
+        }
+    }
+    int steps = 0;
+    for (int s = 0; s < nslot; ++s) {
+        if (8 * pairs[s] > LIMIT) return TAC_E_UNSUPPORTED;
+        steps += 2 * pairs[s];
+    }
+    const long long wtot = 256LL * steps;
+    int waves = 0;
+    for (int wv : {12, 11, 10, 8})
+        if (!waves && n4096_s3_lds_bytes(wv) + n4096_mel_lds_bytes(nslot, (int)wtot) <= 160 * 1024) waves = wv;
+    if (!waves || wtot > wpack_cap) return TAC_E_UNSUPPORTED;               // not band-sparse enough: the two-launch chain
+    std::vector<float> wp((size_t)wtot, 0.0f);
+    std::vector<int32_t> dd((size_t)64 * nslot + N4M_MAX_SLOTS, 0);
+    int base = 0;
+    for (int s = 0; s < nslot; ++s) {
+        for (int l = 0; l < 64; ++l) {
+            const int m = 64 * s + l;
+            int f0 = first[m];
+            if (f0 + 8 * pairs[s] > LIMIT) f0 = (LIMIT - 8 * pairs[s]) & ~3;
+            for (int j = 0; j < 2 * pairs[s]; ++j)
+                for (int u = 0; u < 4; ++u) {
+                    const int bin = f0 + 4 * j + u;
+                    const bool live = m < n_mels && bin >= lo[m] && bin < hi[m];
+                    wp[((size_t)(base + j) * 64 + l) * 4 + u] = live ? h[(size_t)bin * n_mels + m] : 0.0f;
+                }
+            dd[64 * s + l] = f0;
+        }
+        dd[(size_t)64 * nslot + s] = pairs[s];
+        base += 2 * pairs[s];
+    }
+    TAC_HIP(hipMemcpyAsync(wpack, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+    TAC_HIP(hipMemcpyAsync(desc, dd.data(), dd.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    TAC_HIP(hipStreamSynchronize(stream));
+    info_host[0] = (int32_t)wtot;
+    info_host[1] = nslot;
+    info_host[2] = N4M_MARK;
+    info_host[3] = steps;
+    info_host[4] = waves;
+    for (int i = 5; i < 8; ++i) info_host[i] = 0;
+    return TAC_OK;
+}
+
+// Melspectrogram (-> AmplitudeToDb) at fft_length 4096 in one launch (tac_melspec_sparse_f32): TAC_E_UNSUPPORTED for the geometries
+// the twelve-wave form declines (two-sided output, frames that are not 16-byte aligned, rows shorter than one frame)
+int launch_n4096_mel(const FrameGeom& g, float power, const float* wpack, const int32_t* desc, const int32_t* info_host, int n_mels,
+                     int db, float amin, float log10_ref, float* out, hipStream_t stream) {
+    if (info_host[2] != N4M_MARK || info_host[1] < 1 || info_host[1] > N4M_MAX_SLOTS || info_host[0] != 256 * info_host[3] ||
+        n_mels > 64 * info_host[1])
+        return TAC_E_INVALID;
+    if (!g.vec4_ok || g.length < 4096 || (power != 1.0f && power != 2.0f)) return TAC_E_UNSUPPORTED;
+    Tables tb2k, tb4k;
+    int rc = get_tables(2048, &tb2k);
+    if (rc != TAC_OK) return rc;
+    rc = get_tables(4096, &tb4k);
+    if (rc != TAC_OK) return rc;
+    const StftEpilogue ep{nullptr, 1, 1, power, 0, 0.0f, 0.0f};
+    const N4Mel mel{wpack, desc, info_host[1], info_host[0], n_mels, db, amin, log10_ref, out};
+    const bool p2 = power == 2.0f;
+    switch (info_host[4]) {
+        case 12: return p2 ? launch_n4096_s3<1, 12, true>(g, tb2k, tb4k, ep, mel, stream) : launch_n4096_s3<2, 12, true>(g, tb2k, tb4k, ep, mel, stream);
+        case 11: return p2 ? launch_n4096_s3<1, 11, true>(g, tb2k, tb4k, ep, mel, stream) : launch_n4096_s3<2, 11, true>(g, tb2k, tb4k, ep, mel, stream);
+        case 10: return p2 ? launch_n4096_s3<1, 10, true>(g, tb2k, tb4k, ep, mel, stream) : launch_n4096_s3<2, 10, true>(g, tb2k, tb4k, ep, mel, stream);
+        case 8: return p2 ? launch_n4096_s3<1, 8, true>(g, tb2k, tb4k, ep, mel, stream) : launch_n4096_s3<2, 8, true>(g, tb2k, tb4k, ep, mel, stream);
+        default: return TAC_E_INVALID;
+    }
+}
+
 template <int MODE>
 static int launch_n4096(const FrameGeom& g, const Tables& tb1k, const Tables& tb4k, const StftEpilogue& ep,
                         hipStream_t stream) {
@@ -296,6 +409,15 @@ int try_launch_n4096(const FrameGeom& g, const StftEpilogue& ep, int mode, hipSt
     if (rc != TAC_OK) return rc;
     rc = get_tables(4096, &tb4k);
     if (rc != TAC_OK) return rc;
+    if (pmode >= 1 && g.length >= 4096) {       // real-valued rows: the twelve-wave form (stft_n4096_s3.hpp)
+        const N4Mel none{};
+        switch (pmode) {
+            case 1: return launch_n4096_s3<1, 12, false>(g, tb1k, tb4k, ep, none, stream);
+            case 2: return launch_n4096_s3<2, 12, false>(g, tb1k, tb4k, ep, none, stream);
+            case 3: return launch_n4096_s3<3, 12, false>(g, tb1k, tb4k, ep, none, stream);
+            default: return launch_n4096_s3<4, 12, false>(g, tb1k, tb4k, ep, none, stream);
+        }
+    }
     switch (pmode) {
         case 0: return launch_n4096<0>(g, tb1k, tb4k, ep, stream);
         case 1: return launch_n4096<1>(g, tb1k, tb4k, ep, stream);
