@@ -47,6 +47,12 @@ elif what == 'spec4096':
     x4 = torch.rand(8, 8, 480000, device='cuda') * 2 - 1
     m = tac.Spectrogram(4096, 1024).cuda()
     fn = lambda: m(x4)
+elif what == 'mel4096':
+    # the one-launch chain at fft_length 4096 (44.1 kHz bank, 128 bands + dB) on the cfg-4 slice
+    x4 = torch.rand(8, 8, 480000, device='cuda') * 2 - 1
+    m = torch.nn.Sequential(*tac.Melspectrogram(num_mels=128, sample_rate=44100, fft_length=4096, hop_length=1024),
+                            tac.AmplitudeToDb()).cuda()
+    fn = lambda: m(x4)
 elif what == 'gradspec':
     # training step through the Spectrogram layer (power 2): fused forward kernel, one backward kernel + border fold
     m = tac.Spectrogram(2048, 512, power=2.).cuda()

@@ -28,6 +28,7 @@
 #include "melspec_stream3.hpp"
 #include "melspec_mfma.hpp"
 #include "mel_pieces.hpp"
+#include "lane_placement.hpp"
 
 namespace tac {
 
@@ -597,64 +598,8 @@ static int pack_lanes(const std::vector<float>& h, int n_freqs, int n_mels, floa
     const long long wtot = 256LL * total_steps;
     if (wtot > wpack_cap || stream_lds_bytes<1024, 16>((int)wtot) > 160 * 1024) return TAC_E_UNSUPPORTED;
     std::vector<float> wp((size_t)wtot, 0.0f);
-    // Bank-aware placement: a slot runs more steps than most of its bands need, so a band's run may start up to that
-    // many quads earlier (zero weights in front).  The LDS serves a wave's 16-byte reads in four fixed groups of sixteen
-    // lanes, one cycle per group when the sixteen quads fall into sixteen different bank groups ((byte / 16) mod 16;
-    // equal addresses are one broadcast): within every such group the starts are chosen by bipartite matching (lane ->
-    // residue, each lane's candidates being its slack window) with the smallest possible load per residue.  A wave's
-    // conflict pattern is the same for every step of a slot, since all its lanes advance by one quad per step.
-    // (Measured on the standard 128-band bank at 2048: 144 -> 84 LDS cycles per frame for the row reads, ideal 72.)
-    std::vector<int> start(lo);
-    {
-        static const int kGroup[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
-                                          {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
-        for (int s = 0; s < nslot; ++s)
-            for (int gi = 0; gi < 4; ++gi) {
-                int lanes[16];
-                for (int i = 0; i < 16; ++i) lanes[i] = kGroup[gi & 1][i] + 32 * (gi >> 1);
-                std::vector<int> cand[16];
-                for (int i = 0; i < 16; ++i) {
-                    const int m = s * 64 + lanes[i];
-                    const int slack = std::max(0, std::min(steps[s] - (len[m] + 3) / 4, lo[m] / 4));
-                    for (int d = 0; d <= slack; ++d) cand[i].push_back(lo[m] - 4 * d);
-                }
-                for (int cap = 1; cap <= 16; ++cap) {
-                    std::vector<int> load[16];                               // lanes (indices into `lanes`) per residue
-                    int choice[16];
-                    // Kuhn's augmenting search with residue capacities: ONE visited set per top-level lane, shared by the whole
-                    // recursion (a residue that could not be freed once in this search cannot be freed later in it either), so
-                    // an infeasible cap is refused in O(lanes x candidates) instead of exploring every eviction order
-                    unsigned seen = 0;
-                    std::function<bool(int)> place = [&](int i) -> bool {
-                        for (int c : cand[i]) {
-                            const int r = (c / 4) & 15;
-                            if (seen & (1u << r)) continue;
-                            seen |= 1u << r;
-                            if ((int)load[r].size() < cap) { load[r].push_back(i); choice[i] = c; return true; }
-                            for (size_t q = 0; q < load[r].size(); ++q) {
-                                const int other = load[r][q];
-                                if (place(other)) {                       // `other` moved to another residue: its seat here goes to i
-                                    load[r].erase(std::find(load[r].begin(), load[r].end(), other));
-                                    load[r].push_back(i);
-                                    choice[i] = c;
-                                    return true;
-                                }
-                            }
-                        }
-                        return false;
-                    };
-                    bool ok = true;
-                    for (int i = 0; i < 16 && ok; ++i) {
-                        seen = 0;
-                        ok = place(i);
-                    }
-                    if (ok) {
-                        for (int i = 0; i < 16; ++i) start[s * 64 + lanes[i]] = choice[i];
-                        break;
-                    }
-                }
-            }
-    }
+    // bank-aware placement of the runs' first bins (lane_placement.hpp)
+    const std::vector<int> start = place_band_starts(nslot, steps, lo, len);
     int base = 0;
     for (int s = 0; s < nslot; ++s) {
         for (int l = 0; l < 64; ++l) {

@@ -16,6 +16,7 @@
 // recipe.  Two frame buffers per wave: one 8-wave workgroup per CU (157 KB of LDS with the shared window table; round 1's
 // two 3-wave workgroups left two SIMDs with a single wave), frames drawn from a workgroup counter.
 #include "host_common.hpp"
+#include "lane_placement.hpp"
 
 #include <algorithm>
 #include <vector>
@@ -299,7 +300,7 @@ int pack_n4096_mel(const std::vector<float>& h, int n_freqs, int n_mels, float* 
     constexpr int LIMIT = 2049 + 3;
     const int nslot = (n_mels + 63) / 64;
     if (n_freqs != 2049 || n_mels < 1 || nslot > N4M_MAX_SLOTS || 64 * nslot + N4M_MAX_SLOTS > desc_cap) return TAC_E_UNSUPPORTED;
-    std::vector<int> lo(64 * nslot, 0), hi(64 * nslot, 0), first(64 * nslot, 0), pairs(N4M_MAX_SLOTS, 1);
+    std::vector<int> lo(64 * nslot, 0), hi(64 * nslot, 0), first(64 * nslot, 0), len(64 * nslot, 0), pairs(N4M_MAX_SLOTS, 1);
     for (int m = 0; m < n_mels; ++m) {
         int l0 = n_freqs, h0 = 0;
         for (int f = 0; f < n_freqs; ++f)
@@ -308,14 +309,17 @@ int pack_n4096_mel(const std::vector<float>& h, int n_freqs, int n_mels, float* 
             lo[m] = l0;
             hi[m] = h0;
             first[m] = l0 & ~3;
+            len[m] = h0 - first[m];
             pairs[m / 64] = std::max(pairs[m / 64], (h0 - first[m] + 7) / 8);
         }
     }
-    int steps = 0;
+    int steps = 0, slot_steps[N4M_MAX_SLOTS] = {0, 0, 0, 0};
     for (int s = 0; s < nslot; ++s) {
         if (8 * pairs[s] > LIMIT) return TAC_E_UNSUPPORTED;
+        slot_steps[s] = 2 * pairs[s];
         steps += 2 * pairs[s];
     }
+    const std::vector<int> start = place_band_starts(nslot, slot_steps, first, len);    // bank-aware first bins (lane_placement.hpp)
     const long long wtot = 256LL * steps;
     int waves = 0;
     for (int wv : {12, 11, 10, 8})
@@ -327,7 +331,7 @@ int pack_n4096_mel(const std::vector<float>& h, int n_freqs, int n_mels, float* 
     for (int s = 0; s < nslot; ++s) {
         for (int l = 0; l < 64; ++l) {
             const int m = 64 * s + l;
-            int f0 = first[m];
+            int f0 = start[m];
             if (f0 + 8 * pairs[s] > LIMIT) f0 = (LIMIT - 8 * pairs[s]) & ~3;
             for (int j = 0; j < 2 * pairs[s]; ++j)
                 for (int u = 0; u < 4; ++u) {
