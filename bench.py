@@ -223,7 +223,7 @@ def extra_stages(stages, tac, dev, gen, model):
             alg = b4 * c4 * t4 * per_frame
             stages['cfg4_spectrogram_4096'] = {
                 'workload': 'Spectrogram(4096, 1024, power=1) on %d x %dch x %d samples (BASELINE configs[3], full size, one launch)' % (b4, c4, l4),
-                'kernel': 'stft_n4096_kernel (csrc/stft_n4096.hip), |X| rows',
+                'kernel': 'stft_n4096_s3_kernel<2, 12, false> (csrc/stft_n4096_s3.hpp: twelve waves per CU, both 1024-point transforms through one exchange area), |X| rows',
                 'frames': b4 * c4 * t4, 'kernel_ms_mean': ms, 'kernel_ms_median': med, 'alg_bytes_per_frame': per_frame,
                 'alg_bytes_per_launch': alg, 'achieved_GBs': alg / (ms * 1e-3) / 1e9,
                 'frac_of_hbm_peak': alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'frames_per_s': b4 * c4 * t4 / (ms * 1e-3)}
@@ -231,6 +231,27 @@ def extra_stages(stages, tac, dev, gen, model):
             torch.cuda.empty_cache()
     except Exception as exc:            # noqa: BLE001
         stages['cfg4_spectrogram_4096'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
+
+    try:        # the Melspectrogram chain at fft_length 4096 (reference layers.py:307-381): ONE launch since round 6
+        x4m = torch.rand(8, 8, 480000, device=dev, generator=gen) * 2 - 1
+        mel4 = torch.nn.Sequential(*tac.Melspectrogram(num_mels=128, sample_rate=48000, fft_length=4096, hop_length=1024),
+                                   tac.AmplitudeToDb()).to(dev)
+        fn = lambda: mel4(x4m)
+        spin(fn, 0.2)
+        before = dict(tac._hip.launches)
+        fn()
+        calls = {k: v - before.get(k, 0) for k, v in tac._hip.launches.items() if v != before.get(k, 0)}
+        ms, med = event_ms(fn, 50)
+        frames = 64 * (1 + 480000 // 1024)
+        stages['mel4096_one_launch'] = {
+            'workload': 'Sequential(*Melspectrogram(128, 48 kHz, 4096 / 1024), AmplitudeToDb()) on 8 x 8ch x 480 000 samples',
+            'kernel': 'stft_n4096_s3_kernel<1, W, true> (the twelve-wave form of the 4096 rows + band-sparse contraction + dB)',
+            'launches_per_call': calls, 'frames': frames, 'kernel_ms_mean': ms, 'kernel_ms_median': med,
+            'frames_per_s': frames / (ms * 1e-3),
+            'note': 'rounds 2 - 5: two launches (spectrogram rows through HBM + streaming filterbank), 0.163 - 0.166 ms'}
+        del x4m, mel4, fn
+    except Exception as exc:            # noqa: BLE001
+        stages['mel4096_one_launch'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
 
     try:        # configs[4]: 1024 x 1ch x 24 kHz x 5 s, 256 levels (reference functional.py:317-354): f32 -> int64 -> f32
         x5 = torch.rand(1024, 1, 24000 * 5, device=dev, generator=gen) * 2 - 1

@@ -104,6 +104,14 @@ int tac_melspec_f32(const float* wave, const float* window, const tac_stft_desc*
  *      for n_fft = 2048 the pack is the lane layout of the streaming kernel (lane l owns bands l, 64 + l, ...; at most
  *      256 bands): wpack = float[steps][64][2] zero-padded pair weights, desc = int32[slots][64] first bins,
  *      info_host = {weight floats, slots, 64, total steps, steps of slot 0..3}; wpack_cap >= 8192.
+ *      For n_fft = 4096 (round 6: the chain in ONE launch, csrc/stft_n4096_s3.hpp; at most 256 bands, power in {1, 2}, frames 16-byte
+ *      aligned, rows of at least one frame — TAC_E_UNSUPPORTED otherwise and callers chain (2) and (4b)) cells (slot, lane) of up to six
+ *      slots, every slot storing the step pairs of ITS longest run: uncut, cell c is band c (or n_mels - 1 - c); where that table does
+ *      not fit the LDS, bands are cut into pieces that a mix table gathers.  wpack = float[steps][64][4] (wpack_cap >= 256 * steps),
+ *      desc = int32[6][64] first bins, int32[6] step pairs per slot, 10 ints of padding, int32[rounds][pieces][64] mix (desc_cap >=
+ *      400 + 64 * rounds * pieces), info_host = {weight floats, slots, 1000 + 4096, total steps, waves per workgroup the table leaves
+ *      room for (12 / 11 / 8), pieces per band in the mix table (0: uncut), rounds of 64 bands, uncut cells in reversed band order};
+ *      TAC_E_UNSUPPORTED when no layout fits the LDS beside eight waves (dense banks).
  *      tac_melbank_plan_pieces_host (a host tool, no device access): the PIECE layout of round 4 for a host copy of the bank —
  *      a lane runs three segments of L0 / L1 / L2 four-tap steps, each holding a piece of a band; a band takes up to three
  *      pieces in adjacent lanes; 12 steps instead of 18 for the standard 128-band bank.  seg_steps int32[3]; first / band /
@@ -165,7 +173,8 @@ int tac_apply_filterbank_sparse_f32(const float* spec, int64_t rows, int32_t n_f
                                     const int32_t* desc, const int32_t* info_host, int32_t n_mels,
                                     float* out, void* stream);
 /* ... followed by functional.amplitude_to_db (db != 0: 10 (log10(max(x^2, db_amin)) - log10 db_ref)) in the same pass: the
- *      filterbank + dB tail of Melspectrogram -> AmplitudeToDb for the sizes without a fully fused kernel (fft_length 4096). */
+ *      filterbank + dB tail of Melspectrogram -> AmplitudeToDb for a spectrogram that already exists (the chain from the waveform
+ *      is one launch of (3b) up to fft_length 4096). */
 int tac_apply_filterbank_sparse_db_f32(const float* spec, int64_t rows, int32_t n_freqs, int64_t n_frames,
                                        int64_t stride_r, int64_t stride_t, const float* wpack, const int32_t* desc,
                                        const int32_t* info_host, int32_t n_mels, int db, float db_ref, float db_amin,

@@ -616,7 +616,7 @@ def test_melbank_pack_bank_aware_placement_is_polynomial(tac):
     assert rel_err(host(y), np.einsum('...ft,fm->...mt', p, fb.astype(np.float64))) < 1e-5
 
 
-@pytest.mark.parametrize('n_fft', [1024, 400, 512, 2048])
+@pytest.mark.parametrize('n_fft', [1024, 400, 512, 2048, 4096])
 @pytest.mark.parametrize('path', ['sparse', 'mfma'])
 def test_fused_kernels_on_custom_filterbanks(tac, path, n_fft, monkeypatch):
     """Both fused contraction forms against float64 on banks that stress the packing: a band with no support, a band
@@ -643,7 +643,7 @@ def test_fused_kernels_on_custom_filterbanks(tac, path, n_fft, monkeypatch):
                                 tac.AmplitudeToDb()).cuda()
     before = launches(tac)
     y = chain(dev(x))
-    if not (path == 'mfma' and n_fft in (400, 2048)):                          # (the MFMA fused form covers fft_length <= 1024, powers of two)
+    if not (path == 'mfma' and n_fft in (400, 2048, 4096)):                    # (the MFMA fused form covers fft_length <= 1024, powers of two)
         assert launched_since(tac, before) == {fused: 1}                       # really fused
     p = np.abs(numpy_ref.stft(x, n_fft, hop)) ** 2
     mel = np.einsum('...ft,fm->...mt', p, fb.astype(np.float64))
@@ -1826,6 +1826,43 @@ def test_g10_melspectrogram_fft_length_4096(tac, golden):
     xl = signals.audio_like((3, 1, 250000), seed=72)
     want = torch_ref.melspectrogram_db(torch.from_numpy(xl), num_mels=128, sample_rate=44100, n_fft=4096, hop=1024).numpy()
     assert np.abs(host(chain(dev(xl))) - want).max() < DB_ABS
+
+
+def test_melspectrogram_4096_one_launch_geometries(tac):
+    """The one-launch chain at fft_length 4096 (csrc/stft_n4096_s3.hpp) against the float64 oracle over what its launcher and its
+    table builder decide on: band counts that fill one to four lane slots, both powers, no centring, every padding mode, a hop
+    that shares two of four hops, frames the wave count does not divide, rows of exactly one frame — and the geometries it declines
+    (frames that are not 16-byte aligned, rows shorter than a frame), which take the two-launch chain with the same results."""
+    def check(x, n_mels, sr, hop, power, expect_fused, db=True, **kw):
+        layers = list(tac.Melspectrogram(num_mels=n_mels, sample_rate=sr, fft_length=4096, hop_length=hop, **kw))
+        layers[1] = tac.ComplexNorm(power)
+        chain = torch.nn.Sequential(*layers, *([tac.AmplitudeToDb()] if db else [])).cuda()
+        before = launches(tac)
+        got = host(tac.realize(chain(dev(x))))
+        calls = launched_since(tac, before)
+        assert (calls == {'tac_melspec_sparse_f32': 1}) == expect_fused, (calls, n_mels, hop, kw)
+        fb = layers[2].filterbank.double().cpu().numpy()
+        p = np.abs(numpy_ref.stft(x, 4096, hop, center=kw.get('center', True), pad_mode=kw.get('pad_mode', 'reflect'))) ** power
+        mel = np.einsum('...ft,fm->...mt', p, fb)
+        if db:
+            want = 10.0 * np.log10(np.maximum(mel ** 2, 1e-7))
+            live = mel > 1e-5 * mel.max()                                   # (below that the fp32 FFT's own rounding decides the value)
+            assert np.abs(got - want)[live].max() < DB_ABS
+        else:
+            assert rel_err(got, mel) < 1e-5
+    x = signals.audio_like((2, 3, 41000), seed=611)
+    for n_mels, sr in ((40, 16000), (64, 22050), (80, 44100), (128, 44100), (200, 48000), (256, 48000)):
+        check(x, n_mels, sr, 1024, 2.0, True)
+    check(x, 128, 48000, 1024, 1.0, True)
+    check(x, 128, 48000, 1024, 2.0, True, db=False)
+    check(x, 128, 48000, 2048, 2.0, True, center=False)
+    for mode in ('constant', 'replicate', 'circular'):
+        check(x, 80, 44100, 512, 2.0, True, pad_mode=mode)
+    check(signals.audio_like((1, 1, 4096), seed=612), 128, 44100, 1024, 2.0, True)          # five frames, four of them padded
+    check(signals.audio_like((5, 1, 4096 + 1024 * 13), seed=613), 128, 44100, 1024, 2.0, True, center=False)   # 14 frames per row
+    check(x, 128, 48000, 1000, 2.0, True)                                   # hop a multiple of four samples: still aligned
+    check(x, 128, 48000, 1023, 2.0, False)                                  # frames off the 16-byte grid: the two-launch chain
+    check(signals.audio_like((2, 1, 3000), seed=614), 128, 44100, 1024, 2.0, False)          # rows shorter than one frame
 
 
 def test_compiled_binding_carries_the_fused_call(tac):

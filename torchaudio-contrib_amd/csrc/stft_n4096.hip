@@ -279,7 +279,7 @@ static int launch_n4096_s3(const FrameGeom& g, const Tables& tb2k, const Tables&
                            hipStream_t stream) {
     const long long units = g.rows * g.n_frames;
     if (units >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
-    const size_t bytes = n4096_s3_lds_bytes(WAVES) + (MEL ? n4096_mel_lds_bytes(mel.nslot, mel.wtot) : 0);
+    const size_t bytes = n4096_s3_lds_bytes(WAVES) + (MEL ? n4096_mel_lds_bytes(mel.rounds, mel.np, mel.wtot) : 0);
     if (bytes > 160 * 1024) return TAC_E_UNSUPPORTED;
     long long blocks = (units + WAVES - 1) / WAVES;
     const long long cap = (long long)device_cu_count();      // one workgroup per CU
@@ -291,16 +291,23 @@ static int launch_n4096_s3(const FrameGeom& g, const Tables& tb2k, const Tables&
     return TAC_OK;
 }
 
-// ---- the filterbank table of the fused form (tac_melbank_pack, n_fft == 4096): lane l owns bands l, 64 + l, ...; slot s runs the
-// step PAIRS of its widest band; a band's run starts at a multiple of four bins, shifted down (zero weights in front) where the padded
-// run would leave the row and its three zeroed slack floats.  info: [0] floats of weights, [1] slots, [2] N4M_MARK, [3] steps,
-// [4] waves per workgroup the table leaves room for.
+// ---- the filterbank table of the fused form (tac_melbank_pack, n_fft == 4096; layout: stft_n4096_s3.hpp).  A band's run of quads
+// (from its first non-zero bin rounded down to a multiple of four) is cut into ceil(quads / C) pieces of about equal length; all pieces,
+// longest first, fill the cells row by row; slot s runs the (even) number of steps of its longest piece.  C is the cap that minimises
+// the model's LDS cycles per frame (two 16-byte reads per step; cells + gather cost what ~35 steps do — measured in one process: the
+// 54-step uncut layout of a 96-band bank on eight waves 0.1118 ms, its 26-step cut layout on twelve 0.1161; 128 bands: 40 uncut steps
+// 0.1084, 22 cut 0.1124) among those that need at most N4M_SLOTS slots and N4M_MAX_PIECES pieces per band and fit the LDS beside eight
+// waves: bands are cut only where the uncut table does not fit (40 / 64 / 80-band banks, bands of 150 - 300 bins).  A piece's first bin is then moved down within its slot's slack by the bank-aware matching
+// (lane_placement.hpp), and where its padded run would leave the row and its three zeroed slack floats.
+// info: [0] floats of weights, [1] slots in use, [2] N4M_MARK, [3] steps, [4] waves per workgroup the table leaves room for,
+// [5] pieces per band in the mix table (0: uncut), [6] rounds of 64 bands, [7] uncut cells in reversed band order.
 int pack_n4096_mel(const std::vector<float>& h, int n_freqs, int n_mels, float* wpack, int wpack_cap, int32_t* desc, int desc_cap,
                    int32_t* info_host, hipStream_t stream) {
     constexpr int LIMIT = 2049 + 3;
-    const int nslot = (n_mels + 63) / 64;
-    if (n_freqs != 2049 || n_mels < 1 || nslot > N4M_MAX_SLOTS || 64 * nslot + N4M_MAX_SLOTS > desc_cap) return TAC_E_UNSUPPORTED;
-    std::vector<int> lo(64 * nslot, 0), hi(64 * nslot, 0), first(64 * nslot, 0), len(64 * nslot, 0), pairs(N4M_MAX_SLOTS, 1);
+    if (n_freqs != 2049 || n_mels < 1 || n_mels > N4M_MAX_MELS) return TAC_E_UNSUPPORTED;
+    const int rounds = (n_mels + 63) / 64;
+    std::vector<int> lo(n_mels, 0), hi(n_mels, 0), first(n_mels, 0), quads(n_mels, 0);
+    int widest = 1;
     for (int m = 0; m < n_mels; ++m) {
         int l0 = n_freqs, h0 = 0;
         for (int f = 0; f < n_freqs; ++f)
@@ -309,50 +316,113 @@ int pack_n4096_mel(const std::vector<float>& h, int n_freqs, int n_mels, float* 
             lo[m] = l0;
             hi[m] = h0;
             first[m] = l0 & ~3;
-            len[m] = h0 - first[m];
-            pairs[m / 64] = std::max(pairs[m / 64], (h0 - first[m] + 7) / 8);
+            quads[m] = (h0 - first[m] + 3) / 4;
+            widest = std::max(widest, quads[m]);
         }
     }
-    int steps = 0, slot_steps[N4M_MAX_SLOTS] = {0, 0, 0, 0};
-    for (int s = 0; s < nslot; ++s) {
-        if (8 * pairs[s] > LIMIT) return TAC_E_UNSUPPORTED;
-        slot_steps[s] = 2 * pairs[s];
-        steps += 2 * pairs[s];
+    struct Piece { int band, start, q; };
+    const bool rev = quads[n_mels - 1] > quads[0];                          // uncut cells from the widest end of the bank
+    auto cut = [&](int cap, std::vector<Piece>& pieces, int& np_max) {
+        pieces.clear();
+        np_max = 1;
+        for (int mm = 0; mm < n_mels; ++mm) {
+            const int m = rev ? n_mels - 1 - mm : mm;
+            if (!quads[m]) {                                                // a band without support still owns a cell (it sums to zero)
+                pieces.push_back({m, 0, 0});
+                continue;
+            }
+            const int np = (quads[m] + cap - 1) / cap, base = quads[m] / np, extra = quads[m] % np;
+            np_max = std::max(np_max, np);
+            for (int i = 0, at = first[m]; i < np; ++i) {
+                const int q = base + (i < extra ? 1 : 0);
+                pieces.push_back({m, at, q});
+                at += 4 * q;
+            }
+        }
+        if (np_max > 1) std::stable_sort(pieces.begin(), pieces.end(), [](const Piece& x, const Piece& y) { return x.q > y.q; });
+    };                                                                      // (uncut: cell 64 r + l stays band 64 r + l)
+    std::vector<Piece> pieces, best;
+    long long best_cost = -1;
+    int best_np = 1;
+    for (int cap = 1; cap <= widest; ++cap) {
+        int np = 1;
+        cut(cap, pieces, np);
+        const int slots = ((int)pieces.size() + 63) / 64;
+        if (np > N4M_MAX_PIECES || slots > N4M_SLOTS) continue;
+        long long steps = 0;
+        for (int s = 0; s < slots; ++s) {
+            int q = 0;
+            for (int c = 64 * s; c < 64 * s + 64 && c < (int)pieces.size(); ++c) q = std::max(q, pieces[c].q);
+            steps += std::max(2, (q + 1) & ~1);
+        }
+        const int npad = np > 1 ? (np + 3) & ~3 : 0;
+        if (n4096_s3_lds_bytes(8) + n4096_mel_lds_bytes(rounds, npad, (int)(256 * steps)) > 160 * 1024) continue;
+        const long long cost = 8 * steps + (np > 1 ? 300 + 2LL * rounds * npad : 0) + 16 * slots;
+        if (best_cost < 0 || cost <= best_cost) {
+            best_cost = cost;
+            best = pieces;
+            best_np = np;
+        }
     }
-    const std::vector<int> start = place_band_starts(nslot, slot_steps, first, len);    // bank-aware first bins (lane_placement.hpp)
+    if (best_cost < 0) return TAC_E_UNSUPPORTED;                            // bands too many or too wide for the LDS: the two-launch chain
+    const int ncell = (int)best.size(), slots = std::max(1, (ncell + 63) / 64), np = best_np > 1 ? (best_np + 3) & ~3 : 0;     // (mix lists in fours; 0: direct)
+    int slot_steps[N4M_SLOTS] = {0, 0, 0, 0, 0, 0}, steps = 0;
+    for (int s = 0; s < slots; ++s) {
+        int q = 0;
+        for (int c = 64 * s; c < 64 * s + 64 && c < ncell; ++c) q = std::max(q, best[c].q);
+        slot_steps[s] = std::max(2, (q + 1) & ~1);
+        if (4 * slot_steps[s] > LIMIT) return TAC_E_UNSUPPORTED;
+        steps += slot_steps[s];
+    }
     const long long wtot = 256LL * steps;
     int waves = 0;
-    for (int wv : {12, 11, 10, 8})
-        if (!waves && n4096_s3_lds_bytes(wv) + n4096_mel_lds_bytes(nslot, (int)wtot) <= 160 * 1024) waves = wv;
-    if (!waves || wtot > wpack_cap) return TAC_E_UNSUPPORTED;               // not band-sparse enough: the two-launch chain
+    for (int wv : {12, 11, 8})                                               // (ten waves — 3, 3, 2, 2 per SIMD — measured slower than eight)
+        if (!waves && n4096_s3_lds_bytes(wv) + n4096_mel_lds_bytes(rounds, np, (int)wtot) <= 160 * 1024) waves = wv;
+    const int mix_rows = n4096_mix_rows(rounds, np);
+    if (!waves || wtot > wpack_cap || N4M_DESC_HEAD + 64 * mix_rows > desc_cap) return TAC_E_UNSUPPORTED;   // the two-launch chain
+    // bank-aware first bins per slot: a cell's run may start up to (slot steps - its quads) quads earlier
+    std::vector<int> cstart(64 * slots, 0), clen(64 * slots, 0);
+    for (int c = 0; c < ncell; ++c) {
+        cstart[c] = best[c].start;
+        clen[c] = 4 * best[c].q;
+    }
+    const std::vector<int> placed = place_band_starts(slots, slot_steps, cstart, clen);
     std::vector<float> wp((size_t)wtot, 0.0f);
-    std::vector<int32_t> dd((size_t)64 * nslot + N4M_MAX_SLOTS, 0);
+    std::vector<int32_t> dd((size_t)N4M_DESC_HEAD + 64 * mix_rows, 0);
+    for (int i = 0; i < 64 * mix_rows; ++i) dd[(size_t)N4M_DESC_HEAD + i] = N4M_ZERO_CELL;
+    std::vector<int> filled(n_mels, 0);
     int base = 0;
-    for (int s = 0; s < nslot; ++s) {
+    for (int s = 0; s < slots; ++s) {
         for (int l = 0; l < 64; ++l) {
-            const int m = 64 * s + l;
-            int f0 = start[m];
-            if (f0 + 8 * pairs[s] > LIMIT) f0 = (LIMIT - 8 * pairs[s]) & ~3;
-            for (int j = 0; j < 2 * pairs[s]; ++j)
+            const int c = 64 * s + l;
+            int f0 = c < ncell ? placed[c] : 0;
+            if (f0 + 4 * slot_steps[s] > LIMIT) f0 = (LIMIT - 4 * slot_steps[s]) & ~3;
+            dd[c] = f0;
+            if (c >= ncell) continue;
+            const Piece& pc = best[c];
+            for (int j = 0; j < slot_steps[s]; ++j)
                 for (int u = 0; u < 4; ++u) {
                     const int bin = f0 + 4 * j + u;
-                    const bool live = m < n_mels && bin >= lo[m] && bin < hi[m];
-                    wp[((size_t)(base + j) * 64 + l) * 4 + u] = live ? h[(size_t)bin * n_mels + m] : 0.0f;
+                    const bool live = bin >= pc.start && bin < pc.start + 4 * pc.q && bin >= lo[pc.band] && bin < hi[pc.band];
+                    wp[((size_t)(base + j) * 64 + l) * 4 + u] = live ? h[(size_t)bin * n_mels + pc.band] : 0.0f;
                 }
-            dd[64 * s + l] = f0;
+            if (np) dd[(size_t)N4M_DESC_HEAD + ((size_t)(pc.band / 64) * np + filled[pc.band]++) * 64 + (pc.band & 63)] = c;
+
         }
-        dd[(size_t)64 * nslot + s] = pairs[s];
-        base += 2 * pairs[s];
+        dd[(size_t)64 * N4M_SLOTS + s] = slot_steps[s] / 2;
+        base += slot_steps[s];
     }
     TAC_HIP(hipMemcpyAsync(wpack, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice, stream));
     TAC_HIP(hipMemcpyAsync(desc, dd.data(), dd.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
     TAC_HIP(hipStreamSynchronize(stream));
     info_host[0] = (int32_t)wtot;
-    info_host[1] = nslot;
+    info_host[1] = slots;
     info_host[2] = N4M_MARK;
     info_host[3] = steps;
     info_host[4] = waves;
-    for (int i = 5; i < 8; ++i) info_host[i] = 0;
+    info_host[5] = np;
+    info_host[6] = rounds;
+    info_host[7] = (np == 0 && rev) ? 1 : 0;
     return TAC_OK;
 }
 
@@ -360,8 +430,8 @@ int pack_n4096_mel(const std::vector<float>& h, int n_freqs, int n_mels, float* 
 // the twelve-wave form declines (two-sided output, frames that are not 16-byte aligned, rows shorter than one frame)
 int launch_n4096_mel(const FrameGeom& g, float power, const float* wpack, const int32_t* desc, const int32_t* info_host, int n_mels,
                      int db, float amin, float log10_ref, float* out, hipStream_t stream) {
-    if (info_host[2] != N4M_MARK || info_host[1] < 1 || info_host[1] > N4M_MAX_SLOTS || info_host[0] != 256 * info_host[3] ||
-        n_mels > 64 * info_host[1])
+    if (info_host[2] != N4M_MARK || info_host[1] < 1 || info_host[1] > N4M_SLOTS || info_host[0] != 256 * info_host[3] ||
+        info_host[5] < 0 || info_host[5] > N4M_MAX_PIECES || (info_host[5] & 3) || info_host[6] != (n_mels + 63) / 64 || n_mels > N4M_MAX_MELS)
         return TAC_E_INVALID;
     if (!g.vec4_ok || g.length < 4096 || (power != 1.0f && power != 2.0f)) return TAC_E_UNSUPPORTED;
     Tables tb2k, tb4k;
@@ -370,12 +440,11 @@ int launch_n4096_mel(const FrameGeom& g, float power, const float* wpack, const 
     rc = get_tables(4096, &tb4k);
     if (rc != TAC_OK) return rc;
     const StftEpilogue ep{nullptr, 1, 1, power, 0, 0.0f, 0.0f};
-    const N4Mel mel{wpack, desc, info_host[1], info_host[0], n_mels, db, amin, log10_ref, out};
+    const N4Mel mel{wpack, desc, info_host[5], info_host[6], info_host[0], n_mels, db, info_host[7], amin, log10_ref, out};
     const bool p2 = power == 2.0f;
     switch (info_host[4]) {
         case 12: return p2 ? launch_n4096_s3<1, 12, true>(g, tb2k, tb4k, ep, mel, stream) : launch_n4096_s3<2, 12, true>(g, tb2k, tb4k, ep, mel, stream);
         case 11: return p2 ? launch_n4096_s3<1, 11, true>(g, tb2k, tb4k, ep, mel, stream) : launch_n4096_s3<2, 11, true>(g, tb2k, tb4k, ep, mel, stream);
-        case 10: return p2 ? launch_n4096_s3<1, 10, true>(g, tb2k, tb4k, ep, mel, stream) : launch_n4096_s3<2, 10, true>(g, tb2k, tb4k, ep, mel, stream);
         case 8: return p2 ? launch_n4096_s3<1, 8, true>(g, tb2k, tb4k, ep, mel, stream) : launch_n4096_s3<2, 8, true>(g, tb2k, tb4k, ep, mel, stream);
         default: return TAC_E_INVALID;
     }

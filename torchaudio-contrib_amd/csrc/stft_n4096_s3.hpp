@@ -29,19 +29,33 @@ __host__ __device__ constexpr size_t n4096_s3_lds_bytes(int waves) {
     return (size_t)waves * s3_xa_bytes<WaveFft<1024, 16>>() + ST_TW_BYTES + 64 + 64 * 8 * sizeof(cf) + 2 * 64 * 16 * sizeof(cf);
 }
 
-// the filterbank of the fused form (tac_melbank_pack for fft_length 4096): first bins [slot][lane], then the slots' step PAIRS;
-// weights [step][lane][4 taps], a slot's steps behind the previous slot's
-constexpr int N4M_MAX_SLOTS = 4;
+// the filterbank of the fused form (tac_melbank_pack for fft_length 4096; built by pack_n4096_mel, stft_n4096.hip).  A band's run of
+// four-tap steps is cut into PIECES of about equal length; the pieces of all bands, longest first, fill the cells (slot, lane) of up to
+// N4M_SLOTS slots row by row, and slot s runs the step pairs of ITS longest piece — so that 128 mel bands over 2049 bins cost ~20 steps
+// per frame instead of the 40 of "lane l owns bands l and 64 + l", and banks with few, wide bands (40 or 80 bands: up to 300 bins) fit at
+// all.  A lane keeps its slots' partial sums in registers; once the row is dead they go to the area as cells [slot][lane], and band
+// 64 r + l is the sum of the `np` cells (a multiple of four) its mix list names (padded with the index of a cell that holds zero).
+// When no band needs cutting for the table to fit (np == 0: "direct") cell c = 64 r + l IS band c — or band n_mels - 1 - c (`rev`), so
+// that the widest bands of a bank whose band count is not a multiple of 64 share a slot: the lane that contracted it applies the dB and
+// stores it (one coalesced 256-byte store per slot), nothing is gathered and there is no mix table.
+//   desc: int32 first bins [N4M_SLOTS][64], step pairs [N4M_SLOTS] (0: slot not used), 10 ints of padding, mix [rounds][np][64]
+//   wpack: float [step][lane][4 taps], a slot's steps behind the previous slot's
+constexpr int N4M_SLOTS = 6;
+constexpr int N4M_MAX_PIECES = 16;
+constexpr int N4M_MAX_MELS = 256;
+constexpr int N4M_DESC_HEAD = 64 * N4M_SLOTS + N4M_SLOTS + 10;            // ints in front of the mix table (a multiple of four)
+constexpr int N4M_ZERO_CELL = 64 * N4M_SLOTS;
 constexpr int N4M_MARK = 1000 + 4096;                                      // info_host[2] of such a pack
 struct N4Mel {
     const float* wpack;
     const int* desc;
-    int nslot, wtot, n_mels, db;
+    int np, rounds, wtot, n_mels, db, rev;
     float amin, log10_ref;
     float* out;                 // [rows][T][n_mels]
 };
-__host__ __device__ constexpr size_t n4096_mel_lds_bytes(int nslot, int wtot) {
-    return (size_t)(64 * nslot + 16) * sizeof(int) + (size_t)wtot * sizeof(float);
+__host__ __device__ constexpr int n4096_mix_rows(int rounds, int np) { return rounds * np; }
+__host__ __device__ constexpr size_t n4096_mel_lds_bytes(int rounds, int np, int wtot) {
+    return (size_t)(N4M_DESC_HEAD + 64 * n4096_mix_rows(rounds, np)) * sizeof(int) + (size_t)wtot * sizeof(float);
 }
 
 // r2c_power_pair_x2 (fft_core.hpp) for the pairs (zk1, zm1, w) and (zk2, zm2, -i conj(w)): the second twiddle is never formed, its
@@ -92,8 +106,8 @@ stft_n4096_s3_kernel(FrameGeom g, Tables tb2k, Tables tb4k, StftEpilogue ep, N4M
     cf* const ptwl = reinterpret_cast<cf*>(next_unit + 16);               // W_2048^(t + 64 p) as [p >> 1][lane][p & 1]
     cf* const winA = ptwl + 64 * 8;                                       // window pairs of z[2 (t + 64 q)] as [q >> 1][lane][q & 1]
     cf* const winB = winA + 64 * E;                                       // ... of z[2 (t + 64 q) + 1]
-    int* const mlo = reinterpret_cast<int*>(winB + 64 * E);               // MEL: first bins [slot][lane], step pairs per slot
-    float* const mwl = reinterpret_cast<float*>(mlo + 64 * mel.nslot + 16);
+    int* const mlo = reinterpret_cast<int*>(winB + 64 * E);               // MEL: the pack's desc (first bins, step pairs, mix table)
+    float* const mwl = reinterpret_cast<float*>(mlo + N4M_DESC_HEAD + 64 * n4096_mix_rows(mel.rounds, mel.np));
 
     // ---- tables (the R2C split returns 2X: the halving and the transform's scale are folded into the window)
     const float half = 0.5f * g.scale;
@@ -109,7 +123,7 @@ stft_n4096_s3_kernel(FrameGeom g, Tables tb2k, Tables tb4k, StftEpilogue ep, N4M
         winB[slot] = cscale(window_pair(g, 2 * j + 1), half);
     }
     if constexpr (MEL) {
-        for (int i = tid; i < 64 * mel.nslot + N4M_MAX_SLOTS; i += N4S_WAVES * 64) mlo[i] = mel.desc[i];
+        for (int i = tid; i < N4M_DESC_HEAD + 64 * n4096_mix_rows(mel.rounds, mel.np); i += N4S_WAVES * 64) mlo[i] = mel.desc[i];
         for (int i = tid; i < (mel.wtot >> 2); i += N4S_WAVES * 64)
             reinterpret_cast<f4*>(mwl)[i] = reinterpret_cast<const f4*>(mel.wpack)[i];
     }
@@ -284,20 +298,19 @@ stft_n4096_s3_kernel(FrameGeom g, Tables tb2k, Tables tb4k, StftEpilogue ep, N4M
         request(nxt);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (MEL) {
-            // ---- filterbank (reference functional.py:172-184) [+ dB, :291-296]: lane t owns bands t, 64 + t, ...; a step is one
-            //      16-byte weight read, one 16-byte row read and two packed FMAs; a slot runs the step pairs of ITS widest band
+            // ---- filterbank (reference functional.py:172-184) [+ dB, :291-296]: a step is one 16-byte weight read, one 16-byte row
+            //      read and two packed FMAs; slot sl runs the step pairs of its longest piece, the next pair read before this one is used
             const bool fast_db = mel.amin >= 1.1754944e-38f;               // (uniform) hardware log2 unless the clamp admits denormals
             const float ten_log10_ref = 10.0f * mel.log10_ref;
             const f4* wp = reinterpret_cast<const f4*>(mwl) + t;
             float* const orow = mel.out + g0;
-#pragma unroll 1
-            for (int sl = 0; sl < mel.nslot; ++sl) {
+            // the step pairs of one slot from the lane's first bin: the next pair is read before this one is used
+            auto run_slot = [&](int sl, int pairs) -> float {
                 const f4* pp = reinterpret_cast<const f4*>(stage + mlo[64 * sl + t]);
-                const int pairs = __builtin_amdgcn_readfirstlane(mlo[64 * mel.nslot + sl]);
                 cf acc0 = mkc(0.0f, 0.0f), acc1 = mkc(0.0f, 0.0f);
                 f4 w0 = wp[0], w1 = wp[64], p0 = pp[0], p1 = pp[1];
 #pragma unroll 1
-                for (int c = 1; c < pairs; ++c) {                           // the next pair is read before this one is used
+                for (int c = 1; c < pairs; ++c) {
                     wp += 128;
                     pp += 2;
                     const f4 nw0 = wp[0], nw1 = wp[64], np0 = pp[0], np1 = pp[1];
@@ -312,9 +325,46 @@ stft_n4096_s3_kernel(FrameGeom g, Tables tb2k, Tables tb4k, StftEpilogue ep, N4M
                 acc1 = __builtin_elementwise_fma(mkc(w0.z, w0.w), mkc(p0.z, p0.w), acc1);
                 acc0 = __builtin_elementwise_fma(mkc(w1.x, w1.y), mkc(p1.x, p1.y), acc0);
                 acc1 = __builtin_elementwise_fma(mkc(w1.z, w1.w), mkc(p1.z, p1.w), acc1);
-                float val = (acc0.x + acc0.y) + (acc1.x + acc1.y);
+                return (acc0.x + acc0.y) + (acc1.x + acc1.y);
+            };
+            if (mel.np == 0) {                                              // direct: slot sl, lane t is band 64 sl + t
+#pragma unroll 1
+                for (int sl = 0; sl < mel.rounds; ++sl) {
+                    float val = run_slot(sl, __builtin_amdgcn_readfirstlane(mlo[64 * N4M_SLOTS + sl]));
+                    if (mel.db) val = fast_db ? amp_to_db_fast(val, mel.amin, ten_log10_ref) : amp_to_db(val, mel.amin, mel.log10_ref);
+                    const int cell = 64 * sl + t, band = mel.rev ? mel.n_mels - 1 - cell : cell;
+                    if (cell < mel.n_mels) __builtin_nontemporal_store(val, orow + band);
+                }
+                wave_lds_fence();                         // the next frame's first-pass writes follow these reads
+                unit = nxt;
+                continue;
+            }
+            const int* mix = mlo + N4M_DESC_HEAD + t;
+            float part[N4M_SLOTS];
+#pragma unroll
+            for (int sl = 0; sl < N4M_SLOTS; ++sl) {
+                const int pairs = __builtin_amdgcn_readfirstlane(mlo[64 * N4M_SLOTS + sl]);
+                part[sl] = pairs > 0 ? run_slot(sl, pairs) : 0.0f;
+            }
+            // the row is dead: the cells take its place, every band collects its pieces
+            wave_lds_fence();
+            float* const cells = reinterpret_cast<float*>(xa);
+#pragma unroll
+            for (int sl = 0; sl < N4M_SLOTS; ++sl) cells[64 * sl + t] = part[sl];
+            if (t == 0) cells[N4M_ZERO_CELL] = 0.0f;
+            wave_lds_fence();
+#pragma unroll 1
+            for (int r = 0; r < mel.rounds; ++r) {
+                float val = 0.0f;
+#pragma unroll 1
+                for (int i = 0; i < mel.np; i += 4) {                       // (np is a multiple of four: lists are padded with the zero cell)
+                    const int i0 = mix[0], i1 = mix[64], i2 = mix[128], i3 = mix[192];
+                    mix += 256;
+                    const float c0 = cells[i0], c1 = cells[i1], c2 = cells[i2], c3 = cells[i3];
+                    val += (c0 + c1) + (c2 + c3);
+                }
                 if (mel.db) val = fast_db ? amp_to_db_fast(val, mel.amin, ten_log10_ref) : amp_to_db(val, mel.amin, mel.log10_ref);
-                const int band = 64 * sl + t;
+                const int band = 64 * r + t;
                 if (band < mel.n_mels) __builtin_nontemporal_store(val, orow + band);
             }
             wave_lds_fence();                             // the next frame's first-pass writes follow these reads
