@@ -12,7 +12,7 @@ python bench.py > $out/bench_N1.json 2> $out/bench_N1.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o bench -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-stages > $out/kt_bench.log 2>&1
 # ... and the same command with its stages (every other kernel the bench line quotes)
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_stages -o bench -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline > $out/kt_stages.log 2>&1
-for k in mel stft spec; do
+for k in mel stft spec spec4096 mel4096; do
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_${k}_fetch -o p -- python tools/prof_driver.py $k 3 > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_${k}_write -o p -- python tools/prof_driver.py $k 3 > /dev/null 2>&1
   rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $out/pmc_${k}_sq -o p -- python tools/prof_driver.py $k 3 > /dev/null 2>&1
@@ -36,6 +36,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_${k}_write -o p -- py
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $out/pmc_${k}_sq -o p -- python tools/prof_driver.py $k 3 > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $out/pmc_${k}_stall -o p -- python tools/prof_driver.py $k 3 > /dev/null 2>&1
 # steady-state timings of everything else
+python tools/r06/mel4096_pack_info.py > $out/mel4096_banks.txt 2>&1
 python tools/time_steady.py stft spec mel stft4096 spec4096 mel4096 stft512 spec512 stft1024 spec1024 mel512 mel1024 mel400 stft400 spec400 mel256 stft256 spec256 > $out/time_steady.txt 2>&1
 python tools/time_others.py > $out/time_others.txt 2>&1
 ls $out

@@ -38,12 +38,12 @@ for sub, name in (('kt_grad', 'kernel_stats_backward.csv'), ('kt_gradf', 'kernel
         with open(os.path.join(dst, name), 'w') as o:
             csv.writer(o).writerows([[r[0][:140]] + r[1:] for r in rows])
 os.makedirs(os.path.join(dst, 'steady_state'), exist_ok=True)
-for f in ('time_steady.txt', 'time_others.txt'):
+for f in ('time_steady.txt', 'time_others.txt', 'mel4096_banks.txt'):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, 'steady_state', f))
-for k in ('mel', 'stft', 'spec', 'fb', 'grad'):
+for k in ('mel', 'stft', 'spec', 'spec4096', 'mel4096', 'fb', 'grad'):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(src + '/pmc_%s_*/**/*counter_collection.csv' % k, recursive=True):
+    for f in [f for sub in ('fetch', 'write', 'sq', 'mfma', 'stall') for f in glob.glob(src + '/pmc_%s_%s/**/*counter_collection.csv' % (k, sub), recursive=True)]:
         for r in csv.DictReader(open(f)):
             if 'tac::' in r['Kernel_Name'] and 'plan' not in r['Kernel_Name']:
                 agg[r['Kernel_Name'].split('(')[0]][r['Counter_Name']].append(float(r['Counter_Value']))

@@ -329,11 +329,11 @@ def _melbank_pack(fb, n_fft):
         return cache[1][n_fft]
     n_freqs, n_mels = fb.shape
     wpack = torch.empty(24576, dtype=torch.float32, device=fb.device)
-    desc = torch.empty(4096, dtype=torch.int32, device=fb.device)
+    desc = torch.empty(8192, dtype=torch.int32, device=fb.device)
     info = (ctypes.c_int32 * 8)()
     with _native.on_device(fb.device):
         rc = _native.lib().tac_melbank_pack(_native.ptr(fb), n_freqs, n_mels, n_fft, _native.ptr(wpack), 24576,
-                                            _native.ptr(desc), 4096, ctypes.cast(info, ctypes.c_void_p),
+                                            _native.ptr(desc), 8192, ctypes.cast(info, ctypes.c_void_p),
                                             _native.stream_ptr(fb.device))
     if rc == _native.TAC_E_UNSUPPORTED:
         result = None
