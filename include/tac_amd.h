@@ -287,6 +287,9 @@ int tac_mulaw_decode_f64(const void* codes, int32_t codes_are_i64, int64_t n, in
  *       functional.py:126-128.
  *     tac_amplitude_to_db_backward_f32: grad_x = grad_out * 20 / (ln 10 * x) where x^2 >= amin, else 0,
  *       functional.py:291-296.
+ *     tac_magphase_backward_f32 (round 6): gradient of magphase / angle (functional.py:187-201): grad_z[i] = grad_mag[i] * power *
+ *       |z_i|^(power-2) * z_i + grad_phase[i] * (-im_i, re_i) / |z_i|^2, 0 where z_i == 0; grad_mag or grad_phase may be NULL.
+ *     tac_db_to_amplitude_backward_f32 (round 6): grad_x = grad_out * ln(10) / 20 * (10^(x/10 + log10 ref))^0.5, functional.py:299-314.
  *     The filterbank stage's adjoint is (4) with the transposed matrix — or, for banks with at most two non-zero
  *     weights per bin (every triangular mel bank), tac_apply_filterbank_adjoint_f32: grad_spec[i][f] = w0[f] *
  *     grad_mel[i][band0[f]] + w1[f] * grad_mel[i][band1[f]] over i < rows*T frame-major rows, with the per-bin table
@@ -337,6 +340,9 @@ int tac_window_grad_f32(const float* grad_frames_unwindowed, const float* wave, 
 int tac_sum_slabs_f32(const float* x, int64_t n_slabs, int64_t slab_elems, float* out, void* stream);
 int tac_amplitude_to_db_backward_f32(const float* x, const float* grad_out, int64_t n, float amin,
                                      float* grad_x, void* stream);
+int tac_magphase_backward_f32(const float* z, const float* grad_mag, const float* grad_phase, int64_t n, float power,
+                              float* grad_z, void* stream);
+int tac_db_to_amplitude_backward_f32(const float* x, const float* grad_out, int64_t n, float ref, float* grad_x, void* stream);
 
 /* (10) hpss, beta_hpss.py:35-127: median-filter harmonic / percussive separation of a magnitude
  *      spectrogram.  mag element (r, f, t) at mag[r*stride_r + f*stride_f + t*stride_t]; the four outputs use the same

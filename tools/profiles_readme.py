@@ -70,6 +70,34 @@ for label, name, calls, ms, alg, traffic, c in rows:
     out.append('| %s (`%s`) | %.4f ms (%d) | %.1f MB | %.1f MB | %.0f | %.1f %% |'
                % (label, name, ms, calls, alg / 1e6, traffic / 1e6, gbs, 100 * gbs / 8000))
 out.append('')
+# ---- the fft_length-4096 kernels (round 6): cfg-4 slice 64 x 480 000 samples, hop 1024 -> 30 016 frames per launch
+f4096 = 64 * (1 + 480000 // 1024)
+rows4 = []
+for label, key, per_frame in (('\\|X\\| rows (`tools/prof_driver.py spec4096`)', 'spec4096', 4 * 1024 + 4 * 2049),
+                              ('Melspectrogram 128 bands + dB, one launch (`mel4096`)', 'mel4096', 4 * 1024 + 4 * 128)):
+    pth = os.path.join(d, 'pmc_%s.json' % key)
+    if not os.path.exists(pth):
+        continue
+    for kname, c in json.load(open(pth)).items():
+        if 'n4096' in kname:
+            rows4.append((label, kname.replace('void tac::', ''), per_frame, c))
+if rows4:
+    out.append('fft_length 4096 (`pmc_spec4096.json`, `pmc_mel4096.json`: the cfg-4 slice, 64 x 480 000 samples = %d frames per launch; per frame):\n' % f4096)
+    out.append('| kernel | VALU / frame | LDS instr / frame | LDS index cycles / frame | bank-conflict cycles / frame | VALU busy (SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES) | SQ_WAIT_ANY / SQ_WAVE_CYCLES | algorithmic bytes | HBM traffic (PMC) |')
+    out.append('|---|---|---|---|---|---|---|---|---|')
+    for label, kname, per_frame, c in rows4:
+        g = lambda k: c.get(k, float('nan'))
+        out.append('| %s `%s` | %.0f | %.0f | %.0f | %.0f | %.0f %% | %.0f %% | %.1f MB | %.1f MB |'
+                   % (label, kname, g('SQ_INSTS_VALU') / f4096, g('SQ_INSTS_LDS') / f4096, g('SQ_LDS_IDX_ACTIVE') / f4096,
+                      g('SQ_LDS_BANK_CONFLICT') / f4096, 100 * g('SQ_ACTIVE_INST_VALU') / g('SQ_BUSY_CU_CYCLES'),
+                      100 * g('SQ_WAIT_ANY') / g('SQ_WAVE_CYCLES'), f4096 * per_frame / 1e6, g('hbm_traffic_bytes_per_launch') / 1e6))
+    for name, r4 in stage_stats.items():
+        if 'stft_n4096_s3_kernel<2, 12, false>' in name:
+            ms4 = float(r4['AverageNs']) / 1e6
+            alg4 = 512 * (1 + 2880000 // 1024) * (4 * 1024 + 4 * 2049)
+            out.append('\nBASELINE configs[3] at full size in the stage trace (`kernel_stats_stages.csv`): `stft_n4096_s3_kernel<2, 12, false>` %.3f ms average over %s launches = %.0f GB/s = %.1f %% of 8 TB/s (17.70 GB algorithmic per launch).'
+                       % (ms4, r4['Calls'], alg4 / ms4 / 1e6, alg4 / ms4 / 1e6 / 80))
+    out.append('`steady_state/mel4096_banks.txt` — `tools/r06/mel4096_pack_info.py`: what `tac_melbank_pack(..., n_fft = 4096)` builds for the usual mel banks and the time of the one-launch chain with each.\n')
 r = bench['roofline']
 sb = bench.get('single_buffer')
 if sb:

@@ -1158,6 +1158,48 @@ def complex_norm_backward(z, grad_out, power):
     return gz
 
 
+def magphase_backward(z, grad_mag, grad_phase, power):
+    """Gradient of ``magphase`` / ``angle``: (*, F, T, 2) pairs and one or two (*, F, T) gradients in (either may be None), (*, F, T, 2)
+    out — all walked in z's dense storage order."""
+    z = _pairs(z)
+    want = tuple(s // 2 for s in z.stride()[:-1])
+
+    def ordered(g):
+        if g is None or (g.dtype == torch.float32 and g.shape == z.shape[:-1] and g.stride() == want):
+            return g                                                  # already in z's storage order: no copy
+        go = torch.empty_strided(z.shape[:-1], want, dtype=torch.float32, device=z.device)
+        go.copy_(g)
+        return go
+    gm, gp = ordered(grad_mag), ordered(grad_phase)
+    gz = torch.empty_strided(z.shape, z.stride(), dtype=torch.float32, device=z.device)
+    n = z.numel() // 2
+    if n:
+        with _native.on_device(z.device):
+            rc = _native.lib().tac_magphase_backward_f32(_native.ptr(z), None if gm is None else _native.ptr(gm),
+                                                         None if gp is None else _native.ptr(gp), n, float(power),
+                                                         _native.ptr(gz), _native.stream_ptr(z.device))
+        _native.check(rc, 'tac_magphase_backward_f32')
+        _count('tac_magphase_backward_f32')
+    return gz
+
+
+def db_to_amplitude_backward(x, grad_out, ref):
+    x = x if is_dense(x) else x.contiguous()
+    if grad_out.dtype == torch.float32 and grad_out.shape == x.shape and grad_out.stride() == x.stride():
+        go = grad_out                                                 # already in x's storage order: no copy
+    else:
+        go = torch.empty_like(x)
+        go.copy_(grad_out)
+    gx = torch.empty_like(x)
+    if x.numel():
+        with _native.on_device(x.device):
+            rc = _native.lib().tac_db_to_amplitude_backward_f32(_native.ptr(x), _native.ptr(go), x.numel(), float(ref),
+                                                                _native.ptr(gx), _native.stream_ptr(x.device))
+        _native.check(rc, 'tac_db_to_amplitude_backward_f32')
+        _count('tac_db_to_amplitude_backward_f32')
+    return gx
+
+
 def amplitude_to_db_backward(x, grad_out, amin):
     x = x if is_dense(x) else x.contiguous()
     if grad_out.dtype == torch.float32 and grad_out.shape == x.shape and grad_out.stride() == x.stride():

@@ -281,9 +281,28 @@ def _amplitude_to_db_hip_backward(saved, rest, needs, grads):
     return [H.amplitude_to_db_backward(saved[0], grads[0], rest[1])]
 
 
+def _angle_hip_backward(saved, rest, needs, grads):
+    if grads[0] is None or saved[0].shape[-1] != 2:
+        return None
+    return [H.magphase_backward(saved[0], None, grads[0], 1.0)]
+
+
+def _magphase_hip_backward(saved, rest, needs, grads):
+    if (grads[0] is None and grads[1] is None) or saved[0].shape[-1] != 2:
+        return None
+    return [H.magphase_backward(saved[0], grads[0], grads[1], rest[0])]
+
+
+def _db_to_amplitude_hip_backward(saved, rest, needs, grads):
+    if grads[0] is None or not rest[0] > 0.0:
+        return None
+    return [H.db_to_amplitude_backward(saved[0], grads[0], rest[0])]
+
+
 _HIP_BACKWARD = {'stft': _stft_hip_backward, 'spectrogram': _spectrogram_hip_backward,
                  'melspectrogram': _melspectrogram_hip_backward, 'apply_filterbank': _apply_filterbank_hip_backward,
-                 'complex_norm': _complex_norm_hip_backward, 'amplitude_to_db': _amplitude_to_db_hip_backward}
+                 'complex_norm': _complex_norm_hip_backward, 'amplitude_to_db': _amplitude_to_db_hip_backward,
+                 'angle': _angle_hip_backward, 'magphase': _magphase_hip_backward, 'db_to_amplitude': _db_to_amplitude_hip_backward}
 
 
 #: the CUDA-key kernels by op name: `call` below invokes them directly when the dispatcher has nothing to add

@@ -14,7 +14,7 @@
 //   tac_spectrogram_backward_ola_f32   fft_length 2048, hop = 128·H: that kernel with the overlap-add in an LDS ring
 //                                over segments of consecutive frames + ola_fold_kernel (unpadding, segment borders):
 //                                the whole adjoint of Spectrogram with no per-frame data in memory.
-//   tac_complex_norm_backward_f32, tac_amplitude_to_db_backward_f32   elementwise.
+//   tac_complex_norm_backward_f32, tac_magphase_backward_f32, tac_amplitude_to_db_backward_f32, tac_db_to_amplitude_backward_f32   elementwise.
 //   tac_apply_filterbank_adjoint_f32   the filterbank stage's adjoint for banks with <= 2 non-zero weights per bin (mel
 //                                banks); other banks: the forward GEMM with the transposed matrix (tac_apply_filterbank_f32).
 #include "host_common.hpp"
@@ -870,6 +870,32 @@ amplitude_to_db_backward_kernel(const float* __restrict__ x, const float* __rest
     for (long long i = 4 * n4 + tid; i < n; i += nth) gx[i] = one(x[i], gout[i]);
 }
 
+// d/dz of (|z|^power, atan2(im, re)) (functional.py:187-201): g_mag power |z|^(power-2) z + g_phase (-im, re) / |z|^2, both 0 at
+// z == 0 (what torch's norm / atan2 gradients give there); either gradient may be absent
+__global__ void __launch_bounds__(256)
+magphase_backward_kernel(const float* __restrict__ z, const float* __restrict__ gmag, const float* __restrict__ gphase, long long n,
+                         float power, float* __restrict__ gz) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const cf v = *reinterpret_cast<const cf*>(z + 2 * i);
+        cf r = gmag ? norm_pow_grad(v, gmag[i], power) : mkc(0.0f, 0.0f);
+        if (gphase) {
+            const float s = v.x * v.x + v.y * v.y;
+            const float f = s == 0.0f ? 0.0f : gphase[i] / s;
+            r.x -= f * v.y;
+            r.y += f * v.x;
+        }
+        *reinterpret_cast<cf*>(gz + 2 * i) = r;
+    }
+}
+
+// d/dx of (10^(x/10 + log10 ref))^0.5 (functional.py:299-314) = y ln(10) / 20, y re-evaluated as the forward kernel does
+__global__ void __launch_bounds__(256)
+db_to_amplitude_backward_kernel(const float* __restrict__ x, const float* __restrict__ gout, long long n, float log10_ref,
+                                float* __restrict__ gx) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        gx[i] = gout[i] * (0.11512925464970229f * exp2f((x[i] / 10.0f + log10_ref) * 1.6609640474436813f));
+}
+
 template <int NC, int E>
 static int launch_stft_backward(const FrameGeom& g, const Tables& tb, const float* gspec, const float* gnorm, float power,
                                 float* frames, hipStream_t stream, bool from_wave) {
@@ -1415,6 +1441,27 @@ int tac_complex_norm_backward_f32(const float* z, const float* grad_out, int64_t
     if (!z || !grad_out || !grad_z || n < 0) return TAC_E_INVALID;
     hipLaunchKernelGGL(complex_norm_backward_kernel, dim3(bw_blocks(n)), dim3(256), 0, (hipStream_t)stream, z, grad_out,
                        (long long)n, power, grad_z);
+    TAC_HIP(hipGetLastError());
+    return TAC_OK;
+}
+
+int tac_magphase_backward_f32(const float* z, const float* grad_mag, const float* grad_phase, int64_t n, float power,
+                              float* grad_z, void* stream) {
+    using namespace tac;
+    if (n == 0) return TAC_OK;
+    if (!z || !grad_z || (!grad_mag && !grad_phase) || n < 0) return TAC_E_INVALID;
+    hipLaunchKernelGGL(magphase_backward_kernel, dim3(bw_blocks(n)), dim3(256), 0, (hipStream_t)stream, z, grad_mag, grad_phase,
+                       (long long)n, power, grad_z);
+    TAC_HIP(hipGetLastError());
+    return TAC_OK;
+}
+
+int tac_db_to_amplitude_backward_f32(const float* x, const float* grad_out, int64_t n, float ref, float* grad_x, void* stream) {
+    using namespace tac;
+    if (n == 0) return TAC_OK;
+    if (!x || !grad_out || !grad_x || n < 0 || !(ref > 0.0f)) return TAC_E_INVALID;
+    hipLaunchKernelGGL(db_to_amplitude_backward_kernel, dim3(bw_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, grad_out,
+                       (long long)n, log10f(ref), grad_x);
     TAC_HIP(hipGetLastError());
     return TAC_OK;
 }

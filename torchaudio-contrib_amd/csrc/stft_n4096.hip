@@ -297,7 +297,7 @@ static int launch_n4096_s3(const FrameGeom& g, const Tables& tb2k, const Tables&
 // the model's LDS cycles per frame (two 16-byte reads per step; cells + gather cost what ~35 steps do — measured in one process: the
 // 54-step uncut layout of a 96-band bank on eight waves 0.1118 ms, its 26-step cut layout on twelve 0.1161; 128 bands: 40 uncut steps
 // 0.1084, 22 cut 0.1124) among those that need at most N4M_SLOTS slots and N4M_MAX_PIECES pieces per band and fit the LDS beside eight
-// waves: bands are cut only where the uncut table does not fit (40 / 64 / 80-band banks, bands of 150 - 300 bins).  A piece's first bin is then moved down within its slot's slack by the bank-aware matching
+// waves: bands are cut only where the uncut table does not fit beside eight waves (banks of ~40 bands, 300 bins wide).  A piece's first bin is then moved down within its slot's slack by the bank-aware matching
 // (lane_placement.hpp), and where its padded run would leave the row and its three zeroed slack floats.
 // info: [0] floats of weights, [1] slots in use, [2] N4M_MARK, [3] steps, [4] waves per workgroup the table leaves room for,
 // [5] pieces per band in the mix table (0: uncut), [6] rounds of 64 bands, [7] uncut cells in reversed band order.
