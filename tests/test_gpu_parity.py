@@ -1606,6 +1606,62 @@ def test_library_ops_pass_opcheck(tac):
     opcheck(torch.ops.tac_amd.phase_vocoder.default, (z, torch.linspace(0, 3.14 * 128, 257).cuda(), 1.3), test_utils=utils)
 
 
+def test_elementwise_gradient_kernels(tac):
+    """angle, magphase and db_to_amplitude are differentiated by gfx950 kernels (round 6; strict mode is on: a fall-back to torch's
+    operators would raise): against torch.autograd through the oracle on dense pairs, on the strided pairs the STFT kernels return,
+    with either output of magphase unused; at z = 0 the kernels return 0 (torch's atan2 gradient is 0 there too, its norm gradient
+    0 / 0: the convention of tac_complex_norm_backward_f32)."""
+    rng = np.random.default_rng(77)
+    z_np = rng.standard_normal((3, 2, 33, 17, 2)).astype(np.float32)
+    z_np[0, 0, :4, :3] = 0.0
+    for power in (1.0, 2.0, 0.7):
+        gm_np = rng.standard_normal(z_np.shape[:-1]).astype(np.float32)
+        gp_np = rng.standard_normal(z_np.shape[:-1]).astype(np.float32)
+        zr = torch.from_numpy(z_np).requires_grad_(True)
+        mr, pr = torch_ref.magphase(zr, power)
+        (want,) = torch.autograd.grad([mr, pr], zr, [torch.from_numpy(gm_np), torch.from_numpy(gp_np)])
+        (want_m,) = torch.autograd.grad(torch_ref.magphase(zr, power)[0], zr, torch.from_numpy(gm_np))
+        (want_p,) = torch.autograd.grad(torch_ref.angle(zr), zr, torch.from_numpy(gp_np))
+        z = dev(z_np).requires_grad_(True)
+        before = launches(tac)
+        m, ph = tac.magphase(z, power)
+        (got,) = torch.autograd.grad([m, ph], z, [dev(gm_np), dev(gp_np)])
+        assert launched_since(tac, before).get('tac_magphase_backward_f32') == 1
+        live = np.ones(z_np.shape, dtype=bool)
+        live[0, 0, :4, :3] = False
+        scale = np.abs(want.numpy()[live]).max()
+        assert np.abs(host(got) - want.numpy())[live].max() < 1e-5 * scale
+        (got_m,) = torch.autograd.grad(tac.magphase(z, power)[0], z, dev(gm_np))
+        assert np.abs(host(got_m) - want_m.numpy())[live].max() < 1e-5 * scale
+        (got_p,) = torch.autograd.grad(tac.angle(z), z, dev(gp_np))
+        assert np.abs(host(got_p) - want_p.numpy()).max() < 1e-5 * np.abs(want_p.numpy()).max()     # (atan2: 0 at the origin in both)
+        assert np.all(host(got)[0, 0, :4, :3] == 0.0) and np.all(host(got_m)[0, 0, :4, :3] == 0.0)
+    # the strided (frame-major) pairs of the STFT kernels, through a chain: d/dx of sum(angle(stft(x)) * c)
+    x_np = signals.audio_like((2, 1, 6000), seed=78)
+    c_np = rng.standard_normal((2, 1, 129, 1 + 6000 // 64)).astype(np.float32)
+    xr = torch.from_numpy(x_np).requires_grad_(True)
+    (want_x,) = torch.autograd.grad((torch_ref.angle(torch_ref.stft(xr, 256, 64)) * torch.from_numpy(c_np)).sum(), xr)
+    x = dev(x_np).requires_grad_(True)
+    zz = tac.stft(x, 256, 64)
+    assert not zz.is_contiguous()
+    (got_x,) = torch.autograd.grad((tac.angle(zz) * dev(c_np)).sum(), x)
+    assert rel_err(host(got_x), want_x.numpy()) < 1e-3            # (1 / |z|^2 amplifies the forward's rounding at quiet bins)
+    # db_to_amplitude
+    d_np = (rng.standard_normal((4, 3, 50, 21)) * 30.0).astype(np.float32)
+    g_np = rng.standard_normal(d_np.shape).astype(np.float32)
+    for ref in (1.0, 3.5):
+        dr = torch.from_numpy(d_np).requires_grad_(True)
+        (want_d,) = torch.autograd.grad(torch_ref.db_to_amplitude(dr, ref), dr, torch.from_numpy(g_np))
+        d = dev(d_np).requires_grad_(True)
+        before = launches(tac)
+        (got_d,) = torch.autograd.grad(tac.db_to_amplitude(d, ref), d, dev(g_np))
+        assert launched_since(tac, before).get('tac_db_to_amplitude_backward_f32') == 1
+        assert np.abs(host(got_d) - want_d.numpy()).max() < 2e-6 * np.abs(want_d.numpy()).max()
+        dt = dev(d_np).transpose(-1, -2).requires_grad_(True)          # a non-contiguous dense layout
+        (got_t,) = torch.autograd.grad(tac.db_to_amplitude(dt, ref), dt, dev(g_np).transpose(-1, -2))
+        assert np.abs(host(got_t).swapaxes(-1, -2) - want_d.numpy()).max() < 2e-6 * np.abs(want_d.numpy()).max()
+
+
 def test_g8_hpss(tac, golden):
     """hpss on the HIP kernel: golden outputs of the reference (the medians select existing values, so
     harm / perc are exact up to pow and the mask quotient), the strided spectrogram the STFT kernels return, unequal
