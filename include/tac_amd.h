@@ -103,7 +103,8 @@ int tac_melspec_f32(const float* wave, const float* window, const tac_stft_desc*
  *      int32[desc_cap >= 4096]); info_host: HOST int32[8] = {weight floats, desc stride, lane groups, max group load, 0, 0, 0, 0};
  *      for n_fft = 2048 the pack is the lane layout of the streaming kernel (lane l owns bands l, 64 + l, ...; at most
  *      256 bands): wpack = float[steps][64][2] zero-padded pair weights, desc = int32[slots][64] first bins,
- *      info_host = {weight floats, slots, 64, total steps, steps of slot 0..3}; wpack_cap >= 8192.
+ *      info_host = {weight floats, slots, 64 (+ 256 since round 6 when cell 64 s + l holds band n_mels - 1 - (64 s + l): banks whose band
+ *      count is not a multiple of 64, so that their widest bands share slot 0), total steps, steps of slot 0..3}; wpack_cap >= 8192.
  *      For n_fft = 4096 (round 6: the chain in ONE launch, csrc/stft_n4096_s3.hpp; at most 256 bands, power in {1, 2}, frames 16-byte
  *      aligned, rows of at least one frame — TAC_E_UNSUPPORTED otherwise and callers chain (2) and (4b)) cells (slot, lane) of up to six
  *      slots, every slot storing the step pairs of ITS longest run: uncut, cell c is band c (or n_mels - 1 - c); where that table does

@@ -1884,6 +1884,36 @@ def test_g10_melspectrogram_fft_length_4096(tac, golden):
     assert np.abs(host(chain(dev(xl))) - want).max() < DB_ABS
 
 
+def test_melspectrogram_2048_common_banks_take_the_band_sparse_kernel(tac):
+    """Banks of 40 ... 100 bands at fft_length 2048 (round 6): their lane tables (24 - 40 steps) fit beside the twelve waves of
+    melspec_stream3_kernel, but until round 6 the packer asked the older two-waves-per-SIMD kernel's LDS formula and refused them, so
+    the 2.1 x slower MFMA form ran.  Banks whose band count is not a multiple of 64 are laid out from their widest end (info[2] carries
+    ST_REV_MARK = 256): outputs must land on their own bands.  Against the float64 oracle, float32 and int16 PCM input."""
+    x = signals.audio_like((3, 1, 30000), seed=620)
+    for n_mels, sr, rev in ((40, 16000, True), (64, 16000, False), (80, 16000, True), (80, 22050, True), (100, 22050, True), (160, 16000, True)):
+        chain = torch.nn.Sequential(*tac.Melspectrogram(num_mels=n_mels, sample_rate=sr, fft_length=2048, hop_length=512),
+                                    tac.AmplitudeToDb()).cuda()
+        pack = tac._hip._melbank_pack(chain[2].filterbank, 2048)
+        assert pack is not None and (int(pack[2][2]) == 64 + (256 if rev else 0)), (n_mels, [int(v) for v in pack[2]])
+        before = launches(tac)
+        got = host(chain(dev(x)))
+        assert launched_since(tac, before) == {'tac_melspec_sparse_f32': 1}
+        fb = chain[2].filterbank.double().cpu().numpy()
+        mel = np.einsum('...ft,fm->...mt', np.abs(numpy_ref.stft(x, 2048, 512)) ** 2, fb)
+        want = 10.0 * np.log10(np.maximum(mel ** 2, 1e-7))
+        live = mel > 1e-5 * mel.max()
+        assert np.abs(got - want)[live].max() < DB_ABS, n_mels
+        lin = host(tac.realize(torch.nn.Sequential(*list(chain)[:3])(dev(x))))
+        assert rel_err(lin, mel) < 1e-5, n_mels
+    # int16 PCM through the coded-input form of the same kernel, 80 bands (reversed cells)
+    pcm = np.round(x * 32767.0).astype(np.int16)
+    chain = torch.nn.Sequential(*tac.Melspectrogram(num_mels=80, sample_rate=16000, fft_length=2048, hop_length=512)).cuda()
+    got = host(tac.realize(chain(torch.from_numpy(pcm).cuda())))
+    fb = chain[2].filterbank.double().cpu().numpy()
+    want = np.einsum('...ft,fm->...mt', np.abs(numpy_ref.stft(pcm.astype(np.float64) / 32768.0, 2048, 512)) ** 2, fb)
+    assert rel_err(got, want) < 1e-5
+
+
 def test_melspectrogram_4096_one_launch_geometries(tac):
     """The one-launch chain at fft_length 4096 (csrc/stft_n4096_s3.hpp) against the float64 oracle over what its launcher and its
     table builder decide on: band counts that fill one to four lane slots, both powers, no centring, every padding mode, a hop

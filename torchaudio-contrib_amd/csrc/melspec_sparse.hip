@@ -372,7 +372,7 @@ static int launch_stream(FrameGeom g, const Tables& tb, const SparseArgs& sm, co
                     ((reinterpret_cast<uintptr_t>(samples) & (pair - 1)) == 0);
     }
     StreamArgs m{sm.wpack, sm.desc, info_host[1], {info_host[4], info_host[5], info_host[6], info_host[7]}, sm.wtot,
-                 sm.n_mels, sm.db, sm.amin, sm.log10_ref, sm.out, total, samples, lut, 0, nullptr};
+                 sm.n_mels, sm.db, sm.amin, sm.log10_ref, sm.out, total, samples, lut, 0, nullptr, (info_host[2] & ST_REV_MARK) ? 1 : 0};
     long long blocks = (total + 2 * ST_WAVES - 1) / (2 * ST_WAVES);
     if (blocks > device_cu_count()) blocks = device_cu_count();
     if (blocks < 1) blocks = 1;
@@ -563,8 +563,10 @@ static int launch_fb_lanes(const float* spec, long long rows, int n_freqs, long 
     return TAC_OK;
 }
 
-// Lane layout of the streaming kernel: lane l owns bands l, 64 + l, ... (slot s = band / 64).  Every slot is one loop
-// of steps[s] four-tap steps (the longest band of the slot, in whole trips of four steps); shorter bands are
+// Lane layout of the streaming kernel: cell c = 64 s + l (slot s, lane l) holds band c — or, for banks whose band count is not a
+// multiple of 64 and whose bands widen with their number (every mel bank), band n_mels - 1 - c (round 6, ST_REV_MARK in info[2]): the
+// widest bands then share slot 0 instead of defining a mostly empty last slot (80 bands at 16 kHz: 24 steps instead of 32).  Every
+// slot is one loop of steps[s] four-tap steps (the longest band of the slot, in whole trips of four steps); shorter bands are
 // zero-padded, and a band whose padded run would leave the row buffer is shifted down (zeros in front) so that every
 // lane reads inside its row.
 static int pack_lanes(const std::vector<float>& h, int n_freqs, int n_mels, float* wpack, int wpack_cap, int32_t* desc,
@@ -572,17 +574,24 @@ static int pack_lanes(const std::vector<float>& h, int n_freqs, int n_mels, floa
     const int nslot = (n_mels + 63) / 64;
     if (nslot > ST_MAX_SLOTS || nslot * 64 > desc_cap) return TAC_E_UNSUPPORTED;
     const int limit = StreamCfg<1024, 16>::PROW;                             // bins + zeroed slack of a row buffer
-    std::vector<int> lo(nslot * 64, 0), len(nslot * 64, 0);
-    int steps[ST_MAX_SLOTS] = {0, 0, 0, 0};
+    std::vector<int> blo(n_mels, 0), blen(n_mels, 0);                        // per band: first bin (multiple of four), bins from there
     for (int m = 0; m < n_mels; ++m) {
         int l0 = n_freqs, h0 = 0;
         for (int f = 0; f < n_freqs; ++f)
             if (h[(size_t)f * n_mels + m] != 0.0f) { l0 = f < l0 ? f : l0; h0 = f + 1; }
         if (h0 > l0) {
-            lo[m] = l0 & ~3;
-            len[m] = h0 - lo[m];
-            steps[m / 64] = std::max(steps[m / 64], (len[m] + 3) / 4);
+            blo[m] = l0 & ~3;
+            blen[m] = h0 - blo[m];
         }
+    }
+    const bool rev = (n_mels % 64) != 0 && blen[n_mels - 1] > blen[0];
+    auto band_of = [&](int c) { return rev ? n_mels - 1 - c : c; };
+    std::vector<int> lo(nslot * 64, 0), len(nslot * 64, 0);                  // per cell
+    int steps[ST_MAX_SLOTS] = {0, 0, 0, 0};
+    for (int c = 0; c < n_mels; ++c) {
+        lo[c] = blo[band_of(c)];
+        len[c] = blen[band_of(c)];
+        steps[c / 64] = std::max(steps[c / 64], (len[c] + 3) / 4);
     }
     const bool fast_shape = nslot == 2 && (n_mels % 64) == 0 && steps[0] <= ST_FAST_STEPS0 && steps[1] <= ST_FAST_STEPS1;
     if (fast_shape) {                                                        // the shapes the FAST2 kernels are unrolled for
@@ -596,23 +605,25 @@ static int pack_lanes(const std::vector<float>& h, int n_freqs, int n_mels, floa
         total_steps += steps[s];
     }
     const long long wtot = 256LL * total_steps;
-    if (wtot > wpack_cap || stream_lds_bytes<1024, 16>((int)wtot) > 160 * 1024) return TAC_E_UNSUPPORTED;
+    // (the twelve-wave kernel's LDS decides: until round 6 this asked the two-waves-per-SIMD kernel's formula, which refused every
+    // table above ~20 steps — 80- and 96-band banks at 2048 took the two-launch chain for no reason)
+    if (wtot > wpack_cap || stream3_lds_bytes<1024, 16>((int)wtot, S3_WAVES, true) > 160 * 1024) return TAC_E_UNSUPPORTED;
     std::vector<float> wp((size_t)wtot, 0.0f);
     // bank-aware placement of the runs' first bins (lane_placement.hpp)
     const std::vector<int> start = place_band_starts(nslot, steps, lo, len);
     int base = 0;
     for (int s = 0; s < nslot; ++s) {
         for (int l = 0; l < 64; ++l) {
-            const int m = s * 64 + l;
-            int first = start[m];
+            const int c = s * 64 + l, m = c < n_mels ? band_of(c) : 0;
+            int first = start[c];
             if (first + 4 * steps[s] > limit) first = (limit - 4 * steps[s]) & ~3;     // keep the padded run inside the row
             for (int j = 0; j < steps[s]; ++j)
                 for (int u = 0; u < 4; ++u) {
                     const int bin = first + 4 * j + u;
-                    const bool live = m < n_mels && bin >= lo[m] && bin < lo[m] + len[m] && bin < n_freqs;
+                    const bool live = c < n_mels && bin >= lo[c] && bin < lo[c] + len[c] && bin < n_freqs;
                     wp[((size_t)(base + j) * 64 + l) * 4 + u] = live ? h[(size_t)bin * n_mels + m] : 0.0f;
                 }
-            lo[m] = first;
+            lo[c] = first;
         }
         base += steps[s];
     }
@@ -621,7 +632,7 @@ static int pack_lanes(const std::vector<float>& h, int n_freqs, int n_mels, floa
     TAC_HIP(hipStreamSynchronize(stream));
     info_host[0] = (int32_t)wtot;
     info_host[1] = nslot;
-    info_host[2] = 64;
+    info_host[2] = 64 + (rev ? ST_REV_MARK : 0);
     info_host[3] = total_steps;
     for (int s = 0; s < ST_MAX_SLOTS; ++s) info_host[4 + s] = steps[s];
     return TAC_OK;
@@ -743,7 +754,7 @@ int tac_melspec_sparse_f32(const float* wave, const float* window, const tac_stf
                                 (hipStream_t)stream);
     }
     const bool lanes_pack = info_host[2] >= LM_MARK;                               // mel_lanes.hpp layout
-    if (!lanes_pack && info_host[2] != sparse_groups_for(d->n_fft)) return TAC_E_INVALID;   // pack built for another geometry
+    if (!lanes_pack && (info_host[2] & ~(d->n_fft == 2048 ? ST_REV_MARK : 0)) != sparse_groups_for(d->n_fft)) return TAC_E_INVALID;   // pack built for another geometry
     FrameGeom g;
     int64_t T = 0;
     int rc = make_geometry(wave, window, d, &g, &T);
@@ -788,7 +799,7 @@ int tac_melspec_sparse_coded_f32(const void* samples, int32_t sample_format, con
     const bool small = d->n_fft == 256 || d->n_fft == 512 || d->n_fft == 1024 || d->n_fft == 400;   // lane-layout packs
     if (!d->onesided || (d->n_fft != 2048 && !small)) return TAC_E_UNSUPPORTED;
     if (power != 2.0f && power != 1.0f) return TAC_E_UNSUPPORTED;
-    if (small ? info_host[2] < LM_MARK : info_host[2] != sparse_groups_for(d->n_fft)) return small ? TAC_E_UNSUPPORTED : TAC_E_INVALID;
+    if (small ? info_host[2] < LM_MARK : (info_host[2] & ~ST_REV_MARK) != sparse_groups_for(d->n_fft)) return small ? TAC_E_UNSUPPORTED : TAC_E_INVALID;
     FrameGeom g;
     int64_t T = 0;
     int rc = make_geometry(static_cast<const float*>(samples), window, d, &g, &T);

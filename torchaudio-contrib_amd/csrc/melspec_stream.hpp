@@ -58,7 +58,9 @@ struct StreamArgs {
     const float* lut;      // device float[256]: mu-law decode table for the coded formats
     long long chunk;       // frames per workgroup = ceil(total / blocks) (melspec_stream3_kernel; the host divides once)
     unsigned long long* probe;   // diagnostics (tac_debug_clock_probe): [2 * block] = {shader cycles, 100 MHz ticks} of wave 0's frame loop; or null
+    int rev;               // cell 64 s + l is band n_mels - 1 - (64 s + l) (banks whose band count is not a multiple of 64: pack_lanes)
 };
+constexpr int ST_REV_MARK = 256;               // in info_host[2] of such a pack (below LM_MARK)
 
 // sample formats of the frame load (tac_amd.h TAC_SAMPLES_*)
 // (FMT_*: host_common.hpp)
@@ -408,7 +410,8 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
     auto s4 = [&](const float* prow, int i) {
         i = i < nloc ? i : nloc - 1;
         const f4* wp = reinterpret_cast<const f4*>(wlds) + lane;
-        float* orow = m.out + (begin + i) * (long long)m.n_mels + lane;
+        float* orow = m.out + (begin + i) * (long long)m.n_mels + (m.rev ? m.n_mels - 1 - lane : lane);
+        const int ostep = m.rev ? -64 : 64;                               // cell 64 s + lane -> its band (StreamArgs::rev)
 #pragma unroll
         for (int s = 0; s < ST_MAX_SLOTS; ++s) {
             if (s < m.nslot) {
@@ -443,7 +446,7 @@ melspec_stream_kernel(FrameGeom g, Tables tb, StreamArgs m) {
                 for (; j < n; ++j, wp += 64) fma4(wp[0], pp[j], acc0, acc1);   // (slot lengths that are not whole half-trips: the 14-step layout)
                 float v = (acc0.x + acc0.y) + (acc1.x + acc1.y);
                 if (m.db) v = fast_db ? amp_to_db_fast(v, m.amin, ten_log10_ref) : amp_to_db(v, m.amin, m.log10_ref);
-                if (FULLM || s * 64 + lane < m.n_mels) orow[s * 64] = v;
+                if (FULLM || s * 64 + lane < m.n_mels) orow[s * ostep] = v;
             }
         }
     };

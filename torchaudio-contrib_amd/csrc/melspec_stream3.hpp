@@ -505,7 +505,8 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         } else {
             const int ci = cur < nloc ? cur : nloc - 1;
             const f4* wp = reinterpret_cast<const f4*>(wlds) + lane;
-            float* orow = m.out + (begin + place(ci)) * (long long)m.n_mels + lane;
+            float* orow = m.out + (begin + place(ci)) * (long long)m.n_mels + (m.rev ? m.n_mels - 1 - lane : lane);
+            const int ostep = m.rev ? -64 : 64;                           // cell 64 s + lane -> its band (StreamArgs::rev)
 #pragma unroll
             for (int s = 0; s < ST_MAX_SLOTS; ++s) {
                 if (s < m.nslot) {
@@ -540,7 +541,7 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
                     for (; j < n; ++j, wp += 64) fma4(wp[0], pp[j], acc0, acc1);
                     float val = (acc0.x + acc0.y) + (acc1.x + acc1.y);
                     if (m.db) val = fast_db ? amp_to_db_fast(val, m.amin, ten_log10_ref) : amp_to_db(val, m.amin, m.log10_ref);
-                    if (s * 64 + lane < m.n_mels) orow[s * 64] = val;
+                    if (s * 64 + lane < m.n_mels) orow[s * ostep] = val;
                 }
             }
         }
