@@ -23,6 +23,7 @@ __host__ __device__ constexpr int sm_mel_pitch(int nc) { return (nc + 1 + 3 + 3)
 #define TAC_SM_FLY 6
 #endif
 constexpr int SM_FLY = TAC_SM_FLY;       // contraction steps in flight (the packed layout depends on it: groups of slots)
+constexpr int SM_MAX_STEPS_1024 = 20;    // fft_length 1024, float32 input: four-tap steps of the widest band (80 bins; LM_MAX_STEPS = 12 elsewhere)
 }  // namespace tac
 #include "stft_small3.hpp"
 namespace tac {
@@ -327,7 +328,7 @@ static int launch_small_mel_coded_nc(const FrameGeom& g, const Tables& tb, const
 #define TAC_SM_CASE(SS) case SS: return launch_small_mel_coded<NC, SS, FMT>(g, tb, mel, stream, samples, lut);
         TAC_SM_CASE(2) TAC_SM_CASE(4) TAC_SM_CASE(6) TAC_SM_CASE(8) TAC_SM_CASE(10) TAC_SM_CASE(12)
 #undef TAC_SM_CASE
-        default: return TAC_E_INVALID;
+        default: return S > LM_MAX_STEPS && S <= SM_MAX_STEPS_1024 ? TAC_E_UNSUPPORTED : TAC_E_INVALID;   // (wide-band tables: float32 input only)
     }
 }
 
@@ -346,8 +347,17 @@ static int launch_small_mel_nc(const FrameGeom& g, const Tables& tb, float power
 #define TAC_SM_CASE(SS) case SS: return p2 ? launch_small_mel<NC, 1, SS>(g, tb, mel, stream) : launch_small_mel<NC, 2, SS>(g, tb, mel, stream);
         TAC_SM_CASE(2) TAC_SM_CASE(4) TAC_SM_CASE(6) TAC_SM_CASE(8) TAC_SM_CASE(10) TAC_SM_CASE(12)
 #undef TAC_SM_CASE
-        default: return TAC_E_INVALID;
+        default: break;
     }
+    if constexpr (NC == 512) {                                             // fft_length 1024: bands up to 80 bins (40- and 64-band banks; round 6)
+        switch (S) {
+#define TAC_SM_CASE(SS) case SS: return p2 ? launch_small_mel<NC, 1, SS>(g, tb, mel, stream) : launch_small_mel<NC, 2, SS>(g, tb, mel, stream);
+            TAC_SM_CASE(14) TAC_SM_CASE(16) TAC_SM_CASE(18) TAC_SM_CASE(20)
+#undef TAC_SM_CASE
+            default: break;
+        }
+    }
+    return TAC_E_INVALID;
 }
 
 // The fused Melspectrogram (+dB) chain for fft_length 512 / 1024 (melspec_sparse.hip's entry points call these).
@@ -355,7 +365,8 @@ int launch_small_mel_entry(int n_fft, const FrameGeom& g, const Tables& tb, floa
                            const int32_t* info_host, int n_mels, int db, float amin, float log10_ref, float* out,
                            hipStream_t stream, int fmt, const void* samples, const float* lut) {
     const int lanes = n_fft / 32;
-    if ((n_fft != 256 && n_fft != 512 && n_fft != 1024) || !lane_mel_info_ok(info_host, lanes, SM_FLY)) return TAC_E_INVALID;
+    if ((n_fft != 256 && n_fft != 512 && n_fft != 1024) || !lane_mel_info_ok(info_host, lanes, SM_FLY, n_fft == 1024 ? SM_MAX_STEPS_1024 : LM_MAX_STEPS))
+        return TAC_E_INVALID;
     if (n_mels < LM_MIN_MELS || n_mels > LM_MAX_MELS) return TAC_E_UNSUPPORTED;
     const LaneMel mel{wpack, desc, info_host[1], info_host[0], n_mels, db, amin, log10_ref, out};
     if (fmt != FMT_F32) {
@@ -377,7 +388,7 @@ int pack_small(int n_fft, const std::vector<float>& h, int n_freqs, int n_mels, 
     if (n_fft == 256 && !small3_waves()) return TAC_E_UNSUPPORTED;        // (TAC_SMALL2=1: the three-phase kernel's layout)
     const int lanes = n_fft / 32;
     const size_t base = n_fft == 256 ? small3_lds_bytes<128>(12) : (n_fft == 512 ? small_lds_bytes<256>() : small_lds_bytes<512>());
-    return pack_lane_mel(h, n_freqs, n_mels, lanes, sm_mel_pitch(n_fft / 2), 2, SM_FLY, LM_MAX_STEPS, base, wpack, wpack_cap, desc, desc_cap,
+    return pack_lane_mel(h, n_freqs, n_mels, lanes, sm_mel_pitch(n_fft / 2), 2, SM_FLY, n_fft == 1024 ? SM_MAX_STEPS_1024 : LM_MAX_STEPS, base, wpack, wpack_cap, desc, desc_cap,
                          info_host, stream);
 }
 
