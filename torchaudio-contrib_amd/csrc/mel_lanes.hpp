@@ -27,6 +27,7 @@ struct LaneMel {
     int nslot, wtot, n_mels, db;
     float amin, log10_ref;
     float* out;                 // [rows][T][n_mels]
+    int rev;                    // cell LANES i + l holds band n_mels - 1 - (LANES i + l) (info[5]; pack_lane_mel)
 };
 
 constexpr int LM_MAX_MELS = 128, LM_MIN_MELS = 8, LM_MAX_STEPS = 12;
@@ -114,8 +115,8 @@ __device__ __forceinline__ void lane_mel_contract(float* srow, int bins, const i
             lm_slot_dispatch<(S + 1) / 2, S, LANES, FLY>(pairs, wp, pp, acc0, acc1);
             float val = (acc0.x + acc0.y) + (acc1.x + acc1.y);
             if (mel.db) val = fast_db ? amp_to_db_fast(val, mel.amin, ten_log10_ref) : amp_to_db(val, mel.amin, mel.log10_ref);
-            const int band = LANES * i0 + l;
-            if (band < mel.n_mels) mrow[band] = val;
+            const int cell = LANES * i0 + l;
+            if (cell < mel.n_mels) mrow[mel.rev ? mel.n_mels - 1 - cell : cell] = val;
         }
         return;
     }
@@ -147,8 +148,8 @@ __device__ __forceinline__ void lane_mel_contract(float* srow, int bins, const i
             }
             float val = (acc0.x + acc0.y) + (acc1.x + acc1.y);
             if (mel.db) val = fast_db ? amp_to_db_fast(val, mel.amin, ten_log10_ref) : amp_to_db(val, mel.amin, mel.log10_ref);
-            const int band = LANES * (i0 + q) + l;
-            if (band < mel.n_mels) mrow[band] = val;
+            const int cell = LANES * (i0 + q) + l;
+            if (cell < mel.n_mels) mrow[mel.rev ? mel.n_mels - 1 - cell : cell] = val;
         }
     }
 }
@@ -189,17 +190,28 @@ inline int pack_lane_mel(const std::vector<float>& h, int n_freqs, int n_mels, i
                          hipStream_t stream) {
     if (n_mels < LM_MIN_MELS || n_mels > LM_MAX_MELS) return TAC_E_UNSUPPORTED;
     const int nslot = (n_mels + lanes - 1) / lanes;
-    std::vector<int> lo(nslot * lanes, 0), hi(nslot * lanes, 0);
+    std::vector<int> blo(n_mels, 0), bhi(n_mels, 0);                       // per band
     int S = 1;
     for (int m = 0; m < n_mels; ++m) {
         int l0 = n_freqs, h0 = 0;
         for (int f = 0; f < n_freqs; ++f)
             if (h[(size_t)f * n_mels + m] != 0.0f) { l0 = f < l0 ? f : l0; h0 = f + 1; }
         if (h0 > l0) {
-            lo[m] = l0;
-            hi[m] = h0;
+            blo[m] = l0;
+            bhi[m] = h0;
             S = std::max(S, (h0 - (l0 & ~3) + 3) / 4);
         }
+    }
+    // Round 6: a bank whose band count is not a multiple of `lanes` and whose bands widen with their number (every mel bank) is laid out
+    // from its widest end — cell c = lanes i + l holds band n_mels - 1 - c (info[5] = 1, LaneMel::rev) — so that the widest bands share
+    // slot 0 instead of defining a partly empty last slot; every slot runs the steps of ITS longest band (80 bands on 32 lanes: 14
+    // steps per frame instead of 17)
+    const bool rev = (n_mels % lanes) != 0 && (bhi[n_mels - 1] - blo[n_mels - 1]) > (bhi[0] - blo[0]);
+    auto band_of = [&](int c) { return rev ? n_mels - 1 - c : c; };
+    std::vector<int> lo(nslot * lanes, 0), hi(nslot * lanes, 0);           // per cell
+    for (int c = 0; c < n_mels; ++c) {
+        lo[c] = blo[band_of(c)];
+        hi[c] = bhi[band_of(c)];
     }
     S = ((S + step_quantum - 1) / step_quantum) * step_quantum;            // (the kernels are instantiated for these values of S only)
     if (S > max_steps || 4 * S > pitch) return TAC_E_UNSUPPORTED;          // bands too wide: the unfused chain
@@ -219,7 +231,7 @@ inline int pack_lane_mel(const std::vector<float>& h, int n_freqs, int n_mels, i
                 for (int u = 0; u < 4; ++u) {
                     const int bin = first + 4 * j + u;
                     const bool live = m < n_mels && bin >= lo[m] && bin < hi[m];
-                    wp[(((size_t)i * S + j) * lanes + l) * 4 + u] = live ? h[(size_t)bin * n_mels + m] : 0.0f;
+                    wp[(((size_t)i * S + j) * lanes + l) * 4 + u] = live ? h[(size_t)bin * n_mels + band_of(m)] : 0.0f;
                 }
             dd[lanes * i + l] = first;
             if (m < n_mels && hi[m] > lo[m]) {
@@ -236,7 +248,8 @@ inline int pack_lane_mel(const std::vector<float>& h, int n_freqs, int n_mels, i
     info_host[2] = LM_MARK + lanes;
     info_host[3] = S * nslot;
     info_host[4] = S;
-    for (int i = 5; i < 8; ++i) info_host[i] = 0;
+    info_host[5] = rev ? 1 : 0;
+    for (int i = 6; i < 8; ++i) info_host[i] = 0;
     return TAC_OK;
 }
 

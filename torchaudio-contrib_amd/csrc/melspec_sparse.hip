@@ -846,7 +846,7 @@ int tac_apply_filterbank_sparse_db_f32(const float* spec, int64_t rows, int32_t 
         if (!lane_mel_info_ok(info_host, 64, fbl_fly(n_freqs), LM_MAX_STEPS_WAVE)) return TAC_E_INVALID;
         const int chunks = (n_freqs + 3) / 4;
         if (n_mels < LM_MIN_MELS || n_mels > LM_MAX_MELS || chunks > FBL_CHUNKS_WIDE * 64) return TAC_E_UNSUPPORTED;
-        const LaneMel lm{wpack, desc, info_host[1], info_host[0], n_mels, db ? 1 : 0, db_amin, log10_ref, out};
+        const LaneMel lm{wpack, desc, info_host[1], info_host[0], n_mels, db ? 1 : 0, db_amin, log10_ref, out, info_host[5] ? 1 : 0};
         const long long sr = rows > 1 ? stride_r : 0;
         const bool wide = chunks > FBL_CHUNKS * 64;
         switch (info_host[4]) {

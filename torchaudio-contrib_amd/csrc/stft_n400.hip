@@ -473,7 +473,7 @@ int launch_n400_mel(const FrameGeom& g, float power, const float* wpack, const i
     Q4Tables tb;
     const int rc = q4_tables(&tb);
     if (rc != TAC_OK) return rc;
-    const LaneMel mel{wpack, desc, info_host[1], info_host[0], n_mels, db, amin, log10_ref, out};
+    const LaneMel mel{wpack, desc, info_host[1], info_host[0], n_mels, db, amin, log10_ref, out, info_host[5] ? 1 : 0};
     if (fmt != FMT_F32) {
         if (power != 2.0f) return TAC_E_UNSUPPORTED;
         switch (fmt) {

@@ -368,7 +368,7 @@ int launch_small_mel_entry(int n_fft, const FrameGeom& g, const Tables& tb, floa
     if ((n_fft != 256 && n_fft != 512 && n_fft != 1024) || !lane_mel_info_ok(info_host, lanes, SM_FLY, n_fft == 1024 ? SM_MAX_STEPS_1024 : LM_MAX_STEPS))
         return TAC_E_INVALID;
     if (n_mels < LM_MIN_MELS || n_mels > LM_MAX_MELS) return TAC_E_UNSUPPORTED;
-    const LaneMel mel{wpack, desc, info_host[1], info_host[0], n_mels, db, amin, log10_ref, out};
+    const LaneMel mel{wpack, desc, info_host[1], info_host[0], n_mels, db, amin, log10_ref, out, info_host[5] ? 1 : 0};
     if (fmt != FMT_F32) {
         if (power != 2.0f) return TAC_E_UNSUPPORTED;
         switch (fmt) {
