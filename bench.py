@@ -51,6 +51,9 @@ def parse():
                     help='back-to-back repetitions of the K-step timed region; the median region is reported')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-stages', action='store_true')
+    ap.add_argument('--no-live-counters', action='store_true',
+                    help='do not run the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic in this '
+                         'run; the committed counter pass of the same kernel is quoted instead')
     ap.add_argument('--config', choices=('cfg2', 'cfg3'), default='cfg2',
                     help='cfg2 (default): BASELINE configs[1], 256 x 16 kHz x 10 s per GPU — the configuration the metric '
                          'is quoted on, at every N (weak scaling).  cfg3: configs[2]\'s per-GPU shard, 256 x 44.1 kHz x '
@@ -125,13 +128,17 @@ N_SIMD = 256 * 4                                    # MI355X: 256 CUs x 4 SIMDs
 F32_VECTOR_PEAK_TFLOPS = 157.3                      # MI355X_MICROARCH.md: packed f32 vector peak
 
 
-def bound_from_counters(roof, route, clock_mhz):
-    """Fill roofline.traffic / valu_floor_ms / lds_busy / bound from the committed rocprofv3 counter passes of THIS kernel
-    (profiles/rNN/pmc_mel.json — bench.py cannot run the profiler on itself; instruction counts and busy cycles per launch
-    are properties of the kernel binary and the workload, the clock is measured live).  The entry must carry the name of
-    the kernel the library just launched; otherwise the fields stay null and say why."""
+def bound_from_counters(roof, route, clock_mhz, live=None, live_note=None):
+    """Fill roofline.traffic / valu_floor_ms / lds_busy / bound from rocprofv3 counter passes of THIS kernel: `live` (round 6: the
+    passes live_counters() ran as child processes of this very run) or, without it, the committed ones (profiles/rNN/pmc_mel.json;
+    instruction counts and busy cycles per launch are properties of the kernel binary and the workload, the clock is measured live).
+    The entry must carry the name of the kernel the library just launched; otherwise the fields stay null and say why."""
     entry, source = None, None
-    for rnd in ('r06', 'r05', 'r04', 'r03'):
+    if live is not None:
+        roof['counters_committed_pass'] = {k: roof.get(k) for k in ('traffic', 'valu_floor_ms', 'lds_busy', 'counters_source')}
+        roof['counters_source'] = live_note
+        entry = live
+    for rnd in (() if live is not None else ('r06', 'r05', 'r04', 'r03')):
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', rnd, 'pmc_mel.json')))
         except Exception:            # noqa: BLE001
@@ -145,7 +152,8 @@ def bound_from_counters(roof, route, clock_mhz):
     if entry is None:
         roof['counters_note'] = 'no committed counter pass names the launched kernel (%s): traffic / bound not derived' % route
         return
-    roof['counters_source'] = source + ' (rocprofv3 --pmc, separate passes; FETCH_SIZE x2 gfx950 correction applied)'
+    if live is None:
+        roof['counters_source'] = source + ' (rocprofv3 --pmc, separate passes; FETCH_SIZE x2 gfx950 correction applied)'
     if 'hbm_traffic_bytes_per_launch' in entry:
         roof['traffic'] = entry['hbm_traffic_bytes_per_launch']
     busy = {}
@@ -171,6 +179,53 @@ def bound_from_counters(roof, route, clock_mhz):
     roof['bound'] = max(busy, key=busy.get)
     roof['bound_note'] = ('the busiest resource by the counters; `frac` / `peak` stay the HBM figure the contract asks for '
                           '(algorithmic bytes / kernel time / 8 TB/s)')
+
+
+def live_counters(route, timeout=240):
+    """The counter entry of the launched kernel measured in THIS run: three child processes `rocprofv3 --pmc ...` (separate passes, as
+    MI355X_MICROARCH.md prescribes: FETCH_SIZE; WRITE_SIZE; the SQ busy counters) around `tools/prof_driver.py mel 3` — the same kernel
+    on one cfg-2 batch — per-launch means of the kernel's rows, HBM bytes with the guide's gfx950 corrections (FETCH_SIZE in KB, x2 for
+    wide coalesced reads; WRITE_SIZE in KB).  Returns (entry, note) or (None, why).  Never raises; the timed regions are over when it runs."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which('rocprofv3')
+    if exe is None:
+        return None, 'rocprofv3 not on PATH'
+    tmp = tempfile.mkdtemp(prefix='tac_bench_pmc_')
+    env = dict(os.environ, TMPDIR='/tmp')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    entry = {}
+    try:
+        for tag, counters in (('fetch', ['FETCH_SIZE']), ('write', ['WRITE_SIZE']),
+                              ('sq', ['SQ_ACTIVE_INST_VALU', 'SQ_BUSY_CU_CYCLES', 'SQ_LDS_IDX_ACTIVE', 'SQ_VALU_MFMA_BUSY_CYCLES'])):
+            out = os.path.join(tmp, tag)
+            cmd = [exe, '--pmc'] + counters + ['--output-format', 'csv', '-d', out, '-o', 'p', '--', sys.executable,
+                                               os.path.join(ROOT, 'tools', 'prof_driver.py'), 'mel', '3']
+            proc = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout)
+            vals = {}
+            for f in glob.glob(out + '/**/*counter_collection.csv', recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r.get('Counter_Name') in counters and route and route in r.get('Kernel_Name', ''):
+                        vals.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
+            if tag != 'sq' and not vals:
+                return None, 'rocprofv3 --pmc %s (exit %d) produced no row for %s' % (counters[0], proc.returncode, route)
+            for c, v in vals.items():
+                entry[c] = sum(v) / len(v)
+        entry['hbm_read_bytes_corrected'] = entry['FETCH_SIZE'] * 2048.0
+        entry['hbm_write_bytes'] = entry['WRITE_SIZE'] * 1024.0
+        entry['hbm_traffic_bytes_per_launch'] = entry['hbm_read_bytes_corrected'] + entry['hbm_write_bytes']
+        return entry, ('measured in this run: rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE; SQ busy counters) as separate child processes '
+                       'around tools/prof_driver.py mel 3 (the same kernel on one cfg-2 batch), per-launch means, FETCH_SIZE x2 gfx950 '
+                       'correction applied; read %.1f MB + written %.1f MB'
+                       % (entry['hbm_read_bytes_corrected'] / 1e6, entry['hbm_write_bytes'] / 1e6))
+    except Exception as exc:            # noqa: BLE001
+        return None, '%s: %s' % (type(exc).__name__, exc)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def rccl_debug_lines(path, limit=16):
@@ -679,6 +734,13 @@ def run(a):
             result['rccl_debug'] = rccl_debug_lines(rccl_log)
     if rank == 0 and world == 1 and x_host is not None:
         result['cpu_baseline'] = cpu_baseline(x_host)
+    if rank == 0 and world == 1 and not a.no_live_counters and os.environ.get('TAC_BENCH_LIVE_COUNTERS', '1') != '0':
+        roof = result['roofline']
+        live, note = live_counters(route)
+        if live is not None:
+            bound_from_counters(roof, route, clock_mhz, live, note)
+        else:
+            roof['counters_note'] = 'committed counter pass quoted; a live pass was not possible: %s' % note
     if rank == 0:
         print(json.dumps(result))
     if distributed:

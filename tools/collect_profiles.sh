@@ -9,9 +9,9 @@ mkdir -p $out
 cd ${GRAFT_REPO_ROOT:-.}
 python bench.py > $out/bench_N1.json 2> $out/bench_N1.err
 # the headline steps alone (the stages launch the same kernel on other sizes: their launches would dilute its average) ...
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o bench -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-stages > $out/kt_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o bench -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-stages --no-live-counters > $out/kt_bench.log 2>&1
 # ... and the same command with its stages (every other kernel the bench line quotes)
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_stages -o bench -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline > $out/kt_stages.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_stages -o bench -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-live-counters > $out/kt_stages.log 2>&1
 for k in mel stft spec spec4096 mel4096; do
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_${k}_fetch -o p -- python tools/prof_driver.py $k 3 > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_${k}_write -o p -- python tools/prof_driver.py $k 3 > /dev/null 2>&1
