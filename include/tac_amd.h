@@ -206,6 +206,13 @@ int tac_phase_vocoder_f64(const double* spec, int64_t rows, int32_t n_freqs, int
                           int64_t stride_r, int64_t stride_f, int64_t stride_t,
                           const double* phase_advance, const int32_t* idx0, const int32_t* idx1,
                           const double* alpha, int64_t n_out, double* out, void* stream);
+/* ... and its gradient with respect to the spectrogram (round 6; float32): grad_out [rows][n_out][n_freqs][2] and grad_spec
+ *      [rows][n_frames][n_freqs][2] frame-major and dense, grad_spec ZERO-INITIALISED by the caller (the kernel accumulates: a source frame
+ *      is read by several output frames when rate < 1, by none when rate > 2); spec, strides and the grid (idx0, idx1, alpha) as in the
+ *      forward call.  The gradient with respect to phase_advance is zero (the wrap and the advance cancel). */
+int tac_phase_vocoder_backward_f32(const float* spec, int64_t rows, int32_t n_freqs, int64_t n_frames, int64_t stride_r,
+                                   int64_t stride_f, int64_t stride_t, const int32_t* idx0, const int32_t* idx1, const float* alpha,
+                                   int64_t n_out, const float* grad_out, float* grad_spec, void* stream);
 
 /* (1d)-(6d) The path in float64 (the reference keeps f64 -> f64: functional.py:48-113, :116-128, :172-184, :187-201,
  *      :277-314).  Same argument meaning as the _f32 entry points with double data; d->n_fft: any even length <= 8192 whose

@@ -130,9 +130,11 @@ def test_fuzz_spectrogram(tac):
         chain = torch.nn.Sequential(*layer, tac.AmplitudeToDb(ref=1.0, amin=1e-10)).cuda()
         got_db = host(chain(dev(x)))
         want_db = torch_ref.amplitude_to_db(torch.from_numpy(want), ref=1.0, amin=1e-10).numpy()
-        # a single bin may sit at cancellation level, where fp32's absolute error (~3e-7 of the maximum, checked above)
-        # is a large relative one: the dB epilogue is pinned on the bins that carry signal
-        big = want > 1e-2 * want.max()
+        # a single bin may sit at cancellation level, where fp32's absolute error (~3e-7 of the maximum AMPLITUDE, checked above)
+        # is a large relative one: the dB epilogue is pinned on the bins that carry signal — amplitude above 3 % of the maximum,
+        # whatever the power (round 6: the mask used to be taken on |X|^power, which for power 0.7 let bins at 0.14 % of the
+        # maximum amplitude through, where 3.6e-7 of the maximum is 1.6e-3 dB: soak seed 8, case 108, fft_length 2602)
+        big = want > (3e-2 ** power) * want.max()
         assert np.abs(got_db - want_db)[big].max() < DB_ABS, tag
 
 

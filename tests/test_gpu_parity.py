@@ -1662,6 +1662,41 @@ def test_elementwise_gradient_kernels(tac):
         assert np.abs(host(got_t).swapaxes(-1, -2) - want_d.numpy()).max() < 2e-6 * np.abs(want_d.numpy()).max()
 
 
+def test_phase_vocoder_gradient_kernel(tac):
+    """d phase_vocoder / d spec on the gfx950 kernel (round 6; strict mode is on) against torch.autograd through the float64 oracle: rates
+    below and above one (a source frame read by several / by no output frame), the strided pairs the STFT kernels return, a chain
+    STFT -> TimeStretch -> ComplexNorm differentiated down to the waveform; the gradient of phase_advance is zero, as autograd finds."""
+    rng = np.random.default_rng(91)
+    n_freqs, n_frames, hop = 65, 47, 32
+    z_np = rng.standard_normal((2, 3, n_freqs, n_frames, 2)).astype(np.float32)
+    pa_np = np.linspace(0, np.pi * hop, n_freqs, dtype=np.float32)[:, None]
+    for rate in (0.6, 1.0, 1.3, 2.5):
+        zr = torch.from_numpy(z_np).double().requires_grad_(True)
+        par = torch.from_numpy(pa_np).double().requires_grad_(True)
+        outr = torch_ref.phase_vocoder(zr, rate, par)
+        g_np = rng.standard_normal(tuple(outr.shape)).astype(np.float32)
+        want, want_pa = torch.autograd.grad(outr, [zr, par], torch.from_numpy(g_np).double())
+        assert float(want_pa.abs().max()) < 1e-9
+        z = dev(z_np).requires_grad_(True)
+        pa = dev(pa_np).requires_grad_(True)
+        before = launches(tac)
+        out = tac.phase_vocoder(z, rate, pa)
+        got, got_pa = torch.autograd.grad(out, [z, pa], dev(g_np))
+        assert launched_since(tac, before).get('tac_phase_vocoder_backward_f32') == 1
+        assert float(got_pa.abs().max()) == 0.0
+        assert rel_err(host(got), want.numpy()) < 2e-4, rate          # (1 / |z| amplifies float32 rounding at the smallest bins)
+    x_np = signals.audio_like((2, 1, 5000), seed=92)
+    xr = torch.from_numpy(x_np).double().requires_grad_(True)
+    adv = torch.linspace(0, np.pi * 64, 129, dtype=torch.float64)[:, None]
+    yr = torch_ref.complex_norm(torch_ref.phase_vocoder(torch_ref.stft(xr, 256, 64), 1.25, adv), 2.0)
+    c_np = rng.standard_normal(tuple(yr.shape)).astype(np.float32)
+    (want_x,) = torch.autograd.grad((yr * torch.from_numpy(c_np).double()).sum(), xr)
+    x = dev(x_np).requires_grad_(True)
+    chain = torch.nn.Sequential(tac.STFT(256, 64), tac.TimeStretch(64, 129, fixed_rate=1.25), tac.ComplexNorm(2.0)).cuda()
+    (got_x,) = torch.autograd.grad((tac.realize(chain(x)) * dev(c_np)).sum(), x)
+    assert rel_err(host(got_x), want_x.numpy()) < 1e-3
+
+
 def test_g8_hpss(tac, golden):
     """hpss on the HIP kernel: golden outputs of the reference (the medians select existing values, so
     harm / perc are exact up to pow and the mask quotient), the strided spectrogram the STFT kernels return, unequal

@@ -665,6 +665,32 @@ def phase_vocoder(spec, rate, phase_advance):
     return out.transpose(-3, -2)
 
 
+def phase_vocoder_backward(spec, rate, grad_out):
+    """Gradient of the float32 ``phase_vocoder`` with respect to ``spec`` (*, F, T, 2): ``grad_out`` (*, F, n_out, 2) in any layout;
+    the result is frame-major like the forward's output."""
+    n_freqs, n_frames = spec.shape[-3], spec.shape[-2]
+    lead = tuple(spec.shape[:-3])
+    idx0, idx1, alpha = _phase_vocoder_grid(n_frames, rate, spec.device, torch.float32)
+    n_out = idx0.numel()
+    if spec.stride(-1) != 1:
+        spec = spec.contiguous()
+    rows = spec.reshape((-1,) + tuple(spec.shape[-3:]))
+    if any(st % 2 for st in rows.stride()[:-1]) or rows.data_ptr() % (2 * rows.element_size()):
+        rows = rows.contiguous()
+    go = torch.empty(lead + (n_out, n_freqs, 2), dtype=torch.float32, device=spec.device)      # frame-major, dense
+    go.transpose(-3, -2).copy_(grad_out)
+    gs = torch.zeros(lead + (n_frames, n_freqs, 2), dtype=torch.float32, device=spec.device)    # the kernel accumulates into it
+    if go.numel() and n_frames:
+        with _native.on_device(spec.device):
+            rc = _native.lib().tac_phase_vocoder_backward_f32(
+                _native.ptr(rows), rows.shape[0], n_freqs, n_frames, rows.stride(0) if rows.shape[0] > 1 else 0,
+                rows.stride(1), rows.stride(2), _native.ptr(idx0), _native.ptr(idx1), _native.ptr(alpha), n_out,
+                _native.ptr(go), _native.ptr(gs), _native.stream_ptr(spec.device))
+        _native.check(rc, 'tac_phase_vocoder_backward_f32')
+        _count('tac_phase_vocoder_backward_f32')
+    return gs.transpose(-3, -2)
+
+
 # ----------------------------------------------------------------------------- elementwise
 def _unary(x, name, launch):
     x = x if is_dense(x) else x.contiguous()

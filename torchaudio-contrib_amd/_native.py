@@ -28,7 +28,7 @@ EXPORTS = (
     'tac_strerror', 'tac_last_hip_error', 'tac_abi_version', 'tac_num_frames', 'tac_num_bins',
     'tac_stft_f32', 'tac_spectrogram_f32', 'tac_melspec_f32', 'tac_melspec_supported', 'tac_filterbank_plan',
     'tac_melbank_pack', 'tac_melspec_sparse_f32',
-    'tac_apply_filterbank_f32', 'tac_apply_filterbank_sparse_f32', 'tac_apply_filterbank_sparse_db_f32', 'tac_complex_norm_f32', 'tac_magphase_f32', 'tac_phase_vocoder_f32', 'tac_phase_vocoder_f64', 'tac_amplitude_to_db_f32',
+    'tac_apply_filterbank_f32', 'tac_apply_filterbank_sparse_f32', 'tac_apply_filterbank_sparse_db_f32', 'tac_complex_norm_f32', 'tac_magphase_f32', 'tac_phase_vocoder_f32', 'tac_phase_vocoder_f64', 'tac_phase_vocoder_backward_f32', 'tac_amplitude_to_db_f32',
     'tac_db_to_amplitude_f32', 'tac_mulaw_encode_f32_i64', 'tac_mulaw_decode_i64_f32',
     'tac_mulaw_decode_f32_f32', 'tac_mulaw_encode_f64_i64', 'tac_mulaw_decode_f64',
     'tac_stft_backward_f32', 'tac_stft_norm_backward_f32', 'tac_spectrogram_backward_f32', 'tac_spectrogram_backward_ola_workspace', 'tac_spectrogram_backward_ola_f32', 'tac_melspectrogram_backward_ola_f32', 'tac_melspectrogram_backward_f32', 'tac_filterbank_adjoint_pack', 'tac_apply_filterbank_adjoint_f32', 'tac_overlap_add_f32', 'tac_complex_norm_backward_f32', 'tac_amplitude_to_db_backward_f32', 'tac_magphase_backward_f32', 'tac_db_to_amplitude_backward_f32', 'tac_hpss_f32', 'tac_melspec_sparse_coded_f32', 'tac_pcm16_to_f32',
@@ -124,6 +124,7 @@ def lib():
         h.tac_magphase_f32.argtypes = [_P, _I64, _F, _P, _P, _P]
         h.tac_phase_vocoder_f32.argtypes = [_P, _I64, _I32, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _I64, _P, _P]
         h.tac_phase_vocoder_f64.argtypes = h.tac_phase_vocoder_f32.argtypes
+        h.tac_phase_vocoder_backward_f32.argtypes = [_P, _I64, _I32, _I64, _I64, _I64, _I64, _P, _P, _P, _I64, _P, _P, _P]
         h.tac_amplitude_to_db_f32.argtypes = [_P, _I64, _F, _F, _P, _P]
         h.tac_stft_f64.argtypes = [_P, _P, _DESC, _P, _P]
         h.tac_spectrogram_f64.argtypes = [_P, _P, _DESC, _D, _I32, _D, _D, _P, _P]

@@ -293,6 +293,14 @@ def _magphase_hip_backward(saved, rest, needs, grads):
     return [H.magphase_backward(saved[0], grads[0], grads[1], rest[0])]
 
 
+def _phase_vocoder_hip_backward(saved, rest, needs, grads):
+    spec, phase_advance = saved
+    if grads[0] is None or spec.shape[-1] != 2 or spec.dim() < 3:
+        return None
+    return [H.phase_vocoder_backward(spec, rest[0], grads[0]) if needs[0] else None,
+            torch.zeros_like(phase_advance) if needs[1] else None]       # (the wrap and the advance cancel: zero, as autograd finds)
+
+
 def _db_to_amplitude_hip_backward(saved, rest, needs, grads):
     if grads[0] is None or not rest[0] > 0.0:
         return None
@@ -302,7 +310,8 @@ def _db_to_amplitude_hip_backward(saved, rest, needs, grads):
 _HIP_BACKWARD = {'stft': _stft_hip_backward, 'spectrogram': _spectrogram_hip_backward,
                  'melspectrogram': _melspectrogram_hip_backward, 'apply_filterbank': _apply_filterbank_hip_backward,
                  'complex_norm': _complex_norm_hip_backward, 'amplitude_to_db': _amplitude_to_db_hip_backward,
-                 'angle': _angle_hip_backward, 'magphase': _magphase_hip_backward, 'db_to_amplitude': _db_to_amplitude_hip_backward}
+                 'angle': _angle_hip_backward, 'magphase': _magphase_hip_backward, 'db_to_amplitude': _db_to_amplitude_hip_backward,
+                 'phase_vocoder': _phase_vocoder_hip_backward}
 
 
 #: the CUDA-key kernels by op name: `call` below invokes them directly when the dispatcher has nothing to add

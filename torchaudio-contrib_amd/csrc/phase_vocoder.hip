@@ -183,6 +183,88 @@ phase_vocoder_kernel(const T* __restrict__ spec, long long rows, int n_freqs, in
     }
 }
 
+// Gradient of the float32 recurrence with respect to the spectrogram (round 6).  out_j = mag_j e^{i acc_j}, mag_j = alpha_j |s1_j| +
+// (1 - alpha_j) |s0_j|, acc_j = angle(first) + sum_{i<j} (angle(s1_i) - angle(s0_i)) modulo whole turns (the wrap and the phase advance
+// have no derivative: d/d(phase_advance) = 0, as torch.autograd finds through torch.round).  With g_j the incoming gradient:
+//   g_mag_j = Re(conj(u_j) g_j),  g_acc_j = mag_j Im(conj(u_j) g_j),  u_j = e^{i acc_j};
+//   d/d angle(s1_i) = G_i = sum_{j>i} g_acc_j,  d/d angle(s0_i) = -G_i,  d/d angle(first) = sum_j g_acc_j;
+//   d/d|s1_j| = alpha_j g_mag_j,  d/d|s0_j| = (1 - alpha_j) g_mag_j;   d|z|/dz = z / |z|,  d angle(z)/dz = (-im, re) / |z|^2 (0 at z = 0).
+// One lane owns one (row, frequency) series, like the forward kernel, and walks it twice with the forward recurrence: the first walk sums
+// g_acc, the second forms the suffix sums as total - prefix and adds every step's two contributions to the (zero-initialised, frame-major)
+// gradient — plain read-modify-writes: no other lane touches the series.  The zero padding past the last frame takes no gradient.
+__global__ void __launch_bounds__(PV_THREADS)
+phase_vocoder_backward_kernel(const float* __restrict__ spec, long long rows, int n_freqs, int n_frames, long long stride_r,
+                              long long stride_f, long long stride_t, const int* __restrict__ idx0, const int* __restrict__ idx1,
+                              const float* __restrict__ alpha, int n_out, const float* __restrict__ gout, float* __restrict__ gspec) {
+    using M = pv_math<float>;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const long long sid = (long long)blockIdx.x * PV_THREADS + threadIdx.x;
+    if (sid >= rows * n_freqs) return;
+    const long long row = sid / n_freqs;
+    const int f = (int)(sid - row * n_freqs);
+    const float* base = spec + row * stride_r + (long long)f * stride_f;
+    auto frame = [&](int t) -> f2 {
+        const int tc = t < n_frames ? t : n_frames - 1;
+        f2 v = *reinterpret_cast<const f2*>(base + (long long)tc * stride_t);
+        if (t >= n_frames) v.x = v.y = 0.0f;
+        return v;
+    };
+    const float* g = gout + (row * n_out * (long long)n_freqs + f) * 2;
+    float* gs = gspec + (row * n_frames * (long long)n_freqs + f) * 2;
+    const long long step_elems = 2 * (long long)n_freqs;
+    const f2 first = frame(0);
+    M::ang_t u_first;
+    float n_first;
+    M::polar(first.x, first.y, u_first, n_first);
+    // walk 1: the sum of g_acc over the series
+    float total = 0.0f;
+    {
+        M::acc_t acc = M::open(u_first);
+        for (int i = 0; i < n_out; ++i) {
+            const f2 z0 = frame(idx0[i]), z1 = frame(idx1[i]);
+            M::ang_t u0, u1;
+            float n0, n1;
+            M::polar(z0.x, z0.y, u0, n0);
+            M::polar(z1.x, z1.y, u1, n1);
+            const float w = alpha[i], mag = w * n1 + (1.0f - w) * n0;
+            const f2 gi = *reinterpret_cast<const f2*>(g + i * step_elems);
+            total += mag * (acc.x * gi.y - acc.y * gi.x);
+            acc = M::step(acc, u1, u0, 0.0f);
+        }
+    }
+    auto add = [&](int t, M::ang_t u, float n, float g_n, float g_th) {      // gradient through |z| and angle(z) of source frame t
+        if (t >= n_frames) return;
+        const float r = n > 0.0f ? g_th / n : 0.0f;
+        f2* p = reinterpret_cast<f2*>(gs + (long long)t * step_elems);
+        f2 v = *p;
+        v.x += (n > 0.0f ? g_n * u.x : 0.0f) - r * u.y;
+        v.y += (n > 0.0f ? g_n * u.y : 0.0f) + r * u.x;
+        *p = v;
+    };
+    // walk 2: suffix sums as total - prefix, contributions of every step's two source frames
+    {
+        M::acc_t acc = M::open(u_first);
+        float prefix = 0.0f;
+        for (int i = 0; i < n_out; ++i) {
+            const int t0 = idx0[i], t1 = idx1[i];
+            const f2 z0 = frame(t0), z1 = frame(t1);
+            M::ang_t u0, u1;
+            float n0, n1;
+            M::polar(z0.x, z0.y, u0, n0);
+            M::polar(z1.x, z1.y, u1, n1);
+            const float w = alpha[i], mag = w * n1 + (1.0f - w) * n0;
+            const f2 gi = *reinterpret_cast<const f2*>(g + i * step_elems);
+            const float g_mag = acc.x * gi.x + acc.y * gi.y;
+            prefix += mag * (acc.x * gi.y - acc.y * gi.x);
+            const float suffix = total - prefix;                            // sum over the steps after this one
+            add(t0, u0, n0, (1.0f - w) * g_mag, -suffix);
+            add(t1, u1, n1, w * g_mag, suffix);
+            acc = M::step(acc, u1, u0, 0.0f);
+        }
+    }
+    add(0, u_first, n_first, 0.0f, total);                                 // the phase of the first frame opens every running sum
+}
+
 template <class T>
 static int launch_phase_vocoder(const T* spec, int64_t rows, int32_t n_freqs, int64_t n_frames, int64_t stride_r,
                                 int64_t stride_f, int64_t stride_t, const T* phase_advance, const int32_t* idx0,
@@ -209,6 +291,23 @@ int tac_phase_vocoder_f32(const float* spec, int64_t rows, int32_t n_freqs, int6
                           const int32_t* idx1, const float* alpha, int64_t n_out, float* out, void* stream) {
     return tac::launch_phase_vocoder<float>(spec, rows, n_freqs, n_frames, stride_r, stride_f, stride_t, phase_advance,
                                             idx0, idx1, alpha, n_out, out, stream);
+}
+
+int tac_phase_vocoder_backward_f32(const float* spec, int64_t rows, int32_t n_freqs, int64_t n_frames, int64_t stride_r,
+                                   int64_t stride_f, int64_t stride_t, const int32_t* idx0, const int32_t* idx1, const float* alpha,
+                                   int64_t n_out, const float* grad_out, float* grad_spec, void* stream) {
+    using namespace tac;
+    if (rows == 0 || n_out == 0 || n_freqs == 0) return TAC_OK;
+    if (!spec || !idx0 || !idx1 || !alpha || !grad_out || !grad_spec) return TAC_E_INVALID;
+    if (rows < 0 || n_freqs < 0 || n_frames <= 0 || n_out < 0) return TAC_E_INVALID;
+    if (n_frames >= 0x7fffffffLL || n_out >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
+    const long long blocks = (rows * (long long)n_freqs + PV_THREADS - 1) / PV_THREADS;
+    if (blocks >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
+    hipLaunchKernelGGL(phase_vocoder_backward_kernel, dim3((unsigned)blocks), dim3(PV_THREADS), 0, (hipStream_t)stream, spec,
+                       (long long)rows, (int)n_freqs, (int)n_frames, (long long)stride_r, (long long)stride_f, (long long)stride_t,
+                       idx0, idx1, alpha, (int)n_out, grad_out, grad_spec);
+    TAC_HIP(hipGetLastError());
+    return TAC_OK;
 }
 
 int tac_phase_vocoder_f64(const double* spec, int64_t rows, int32_t n_freqs, int64_t n_frames, int64_t stride_r,
