@@ -365,6 +365,14 @@ int tac_db_to_amplitude_backward_f32(const float* x, const float* grad_out, int6
 int tac_hpss_f32(const float* mag, int64_t rows, int32_t n_freqs, int32_t n_frames, int64_t stride_r,
                  int64_t stride_f, int64_t stride_t, int32_t kernel_f, int32_t kernel_t, float power,
                  int hard, float* harm, float* perc, float* mask_harm, float* mask_perc, void* stream);
+/* ... and its gradient with respect to mag (round 6): the four incoming gradients (each may be NULL) and grad_mag use mag's strides;
+ *      grad_mag ZERO-INITIALISED by the caller (the kernel scatters with float atomics: the gradient of a median goes to the element it
+ *      selected; the sum order, hence the last bits, are not reproducible from run to run).  hard != 0: the masks are not differentiable,
+ *      only harm = mag * mask / perc = mag * mask are. */
+int tac_hpss_backward_f32(const float* mag, int64_t rows, int32_t n_freqs, int32_t n_frames, int64_t stride_r, int64_t stride_f,
+                          int64_t stride_t, int32_t kernel_f, int32_t kernel_t, float power, int hard, const float* grad_harm,
+                          const float* grad_perc, const float* grad_mask_harm, const float* grad_mask_perc, float* grad_mag,
+                          void* stream);
 
 /* (11) Diagnostics (bench.py's roofline object; no effect on results).
  *      tac_last_route: name of the kernel instantiation the calling thread's last fused-chain launch (3b / 3c at fft_length

@@ -1447,8 +1447,8 @@ def test_fft_length_400_trains_on_the_mixed_radix_kernels(tac):
 def test_backward_without_a_kernel_is_announced(tac):
     """What still differentiates through stock torch operators on the device (ops without gradient kernels, double
     backward) says so: an error under strict mode, a CompositeRouteWarning and a composite_calls entry otherwise."""
-    mag = dev(np.abs(signals.uniform((2, 1, 40, 30), seed=305)) + 0.1).requires_grad_(True)    # (hpss: the op left without a gradient kernel)
-    y = tac.hpss(mag, 5, 2.0)[0]
+    x64 = dev(signals.audio_like((1, 1, 3000), seed=305).astype(np.float64)).requires_grad_(True)    # (float64: forward kernels, no gradient kernels)
+    y = tac.Spectrogram(256, 64, power=2.).cuda().double()(x64)
     with pytest.raises(RuntimeError, match='strict mode'):
         y.sum().backward()
     x = dev(signals.audio_like((1, 1, 3000), seed=306)).requires_grad_(True)
@@ -1694,6 +1694,59 @@ def test_phase_vocoder_gradient_kernel(tac):
     chain = torch.nn.Sequential(tac.STFT(256, 64), tac.TimeStretch(64, 129, fixed_rate=1.25), tac.ComplexNorm(2.0)).cuda()
     (got_x,) = torch.autograd.grad((tac.realize(chain(x)) * dev(c_np)).sum(), x)
     assert rel_err(host(got_x), want_x.numpy()) < 1e-3
+
+
+def test_hpss_gradient_kernel(tac):
+    """d hpss / d mag on the gfx950 kernel (round 6; strict mode is on) against torch.autograd through the float64 oracle: soft masks at
+    powers 1 / 2 / 0.7 with all four outputs, each output alone, the masks-only op, unequal widths, the strided spectrogram the STFT
+    kernels return; hard masks (only harm = mag * mask and perc = mag * mask are differentiable)."""
+    rng = np.random.default_rng(131)
+    mag_np = (np.abs(rng.standard_normal((2, 2, 37, 29))) + 0.05).astype(np.float32)          # (continuous values: no ties in a window)
+    for ks, power in (((5, 5), 2.0), ((7, 3), 1.0), ((9, 9), 0.7), ((3, 11), 2.0)):
+        g_np = [rng.standard_normal(mag_np.shape).astype(np.float32) for _ in range(4)]
+        mr = torch.from_numpy(mag_np).double().requires_grad_(True)
+        outs_r = torch_ref.hpss(mr, ks[0], power) if ks[0] == ks[1] else None
+        if outs_r is None:                                               # unequal widths: the documented behaviour, restated with torch ops
+            kf, kt = ks
+            pf = torch.nn.functional.pad(mr, (0, 0, kf // 2, kf // 2), mode='reflect')
+            pt = torch.nn.functional.pad(mr, (kt // 2, kt // 2, 0, 0), mode='reflect')
+            perc = pf.unfold(2, kf, 1).median(dim=-1)[0]
+            harm = pt.unfold(3, kt, 1).median(dim=-1)[0]
+            if power != 1.0:
+                perc, harm = perc.pow(power), harm.pow(power)
+            mh, mp = (harm + 1e-6) / (harm + perc + 1e-6), (perc + 1e-6) / (harm + perc + 1e-6)
+            outs_r = (mr * mh, mr * mp, mh, mp)
+        (want,) = torch.autograd.grad(outs_r, mr, [torch.from_numpy(g).double() for g in g_np], retain_graph=True)
+        m = dev(mag_np).requires_grad_(True)
+        before = launches(tac)
+        outs = tac.hpss(m, ks if ks[0] != ks[1] else ks[0], power)
+        (got,) = torch.autograd.grad(outs, m, [dev(g) for g in g_np])
+        assert launched_since(tac, before).get('tac_hpss_backward_f32') == 1
+        assert rel_err(host(got), want.numpy()) < 1e-4, (ks, power)
+        for i in range(4):                                               # each output alone
+            (w1,) = torch.autograd.grad(outs_r[i], mr, torch.from_numpy(g_np[i]).double(), retain_graph=True)
+            (g1,) = torch.autograd.grad(tac.hpss(m, ks if ks[0] != ks[1] else ks[0], power)[i], m, dev(g_np[i]))
+            assert rel_err(host(g1), w1.numpy()) < 1e-4, (ks, power, i)
+    # masks only, on the strided spectrogram of the STFT kernels, down to the waveform
+    x_np = signals.audio_like((2, 1, 4000), seed=132)
+    xr = torch.from_numpy(x_np).double().requires_grad_(True)
+    sr = torch_ref.complex_norm(torch_ref.stft(xr, 128, 32), 1.0)
+    c_np = rng.standard_normal(tuple(sr.shape)).astype(np.float32)
+    (want_x,) = torch.autograd.grad((torch_ref.hpss(sr, 5, 2.0)[2] * torch.from_numpy(c_np).double()).sum(), xr)
+    x = dev(x_np).requires_grad_(True)
+    spec = tac.Spectrogram(128, 32).cuda()(x)
+    mh = tac.hpss(spec, 5, 2.0, mask_only=True)[2]
+    (got_x,) = torch.autograd.grad((mh * dev(c_np)).sum(), x)
+    assert rel_err(host(got_x), want_x.numpy()) < 1e-3
+    # hard masks
+    mr = torch.from_numpy(mag_np).double().requires_grad_(True)
+    hr = torch_ref.hpss(mr, 5, 2.0, True)
+    g0, g1 = rng.standard_normal(mag_np.shape).astype(np.float32), rng.standard_normal(mag_np.shape).astype(np.float32)
+    (want_h,) = torch.autograd.grad([hr[0], hr[1]], mr, [torch.from_numpy(g0).double(), torch.from_numpy(g1).double()])
+    m = dev(mag_np).requires_grad_(True)
+    hh = tac.hpss(m, 5, 2.0, True)
+    (got_h,) = torch.autograd.grad([hh[0], hh[1]], m, [dev(g0), dev(g1)])
+    assert rel_err(host(got_h), want_h.numpy()) < 1e-6
 
 
 def test_g8_hpss(tac, golden):

@@ -1272,6 +1272,38 @@ def hpss(mag, kernel_f, kernel_t, power, hard, masks_only=False):
     return tuple(outs)
 
 
+def hpss_backward(mag, kernel_f, kernel_t, power, hard, grads):
+    """d hpss / d mag: ``grads`` = the gradients of (harm, perc, mask_harm, mask_perc), each a tensor of mag's shape or None; the result
+    is in mag's (dense) layout.  The gradient of a median goes to the element it selected (float atomics: the last bits vary)."""
+    mag = mag if is_dense(mag) else mag.contiguous()
+    n_freqs, n_frames = mag.shape[-2], mag.shape[-1]
+    rows = mag.reshape(-1, n_freqs, n_frames)
+    if rows.data_ptr() != mag.data_ptr():
+        mag = mag.contiguous()
+        rows = mag.reshape(-1, n_freqs, n_frames)
+
+    def like_mag(g):
+        if g is None:
+            return None
+        if g.dtype == torch.float32 and g.shape == mag.shape and g.stride() == mag.stride():
+            return g
+        out = torch.empty_like(mag)
+        out.copy_(g)
+        return out
+    gs = [like_mag(g) for g in grads]
+    gmag = torch.zeros_like(mag)                                   # the kernel accumulates into it
+    if mag.numel():
+        null = ctypes.c_void_p(0)
+        with _native.on_device(mag.device):
+            rc = _native.lib().tac_hpss_backward_f32(
+                _native.ptr(rows), rows.shape[0], n_freqs, n_frames, rows.stride(0) if rows.shape[0] > 1 else 0, rows.stride(1),
+                rows.stride(2), kernel_f, kernel_t, float(power), 1 if hard else 0,
+                *[null if g is None else _native.ptr(g) for g in gs], _native.ptr(gmag), _native.stream_ptr(mag.device))
+        _native.check(rc, 'tac_hpss_backward_f32')
+        _count('tac_hpss_backward_f32')
+    return gmag
+
+
 # ----------------------------------------------------------------------------- coded waveforms (int16 PCM, mu-law codes)
 def pcm16_to_f32(x):
     """int16 PCM -> float32 in [-1, 1): x * 2^-15 (for the kernels without a coded frame load)."""

@@ -31,7 +31,7 @@ EXPORTS = (
     'tac_apply_filterbank_f32', 'tac_apply_filterbank_sparse_f32', 'tac_apply_filterbank_sparse_db_f32', 'tac_complex_norm_f32', 'tac_magphase_f32', 'tac_phase_vocoder_f32', 'tac_phase_vocoder_f64', 'tac_phase_vocoder_backward_f32', 'tac_amplitude_to_db_f32',
     'tac_db_to_amplitude_f32', 'tac_mulaw_encode_f32_i64', 'tac_mulaw_decode_i64_f32',
     'tac_mulaw_decode_f32_f32', 'tac_mulaw_encode_f64_i64', 'tac_mulaw_decode_f64',
-    'tac_stft_backward_f32', 'tac_stft_norm_backward_f32', 'tac_spectrogram_backward_f32', 'tac_spectrogram_backward_ola_workspace', 'tac_spectrogram_backward_ola_f32', 'tac_melspectrogram_backward_ola_f32', 'tac_melspectrogram_backward_f32', 'tac_filterbank_adjoint_pack', 'tac_apply_filterbank_adjoint_f32', 'tac_overlap_add_f32', 'tac_complex_norm_backward_f32', 'tac_amplitude_to_db_backward_f32', 'tac_magphase_backward_f32', 'tac_db_to_amplitude_backward_f32', 'tac_hpss_f32', 'tac_melspec_sparse_coded_f32', 'tac_pcm16_to_f32',
+    'tac_stft_backward_f32', 'tac_stft_norm_backward_f32', 'tac_spectrogram_backward_f32', 'tac_spectrogram_backward_ola_workspace', 'tac_spectrogram_backward_ola_f32', 'tac_melspectrogram_backward_ola_f32', 'tac_melspectrogram_backward_f32', 'tac_filterbank_adjoint_pack', 'tac_apply_filterbank_adjoint_f32', 'tac_overlap_add_f32', 'tac_complex_norm_backward_f32', 'tac_amplitude_to_db_backward_f32', 'tac_magphase_backward_f32', 'tac_db_to_amplitude_backward_f32', 'tac_hpss_f32', 'tac_hpss_backward_f32', 'tac_melspec_sparse_coded_f32', 'tac_pcm16_to_f32',
     'tac_fold_twosided_f32', 'tac_window_grad_partials', 'tac_window_grad_f32', 'tac_sum_slabs_f32',
     'tac_stft_f64', 'tac_spectrogram_f64', 'tac_apply_filterbank_f64', 'tac_magphase_f64', 'tac_amplitude_to_db_f64',
     'tac_db_to_amplitude_f64',
@@ -159,6 +159,7 @@ def lib():
         h.tac_window_grad_f32.argtypes = [_P, _P, _DESC, _P, _I64, _P]
         h.tac_sum_slabs_f32.argtypes = [_P, _I64, _I64, _P, _P]
         h.tac_hpss_f32.argtypes = [_P, _I64, _I32, _I32, _I64, _I64, _I64, _I32, _I32, _F, ctypes.c_int, _P, _P, _P, _P, _P]
+        h.tac_hpss_backward_f32.argtypes = [_P, _I64, _I32, _I32, _I64, _I64, _I64, _I32, _I32, _F, ctypes.c_int, _P, _P, _P, _P, _P, _P]
         h.tac_melbank_plan_pieces_host.argtypes = [_P, _I32, _I32, _P, _P, _P, _P, _P, _I32]
         h.tac_melbank_plan_pieces_host.restype = ctypes.c_int
         h.tac_last_route.restype = ctypes.c_char_p

@@ -301,6 +301,16 @@ def _phase_vocoder_hip_backward(saved, rest, needs, grads):
             torch.zeros_like(phase_advance) if needs[1] else None]       # (the wrap and the advance cancel: zero, as autograd finds)
 
 
+def _hpss_hip_backward(saved, rest, needs, grads):
+    kernel_f, kernel_t, power, hard = rest
+    if all(g is None for g in grads) or not H.hpss_supported(kernel_f, kernel_t):
+        return None
+    gs = list(grads) if len(grads) == 4 else [None, None] + list(grads)      # (hpss_masks: the two masks only)
+    if hard:
+        gs[2] = gs[3] = None                                                  # boolean masks carry no gradient
+    return [H.hpss_backward(saved[0], kernel_f, kernel_t, power, hard, gs)]
+
+
 def _db_to_amplitude_hip_backward(saved, rest, needs, grads):
     if grads[0] is None or not rest[0] > 0.0:
         return None
@@ -311,7 +321,7 @@ _HIP_BACKWARD = {'stft': _stft_hip_backward, 'spectrogram': _spectrogram_hip_bac
                  'melspectrogram': _melspectrogram_hip_backward, 'apply_filterbank': _apply_filterbank_hip_backward,
                  'complex_norm': _complex_norm_hip_backward, 'amplitude_to_db': _amplitude_to_db_hip_backward,
                  'angle': _angle_hip_backward, 'magphase': _magphase_hip_backward, 'db_to_amplitude': _db_to_amplitude_hip_backward,
-                 'phase_vocoder': _phase_vocoder_hip_backward}
+                 'phase_vocoder': _phase_vocoder_hip_backward, 'hpss': _hpss_hip_backward, 'hpss_masks': _hpss_hip_backward}
 
 
 #: the CUDA-key kernels by op name: `call` below invokes them directly when the dispatcher has nothing to add

@@ -655,8 +655,103 @@ static void launch_tile(const float* mag, long long rows, int F, int T, long lon
 
 }  // namespace tac
 
+namespace tac {
+
+// ---------------------------------------------------------------- gradient (round 6)
+// d hpss / d mag (beta_hpss.py:35-127 under autograd).  With H / P the medians along time / frequency of the reflect-padded spectrogram,
+// Hp = H^power, Pp = P^power, D = Hp + Pp + eps:  harm = mag mh, perc = mag mp, mh = (Hp + eps) / D, mp = (Pp + eps) / D (soft masks).
+//   direct:  g_mag += g_harm mh + g_perc mp
+//   masks:   G_h = g_mh + g_harm mag, G_p = g_mp + g_perc mag;  g_Hp = (G_h Pp - G_p (Pp + eps)) / D^2,  g_Pp = (G_p Hp - G_h (Hp + eps)) / D^2
+//   medians: g_H = g_Hp power H^(power-1) goes to THE element the time window's median selected, g_P to the frequency window's
+// (torch.median's gradient; hard masks are not differentiable: only the direct term).  One thread per element re-selects both medians by
+// rank counting (the element with exactly (k-1)/2 smaller ones, ties by position) and scatters with float atomics: the sum order, hence
+// the last bits, vary from run to run.  Training through hpss is not on the measured path: nothing here is tuned (k^2 / 2 compares per window).
+__device__ __forceinline__ int hp_reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
+
+__global__ void __launch_bounds__(256)
+hpss_backward_kernel(const float* __restrict__ mag, long long rows, int n_freqs, int n_frames, long long stride_r, long long stride_f,
+                     long long stride_t, int kf, int kt, float power, int hard, const float* __restrict__ g_harm,
+                     const float* __restrict__ g_perc, const float* __restrict__ g_mh, const float* __restrict__ g_mp,
+                     float* __restrict__ g_mag) {
+    const long long total = rows * n_freqs * (long long)n_frames;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        // consecutive threads walk the faster-varying axis of the layout
+        const bool t_fast = stride_t <= stride_f;
+        const int nb = t_fast ? n_frames : n_freqs;
+        const long long q = e / nb;
+        const int ib = (int)(e - q * nb), ia = (int)(q % (t_fast ? n_freqs : n_frames));
+        const long long r = q / (t_fast ? n_freqs : n_frames);
+        const int f = t_fast ? ia : ib, t = t_fast ? ib : ia;
+        const float* base = mag + r * stride_r;
+        const long long at = r * stride_r + (long long)f * stride_f + (long long)t * stride_t;
+        // median of `k` values along one axis (stride `st`, length `n`, centre `c`): value and source index
+        auto median = [&](const float* line, long long st, int n, int c, int k, int& src) -> float {
+            const int half = k / 2;
+            for (int i = 0; i < k; ++i) {
+                const int si = hp_reflect(c - half + i, n);
+                const float v = line[(long long)si * st];
+                int below = 0;
+                for (int j = 0; j < k; ++j) {
+                    const float u = line[(long long)hp_reflect(c - half + j, n) * st];
+                    below += (u < v || (u == v && j < i)) ? 1 : 0;
+                }
+                if (below == half) {
+                    src = si;
+                    return v;
+                }
+            }
+            src = c;                                   // (NaNs in the window: no rank matches; the gradient stays where it is)
+            return line[(long long)c * st];
+        };
+        int src_t = t, src_f = f;
+        const float H = median(base + (long long)f * stride_f, stride_t, n_frames, t, kt, src_t);
+        const float P = median(base + (long long)t * stride_t, stride_f, n_freqs, f, kf, src_f);
+        const float x = mag[at];
+        const float Hp = power == 1.0f ? H : powf(H, power), Pp = power == 1.0f ? P : powf(P, power);
+        const float gh = g_harm ? g_harm[at] : 0.0f, gp = g_perc ? g_perc[at] : 0.0f;
+        float direct;
+        if (hard) {
+            direct = gh * (Hp > Pp ? 1.0f : 0.0f) + gp * (Hp < Pp ? 1.0f : 0.0f);
+        } else {
+            const float eps = 1e-6f, D = Hp + Pp + eps, inv = 1.0f / D;
+            direct = gh * ((Hp + eps) * inv) + gp * ((Pp + eps) * inv);
+            const float Gh = (g_mh ? g_mh[at] : 0.0f) + gh * x, Gp = (g_mp ? g_mp[at] : 0.0f) + gp * x;
+            float gHp = (Gh * Pp - Gp * (Pp + eps)) * inv * inv, gPp = (Gp * Hp - Gh * (Hp + eps)) * inv * inv;
+            if (power != 1.0f) {
+                gHp *= power * powf(H, power - 1.0f);
+                gPp *= power * powf(P, power - 1.0f);
+            }
+            if (gHp != 0.0f) unsafeAtomicAdd(g_mag + r * stride_r + (long long)f * stride_f + (long long)src_t * stride_t, gHp);
+            if (gPp != 0.0f) unsafeAtomicAdd(g_mag + r * stride_r + (long long)src_f * stride_f + (long long)t * stride_t, gPp);
+        }
+        if (direct != 0.0f) unsafeAtomicAdd(g_mag + at, direct);
+    }
+}
+
+}  // namespace tac
+
 extern "C" {
 
+int tac_hpss_backward_f32(const float* mag, int64_t rows, int32_t n_freqs, int32_t n_frames, int64_t stride_r, int64_t stride_f,
+                          int64_t stride_t, int32_t kernel_f, int32_t kernel_t, float power, int hard, const float* grad_harm,
+                          const float* grad_perc, const float* grad_mask_harm, const float* grad_mask_perc, float* grad_mag,
+                          void* stream) {
+    using namespace tac;
+    if (rows == 0 || n_freqs == 0 || n_frames == 0) return TAC_OK;
+    if (!mag || !grad_mag || rows < 0 || n_freqs < 0 || n_frames < 0 || stride_r < 0 || stride_f < 0 || stride_t < 0) return TAC_E_INVALID;
+    if (kernel_f < 1 || kernel_t < 1 || !(kernel_f & 1) || !(kernel_t & 1) || kernel_f > 63 || kernel_t > 63)
+        return TAC_E_UNSUPPORTED;
+    if (kernel_f / 2 >= n_freqs || kernel_t / 2 >= n_frames) return TAC_E_SHORT_INPUT;
+    const long long total = rows * n_freqs * (long long)n_frames;
+    long long blocks = (total + 255) / 256;
+    const long long cap = (long long)device_cu_count() * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(hpss_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, mag, (long long)rows, (int)n_freqs,
+                       (int)n_frames, (long long)stride_r, (long long)stride_f, (long long)stride_t, (int)kernel_f, (int)kernel_t, power, hard,
+                       grad_harm, grad_perc, grad_mask_harm, grad_mask_perc, grad_mag);
+    TAC_HIP(hipGetLastError());
+    return TAC_OK;
+}
 
 int tac_hpss_f32(const float* mag, int64_t rows, int32_t n_freqs, int32_t n_frames, int64_t stride_r, int64_t stride_f,
                  int64_t stride_t, int32_t kernel_f, int32_t kernel_t, float power, int hard, float* harm, float* perc,
