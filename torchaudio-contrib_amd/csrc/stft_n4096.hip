@@ -15,6 +15,10 @@
 // one frame ahead, before the previous frame's (nontemporal, unconditional) row stores — the stft_pipe_kernel
 // recipe.  Two frame buffers per wave: one 8-wave workgroup per CU (157 KB of LDS with the shared window table; round 1's
 // two 3-wave workgroups left two SIMDs with a single wave), frames drawn from a workgroup counter.
+//
+// Round 6: this kernel serves the COMPLEX rows; the real-valued rows (|X|, |X|^2, their dB forms) and the one-launch Melspectrogram
+// chain run stft_n4096_s3_kernel (stft_n4096_s3.hpp: the two transforms one after the other through ONE area, twelve waves) — its
+// launchers, the filterbank table builder of the fused chain (pack_n4096_mel) and the routing between the two are below.
 #include "host_common.hpp"
 #include "lane_placement.hpp"
 
