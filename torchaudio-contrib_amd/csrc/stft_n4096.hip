@@ -283,7 +283,7 @@ static int launch_n4096_s3(const FrameGeom& g, const Tables& tb2k, const Tables&
                            hipStream_t stream) {
     const long long units = g.rows * g.n_frames;
     if (units >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
-    const size_t bytes = n4096_s3_lds_bytes(WAVES) + (MEL ? n4096_mel_lds_bytes(mel.rounds, mel.np, mel.wtot) : 0);
+    const size_t bytes = n4096_s3_lds_bytes(WAVES) + (MEL ? n4096_mel_lds_bytes(mel.rounds, mel.np, mel.wtot) : N4S_ROW_TABLE_BYTES);
     if (bytes > 160 * 1024) return TAC_E_UNSUPPORTED;
     long long blocks = (units + WAVES - 1) / WAVES;
     const long long cap = (long long)device_cu_count();      // one workgroup per CU

@@ -28,6 +28,8 @@ typedef float n4s_f4 __attribute__((ext_vector_type(4)));
 __host__ __device__ constexpr size_t n4096_s3_lds_bytes(int waves) {
     return (size_t)waves * s3_xa_bytes<WaveFft<1024, 16>>() + ST_TW_BYTES + 64 + 64 * 8 * sizeof(cf) + 2 * 64 * 16 * sizeof(cf);
 }
+// ... + the row-store form's twiddle tables (pass 2: 64 x 12, W_4096^k: 64 x 8 complex values)
+constexpr size_t N4S_ROW_TABLE_BYTES = 64 * 20 * sizeof(cf);
 
 // the filterbank of the fused form (tac_melbank_pack for fft_length 4096; built by pack_n4096_mel, stft_n4096.hip).  A band's run of
 // four-tap steps is cut into PIECES of about equal length; the pieces of all bands, longest first, fill the cells (slot, lane) of up to
@@ -127,6 +129,25 @@ stft_n4096_s3_kernel(FrameGeom g, Tables tb2k, Tables tb4k, StftEpilogue ep, N4M
         for (int i = tid; i < (mel.wtot >> 2); i += N4S_WAVES * 64)
             reinterpret_cast<f4*>(mwl)[i] = reinterpret_cast<const f4*>(mel.wpack)[i];
     }
+    // Row-store form (!MEL; round 6, late): the pass-2 twiddles with the last pass's constants multiplied in — W_1024^((t + 64 b) q), b < 4,
+    // q = 1 .. 3, as [u < 6][lane] pairs — and the eight W_4096^(t + 64 p) come from LDS tables instead of being formed per frame from
+    // four registers: 52 fewer vector instructions per frame (of ~1 050) and five fewer spilled registers for sixteen more 16-byte LDS reads;
+    // same process -5.2 % on the cfg-4 slice, -6.3 % at full size (4.683 -> 4.390 ms = 50.4 % of 8 TB/s).  The kernel is bound by its
+    // instruction stream at the power limit and its LDS is 40 % busy; the fused form (MEL), whose LDS holds the bank, keeps the registers.
+    cf* const tw2l = reinterpret_cast<cf*>(mlo);
+    if constexpr (!MEL) {
+        for (int i = tid; i < 64 * 12; i += N4S_WAVES * 64) {
+            const int tt = i & 63, e = i >> 6, b = e / 3, q = e % 3 + 1;
+            tw2l[((e >> 1) * 64 + tt) * 2 + (e & 1)] = tb2k.w_nc[((tt + 64 * b) * q) & 1023];
+        }
+    }
+    cf* const w4l = reinterpret_cast<cf*>(mlo) + 64 * 12;                  // W_4096^(t + 64 p), p < 8, as [p >> 1][lane][p & 1]
+    if constexpr (!MEL) {
+        for (int i = tid; i < 64 * 8; i += N4S_WAVES * 64) {
+            const int tt = i & 63, p8 = i >> 6;
+            w4l[((p8 >> 1) * 64 + tt) * 2 + (p8 & 1)] = tb4k.w_n[tt + 64 * p8];
+        }
+    }
     cf tw2[3];
     {
         cf all[F::NTW];
@@ -198,7 +219,23 @@ stft_n4096_s3_kernel(FrameGeom g, Tables tb2k, Tables tb4k, StftEpilogue ep, N4M
         F::template pass_twiddle<1, true>(v, tw1);
         F::template pass_butterflies<1>(v);
         F::exchange_1_2_in_registers(v);
-        F::template pass_twiddle<2, true>(v, tw2);
+        if constexpr (!MEL) {
+            const f4* tl2 = reinterpret_cast<const f4*>(tw2l) + t;
+            cf w2[12];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const f4 x = tl2[u * 64];
+                w2[2 * u] = mkc(x.x, x.y);
+                w2[2 * u + 1] = mkc(x.z, x.w);
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                cmul_x2(v[4 * b + 1], w2[3 * b], v[4 * b + 2], w2[3 * b + 1]);
+                v[4 * b + 3] = cmul(v[4 * b + 3], w2[3 * b + 2]);
+            }
+        } else {
+            F::template pass_twiddle<2, true>(v, tw2);
+        }
         F::template pass_butterflies<2>(v);
         s3_r2c_partners<F>(v, xa, zm, mid, t);
 #pragma unroll
@@ -268,6 +305,16 @@ stft_n4096_s3_kernel(FrameGeom g, Tables tb2k, Tables tb4k, StftEpilogue ep, N4M
                 w2k[2 * u] = mkc(x.x, x.y);
                 w2k[2 * u + 1] = mkc(x.z, x.w);
             }
+            cf w4t[8];
+            if constexpr (!MEL) {
+                const f4* ql = reinterpret_cast<const f4*>(w4l) + t;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const f4 x = ql[u * 64];
+                    w4t[2 * u] = mkc(x.x, x.y);
+                    w4t[2 * u + 1] = mkc(x.z, x.w);
+                }
+            }
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
                 const int k = t + 64 * p;
@@ -275,7 +322,7 @@ stft_n4096_s3_kernel(FrameGeom g, Tables tb2k, Tables tb4k, StftEpilogue ep, N4M
                 const cf qq = cmul_conj(bm[p], w2k[p]);
                 const cf zk = cadd(alo[p], pp), zk2 = csub(alo[p], pp);     // Z[k], Z[1024 + k]
                 const cf zp = cadd(am[p], qq), zm = csub(am[p], qq);        // Z[2048 - k], Z[1024 - k]
-                const cf wq = mul_w64(w4, p);                               // W_4096^k = W_4096^t W_64^p
+                const cf wq = MEL ? mul_w64(w4, p) : w4t[p];                // W_4096^k (MEL: W_4096^t W_64^p)
                 cf x0, x1;                                                  // W_4096^(1024 - k) = -i conj(W_4096^k)
                 r2c_power_pair_x2_mirror(zk, zp, zm, zk2, wq, x0, x1);      // (|X[k]|^2, |X[2048-k]|^2), (|X[1024-k]|^2, |X[1024+k]|^2)
                 stage[k] = spectral_row_value<MODE>(x0.x, ep);
