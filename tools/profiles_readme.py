@@ -53,7 +53,7 @@ for label, sub, key, per_frame in (('fused STFT + power + band-sparse mel + dB',
 out = []
 out.append('# profiles/%s — MI355X (gfx950), ROCm 7.2, collected by `tools/collect_profiles.sh %s`, summarised by '
            '`tools/summarize_profiles.py` and this table by `tools/profiles_readme.py`\n' % (tag, tag))
-out.append('* `bench_N1.json` — the JSON line of `python bench.py` (N=1, cfg-2; r06: the final binary\'s line, taken after the collection on another box of the pool): **%.0f M mel frames/s**, '
+out.append('* `bench_N1.json` — the JSON line of `python bench.py` (N=1, cfg-2) on the same box: **%.0f M mel frames/s**, '
            '%.4f ms per step; CPU baseline on that box %.0f K frames/s (%d threads).'
            % (bench['value'] / 1e6, bench['ms_per_step'], bench['cpu_baseline']['value'] / 1e3, bench['cpu_baseline']['cores']))
 out.append('* `kernel_stats.csv` — `rocprofv3 --kernel-trace --stats -- python bench.py --steps 50 --warmup 10 '
