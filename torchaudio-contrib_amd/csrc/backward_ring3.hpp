@@ -26,12 +26,19 @@ __device__ __forceinline__ T br3_load_once(const T* p) {
     return __builtin_nontemporal_load(p);
 }
 
+// Round 6: the pass-2 twiddles with the last pass's W_16 constants multiplied in — W_NC^((t + 64 b) q), b < 4, q = 1 .. 3, as [u < 6][lane]
+// pairs in LDS — instead of three hoisted registers and nine constant multiplies per transform: the kernel runs two transforms per frame
+// at the 168-register cap with 24 KB of LDS to spare, and is bound by its instruction stream: 36 fewer vector instructions per frame of
+// ~965 and five fewer spilled registers for twelve more 16-byte LDS reads: 0.2585 -> 0.2407 ms (-6.9 %, same process,
+// profiles/r06/ab/batch23_backward_pass2_table.txt).
+constexpr int BR3_TW2L_BYTES = 64 * 12 * (int)sizeof(cf);
+
 template <int NC, int E>
 __host__ __device__ inline size_t ring3_lds_bytes(int mel_stride) {
     using F = WaveFft<NC, E>;
     size_t xa = ((size_t)F::PADDED * sizeof(cf) + 15) & ~(size_t)15;
     return (size_t)BR_WAVES * xa + ST_TW_BYTES + 64 * (F::NPAIR + E) * sizeof(cf) + (size_t)(NC + 1) * sizeof(AdjEntry) +
-           (size_t)BR_WAVES * mel_stride * sizeof(float);
+           (size_t)BR_WAVES * mel_stride * sizeof(float) + BR3_TW2L_BYTES;
 }
 
 // FUSE: `gmel` is the gradient of the mel values and the filterbank adjoint happens here (fz); otherwise it is the gradient of
@@ -68,7 +75,12 @@ melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ 
         const int tt = idx / E, q = idx - tt * E;
         winl[((q >> 1) * 64 + tt) * 2 + (q & 1)] = cscale(window_pair(g, tt + q * F::LPF), half);
     }
-    AdjEntry* const adj_lds = reinterpret_cast<AdjEntry*>(winl + 64 * E);
+    cf* const tw2l = winl + 64 * E;
+    for (int i = tid; i < 64 * 12; i += WAVES * 64) {
+        const int tt = i & 63, e = i >> 6, b = e / 3, q = e % 3 + 1;
+        tw2l[((e >> 1) * 64 + tt) * 2 + (e & 1)] = tb.w_nc[((tt + 64 * b) * q) & 1023];
+    }
+    AdjEntry* const adj_lds = reinterpret_cast<AdjEntry*>(reinterpret_cast<unsigned char*>(tw2l) + BR3_TW2L_BYTES);
     if constexpr (FUSE)
         for (int k = tid; k < NBINS; k += WAVES * 64) adj_lds[k] = fz.adj[k];
     float* const grow = reinterpret_cast<float*>(adj_lds + NBINS) + w * fz.mel_stride;
@@ -82,13 +94,6 @@ melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ 
     int row = (int)(seg / spr), sidx = (int)(seg - (long long)row * spr);
     int f0 = sidx * S, f1 = f0 + S < T ? f0 + S : T, f = f0;
 
-    cf tw2[3];
-    {
-        cf all[F::NTW];
-        F::load_twiddles(all, tb.w_nc, t);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) tw2[q] = all[twiddles_before(NC, E, 2) + q];
-    }
     typedef float f4 __attribute__((ext_vector_type(4)));
     cf v[E];
     float gq[4];
@@ -135,7 +140,21 @@ melspec_backward_ring3_kernel(FrameGeom g, Tables tb, const float* __restrict__ 
         F::template pass_twiddle<1, true>(v, tw1);
         F::template pass_butterflies<1>(v);
         F::exchange_1_2_in_registers(v);
-        F::template pass_twiddle<2, true>(v, tw2);
+        {
+            const f4* tl2 = reinterpret_cast<const f4*>(tw2l) + t;
+            cf w2[12];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const f4 x = tl2[u * 64];
+                w2[2 * u] = mkc(x.x, x.y);
+                w2[2 * u + 1] = mkc(x.z, x.w);
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                cmul_x2(v[4 * b + 1], w2[3 * b], v[4 * b + 2], w2[3 * b + 1]);
+                v[4 * b + 3] = cmul(v[4 * b + 3], w2[3 * b + 2]);
+            }
+        }
         F::template pass_butterflies<2>(v);
         wave_lds_fence();
         F::template pass_write<2, HALF>(v, xa, t, t);
