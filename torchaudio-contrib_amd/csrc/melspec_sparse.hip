@@ -412,7 +412,7 @@ static int launch_stream(FrameGeom g, const Tables& tb, const SparseArgs& sm, co
             return TAC_OK;
         }
     }
-    const size_t lds3 = stream3_lds_bytes<NC, E>(sm.wtot, waves3, coded);
+    const size_t lds3 = stream3_lds_bytes<NC, E>(sm.wtot, waves3, coded) + ((FMT == FMT_F32 && fast2) ? S3_TW2L_BYTES : 0);   // (FAST1 kernels: + their pass-2 twiddle table)
     if (!two_waves && lds3 <= 160 * 1024) {
         void (*k3)(FrameGeom, Tables, StreamArgs);
         if constexpr (FMT == FMT_F32) {

@@ -15,6 +15,7 @@
 namespace tac {
 
 constexpr int S3_WAVES = 12;
+constexpr int S3_TW2L_BYTES = 64 * 12 * 8;     // pass-2 twiddle table of the FAST1 kernels (behind the window table)
 
 // Frozen in round 5 (the knobs, their ablation branches and the piece-layout / 15-wave / stamp variants of this kernel are in
 // tools/ablation/stream3_lab_knobs_r05.patch with the measurement that decided each): first exchange XOR-swizzled instead of
@@ -331,6 +332,18 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
 #pragma unroll
     for (int p = 0; p < F::NPAIR; ++p) ptw_regs[p] = tb.w_n[t + p * F::LPF];
     float* const lutlds = reinterpret_cast<float*>(winl + 64 * E);                 // mu-law decode table (coded inputs)
+    // FAST1 kernels (the standard 128-band banks: 18 - 20 KB of weights, float32 samples; round 6): the pass-2 twiddles with the last
+    // pass's W_16 constants multiplied in, W_NC^((t + 64 b) q), b < 4, q = 1 .. 3, as [u < 6][lane] pairs in LDS instead of three hoisted
+    // registers + nine constant multiplies per frame: -1.2 % same process (profiles/r06/ab/batch24_mel_pass2_table.txt).  The general
+    // kernels keep the registers: their LDS belongs to the bank (tables of up to 42 steps)
+    constexpr bool TW2L = FAST1 > 0;
+    cf* const tw2l = reinterpret_cast<cf*>(lutlds);
+    if constexpr (TW2L) {
+        for (int i = tid; i < 64 * 12; i += WAVES * 64) {
+            const int tt = i & 63, e = i >> 6, b = e / 3, q = e % 3 + 1;
+            tw2l[((e >> 1) * 64 + tt) * 2 + (e & 1)] = tb.w_nc[((tt + 64 * b) * q) & 1023];
+        }
+    }
     if (FMT >= FMT_MULAW_U8 && tid < 256) lutlds[tid] = lutv;
     __syncthreads();
     if (nloc <= 0) return;
@@ -421,7 +434,23 @@ melspec_stream3_kernel(FrameGeom g, Tables tb, StreamArgs m) {
         F::template pass_twiddle<1, true>(v, tw1);
         F::template pass_butterflies<1>(v);
         F::exchange_1_2_in_registers(v);
-        F::template pass_twiddle<2, true>(v, tw2);
+        if constexpr (TW2L) {
+            const f4* tl2 = reinterpret_cast<const f4*>(tw2l) + t;
+            cf w2[12];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const f4 x = tl2[u * 64];
+                w2[2 * u] = mkc(x.x, x.y);
+                w2[2 * u + 1] = mkc(x.z, x.w);
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                cmul_x2(v[4 * b + 1], w2[3 * b], v[4 * b + 2], w2[3 * b + 1]);
+                v[4 * b + 3] = cmul(v[4 * b + 3], w2[3 * b + 2]);
+            }
+        } else {
+            F::template pass_twiddle<2, true>(v, tw2);
+        }
         F::template pass_butterflies<2>(v);
         cf zm[F::NPAIR], zmid;
         s3_r2c_partners<F>(v, xa, zm, zmid, t);
