@@ -278,17 +278,17 @@ stft_n4096_kernel(FrameGeom g, Tables tb1k, Tables tb4k, StftEpilogue ep) {
 
 namespace tac {
 
-template <int MODE, int WAVES, bool MEL>
+template <int MODE, int WAVES, bool MEL, bool TBL = !MEL>
 static int launch_n4096_s3(const FrameGeom& g, const Tables& tb2k, const Tables& tb4k, const StftEpilogue& ep, const N4Mel& mel,
                            hipStream_t stream) {
     const long long units = g.rows * g.n_frames;
     if (units >= 0x7fffffffLL) return TAC_E_UNSUPPORTED;
-    const size_t bytes = n4096_s3_lds_bytes(WAVES) + (MEL ? n4096_mel_lds_bytes(mel.rounds, mel.np, mel.wtot) : N4S_ROW_TABLE_BYTES);
+    const size_t bytes = n4096_s3_lds_bytes(WAVES) + (MEL ? n4096_mel_lds_bytes(mel.rounds, mel.np, mel.wtot) : 0) + (TBL ? N4S_ROW_TABLE_BYTES : 0);
     if (bytes > 160 * 1024) return TAC_E_UNSUPPORTED;
     long long blocks = (units + WAVES - 1) / WAVES;
     const long long cap = (long long)device_cu_count();      // one workgroup per CU
     if (blocks > cap) blocks = cap;
-    auto kern = stft_n4096_s3_kernel<MODE, WAVES, MEL>;
+    auto kern = stft_n4096_s3_kernel<MODE, WAVES, MEL, TBL>;
     TAC_HIP(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), bytes, stream, g, tb2k, tb4k, ep, mel);
     TAC_HIP(hipGetLastError());
@@ -380,8 +380,14 @@ int pack_n4096_mel(const std::vector<float>& h, int n_freqs, int n_mels, float* 
     }
     const long long wtot = 256LL * steps;
     int waves = 0;
-    for (int wv : {12, 11, 8})                                               // (ten waves — 3, 3, 2, 2 per SIMD — measured slower than eight)
-        if (!waves && n4096_s3_lds_bytes(wv) + n4096_mel_lds_bytes(rounds, np, (int)wtot) <= 160 * 1024) waves = wv;
+    // twelve or eleven waves with the twiddle tables of the row-store form beside the bank (stft_n4096_s3.hpp, TBL: eleven waves with them beat
+    // twelve without by 5 - 9 %), else twelve / eleven / eight without asking (eight always have the room; ten waves — 3, 3, 2, 2 per SIMD —
+    // measured slower than eight): profiles/r06/ab/batch25_mel4096_tables.txt
+    for (int pass = 0; pass < 2 && !waves; ++pass)
+        for (int wv : {12, 11, 8})
+            if (!waves && (pass == 1 || wv > 8) &&
+                n4096_s3_lds_bytes(wv) + n4096_mel_lds_bytes(rounds, np, (int)wtot) + (pass == 0 ? N4S_ROW_TABLE_BYTES : 0) <= 160 * 1024)
+                waves = wv;
     const int mix_rows = n4096_mix_rows(rounds, np);
     if (!waves || wtot > wpack_cap || N4M_DESC_HEAD + 64 * mix_rows > desc_cap) return TAC_E_UNSUPPORTED;   // the two-launch chain
     // bank-aware first bins per slot: a cell's run may start up to (slot steps - its quads) quads earlier
@@ -446,10 +452,16 @@ int launch_n4096_mel(const FrameGeom& g, float power, const float* wpack, const 
     const StftEpilogue ep{nullptr, 1, 1, power, 0, 0.0f, 0.0f};
     const N4Mel mel{wpack, desc, info_host[5], info_host[6], info_host[0], n_mels, db, info_host[7], amin, log10_ref, out};
     const bool p2 = power == 2.0f;
-    switch (info_host[4]) {
-        case 12: return p2 ? launch_n4096_s3<1, 12, true>(g, tb2k, tb4k, ep, mel, stream) : launch_n4096_s3<2, 12, true>(g, tb2k, tb4k, ep, mel, stream);
-        case 11: return p2 ? launch_n4096_s3<1, 11, true>(g, tb2k, tb4k, ep, mel, stream) : launch_n4096_s3<2, 11, true>(g, tb2k, tb4k, ep, mel, stream);
-        case 8: return p2 ? launch_n4096_s3<1, 8, true>(g, tb2k, tb4k, ep, mel, stream) : launch_n4096_s3<2, 8, true>(g, tb2k, tb4k, ep, mel, stream);
+    const int waves = info_host[4];
+    // the twiddle tables of the row-store form where the bank leaves them the room
+    const bool tbl = n4096_s3_lds_bytes(waves) + n4096_mel_lds_bytes(mel.rounds, mel.np, mel.wtot) + N4S_ROW_TABLE_BYTES <= 160 * 1024;
+#define TAC_N4M_CASE(W)                                                                                                     \
+    case W:                                                                                                                \
+        if (tbl) return p2 ? launch_n4096_s3<1, W, true, true>(g, tb2k, tb4k, ep, mel, stream) : launch_n4096_s3<2, W, true, true>(g, tb2k, tb4k, ep, mel, stream); \
+        return p2 ? launch_n4096_s3<1, W, true, false>(g, tb2k, tb4k, ep, mel, stream) : launch_n4096_s3<2, W, true, false>(g, tb2k, tb4k, ep, mel, stream);
+    switch (waves) {
+        TAC_N4M_CASE(12) TAC_N4M_CASE(11) TAC_N4M_CASE(8)
+#undef TAC_N4M_CASE
         default: return TAC_E_INVALID;
     }
 }

@@ -87,10 +87,12 @@ __device__ __forceinline__ void r2c_power_pair_x2_mirror(cf zk1, cf zm1, cf zk2,
 
 // MODE: 1 |X|^2, 2 |X|, 3 |X|^2 in dB, 4 |X| in dB (spectral_row_value); MEL: the row is contracted with `mel` instead of stored
 // (MODE 1 / 2 only); WAVES: 12, or fewer when the bank's table needs the LDS
-template <int MODE, int WAVES, bool MEL>
+// TBL: the pass-2 / W_4096 twiddle tables in LDS (always in the row-store form; in the fused form where the bank leaves the room)
+template <int MODE, int WAVES, bool MEL, bool TBL = !MEL>
 __global__ void __launch_bounds__(WAVES * 64, (WAVES + 3) / 4)
 stft_n4096_s3_kernel(FrameGeom g, Tables tb2k, Tables tb4k, StftEpilogue ep, N4Mel mel) {
     constexpr int N4S_WAVES = WAVES;
+    static_assert(MEL || TBL, "the row-store form has the room");
     using F = WaveFft<1024, 16>;
     using f4 = n4s_f4;
     static_assert(MODE >= 1 && MODE <= 4 && (!MEL || MODE <= 2), "real-valued rows");
@@ -129,20 +131,21 @@ stft_n4096_s3_kernel(FrameGeom g, Tables tb2k, Tables tb4k, StftEpilogue ep, N4M
         for (int i = tid; i < (mel.wtot >> 2); i += N4S_WAVES * 64)
             reinterpret_cast<f4*>(mwl)[i] = reinterpret_cast<const f4*>(mel.wpack)[i];
     }
-    // Row-store form (!MEL; round 6, late): the pass-2 twiddles with the last pass's constants multiplied in — W_1024^((t + 64 b) q), b < 4,
+    // TBL (the row-store form always; round 6, late): the pass-2 twiddles with the last pass's constants multiplied in — W_1024^((t + 64 b) q), b < 4,
     // q = 1 .. 3, as [u < 6][lane] pairs — and the eight W_4096^(t + 64 p) come from LDS tables instead of being formed per frame from
     // four registers: 52 fewer vector instructions per frame (of ~1 050) and five fewer spilled registers for sixteen more 16-byte LDS reads;
     // same process -5.2 % on the cfg-4 slice, -6.3 % at full size (4.683 -> 4.390 ms = 50.4 % of 8 TB/s).  The kernel is bound by its
-    // instruction stream at the power limit and its LDS is 40 % busy; the fused form (MEL), whose LDS holds the bank, keeps the registers.
-    cf* const tw2l = reinterpret_cast<cf*>(mlo);
-    if constexpr (!MEL) {
+    // instruction stream at the power limit and its LDS is 40 % busy; the fused form (MEL) takes the tables where the bank leaves them the
+    // room (TBL; behind the bank's weights), else it keeps the registers.
+    cf* const tw2l = MEL ? reinterpret_cast<cf*>(mwl + mel.wtot) : reinterpret_cast<cf*>(mlo);
+    if constexpr (TBL) {
         for (int i = tid; i < 64 * 12; i += N4S_WAVES * 64) {
             const int tt = i & 63, e = i >> 6, b = e / 3, q = e % 3 + 1;
             tw2l[((e >> 1) * 64 + tt) * 2 + (e & 1)] = tb2k.w_nc[((tt + 64 * b) * q) & 1023];
         }
     }
-    cf* const w4l = reinterpret_cast<cf*>(mlo) + 64 * 12;                  // W_4096^(t + 64 p), p < 8, as [p >> 1][lane][p & 1]
-    if constexpr (!MEL) {
+    cf* const w4l = tw2l + 64 * 12;                                        // W_4096^(t + 64 p), p < 8, as [p >> 1][lane][p & 1]
+    if constexpr (TBL) {
         for (int i = tid; i < 64 * 8; i += N4S_WAVES * 64) {
             const int tt = i & 63, p8 = i >> 6;
             w4l[((p8 >> 1) * 64 + tt) * 2 + (p8 & 1)] = tb4k.w_n[tt + 64 * p8];
@@ -219,7 +222,7 @@ stft_n4096_s3_kernel(FrameGeom g, Tables tb2k, Tables tb4k, StftEpilogue ep, N4M
         F::template pass_twiddle<1, true>(v, tw1);
         F::template pass_butterflies<1>(v);
         F::exchange_1_2_in_registers(v);
-        if constexpr (!MEL) {
+        if constexpr (TBL) {
             const f4* tl2 = reinterpret_cast<const f4*>(tw2l) + t;
             cf w2[12];
 #pragma unroll
@@ -306,7 +309,7 @@ stft_n4096_s3_kernel(FrameGeom g, Tables tb2k, Tables tb4k, StftEpilogue ep, N4M
                 w2k[2 * u + 1] = mkc(x.z, x.w);
             }
             cf w4t[8];
-            if constexpr (!MEL) {
+            if constexpr (TBL) {
                 const f4* ql = reinterpret_cast<const f4*>(w4l) + t;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -322,7 +325,7 @@ stft_n4096_s3_kernel(FrameGeom g, Tables tb2k, Tables tb4k, StftEpilogue ep, N4M
                 const cf qq = cmul_conj(bm[p], w2k[p]);
                 const cf zk = cadd(alo[p], pp), zk2 = csub(alo[p], pp);     // Z[k], Z[1024 + k]
                 const cf zp = cadd(am[p], qq), zm = csub(am[p], qq);        // Z[2048 - k], Z[1024 - k]
-                const cf wq = MEL ? mul_w64(w4, p) : w4t[p];                // W_4096^k (MEL: W_4096^t W_64^p)
+                const cf wq = TBL ? w4t[p] : mul_w64(w4, p);                // W_4096^k (without the table: W_4096^t W_64^p)
                 cf x0, x1;                                                  // W_4096^(1024 - k) = -i conj(W_4096^k)
                 r2c_power_pair_x2_mirror(zk, zp, zm, zk2, wq, x0, x1);      // (|X[k]|^2, |X[2048-k]|^2), (|X[1024-k]|^2, |X[1024+k]|^2)
                 stage[k] = spectral_row_value<MODE>(x0.x, ep);
