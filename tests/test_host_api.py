@@ -681,6 +681,78 @@ def test_piece_layout_refuses_what_it_cannot_hold(tac):
     assert rc == tac._native.TAC_E_UNSUPPORTED
 
 
+@pytest.mark.parametrize('n_fft,n_mels,sr,htk', [(2048, 128, 16000, False), (2048, 80, 16000, False), (2048, 40, 16000, False),
+                                                 (2048, 160, 22050, True), (4096, 128, 48000, False), (4096, 80, 44100, False),
+                                                 (4096, 200, 48000, False), (4096, 40, 16000, False), (4096, 64, 22050, True)])
+def test_lane_tables_of_the_fused_kernels_match_the_dense_product(tac, n_fft, n_mels, sr, htk):
+    """tac_melbank_pack_host (round 6): the filterbank tables of the fused fft_length-2048 / 4096 kernels, built without a device — cells
+    from the widest end of the bank (2048: info[2] = 64 + 256; 4096: info[7]), per-slot step counts, bank-aware first bins, and at 4096
+    the cut layout with its mix table (40 bands).  The kernels' contraction emulated on the tables equals row @ bank (reference
+    functional.py:183-184) for random rows; every read stays inside the row and its three zeroed slack floats."""
+    h = tac._native.lib()
+    n_freqs = n_fft // 2 + 1
+    fb = np.ascontiguousarray(tac.create_mel_filter(n_freqs, n_mels, 0.0, sr / 2.0, htk).numpy().astype(np.float32))
+    wpack, desc, info = np.zeros(24576, dtype=np.float32), np.zeros(8192, dtype=np.int32), (ctypes.c_int32 * 8)()
+    h.tac_melbank_pack_host.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+                                        ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+    rc = h.tac_melbank_pack_host(fb.ctypes.data, n_freqs, n_mels, n_fft, wpack.ctypes.data, wpack.size, desc.ctypes.data, desc.size,
+                                 ctypes.cast(info, ctypes.c_void_p))
+    assert rc == tac._native.TAC_OK, rc
+    info = [int(v) for v in info]
+    rng = np.random.default_rng(5)
+    rows = rng.random((3, n_freqs)).astype(np.float64)
+    want = rows @ fb.astype(np.float64)
+
+    def cell_sum(row, first, base, steps, lane):                         # one cell: `steps` four-tap steps from bin `first`
+        assert first % 4 == 0 and 0 <= first and first + 4 * steps <= n_freqs + (7 if n_fft == 2048 else 3)
+        acc = 0.0
+        for j in range(steps):
+            taps = wpack[((base + j) * 64 + lane) * 4:((base + j) * 64 + lane) * 4 + 4].astype(np.float64)
+            bins = np.arange(first + 4 * j, first + 4 * j + 4)
+            vals = np.where(bins < n_freqs, row[np.minimum(bins, n_freqs - 1)], 0.0)
+            acc += float(taps @ vals)
+        return acc
+
+    got = np.zeros_like(want)
+    if n_fft == 2048:
+        assert info[2] in (64, 64 + 256) and info[0] == 256 * info[3]
+        rev, nslot, steps = info[2] != 64, info[1], info[4:4 + info[1]]
+        assert rev == (n_mels % 64 != 0)
+        for r, row in enumerate(rows):
+            base = 0
+            for s in range(nslot):
+                for lane in range(64):
+                    c = 64 * s + lane
+                    if c < n_mels:
+                        got[r, n_mels - 1 - c if rev else c] = cell_sum(row, int(desc[c]), base, steps[s], lane)
+                base += steps[s]
+    else:
+        floats, slots, mark, total, waves, np_, rounds, rev = info
+        assert mark == 1000 + 4096 and floats == 256 * total and waves in (12, 11, 8) and rounds == (n_mels + 63) // 64
+        pairs = [int(v) for v in desc[64 * 6:64 * 6 + 6]]
+        assert sum(2 * p for p in pairs) == total and all(p == 0 for p in pairs[slots:])
+        for r, row in enumerate(rows):
+            cells, base = np.zeros(64 * 6 + 1), 0
+            for s in range(slots):
+                for lane in range(64):
+                    cells[64 * s + lane] = cell_sum(row, int(desc[64 * s + lane]), base, 2 * pairs[s], lane)
+                base += 2 * pairs[s]
+            if np_ == 0:                                                  # uncut: cell c is band c (or n - 1 - c)
+                for c in range(n_mels):
+                    got[r, n_mels - 1 - c if rev else c] = cells[c]
+            else:                                                         # cut: every band gathers its pieces through the mix table
+                assert np_ % 4 == 0 and not rev
+                mix = desc[400:400 + 64 * rounds * np_].reshape(rounds, np_, 64)
+                assert mix.min() >= 0 and mix.max() <= 64 * 6
+                for b in range(n_mels):
+                    got[r, b] = cells[mix[b // 64, :, b % 64]].sum()
+    assert np.abs(got - want).max() < 1e-5 * np.abs(want).max()
+    if n_fft == 4096 and n_mels == 40:
+        assert info[5] > 0                                                # (bands of 300 bins: the cut layout)
+    if n_fft == 4096 and n_mels == 128:
+        assert info[5] == 0 and info[4] == 11                             # (uncut, eleven waves beside the 40 KB table)
+
+
 def test_float64_size_coverage_matches_the_kernel_plan(tac):
     """``_hip64.covers``: even lengths <= 8192 with a 5-smooth half take the LDS Stockham transform of csrc/chain_f64.hip; other
     lengths go to its O(N^2) direct transform only up to ``DIRECT_MAX`` (longer ones stay on the announced stock-torch route,

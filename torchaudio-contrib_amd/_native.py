@@ -27,7 +27,7 @@ SAMPLES_F32, SAMPLES_I16, SAMPLES_MULAW_U8, SAMPLES_MULAW_I64 = 0, 1, 2, 3
 EXPORTS = (
     'tac_strerror', 'tac_last_hip_error', 'tac_abi_version', 'tac_num_frames', 'tac_num_bins',
     'tac_stft_f32', 'tac_spectrogram_f32', 'tac_melspec_f32', 'tac_melspec_supported', 'tac_filterbank_plan',
-    'tac_melbank_pack', 'tac_melspec_sparse_f32',
+    'tac_melbank_pack', 'tac_melbank_pack_host', 'tac_melspec_sparse_f32',
     'tac_apply_filterbank_f32', 'tac_apply_filterbank_sparse_f32', 'tac_apply_filterbank_sparse_db_f32', 'tac_complex_norm_f32', 'tac_magphase_f32', 'tac_phase_vocoder_f32', 'tac_phase_vocoder_f64', 'tac_phase_vocoder_backward_f32', 'tac_amplitude_to_db_f32',
     'tac_db_to_amplitude_f32', 'tac_mulaw_encode_f32_i64', 'tac_mulaw_decode_i64_f32',
     'tac_mulaw_decode_f32_f32', 'tac_mulaw_encode_f64_i64', 'tac_mulaw_decode_f64',

@@ -48,7 +48,7 @@ int pack_small(int n_fft, const std::vector<float>& h, int n_freqs, int n_mels, 
 int launch_n4096_mel(const FrameGeom& g, float power, const float* wpack, const int32_t* desc, const int32_t* info_host, int n_mels,
                      int db, float amin, float log10_ref, float* out, hipStream_t stream);
 int pack_n4096_mel(const std::vector<float>& h, int n_freqs, int n_mels, float* wpack, int wpack_cap, int32_t* desc, int desc_cap,
-                   int32_t* info_host, hipStream_t stream);
+                   int32_t* info_host, hipStream_t stream, bool to_host = false);
 
 constexpr int SP_TILE = 16;
 constexpr int SP_MAX_W = 3072;               // floats of packed weights that may live in LDS (12 KB)
@@ -570,7 +570,7 @@ static int launch_fb_lanes(const float* spec, long long rows, int n_freqs, long 
 // zero-padded, and a band whose padded run would leave the row buffer is shifted down (zeros in front) so that every
 // lane reads inside its row.
 static int pack_lanes(const std::vector<float>& h, int n_freqs, int n_mels, float* wpack, int wpack_cap, int32_t* desc,
-                      int desc_cap, int32_t* info_host, hipStream_t stream) {
+                      int desc_cap, int32_t* info_host, hipStream_t stream, bool to_host = false) {
     const int nslot = (n_mels + 63) / 64;
     if (nslot > ST_MAX_SLOTS || nslot * 64 > desc_cap) return TAC_E_UNSUPPORTED;
     const int limit = StreamCfg<1024, 16>::PROW;                             // bins + zeroed slack of a row buffer
@@ -627,9 +627,14 @@ static int pack_lanes(const std::vector<float>& h, int n_freqs, int n_mels, floa
         }
         base += steps[s];
     }
-    TAC_HIP(hipMemcpyAsync(wpack, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice, stream));
-    TAC_HIP(hipMemcpyAsync(desc, lo.data(), lo.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-    TAC_HIP(hipStreamSynchronize(stream));
+    if (to_host) {                                                           // (tac_melbank_pack_host: host buffers, no device)
+        std::copy(wp.begin(), wp.end(), wpack);
+        std::copy(lo.begin(), lo.end(), desc);
+    } else {
+        TAC_HIP(hipMemcpyAsync(wpack, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+        TAC_HIP(hipMemcpyAsync(desc, lo.data(), lo.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        TAC_HIP(hipStreamSynchronize(stream));
+    }
     info_host[0] = (int32_t)wtot;
     info_host[1] = nslot;
     info_host[2] = 64 + (rev ? ST_REV_MARK : 0);
@@ -657,6 +662,16 @@ int tac_melbank_plan_pieces_host(const float* fb_host, int32_t n_freqs, int32_t 
     }
     std::copy(p.w.begin(), p.w.end(), weights);
     return TAC_OK;
+}
+
+int tac_melbank_pack_host(const float* fb_host, int32_t n_freqs, int32_t n_mels, int32_t n_fft, float* wpack_host, int32_t wpack_cap,
+                          int32_t* desc_host, int32_t desc_cap, int32_t* info_host) {
+    using namespace tac;
+    if (!fb_host || !wpack_host || !desc_host || !info_host || n_freqs <= 0 || n_mels <= 0) return TAC_E_INVALID;
+    if ((n_fft != 2048 && n_fft != 4096) || n_freqs != n_fft / 2 + 1) return TAC_E_UNSUPPORTED;
+    const std::vector<float> h(fb_host, fb_host + (size_t)n_freqs * n_mels);
+    return n_fft == 2048 ? pack_lanes(h, n_freqs, n_mels, wpack_host, wpack_cap, desc_host, desc_cap, info_host, nullptr, true)
+                         : pack_n4096_mel(h, n_freqs, n_mels, wpack_host, wpack_cap, desc_host, desc_cap, info_host, nullptr, true);
 }
 
 int tac_melbank_pack(const float* fb, int32_t n_freqs, int32_t n_mels, int32_t n_fft, float* wpack,

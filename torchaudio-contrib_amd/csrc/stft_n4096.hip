@@ -305,8 +305,9 @@ static int launch_n4096_s3(const FrameGeom& g, const Tables& tb2k, const Tables&
 // (lane_placement.hpp), and where its padded run would leave the row and its three zeroed slack floats.
 // info: [0] floats of weights, [1] slots in use, [2] N4M_MARK, [3] steps, [4] waves per workgroup the table leaves room for,
 // [5] pieces per band in the mix table (0: uncut), [6] rounds of 64 bands, [7] uncut cells in reversed band order.
+// to_host: wpack / desc are HOST buffers (tac_melbank_pack_host: the same tables without a device, for the CPU tests)
 int pack_n4096_mel(const std::vector<float>& h, int n_freqs, int n_mels, float* wpack, int wpack_cap, int32_t* desc, int desc_cap,
-                   int32_t* info_host, hipStream_t stream) {
+                   int32_t* info_host, hipStream_t stream, bool to_host) {
     constexpr int LIMIT = 2049 + 3;
     if (n_freqs != 2049 || n_mels < 1 || n_mels > N4M_MAX_MELS) return TAC_E_UNSUPPORTED;
     const int rounds = (n_mels + 63) / 64;
@@ -422,9 +423,14 @@ int pack_n4096_mel(const std::vector<float>& h, int n_freqs, int n_mels, float* 
         dd[(size_t)64 * N4M_SLOTS + s] = slot_steps[s] / 2;
         base += slot_steps[s];
     }
-    TAC_HIP(hipMemcpyAsync(wpack, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice, stream));
-    TAC_HIP(hipMemcpyAsync(desc, dd.data(), dd.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-    TAC_HIP(hipStreamSynchronize(stream));
+    if (to_host) {
+        std::copy(wp.begin(), wp.end(), wpack);
+        std::copy(dd.begin(), dd.end(), desc);
+    } else {
+        TAC_HIP(hipMemcpyAsync(wpack, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+        TAC_HIP(hipMemcpyAsync(desc, dd.data(), dd.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        TAC_HIP(hipStreamSynchronize(stream));
+    }
     info_host[0] = (int32_t)wtot;
     info_host[1] = slots;
     info_host[2] = N4M_MARK;
