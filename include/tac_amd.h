@@ -121,7 +121,7 @@ int tac_melspec_f32(const float* wave, const float* window, const tac_stft_desc*
  *      (tools/ablation/README.md); tests emulate its contraction on the plan. */
 int tac_melbank_pack(const float* fb, int32_t n_freqs, int32_t n_mels, int32_t n_fft, float* wpack,
                      int32_t wpack_cap, int32_t* desc, int32_t desc_cap, int32_t* info_host, void* stream);
-/* ... the same tables without a device (round 6; n_fft = 2048 or 4096): fb_host, wpack_host, desc_host are HOST buffers, nothing is launched
+/* ... the same tables without a device (round 6; n_fft = 256, 400, 512, 1024, 2048 or 4096): fb_host, wpack_host, desc_host are HOST buffers, nothing is launched
  *      or copied — what tests/test_host_api.py emulates the kernels' contraction on. */
 int tac_melbank_pack_host(const float* fb_host, int32_t n_freqs, int32_t n_mels, int32_t n_fft, float* wpack_host,
                           int32_t wpack_cap, int32_t* desc_host, int32_t desc_cap, int32_t* info_host);

@@ -753,6 +753,50 @@ def test_lane_tables_of_the_fused_kernels_match_the_dense_product(tac, n_fft, n_
         assert info[5] == 0 and info[4] == 11                             # (uncut, eleven waves beside the 40 KB table)
 
 
+@pytest.mark.parametrize('n_fft,n_mels,sr', [(1024, 80, 22050), (1024, 40, 16000), (1024, 128, 22050), (512, 80, 16000), (512, 40, 16000),
+                                             (400, 80, 16000), (400, 40, 16000), (256, 40, 16000)])
+def test_lane_layout_tables_match_the_dense_product(tac, n_fft, n_mels, sr):
+    """tac_melbank_pack_host for the kernels that keep several frames per wave (fft_length 256 / 400 / 512 / 1024: 8 ... 32 lanes per
+    frame, csrc/mel_lanes.hpp): cell c = lanes i + l holds band c, or band n - 1 - c (info[5], round 6) when the band count is not a multiple
+    of the lanes; a uniform S steps per band in the table, the slots' own step pairs behind the first bins.  The contraction emulated on
+    the table equals row @ bank; at 1024 the 40-band bank (bands of 70 - 80 bins: S = 18 ... 20) is accepted since round 6."""
+    h = tac._native.lib()
+    n_freqs = n_fft // 2 + 1
+    fb = np.ascontiguousarray(tac.create_mel_filter(n_freqs, n_mels, 0.0, sr / 2.0, False).numpy().astype(np.float32))
+    wpack, desc, info = np.zeros(24576, dtype=np.float32), np.zeros(8192, dtype=np.int32), (ctypes.c_int32 * 8)()
+    h.tac_melbank_pack_host.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+                                        ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+    rc = h.tac_melbank_pack_host(fb.ctypes.data, n_freqs, n_mels, n_fft, wpack.ctypes.data, wpack.size, desc.ctypes.data, desc.size,
+                                 ctypes.cast(info, ctypes.c_void_p))
+    assert rc == tac._native.TAC_OK, rc
+    wtot, nslot, mark, _, S, rev = [int(v) for v in info][:6]
+    lanes = mark - 1000
+    assert lanes == (8 if n_fft == 400 else n_fft // 32) and nslot == (n_mels + lanes - 1) // lanes
+    assert bool(rev) == (n_mels % lanes != 0)
+    if n_fft == 1024 and n_mels == 40:
+        assert S > 12                                                     # (the wide-band step counts of round 6)
+    rng = np.random.default_rng(6)
+    rows = rng.random((3, n_freqs)).astype(np.float64)
+    want = rows @ fb.astype(np.float64)
+    got = np.zeros_like(want)
+    for r, row in enumerate(rows):
+        for i in range(nslot):
+            for l in range(lanes):
+                c = lanes * i + l
+                if c >= n_mels:
+                    continue
+                first = int(desc[lanes * i + l])
+                assert first % 4 == 0 and first >= 0
+                acc = 0.0
+                for j in range(S):
+                    at = ((i * S + j) * lanes + l) * 4
+                    bins = np.arange(first + 4 * j, first + 4 * j + 4)
+                    vals = np.where(bins < n_freqs, row[np.minimum(bins, n_freqs - 1)], 0.0)
+                    acc += float(wpack[at:at + 4].astype(np.float64) @ vals)
+                got[r, n_mels - 1 - c if rev else c] = acc
+    assert np.abs(got - want).max() < 1e-5 * np.abs(want).max()
+
+
 def test_float64_size_coverage_matches_the_kernel_plan(tac):
     """``_hip64.covers``: even lengths <= 8192 with a 5-smooth half take the LDS Stockham transform of csrc/chain_f64.hip; other
     lengths go to its O(N^2) direct transform only up to ``DIRECT_MAX`` (longer ones stay on the announced stock-torch route,

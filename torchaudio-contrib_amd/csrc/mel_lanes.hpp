@@ -187,7 +187,7 @@ __device__ __forceinline__ void lane_mel_store(const float* mstage, int am, int 
 // TAC_E_UNSUPPORTED when the bank does not fit (fewer than 8 / more than 128 bands, bands wider than 4 LM_MAX_STEPS).
 inline int pack_lane_mel(const std::vector<float>& h, int n_freqs, int n_mels, int lanes, int pitch, int step_quantum, int fly,
                          int max_steps, size_t base_lds, float* wpack, int wpack_cap, int32_t* desc, int desc_cap, int32_t* info_host,
-                         hipStream_t stream) {
+                         hipStream_t stream, bool to_host = false) {
     if (n_mels < LM_MIN_MELS || n_mels > LM_MAX_MELS) return TAC_E_UNSUPPORTED;
     const int nslot = (n_mels + lanes - 1) / lanes;
     std::vector<int> blo(n_mels, 0), bhi(n_mels, 0);                       // per band
@@ -240,9 +240,14 @@ inline int pack_lane_mel(const std::vector<float>& h, int n_freqs, int n_mels, i
                 pr = std::max<int32_t>(pr, std::min((need + 1) / 2, (S + 1) / 2));
             }
         }
-    TAC_HIP(hipMemcpyAsync(wpack, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice, stream));
-    TAC_HIP(hipMemcpyAsync(desc, dd.data(), dd.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-    TAC_HIP(hipStreamSynchronize(stream));
+    if (to_host) {                                                         // (tac_melbank_pack_host: host buffers, no device)
+        std::copy(wp.begin(), wp.end(), wpack);
+        std::copy(dd.begin(), dd.end(), desc);
+    } else {
+        TAC_HIP(hipMemcpyAsync(wpack, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+        TAC_HIP(hipMemcpyAsync(desc, dd.data(), dd.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        TAC_HIP(hipStreamSynchronize(stream));
+    }
     info_host[0] = (int32_t)wtot;
     info_host[1] = nslot;
     info_host[2] = LM_MARK + lanes;

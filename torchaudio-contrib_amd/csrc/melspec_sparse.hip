@@ -37,13 +37,13 @@ int launch_n400_mel(const FrameGeom& g, float power, const float* wpack, const i
                     int n_mels, int db, float amin, float log10_ref, float* out, hipStream_t stream, int fmt = FMT_F32,
                     const void* samples = nullptr, const float* lut = nullptr);
 int pack_n400(const std::vector<float>& h, int n_freqs, int n_mels, float* wpack, int wpack_cap, int32_t* desc,
-              int desc_cap, int32_t* info_host, hipStream_t stream);
+              int desc_cap, int32_t* info_host, hipStream_t stream, bool to_host = false);
 // stft_small.hip: the same form for fft_length 512 / 1024 (the three-phase kernel below stays the fallback)
 int launch_small_mel_entry(int n_fft, const FrameGeom& g, const Tables& tb, float power, const float* wpack, const int* desc,
                            const int32_t* info_host, int n_mels, int db, float amin, float log10_ref, float* out,
                            hipStream_t stream, int fmt = FMT_F32, const void* samples = nullptr, const float* lut = nullptr);
 int pack_small(int n_fft, const std::vector<float>& h, int n_freqs, int n_mels, float* wpack, int wpack_cap, int32_t* desc,
-               int desc_cap, int32_t* info_host, hipStream_t stream);
+               int desc_cap, int32_t* info_host, hipStream_t stream, bool to_host = false);
 // stft_n4096.hip: fft_length 4096 (the twelve-wave form of its real-valued rows + the contraction, stft_n4096_s3.hpp)
 int launch_n4096_mel(const FrameGeom& g, float power, const float* wpack, const int32_t* desc, const int32_t* info_host, int n_mels,
                      int db, float amin, float log10_ref, float* out, hipStream_t stream);
@@ -668,8 +668,11 @@ int tac_melbank_pack_host(const float* fb_host, int32_t n_freqs, int32_t n_mels,
                           int32_t* desc_host, int32_t desc_cap, int32_t* info_host) {
     using namespace tac;
     if (!fb_host || !wpack_host || !desc_host || !info_host || n_freqs <= 0 || n_mels <= 0) return TAC_E_INVALID;
-    if ((n_fft != 2048 && n_fft != 4096) || n_freqs != n_fft / 2 + 1) return TAC_E_UNSUPPORTED;
+    const bool lanes = n_fft == 256 || n_fft == 400 || n_fft == 512 || n_fft == 1024;
+    if ((n_fft != 2048 && n_fft != 4096 && !lanes) || n_freqs != n_fft / 2 + 1) return TAC_E_UNSUPPORTED;
     const std::vector<float> h(fb_host, fb_host + (size_t)n_freqs * n_mels);
+    if (n_fft == 400) return pack_n400(h, n_freqs, n_mels, wpack_host, wpack_cap, desc_host, desc_cap, info_host, nullptr, true);
+    if (lanes) return pack_small(n_fft, h, n_freqs, n_mels, wpack_host, wpack_cap, desc_host, desc_cap, info_host, nullptr, true);
     return n_fft == 2048 ? pack_lanes(h, n_freqs, n_mels, wpack_host, wpack_cap, desc_host, desc_cap, info_host, nullptr, true)
                          : pack_n4096_mel(h, n_freqs, n_mels, wpack_host, wpack_cap, desc_host, desc_cap, info_host, nullptr, true);
 }

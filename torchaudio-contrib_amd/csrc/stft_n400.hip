@@ -494,10 +494,10 @@ int launch_n400_mel(const FrameGeom& g, float power, const float* wpack, const i
 
 // Band-slot layout of the fused form (mel_lanes.hpp).  h: the (n_freqs x n_mels) bank on the host.
 int pack_n400(const std::vector<float>& h, int n_freqs, int n_mels, float* wpack, int wpack_cap, int32_t* desc,
-              int desc_cap, int32_t* info_host, hipStream_t stream) {
+              int desc_cap, int32_t* info_host, hipStream_t stream, bool to_host) {
     if (n_freqs != Q4_BINS) return TAC_E_UNSUPPORTED;
     return pack_lane_mel(h, n_freqs, n_mels, 8, Q4_MEL_PITCH, 1, Q4_FLY, LM_MAX_STEPS, q4_lds_bytes(0), wpack, wpack_cap, desc, desc_cap, info_host,
-                         stream);
+                         stream, to_host);
 }
 
 // ---------------------------------------------------------------- gradient: the inverse real transform per frame

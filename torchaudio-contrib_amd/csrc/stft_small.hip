@@ -383,13 +383,13 @@ int launch_small_mel_entry(int n_fft, const FrameGeom& g, const Tables& tb, floa
 }
 
 int pack_small(int n_fft, const std::vector<float>& h, int n_freqs, int n_mels, float* wpack, int wpack_cap, int32_t* desc,
-               int desc_cap, int32_t* info_host, hipStream_t stream) {
+               int desc_cap, int32_t* info_host, hipStream_t stream, bool to_host) {
     if ((n_fft != 256 && n_fft != 512 && n_fft != 1024) || n_freqs != n_fft / 2 + 1) return TAC_E_UNSUPPORTED;
     if (n_fft == 256 && !small3_waves()) return TAC_E_UNSUPPORTED;        // (TAC_SMALL2=1: the three-phase kernel's layout)
     const int lanes = n_fft / 32;
     const size_t base = n_fft == 256 ? small3_lds_bytes<128>(12) : (n_fft == 512 ? small_lds_bytes<256>() : small_lds_bytes<512>());
     return pack_lane_mel(h, n_freqs, n_mels, lanes, sm_mel_pitch(n_fft / 2), 2, SM_FLY, n_fft == 1024 ? SM_MAX_STEPS_1024 : LM_MAX_STEPS, base, wpack, wpack_cap, desc, desc_cap,
-                         info_host, stream);
+                         info_host, stream, to_host);
 }
 
 template <int NC>
