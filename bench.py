@@ -181,7 +181,7 @@ def bound_from_counters(roof, route, clock_mhz, live=None, live_note=None):
                           '(algorithmic bytes / kernel time / 8 TB/s)')
 
 
-def live_counters(route, timeout=240):
+def live_counters(route, timeout=75):
     """The counter entry of the launched kernel measured in THIS run: three child processes `rocprofv3 --pmc ...` (separate passes, as
     MI355X_MICROARCH.md prescribes: FETCH_SIZE; WRITE_SIZE; the SQ busy counters) around `tools/prof_driver.py mel 3` — the same kernel
     on one cfg-2 batch — per-launch means of the kernel's rows, HBM bytes with the guide's gfx950 corrections (FETCH_SIZE in KB, x2 for
